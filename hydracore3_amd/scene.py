@@ -1,0 +1,671 @@
+"""Host-side scene tables for the HIP path tracer (and, in tests, for the CPU oracle).
+
+This module produces exactly the flat buffers HydraCore3's ``Integrator::LoadScene`` fills
+(``integrator_pt.h:472-500``): ``m_materials`` (320-byte records, ``include/cmaterial.h:187-203``),
+``m_lights`` (320-byte records, ``include/clight.h:19-56``), ``m_vData8f``, ``m_triIndices``,
+``m_matIdByPrimId``, ``m_matVertOffset``, ``m_normMatrices``, ``m_remapInst`` and the camera matrices.
+
+Two producers:
+  * :func:`load_hydra_xml` -- a small reader of the Hydra scene XML + VSGF + image4ub files for the scenes the
+    reference ships (``scenes/test_035``, ``scenes/test_228``), following ``integrator_pt_scene.cpp:421-943``,
+    ``integrator_pt_scene_mat.cpp:280-450``, ``integrator_pt_scene_lgt.cpp:5-222``, ``integrator_pt_scene_tex.cpp:53-93``
+    and ``external/LiteScene/cmesh4.cpp:140-167``.  It is a fixture loader, not a replacement for the reference's
+    scene loader (which stays in front of the HIP core in a real integration).
+  * :class:`SceneBuilder` -- programmatic construction for the synthetic benchmark scenes (bench/scenes.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import struct
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+# ---------------------------------------------------------------------------------------------------------------------
+# record layouts
+# ---------------------------------------------------------------------------------------------------------------------
+MATERIAL_DTYPE = np.dtype([
+    ("mtype", "<u4"), ("cflags", "<u4"), ("lightId", "<u4"), ("nonlinear", "<u4"),
+    ("texid", "<u4", 4), ("spdid", "<u4", 4), ("datai", "<u4", 4),
+    ("colors", "<f4", (4, 4)), ("row0", "<f4", (4, 4)), ("row1", "<f4", (4, 4)),
+    ("data", "<f4", 16),
+])
+assert MATERIAL_DTYPE.itemsize == 320
+
+LIGHT_DTYPE = np.dtype([
+    ("matrix", "<f4", 16), ("iesMatrix", "<f4", 16),
+    ("samplerRow0", "<f4", 4), ("samplerRow1", "<f4", 4), ("samplerRow0Inv", "<f4", 4), ("samplerRow1Inv", "<f4", 4),
+    ("pos", "<f4", 4), ("intensity", "<f4", 4), ("norm", "<f4", 4),
+    ("size", "<f4", 2), ("pdfA", "<f4"), ("geomType", "<u4"),
+    ("distType", "<u4"), ("flags", "<u4"), ("pdfTableOffset", "<u4"), ("pdfTableSize", "<u4"),
+    ("specId", "<u4"), ("texId", "<u4"), ("iesId", "<u4"), ("mult", "<f4"),
+    ("pdfTableSizeX", "<u4"), ("pdfTableSizeY", "<u4"), ("camBackTexId", "<u4"), ("lightCos1", "<f4"),
+    ("lightCos2", "<f4"), ("matId", "<u4"), ("dummy2", "<f4"), ("dummy3", "<f4"),
+])
+assert LIGHT_DTYPE.itemsize == 320
+
+# include/cmaterial.h:26-46
+GLTF_COMPONENT_LAMBERT, GLTF_COMPONENT_COAT, GLTF_COMPONENT_METAL, GLTF_COMPONENT_ORENNAYAR = 1, 2, 4, 16
+MAT_TYPE_GLTF, MAT_TYPE_CONDUCTOR, MAT_TYPE_DIFFUSE, MAT_TYPE_DIELECTRIC = 1, 3, 4, 7
+MAT_TYPE_LIGHT_SOURCE = 0xEFFFFFFF
+# include/cmaterial.h:67-147 (slots in Material::colors / Material::data)
+GLTF_COLOR_BASE, GLTF_COLOR_COAT, GLTF_COLOR_METAL = 0, 1, 2
+GLTF_FLOAT_MI_FDR_INT, GLTF_FLOAT_MI_FDR_EXT, GLTF_FLOAT_MI_SSW, GLTF_FLOAT_ALPHA = 0, 1, 2, 3
+GLTF_FLOAT_GLOSINESS, GLTF_FLOAT_IOR, GLTF_FLOAT_ROUGH_ORENNAYAR, GLTF_FLOAT_REFL_COAT = 4, 5, 6, 7
+EMISSION_COLOR, EMISSION_MULT = 0, 0
+# include/clight.h:5-17
+LIGHT_GEOM_RECT, LIGHT_GEOM_DISC, LIGHT_GEOM_SPHERE, LIGHT_GEOM_DIRECT, LIGHT_GEOM_POINT, LIGHT_GEOM_ENV = 1, 2, 3, 4, 5, 6
+LIGHT_DIST_LAMBERT, LIGHT_DIST_OMNI, LIGHT_DIST_SPOT = 0, 1, 2
+# LiteImage::Sampler numbering
+ADDR_WRAP, ADDR_CLAMP = 0, 2
+FILTER_NEAREST, FILTER_LINEAR = 0, 1
+TEX_RGBA8, TEX_RGBA32F, TEX_R32F = 0, 1, 2
+# integrator_pt.h:330-332
+INTEGRATOR_STUPID_PT, INTEGRATOR_SHADOW_PT, INTEGRATOR_MIS_PT = 0, 1, 2
+UINT_MAX = 0xFFFFFFFF
+
+
+class TextureDesc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32), ("flags", C.c_uint32),
+                ("addressU", C.c_uint32), ("addressV", C.c_uint32), ("filter", C.c_uint32), ("reserved", C.c_uint32),
+                ("data", C.c_void_p)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("numGeoms", C.c_uint32), ("numInsts", C.c_uint32), ("numVerts", C.c_uint32), ("numTris", C.c_uint32),
+                ("vPos4f", C.c_void_p), ("vData8f", C.c_void_p), ("triIndices", C.c_void_p), ("matIdByPrimId", C.c_void_p),
+                ("matVertOffset", C.c_void_p), ("geomTriCount", C.c_void_p), ("geomVertCount", C.c_void_p),
+                ("instGeomId", C.c_void_p), ("instMatrices", C.c_void_p), ("normMatrices", C.c_void_p),
+                ("remapInst", C.c_void_p), ("allRemapLists", C.c_void_p),
+                ("allRemapListsLen", C.c_uint32), ("allRemapListsSize", C.c_uint32),
+                ("materials", C.c_void_p), ("numMaterials", C.c_uint32), ("numLights", C.c_uint32),
+                ("lights", C.c_void_p), ("textures", C.POINTER(TextureDesc)),
+                ("numTextures", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("projInv", C.c_float * 16), ("worldViewInv", C.c_float * 16),
+                ("winStartX", C.c_int32), ("winStartY", C.c_int32), ("winWidth", C.c_int32), ("winHeight", C.c_int32),
+                ("fbWidth", C.c_int32), ("fbHeight", C.c_int32),
+                ("traceDepth", C.c_uint32), ("integratorType", C.c_uint32), ("renderLayer", C.c_uint32),
+                ("tileSize", C.c_uint32), ("spectralMode", C.c_uint32), ("reserved0", C.c_uint32),
+                ("exposureMult", C.c_float), ("camLensRadius", C.c_float), ("camTargetDist", C.c_float), ("reserved1", C.c_float),
+                ("camRespoceRGB", C.c_float * 4), ("envColor", C.c_float * 4)]
+
+
+class Hit(C.Structure):     # CRT_Hit, external/CrossRT/CrossRT.h:23-30
+    _fields_ = [("t", C.c_float), ("primId", C.c_uint32), ("instId", C.c_uint32), ("geomId", C.c_uint32),
+                ("coords", C.c_float * 4)]
+
+
+HIT_DTYPE = np.dtype([("t", "<f4"), ("primId", "<u4"), ("instId", "<u4"), ("geomId", "<u4"), ("coords", "<f4", 4)])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# LiteMath-convention matrices (column-major storage: flat[col*4+row])
+# ---------------------------------------------------------------------------------------------------------------------
+def colmajor(m_rowmajor_4x4: np.ndarray) -> np.ndarray:
+    """4x4 array indexed [row, col] -> 16 floats in LiteMath's column-major order."""
+    return np.asarray(m_rowmajor_4x4, dtype=np.float64).T.reshape(16).astype(np.float32)
+
+
+def perspective_matrix(fovy_deg: float, aspect: float, z_near: float, z_far: float) -> np.ndarray:
+    ymax = z_near * math.tan(fovy_deg * math.pi / 360.0)
+    xmax = ymax * aspect
+    left, right, bottom, top = -xmax, xmax, -ymax, ymax
+    t, t2, t3, t4 = 2.0 * z_near, right - left, top - bottom, z_far - z_near
+    m = np.zeros((4, 4))
+    m[0, 0] = t / t2
+    m[1, 1] = t / t3
+    m[0, 2] = (right + left) / t2
+    m[1, 2] = (top + bottom) / t3
+    m[2, 2] = (-z_far - z_near) / t4
+    m[3, 2] = -1.0
+    m[2, 3] = (-t * z_far) / t4
+    return m
+
+
+def look_at(eye, center, up) -> np.ndarray:
+    eye, center, up = (np.asarray(v, dtype=np.float64) for v in (eye, center, up))
+    f = center - eye
+    f /= np.linalg.norm(f)
+    s = np.cross(f, up / np.linalg.norm(up))
+    s /= np.linalg.norm(s)
+    u = np.cross(s, f)
+    m = np.eye(4)
+    m[0, :3], m[1, :3], m[2, :3] = s, u, -f
+    m[0, 3], m[1, 3], m[2, 3] = -s.dot(eye), -u.dot(eye), f.dot(eye)
+    return m
+
+
+def translate(x, y, z):
+    m = np.eye(4)
+    m[:3, 3] = (x, y, z)
+    return m
+
+
+def scale(x, y, z):
+    return np.diag([x, y, z, 1.0])
+
+
+def rotate_y(deg):
+    a = math.radians(deg)
+    m = np.eye(4)
+    m[0, 0], m[0, 2], m[2, 0], m[2, 2] = math.cos(a), math.sin(a), -math.sin(a), math.cos(a)
+    return m
+
+
+def rotate_x(deg):
+    a = math.radians(deg)
+    m = np.eye(4)
+    m[1, 1], m[1, 2], m[2, 1], m[2, 2] = math.cos(a), -math.sin(a), math.sin(a), math.cos(a)
+    return m
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# material / light constructors
+# ---------------------------------------------------------------------------------------------------------------------
+def _blank_material() -> np.ndarray:
+    m = np.zeros((), dtype=MATERIAL_DTYPE)
+    m["lightId"] = UINT_MAX
+    m["texid"] = (0, UINT_MAX, 0, 0)      # texid[1] = 0xFFFFFFFF: no normal map (integrator_pt_scene.cpp:604)
+    m["spdid"] = UINT_MAX
+    for i in range(4):
+        m["row0"][i] = (1, 0, 0, 0)
+        m["row1"][i] = (0, 1, 0, 0)
+    return m
+
+
+def fresnel_diffuse_reflectance(eta: float) -> float:
+    """mi::fresnel_diffuse_reflectance (mi_materials.cpp:105-130), float arithmetic."""
+    f = np.float32
+    eta = f(eta)
+    inv_eta = f(1.0) / eta
+    approx_1 = f(0.0636) * inv_eta + (eta * (eta * f(-1.4399) + f(0.7099)) + f(0.6681))
+    acc = f(0.0)
+    for c in reversed([0.919317, -3.4793, 6.75335, -7.80989, 4.98554, -1.36881]):
+        acc = acc * inv_eta + f(c)
+    return float(approx_1 if eta < 1.0 else acc)
+
+
+def set_mi_plastic(m, int_ior, ext_ior, diffuse, specular):
+    """SetMiPlastic (mi_materials.cpp:455-469)."""
+    m["colors"][GLTF_COLOR_BASE] = diffuse
+    m["colors"][GLTF_COLOR_COAT] = specular
+    eta = np.float32(int_ior) / np.float32(ext_ior)
+    m["data"][GLTF_FLOAT_IOR] = eta
+    m["data"][GLTF_FLOAT_MI_FDR_INT] = fresnel_diffuse_reflectance(1.0 / float(eta))
+    m["data"][GLTF_FLOAT_MI_FDR_EXT] = fresnel_diffuse_reflectance(float(eta))
+    d_mean = 0.3333333 * (diffuse[0] + diffuse[1] + diffuse[2])
+    s_mean = 0.3333333 * (specular[0] + specular[1] + specular[2])
+    m["data"][GLTF_FLOAT_MI_SSW] = s_mean / (d_mean + s_mean)
+
+
+def material_lambert(color, tex_id=0) -> np.ndarray:
+    """Diffuse-only branch of ConvertOldHydraMaterial (integrator_pt_scene_mat.cpp:410-419, 446-447)."""
+    m = _blank_material()
+    m["mtype"] = MAT_TYPE_GLTF
+    m["cflags"] = GLTF_COMPONENT_LAMBERT
+    m["colors"][GLTF_COLOR_BASE] = (*color[:3], 0.0)
+    m["data"][GLTF_FLOAT_GLOSINESS] = 1.0
+    m["data"][GLTF_FLOAT_IOR] = 0.0
+    m["texid"][0] = tex_id
+    return m
+
+
+def material_gltf(base_color, metalness=0.0, glossiness=1.0, coat=1.0, ior=1.5, tex_id=0) -> np.ndarray:
+    """ConvertGLTFMaterial (integrator_pt_scene_mat.cpp:176-278)."""
+    m = _blank_material()
+    m["mtype"] = MAT_TYPE_GLTF
+    m["cflags"] = GLTF_COMPONENT_LAMBERT | GLTF_COMPONENT_COAT
+    m["data"][GLTF_FLOAT_REFL_COAT] = coat
+    bc = (*base_color[:3], base_color[3] if len(base_color) > 3 else 0.0)
+    m["colors"][GLTF_COLOR_METAL] = 1.0
+    m["data"][GLTF_FLOAT_ALPHA] = metalness
+    m["data"][GLTF_FLOAT_GLOSINESS] = glossiness
+    set_mi_plastic(m, ior, 1.0, bc, (1.0, 1.0, 1.0, 1.0))
+    m["colors"][GLTF_COLOR_COAT] = 1.0
+    m["texid"][0] = tex_id
+    return m
+
+
+def material_diffuse(color, roughness=0.0, tex_id=0) -> np.ndarray:
+    """type="diffuse" material (integrator_pt_scene_mat.cpp:516-572): Lambert or Oren-Nayar."""
+    m = _blank_material()
+    m["mtype"] = MAT_TYPE_DIFFUSE
+    m["cflags"] = GLTF_COMPONENT_LAMBERT
+    m["colors"][0] = (*color[:3], 0.0)
+    if roughness > 0.0:
+        m["cflags"] = GLTF_COMPONENT_ORENNAYAR
+        m["data"][0] = roughness
+    m["texid"][0] = tex_id
+    return m
+
+
+def material_conductor(eta, k, alpha_u=0.0, alpha_v=0.0, reflectance=(1, 1, 1, 1)) -> np.ndarray:
+    """type="rough_conductor" material (integrator_pt_scene_mat.cpp:452-514), RGB mode: scalar eta / k."""
+    m = _blank_material()
+    m["mtype"] = MAT_TYPE_CONDUCTOR
+    m["colors"][0] = reflectance
+    m["data"][0], m["data"][1], m["data"][2], m["data"][3] = alpha_u, alpha_v, eta, k
+    return m
+
+
+def material_dielectric(int_ior=1.5, ext_ior=1.00028) -> np.ndarray:
+    """type="dielectric" material (integrator_pt_scene_mat.cpp:574-617)."""
+    m = _blank_material()
+    m["mtype"] = MAT_TYPE_DIELECTRIC
+    m["colors"][0] = 1.0
+    m["colors"][1] = 1.0
+    m["data"][0], m["data"][1] = ext_ior, int_ior
+    return m
+
+
+def material_emissive(color, mult=1.0, light_id=UINT_MAX, tex_id=0) -> np.ndarray:
+    m = _blank_material()
+    m["mtype"] = MAT_TYPE_LIGHT_SOURCE
+    m["colors"][EMISSION_COLOR] = (*color[:3], 0.0)
+    m["data"][EMISSION_MULT] = mult
+    m["lightId"] = light_id
+    m["texid"][0] = tex_id
+    return m
+
+
+def _blank_light() -> np.ndarray:
+    lt = np.zeros((), dtype=LIGHT_DTYPE)
+    lt["distType"] = LIGHT_DIST_LAMBERT
+    lt["iesId"] = lt["texId"] = lt["specId"] = lt["camBackTexId"] = lt["matId"] = UINT_MAX
+    lt["samplerRow0"] = (1, 0, 0, 0)
+    lt["samplerRow1"] = (0, 1, 0, 0)
+    lt["mult"] = 1.0
+    return lt
+
+
+def light_rect(matrix, half_length, half_width, color, mult, disk_radius=None) -> np.ndarray:
+    """rect / disk branch of LoadLightSourceFromNode (integrator_pt_scene_lgt.cpp:69-91)."""
+    m = np.asarray(matrix, dtype=np.float64)
+    lt = _blank_light()
+    lt["pos"] = (m @ np.array([0, 0, 0, 1.0])).astype(np.float32)
+    n = m @ np.array([0, -1.0, 0, 0])
+    lt["norm"] = (n / np.linalg.norm(n)).astype(np.float32)
+    lt["intensity"] = (*color[:3], 0.0)
+    lt["mult"] = mult
+    sc = [np.linalg.norm(m[:3, i]) for i in range(3)]
+    rot = m.copy()
+    rot[:, 3] = (0, 0, 0, 1)
+    lt["matrix"] = colmajor(rot)
+    lt["size"] = (half_length, half_width)
+    if disk_radius is not None:
+        lt["geomType"] = LIGHT_GEOM_DISC
+        lt["size"][0] = disk_radius
+        lt["pdfA"] = 1.0 / (math.pi * disk_radius * disk_radius * sc[0] * sc[2])
+    else:
+        lt["geomType"] = LIGHT_GEOM_RECT
+        lt["pdfA"] = 1.0 / (4.0 * half_length * half_width * sc[0] * sc[2])
+    return lt
+
+
+def light_sphere(matrix, radius, color, mult) -> np.ndarray:
+    m = np.asarray(matrix, dtype=np.float64)
+    lt = _blank_light()
+    r = radius * np.linalg.norm(m[:3, 0])
+    lt["pos"] = (m @ np.array([0, 0, 0, 1.0])).astype(np.float32)
+    lt["norm"] = (0, -1, 0, 0)
+    lt["intensity"] = (*color[:3], 0.0)
+    lt["mult"] = mult
+    lt["geomType"] = LIGHT_GEOM_SPHERE
+    lt["size"] = (r, r)
+    lt["pdfA"] = 1.0 / (4.0 * math.pi * r * r)
+    return lt
+
+
+def light_point(matrix, color, mult, dist="omni", cos1=0.0, cos2=0.0) -> np.ndarray:
+    m = np.asarray(matrix, dtype=np.float64)
+    lt = _blank_light()
+    lt["pos"] = (m @ np.array([0, 0, 0, 1.0])).astype(np.float32)
+    n = m @ np.array([0, -1.0, 0, 0])
+    lt["norm"] = (n / np.linalg.norm(n)).astype(np.float32)
+    lt["intensity"] = (*color[:3], 0.0)
+    lt["mult"] = mult
+    lt["geomType"] = LIGHT_GEOM_POINT
+    lt["distType"] = {"omni": LIGHT_DIST_OMNI, "uniform": LIGHT_DIST_OMNI, "ies": LIGHT_DIST_OMNI,
+                      "spot": LIGHT_DIST_SPOT}.get(dist, LIGHT_DIST_LAMBERT)
+    lt["pdfA"] = 1.0
+    lt["lightCos1"], lt["lightCos2"] = cos1, cos2
+    return lt
+
+
+def light_directional(matrix, color, mult) -> np.ndarray:
+    m = np.asarray(matrix, dtype=np.float64)
+    lt = _blank_light()
+    lt["pos"] = (m @ np.array([0, 0, 0, 1.0])).astype(np.float32)
+    n = m @ np.array([0, -1.0, 0, 0])
+    lt["norm"] = (n / np.linalg.norm(n)).astype(np.float32)
+    lt["intensity"] = (*color[:3], 0.0)
+    lt["mult"] = mult
+    lt["geomType"] = LIGHT_GEOM_DIRECT
+    return lt
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class Texture:
+    def __init__(self, data: np.ndarray, fmt: int, srgb: bool, addr_u=ADDR_WRAP, addr_v=ADDR_WRAP, filt=FILTER_LINEAR):
+        self.fmt, self.srgb, self.addr_u, self.addr_v, self.filter = fmt, srgb, addr_u, addr_v, filt
+        if fmt == TEX_RGBA8:
+            self.data = np.ascontiguousarray(data, dtype=np.uint32)
+            self.height, self.width = self.data.shape
+        elif fmt == TEX_RGBA32F:
+            self.data = np.ascontiguousarray(data, dtype=np.float32)
+            self.height, self.width = self.data.shape[:2]
+        else:
+            self.data = np.ascontiguousarray(data, dtype=np.float32)
+            self.height, self.width = self.data.shape
+
+
+def white_dummy_texture() -> Texture:
+    """m_textures[0]: 1x1 white, NEAREST / CLAMP (integrator_pt_scene_tex.cpp:7-16)."""
+    return Texture(np.full((1, 1), 0xFFFFFFFF, dtype=np.uint32), TEX_RGBA8, False, ADDR_CLAMP, ADDR_CLAMP, FILTER_NEAREST)
+
+
+class SceneData:
+    """Flat scene buffers + camera/settings, convertible to the C ABI structures."""
+
+    def __init__(self):
+        self.vpos = np.zeros((0, 4), np.float32)
+        self.vdata = np.zeros((0, 8), np.float32)
+        self.tri_indices = np.zeros((0,), np.uint32)
+        self.mat_id_by_prim = np.zeros((0,), np.uint32)
+        self.mat_vert_offset = []       # (triOffset, vertOffset) per geom
+        self.geom_tri_count, self.geom_vert_count = [], []
+        self.inst_geom, self.inst_matrices, self.remap_inst = [], [], []
+        self.all_remap_lists = np.zeros((1,), np.int32)     # no lists: just the trailing offset 0
+        self.all_remap_lists_size = 0
+        self.materials, self.lights = [], []
+        self.textures = [white_dummy_texture()]
+        # camera / settings
+        self.width, self.height = 512, 512
+        self.fov, self.near, self.far = 45.0, 0.01, 100.0
+        self.cam_pos, self.cam_look_at, self.cam_up = (0, 0, 15), (0, 0, 0), (0, 1, 0)
+        self.trace_depth, self.spp = 6, 1
+        self.env_color = (0.0, 0.0, 0.0, 0.0)
+        self.exposure_mult = 1.0
+        self.cam_lens_radius = 0.0
+        self._keep = []
+
+    # -- geometry ----------------------------------------------------------------------------------------------------
+    def add_mesh(self, pos4, norm4, tang4, uv2, indices, mat_ids) -> int:
+        """LoadSceneGeometry (integrator_pt_scene.cpp:727-837): returns geomId."""
+        pos4 = np.asarray(pos4, np.float32).reshape(-1, 4)
+        nv = pos4.shape[0]
+        vd = np.zeros((nv, 8), np.float32)
+        vd[:, 0:3] = np.asarray(norm4, np.float32).reshape(nv, -1)[:, :3]
+        vd[:, 4:7] = np.asarray(tang4, np.float32).reshape(nv, -1)[:, :3]
+        uv2 = np.asarray(uv2, np.float32).reshape(nv, 2)
+        vd[:, 3], vd[:, 7] = uv2[:, 0], uv2[:, 1]
+        indices = np.asarray(indices, np.uint32).reshape(-1)
+        nt = indices.size // 3
+        mat_ids = np.asarray(mat_ids, np.uint32).reshape(-1)
+        if mat_ids.size == 1:
+            mat_ids = np.full((nt,), mat_ids[0], np.uint32)
+        self.mat_vert_offset.append((self.mat_id_by_prim.size, self.vpos.shape[0]))
+        self.geom_tri_count.append(nt)
+        self.geom_vert_count.append(nv)
+        self.vpos = np.concatenate([self.vpos, pos4])
+        self.vdata = np.concatenate([self.vdata, vd])
+        self.tri_indices = np.concatenate([self.tri_indices, indices])
+        self.mat_id_by_prim = np.concatenate([self.mat_id_by_prim, mat_ids])
+        return len(self.geom_tri_count) - 1
+
+    def add_instance(self, geom_id, matrix_rowmajor, remap_list=-1, light_id=-1) -> int:
+        self.inst_geom.append(geom_id)
+        self.inst_matrices.append(np.asarray(matrix_rowmajor, np.float64).reshape(4, 4))
+        self.remap_inst.append((remap_list, light_id))
+        return len(self.inst_geom) - 1
+
+    def set_remap_lists(self, lists):
+        """LoadSceneRemapLists (integrator_pt_scene.cpp:909-924): lists of (from,to) pairs sorted by `from`."""
+        flat, offs = [], []
+        for lst in lists:
+            offs.append(len(flat))
+            flat.extend(int(v) for v in lst)
+        offs.append(len(flat))
+        self.all_remap_lists_size = len(flat)
+        self.all_remap_lists = np.asarray(flat + offs, np.int32)
+
+    def add_texture(self, tex: Texture) -> int:
+        self.textures.append(tex)
+        return len(self.textures) - 1
+
+    # -- C structures ------------------------------------------------------------------------------------------------
+    def tile_size(self) -> int:
+        """SetViewport (integrator_pt.h:379-389)."""
+        for ts in (8, 4, 2):
+            if self.width % ts == 0 and self.height % ts == 0:
+                return ts
+        return 1
+
+    def params(self, integrator=INTEGRATOR_MIS_PT, render_layer=0, trace_depth=None) -> Params:
+        p = Params()
+        aspect = float(self.width) / float(self.height)
+        proj = perspective_matrix(self.fov, aspect, self.near, self.far)
+        wv = look_at(self.cam_pos, self.cam_look_at, self.cam_up)
+        p.projInv[:] = colmajor(np.linalg.inv(proj)).tolist()
+        p.worldViewInv[:] = colmajor(np.linalg.inv(wv)).tolist()
+        p.winStartX = p.winStartY = 0
+        p.winWidth = p.fbWidth = self.width
+        p.winHeight = p.fbHeight = self.height
+        p.traceDepth = self.trace_depth if trace_depth is None else trace_depth
+        p.integratorType = integrator
+        p.renderLayer = render_layer
+        p.tileSize = self.tile_size()
+        p.spectralMode = 0
+        p.exposureMult = self.exposure_mult
+        p.camLensRadius = self.cam_lens_radius
+        p.camTargetDist = float(np.linalg.norm(np.asarray(self.cam_look_at, float) - np.asarray(self.cam_pos, float)))
+        p.camRespoceRGB[:] = [1.0, 1.0, 1.0, 1.0]
+        p.envColor[:] = list(self.env_color)
+        return p
+
+    def desc(self) -> SceneDesc:
+        d = SceneDesc()
+        k = self._keep = []
+
+        def ptr(a):
+            a = np.ascontiguousarray(a)
+            k.append(a)
+            return a.ctypes.data
+
+        ni = len(self.inst_geom)
+        d.numGeoms, d.numInsts = len(self.geom_tri_count), ni
+        d.numVerts, d.numTris = self.vpos.shape[0], self.mat_id_by_prim.size
+        d.vPos4f, d.vData8f = ptr(self.vpos), ptr(self.vdata)
+        d.triIndices, d.matIdByPrimId = ptr(self.tri_indices), ptr(self.mat_id_by_prim)
+        d.matVertOffset = ptr(np.asarray(self.mat_vert_offset, np.uint32).reshape(-1, 2))
+        d.geomTriCount = ptr(np.asarray(self.geom_tri_count, np.uint32))
+        d.geomVertCount = ptr(np.asarray(self.geom_vert_count, np.uint32))
+        d.instGeomId = ptr(np.asarray(self.inst_geom, np.uint32))
+        mats = np.stack([colmajor(m) for m in self.inst_matrices]) if ni else np.zeros((0, 16), np.float32)
+        # m_normMatrices[i] = transpose(inverse4x4(M_i))  (integrator_pt_scene.cpp:877)
+        nm = np.stack([colmajor(np.linalg.inv(m).T) for m in self.inst_matrices]) if ni else np.zeros((0, 16), np.float32)
+        d.instMatrices, d.normMatrices = ptr(mats), ptr(nm)
+        d.remapInst = ptr(np.asarray(self.remap_inst, np.int32).reshape(-1, 2))
+        d.allRemapLists = ptr(self.all_remap_lists)
+        d.allRemapListsLen, d.allRemapListsSize = self.all_remap_lists.size, self.all_remap_lists_size
+        marr = np.array(self.materials, dtype=MATERIAL_DTYPE) if self.materials else np.zeros((0,), MATERIAL_DTYPE)
+        larr = np.array(self.lights, dtype=LIGHT_DTYPE) if self.lights else np.zeros((0,), LIGHT_DTYPE)
+        d.materials, d.numMaterials = ptr(marr), marr.size
+        d.lights, d.numLights = ptr(larr) if larr.size else None, larr.size
+        tarr = (TextureDesc * len(self.textures))()
+        for i, t in enumerate(self.textures):
+            tarr[i].width, tarr[i].height, tarr[i].format = t.width, t.height, t.fmt
+            tarr[i].flags = 1 if t.srgb else 0
+            tarr[i].addressU, tarr[i].addressV, tarr[i].filter = t.addr_u, t.addr_v, t.filter
+            tarr[i].data = ptr(t.data)
+        k.append(tarr)
+        d.textures, d.numTextures = tarr, len(self.textures)
+        return d
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fixture loader for the scenes the reference ships
+# ---------------------------------------------------------------------------------------------------------------------
+def load_vsgf(path):
+    """cmesh4::LoadMeshFromVSGF (external/LiteScene/cmesh4.cpp:140-167, header cmesh4.h:18-32)."""
+    raw = open(path, "rb").read()
+    _size, nv, ni, _nm, flags = struct.unpack_from("<QIIII", raw, 0)
+    off = 24
+    pos = np.frombuffer(raw, "<f4", nv * 4, off).reshape(nv, 4); off += nv * 16
+    if not (flags & 8):
+        norm = np.frombuffer(raw, "<f4", nv * 4, off).reshape(nv, 4); off += nv * 16
+    else:
+        norm = np.zeros((nv, 4), np.float32)
+    if flags & 1:
+        tang = np.frombuffer(raw, "<f4", nv * 4, off).reshape(nv, 4); off += nv * 16
+    else:
+        tang = np.zeros((nv, 4), np.float32)
+    uv = np.frombuffer(raw, "<f4", nv * 2, off).reshape(nv, 2); off += nv * 8
+    idx = np.frombuffer(raw, "<u4", ni, off); off += ni * 4
+    mats = np.frombuffer(raw, "<u4", ni // 3, off)
+    return pos, norm, tang, uv, idx, mats
+
+
+def load_image4ub(path):
+    """integrator_pt_scene_tex.cpp:53-93: 8-byte {w,h} header, then RGBA8 texels."""
+    raw = open(path, "rb").read()
+    w, h = struct.unpack_from("<II", raw, 0)
+    return np.frombuffer(raw, "<u4", w * h, 8).reshape(h, w)
+
+
+def ies_spherical_texture(path):
+    """CreateSphericalTextureFromIES (ies_parser/ies_render.cpp:29-120), axially symmetric photometry only
+    (one horizontal angle), which is what scenes/test_228 uses; normalised to max 1
+    (integrator_pt_scene_lgt.cpp:171-186)."""
+    toks = open(path).read().split("TILT=NONE", 1)[1].split()
+    vals = [float(t) for t in toks]
+    n_vert, n_horz = int(vals[3]), int(vals[4])
+    vals = vals[13:]
+    vert = vals[:n_vert]
+    horz = vals[n_vert:n_vert + n_horz]
+    cand = vals[n_vert + n_horz:]
+    if n_horz != 1:
+        raise NotImplementedError("only axially symmetric IES files are handled by the fixture loader")
+    v0, v1 = vert[0], vert[-1]
+    h = n_vert * 2 if (abs(v0) < 1e-5 and abs(v1 - 90) < 1e-5) or (abs(v0 - 90) < 1e-5 and abs(v1 - 180) < 1e-5) else n_vert
+    img = np.zeros((h, 1), np.float32)
+    step = np.float32(v1 - v0) / np.float32(n_vert)
+    theta_grad = np.float32(v0)
+    for ti in range(n_vert):
+        theta = np.float32(math.pi / 180.0) * theta_grad
+        iy = min(int((theta * np.float32(1.0 / math.pi)) * np.float32(h) + np.float32(0.5)), h - 1)
+        img[iy, 0] = cand[ti]
+        theta_grad = np.float32(theta_grad + step)
+    mx = float(img.max()) or 1.0
+    return (img * np.float32(1.0 / mx)).astype(np.float32)
+
+
+def _f(s):
+    return [float(v) for v in s.split()]
+
+
+def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
+    folder = os.path.dirname(os.path.abspath(xml_path))
+    text = open(xml_path, encoding="utf-8").read()
+    text = text.replace('<?xml version="1.0"?>', "")
+    root = ET.fromstring("<root>" + text + "</root>")
+    sc = SceneData()
+
+    settings = root.find("render_lib/render_settings")
+    sc.width = int(settings.findtext("width")) if width is None else width
+    sc.height = int(settings.findtext("height")) if height is None else height
+    sc.trace_depth = int(settings.findtext("trace_depth") or 0) or 6          # LoadSceneSettings :926-940
+    sc.spp = int(settings.findtext("maxRaysPerPixel") or 0) or 1
+
+    cam = root.find("cam_lib/camera")
+    sc.fov = float(cam.findtext("fov"))
+    sc.near, sc.far = float(cam.findtext("nearClipPlane")), float(cam.findtext("farClipPlane"))
+    sc.cam_pos, sc.cam_look_at, sc.cam_up = _f(cam.findtext("position")), _f(cam.findtext("look_at")), _f(cam.findtext("up"))
+
+    # textures: XML id -> loaded lazily into m_textures on first use by a material (integrator_pt_scene_tex.cpp:105-144)
+    tex_nodes = {int(t.get("id")): t for t in root.findall("textures_lib/texture")}
+    tex_cache = {}
+
+    def texture_from_color_node(node):
+        tnode = node.find("texture") if node is not None else None
+        if tnode is None:
+            return 0
+        xid = int(tnode.get("id"))
+        if xid in tex_cache:
+            return tex_cache[xid]
+        data = load_image4ub(os.path.join(folder, tex_nodes[xid].get("loc")))
+        tex_cache[xid] = sc.add_texture(Texture(data, TEX_RGBA8, True, ADDR_WRAP, ADDR_WRAP, FILTER_LINEAR))
+        return tex_cache[xid]
+
+    # lights first: materials with light_id copy intensity from them (integrator_pt_scene.cpp:973-996, 575-599)
+    scene_node = root.find("scenes/scene")
+    light_nodes = {int(l.get("id")): l for l in root.findall("lights_lib/light")}
+    old_to_new = []
+    for linst in scene_node.findall("instance_light"):
+        lnode = light_nodes[int(linst.get("light_id"))]
+        m = np.asarray(_f(linst.get("matrix"))).reshape(4, 4)
+        ltype, shape, dist = lnode.get("type"), lnode.get("shape"), lnode.get("distribution")
+        inten = lnode.find("intensity")
+        color = _f(inten.find("color").get("val"))
+        mult_node = inten.find("multiplier")
+        power = float(mult_node.get("val")) if mult_node is not None else 1.0
+        if ltype == "sky":
+            sc.env_color = (*color[:3], 0.0)
+            old_to_new.append(-1)           # plain-colour environment: not sampled (:439-486)
+            continue
+        size = lnode.find("size")
+        if ltype == "directional":
+            lt = light_directional(m, color, power)
+        elif shape in ("rect", "disk"):
+            hw, hl = float(size.get("half_width", 0)), float(size.get("half_length", 0))
+            lt = light_rect(m, hl, hw, color, power, float(size.get("radius")) if shape == "disk" else None)
+        elif shape == "sphere":
+            lt = light_sphere(m, float(size.get("radius")), color, power)
+        else:
+            lt = light_point(m, color, power, dist)
+        ies = lnode.find("ies")
+        if ies is not None:
+            img = ies_spherical_texture(os.path.join(folder, ies.get("loc")))
+            lt["iesId"] = sc.add_texture(Texture(img, TEX_R32F, False, ADDR_CLAMP, ADDR_CLAMP, FILTER_LINEAR))
+            if ies.get("matrix") is not None:
+                mnode = np.asarray(_f(ies.get("matrix"))).reshape(4, 4)
+                inst = m.copy(); inst[:, 3] = (0, 0, 0, 1)
+                im = rotate_y(90.0) @ (mnode.T @ inst).T        # mrot*transpose(transpose(matrixFromNode)*instMatrix)
+                im[:, 3] = (0, 0, 0, 1)
+                lt["iesMatrix"] = colmajor(im)
+        old_to_new.append(len(sc.lights))
+        sc.lights.append(lt)
+
+    for mnode in root.findall("materials_lib/material"):
+        emis, diff = mnode.find("emission"), mnode.find("diffuse")
+        if mnode.get("light_id") is not None or emis is not None:
+            cnode = emis.find("color")
+            mat = material_emissive(_f(cnode.get("val")), 1.0, int(mnode.get("light_id", -1)) & UINT_MAX, texture_from_color_node(cnode))
+            lid = int(mnode.get("light_id", -1))
+            if 0 <= lid < len(sc.lights):
+                mat["colors"][EMISSION_COLOR] = sc.lights[lid]["intensity"]
+                mat["data"][EMISSION_MULT] = sc.lights[lid]["mult"]
+                sc.lights[lid]["matId"] = len(sc.materials)
+        else:
+            cnode = diff.find("color")
+            mat = material_lambert(_f(cnode.get("val")), texture_from_color_node(cnode))
+            if diff.find("roughness") is not None:
+                mat["data"][GLTF_FLOAT_ROUGH_ORENNAYAR] = float(diff.find("roughness").get("val"))
+                mat["cflags"] |= GLTF_COMPONENT_ORENNAYAR
+        sc.materials.append(mat)
+
+    for mesh in root.findall("geometry_lib/mesh"):
+        pos, norm, tang, uv, idx, mats = load_vsgf(os.path.join(folder, mesh.get("loc")))
+        sc.add_mesh(pos, norm, tang, uv, idx, mats)
+
+    for inst in scene_node.findall("instance"):
+        linst = inst.get("linst_id")
+        light_id = old_to_new[int(linst)] if linst is not None and int(linst) >= 0 else -1
+        sc.add_instance(int(inst.get("mesh_id")), np.asarray(_f(inst.get("matrix"))).reshape(4, 4),
+                        int(inst.get("rmap_id", -1)), light_id)
+    return sc

@@ -1,0 +1,907 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).  PARITY UNPINNED: the
+// reference has no golden vectors for this path and cannot be compiled in this image (LiteMath, Embree,
+// Enzyme absent); this file restates its algorithm and is pinned only by closed-form checks in tests/.
+//
+// CPU restatement of
+//   Integrator::PathTraceBlock / NaivePathTraceBlock      integrator_pt_host.cpp:39-73
+//   Integrator::PathTrace / NaivePathTrace + kernel_*     integrator_pt.cpp:13-157, 214-657, 681-759
+//   MaterialSampleAndEval / MaterialEval / RemapMaterialId integrator_pt_mat.cpp:109-306, 308-573
+//   LightSampleRev / LightEvalPDF / LightIntensity        integrator_pt_lgt.cpp:21-173
+//   kernel_PackXY                                         integrator_rt.cpp:13-31
+//   IntegratorDR::PathTraceDR / PathTraceReplay / PixelLossPT / Tex2DFetchAD / PutDiffTex2D
+//                                                         diff_render/integrator_dr.cpp:33-161, 461-612, 790-1218
+//   AdamOptimizer<float>::step                            diff_render/adam.h:43-62
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+#include "orc_shade.h"
+#include <omp.h>
+#include <cstdio>
+#include <cstdlib>
+
+namespace orc {
+
+struct Params
+{
+  m4 projInv, worldViewInv;
+  int winStartX, winStartY, winWidth, winHeight, fbWidth, fbHeight;
+  uint traceDepth, integratorType, renderLayer, tileSize, spectralMode;
+  float exposureMult, camLensRadius, camTargetDist;
+  f4 camRespoceRGB, envColor;
+};
+
+// IntegratorDR::TexInfo (diff_render/integrator_dr.h:56-64)
+struct TexInfo { size_t offset; int width, height, channels; };
+
+// what the Record* hooks capture (diff_render/integrator_dr2.cpp:22-80, integrator_dr.h:93-136)
+static const int MAX_REC_BOUNCE = 16;
+struct Record
+{
+  f4 lens;                       // pixel offsets / lens randoms
+  orc_hit hit[MAX_REC_BOUNCE];
+  int inShadow[MAX_REC_BOUNCE];  // NOTE inverted naming in the reference: 0 means "needShade"
+  f4 lgt[MAX_REC_BOUNCE], mat[MAX_REC_BOUNCE];
+  bool enabled;
+};
+
+// ---- forward-mode dual colour for the DR replay ------------------------------------------------------------------
+// value + d(value)/d(texColor fetched at bounce b), per channel (channels never mix in the gltf/lambert path).
+static const int MAXB = MAX_REC_BOUNCE;
+struct AF4
+{
+  f4 v; f4 d[MAXB];
+  AF4() { v = splat4(0); for (int i = 0; i < MAXB; i++) d[i] = splat4(0); }
+  AF4(f4 a) { v = a; for (int i = 0; i < MAXB; i++) d[i] = splat4(0); }
+};
+static inline AF4 operator*(const AF4& a, f4 s) { AF4 r; r.v = a.v * s; for (int i = 0; i < MAXB; i++) r.d[i] = a.d[i] * s; return r; }
+static inline AF4 operator*(const AF4& a, float s) { AF4 r; r.v = a.v * s; for (int i = 0; i < MAXB; i++) r.d[i] = a.d[i] * s; return r; }
+static inline AF4 operator+(const AF4& a, const AF4& b) { AF4 r; r.v = a.v + b.v; for (int i = 0; i < MAXB; i++) r.d[i] = a.d[i] + b.d[i]; return r; }
+static inline AF4 operator-(const AF4& a, const AF4& b) { AF4 r; r.v = a.v - b.v; for (int i = 0; i < MAXB; i++) r.d[i] = a.d[i] - b.d[i]; return r; }
+static inline AF4 operator/(const AF4& a, float s) { AF4 r; r.v = a.v / s; for (int i = 0; i < MAXB; i++) r.d[i] = a.d[i] / s; return r; }
+static inline AF4 mulAA(const AF4& a, const AF4& b) { AF4 r; r.v = a.v * b.v; for (int i = 0; i < MAXB; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+
+struct Ctx
+{
+  Scene  sc;
+  Params p;
+  std::vector<uint>      packedXY;
+  std::vector<RandomGen> randomGens;
+  std::vector<TexInfo>   texAddressTable;   // DR
+  size_t                 gradSize = 0;
+
+  // ------------------------------------------------------------------------------------------------------------
+  // integrator_rt.cpp:13-31
+  void PackXY()
+  {
+    const int W = p.winWidth, H = p.winHeight;
+    packedXY.assign((size_t)W * H, 0u);
+    const uint ts = p.tileSize;
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++) {
+        uint offset = (uint)y * (uint)W + (uint)x;
+        if (ts != 1) {
+          const uint inX = (uint)x % ts, inY = (uint)y % ts;
+          const uint localIndex = inY * ts + inX;
+          const uint wBlocks = (uint)W / ts;
+          const uint blockX = (uint)x / ts, blockY = (uint)y / ts;
+          offset = (blockX + blockY * wBlocks) * ts * ts + localIndex;
+        }
+        packedXY[offset] = (((uint)y << 16) & 0xFFFF0000u) | ((uint)x & 0x0000FFFFu);
+      }
+  }
+
+  // integrator_pt_mat.cpp:530-573
+  uint RemapMaterialId(uint a_mId, int a_instId) const
+  {
+    const int remapListId = sc.remapInst[2 * a_instId + 0];
+    if (remapListId == -1) return a_mId;
+    const int r_offset = sc.allRemapLists[sc.allRemapListsSize + remapListId];
+    const int r_size = sc.allRemapLists[sc.allRemapListsSize + remapListId + 1] - r_offset;
+    uint res = a_mId;
+    int low = 0, high = r_size - 1;
+    while (low <= high) {
+      const int mid = low + ((high - low) / 2);
+      const int idRemapFrom = sc.allRemapLists[r_offset + mid * 2 + 0];
+      if (uint(idRemapFrom) >= a_mId) high = mid - 1; else low = mid + 1;
+    }
+    if (high + 1 < r_size) {
+      const int idRemapFrom = sc.allRemapLists[r_offset + (high + 1) * 2 + 0];
+      const int idRemapTo = sc.allRemapLists[r_offset + (high + 1) * 2 + 1];
+      res = (uint(idRemapFrom) == a_mId) ? uint(idRemapTo) : a_mId;
+    }
+    return res;
+  }
+
+  // ---- lights (integrator_pt_lgt.cpp) ------------------------------------------------------------------------------
+  LightSample LightSampleRev(int a_lightId, f3 rands, f3 illiminationPoint) const   // :21-58
+  {
+    const LightSource& L = sc.lights[a_lightId];
+    const f2 rands2 = mk2(rands.x, rands.y);
+    switch (L.geomType) {
+      case LIGHT_GEOM_DIRECT: return directLightSampleRev(L, rands2, illiminationPoint);
+      case LIGHT_GEOM_SPHERE: return sphereLightSampleRev(L, rands2);
+      case LIGHT_GEOM_POINT:  return pointLightSampleRev(L);
+      default:                return areaLightSampleRev(L, rands2);   // env-map lights: out of scope
+    }
+  }
+  float LightPdfSelectRev(int) const { return 1.0f / float(sc.lights.size()); }   // :60-63
+
+  float LightEvalPDF(int a_lightId, f3 illuminationPoint, f3 ray_dir, f3 lpos, f3 lnorm, float a_envPdf) const   // :71-107
+  {
+    const LightSource& L = sc.lights[a_lightId];
+    const uint gtype = L.geomType;
+    if (gtype == LIGHT_GEOM_ENV) return a_envPdf;
+    const float hitDist = length(illuminationPoint - lpos);
+    const float cosValTmp = dot(ray_dir, -1.0f * lnorm);
+    float cosVal = 1.0f;
+    switch (gtype) {
+      case LIGHT_GEOM_SPHERE: { const f3 dirToV = normalize(lpos - illuminationPoint); cosVal = std::abs(dot(dirToV, lnorm)); } break;
+      case LIGHT_GEOM_POINT:  { if (L.distType == LIGHT_DIST_LAMBERT) cosVal = std::max(cosValTmp, 0.0f); } break;
+      default: cosVal = (L.iesId == uint(-1)) ? std::max(cosValTmp, 0.0f) : std::abs(cosValTmp); break;
+    }
+    return PdfAtoW(L.pdfA, hitDist, cosVal);
+  }
+
+  f4 LightIntensity(uint a_lightId, f3 a_rayPos, f3 a_rayDir) const   // :109-173 (RGB mode; env / projective textures out of scope)
+  {
+    const LightSource& L = sc.lights[a_lightId];
+    f4 lightColor = L.intensity;
+    lightColor = lightColor * L.mult;
+    const uint iesId = L.iesId;
+    if (iesId != uint(-1)) {
+      if ((L.flags & LIGHT_FLAG_POINT_AREA) != 0) a_rayDir = normalize(xyz(L.pos) - a_rayPos);
+      const f3 dirTrans = xyz(mul(L.iesMatrix, xyzw(a_rayDir, 0.0f)));
+      float sintheta = 0.0f;
+      const f2 texCoord = sphereMapTo2DTexCoord((-1.0f) * dirTrans, &sintheta);
+      const f4 texColor = sc.tex_sample(iesId, texCoord);
+      lightColor = lightColor * texColor;
+    }
+    if (L.distType == LIGHT_DIST_SPOT) {
+      const float cos1 = L.lightCos1, cos2 = L.lightCos2;
+      const f3 norm = xyz(L.norm);
+      const float cos_theta = std::max(-dot(a_rayDir, norm), 0.0f);
+      lightColor = lightColor * mylocalsmoothstep(cos2, cos1, cos_theta);
+    }
+    return lightColor;
+  }
+
+  // ---- materials (integrator_pt_mat.cpp) -----------------------------------------------------------------------------
+  f4 fourScalarMatParams(const Material& m, f2 tc) const   // :151-167 / :360-376
+  {
+    f4 four = mk4(1, 1, 1, 1);
+    if ((m.cflags & FLAG_FOUR_TEXTURES) != 0) {
+      const f2 tc2 = mulRows2x4(m.row0[2], m.row1[2], tc), tc3 = mulRows2x4(m.row0[3], m.row1[3], tc);
+      const f4 color2 = sc.tex_sample(m.texid[2], tc2), color3 = sc.tex_sample(m.texid[3], tc3);
+      if ((m.cflags & FLAG_PACK_FOUR_PARAMS_IN_TEXTURE) != 0) four = color2; else four = mk4(color2.x, color3.x, 1, 1);
+    }
+    return four;
+  }
+
+  BsdfSample MaterialSampleAndEval(uint a_materialId, RandomGen* a_gen, f3 v, f3 n, f3 tan, f2 tc, MisData* a_misPrev, uint a_currRayFlags, Record* rec, uint bounce) const   // :109-306
+  {
+    BsdfSample res;
+    res.val = mk4(0, 0, 0, 0); res.pdf = 1.0f; res.dir = mk3(0, 1, 0); res.ior = 1.0f; res.flags = a_currRayFlags;
+    const Material& m = sc.materials[a_materialId];
+    const uint mtype = m.mtype;                         // blend descent / bump mapping: out of scope
+    const f3 shadeNormal = n;
+    const f2 texCoordT = mulRows2x4(m.row0[0], m.row1[0], tc);
+    const f4 texColor = sc.tex_sample(m.texid[0], texCoordT);
+    const f4 rands = rndFloat4(a_gen);                  // GetRandomNumbersMats, drawn for every material type (:147)
+    if (rec && rec->enabled) rec->mat[bounce] = rands;
+    const f4 four = fourScalarMatParams(m, tc);
+
+    switch (mtype) {
+      case MAT_TYPE_GLTF: {
+        const f4 color = m.colors[GLTF_COLOR_BASE] * texColor;
+        BsdfSampleT<f4> r; r.val = res.val; r.dir = res.dir; r.pdf = res.pdf; r.flags = res.flags; r.ior = res.ior;
+        gltfSampleAndEval<f4>(m, rands, v, shadeNormal, tc, color, four, &r);
+        res.val = r.val; res.dir = r.dir; res.pdf = r.pdf; res.flags = r.flags; res.ior = r.ior;
+      } break;
+      case MAT_TYPE_CONDUCTOR: {
+        const f3 alphaTex = xyz(texColor);
+        const f2 alpha = mk2(m.data[CONDUCTOR_ROUGH_V], m.data[CONDUCTOR_ROUGH_U]);
+        const f4 etaSpec = splat4(m.data[CONDUCTOR_ETA]), kSpec = splat4(m.data[CONDUCTOR_K]);   // integrator_spectrum.cpp:25-29 RGB early-out
+        if (trEffectivelySmooth(alpha)) conductorSmoothSampleAndEval(m, etaSpec, kSpec, rands, v, shadeNormal, tc, &res);
+        else                            conductorRoughSampleAndEval(m, etaSpec, kSpec, rands, v, shadeNormal, tc, alphaTex, &res);
+      } break;
+      case MAT_TYPE_DIFFUSE: {
+        f4 reflSpec = m.colors[DIFFUSE_COLOR];                                                     // integrator_spectrum.cpp:128-133
+        reflSpec = reflSpec * texColor;
+        diffuseSampleAndEval(m, reflSpec, rands, v, shadeNormal, tc, &res);
+      } break;
+      case MAT_TYPE_DIELECTRIC: {
+        const f4 intIORSpec = splat4(m.data[DIELECTRIC_ETA_INT]);
+        const uint specId = m.spdid[0];
+        dielectricSmoothSampleAndEval(m, intIORSpec, a_misPrev->ior, rands, v, shadeNormal, tc, &res);
+        res.flags |= (specId < 0xFFFFFFFFu) ? RAY_FLAG_WAVES_DIVERGED : 0;
+        a_misPrev->ior = res.ior;
+      } break;
+      default: break;
+    }
+    return res;
+  }
+
+  BsdfEval MaterialEval(uint a_materialId, f3 l, f3 v, f3 n, f3 tan, f2 tc) const   // :308-528
+  {
+    BsdfEval res; res.val = mk4(0, 0, 0, 0); res.pdf = 0.0f;
+    const Material& m = sc.materials[a_materialId];
+    const f3 shadeNormal = n;
+    const float weight = 1.0f, bumpCosMult = 1.0f;
+    const f2 texCoordT = mulRows2x4(m.row0[0], m.row1[0], tc);
+    const f4 texColor = sc.tex_sample(m.texid[0], texCoordT);
+    const f4 four = fourScalarMatParams(m, tc);
+    BsdfEval currVal; currVal.val = mk4(0, 0, 0, 0); currVal.pdf = 0.0f;
+    switch (m.mtype) {
+      case MAT_TYPE_GLTF: {
+        const f4 color = m.colors[GLTF_COLOR_BASE] * texColor;
+        BsdfEvalT<f4> r; r.val = currVal.val; r.pdf = currVal.pdf;
+        gltfEval<f4>(m, l, v, shadeNormal, tc, color, four, &r);
+        res.val = res.val + r.val * weight * bumpCosMult;
+        res.pdf += r.pdf * weight;
+      } break;
+      case MAT_TYPE_CONDUCTOR: {
+        const f3 alphaTex = xyz(texColor);
+        const f2 alpha = mk2(m.data[CONDUCTOR_ROUGH_V], m.data[CONDUCTOR_ROUGH_U]);
+        if (!trEffectivelySmooth(alpha)) {
+          const f4 etaSpec = splat4(m.data[CONDUCTOR_ETA]), kSpec = splat4(m.data[CONDUCTOR_K]);
+          conductorRoughEval(m, etaSpec, kSpec, l, v, shadeNormal, tc, alphaTex, &currVal);
+        }
+        res.val = res.val + currVal.val * weight * bumpCosMult;
+        res.pdf += currVal.pdf * weight;
+      } break;
+      case MAT_TYPE_DIFFUSE: {
+        f4 reflSpec = m.colors[DIFFUSE_COLOR];
+        reflSpec = reflSpec * texColor;
+        diffuseEval(m, reflSpec, l, v, shadeNormal, tc, &currVal);
+        res.val = res.val + currVal.val * weight * bumpCosMult;
+        res.pdf += currVal.pdf * weight;
+      } break;
+      case MAT_TYPE_DIELECTRIC: res.val = splat4(0.0f); res.pdf = 0.0f; break;   // cmat_dielectric.h:59-63
+      default: break;
+    }
+    return res;
+  }
+
+  // ---- per-path kernels (integrator_pt.cpp) --------------------------------------------------------------------------
+  struct Path
+  {
+    f4 accumColor, accumThroughput, rayPosAndNear, rayDirAndFar;
+    RandomGen gen; MisData mis; uint rayFlags;
+    f4 hit1, hit2, hit3; uint instId;
+  };
+
+  static inline bool isDeadRay(uint f) { return (f & RAY_FLAG_IS_DEAD) != 0; }
+  static inline bool hasNonSpecular(uint f) { return (f & RAY_FLAG_HAS_NON_SPEC) != 0; }
+  static inline uint extractMatId(uint f) { return f & 0x00FFFFFFu; }
+  static inline uint packMatId(uint f, uint m) { return (f & 0xFF000000u) | (m & 0x00FFFFFFu); }
+
+  // SampleCameraRay + kernel_InitEyeRay2 (:44-157); the camera part is shared with the DR replay
+  void CameraRay(uint tid, f4 pixelOffsets, f4* rayPosAndNear, f4* rayDirAndFar) const
+  {
+    const uint XY = packedXY[tid];
+    const uint x = (XY & 0x0000FFFFu), y = (XY & 0xFFFF0000u) >> 16;
+    const float fx = float(x) + pixelOffsets.x, fy = float(y) + pixelOffsets.y;
+    const float xCoordNormalized = (fx + float(p.winStartX)) / float(p.fbWidth);
+    const float yCoordNormalized = (fy + float(p.winStartY)) / float(p.fbHeight);
+    f3 rayDir = EyeRayDirNormalized(xCoordNormalized, yCoordNormalized, p.projInv);
+    f3 rayPos = mk3(0, 0, 0);
+    if (p.camLensRadius > 0.0f) {
+      const float tFocus = p.camTargetDist / (-rayDir.z);
+      const f3 focusPosition = rayPos + rayDir * tFocus;
+      const f2 xy = p.camLensRadius * 2.0f * MapSamplesToDisc(mk2(pixelOffsets.z - 0.5f, pixelOffsets.w - 0.5f));
+      rayPos.x += xy.x; rayPos.y += xy.y;
+      rayDir = normalize(focusPosition - rayPos);
+    }
+    transform_ray3f(p.worldViewInv, &rayPos, &rayDir);
+    *rayPosAndNear = xyzw(rayPos, 0.0f);
+    *rayDirAndFar = xyzw(rayDir, FLT_MAX);
+  }
+
+  void InitEyeRay2(uint tid, Path* s, Record* rec) const
+  {
+    s->accumColor = mk4(0, 0, 0, 0);
+    s->accumThroughput = mk4(1, 1, 1, 1);
+    RandomGen genLocal = randomGens[tid];
+    s->rayFlags = 0;
+    s->mis = makeInitialMisData();
+    const f4 pixelOffsets = rndFloat4(&genLocal);      // GetRandomNumbersLens; no time / wavelength draws in RGB, static scenes
+    if (rec && rec->enabled) rec->lens = pixelOffsets;
+    CameraRay(tid, pixelOffsets, &s->rayPosAndNear, &s->rayDirAndFar);
+    s->gen = genLocal;
+  }
+
+  // shading data of a hit, shared by kernel_RayTrace2 (:238-311) and PathTraceReplay (integrator_dr.cpp:843-892)
+  void SurfaceFromHit(const orc_hit& hit, f4 rayPos, f4 rayDir, Path* s) const
+  {
+    uint currRayFlags = s->rayFlags;
+    const uint geomId = hit.geomId;
+    const uint triOffset = sc.matVertOffset[2 * geomId + 0], vertOffset = sc.matVertOffset[2 * geomId + 1];
+    const f3 hitPos = xyz(rayPos) + hit.t * (1.f - 1e-6f) * xyz(rayDir);
+    const f2 uv = mk2(hit.coords[0], hit.coords[1]);
+    const uint A = sc.triIndices[(triOffset + hit.primId) * 3 + 0];
+    const uint B = sc.triIndices[(triOffset + hit.primId) * 3 + 1];
+    const uint C = sc.triIndices[(triOffset + hit.primId) * 3 + 2];
+    const f4 data1 = (1.0f - uv.x - uv.y) * sc.vData8f[2 * (A + vertOffset)] + uv.y * sc.vData8f[2 * (B + vertOffset)] + uv.x * sc.vData8f[2 * (C + vertOffset)];
+    const f4 data2 = (1.0f - uv.x - uv.y) * sc.vData8f[2 * (A + vertOffset) + 1] + uv.y * sc.vData8f[2 * (B + vertOffset) + 1] + uv.x * sc.vData8f[2 * (C + vertOffset) + 1];
+    const f2 hitTexCoord = mk2(data1.w, data2.w);
+    f3 hitNorm = mul3x3(sc.normMatrices[hit.instId], xyz(data1));
+    f3 hitTang = mul3x3(sc.normMatrices[hit.instId], xyz(data2));
+    hitNorm = normalize(hitNorm);
+    hitTang = normalize(hitTang);
+    const float flipNorm = dot(xyz(rayDir), hitNorm) > 0.001f ? -1.0f : 1.0f;
+    hitNorm = flipNorm * hitNorm;
+    hitTang = flipNorm * hitTang;
+    if (flipNorm < 0.0f) currRayFlags |= RAY_FLAG_HAS_INV_NORMAL; else currRayFlags &= ~RAY_FLAG_HAS_INV_NORMAL;
+    const uint midOriginal = sc.matIdByPrimId[triOffset + hit.primId];
+    const uint midRemaped = RemapMaterialId(midOriginal, (int)hit.instId);
+    s->rayFlags = packMatId(currRayFlags, midRemaped);
+    s->hit1 = xyzw(hitPos, hitTexCoord.x);
+    s->hit2 = xyzw(hitNorm, hitTexCoord.y);
+    s->hit3 = xyzw(hitTang, hit.t);
+    s->instId = hit.instId;
+  }
+
+  void RayTrace2(uint bounce, Path* s, Record* rec) const   // :214-348
+  {
+    if (isDeadRay(s->rayFlags)) return;
+    const orc_hit hit = sc.nearest_hit(s->rayPosAndNear, s->rayDirAndFar);
+    if (rec && rec->enabled) rec->hit[bounce] = hit;
+    if (hit.geomId != uint(-1)) SurfaceFromHit(hit, s->rayPosAndNear, s->rayDirAndFar, s);
+    else {
+      const uint flagsToAdd = (bounce == 0) ? (RAY_FLAG_PRIME_RAY_MISS | RAY_FLAG_IS_DEAD | RAY_FLAG_OUT_OF_SCENE) : (RAY_FLAG_IS_DEAD | RAY_FLAG_OUT_OF_SCENE);
+      s->rayFlags = s->rayFlags | flagsToAdd;
+    }
+  }
+
+  f4 SampleLightSource(uint bounce, Path* s, Record* rec) const   // :350-424
+  {
+    f4 shade = mk4(0, 0, 0, 0);
+    const uint currRayFlags = s->rayFlags;
+    if (isDeadRay(currRayFlags)) return shade;
+    const uint matId = extractMatId(currRayFlags);
+    const f3 ray_dir = xyz(s->rayDirAndFar);
+    const f3 hpos = xyz(s->hit1), hnorm = xyz(s->hit2), htang = xyz(s->hit3);
+    const f2 huv = mk2(s->hit1.w, s->hit2.w);
+
+    const float rndId = rndFloat1(&s->gen);              // GetRandomNumbersLgts (:30-35): two generator steps, in this order
+    const f4 r4 = rndFloat4(&s->gen);
+    const f4 rands = mk4(r4.x, r4.y, r4.z, rndId);
+    const int nLights = (int)sc.lights.size();
+    const int lightId = std::min(int(std::floor(rands.w * float(nLights))), nLights - 1);
+    if (rec && rec->enabled) rec->lgt[bounce] = rands;
+    if (lightId < 0) return shade;
+
+    const LightSample lSam = LightSampleRev(lightId, xyz(rands), hpos);
+    const float hitDist = std::sqrt(dot(hpos - lSam.pos, hpos - lSam.pos));
+    const f3 shadowRayDir = normalize(lSam.pos - hpos);
+    const f3 shadowRayPos = hpos + hnorm * std::max(maxcomp(hpos), 1.0f) * 5e-6f;
+    const bool inIllumArea = (dot(shadowRayDir, lSam.norm) < 0.0f) || lSam.isOmni || lSam.hasIES;
+    const bool needShade = inIllumArea && !sc.any_hit(xyzw(shadowRayPos, 0.0f), xyzw(shadowRayDir, hitDist * 0.9995f));
+    if (rec && rec->enabled) rec->inShadow[bounce] = needShade ? 0 : 1;
+    if (needShade) {
+      const BsdfEval bsdfV = MaterialEval(matId, shadowRayDir, (-1.0f) * ray_dir, hnorm, htang, huv);
+      const float cosThetaOut = std::max(dot(shadowRayDir, hnorm), 0.0f);
+      float lgtPdfW = LightPdfSelectRev(lightId) * LightEvalPDF(lightId, shadowRayPos, shadowRayDir, lSam.pos, lSam.norm, lSam.pdf);
+      float misWeight = (p.integratorType == INTEGRATOR_MIS_PT) ? misWeightHeuristic(lgtPdfW, bsdfV.pdf) : 1.0f;
+      const bool isDirect = (sc.lights[lightId].geomType == LIGHT_GEOM_DIRECT);
+      const bool isPoint = (sc.lights[lightId].geomType == LIGHT_GEOM_POINT);
+      if (isDirect) { misWeight = 1.0f; lgtPdfW = 1.0f; }
+      else if (isPoint) misWeight = 1.0f;
+      const bool isDirectLight = !hasNonSpecular(currRayFlags);
+      if ((p.renderLayer == FB_DIRECT && !isDirectLight) || (p.renderLayer == FB_INDIRECT && isDirectLight)) misWeight = 0.0f;
+      const f4 lightColor = LightIntensity(lightId, shadowRayPos, shadowRayDir);
+      shade = (lightColor * bsdfV.val / lgtPdfW) * cosThetaOut * misWeight;
+    }
+    return shade;
+  }
+
+  void NextBounce(uint bounce, f4 shadeColor, Path* s, Record* rec) const   // :426-548
+  {
+    const uint currRayFlags = s->rayFlags;
+    if (isDeadRay(currRayFlags)) return;
+    const uint matId = extractMatId(currRayFlags);
+    const f3 ray_dir = xyz(s->rayDirAndFar), ray_pos = xyz(s->rayPosAndNear);
+    f3 hpos = xyz(s->hit1);
+    const f3 hnorm = xyz(s->hit2), htang = xyz(s->hit3);
+    const f2 huv = mk2(s->hit1.w, s->hit2.w);
+    const float hitDist = s->hit3.w;
+    const float prevPdfW = s->mis.matSamplePdf;
+    const Material& m = sc.materials[matId];
+
+    if (m.mtype == MAT_TYPE_LIGHT_SOURCE) {
+      const f2 texCoordT = mulRows2x4(m.row0[0], m.row1[0], huv);
+      const f4 texColor = sc.tex_sample(m.texid[0], texCoordT);
+      const uint lightId = (uint)sc.remapInst[2 * s->instId + 1];
+      const f4 emissColor = m.colors[EMISSION_COLOR];
+      f4 lightIntensity = emissColor * texColor;
+      if (lightId != 0xFFFFFFFFu) {
+        const float lightCos = dot(ray_dir, xyz(sc.lights[lightId].norm));
+        const float lightDirectionAtten = (lightCos < 0.0f || sc.lights[lightId].geomType == LIGHT_GEOM_SPHERE) ? 1.0f : 0.0f;
+        lightIntensity = LightIntensity(lightId, ray_pos, ray_dir) * lightDirectionAtten;
+      }
+      float misWeight = 1.0f;
+      if (p.integratorType == INTEGRATOR_MIS_PT) {
+        if (bounce > 0 && lightId != 0xFFFFFFFFu) {
+          const float lgtPdf = LightPdfSelectRev(lightId) * LightEvalPDF(lightId, ray_pos, ray_dir, hpos, hnorm, 1.0f);
+          misWeight = misWeightHeuristic(prevPdfW, lgtPdf);
+          if (prevPdfW <= 0.0f) misWeight = 1.0f;
+        }
+      } else if (p.integratorType == INTEGRATOR_SHADOW_PT && hasNonSpecular(currRayFlags)) misWeight = 0.0f;
+      const bool isDirectLight = !hasNonSpecular(currRayFlags);
+      const bool isFirstNonSpec = (currRayFlags & RAY_FLAG_FIRST_NON_SPEC) != 0;
+      if (p.renderLayer == FB_INDIRECT && (isDirectLight || isFirstNonSpec)) misWeight = 0.0f;
+      s->accumColor = s->accumColor + s->accumThroughput * lightIntensity * misWeight;
+      s->rayFlags = currRayFlags | (RAY_FLAG_IS_DEAD | RAY_FLAG_HIT_LIGHT);
+      return;
+    }
+
+    const BsdfSample matSam = MaterialSampleAndEval(matId, &s->gen, (-1.0f) * ray_dir, hnorm, htang, huv, &s->mis, currRayFlags, rec, bounce);
+    const f4 bxdfVal = matSam.val * (1.0f / std::max(matSam.pdf, 1e-20f));
+    const float cosTheta = std::abs(dot(matSam.dir, hnorm));
+    s->mis.matSamplePdf = (matSam.flags & RAY_EVENT_S) != 0 ? -1.0f : matSam.pdf;
+    s->mis.cosTheta = cosTheta;
+    if (p.integratorType == INTEGRATOR_STUPID_PT) s->accumThroughput = s->accumThroughput * (cosTheta * bxdfVal);
+    else {
+      const f4 currThoroughput = s->accumThroughput;
+      s->accumColor = s->accumColor + currThoroughput * shadeColor;
+      s->accumThroughput = currThoroughput * cosTheta * bxdfVal;
+    }
+    if ((matSam.flags & RAY_EVENT_T) != 0) hpos = hpos + hitDist * ray_dir * 2.0f * 1e-6f;
+    s->rayPosAndNear = xyzw(OffsRayPos(hpos, hnorm, matSam.dir), 0.0f);
+    s->rayDirAndFar = xyzw(matSam.dir, FLT_MAX);
+    uint nextFlags = ((currRayFlags & ~RAY_FLAG_FIRST_NON_SPEC) | matSam.flags);
+    if (p.renderLayer == FB_DIRECT && hasNonSpecular(currRayFlags)) nextFlags |= RAY_FLAG_IS_DEAD;
+    else if (!hasNonSpecular(currRayFlags) && hasNonSpecular(nextFlags)) nextFlags |= RAY_FLAG_FIRST_NON_SPEC;
+    s->rayFlags = nextFlags;
+  }
+
+  void HitEnvironment(Path* s) const   // :550-595 (constant environment colour; env texture / camera back plate out of scope)
+  {
+    if ((s->rayFlags & RAY_FLAG_OUT_OF_SCENE) == 0) return;
+    const f4 envColor = p.envColor;
+    if (p.integratorType == INTEGRATOR_STUPID_PT) s->accumColor = s->accumThroughput * envColor;
+    else                                          s->accumColor = s->accumColor + s->accumThroughput * envColor;
+  }
+
+  void ContributeToImage(uint tid, uint channels, const Path* s, float* out_color, bool disableImageContrib)   // :598-657
+  {
+    randomGens[tid] = s->gen;
+    if (disableImageContrib) return;
+    const uint XY = packedXY[tid];
+    const uint x = (XY & 0x0000FFFFu), y = (XY & 0xFFFF0000u) >> 16;
+    const f4 tmpVal = s->accumColor * p.camRespoceRGB;
+    const f4 colorRes = p.exposureMult * mk4(tmpVal.x, tmpVal.y, tmpVal.z, 1.0f);
+    if (channels == 1) out_color[y * p.winWidth + x] += s->accumColor.x * p.exposureMult;
+    else {
+      out_color[(y * p.winWidth + x) * channels + 0] += colorRes.x;
+      out_color[(y * p.winWidth + x) * channels + 1] += colorRes.y;
+      out_color[(y * p.winWidth + x) * channels + 2] += colorRes.z;
+    }
+  }
+
+  f4 PathTrace(uint tid, uint channels, float* out_color, Record* rec, bool disableImageContrib)   // :719-759
+  {
+    Path s;
+    InitEyeRay2(tid, &s, rec);
+    for (uint depth = 0; depth < p.traceDepth; depth++) {
+      RayTrace2(depth, &s, rec);
+      if (isDeadRay(s.rayFlags)) break;
+      const f4 shadeColor = SampleLightSource(depth, &s, rec);
+      NextBounce(depth, shadeColor, &s, rec);
+      if (isDeadRay(s.rayFlags)) break;
+    }
+    HitEnvironment(&s);
+    ContributeToImage(tid, channels, &s, out_color, disableImageContrib);
+    return s.accumColor;
+  }
+
+  void NaivePathTrace(uint tid, uint channels, float* out_color)   // :681-717
+  {
+    Path s;
+    InitEyeRay2(tid, &s, nullptr);
+    for (uint depth = 0; depth < p.traceDepth + 1; ++depth) {
+      RayTrace2(depth, &s, nullptr);
+      if (isDeadRay(s.rayFlags)) break;
+      NextBounce(depth, mk4(0, 0, 0, 0), &s, nullptr);
+      if (isDeadRay(s.rayFlags)) break;
+    }
+    HitEnvironment(&s);
+    ContributeToImage(tid, channels, &s, out_color, false);
+  }
+
+  // ---- differentiable rendering (diff_render/integrator_dr.cpp) ---------------------------------------------------------
+  // Tex2DFetchAD (:95-161): fetch from the flat parameter vector when the texture is registered, else the ordinary sampler.
+  // Returns a dual colour whose derivative slot `bounce` is the identity (d texColor / d texColor).
+  AF4 Tex2DFetchAD(uint texId, f2 uv, const float* tex_data, int bounce, Scene::Taps* tapsOut, bool* isParam) const
+  {
+    const TexInfo& info = texAddressTable[texId];
+    *isParam = false;
+    if (info.offset != size_t(-1) && tex_data != nullptr) {
+      const Texture& geo = sc.textures[texId];   // address modes come from the bound sampler (:110-113); size from the table
+      Texture t; t.w = (uint)info.width; t.h = (uint)info.height; t.addrU = geo.addrU; t.addrV = geo.addrV;
+      const Scene::Taps k = Scene::bilinear_taps(t, uv);
+      *tapsOut = k; *isParam = true;
+      f4 r;
+      if (info.channels == 4) {
+        const float* d = tex_data + info.offset;
+        r.x = d[k.off[0] * 4 + 0] * k.w[0] + d[k.off[1] * 4 + 0] * k.w[1] + d[k.off[2] * 4 + 0] * k.w[2] + d[k.off[3] * 4 + 0] * k.w[3];
+        r.y = d[k.off[0] * 4 + 1] * k.w[0] + d[k.off[1] * 4 + 1] * k.w[1] + d[k.off[2] * 4 + 1] * k.w[2] + d[k.off[3] * 4 + 1] * k.w[3];
+        r.z = d[k.off[0] * 4 + 2] * k.w[0] + d[k.off[1] * 4 + 2] * k.w[1] + d[k.off[2] * 4 + 2] * k.w[2] + d[k.off[3] * 4 + 2] * k.w[3];
+        r.w = d[k.off[0] * 4 + 3] * k.w[0] + d[k.off[1] * 4 + 3] * k.w[1] + d[k.off[2] * 4 + 3] * k.w[2] + d[k.off[3] * 4 + 3] * k.w[3];
+      } else {
+        const float* d = tex_data + info.offset;
+        const float o = d[k.off[0]] * k.w[0] + d[k.off[1]] * k.w[1] + d[k.off[2]] * k.w[2] + d[k.off[3]] * k.w[3];
+        r = mk4(o, o, o, o);
+      }
+      AF4 a(r);
+      a.d[bounce] = splat4(1.0f);
+      return a;
+    }
+    return AF4(sc.tex_sample(texId, uv));
+  }
+
+  struct ReplayOut { AF4 color; Scene::Taps taps[MAXB]; uint texId[MAXB]; bool isParam[MAXB]; };
+
+  // PathTraceReplay (:790-1101): re-shade a recorded path; no BVH queries, no RNG. Only MAT_TYPE_GLTF is
+  // differentiable / supported on this path (DR-specific MaterialSampleAndEval / MaterialEval, :461-612).
+  void PathTraceReplay(uint tid, const Record& rec, const float* dparams, ReplayOut* out) const
+  {
+    AF4 accumColor(splat4(0.0f)), accumThroughput(splat4(1.0f));
+    Path s; s.mis = makeInitialMisData(); s.rayFlags = 0;
+    for (int b = 0; b < MAXB; b++) { out->isParam[b] = false; out->texId[b] = 0; }
+    CameraRay(tid, rec.lens, &s.rayPosAndNear, &s.rayDirAndFar);
+
+    for (uint bounce = 0; bounce < p.traceDepth; bounce++) {
+      if (!isDeadRay(s.rayFlags)) {
+        const orc_hit hit = rec.hit[bounce];
+        if (hit.geomId != uint(-1)) SurfaceFromHit(hit, s.rayPosAndNear, s.rayDirAndFar, &s);
+        else {
+          const uint flagsToAdd = (bounce == 0) ? (RAY_FLAG_PRIME_RAY_MISS | RAY_FLAG_IS_DEAD | RAY_FLAG_OUT_OF_SCENE) : (RAY_FLAG_IS_DEAD | RAY_FLAG_OUT_OF_SCENE);
+          s.rayFlags |= flagsToAdd;
+        }
+      }
+      AF4 shadeColor(splat4(0.0f));
+      if (!isDeadRay(s.rayFlags)) {        // kernel_SampleLightSource replayed (:903-956)
+        const uint matId = extractMatId(s.rayFlags);
+        const f3 ray_dir = xyz(s.rayDirAndFar);
+        const f3 hpos = xyz(s.hit1), hnorm = xyz(s.hit2);
+        const f2 huv = mk2(s.hit1.w, s.hit2.w);
+        const f4 rands = rec.lgt[bounce];
+        const int nLights = (int)sc.lights.size();
+        const int lightId = std::min(int(std::floor(rands.w * float(nLights))), nLights - 1);
+        if (lightId >= 0) {
+          const LightSample lSam = LightSampleRev(lightId, xyz(rands), hpos);
+          const f3 shadowRayDir = normalize(lSam.pos - hpos);
+          const f3 shadowRayPos = hpos + hnorm * std::max(maxcomp(hpos), 1.0f) * 5e-6f;
+          const bool inIllumArea = (dot(shadowRayDir, lSam.norm) < 0.0f) || lSam.isOmni || lSam.hasIES;
+          const bool needShade = inIllumArea && (rec.inShadow[bounce] == 0);
+          if (needShade) {
+            const Material& m = sc.materials[matId];
+            BsdfEvalT<AF4> bsdfV; bsdfV.val = AF4(splat4(0)); bsdfV.pdf = 0.0f;
+            if (m.mtype == MAT_TYPE_GLTF) {
+              const f2 texCoordT = mulRows2x4(m.row0[0], m.row1[0], huv);
+              const AF4 texColor = Tex2DFetchAD(m.texid[0], texCoordT, dparams, (int)bounce, &out->taps[bounce], &out->isParam[bounce]);
+              out->texId[bounce] = m.texid[0];
+              const AF4 color = texColor * m.colors[GLTF_COLOR_BASE];
+              BsdfEvalT<AF4> r; r.val = AF4(splat4(0)); r.pdf = 0.0f;
+              gltfEval<AF4>(m, shadowRayDir, (-1.0f) * ray_dir, hnorm, huv, color, mk4(1, 1, 1, 1), &r);
+              bsdfV.val = r.val; bsdfV.pdf = r.pdf;
+            }
+            const float cosThetaOut = std::max(dot(shadowRayDir, hnorm), 0.0f);
+            float lgtPdfW = LightPdfSelectRev(lightId) * LightEvalPDF(lightId, shadowRayPos, shadowRayDir, lSam.pos, lSam.norm, lSam.pdf);
+            float misWeight = (p.integratorType == INTEGRATOR_MIS_PT) ? misWeightHeuristic(lgtPdfW, bsdfV.pdf) : 1.0f;
+            const bool isDirect = (sc.lights[lightId].geomType == LIGHT_GEOM_DIRECT);
+            const bool isPoint = (sc.lights[lightId].geomType == LIGHT_GEOM_POINT);
+            if (isDirect) { misWeight = 1.0f; lgtPdfW = 1.0f; }
+            else if (isPoint) misWeight = 1.0f;
+            const bool isDirectLight = !hasNonSpecular(s.rayFlags);
+            if ((p.renderLayer == FB_DIRECT && !isDirectLight) || (p.renderLayer == FB_INDIRECT && isDirectLight)) misWeight = 0.0f;
+            const f4 lightColor = LightIntensity(lightId, shadowRayPos, shadowRayDir);
+            shadeColor = ((bsdfV.val * lightColor) / lgtPdfW) * cosThetaOut * misWeight;
+          }
+        }
+      }
+      if (!isDeadRay(s.rayFlags)) {        // kernel_NextBounce replayed (:964-1072)
+        const uint matId = extractMatId(s.rayFlags);
+        const f3 ray_dir = xyz(s.rayDirAndFar), ray_pos = xyz(s.rayPosAndNear);
+        f3 hpos = xyz(s.hit1);
+        const f3 hnorm = xyz(s.hit2);
+        const f2 huv = mk2(s.hit1.w, s.hit2.w);
+        const float hitDist = s.hit3.w;
+        const float prevPdfW = s.mis.matSamplePdf;
+        const Material& m = sc.materials[matId];
+        if (m.mtype == MAT_TYPE_LIGHT_SOURCE) {
+          const f2 texCoordT = mulRows2x4(m.row0[0], m.row1[0], huv);
+          const f4 texColor = sc.tex_sample(m.texid[0], texCoordT);
+          const uint lightId = (uint)sc.remapInst[2 * s.instId + 1];
+          f4 lightIntensity = m.colors[EMISSION_COLOR] * texColor;
+          if (lightId != 0xFFFFFFFFu) {
+            const float lightCos = dot(ray_dir, xyz(sc.lights[lightId].norm));
+            const float atten = (lightCos < 0.0f || sc.lights[lightId].geomType == LIGHT_GEOM_SPHERE) ? 1.0f : 0.0f;
+            lightIntensity = LightIntensity(lightId, ray_pos, ray_dir) * atten;
+          }
+          float misWeight = 1.0f;
+          if (p.integratorType == INTEGRATOR_MIS_PT) {
+            if (bounce > 0 && lightId != 0xFFFFFFFFu) {
+              const float lgtPdf = LightPdfSelectRev(lightId) * LightEvalPDF(lightId, ray_pos, ray_dir, hpos, hnorm, 1.0f);
+              misWeight = misWeightHeuristic(prevPdfW, lgtPdf);
+              if (prevPdfW <= 0.0f) misWeight = 1.0f;
+            }
+          } else if (p.integratorType == INTEGRATOR_SHADOW_PT && hasNonSpecular(s.rayFlags)) misWeight = 0.0f;
+          const bool isDirectLight = !hasNonSpecular(s.rayFlags);
+          const bool isFirstNonSpec = (s.rayFlags & RAY_FLAG_FIRST_NON_SPEC) != 0;
+          if (p.renderLayer == FB_INDIRECT && (isDirectLight || isFirstNonSpec)) misWeight = 0.0f;
+          accumColor = accumColor + (accumThroughput * lightIntensity) * misWeight;
+          s.rayFlags |= (RAY_FLAG_IS_DEAD | RAY_FLAG_HIT_LIGHT);
+        } else {
+          BsdfSampleT<AF4> matSam; matSam.val = AF4(splat4(0)); matSam.pdf = 1.0f; matSam.dir = mk3(0, 1, 0); matSam.ior = 1.0f; matSam.flags = s.rayFlags;
+          if (m.mtype == MAT_TYPE_GLTF) {
+            const f2 texCoordT = mulRows2x4(m.row0[0], m.row1[0], huv);
+            const AF4 texColor = Tex2DFetchAD(m.texid[0], texCoordT, dparams, (int)bounce, &out->taps[bounce], &out->isParam[bounce]);
+            out->texId[bounce] = m.texid[0];
+            const AF4 color = texColor * m.colors[GLTF_COLOR_BASE];
+            gltfSampleAndEval<AF4>(m, rec.mat[bounce], (-1.0f) * ray_dir, hnorm, huv, color, mk4(1, 1, 1, 1), &matSam);
+          }
+          const AF4 bxdfVal = matSam.val * (1.0f / std::max(matSam.pdf, 1e-20f));
+          const float cosTheta = std::abs(dot(matSam.dir, hnorm));
+          s.mis.matSamplePdf = (matSam.flags & RAY_EVENT_S) != 0 ? -1.0f : matSam.pdf;
+          s.mis.cosTheta = cosTheta;
+          if (p.integratorType == INTEGRATOR_STUPID_PT) accumThroughput = mulAA(accumThroughput, bxdfVal * cosTheta);
+          else {
+            accumColor = accumColor + mulAA(accumThroughput, shadeColor);
+            accumThroughput = mulAA(accumThroughput * cosTheta, bxdfVal);
+          }
+          if ((matSam.flags & RAY_EVENT_T) != 0) hpos = hpos + hitDist * ray_dir * 2.0f * 1e-6f;
+          s.rayPosAndNear = xyzw(OffsRayPos(hpos, hnorm, matSam.dir), 0.0f);
+          s.rayDirAndFar = xyzw(matSam.dir, FLT_MAX);
+          uint nextFlags = ((s.rayFlags & ~RAY_FLAG_FIRST_NON_SPEC) | matSam.flags);
+          if (p.renderLayer == FB_DIRECT && hasNonSpecular(s.rayFlags)) nextFlags |= RAY_FLAG_IS_DEAD;
+          else if (!hasNonSpecular(s.rayFlags) && hasNonSpecular(nextFlags)) nextFlags |= RAY_FLAG_FIRST_NON_SPEC;
+          s.rayFlags = nextFlags;
+        }
+      }
+    }
+    // environment term, added unconditionally in the replay (:1077-1098)
+    accumColor = accumColor + accumThroughput * p.envColor;
+    out->color = accumColor;
+  }
+};
+
+static int g_threads = 0;
+
+} // namespace orc
+
+using namespace orc;
+
+struct orc_ctx { Ctx c; };
+
+static void copy_params(Params& p, const orc_params* s)
+{
+  std::memcpy(&p.projInv, s->projInv, 64);
+  std::memcpy(&p.worldViewInv, s->worldViewInv, 64);
+  p.winStartX = s->winStartX; p.winStartY = s->winStartY; p.winWidth = s->winWidth; p.winHeight = s->winHeight;
+  p.fbWidth = s->fbWidth; p.fbHeight = s->fbHeight;
+  p.traceDepth = s->traceDepth; p.integratorType = s->integratorType; p.renderLayer = s->renderLayer;
+  p.tileSize = s->tileSize; p.spectralMode = s->spectralMode;
+  p.exposureMult = s->exposureMult; p.camLensRadius = s->camLensRadius; p.camTargetDist = s->camTargetDist;
+  std::memcpy(&p.camRespoceRGB, s->camRespoceRGB, 16);
+  std::memcpy(&p.envColor, s->envColor, 16);
+}
+
+extern "C" {
+
+orc_ctx* orc_create(const orc_scene_desc* scene, const orc_params* params)
+{
+  orc_ctx* h = new orc_ctx();
+  h->c.sc.load(scene);
+  copy_params(h->c.p, params);
+  h->c.texAddressTable.assign(h->c.sc.textures.size(), TexInfo{size_t(-1), 0, 0, 0});   // LoadSceneEnd (integrator_dr.cpp:24-31)
+  h->c.gradSize = 0;
+  return h;
+}
+void orc_destroy(orc_ctx* h) { delete h; }
+void orc_set_params(orc_ctx* h, const orc_params* p) { copy_params(h->c.p, p); }
+void orc_set_threads(int n) { g_threads = n; }
+
+void orc_pack_xy(orc_ctx* h, uint32_t* out)
+{
+  h->c.PackXY();
+  if (out) std::memcpy(out, h->c.packedXY.data(), h->c.packedXY.size() * 4);
+}
+void orc_init_random_gens(orc_ctx* h, uint32_t count)
+{
+  h->c.randomGens.resize(count);
+  for (uint32_t i = 0; i < count; i++) h->c.randomGens[i] = RandomGenInit((int)i);
+}
+void orc_get_random_gens(orc_ctx* h, uint32_t* out, uint32_t count) { std::memcpy(out, h->c.randomGens.data(), (size_t)count * 8); }
+void orc_set_random_gens(orc_ctx* h, const uint32_t* in, uint32_t count) { h->c.randomGens.resize(count); std::memcpy(h->c.randomGens.data(), in, (size_t)count * 8); }
+
+static int nthreads() { return g_threads > 0 ? g_threads : omp_get_max_threads(); }
+
+void orc_path_trace_block(orc_ctx* h, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out_color, uint32_t passNum)
+{
+  Ctx& c = h->c;
+  #pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads())
+  for (long i = (long)tidBegin; i < (long)(tidBegin + tidCount); ++i)
+    for (uint32_t j = 0; j < passNum; ++j)
+      c.PathTrace((uint)i, channels, out_color, nullptr, false);
+}
+void orc_naive_path_trace_block(orc_ctx* h, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out_color, uint32_t passNum)
+{
+  Ctx& c = h->c;
+  #pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads())
+  for (long i = (long)tidBegin; i < (long)(tidBegin + tidCount); ++i)
+    for (uint32_t j = 0; j < passNum; ++j)
+      c.NaivePathTrace((uint)i, channels, out_color);
+}
+
+void orc_ray_nearest(orc_ctx* h, const float* posNear4, const float* dirFar4, uint32_t n, orc_hit* out, int bruteForce)
+{
+  const Scene& sc = h->c.sc;
+  #pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads())
+  for (long i = 0; i < (long)n; i++)
+    out[i] = sc.nearest_hit(((const f4*)posNear4)[i], ((const f4*)dirFar4)[i], bruteForce != 0);
+}
+void orc_ray_any(orc_ctx* h, const float* posNear4, const float* dirFar4, uint32_t n, uint32_t* out, int bruteForce)
+{
+  const Scene& sc = h->c.sc;
+  #pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads())
+  for (long i = 0; i < (long)n; i++)
+    out[i] = sc.any_hit(((const f4*)posNear4)[i], ((const f4*)dirFar4)[i], bruteForce != 0) ? 1u : 0u;
+}
+
+// IntegratorDR::PutDiffTex2D (integrator_dr.cpp:33-53)
+int orc_put_diff_tex2d(orc_ctx* h, uint32_t texId, uint32_t width, uint32_t height, uint32_t channels, uint64_t* outOffset, uint64_t* outSize)
+{
+  Ctx& c = h->c;
+  if (texId >= c.texAddressTable.size()) {
+    std::printf("[orc_put_diff_tex2d]: bad tex id = %u\n", texId);
+    *outOffset = (uint64_t)-1; *outSize = 0;
+    return 1;
+  }
+  TexInfo& t = c.texAddressTable[texId];
+  t.offset = c.gradSize; t.width = (int)width; t.height = (int)height; t.channels = (int)channels;
+  const size_t currSize = size_t(width) * size_t(height) * size_t(channels);
+  *outOffset = c.gradSize; *outSize = currSize;
+  c.gradSize += currSize;
+  return 0;
+}
+
+// PixelLossPT + the per-sample body of PathTraceDR (integrator_dr.cpp:1103-1132, 1156-1187).
+// The reverse sweep Enzyme generates is replaced by forward-mode duals over the <= traceDepth texture fetches.
+static float dr_sample(Ctx& c, uint tid, uint channels, float* out_color, const float* refImg, const float* data, float* grad, Record& rec)
+{
+  rec.enabled = true;
+  c.PathTrace(tid, channels, out_color, &rec, true);      // (1) record; image contribution disabled (:1138)
+  rec.enabled = false;
+  Ctx::ReplayOut ro;
+  c.PathTraceReplay(tid, rec, data, &ro);                 // (2) replay
+  const uint XY = c.packedXY[tid];
+  const uint x = (XY & 0x0000FFFFu), y = (XY & 0xFFFF0000u) >> 16;
+  const uint pitch = (uint)c.p.winWidth;
+  const uint yRef = (uint)c.p.winHeight - y - 1;
+  const f4 colorRend = ro.color.v;
+  const f4 colorRef = mk4(refImg[(yRef * pitch + x) * channels + 0], refImg[(yRef * pitch + x) * channels + 1], refImg[(yRef * pitch + x) * channels + 2], 0.0f);
+  out_color[(y * pitch + x) * channels + 0] += colorRend.x;
+  out_color[(y * pitch + x) * channels + 1] += colorRend.y;
+  out_color[(y * pitch + x) * channels + 2] += colorRend.z;
+  const f4 diff = colorRend - colorRef;
+  const float loss = diff.x * diff.x + diff.y * diff.y + diff.z * diff.z;
+  if (grad) {
+    for (uint b = 0; b < c.p.traceDepth && b < (uint)MAXB; b++) {
+      if (!ro.isParam[b]) continue;
+      const TexInfo& info = c.texAddressTable[ro.texId[b]];
+      const f4 dC = ro.color.d[b];                       // dC_ch / d texColor_ch at bounce b
+      const float g[3] = { 2.0f * diff.x * dC.x, 2.0f * diff.y * dC.y, 2.0f * diff.z * dC.z };
+      for (int k = 0; k < 4; k++) {
+        const float w = ro.taps[b].w[k];
+        if (info.channels == 4) {
+          grad[info.offset + (size_t)ro.taps[b].off[k] * 4 + 0] += g[0] * w;
+          grad[info.offset + (size_t)ro.taps[b].off[k] * 4 + 1] += g[1] * w;
+          grad[info.offset + (size_t)ro.taps[b].off[k] * 4 + 2] += g[2] * w;
+        } else {
+          grad[info.offset + (size_t)ro.taps[b].off[k]] += (g[0] + g[1] + g[2]) * w;
+        }
+      }
+    }
+  }
+  return loss;
+}
+
+float orc_path_trace_dr(orc_ctx* h, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out_color, uint32_t passNum,
+                        const float* refImg, const float* data, float* dataGrad, uint64_t gradSize)
+{
+  Ctx& c = h->c;
+  std::memset(dataGrad, 0, sizeof(float) * gradSize);
+  const int T = nthreads();
+  std::vector<std::vector<float>> grads(T, std::vector<float>(gradSize, 0.0f));   // private gradient per thread (:1143-1147)
+  std::vector<double> lossT(T, 0.0);
+  #pragma omp parallel for schedule(static) num_threads(T)
+  for (long i = (long)tidBegin; i < (long)(tidBegin + tidCount); ++i) {
+    const int th = omp_get_thread_num();
+    Record rec; rec.enabled = false;
+    for (uint32_t passId = 0; passId < passNum; passId++) {
+      const float lossVal = dr_sample(c, (uint)i, channels, out_color, refImg, data, grads[th].data(), rec);
+      lossT[th] += double(lossVal) / double(passNum);
+    }
+  }
+  for (int t = 0; t < T; t++)
+    for (size_t j = 0; j < gradSize; j++) dataGrad[j] += grads[t][j];                // (:1202-1204)
+  double avgLoss = 0.0;
+  for (int t = 0; t < T; t++) avgLoss += lossT[t];
+  return float(avgLoss / double(c.p.winWidth * c.p.winHeight));                        // (:1206)
+}
+
+void orc_path_trace_dr_fd(orc_ctx* h, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, uint32_t passNum,
+                          const float* refImg, const float* data, uint64_t gradSize,
+                          const uint64_t* idx, uint32_t nIdx, float hstep, double* outDeriv)
+{
+  Ctx& c = h->c;
+  for (uint32_t k = 0; k < nIdx; k++) outDeriv[k] = 0.0;
+  std::vector<RandomGen> saved = c.randomGens;
+  std::vector<float> scratch((size_t)c.p.winWidth * c.p.winHeight * channels, 0.0f);
+  // record every sample once, then re-shade it with perturbed parameters
+  std::vector<Record> recs((size_t)tidCount * passNum);
+  for (uint32_t i = 0; i < tidCount; i++)
+    for (uint32_t j = 0; j < passNum; j++) {
+      Record& r = recs[(size_t)i * passNum + j];
+      r.enabled = true;
+      c.PathTrace(tidBegin + i, channels, scratch.data(), &r, true);
+      r.enabled = false;
+    }
+  c.randomGens = saved;
+  std::vector<float> pd(data, data + gradSize);
+  const uint pitch = (uint)c.p.winWidth;
+  for (uint32_t k = 0; k < nIdx; k++) {
+    double lossPM[2] = {0.0, 0.0};
+    for (int s = 0; s < 2; s++) {
+      pd[idx[k]] = data[idx[k]] + (s == 0 ? hstep : -hstep);
+      for (uint32_t i = 0; i < tidCount; i++)
+        for (uint32_t j = 0; j < passNum; j++) {
+          Ctx::ReplayOut ro;
+          c.PathTraceReplay(tidBegin + i, recs[(size_t)i * passNum + j], pd.data(), &ro);
+          const uint XY = c.packedXY[tidBegin + i];
+          const uint x = (XY & 0x0000FFFFu), y = (XY & 0xFFFF0000u) >> 16;
+          const uint yRef = (uint)c.p.winHeight - y - 1;
+          const double dx = double(ro.color.v.x) - refImg[(yRef * pitch + x) * channels + 0];
+          const double dy = double(ro.color.v.y) - refImg[(yRef * pitch + x) * channels + 1];
+          const double dz = double(ro.color.v.z) - refImg[(yRef * pitch + x) * channels + 2];
+          lossPM[s] += dx * dx + dy * dy + dz * dz;
+        }
+    }
+    pd[idx[k]] = data[idx[k]];
+    outDeriv[k] = (lossPM[0] - lossPM[1]) / (2.0 * double(hstep));
+  }
+}
+
+void orc_rng_kat(int seed, uint32_t nDraws, uint32_t* outState2, float* outFloat4PerDraw)
+{
+  RandomGen g = RandomGenInit(seed);
+  outState2[0] = g.sx; outState2[1] = g.sy;
+  for (uint32_t i = 0; i < nDraws; i++) {
+    const f4 r = rndFloat4(&g);
+    outFloat4PerDraw[4 * i + 0] = r.x; outFloat4PerDraw[4 * i + 1] = r.y; outFloat4PerDraw[4 * i + 2] = r.z; outFloat4PerDraw[4 * i + 3] = r.w;
+  }
+  outState2[2] = g.sx; outState2[3] = g.sy;
+}
+
+void orc_tex_sample(orc_ctx* h, uint32_t texId, const float* uv2, uint32_t n, float* out4)
+{
+  for (uint32_t i = 0; i < n; i++) {
+    const f4 r = h->c.sc.tex_sample(texId, mk2(uv2[2 * i], uv2[2 * i + 1]));
+    out4[4 * i + 0] = r.x; out4[4 * i + 1] = r.y; out4[4 * i + 2] = r.z; out4[4 * i + 3] = r.w;
+  }
+}
+
+// AdamOptimizer<float>::step (diff_render/adam.h:43-62)
+void orc_adam_step(float* state, const float* grad, float* momentum, float* gsquare, uint64_t n, int iter)
+{
+  const int factorGamma = iter / 100 + 1;
+  const float alpha = 0.5f, beta = 0.25f, gamma = 0.25f / float(factorGamma), epsilon = 1e-8f;
+  for (uint64_t i = 0; i < n; i++) {
+    const float g = grad[i];
+    momentum[i] = momentum[i] * beta + g * (1.0f - beta);
+    gsquare[i] = 2.0f * (gsquare[i] * alpha + (g * g) * (1.0f - alpha));
+  }
+  for (uint64_t i = 0; i < n; i++) state[i] -= (gamma * momentum[i] / (std::sqrt(gsquare[i] + epsilon)));
+}
+
+} // extern "C"

@@ -1,0 +1,630 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).  PARITY UNPINNED.
+//
+// RNG, sampling helpers, BSDFs and light samplers of HydraCore3, restated for the CPU checker.
+// Every function names the reference lines it follows; arithmetic is kept in the reference's order so that
+// the result is what the reference's CPU build (USE_VULKAN=OFF) computes, up to libm.
+#pragma once
+#include "orc_scene.h"
+
+namespace orc {
+
+// ---- include/cglobals.h:9-16 ----------------------------------------------------------------------------------
+static const uint RAY_FLAG_IS_DEAD        = 0x80000000u;
+static const uint RAY_FLAG_OUT_OF_SCENE   = 0x40000000u;
+static const uint RAY_FLAG_HIT_LIGHT      = 0x20000000u;
+static const uint RAY_FLAG_HAS_NON_SPEC   = 0x10000000u;
+static const uint RAY_FLAG_HAS_INV_NORMAL = 0x08000000u;
+static const uint RAY_FLAG_WAVES_DIVERGED = 0x04000000u;
+static const uint RAY_FLAG_PRIME_RAY_MISS = 0x02000000u;
+static const uint RAY_FLAG_FIRST_NON_SPEC = 0x01000000u;
+
+// ---- include/cmaterial.h:26-56 --------------------------------------------------------------------------------
+static const uint GLTF_COMPONENT_METAL = 4, GLTF_COMPONENT_ORENNAYAR = 16, FLAG_FOUR_TEXTURES = 256, FLAG_PACK_FOUR_PARAMS_IN_TEXTURE = 512;
+static const uint MAT_TYPE_GLTF = 1, MAT_TYPE_CONDUCTOR = 3, MAT_TYPE_DIFFUSE = 4, MAT_TYPE_DIELECTRIC = 7, MAT_TYPE_LIGHT_SOURCE = 0xEFFFFFFFu;
+static const uint RAY_EVENT_S = 1, RAY_EVENT_T = 8;
+// include/cmaterial.h:67-147
+static const int GLTF_COLOR_BASE = 0, GLTF_COLOR_COAT = 1, GLTF_COLOR_METAL = 2;
+static const int GLTF_FLOAT_MI_FDR_INT = 0, GLTF_FLOAT_ALPHA = 3, GLTF_FLOAT_GLOSINESS = 4, GLTF_FLOAT_IOR = 5, GLTF_FLOAT_REFL_COAT = 7;
+static const int DIELECTRIC_ETA_EXT = 0, DIELECTRIC_ETA_INT = 1;
+static const int EMISSION_COLOR = 0;
+static const int CONDUCTOR_COLOR = 0, CONDUCTOR_ROUGH_U = 0, CONDUCTOR_ROUGH_V = 1, CONDUCTOR_ETA = 2, CONDUCTOR_K = 3;
+static const int DIFFUSE_COLOR = 0, DIFFUSE_ROUGHNESS = 0;
+// include/clight.h:5-17
+static const uint LIGHT_GEOM_RECT = 1, LIGHT_GEOM_DISC = 2, LIGHT_GEOM_SPHERE = 3, LIGHT_GEOM_DIRECT = 4, LIGHT_GEOM_POINT = 5, LIGHT_GEOM_ENV = 6;
+static const uint LIGHT_DIST_LAMBERT = 0, LIGHT_DIST_OMNI = 1, LIGHT_DIST_SPOT = 2;
+static const uint LIGHT_FLAG_POINT_AREA = 1;
+// integrator_pt.h:330-332, 406-408
+static const uint INTEGRATOR_STUPID_PT = 0, INTEGRATOR_SHADOW_PT = 1, INTEGRATOR_MIS_PT = 2;
+static const uint FB_COLOR = 0, FB_DIRECT = 1, FB_INDIRECT = 2;
+
+static const float GEPSILON = 1e-5f, DEPSILON = 1e-20f;
+
+// ---- include/crandom.h ----------------------------------------------------------------------------------------
+struct RandomGen { uint sx, sy; };
+
+static inline uint NextState(RandomGen* g)                           // crandom.h:17-23
+{
+  const uint x = g->sx * 17u + g->sy * 13123u;
+  g->sx = (x << 13) ^ x;
+  g->sy ^= (x << 7);
+  return x;
+}
+static inline RandomGen RandomGenInit(int seed)                      // crandom.h:25-36 (int arithmetic wraps; done in uint here)
+{
+  const uint s = (uint)seed;
+  RandomGen g;
+  g.sx = (s * (s * s * 15731u + 74323u) + 871483u);
+  g.sy = (s * (s * s * 13734u + 37828u) + 234234u);
+  for (int i = 0; i < (seed % 7); i++) NextState(&g);
+  return g;
+}
+static inline f4 rndFloat4(RandomGen* g)                             // crandom.h:43-55
+{
+  const uint x = NextState(g);
+  const uint x1 = (x * (x * x * 15731u + 74323u) + 871483u);
+  const uint y1 = (x * (x * x * 13734u + 37828u) + 234234u);
+  const uint z1 = (x * (x * x * 11687u + 26461u) + 137589u);
+  const uint w1 = (x * (x * x * 15707u + 789221u) + 1376312589u);
+  const float scale = (1.0f / 4294967296.0f);
+  return mk4((float)x1, (float)y1, (float)z1, (float)w1) * scale;
+}
+static inline float rndFloat1(RandomGen* g)                          // crandom.h:69-75
+{
+  const uint x = NextState(g);
+  const uint tmp = (x * (x * x * 15731u + 74323u) + 871483u);
+  return ((float)tmp) * (1.0f / 4294967296.0f);
+}
+
+// ---- include/cglobals.h helpers -------------------------------------------------------------------------------
+struct MisData { float matSamplePdf, cosTheta, ior, dummy; };       // cglobals.h:292-311
+static inline MisData makeInitialMisData() { MisData d = {1.0f, 1.0f, 1.0f, 0.0f}; return d; }
+
+static inline f3 EyeRayDirNormalized(float x, float y, const m4& projInv)   // cglobals.h:49-55
+{
+  f4 pos = mk4(2.0f * x - 1.0f, 2.0f * y - 1.0f, 0.0f, 1.0f);
+  pos = mul(projInv, pos);
+  pos = pos / pos.w;
+  return normalize(xyz(pos));
+}
+
+static inline void CoordinateSystemV2(f3 n, f3* s, f3* t)            // cglobals.h:120-132
+{
+  const float sign = n.z >= 0 ? 1.0f : -1.0f;
+  const float a = -(1.0f / (sign + n.z));
+  const float b = n.x * n.y * a;
+  const float tmp = (n.z >= 0 ? n.x * n.x * a : -n.x * n.x * a);
+  *s = mk3(tmp + 1.0f, n.z >= 0 ? b : -b, n.z >= 0 ? -n.x : n.x);
+  *t = mk3(b, n.y * n.y * a + sign, -n.y);
+}
+
+static inline f3 MapSampleToCosineDistribution(float r1, float r2, f3 direction, f3 hit_norm, float power)   // cglobals.h:143-181
+{
+  if (power >= 1e6f) return direction;
+  const float sin_phi = std::sin(kTWOPI * r1);
+  const float cos_phi = std::cos(kTWOPI * r1);
+  const float cos_theta = std::pow(1.0f - r2, 1.0f / (power + 1.0f));
+  const float sin_theta = std::sqrt(1.0f - cos_theta * cos_theta);
+  const f3 deviation = mk3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
+  f3 ny = direction, nx, nz;
+  CoordinateSystemV2(ny, &nx, &nz);
+  { const f3 temp = ny; ny = nz; nz = temp; }
+  f3 res = nx * deviation.x + ny * deviation.y + nz * deviation.z;
+  const float invSign = dot(direction, hit_norm) > 0.0f ? 1.0f : -1.0f;
+  if (invSign * dot(res, hit_norm) < 0.0f)
+    res = (-1.0f) * nx * deviation.x + ny * deviation.y - nz * deviation.z;
+  return res;
+}
+
+static inline f2 MapSamplesToDisc(f2 xy)                             // cglobals.h:188-231
+{
+  const float x = xy.x, y = xy.y;
+  float r = 0, phi = 0;
+  if (x > y && x > -y)  { r = x;  phi = 0.25f * 3.141592654f * (y / x); }
+  if (x < y && x > -y)  { r = y;  phi = 0.25f * 3.141592654f * (2.0f - x / y); }
+  if (x < y && x < -y)  { r = -x; phi = 0.25f * 3.141592654f * (4.0f + y / x); }
+  if (x > y && x < -y)  { r = -y; phi = 0.25f * 3.141592654f * (6 - x / y); }
+  const float sin_phi = std::sin(phi), cos_phi = std::cos(phi);
+  return mk2(r * sin_phi, r * cos_phi);
+}
+
+static inline float epsilonOfPos(f3 p)                               // cglobals.h:233
+{
+  return std::max(std::max(std::abs(p.x), std::max(std::abs(p.y), std::abs(p.z))), 2.0f * GEPSILON) * GEPSILON;
+}
+static inline f3 OffsRayPos(f3 hitPos, f3 surfaceNorm, f3 sampleDir)  // cglobals.h:242-247
+{
+  const float signOfNormal2 = dot(sampleDir, surfaceNorm) < 0.0f ? -1.0f : 1.0f;
+  const float offsetEps = epsilonOfPos(hitPos);
+  return hitPos + signOfNormal2 * offsetEps * surfaceNorm;
+}
+static inline void transform_ray3f(const m4& worldViewInv, f3* ray_pos, f3* ray_dir)   // cglobals.h:254-263
+{
+  const f3 pos = mul4x3(worldViewInv, *ray_pos);
+  const f3 pos2 = mul4x3(worldViewInv, (*ray_pos) + 100.0f * (*ray_dir));
+  const f3 diff = pos2 - pos;
+  *ray_pos = pos;
+  *ray_dir = normalize(diff);
+}
+static inline float PdfAtoW(float aPdfA, float aDist, float aCosThere) { return (aPdfA * aDist * aDist) / std::max(aCosThere, 1e-30f); }  // cglobals.h:265-268
+static inline float maxcomp(f3 v) { return std::max(v.x, std::max(v.y, v.z)); }                                                       // cglobals.h:275
+static inline float misHeuristicPower1(float p) { return std::isfinite(p) ? std::abs(p) : 0.0f; }                                   // cglobals.h:277
+static inline float misWeightHeuristic(float a, float b)                                                                              // cglobals.h:278-282
+{
+  const float w = misHeuristicPower1(a) / std::max(misHeuristicPower1(a) + misHeuristicPower1(b), 1e-30f);
+  return std::isfinite(w) ? w : 0.0f;
+}
+static inline f2 mulRows2x4(f4 row0, f4 row1, f2 v)                  // cglobals.h:315-321
+{
+  return mk2(row0.x * v.x + row0.y * v.y + row0.w, row1.x * v.x + row1.y * v.y + row1.w);
+}
+static inline f2 sphereMapTo2DTexCoord(f3 ray_dir, float* pSinTheta) // cglobals.h:335-362
+{
+  const float x = ray_dir.z, y = ray_dir.x, z = -ray_dir.y;
+  float theta = std::acos(z);
+  float phi = std::atan2(y, x);
+  if (phi < 0.0f) phi += 2.0f * kPI;
+  const float texX = clampf(phi * 0.5f * kINV_PI, 0.0f, 1.0f);
+  const float texY = clampf(theta * kINV_PI, 0.0f, 1.0f);
+  *pSinTheta = std::sqrt(1.0f - ray_dir.y * ray_dir.y);
+  return mk2(texX, texY);
+}
+
+// ---- include/cmaterial.h --------------------------------------------------------------------------------------
+struct BsdfSample { f4 val; f3 dir; float pdf; uint flags; float ior; };   // cmaterial.h:9-16
+struct BsdfEval { f4 val; float pdf; };                                    // cmaterial.h:18-22
+
+static inline float safe_sqrt(float v) { return std::sqrt(std::max(v, 0.0f)); }                      // :206-209
+static inline f3 lambertSample(f2 rands, f3 v, f3 n) { return MapSampleToCosineDistribution(rands.x, rands.y, n, n, 1.0f); }  // :215-218
+static inline float lambertEvalPDF(f3 l, f3 v, f3 n) { return std::abs(dot(l, n)) * kINV_PI; }        // :220-223
+static inline float lambertEvalBSDF(f3 l, f3 v, f3 n) { return kINV_PI; }                             // :225-228
+
+static inline float cosPhiPBRT(f3 w, float sintheta) { return sintheta == 0.0f ? 1.0f : clampf(w.x / sintheta, -1.0f, 1.0f); }   // :234-240
+static inline float sinPhiPBRT(f3 w, float sintheta) { return sintheta == 0.0f ? 0.0f : clampf(w.y / sintheta, -1.0f, 1.0f); }   // :242-248
+
+static inline float orennayarFunc(f3 a_l, f3 a_v, f3 a_n, float a_roughness)    // :254-306
+{
+  const float cosTheta_wi = dot(a_l, a_n), cosTheta_wo = dot(a_v, a_n);
+  const float sinTheta_wi = safe_sqrt(1.0f - cosTheta_wi * cosTheta_wi);
+  const float sinTheta_wo = safe_sqrt(1.0f - cosTheta_wo * cosTheta_wo);
+  const float sigma = a_roughness * kPI * 0.5f;
+  const float sigma2 = sigma * sigma;
+  const float A = 1.0f - (sigma2 / (2.0f * (sigma2 + 0.33f)));
+  const float B = 0.45f * sigma2 / (sigma2 + 0.09f);
+  f3 nx, ny, nz = a_n;
+  CoordinateSystemV2(nz, &nx, &ny);
+  float maxcos = 0.0f;
+  if (sinTheta_wi > 1e-4f && sinTheta_wo > 1e-4f) {
+    const f3 wo = mk3(-dot(a_v, nx), -dot(a_v, ny), -dot(a_v, nz));
+    const f3 wi = mk3(-dot(a_l, nx), -dot(a_l, ny), -dot(a_l, nz));
+    const float sinphii = sinPhiPBRT(wi, sinTheta_wi), cosphii = cosPhiPBRT(wi, sinTheta_wi);
+    const float sinphio = sinPhiPBRT(wo, sinTheta_wo), cosphio = cosPhiPBRT(wo, sinTheta_wo);
+    const float dcos = cosphii * cosphio + sinphii * sinphio;
+    maxcos = std::max(0.0f, dcos);
+  }
+  float sinalpha = 0.0f, tanbeta = 0.0f;
+  if (std::abs(cosTheta_wi) > std::abs(cosTheta_wo)) { sinalpha = sinTheta_wo; tanbeta = sinTheta_wi / std::max(std::abs(cosTheta_wi), DEPSILON); }
+  else                                               { sinalpha = sinTheta_wi; tanbeta = sinTheta_wo / std::max(std::abs(cosTheta_wo), DEPSILON); }
+  return (A + B * maxcos * sinalpha * tanbeta);
+}
+
+static inline float GGX_Distribution(float cosThetaNH, float alpha)  // :322-328
+{
+  const float alpha2 = alpha * alpha;
+  const float NH_sqr = clampf(cosThetaNH * cosThetaNH, 0.0f, 1.0f);
+  const float den = NH_sqr * alpha2 + (1.0f - NH_sqr);
+  return alpha2 / std::max((float)(kPI) * den * den, 1e-6f);
+}
+static inline float GGX_GeomShadMask(float cosThetaN, float alpha)   // :330-343
+{
+  const float cosTheta_sqr = clampf(cosThetaN * cosThetaN, 0.0f, 1.0f);
+  const float tan2 = (1.0f - cosTheta_sqr) / std::max(cosTheta_sqr, 1e-6f);
+  return 2.0f / (1.0f + safe_sqrt(1.0f + alpha * alpha * tan2));
+}
+static inline f3 ggxSample(f2 rands, f3 v, f3 n, float roughness)    // :347-362
+{
+  const float roughSqr = roughness * roughness;
+  f3 nx, ny, nz = n;
+  CoordinateSystemV2(nz, &nx, &ny);
+  const f3 wo = mk3(dot(v, nx), dot(v, ny), dot(v, nz));
+  const float phi = rands.x * kTWOPI;
+  const float cosTheta = clampf(safe_sqrt((1.0f - rands.y) / (1.0f + roughSqr * roughSqr * rands.y - rands.y)), 0.0f, 1.0f);
+  const float sinTheta = safe_sqrt(1.0f - cosTheta * cosTheta);
+  const f3 wh = mk3(sinTheta * std::cos(phi), sinTheta * std::sin(phi), cosTheta);
+  const f3 wi = 2.0f * dot(wo, wh) * wh - wo;
+  return normalize(wi.x * nx + wi.y * ny + wi.z * nz);
+}
+static inline float ggxEvalPDF(f3 l, f3 v, f3 n, float roughness)    // :364-378
+{
+  const float dotNV = dot(n, v), dotNL = dot(n, l);
+  if (dotNV < 1e-6f || dotNL < 1e-6f) return 1.0f;
+  const float roughSqr = roughness * roughness;
+  const f3 h = normalize(v + l);
+  const float dotNH = dot(n, h), dotHV = dot(h, v);
+  const float D = GGX_Distribution(dotNH, roughSqr);
+  return D * dotNH / (4.0f * std::max(dotHV, 1e-6f));
+}
+static inline float ggxEvalBSDF(f3 l, f3 v, f3 n, float roughness)   // :380-397
+{
+  if (std::abs(dot(l, n)) < 1e-5f) return 0.0f;
+  const float dotNV = dot(n, v), dotNL = dot(n, l);
+  if (dotNV < 1e-6f || dotNL < 1e-6f) return 0.0f;
+  const float roughSqr = roughness * roughness;
+  const f3 h = normalize(v + l);
+  const float dotNH = dot(n, h);
+  const float D = GGX_Distribution(dotNH, roughSqr);
+  const float G = GGX_GeomShadMask(dotNV, roughSqr) * GGX_GeomShadMask(dotNL, roughSqr);
+  return (D * G / std::max(4.0f * dotNV * dotNL, 1e-6f));
+}
+
+// Trowbridge-Reitz (cmaterial.h:405-530)
+static inline float Cos2Theta(f3 w) { return w.z * w.z; }
+static inline float AbsCosTheta(f3 w) { return std::abs(w.z); }
+static inline float Sin2Theta(f3 w) { return std::max(0.0f, 1.0f - Cos2Theta(w)); }
+static inline float SinTheta(f3 w) { return safe_sqrt(Sin2Theta(w)); }
+static inline float Tan2Theta(f3 w) { return Sin2Theta(w) / Cos2Theta(w); }
+static inline float CosPhi(f3 w) { const float s = SinTheta(w); return (s == 0) ? 1 : clampf(w.x / s, -1.0f, 1.0f); }
+static inline float SinPhi(f3 w) { const float s = SinTheta(w); return (s == 0) ? 0 : clampf(w.y / s, -1.0f, 1.0f); }
+static inline f3 FaceForward(f3 v, f3 n2) { return (dot(v, n2) < 0.f) ? (-1.0f) * v : v; }
+static inline f2 SampleUniformDiskPolar(f2 u) { const float r = safe_sqrt(u.x); const float th = kTWOPI * u.y; return mk2(r * std::cos(th), r * std::sin(th)); }
+static inline float trD(f3 wm, f2 alpha)                             // :460-470
+{
+  const float tan2Theta = Tan2Theta(wm);
+  if (std::isinf(tan2Theta)) return 0;
+  const float cos4Theta = Cos2Theta(wm) * Cos2Theta(wm);
+  if (cos4Theta < 1e-16f) return 0;
+  const float e = tan2Theta * ((CosPhi(wm) / alpha.x) * (CosPhi(wm) / alpha.x) + (SinPhi(wm) / alpha.y) * (SinPhi(wm) / alpha.y));
+  return 1.0f / (kPI * alpha.x * alpha.y * cos4Theta * (1 + e) * (1 + e));
+}
+static inline bool trEffectivelySmooth(f2 alpha) { return std::max(alpha.x, alpha.y) < 1e-3f; }     // :472-475
+static inline float trLambda(f3 w, f2 alpha)                         // :477-484
+{
+  const float tan2Theta = Tan2Theta(w);
+  if (std::isinf(tan2Theta)) return 0;
+  const float alpha2 = (CosPhi(w) * alpha.x) * (CosPhi(w) * alpha.x) + (SinPhi(w) * alpha.y) * (SinPhi(w) * alpha.y);
+  return (safe_sqrt(1.0f + alpha2 * tan2Theta) - 1.0f) / 2.0f;
+}
+static inline float trG1(f3 w, f2 alpha) { return 1.0f / (1.0f + trLambda(w, alpha)); }
+static inline float trG(f3 wo, f3 wi, f2 alpha) { return 1.0f / (1.0f + trLambda(wo, alpha) + trLambda(wi, alpha)); }
+static inline float trD2(f3 w, f3 wm, f2 alpha) { return trG1(w, alpha) / AbsCosTheta(w) * trD(wm, alpha) * std::abs(dot(w, wm)); }   // :496-499
+static inline float trPDF(f3 w, f3 wm, f2 alpha) { return trD2(w, wm, alpha); }
+static inline f3 trSample(f3 wo, f2 rands, f2 alpha)                 // :506-530
+{
+  f3 wh = normalize(mk3(alpha.x * wo.x, alpha.y * wo.y, wo.z));
+  if (wh.z < 0) wh = (-1.0f) * wh;
+  const f3 T1 = (wh.z < 0.99999f) ? normalize(cross(mk3(0, 0, 1), wh)) : mk3(1, 0, 0);
+  const f3 T2 = cross(wh, T1);
+  f2 p = SampleUniformDiskPolar(rands);
+  const float h = safe_sqrt(1 - p.x * p.x);
+  p.y = lerpf(h, p.y, (1 + wh.z) / 2);
+  const float pz = safe_sqrt(1.0f - dot2(p, p));
+  const f3 nh = p.x * T1 + p.y * T2 + pz * wh;
+  return normalize(mk3(alpha.x * nh.x, alpha.y * nh.y, std::max(1e-6f, nh.z)));
+}
+
+static inline float FrDielectricPBRT(float cosThetaI, float etaI, float etaT)   // :536-561
+{
+  cosThetaI = clampf(cosThetaI, -1.0f, 1.0f);
+  const bool entering = cosThetaI > 0.0f;
+  if (!entering) { const float tmp = etaI; etaI = etaT; etaT = tmp; cosThetaI = std::abs(cosThetaI); }
+  const float sinThetaI = safe_sqrt(1.0f - cosThetaI * cosThetaI);
+  const float sinThetaT = etaI / etaT * sinThetaI;
+  if (sinThetaT >= 1.0f) return 1.0f;
+  const float cosThetaT = safe_sqrt(1.0f - sinThetaT * sinThetaT);
+  const float Rparl = ((etaT * cosThetaI) - (etaI * cosThetaT)) / ((etaT * cosThetaI) + (etaI * cosThetaT));
+  const float Rperp = ((etaI * cosThetaI) - (etaT * cosThetaT)) / ((etaI * cosThetaI) + (etaT * cosThetaT));
+  return 0.5f * (Rparl * Rparl + Rperp * Rperp);
+}
+static inline f4 FrDielectricDetailedV2(float cos_theta_i, float eta)          // :646-683
+{
+  cos_theta_i = clampf(cos_theta_i, -1.0f, 1.0f);
+  float eta_it = eta, eta_ti = 1.f / eta;
+  if (cos_theta_i < 0.0f) { eta_it = eta_ti; eta_ti = eta; }
+  const float cos_theta_t_sqr = -1.f * (-1.f * cos_theta_i * cos_theta_i + 1.f) * eta_ti * eta_ti + 1.f;
+  const float cos_theta_i_abs = std::abs(cos_theta_i);
+  const float cos_theta_t_abs = safe_sqrt(cos_theta_t_sqr);
+  float r = 0.0f;
+  if ((eta == 1.f) || (cos_theta_i_abs == 0.f)) r = (eta == 1.f) ? 0.f : 1.f;
+  else {
+    const float a_s = (-1.f * eta_it * cos_theta_t_abs + cos_theta_i_abs) / (eta_it * cos_theta_t_abs + cos_theta_i_abs);
+    const float a_p = (-1.f * eta_it * cos_theta_i_abs + cos_theta_t_abs) / (eta_it * cos_theta_i_abs + cos_theta_t_abs);
+    r = 0.5f * (a_s * a_s + a_p * a_p);
+  }
+  const float cos_theta_t = cos_theta_i >= 0 ? -cos_theta_t_abs : cos_theta_t_abs;
+  return mk4(r, cos_theta_t, eta_it, eta_ti);
+}
+static inline float FrComplexConductor(float cosThetaI, cplx eta)    // :685-694
+{
+  const float sinThetaI = 1.0f - cosThetaI * cosThetaI;
+  const cplx sinThetaT = rdiv(sinThetaI, eta * eta);
+  const cplx cosThetaT = csqrt_(rsub(1.0f, sinThetaT));
+  const cplx r_parl = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+  const cplx r_perp = rsub(cosThetaI, eta * cosThetaT) / radd(cosThetaI, eta * cosThetaT);
+  return (cnorm(r_parl) + cnorm(r_perp)) / 2.0f;
+}
+static inline float fresnelSlick(float VdotH) { const float tmp = 1.0f - std::abs(VdotH); return (tmp * tmp) * (tmp * tmp) * tmp; }   // :705-709
+static inline f4 hydraFresnelCond(f4 f0, float VdotH, float ior, float roughness)   // :711-717
+{
+  if (ior == 0.0f) return f0;
+  return f0 + (splat4(1.0f) - f0) * fresnelSlick(VdotH);
+}
+static inline f3 refract_(f3 wi, float cos_theta_t, float eta_ti) { return mk3(-eta_ti * wi.x, -eta_ti * wi.y, cos_theta_t); }   // :917-920
+
+// ---- include/cmat_gltf.h --------------------------------------------------------------------------------------
+// The base colour is generic (`C`) so that the DR replay can push a dual number through the very same code.
+template <class C>
+struct BsdfSampleT { C val; f3 dir; float pdf; uint flags; float ior; };
+template <class C>
+struct BsdfEvalT { C val; float pdf; };
+
+template <class C>
+static inline void gltfSampleAndEval(const Material& m, f4 rands, f3 v, f3 n, f2 tc, C baseColor, f4 fourParams, BsdfSampleT<C>* pRes)   // cmat_gltf.h:6-90
+{
+  const uint cflags = m.cflags;
+  const C metalCol = baseColor * m.colors[GLTF_COLOR_METAL];
+  const f4 coatCol = m.colors[GLTF_COLOR_COAT];
+  const float roughness = clampf(1.0f - m.data[GLTF_FLOAT_GLOSINESS] * fourParams.x, 0.0f, 1.0f);
+  float metalness = m.data[GLTF_FLOAT_ALPHA] * fourParams.y;
+  const float coatValue = m.data[GLTF_FLOAT_REFL_COAT] * fourParams.z;
+  const float fresnelIOR = m.data[GLTF_FLOAT_IOR];
+  if (cflags == GLTF_COMPONENT_METAL) metalness = 1.0f;
+
+  f3 ggxDir; float ggxPdf, ggxVal;
+  if (roughness == 0.0f) {
+    const f3 pefReflDir = reflect((-1.0f) * v, n);
+    const float cosThetaOut = dot(pefReflDir, n);
+    ggxDir = pefReflDir;
+    ggxVal = (cosThetaOut <= 1e-6f) ? 0.0f : (1.0f / std::max(cosThetaOut, 1e-6f));
+    ggxPdf = 1.0f;
+  } else {
+    ggxDir = ggxSample(mk2(rands.x, rands.y), v, n, roughness);
+    ggxPdf = ggxEvalPDF(ggxDir, v, n, roughness);
+    ggxVal = ggxEvalBSDF(ggxDir, v, n, roughness);
+  }
+  const f3 lambertDir = lambertSample(mk2(rands.x, rands.y), v, n);
+  const float lambertPdf = lambertEvalPDF(lambertDir, v, n);
+  const float lambertVal = lambertEvalBSDF(lambertDir, v, n);
+
+  float pdfSelect = 1.0f;
+  if (rands.z < metalness) {
+    pdfSelect *= metalness;
+    const float VdotH = dot(v, normalize(v + ggxDir));
+    pRes->dir = ggxDir;
+    // hydraFresnelCond (cmaterial.h:711-717) on a generic colour
+    C fr = metalCol;
+    if (fresnelIOR != 0.0f) fr = metalCol + (C(splat4(1.0f)) - metalCol) * fresnelSlick(VdotH);
+    pRes->val = fr * (ggxVal * metalness);
+    pRes->pdf = ggxPdf;
+    pRes->flags = (roughness == 0.0f) ? RAY_EVENT_S : RAY_FLAG_HAS_NON_SPEC;
+  } else {
+    pdfSelect *= 1.0f - metalness;
+    const float f_i = FrDielectricPBRT(std::abs(dot(v, n)), 1.0f, fresnelIOR);
+    const float prob_specular = 0.5f * coatValue;
+    const float prob_diffuse = 1.0f - prob_specular;
+    if (rands.w < prob_specular) {
+      pdfSelect *= prob_specular;
+      pRes->dir = ggxDir;
+      pRes->val = C(ggxVal * coatCol * (1.0f - metalness) * f_i * coatValue);
+      pRes->pdf = ggxPdf;
+      pRes->flags = (roughness == 0.0f) ? RAY_EVENT_S : RAY_FLAG_HAS_NON_SPEC;
+    } else {
+      pdfSelect *= prob_diffuse;
+      pRes->dir = lambertDir;
+      pRes->val = baseColor * lambertVal * (1.0f - metalness);
+      pRes->pdf = lambertPdf;
+      pRes->flags = RAY_FLAG_HAS_NON_SPEC;
+      if (coatValue > 0.0f && fresnelIOR > 0.0f) {
+        const float m_fdr_int = m.data[GLTF_FLOAT_MI_FDR_INT];
+        const float f_o = FrDielectricPBRT(std::abs(dot(lambertDir, n)), 1.0f, fresnelIOR);
+        pRes->val = pRes->val * lerpf(1.0f, (1.0f - f_i) * (1.0f - f_o) / (fresnelIOR * fresnelIOR * (1.0f - m_fdr_int)), coatValue);
+      }
+    }
+  }
+  pRes->pdf *= pdfSelect;
+}
+
+template <class C>
+static inline void gltfEval(const Material& m, f3 l, f3 v, f3 n, f2 tc, C baseColor, f4 fourParams, BsdfEvalT<C>* res)    // cmat_gltf.h:93-147
+{
+  const uint cflags = m.cflags;
+  const C metalCol = baseColor * m.colors[GLTF_COLOR_METAL];
+  const f4 coatCol = m.colors[GLTF_COLOR_COAT];
+  const float roughness = clampf(1.0f - m.data[GLTF_FLOAT_GLOSINESS] * fourParams.x, 0.0f, 1.0f);
+  float metalness = m.data[GLTF_FLOAT_ALPHA] * fourParams.y;
+  const float coatValue = m.data[GLTF_FLOAT_REFL_COAT] * fourParams.z;
+  const float fresnelIOR = m.data[GLTF_FLOAT_IOR];
+  if (cflags == GLTF_COMPONENT_METAL) metalness = 1.0f;
+
+  float ggxVal, ggxPdf, VdotH;
+  if (roughness != 0.0f) {
+    ggxVal = ggxEvalBSDF(l, v, n, roughness);
+    ggxPdf = ggxEvalPDF(l, v, n, roughness);
+    VdotH = dot(v, normalize(v + l));
+  } else { ggxVal = 0.0f; ggxPdf = 0.0f; VdotH = dot(v, n); }
+
+  float lambertVal = lambertEvalBSDF(l, v, n);
+  const float lambertPdf = lambertEvalPDF(l, v, n);
+  float f_i = 1.0f;
+  if (coatValue > 0.0f && metalness < 1.0f && fresnelIOR > 0.0f) {
+    f_i = FrDielectricPBRT(std::abs(dot(v, n)), 1.0f, fresnelIOR);
+    const float f_o = FrDielectricPBRT(std::abs(dot(l, n)), 1.0f, fresnelIOR);
+    const float m_fdr_int = m.data[GLTF_FLOAT_MI_FDR_INT];
+    const float coeff = lerpf(1.0f, (1.f - f_i) * (1.f - f_o) / (fresnelIOR * fresnelIOR * (1.f - m_fdr_int)), coatValue);
+    lambertVal *= coeff;
+  }
+  C fConductor = metalCol;
+  if (fresnelIOR != 0.0f) fConductor = metalCol + (C(splat4(1.0f)) - metalCol) * fresnelSlick(VdotH);
+  const C specularColor = fConductor * ggxVal;
+  const float prob_specular = 0.5f * coatValue;
+  const float prob_diffuse = 1.0f - prob_specular;
+  const C dielectricVal = baseColor * lambertVal + C(ggxVal * coatCol * f_i * coatValue);
+  const float dielectricPdf = lambertPdf * prob_diffuse + ggxPdf * prob_specular;
+  res->val = specularColor * metalness + dielectricVal * (1.0f - metalness);
+  res->pdf = metalness * ggxPdf + (1.0f - metalness) * dielectricPdf;
+}
+
+// ---- include/cmat_diffuse.h -----------------------------------------------------------------------------------
+static inline void diffuseSampleAndEval(const Material& m, f4 reflSpec, f4 rands, f3 v, f3 n, f2 tc, BsdfSample* pRes)   // :8-24
+{
+  const f3 lambertDir = lambertSample(mk2(rands.x, rands.y), v, n);
+  const float lambertPdf = lambertEvalPDF(lambertDir, v, n);
+  const float lambertVal = lambertEvalBSDF(lambertDir, v, n);
+  pRes->dir = lambertDir;
+  pRes->val = lambertVal * reflSpec;
+  pRes->pdf = lambertPdf;
+  pRes->flags = RAY_FLAG_HAS_NON_SPEC;
+  if ((m.cflags & GLTF_COMPONENT_ORENNAYAR) != 0)
+    pRes->val = pRes->val * orennayarFunc(lambertDir, (-1.0f) * v, n, m.data[DIFFUSE_ROUGHNESS]);
+}
+static inline void diffuseEval(const Material& m, f4 reflSpec, f3 l, f3 v, f3 n, f2 tc, BsdfEval* res)   // :27-39
+{
+  float lambertVal = lambertEvalBSDF(l, v, n);
+  const float lambertPdf = lambertEvalPDF(l, v, n);
+  if ((m.cflags & GLTF_COMPONENT_ORENNAYAR) != 0)
+    lambertVal *= orennayarFunc(l, v, n, m.data[DIFFUSE_ROUGHNESS]);
+  res->val = lambertVal * reflSpec;
+  res->pdf = lambertPdf;
+}
+
+// ---- include/cmat_conductor.h ---------------------------------------------------------------------------------
+static inline void conductorSmoothSampleAndEval(const Material& m, f4 etaSpec, f4 kSpec, f4 rands, f3 v, f3 n, f2 tc, BsdfSample* pRes)   // :7-28
+{
+  const f4 rgb_reflectance = m.colors[CONDUCTOR_COLOR];
+  const f3 pefReflDir = reflect((-1.0f) * v, n);
+  const float cosThetaOut = dot(pefReflDir, n);
+  float val[4];
+  const float eta[4] = { etaSpec.x, etaSpec.y, etaSpec.z, etaSpec.w }, kk[4] = { kSpec.x, kSpec.y, kSpec.z, kSpec.w };
+  for (int i = 0; i < 4; ++i) {
+    val[i] = FrComplexConductor(cosThetaOut, cmk(eta[i], kk[i]));
+    val[i] = (cosThetaOut <= 1e-6f) ? 0.0f : (val[i] / std::max(cosThetaOut, 1e-6f));
+  }
+  pRes->val = mk4(val[0], val[1], val[2], val[3]) * rgb_reflectance;
+  pRes->dir = pefReflDir;
+  pRes->pdf = 1.0f;
+  pRes->flags = RAY_EVENT_S;
+}
+static inline float conductorRoughEvalInternal(f3 wo, f3 wi, f3 wm, f2 alpha, cplx ior)   // :42-58
+{
+  if (wo.z * wi.z < 0) return 0.0f;
+  const float cosTheta_o = AbsCosTheta(wo), cosTheta_i = AbsCosTheta(wi);
+  if (cosTheta_i == 0 || cosTheta_o == 0) return 0.0f;
+  const float F = FrComplexConductor(std::abs(dot(wo, wm)), ior);
+  return trD(wm, alpha) * F * trG(wo, wi, alpha) / (4.0f * cosTheta_i * cosTheta_o);
+}
+static inline void conductorRoughSampleAndEval(const Material& m, f4 etaSpec, f4 kSpec, f4 rands, f3 v, f3 n, f2 tc, f3 alpha_tex, BsdfSample* pRes)   // :61-100
+{
+  if (v.z == 0) return;
+  const f4 rgb_reflectance = m.colors[CONDUCTOR_COLOR];
+  const f2 alpha = mk2(std::min(m.data[CONDUCTOR_ROUGH_U], alpha_tex.x), std::min(m.data[CONDUCTOR_ROUGH_V], alpha_tex.y));
+  f3 nx, ny, nz = n;
+  CoordinateSystemV2(nz, &nx, &ny);
+  const f3 wo = mk3(dot(v, nx), dot(v, ny), dot(v, nz));
+  if (wo.z == 0) return;
+  const f3 wm = trSample(wo, mk2(rands.x, rands.y), alpha);
+  const f3 wi = reflect((-1.0f) * wo, wm);
+  if (wo.z * wi.z < 0) return;
+  const float eta[4] = { etaSpec.x, etaSpec.y, etaSpec.z, etaSpec.w }, kk[4] = { kSpec.x, kSpec.y, kSpec.z, kSpec.w };
+  float val[4];
+  for (int i = 0; i < 4; ++i) val[i] = conductorRoughEvalInternal(wo, wi, wm, alpha, cmk(eta[i], kk[i]));
+  pRes->val = mk4(val[0], val[1], val[2], val[3]) * rgb_reflectance;
+  pRes->dir = normalize(wi.x * nx + wi.y * ny + wi.z * nz);
+  pRes->pdf = trPDF(wo, wm, alpha) / (4.0f * std::abs(dot(wo, wm)));
+  pRes->flags = RAY_FLAG_HAS_NON_SPEC;
+}
+static inline void conductorRoughEval(const Material& m, f4 etaSpec, f4 kSpec, f3 l, f3 v, f3 n, f2 tc, f3 alpha_tex, BsdfEval* pRes)   // :103-137
+{
+  const f2 alpha = mk2(std::min(m.data[CONDUCTOR_ROUGH_U], alpha_tex.x), std::min(m.data[CONDUCTOR_ROUGH_V], alpha_tex.y));
+  const f4 rgb_reflectance = m.colors[CONDUCTOR_COLOR];
+  f3 nx, ny, nz = n;
+  CoordinateSystemV2(nz, &nx, &ny);
+  const f3 wo = mk3(dot(v, nx), dot(v, ny), dot(v, nz));
+  const f3 wi = mk3(dot(l, nx), dot(l, ny), dot(l, nz));
+  if (wo.z * wi.z < 0.0f) return;
+  f3 wm = wo + wi;
+  if (dot(wm, wm) == 0) return;
+  wm = normalize(wm);
+  const float eta[4] = { etaSpec.x, etaSpec.y, etaSpec.z, etaSpec.w }, kk[4] = { kSpec.x, kSpec.y, kSpec.z, kSpec.w };
+  float val[4];
+  for (int i = 0; i < 4; ++i) val[i] = conductorRoughEvalInternal(wo, wi, wm, alpha, cmk(eta[i], kk[i]));
+  pRes->val = mk4(val[0], val[1], val[2], val[3]) * rgb_reflectance;
+  wm = FaceForward(wm, mk3(0.0f, 0.0f, 1.0f));
+  pRes->pdf = trPDF(wo, wm, alpha) / (4.0f * std::abs(dot(wo, wm)));
+}
+
+// ---- include/cmat_dielectric.h --------------------------------------------------------------------------------
+static inline void dielectricSmoothSampleAndEval(const Material& m, f4 etaSpec, float _extIOR, f4 rands, f3 v, f3 n, f2 tc, BsdfSample* pRes)   // :8-56
+{
+  const float extIOR = m.data[DIELECTRIC_ETA_EXT];
+  if ((pRes->flags & RAY_FLAG_HAS_INV_NORMAL) != 0) n = (-1.0f) * n;
+  f3 s, t = n;
+  CoordinateSystemV2(n, &s, &t);
+  const f3 wi = mk3(dot(v, s), dot(v, t), dot(v, n));
+  const float eta = etaSpec.x / extIOR;
+  const f4 fr = FrDielectricDetailedV2(wi.z, eta);
+  const float R = fr.x, cos_theta_t = fr.y, eta_ti = fr.w;
+  const float T = 1 - R;
+  if (rands.x < R) {
+    const f3 wo = mk3(-wi.x, -wi.y, wi.z);
+    pRes->val = splat4(R);
+    pRes->pdf = R;
+    pRes->dir = normalize(wo.x * s + wo.y * t + wo.z * n);
+    pRes->flags |= RAY_EVENT_S;
+    pRes->ior = _extIOR;
+  } else {
+    const f3 wo = refract_(wi, cos_theta_t, eta_ti);
+    pRes->val = splat4((eta_ti * eta_ti) * T);
+    pRes->pdf = T;
+    pRes->dir = normalize(wo.x * s + wo.y * t + wo.z * n);
+    pRes->flags |= (RAY_EVENT_S | RAY_EVENT_T);
+    pRes->ior = (_extIOR == etaSpec.x) ? extIOR : etaSpec.x;
+  }
+  pRes->val = pRes->val / std::max(std::abs(dot(pRes->dir, n)), 1e-6f);
+}
+
+// ---- include/clight.h -----------------------------------------------------------------------------------------
+struct LightSample { f3 pos, norm; float pdf; bool isOmni, hasIES; };   // :58-65
+
+static inline LightSample areaLightSampleRev(const LightSource& L, f2 rands)   // :67-84
+{
+  f2 sampleOff = 2.0f * (mk2(-0.5f, -0.5f) + rands) * L.size;
+  if (L.geomType == LIGHT_GEOM_DISC) {
+    const float offsetX = rands.x * 2.0f - 1.0f, offsetY = rands.y * 2.0f - 1.0f;
+    sampleOff = MapSamplesToDisc(mk2(offsetX, offsetY)) * L.size.x;
+  }
+  const f3 samplePos = mul3x3(L.matrix, mk3(sampleOff.x, 0.0f, sampleOff.y)) + xyz(L.pos) + epsilonOfPos(xyz(L.pos)) * xyz(L.norm);
+  LightSample r;
+  r.pos = samplePos; r.norm = xyz(L.norm); r.isOmni = false; r.hasIES = (L.iesId != uint(-1)); r.pdf = 1.0f;
+  return r;
+}
+static inline LightSample sphereLightSampleRev(const LightSource& L, f2 rands)   // :86-103
+{
+  const float theta = 2.0f * kPI * rands.x;
+  const float phi = std::acos(1.0f - 2.0f * rands.y);
+  const float x = std::sin(phi) * std::cos(theta), y = std::sin(phi) * std::sin(theta), z = std::cos(phi);
+  const f3 lcenter = xyz(L.pos);
+  const float lradius = L.size.x;
+  const f3 samplePos = lcenter + (lradius * 1.000001f) * mk3(x, y, z);
+  LightSample r;
+  r.pos = samplePos; r.norm = normalize(samplePos - lcenter); r.isOmni = false; r.hasIES = (L.iesId != uint(-1)); r.pdf = 1.0f;
+  return r;
+}
+static inline LightSample directLightSampleRev(const LightSource& L, f2 rands, f3 illuminationPoint)   // :105-115
+{
+  const f3 norm = xyz(L.norm);
+  LightSample r;
+  r.pos = illuminationPoint - norm * 100000.0f; r.norm = norm; r.isOmni = false; r.hasIES = false; r.pdf = 1.0f;
+  return r;
+}
+static inline LightSample pointLightSampleRev(const LightSource& L)   // :117-126
+{
+  LightSample r;
+  r.pos = xyz(L.pos); r.norm = xyz(L.norm); r.isOmni = (L.distType == LIGHT_DIST_OMNI); r.hasIES = (L.iesId != uint(-1)); r.pdf = 1.0f;
+  return r;
+}
+static inline float mylocalsmoothstep(float edge0, float edge1, float x)   // :220-225
+{
+  const float tVal = (x - edge0) / (edge1 - edge0);
+  const float t = std::min(std::max(tVal, 0.0f), 1.0f);
+  return t * t * (3.0f - 2.0f * t);
+}
+
+} // namespace orc

@@ -1,0 +1,238 @@
+"""ctypes binding of the C ABI in include/hydra_hip.h (hydracore3_amd/libhydra_hip.so).
+
+`HipIntegrator` mirrors the slice of the reference's `Integrator` / `IntegratorDR` class surface that the hot path
+needs (integrator_pt.h:123-703, diff_render/integrator_dr.h:27-136): same method names, same argument meaning, same
+ownership rules (the caller owns ``out_color`` and it is accumulated into; ``m_randomGens`` lives with the integrator).
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is visible this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .scene import HIT_DTYPE, Params, SceneData, SceneDesc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhydra_hip.so")
+
+# every symbol include/hydra_hip.h declares: name -> (restype, argtypes)
+_vp, _u32, _u64, _f, _i, _sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int, C.c_size_t
+ABI = {
+    "hpt_create": (_i, [_i, C.POINTER(_vp)]),
+    "hpt_destroy": (None, [_vp]),
+    "hpt_last_error": (C.c_char_p, [_vp]),
+    "hpt_device_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.c_char_p, _sz]),
+    "hpt_clear_geom": (_i, [_vp]),
+    "hpt_add_geom_triangles3f": (_u32, [_vp, _vp, _sz, _vp, _sz, _u32, _sz]),
+    "hpt_update_geom_triangles3f": (_i, [_vp, _u32, _vp, _sz, _vp, _sz, _u32, _sz]),
+    "hpt_clear_scene": (_i, [_vp]),
+    "hpt_add_instance": (_u32, [_vp, _u32, _vp]),
+    "hpt_update_instance": (_i, [_vp, _u32, _vp]),
+    "hpt_commit_scene": (_i, [_vp, _u32]),
+    "hpt_ray_query_nearest": (_i, [_vp, _vp, _vp, _u32, _vp]),
+    "hpt_ray_query_any": (_i, [_vp, _vp, _vp, _u32, _vp]),
+    "hpt_upload_scene": (_i, [_vp, C.POINTER(SceneDesc)]),
+    "hpt_update_params": (_i, [_vp, C.POINTER(Params)]),
+    "hpt_update_materials": (_i, [_vp, _sz, _sz, _vp]),
+    "hpt_update_lights": (_i, [_vp, _sz, _sz, _vp]),
+    "hpt_pack_xy": (_i, [_vp, _u32, _u32]),
+    "hpt_get_packed_xy": (_i, [_vp, _vp, _u32]),
+    "hpt_init_random_gens": (_i, [_vp, _u32]),
+    "hpt_get_random_gens": (_i, [_vp, _vp, _u32]),
+    "hpt_set_random_gens": (_i, [_vp, _vp, _u32]),
+    "hpt_path_trace_block": (_i, [_vp, _u32, _u32, _u32, _vp, _u32]),
+    "hpt_naive_path_trace_block": (_i, [_vp, _u32, _u32, _u32, _vp, _u32]),
+    "hpt_path_trace_block_dev": (_i, [_vp, _u32, _u32, _u32, _vp, _u32, _i, _vp]),
+    "hpt_put_diff_tex2d": (_i, [_vp, _u32, _u32, _u32, _u32, C.POINTER(_u64), C.POINTER(_u64)]),
+    "hpt_reset_diff_tex": (_i, [_vp]),
+    "hpt_path_trace_dr": (_i, [_vp, _u32, _u32, _u32, _vp, _u32, _vp, _vp, _vp, _sz, C.POINTER(_f)]),
+    "hpt_path_trace_dr_dev": (_i, [_vp, _u32, _u32, _u32, _vp, _u32, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "hpt_adam_step_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
+    "hpt_get_execution_time": (_i, [_vp, C.c_char_p, C.POINTER(_f)]),
+    "hpt_set_instrumentation": (_i, [_vp, _i]),
+    "hpt_get_counters": (_i, [_vp, C.POINTER(_u64)]),
+    "hpt_set_launch_config": (_i, [_vp, _i]),
+    "hpt_last_kernel_ms": (_i, [_vp, C.POINTER(_f)]),
+}
+
+_LIB = None
+
+
+class HydraHipError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen the in-tree HIP library and bind every ABI symbol; raises if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise HydraHipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in ABI.items():
+            fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _LIB = lib
+    return _LIB
+
+
+COUNTER_NAMES = ("rays", "nodes", "tris", "surface_hits", "shadow_rays", "paths", "instances_entered", "tex_fetches")
+
+
+class HipIntegrator:
+    """Integrator-shaped front end of the HIP core. One instance = one hpt_ctx = one GPU."""
+
+    def __init__(self, scene: SceneData = None, params: Params = None, device: int = 0):
+        self.L = load_library()
+        h = _vp()
+        rc = self.L.hpt_create(device, C.byref(h))
+        if rc != 0:
+            raise HydraHipError(f"hpt_create(device={device}) failed with code {rc}: no usable MI355X / HIP device")
+        self.h = h
+        self.scene = None
+        self.params = None
+        self.W = self.H = self.N = 0
+        if scene is not None:
+            self.LoadScene(scene, params)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.L.hpt_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise HydraHipError(f"hydra_hip error {rc}: {self.L.hpt_last_error(self.h).decode()}")
+
+    # ---- LoadScene / CommitDeviceData / UpdateMembersPlainData / PackXYBlock (main.cpp:249-267) ---------------------
+    def LoadScene(self, scene: SceneData, params: Params = None):
+        self.scene = scene
+        self._desc = scene.desc()
+        self.CommitDeviceData()
+        self.UpdateMembersPlainData(params if params is not None else scene.params())
+        self.PackXYBlock(self.W, self.H, 1)
+        self.InitRandomGens(self.N)
+
+    def CommitDeviceData(self):
+        self._chk(self.L.hpt_upload_scene(self.h, C.byref(self._desc)))
+
+    def UpdateMembersPlainData(self, params: Params):
+        self.params = params
+        self._chk(self.L.hpt_update_params(self.h, C.byref(params)))
+        self.W, self.H = params.winWidth, params.winHeight
+        self.N = self.W * self.H
+
+    def PackXYBlock(self, tidX, tidY, a_passNum=1):
+        self._chk(self.L.hpt_pack_xy(self.h, tidX, tidY))
+
+    def InitRandomGens(self, a_maxThreads):
+        self._chk(self.L.hpt_init_random_gens(self.h, a_maxThreads))
+
+    def packed_xy(self):
+        out = np.zeros(self.N, np.uint32)
+        self._chk(self.L.hpt_get_packed_xy(self.h, out.ctypes.data, self.N))
+        return out
+
+    def random_gens(self):
+        out = np.zeros((self.N, 2), np.uint32)
+        self._chk(self.L.hpt_get_random_gens(self.h, out.ctypes.data, self.N))
+        return out
+
+    def set_random_gens(self, gens):
+        gens = np.ascontiguousarray(gens, np.uint32)
+        self._chk(self.L.hpt_set_random_gens(self.h, gens.ctypes.data, gens.shape[0]))
+
+    def Update_m_materials(self, first, mats):
+        mats = np.ascontiguousarray(mats)
+        self._chk(self.L.hpt_update_materials(self.h, first, mats.size, mats.ctypes.data))
+
+    def Update_m_lights(self, first, lights):
+        lights = np.ascontiguousarray(lights)
+        self._chk(self.L.hpt_update_lights(self.h, first, lights.size, lights.ctypes.data))
+
+    # ---- the hot path -----------------------------------------------------------------------------------------------
+    def PathTraceBlock(self, tid, channels, out_color, a_passNum, tid_begin=0):
+        """Integrator::PathTraceBlock(tid, channels, out_color, a_passNum); `tid` = number of threads (pixels)."""
+        assert out_color.dtype == np.float32 and out_color.flags["C_CONTIGUOUS"]
+        self._chk(self.L.hpt_path_trace_block(self.h, tid_begin, tid, channels, out_color.ctypes.data, a_passNum))
+
+    def NaivePathTraceBlock(self, tid, channels, out_color, a_passNum, tid_begin=0):
+        assert out_color.dtype == np.float32 and out_color.flags["C_CONTIGUOUS"]
+        self._chk(self.L.hpt_naive_path_trace_block(self.h, tid_begin, tid, channels, out_color.ctypes.data, a_passNum))
+
+    def path_trace_block_dev(self, dev_ptr, pass_num, tid_begin=0, tid_count=None, channels=4, naive=False, stream=None):
+        tid_count = self.N - tid_begin if tid_count is None else tid_count
+        self._chk(self.L.hpt_path_trace_block_dev(self.h, tid_begin, tid_count, channels, dev_ptr, pass_num, int(naive), stream))
+
+    def render(self, spp, channels=4, naive=False):
+        img = np.zeros((self.H, self.W, channels), np.float32)
+        (self.NaivePathTraceBlock if naive else self.PathTraceBlock)(self.N, channels, img, spp)
+        return img
+
+    def GetExecutionTime(self, name):
+        out = (C.c_float * 4)(0, 0, 0, 0)
+        self._chk(self.L.hpt_get_execution_time(self.h, name.encode(), out))
+        return list(out)
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        self._chk(self.L.hpt_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    # ---- ISceneObject queries -----------------------------------------------------------------------------------------
+    def RayQuery_NearestHit(self, pos_near, dir_far):
+        pos_near = np.ascontiguousarray(pos_near, np.float32)
+        dir_far = np.ascontiguousarray(dir_far, np.float32)
+        out = np.zeros(pos_near.shape[0], HIT_DTYPE)
+        self._chk(self.L.hpt_ray_query_nearest(self.h, pos_near.ctypes.data, dir_far.ctypes.data, pos_near.shape[0], out.ctypes.data))
+        return out
+
+    def RayQuery_AnyHit(self, pos_near, dir_far):
+        pos_near = np.ascontiguousarray(pos_near, np.float32)
+        dir_far = np.ascontiguousarray(dir_far, np.float32)
+        out = np.zeros(pos_near.shape[0], np.uint32)
+        self._chk(self.L.hpt_ray_query_any(self.h, pos_near.ctypes.data, dir_far.ctypes.data, pos_near.shape[0], out.ctypes.data))
+        return out
+
+    # ---- IntegratorDR -----------------------------------------------------------------------------------------------------
+    def PutDiffTex2D(self, texId, width, height, channels):
+        off, size = _u64(0), _u64(0)
+        rc = self.L.hpt_put_diff_tex2d(self.h, texId, width, height, channels, C.byref(off), C.byref(size))
+        if rc != 0 and size.value == 0 and off.value == 0xFFFFFFFFFFFFFFFF:
+            return (off.value, 0)          # reference behaviour for a bad id: message + (size_t(-1), 0)
+        self._chk(rc)
+        return (off.value, size.value)
+
+    def PathTraceDR(self, tid, channels, out_color, a_passNum, a_refImg, a_data, a_dataGrad, tid_begin=0):
+        a_refImg = np.ascontiguousarray(a_refImg, np.float32)
+        a_data = np.ascontiguousarray(a_data, np.float32)
+        assert a_dataGrad.dtype == np.float32 and a_dataGrad.size == a_data.size
+        loss = C.c_float(0)
+        self._chk(self.L.hpt_path_trace_dr(self.h, tid_begin, tid, channels, out_color.ctypes.data, a_passNum, a_refImg.ctypes.data,
+                                           a_data.ctypes.data, a_dataGrad.ctypes.data, a_data.size, C.byref(loss)))
+        return loss.value
+
+    # ---- instrumentation ----------------------------------------------------------------------------------------------------
+    def set_instrumentation(self, enabled: bool):
+        self._chk(self.L.hpt_set_instrumentation(self.h, int(enabled)))
+
+    def counters(self):
+        out = (_u64 * 8)()
+        self._chk(self.L.hpt_get_counters(self.h, out))
+        return dict(zip(COUNTER_NAMES, [int(v) for v in out]))
+
+    def set_launch_config(self, blocks_per_cu: int):
+        self._chk(self.L.hpt_set_launch_config(self.h, blocks_per_cu))
+
+    def device_info(self):
+        cu, wf = C.c_int(0), C.c_int(0)
+        name = C.create_string_buffer(128)
+        self._chk(self.L.hpt_device_info(self.h, C.byref(cu), C.byref(wf), name, 128))
+        return {"cus": cu.value, "wavefront": wf.value, "arch": name.value.decode()}

@@ -1,0 +1,868 @@
+// gfx950 device functions of the path-tracing core: RNG, sampling, BSDFs, lights, texture fetch and BVH2 traversal.
+//
+// Written for wave64 / CDNA4: everything is inlined into one persistent kernel (hpt_kernels.hip), per-lane state
+// lives in VGPRs, the traversal stack lives in LDS ([depth][lane] so that a push/pop is one conflict-free
+// ds_write/ds_read_b32 per wave), nodes are fetched as 64-byte lines, triangles as 3 x 16 bytes.
+//
+// Results must equal the reference's CPU integrator at fixed seeds, so the arithmetic follows the reference's
+// formulas in the reference's evaluation order (cited per function), is compiled with -ffp-contract=off, uses
+// IEEE division / sqrt, and min/max follow std::min/std::max (not fminf/fmaxf) wherever a value is consumed.
+// Only the ray/box test uses fmin/fmax: it merely has to be conservative.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "hpt_types.h"
+
+namespace hpt {
+
+#define HPT_DEV __device__ __forceinline__
+
+// ---- flags / enums (include/cglobals.h:9-16, include/cmaterial.h:26-56, include/clight.h:5-17, integrator_pt.h:330-332,406-408)
+enum : uint {
+  RAY_FLAG_IS_DEAD = 0x80000000u, RAY_FLAG_OUT_OF_SCENE = 0x40000000u, RAY_FLAG_HIT_LIGHT = 0x20000000u,
+  RAY_FLAG_HAS_NON_SPEC = 0x10000000u, RAY_FLAG_HAS_INV_NORMAL = 0x08000000u, RAY_FLAG_WAVES_DIVERGED = 0x04000000u,
+  RAY_FLAG_PRIME_RAY_MISS = 0x02000000u, RAY_FLAG_FIRST_NON_SPEC = 0x01000000u };
+enum : uint { GLTF_COMPONENT_METAL = 4, GLTF_COMPONENT_ORENNAYAR = 16, FLAG_FOUR_TEXTURES = 256, FLAG_PACK_FOUR_PARAMS_IN_TEXTURE = 512 };
+enum : uint { MAT_TYPE_GLTF = 1, MAT_TYPE_CONDUCTOR = 3, MAT_TYPE_DIFFUSE = 4, MAT_TYPE_DIELECTRIC = 7, MAT_TYPE_LIGHT_SOURCE = 0xEFFFFFFFu };
+enum : uint { RAY_EVENT_S = 1, RAY_EVENT_T = 8 };
+enum : uint { LIGHT_GEOM_RECT = 1, LIGHT_GEOM_DISC = 2, LIGHT_GEOM_SPHERE = 3, LIGHT_GEOM_DIRECT = 4, LIGHT_GEOM_POINT = 5, LIGHT_GEOM_ENV = 6 };
+enum : uint { LIGHT_DIST_LAMBERT = 0, LIGHT_DIST_OMNI = 1, LIGHT_DIST_SPOT = 2, LIGHT_FLAG_POINT_AREA = 1 };
+enum : uint { INTEGRATOR_STUPID_PT = 0, INTEGRATOR_SHADOW_PT = 1, INTEGRATOR_MIS_PT = 2, FB_COLOR = 0, FB_DIRECT = 1, FB_INDIRECT = 2 };
+// Material::colors / Material::data slots (include/cmaterial.h:67-147)
+enum { GLTF_COLOR_BASE = 0, GLTF_COLOR_COAT = 1, GLTF_COLOR_METAL = 2 };
+enum { GLTF_FLOAT_MI_FDR_INT = 0, GLTF_FLOAT_ALPHA = 3, GLTF_FLOAT_GLOSINESS = 4, GLTF_FLOAT_IOR = 5, GLTF_FLOAT_REFL_COAT = 7 };
+
+#define HPT_PI      3.14159265358979323846f
+#define HPT_TWOPI   6.28318530717958647692f
+#define HPT_INV_PI  0.31830988618379067154f
+#define HPT_FLT_MAX 3.402823466e+38f
+
+// ---- small vector helpers ------------------------------------------------------------------------------------------
+struct V2 { float x, y; };
+struct V3 { float x, y, z; };
+struct V4 { float x, y, z, w; };
+
+HPT_DEV V2 v2(float x, float y) { V2 r; r.x = x; r.y = y; return r; }
+HPT_DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+HPT_DEV V3 v3s(float a) { return v3(a, a, a); }
+HPT_DEV V4 v4(float x, float y, float z, float w) { V4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+HPT_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+HPT_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+HPT_DEV V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+HPT_DEV V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+HPT_DEV V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+HPT_DEV V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+HPT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+HPT_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+HPT_DEV float length(V3 a) { return __builtin_sqrtf(dot(a, a)); }
+HPT_DEV V3 normalize(V3 a) { return a / length(a); }
+HPT_DEV V3 reflect(V3 i, V3 n) { return i - 2.0f * dot(n, i) * n; }
+// std::min / std::max semantics (NaN behaviour included), as the reference's host build evaluates them
+HPT_DEV float smax(float a, float b) { return (a < b) ? b : a; }
+HPT_DEV float smin(float a, float b) { return (b < a) ? b : a; }
+HPT_DEV float clampf(float x, float lo, float hi) { return smin(smax(x, lo), hi); }
+HPT_DEV float lerpf(float a, float b, float t) { return a + t * (b - a); }
+HPT_DEV float absf(float a) { return __builtin_fabsf(a); }
+HPT_DEV float sqrtf_(float a) { return __builtin_sqrtf(a); }
+HPT_DEV bool finitef(float a) { return absf(a) <= HPT_FLT_MAX; }     // false for NaN and +-inf
+
+// column-major 4x4 (LiteMath float4x4): element (row,col) = m[col*4+row]
+HPT_DEV V4 mul4x4(const float* m, V4 v)
+{
+  V4 r;
+  r.x = v.x * m[0] + v.y * m[4] + v.z * m[8]  + v.w * m[12];
+  r.y = v.x * m[1] + v.y * m[5] + v.z * m[9]  + v.w * m[13];
+  r.z = v.x * m[2] + v.y * m[6] + v.z * m[10] + v.w * m[14];
+  r.w = v.x * m[3] + v.y * m[7] + v.z * m[11] + v.w * m[15];
+  return r;
+}
+HPT_DEV V3 mul4x3(const float* m, V3 p)
+{
+  return v3(m[0] * p.x + m[4] * p.y + m[8]  * p.z + m[12],
+            m[1] * p.x + m[5] * p.y + m[9]  * p.z + m[13],
+            m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
+}
+HPT_DEV V3 mul3x3(const float* m, V3 v)
+{
+  return v3(m[0] * v.x + m[4] * v.y + m[8]  * v.z,
+            m[1] * v.x + m[5] * v.y + m[9]  * v.z,
+            m[2] * v.x + m[6] * v.y + m[10] * v.z);
+}
+
+// ---- RNG: include/crandom.h:11-75 (pure uint32 arithmetic, one state step per draw) --------------------------------
+struct Rng { uint sx, sy; };
+
+HPT_DEV uint rng_next(Rng& g)
+{
+  const uint x = g.sx * 17u + g.sy * 13123u;
+  g.sx = (x << 13) ^ x;
+  g.sy ^= (x << 7);
+  return x;
+}
+HPT_DEV Rng rng_init(uint seed)                                       // RandomGenInit (crandom.h:25-36); seed = tid >= 0
+{
+  Rng g;
+  g.sx = (seed * (seed * seed * 15731u + 74323u) + 871483u);
+  g.sy = (seed * (seed * seed * 13734u + 37828u) + 234234u);
+  const uint warm = seed % 7u;
+  for (uint i = 0; i < warm; i++) rng_next(g);
+  return g;
+}
+HPT_DEV V4 rng_float4(Rng& g)
+{
+  const uint x = rng_next(g);
+  const uint x1 = (x * (x * x * 15731u + 74323u) + 871483u);
+  const uint y1 = (x * (x * x * 13734u + 37828u) + 234234u);
+  const uint z1 = (x * (x * x * 11687u + 26461u) + 137589u);
+  const uint w1 = (x * (x * x * 15707u + 789221u) + 1376312589u);
+  const float scale = (1.0f / 4294967296.0f);
+  return v4((float)x1 * scale, (float)y1 * scale, (float)z1 * scale, (float)w1 * scale);
+}
+HPT_DEV float rng_float1(Rng& g)
+{
+  const uint x = rng_next(g);
+  const uint t = (x * (x * x * 15731u + 74323u) + 871483u);
+  return ((float)t) * (1.0f / 4294967296.0f);
+}
+
+// ---- include/cglobals.h ---------------------------------------------------------------------------------------------
+HPT_DEV void coordinateSystemV2(V3 n, V3& s, V3& t)                    // :120-132
+{
+  const float sign = n.z >= 0 ? 1.0f : -1.0f;
+  const float a = -(1.0f / (sign + n.z));
+  const float b = n.x * n.y * a;
+  const float tmp = (n.z >= 0 ? n.x * n.x * a : -n.x * n.x * a);
+  s = v3(tmp + 1.0f, n.z >= 0 ? b : -b, n.z >= 0 ? -n.x : n.x);
+  t = v3(b, n.y * n.y * a + sign, -n.y);
+}
+
+HPT_DEV V3 mapSampleToCosineDistribution(float r1, float r2, V3 direction, V3 hit_norm, float power)   // :143-181
+{
+  if (power >= 1e6f) return direction;
+  const float sin_phi = sinf(HPT_TWOPI * r1);
+  const float cos_phi = cosf(HPT_TWOPI * r1);
+  const float cos_theta = powf(1.0f - r2, 1.0f / (power + 1.0f));
+  const float sin_theta = sqrtf_(1.0f - cos_theta * cos_theta);
+  const V3 dev = v3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
+  V3 nx, nz;
+  coordinateSystemV2(direction, nx, nz);
+  const V3 ny = nz;                 // the reference swaps ny and nz after building the frame
+  const V3 nz2 = direction;
+  V3 res = nx * dev.x + ny * dev.y + nz2 * dev.z;
+  const float invSign = dot(direction, hit_norm) > 0.0f ? 1.0f : -1.0f;
+  if (invSign * dot(res, hit_norm) < 0.0f)
+    res = (-1.0f) * nx * dev.x + ny * dev.y - nz2 * dev.z;
+  return res;
+}
+
+HPT_DEV V2 mapSamplesToDisc(V2 xy)                                     // :188-231
+{
+  const float x = xy.x, y = xy.y;
+  float r = 0, phi = 0;
+  if (x > y && x > -y)  { r = x;  phi = 0.25f * 3.141592654f * (y / x); }
+  if (x < y && x > -y)  { r = y;  phi = 0.25f * 3.141592654f * (2.0f - x / y); }
+  if (x < y && x < -y)  { r = -x; phi = 0.25f * 3.141592654f * (4.0f + y / x); }
+  if (x > y && x < -y)  { r = -y; phi = 0.25f * 3.141592654f * (6 - x / y); }
+  const float sin_phi = sinf(phi), cos_phi = cosf(phi);
+  return v2(r * sin_phi, r * cos_phi);
+}
+
+HPT_DEV float epsilonOfPos(V3 p) { return smax(smax(absf(p.x), smax(absf(p.y), absf(p.z))), 2.0f * 1e-5f) * 1e-5f; }   // :233
+HPT_DEV V3 offsRayPos(V3 hitPos, V3 surfaceNorm, V3 sampleDir)         // :242-247
+{
+  const float signOfNormal2 = dot(sampleDir, surfaceNorm) < 0.0f ? -1.0f : 1.0f;
+  const float offsetEps = epsilonOfPos(hitPos);
+  return hitPos + signOfNormal2 * offsetEps * surfaceNorm;
+}
+HPT_DEV float pdfAtoW(float aPdfA, float aDist, float aCosThere) { return (aPdfA * aDist * aDist) / smax(aCosThere, 1e-30f); }   // :265-268
+HPT_DEV float maxcomp(V3 v) { return smax(v.x, smax(v.y, v.z)); }       // :275
+HPT_DEV float misPower1(float p) { return finitef(p) ? absf(p) : 0.0f; }   // :277
+HPT_DEV float misWeightHeuristic(float a, float b)                      // :278-282
+{
+  const float w = misPower1(a) / smax(misPower1(a) + misPower1(b), 1e-30f);
+  return finitef(w) ? w : 0.0f;
+}
+HPT_DEV V2 mulRows2x4(const float* row0, const float* row1, V2 v)       // :315-321
+{
+  return v2(row0[0] * v.x + row0[1] * v.y + row0[3], row1[0] * v.x + row1[1] * v.y + row1[3]);
+}
+HPT_DEV V2 sphereMapTo2DTexCoord(V3 ray_dir)                            // :335-362
+{
+  const float x = ray_dir.z, y = ray_dir.x, z = -ray_dir.y;
+  const float theta = acosf(z);
+  float phi = atan2f(y, x);
+  if (phi < 0.0f) phi += 2.0f * HPT_PI;
+  return v2(clampf(phi * 0.5f * HPT_INV_PI, 0.0f, 1.0f), clampf(theta * HPT_INV_PI, 0.0f, 1.0f));
+}
+
+// ---- textures: LiteImage bilinear sampler as restated in-tree by Tex2DFetchAD (diff_render/integrator_dr.cpp:60-161) --
+struct Taps { int off[4]; float w[4]; };
+
+HPT_DEV int wrapi(int p, int n) { const int r = p % n; return r < 0 ? r + n : r; }
+
+HPT_DEV Taps bilinearTaps(uint w, uint h, uint addrU, uint addrV, V2 uv)
+{
+  float ffx = uv.x * float(w) - 0.5f;
+  float ffy = uv.y * float(h) - 0.5f;
+  if (addrU == 2 && ffx < 0) ffx = 0.0f;
+  if (addrV == 2 && ffy < 0) ffy = 0.0f;
+  const int px = (int)ffx, py = (int)ffy;
+  const float fx = absf(ffx - (float)px), fy = absf(ffy - (float)py);
+  const float fx1 = 1.0f - fx, fy1 = 1.0f - fy;
+  const int sx = (ffx > 0.0f) ? 1 : -1, sy = (ffy > 0.0f) ? 1 : -1;
+  const int x0 = wrapi(px, (int)w), x1 = wrapi(px + sx, (int)w);
+  const int y0 = wrapi(py, (int)h), y1 = wrapi(py + sy, (int)h);
+  Taps r;
+  r.off[0] = y0 * (int)w + x0; r.off[1] = y0 * (int)w + x1; r.off[2] = y1 * (int)w + x0; r.off[3] = y1 * (int)w + x1;
+  r.w[0] = fx1 * fy1; r.w[1] = fx * fy1; r.w[2] = fx1 * fy; r.w[3] = fx * fy;
+  return r;
+}
+
+HPT_DEV V4 texel(const TexRec& t, int off)
+{
+  if (t.format == 0) {
+    const uint v = ((const uint*)t.data)[off];
+    const float s = 1.0f / 255.0f;
+    return v4(float(v & 0xFF) * s, float((v >> 8) & 0xFF) * s, float((v >> 16) & 0xFF) * s, float(v >> 24) * s);
+  }
+  if (t.format == 1) { const float4 q = ((const float4*)t.data)[off]; return v4(q.x, q.y, q.z, q.w); }
+  const float v = ((const float*)t.data)[off];
+  return v4(v, v, v, v);
+}
+
+HPT_DEV V4 texSample(const TexRec* texs, uint texId, V2 uv)
+{
+  const TexRec t = texs[texId];
+  V4 res;
+  if (t.filter == 0) {
+    int px = (int)floorf(uv.x * float(t.w)), py = (int)floorf(uv.y * float(t.h));
+    px = (t.addrU == 2) ? min(max(px, 0), (int)t.w - 1) : wrapi(px, (int)t.w);
+    py = (t.addrV == 2) ? min(max(py, 0), (int)t.h - 1) : wrapi(py, (int)t.h);
+    res = texel(t, py * (int)t.w + px);
+  } else {
+    const Taps k = bilinearTaps(t.w, t.h, t.addrU, t.addrV, uv);
+    const V4 a = texel(t, k.off[0]), b = texel(t, k.off[1]), c = texel(t, k.off[2]), d = texel(t, k.off[3]);
+    res.x = a.x * k.w[0] + b.x * k.w[1] + c.x * k.w[2] + d.x * k.w[3];
+    res.y = a.y * k.w[0] + b.y * k.w[1] + c.y * k.w[2] + d.y * k.w[3];
+    res.z = a.z * k.w[0] + b.z * k.w[1] + c.z * k.w[2] + d.z * k.w[3];
+    res.w = a.w * k.w[0] + b.w * k.w[1] + c.w * k.w[2] + d.w * k.w[3];
+  }
+  if (t.flags & 1u) { res.x = powf(res.x, 2.2f); res.y = powf(res.y, 2.2f); res.z = powf(res.z, 2.2f); }
+  return res;
+}
+
+// ---- include/cmaterial.h ------------------------------------------------------------------------------------------------
+HPT_DEV float safe_sqrt(float v) { return sqrtf_(smax(v, 0.0f)); }
+HPT_DEV float cosPhiPBRT(V3 w, float sintheta) { return sintheta == 0.0f ? 1.0f : clampf(w.x / sintheta, -1.0f, 1.0f); }
+HPT_DEV float sinPhiPBRT(V3 w, float sintheta) { return sintheta == 0.0f ? 0.0f : clampf(w.y / sintheta, -1.0f, 1.0f); }
+
+HPT_DEV float orennayarFunc(V3 a_l, V3 a_v, V3 a_n, float a_roughness)     // :254-306
+{
+  const float cosTheta_wi = dot(a_l, a_n), cosTheta_wo = dot(a_v, a_n);
+  const float sinTheta_wi = safe_sqrt(1.0f - cosTheta_wi * cosTheta_wi);
+  const float sinTheta_wo = safe_sqrt(1.0f - cosTheta_wo * cosTheta_wo);
+  const float sigma = a_roughness * HPT_PI * 0.5f;
+  const float sigma2 = sigma * sigma;
+  const float A = 1.0f - (sigma2 / (2.0f * (sigma2 + 0.33f)));
+  const float B = 0.45f * sigma2 / (sigma2 + 0.09f);
+  V3 nx, ny;
+  coordinateSystemV2(a_n, nx, ny);
+  float maxcos = 0.0f;
+  if (sinTheta_wi > 1e-4f && sinTheta_wo > 1e-4f) {
+    const V3 wo = v3(-dot(a_v, nx), -dot(a_v, ny), -dot(a_v, a_n));
+    const V3 wi = v3(-dot(a_l, nx), -dot(a_l, ny), -dot(a_l, a_n));
+    const float sinphii = sinPhiPBRT(wi, sinTheta_wi), cosphii = cosPhiPBRT(wi, sinTheta_wi);
+    const float sinphio = sinPhiPBRT(wo, sinTheta_wo), cosphio = cosPhiPBRT(wo, sinTheta_wo);
+    const float dcos = cosphii * cosphio + sinphii * sinphio;
+    maxcos = smax(0.0f, dcos);
+  }
+  float sinalpha, tanbeta;
+  if (absf(cosTheta_wi) > absf(cosTheta_wo)) { sinalpha = sinTheta_wo; tanbeta = sinTheta_wi / smax(absf(cosTheta_wi), 1e-20f); }
+  else                                       { sinalpha = sinTheta_wi; tanbeta = sinTheta_wo / smax(absf(cosTheta_wo), 1e-20f); }
+  return (A + B * maxcos * sinalpha * tanbeta);
+}
+
+HPT_DEV float ggxDistribution(float cosThetaNH, float alpha)             // :322-328
+{
+  const float alpha2 = alpha * alpha;
+  const float NH_sqr = clampf(cosThetaNH * cosThetaNH, 0.0f, 1.0f);
+  const float den = NH_sqr * alpha2 + (1.0f - NH_sqr);
+  return alpha2 / smax(HPT_PI * den * den, 1e-6f);
+}
+HPT_DEV float ggxGeomShadMask(float cosThetaN, float alpha)              // :330-343
+{
+  const float c2 = clampf(cosThetaN * cosThetaN, 0.0f, 1.0f);
+  const float tan2 = (1.0f - c2) / smax(c2, 1e-6f);
+  return 2.0f / (1.0f + safe_sqrt(1.0f + alpha * alpha * tan2));
+}
+HPT_DEV V3 ggxSample(V2 rands, V3 v, V3 n, float roughness)              // :347-362
+{
+  const float roughSqr = roughness * roughness;
+  V3 nx, ny;
+  coordinateSystemV2(n, nx, ny);
+  const V3 wo = v3(dot(v, nx), dot(v, ny), dot(v, n));
+  const float phi = rands.x * HPT_TWOPI;
+  const float cosTheta = clampf(safe_sqrt((1.0f - rands.y) / (1.0f + roughSqr * roughSqr * rands.y - rands.y)), 0.0f, 1.0f);
+  const float sinTheta = safe_sqrt(1.0f - cosTheta * cosTheta);
+  const V3 wh = v3(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta);
+  const V3 wi = 2.0f * dot(wo, wh) * wh - wo;
+  return normalize(wi.x * nx + wi.y * ny + wi.z * n);
+}
+HPT_DEV float ggxEvalPDF(V3 l, V3 v, V3 n, float roughness)              // :364-378
+{
+  const float dotNV = dot(n, v), dotNL = dot(n, l);
+  if (dotNV < 1e-6f || dotNL < 1e-6f) return 1.0f;
+  const float roughSqr = roughness * roughness;
+  const V3 h = normalize(v + l);
+  const float dotNH = dot(n, h), dotHV = dot(h, v);
+  const float D = ggxDistribution(dotNH, roughSqr);
+  return D * dotNH / (4.0f * smax(dotHV, 1e-6f));
+}
+HPT_DEV float ggxEvalBSDF(V3 l, V3 v, V3 n, float roughness)             // :380-397
+{
+  if (absf(dot(l, n)) < 1e-5f) return 0.0f;
+  const float dotNV = dot(n, v), dotNL = dot(n, l);
+  if (dotNV < 1e-6f || dotNL < 1e-6f) return 0.0f;
+  const float roughSqr = roughness * roughness;
+  const V3 h = normalize(v + l);
+  const float dotNH = dot(n, h);
+  const float D = ggxDistribution(dotNH, roughSqr);
+  const float G = ggxGeomShadMask(dotNV, roughSqr) * ggxGeomShadMask(dotNL, roughSqr);
+  return (D * G / smax(4.0f * dotNV * dotNL, 1e-6f));
+}
+
+// Trowbridge-Reitz (cmaterial.h:405-530)
+HPT_DEV float cos2Theta(V3 w) { return w.z * w.z; }
+HPT_DEV float sin2Theta(V3 w) { return smax(0.0f, 1.0f - cos2Theta(w)); }
+HPT_DEV float sinTheta_(V3 w) { return safe_sqrt(sin2Theta(w)); }
+HPT_DEV float tan2Theta(V3 w) { return sin2Theta(w) / cos2Theta(w); }
+HPT_DEV float cosPhi(V3 w) { const float s = sinTheta_(w); return (s == 0) ? 1 : clampf(w.x / s, -1.0f, 1.0f); }
+HPT_DEV float sinPhi(V3 w) { const float s = sinTheta_(w); return (s == 0) ? 0 : clampf(w.y / s, -1.0f, 1.0f); }
+HPT_DEV bool isinf_(float a) { return absf(a) > HPT_FLT_MAX; }
+HPT_DEV float trD(V3 wm, V2 alpha)                                       // :460-470
+{
+  const float t2 = tan2Theta(wm);
+  if (isinf_(t2)) return 0;
+  const float cos4Theta = cos2Theta(wm) * cos2Theta(wm);
+  if (cos4Theta < 1e-16f) return 0;
+  const float e = t2 * ((cosPhi(wm) / alpha.x) * (cosPhi(wm) / alpha.x) + (sinPhi(wm) / alpha.y) * (sinPhi(wm) / alpha.y));
+  return 1.0f / (HPT_PI * alpha.x * alpha.y * cos4Theta * (1 + e) * (1 + e));
+}
+HPT_DEV float trLambda(V3 w, V2 alpha)                                   // :477-484
+{
+  const float t2 = tan2Theta(w);
+  if (isinf_(t2)) return 0;
+  const float alpha2 = (cosPhi(w) * alpha.x) * (cosPhi(w) * alpha.x) + (sinPhi(w) * alpha.y) * (sinPhi(w) * alpha.y);
+  return (safe_sqrt(1.0f + alpha2 * t2) - 1.0f) / 2.0f;
+}
+HPT_DEV float trG1(V3 w, V2 alpha) { return 1.0f / (1.0f + trLambda(w, alpha)); }
+HPT_DEV float trG(V3 wo, V3 wi, V2 alpha) { return 1.0f / (1.0f + trLambda(wo, alpha) + trLambda(wi, alpha)); }
+HPT_DEV float trPDF(V3 w, V3 wm, V2 alpha) { return trG1(w, alpha) / absf(w.z) * trD(wm, alpha) * absf(dot(w, wm)); }   // :496-504
+HPT_DEV V3 trSample(V3 wo, V2 rands, V2 alpha)                            // :506-530
+{
+  V3 wh = normalize(v3(alpha.x * wo.x, alpha.y * wo.y, wo.z));
+  if (wh.z < 0) wh = (-1.0f) * wh;
+  const V3 T1 = (wh.z < 0.99999f) ? normalize(cross(v3(0, 0, 1), wh)) : v3(1, 0, 0);
+  const V3 T2 = cross(wh, T1);
+  const float r = safe_sqrt(rands.x);
+  const float th = HPT_TWOPI * rands.y;
+  V2 p = v2(r * cosf(th), r * sinf(th));
+  const float h = safe_sqrt(1 - p.x * p.x);
+  p.y = lerpf(h, p.y, (1 + wh.z) / 2);
+  const float pz = safe_sqrt(1.0f - (p.x * p.x + p.y * p.y));
+  const V3 nh = p.x * T1 + p.y * T2 + pz * wh;
+  return normalize(v3(alpha.x * nh.x, alpha.y * nh.y, smax(1e-6f, nh.z)));
+}
+
+HPT_DEV float frDielectricPBRT(float cosThetaI, float etaI, float etaT)  // :536-561
+{
+  cosThetaI = clampf(cosThetaI, -1.0f, 1.0f);
+  const bool entering = cosThetaI > 0.0f;
+  if (!entering) { const float tmp = etaI; etaI = etaT; etaT = tmp; cosThetaI = absf(cosThetaI); }
+  const float sinThetaI = safe_sqrt(1.0f - cosThetaI * cosThetaI);
+  const float sinThetaT = etaI / etaT * sinThetaI;
+  if (sinThetaT >= 1.0f) return 1.0f;
+  const float cosThetaT = safe_sqrt(1.0f - sinThetaT * sinThetaT);
+  const float Rparl = ((etaT * cosThetaI) - (etaI * cosThetaT)) / ((etaT * cosThetaI) + (etaI * cosThetaT));
+  const float Rperp = ((etaI * cosThetaI) - (etaT * cosThetaT)) / ((etaI * cosThetaI) + (etaT * cosThetaT));
+  return 0.5f * (Rparl * Rparl + Rperp * Rperp);
+}
+
+// complex helpers for FrComplexConductor (cmaterial.h:685-694); LiteMath's complex is absent: pbrt-v4 formulation
+struct Cx { float re, im; };
+HPT_DEV Cx cx(float re, float im) { Cx r; r.re = re; r.im = im; return r; }
+HPT_DEV Cx operator+(Cx a, Cx b) { return cx(a.re + b.re, a.im + b.im); }
+HPT_DEV Cx operator-(Cx a, Cx b) { return cx(a.re - b.re, a.im - b.im); }
+HPT_DEV Cx operator*(Cx a, Cx b) { return cx(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+HPT_DEV Cx operator*(Cx a, float s) { return cx(a.re * s, a.im * s); }
+HPT_DEV Cx operator/(Cx a, Cx b)
+{
+  const float scale = 1.0f / (b.re * b.re + b.im * b.im);
+  return cx(scale * (a.re * b.re + a.im * b.im), scale * (a.im * b.re - a.re * b.im));
+}
+HPT_DEV float cnorm(Cx a) { return a.re * a.re + a.im * a.im; }
+HPT_DEV Cx csqrt_(Cx z)
+{
+  const float n = sqrtf_(cnorm(z));
+  if (n == 0.0f) return cx(0.0f, 0.0f);
+  const float t1 = sqrtf_(0.5f * (n + absf(z.re)));
+  const float t2 = 0.5f * z.im / t1;
+  if (z.re >= 0.0f) return cx(t1, t2);
+  return cx(absf(t2), __builtin_copysignf(t1, z.im));
+}
+HPT_DEV float frComplexConductor(float cosThetaI, Cx eta)
+{
+  const float sinThetaI = 1.0f - cosThetaI * cosThetaI;
+  const Cx sinThetaT = cx(sinThetaI, 0.0f) / (eta * eta);
+  const Cx cosThetaT = csqrt_(cx(1.0f - sinThetaT.re, -sinThetaT.im));
+  const Cx r_parl = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+  const Cx ect = eta * cosThetaT;
+  const Cx r_perp = cx(cosThetaI - ect.re, -ect.im) / cx(cosThetaI + ect.re, ect.im);
+  return (cnorm(r_parl) + cnorm(r_perp)) / 2.0f;
+}
+HPT_DEV float fresnelSlick(float VdotH) { const float t = 1.0f - absf(VdotH); return (t * t) * (t * t) * t; }   // :705-709
+
+HPT_DEV V4 frDielectricDetailedV2(float cos_theta_i, float eta)          // :646-683
+{
+  cos_theta_i = clampf(cos_theta_i, -1.0f, 1.0f);
+  float eta_it = eta, eta_ti = 1.f / eta;
+  if (cos_theta_i < 0.0f) { eta_it = eta_ti; eta_ti = eta; }
+  const float cos_theta_t_sqr = -1.f * (-1.f * cos_theta_i * cos_theta_i + 1.f) * eta_ti * eta_ti + 1.f;
+  const float cos_theta_i_abs = absf(cos_theta_i);
+  const float cos_theta_t_abs = safe_sqrt(cos_theta_t_sqr);
+  float r;
+  if ((eta == 1.f) || (cos_theta_i_abs == 0.f)) r = (eta == 1.f) ? 0.f : 1.f;
+  else {
+    const float a_s = (-1.f * eta_it * cos_theta_t_abs + cos_theta_i_abs) / (eta_it * cos_theta_t_abs + cos_theta_i_abs);
+    const float a_p = (-1.f * eta_it * cos_theta_i_abs + cos_theta_t_abs) / (eta_it * cos_theta_i_abs + cos_theta_t_abs);
+    r = 0.5f * (a_s * a_s + a_p * a_p);
+  }
+  const float cos_theta_t = cos_theta_i >= 0 ? -cos_theta_t_abs : cos_theta_t_abs;
+  return v4(r, cos_theta_t, eta_it, eta_ti);
+}
+
+// ---- BSDF results ---------------------------------------------------------------------------------------------------
+// val / dir / pdf / flags / ior as in BsdfSample (cmaterial.h:9-16); dval = d val / d baseColor per channel, filled only
+// by the differentiable path (gltf is the only differentiable material, diff_render/integrator_dr.cpp:461-612).
+struct BsdfS { V3 val; V3 dir; float pdf; uint flags; float ior; V3 dval; };
+struct BsdfE { V3 val; float pdf; V3 dval; };
+
+HPT_DEV V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
+
+// include/cmat_gltf.h:6-90
+HPT_DEV void gltfSampleAndEval(const MaterialRec& m, V4 rands, V3 v, V3 n, V3 baseColor, V3 fourParams, BsdfS& r)
+{
+  const uint cflags = m.cflags;
+  const V3 Mcol = ld3(m.colors[GLTF_COLOR_METAL]);
+  const V3 metalCol = baseColor * Mcol;
+  const V3 coatCol = ld3(m.colors[GLTF_COLOR_COAT]);
+  const float roughness = clampf(1.0f - m.data[GLTF_FLOAT_GLOSINESS] * fourParams.x, 0.0f, 1.0f);
+  float metalness = m.data[GLTF_FLOAT_ALPHA] * fourParams.y;
+  const float coatValue = m.data[GLTF_FLOAT_REFL_COAT] * fourParams.z;
+  const float fresnelIOR = m.data[GLTF_FLOAT_IOR];
+  if (cflags == GLTF_COMPONENT_METAL) metalness = 1.0f;
+
+  V3 ggxDir; float ggxPdf, ggxVal;
+  if (roughness == 0.0f) {
+    const V3 pefReflDir = reflect((-1.0f) * v, n);
+    const float cosThetaOut = dot(pefReflDir, n);
+    ggxDir = pefReflDir;
+    ggxVal = (cosThetaOut <= 1e-6f) ? 0.0f : (1.0f / smax(cosThetaOut, 1e-6f));
+    ggxPdf = 1.0f;
+  } else {
+    ggxDir = ggxSample(v2(rands.x, rands.y), v, n, roughness);
+    ggxPdf = ggxEvalPDF(ggxDir, v, n, roughness);
+    ggxVal = ggxEvalBSDF(ggxDir, v, n, roughness);
+  }
+  const V3 lambertDir = mapSampleToCosineDistribution(rands.x, rands.y, n, n, 1.0f);
+  const float lambertPdf = absf(dot(lambertDir, n)) * HPT_INV_PI;
+  const float lambertVal = HPT_INV_PI;
+
+  float pdfSelect = 1.0f;
+  if (rands.z < metalness) {
+    pdfSelect *= metalness;
+    const float VdotH = dot(v, normalize(v + ggxDir));
+    r.dir = ggxDir;
+    V3 fr = metalCol, dfr = Mcol;                              // hydraFresnelCond (cmaterial.h:711-717)
+    if (fresnelIOR != 0.0f) { const float s = fresnelSlick(VdotH); fr = metalCol + (v3s(1.0f) - metalCol) * s; dfr = Mcol * (1.0f - s); }
+    r.val = fr * (ggxVal * metalness);
+    r.dval = dfr * (ggxVal * metalness);
+    r.pdf = ggxPdf;
+    r.flags = (roughness == 0.0f) ? RAY_EVENT_S : RAY_FLAG_HAS_NON_SPEC;
+  } else {
+    pdfSelect *= 1.0f - metalness;
+    const float f_i = frDielectricPBRT(absf(dot(v, n)), 1.0f, fresnelIOR);
+    const float prob_specular = 0.5f * coatValue;
+    const float prob_diffuse = 1.0f - prob_specular;
+    if (rands.w < prob_specular) {
+      pdfSelect *= prob_specular;
+      r.dir = ggxDir;
+      r.val = ggxVal * coatCol * (1.0f - metalness) * f_i * coatValue;
+      r.dval = v3s(0.0f);
+      r.pdf = ggxPdf;
+      r.flags = (roughness == 0.0f) ? RAY_EVENT_S : RAY_FLAG_HAS_NON_SPEC;
+    } else {
+      pdfSelect *= prob_diffuse;
+      r.dir = lambertDir;
+      r.val = baseColor * lambertVal * (1.0f - metalness);
+      r.dval = v3s(lambertVal * (1.0f - metalness));
+      r.pdf = lambertPdf;
+      r.flags = RAY_FLAG_HAS_NON_SPEC;
+      if (coatValue > 0.0f && fresnelIOR > 0.0f) {
+        const float m_fdr_int = m.data[GLTF_FLOAT_MI_FDR_INT];
+        const float f_o = frDielectricPBRT(absf(dot(lambertDir, n)), 1.0f, fresnelIOR);
+        const float k = lerpf(1.0f, (1.0f - f_i) * (1.0f - f_o) / (fresnelIOR * fresnelIOR * (1.0f - m_fdr_int)), coatValue);
+        r.val = r.val * k;
+        r.dval = r.dval * k;
+      }
+    }
+  }
+  r.pdf *= pdfSelect;
+}
+
+// include/cmat_gltf.h:93-147
+HPT_DEV void gltfEval(const MaterialRec& m, V3 l, V3 v, V3 n, V3 baseColor, V3 fourParams, BsdfE& res)
+{
+  const uint cflags = m.cflags;
+  const V3 Mcol = ld3(m.colors[GLTF_COLOR_METAL]);
+  const V3 metalCol = baseColor * Mcol;
+  const V3 coatCol = ld3(m.colors[GLTF_COLOR_COAT]);
+  const float roughness = clampf(1.0f - m.data[GLTF_FLOAT_GLOSINESS] * fourParams.x, 0.0f, 1.0f);
+  float metalness = m.data[GLTF_FLOAT_ALPHA] * fourParams.y;
+  const float coatValue = m.data[GLTF_FLOAT_REFL_COAT] * fourParams.z;
+  const float fresnelIOR = m.data[GLTF_FLOAT_IOR];
+  if (cflags == GLTF_COMPONENT_METAL) metalness = 1.0f;
+
+  float ggxVal, ggxPdf, VdotH;
+  if (roughness != 0.0f) {
+    ggxVal = ggxEvalBSDF(l, v, n, roughness);
+    ggxPdf = ggxEvalPDF(l, v, n, roughness);
+    VdotH = dot(v, normalize(v + l));
+  } else { ggxVal = 0.0f; ggxPdf = 0.0f; VdotH = dot(v, n); }
+
+  float lambertVal = HPT_INV_PI;
+  const float lambertPdf = absf(dot(l, n)) * HPT_INV_PI;
+  float f_i = 1.0f;
+  if (coatValue > 0.0f && metalness < 1.0f && fresnelIOR > 0.0f) {
+    f_i = frDielectricPBRT(absf(dot(v, n)), 1.0f, fresnelIOR);
+    const float f_o = frDielectricPBRT(absf(dot(l, n)), 1.0f, fresnelIOR);
+    const float m_fdr_int = m.data[GLTF_FLOAT_MI_FDR_INT];
+    const float coeff = lerpf(1.0f, (1.f - f_i) * (1.f - f_o) / (fresnelIOR * fresnelIOR * (1.f - m_fdr_int)), coatValue);
+    lambertVal *= coeff;
+  }
+  V3 fConductor = metalCol, dfc = Mcol;
+  if (fresnelIOR != 0.0f) { const float s = fresnelSlick(VdotH); fConductor = metalCol + (v3s(1.0f) - metalCol) * s; dfc = Mcol * (1.0f - s); }
+  const V3 specularColor = fConductor * ggxVal;
+  const float prob_specular = 0.5f * coatValue;
+  const float prob_diffuse = 1.0f - prob_specular;
+  const V3 dielectricVal = baseColor * lambertVal + ggxVal * coatCol * f_i * coatValue;
+  const float dielectricPdf = lambertPdf * prob_diffuse + ggxPdf * prob_specular;
+  res.val = specularColor * metalness + dielectricVal * (1.0f - metalness);
+  res.dval = dfc * (ggxVal * metalness) + v3s(lambertVal * (1.0f - metalness));
+  res.pdf = metalness * ggxPdf + (1.0f - metalness) * dielectricPdf;
+}
+
+// include/cmat_diffuse.h:8-39
+HPT_DEV void diffuseSampleAndEval(const MaterialRec& m, V3 reflSpec, V4 rands, V3 v, V3 n, BsdfS& r)
+{
+  const V3 lambertDir = mapSampleToCosineDistribution(rands.x, rands.y, n, n, 1.0f);
+  r.dir = lambertDir;
+  r.val = HPT_INV_PI * reflSpec;
+  r.pdf = absf(dot(lambertDir, n)) * HPT_INV_PI;
+  r.flags = RAY_FLAG_HAS_NON_SPEC;
+  if ((m.cflags & GLTF_COMPONENT_ORENNAYAR) != 0) r.val = r.val * orennayarFunc(lambertDir, (-1.0f) * v, n, m.data[0]);
+}
+HPT_DEV void diffuseEval(const MaterialRec& m, V3 reflSpec, V3 l, V3 v, V3 n, BsdfE& res)
+{
+  float lambertVal = HPT_INV_PI;
+  if ((m.cflags & GLTF_COMPONENT_ORENNAYAR) != 0) lambertVal *= orennayarFunc(l, v, n, m.data[0]);
+  res.val = lambertVal * reflSpec;
+  res.pdf = absf(dot(l, n)) * HPT_INV_PI;
+}
+
+// include/cmat_conductor.h (RGB mode: eta / k are the same scalar in every channel, integrator_spectrum.cpp:25-29)
+HPT_DEV void conductorSmoothSampleAndEval(const MaterialRec& m, float eta, float k, V3 v, V3 n, BsdfS& r)   // :7-28
+{
+  const V3 pefReflDir = reflect((-1.0f) * v, n);
+  const float cosThetaOut = dot(pefReflDir, n);
+  float val = frComplexConductor(cosThetaOut, cx(eta, k));
+  val = (cosThetaOut <= 1e-6f) ? 0.0f : (val / smax(cosThetaOut, 1e-6f));
+  r.val = v3s(val) * ld3(m.colors[0]);
+  r.dir = pefReflDir;
+  r.pdf = 1.0f;
+  r.flags = RAY_EVENT_S;
+}
+HPT_DEV float conductorRoughEvalInternal(V3 wo, V3 wi, V3 wm, V2 alpha, Cx ior)   // :42-58
+{
+  if (wo.z * wi.z < 0) return 0.0f;
+  const float cosTheta_o = absf(wo.z), cosTheta_i = absf(wi.z);
+  if (cosTheta_i == 0 || cosTheta_o == 0) return 0.0f;
+  const float F = frComplexConductor(absf(dot(wo, wm)), ior);
+  return trD(wm, alpha) * F * trG(wo, wi, alpha) / (4.0f * cosTheta_i * cosTheta_o);
+}
+HPT_DEV void conductorRoughSampleAndEval(const MaterialRec& m, float eta, float k, V4 rands, V3 v, V3 n, V3 alpha_tex, BsdfS& r)   // :61-100
+{
+  if (v.z == 0) return;
+  const V2 alpha = v2(smin(m.data[0], alpha_tex.x), smin(m.data[1], alpha_tex.y));
+  V3 nx, ny;
+  coordinateSystemV2(n, nx, ny);
+  const V3 wo = v3(dot(v, nx), dot(v, ny), dot(v, n));
+  if (wo.z == 0) return;
+  const V3 wm = trSample(wo, v2(rands.x, rands.y), alpha);
+  const V3 wi = reflect((-1.0f) * wo, wm);
+  if (wo.z * wi.z < 0) return;
+  const float val = conductorRoughEvalInternal(wo, wi, wm, alpha, cx(eta, k));
+  r.val = v3s(val) * ld3(m.colors[0]);
+  r.dir = normalize(wi.x * nx + wi.y * ny + wi.z * n);
+  r.pdf = trPDF(wo, wm, alpha) / (4.0f * absf(dot(wo, wm)));
+  r.flags = RAY_FLAG_HAS_NON_SPEC;
+}
+HPT_DEV void conductorRoughEval(const MaterialRec& m, float eta, float k, V3 l, V3 v, V3 n, V3 alpha_tex, BsdfE& res)   // :103-137
+{
+  const V2 alpha = v2(smin(m.data[0], alpha_tex.x), smin(m.data[1], alpha_tex.y));
+  V3 nx, ny;
+  coordinateSystemV2(n, nx, ny);
+  const V3 wo = v3(dot(v, nx), dot(v, ny), dot(v, n));
+  const V3 wi = v3(dot(l, nx), dot(l, ny), dot(l, n));
+  if (wo.z * wi.z < 0.0f) return;
+  V3 wm = wo + wi;
+  if (dot(wm, wm) == 0) return;
+  wm = normalize(wm);
+  const float val = conductorRoughEvalInternal(wo, wi, wm, alpha, cx(eta, k));
+  res.val = v3s(val) * ld3(m.colors[0]);
+  if (dot(wm, v3(0.0f, 0.0f, 1.0f)) < 0.f) wm = (-1.0f) * wm;       // FaceForward
+  res.pdf = trPDF(wo, wm, alpha) / (4.0f * absf(dot(wo, wm)));
+}
+
+// include/cmat_dielectric.h:8-56
+HPT_DEV void dielectricSmoothSampleAndEval(const MaterialRec& m, float etaInt, float _extIOR, V4 rands, V3 v, V3 n, BsdfS& r)
+{
+  const float extIOR = m.data[0];
+  if ((r.flags & RAY_FLAG_HAS_INV_NORMAL) != 0) n = (-1.0f) * n;
+  V3 s, t;
+  coordinateSystemV2(n, s, t);
+  const V3 wi = v3(dot(v, s), dot(v, t), dot(v, n));
+  const float eta = etaInt / extIOR;
+  const V4 fr = frDielectricDetailedV2(wi.z, eta);
+  const float R = fr.x, cos_theta_t = fr.y, eta_ti = fr.w;
+  const float T = 1 - R;
+  if (rands.x < R) {
+    const V3 wo = v3(-wi.x, -wi.y, wi.z);
+    r.val = v3s(R);
+    r.pdf = R;
+    r.dir = normalize(wo.x * s + wo.y * t + wo.z * n);
+    r.flags |= RAY_EVENT_S;
+    r.ior = _extIOR;
+  } else {
+    const V3 wo = v3(-eta_ti * wi.x, -eta_ti * wi.y, cos_theta_t);   // refract (cmaterial.h:917-920)
+    r.val = v3s((eta_ti * eta_ti) * T);
+    r.pdf = T;
+    r.dir = normalize(wo.x * s + wo.y * t + wo.z * n);
+    r.flags |= (RAY_EVENT_S | RAY_EVENT_T);
+    r.ior = (_extIOR == etaInt) ? extIOR : etaInt;
+  }
+  r.val = r.val / smax(absf(dot(r.dir, n)), 1e-6f);
+}
+
+// ---- lights: include/clight.h:58-126, integrator_pt_lgt.cpp:21-173 ------------------------------------------------------
+struct LightSam { V3 pos, norm; float pdf; bool isOmni, hasIES; };
+
+HPT_DEV LightSam lightSampleRev(const LightRec& L, V3 rands, V3 illuminationPoint)
+{
+  LightSam r;
+  r.pdf = 1.0f; r.isOmni = false; r.hasIES = (L.iesId != 0xFFFFFFFFu);
+  const uint g = L.geomType;
+  if (g == LIGHT_GEOM_DIRECT) {
+    const V3 norm = ld3(L.norm);
+    r.pos = illuminationPoint - norm * 100000.0f; r.norm = norm; r.hasIES = false;
+  } else if (g == LIGHT_GEOM_SPHERE) {
+    const float theta = 2.0f * HPT_PI * rands.x;
+    const float phi = acosf(1.0f - 2.0f * rands.y);
+    const float x = sinf(phi) * cosf(theta), y = sinf(phi) * sinf(theta), z = cosf(phi);
+    const V3 lcenter = ld3(L.pos);
+    const V3 samplePos = lcenter + (L.size[0] * 1.000001f) * v3(x, y, z);
+    r.pos = samplePos; r.norm = normalize(samplePos - lcenter);
+  } else if (g == LIGHT_GEOM_POINT) {
+    r.pos = ld3(L.pos); r.norm = ld3(L.norm); r.isOmni = (L.distType == LIGHT_DIST_OMNI);
+  } else {                                                   // rect / disc (clight.h:67-84)
+    V2 off = v2((2.0f * (-0.5f + rands.x)) * L.size[0], (2.0f * (-0.5f + rands.y)) * L.size[1]);
+    if (g == LIGHT_GEOM_DISC) {
+      const V2 d = mapSamplesToDisc(v2(rands.x * 2.0f - 1.0f, rands.y * 2.0f - 1.0f));
+      off = v2(d.x * L.size[0], d.y * L.size[0]);
+    }
+    const V3 lp = ld3(L.pos);
+    r.pos = mul3x3(L.matrix, v3(off.x, 0.0f, off.y)) + lp + epsilonOfPos(lp) * ld3(L.norm);
+    r.norm = ld3(L.norm);
+  }
+  return r;
+}
+
+HPT_DEV float lightEvalPDF(const LightRec& L, V3 illuminationPoint, V3 ray_dir, V3 lpos, V3 lnorm, float a_envPdf)   // :71-107
+{
+  const uint g = L.geomType;
+  if (g == LIGHT_GEOM_ENV) return a_envPdf;
+  const float hitDist = length(illuminationPoint - lpos);
+  const float cosValTmp = dot(ray_dir, -1.0f * lnorm);
+  float cosVal = 1.0f;
+  if (g == LIGHT_GEOM_SPHERE) { const V3 dirToV = normalize(lpos - illuminationPoint); cosVal = absf(dot(dirToV, lnorm)); }
+  else if (g == LIGHT_GEOM_POINT) { if (L.distType == LIGHT_DIST_LAMBERT) cosVal = smax(cosValTmp, 0.0f); }
+  else cosVal = (L.iesId == 0xFFFFFFFFu) ? smax(cosValTmp, 0.0f) : absf(cosValTmp);
+  return pdfAtoW(L.pdfA, hitDist, cosVal);
+}
+
+HPT_DEV V3 lightIntensity(const DevScene& S, const LightRec& L, V3 a_rayPos, V3 a_rayDir)   // :109-173 (RGB; env / projective out of scope)
+{
+  V3 lightColor = ld3(L.intensity);
+  lightColor = lightColor * L.mult;
+  if (L.iesId != 0xFFFFFFFFu) {
+    if ((L.flags & LIGHT_FLAG_POINT_AREA) != 0) a_rayDir = normalize(ld3(L.pos) - a_rayPos);
+    const V4 dt = mul4x4(L.iesMatrix, v4(a_rayDir.x, a_rayDir.y, a_rayDir.z, 0.0f));
+    const V2 tc = sphereMapTo2DTexCoord((-1.0f) * v3(dt.x, dt.y, dt.z));
+    const V4 texColor = texSample(S.textures, L.iesId, tc);
+    lightColor = lightColor * v3(texColor.x, texColor.y, texColor.z);
+  }
+  if (L.distType == LIGHT_DIST_SPOT) {
+    const float cos_theta = smax(-dot(a_rayDir, ld3(L.norm)), 0.0f);
+    const float tVal = (cos_theta - L.lightCos2) / (L.lightCos1 - L.lightCos2);    // mylocalsmoothstep (clight.h:220-225)
+    const float t = smin(smax(tVal, 0.0f), 1.0f);
+    lightColor = lightColor * (t * t * (3.0f - 2.0f * t));
+  }
+  return lightColor;
+}
+
+// RemapMaterialId (integrator_pt_mat.cpp:530-573)
+HPT_DEV uint remapMaterialId(const DevScene& S, uint a_mId, uint a_instId)
+{
+  const int remapListId = S.remapInst[2 * a_instId + 0];
+  if (remapListId == -1) return a_mId;
+  const int r_offset = S.allRemapLists[S.allRemapListsSize + remapListId];
+  const int r_size = S.allRemapLists[S.allRemapListsSize + remapListId + 1] - r_offset;
+  uint res = a_mId;
+  int low = 0, high = r_size - 1;
+  while (low <= high) {
+    const int mid = low + ((high - low) / 2);
+    const int idRemapFrom = S.allRemapLists[r_offset + mid * 2 + 0];
+    if (uint(idRemapFrom) >= a_mId) high = mid - 1; else low = mid + 1;
+  }
+  if (high + 1 < r_size) {
+    const int idRemapFrom = S.allRemapLists[r_offset + (high + 1) * 2 + 0];
+    const int idRemapTo = S.allRemapLists[r_offset + (high + 1) * 2 + 1];
+    res = (uint(idRemapFrom) == a_mId) ? uint(idRemapTo) : a_mId;
+  }
+  return res;
+}
+
+// ---- BVH2 traversal: replaces ISceneObject::RayQuery_NearestHit / RayQuery_AnyHit (CrossRT.h:148-176) ---------------------
+// Semantics of the Embree backend (EmbreeRT.cpp:310-484): two-level scene, ray taken into object space with the inverse
+// instance matrix, t shared between spaces, no back-face culling, hit iff tnear <= t <= tfar.
+// Closest hit = min t with ties broken by (instId, primId): independent of tree shape and traversal order.
+struct HitRec { float t; uint prim, inst; float u, v; };   // inst == 0xFFFFFFFF: miss
+
+struct TravStats { uint nodes, tris, insts; };
+
+template <bool ANY, bool STATS>
+HPT_DEV bool traceRay(const DevScene& S, V3 o, V3 d, float tnear, float tfar, HitRec& hit, uint* stk /* LDS: &stack[0][lane] */, const int stride, TravStats& st)
+{
+  hit.t = tfar; hit.prim = 0xFFFFFFFFu; hit.inst = 0xFFFFFFFFu; hit.u = 0.0f; hit.v = 0.0f;
+  bool found = false;
+  uint cur = S.rootRef;
+  if (cur == REF_NONE) return false;
+
+  const V3 wo = o, wd = d;                                   // world-space ray, restored when an instance is left
+  V3 id = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  const V3 wid = id;
+  uint curInst = 0xFFFFFFFFu;
+  int sp = 0;
+
+  while (true) {
+    bool pop = false;
+    if ((cur & REF_LEAF) == 0u) {
+      // ---- inner node: one 64-byte line, both child boxes ---------------------------------------------------------
+      const float4* np = (const float4*)(S.nodes + cur);
+      const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+      const uint4  q3 = ((const uint4*)np)[3];
+      if (STATS) st.nodes++;
+      const float best = hit.t;
+      // slabs of child 0: lo = (q0.x q0.y q0.z), hi = (q0.w q1.x q1.y); child 1: lo = (q1.z q1.w q2.x), hi = (q2.y q2.z q2.w)
+      float ax = (q0.x - o.x) * id.x, bx = (q0.w - o.x) * id.x;
+      float ay = (q0.y - o.y) * id.y, by = (q1.x - o.y) * id.y;
+      float az = (q0.z - o.z) * id.z, bz = (q1.y - o.z) * id.z;
+      const float t0n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tnear));
+      const float t0f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
+      ax = (q1.z - o.x) * id.x; bx = (q2.y - o.x) * id.x;
+      ay = (q1.w - o.y) * id.y; by = (q2.z - o.y) * id.y;
+      az = (q2.x - o.z) * id.z; bz = (q2.w - o.z) * id.z;
+      const float t1n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tnear));
+      const float t1f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
+      // boxes were padded by the builder; widen the interval by a few ulps so the test stays conservative
+      const bool h0 = (t0n * 0.9999995f <= t0f * 1.0000005f);
+      const bool h1 = (t1n * 0.9999995f <= t1f * 1.0000005f);
+      if (h0 && h1) {
+        const bool firstIs0 = t0n <= t1n;
+        stk[sp * stride] = firstIs0 ? q3.y : q3.x;
+        sp++;
+        cur = firstIs0 ? q3.x : q3.y;
+      } else if (h0) cur = q3.x;
+      else if (h1) cur = q3.y;
+      else pop = true;
+    } else {
+      const uint cnt = (cur >> 28) & 7u;
+      if (cnt == 0u) {
+        // ---- instance leaf: enter object space ---------------------------------------------------------------------
+        const uint inst = cur & 0x0FFFFFFFu;
+        const float4* ip = (const float4*)(S.insts + inst);
+        const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
+        const uint4  r3 = ((const uint4*)ip)[3];
+        if (STATS) st.insts++;
+        o = v3(r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w,
+               r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w,
+               r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w);
+        d = v3(r0.x * wd.x + r0.y * wd.y + r0.z * wd.z,
+               r1.x * wd.x + r1.y * wd.y + r1.z * wd.z,
+               r2.x * wd.x + r2.y * wd.y + r2.z * wd.z);
+        id = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        curInst = inst;
+        stk[sp * stride] = REF_RESTORE;
+        sp++;
+        cur = r3.x;
+      } else if (cnt == 7u) {
+        // ---- marker: back to world space ----------------------------------------------------------------------------
+        o = wo; d = wd; id = wid; curInst = 0xFFFFFFFFu;
+        pop = true;
+      } else {
+        // ---- triangle leaf: Moeller-Trumbore on (v0, e1, e2), 3 x 16-byte loads per triangle -----------------------
+        const uint first = cur & 0x0FFFFFFFu;
+        for (uint k = 0; k < cnt; k++) {
+          const float4* tp = (const float4*)(S.tris + first + k);
+          const float4 a = tp[0], b = tp[1], c = tp[2];
+          if (STATS) st.tris++;
+          const V3 e1 = v3(b.x, b.y, b.z), e2 = v3(c.x, c.y, c.z);
+          const V3 pvec = cross(d, e2);
+          const float det = dot(e1, pvec);
+          const float inv = 1.0f / det;
+          const V3 tvec = o - v3(a.x, a.y, a.z);
+          const float uu = dot(tvec, pvec) * inv;
+          const V3 qvec = cross(tvec, e1);
+          const float vv = dot(d, qvec) * inv;
+          const float tt = dot(e2, qvec) * inv;
+          const uint prim = __float_as_uint(a.w);
+          bool ok = (det != 0.0f) && (uu >= 0.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f) && (tt >= tnear) && (tt <= hit.t);
+          if (ok && found && tt == hit.t)            // equal distance: lower (instId, primId) wins
+            ok = (curInst != hit.inst) ? (curInst < hit.inst) : (prim < hit.prim);
+          if (ok) {
+            hit.t = tt; hit.prim = prim; hit.inst = curInst; hit.u = uu; hit.v = vv; found = true;
+            if (ANY) return true;
+          }
+        }
+        pop = true;
+      }
+    }
+    if (pop) {
+      if (sp == 0) break;
+      sp--;
+      cur = stk[sp * stride];
+    }
+  }
+  return found;
+}
+
+} // namespace hpt

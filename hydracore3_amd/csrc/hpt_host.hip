@@ -1,0 +1,711 @@
+// Host side of the C ABI (include/hydra_hip.h): context, BVH2 build + upload, scene tables, launches, timing.
+// Compiled by hipcc together with the kernels; exports only the extern "C" hpt_* symbols.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <chrono>
+
+#include "../../include/hydra_hip.h"
+#include "hpt_kernels.hip"
+#include "bvh_build.h"
+
+using namespace hpt;
+
+namespace {
+
+struct Geom
+{
+  std::vector<float> pos;        // xyz per vertex (tightly packed copy)
+  std::vector<uint>  idx;
+  Bvh2               bvh;        // local references
+  std::vector<BvhTri> tris;      // BVH order
+  bool               dirty = true;
+};
+
+struct Inst { uint geomId; float m[16]; };
+
+template <class T>
+struct DevBuf
+{
+  T* p = nullptr; size_t n = 0;
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  hipError_t alloc(size_t count) { if (count <= n && p) return hipSuccess; release(); n = count; return count ? hipMalloc((void**)&p, count * sizeof(T)) : hipSuccess; }
+  hipError_t upload(const T* src, size_t count)
+  {
+    hipError_t e = alloc(count); if (e != hipSuccess) return e;
+    return count ? hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice) : hipSuccess;
+  }
+};
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+} // namespace
+
+struct hpt_ctx
+{
+  int device = 0, numCUs = 256;
+  std::string err, devName;
+
+  // ISceneObject state
+  std::vector<Geom> geoms;
+  std::vector<Inst> insts;
+  bool accelCommitted = false;
+  uint stackNeeded = 0;
+
+  // device buffers
+  DevBuf<BvhNode> dNodes; DevBuf<BvhTri> dTris; DevBuf<BvhInst> dInsts;
+  DevBuf<uint> dTriIndices, dMatIdByPrim, dMatVertOffset, dPackedXY;
+  DevBuf<float> dVData, dNormMat;
+  DevBuf<int> dRemapInst, dRemapLists;
+  DevBuf<MaterialRec> dMaterials; DevBuf<LightRec> dLights; DevBuf<TexRec> dTextures;
+  std::vector<void*> texData; std::vector<TexRec> hTextures;
+  DevBuf<Rng> dGens;
+  DevBuf<uint> dQueue; DevBuf<Counters> dCounters;
+  DevBuf<float> dFrame, dRecord, dRef, dData, dGrad, dLoss;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+  DevScene S;
+  bool sceneUploaded = false, paramsSet = false;
+  uint packedCount = 0;
+  int  blocksPerCU = 0;
+  bool instrument = false;
+  uint64_t gradSize = 0;
+
+  // GetExecutionTime slots
+  float tPathTrace[4] = {0, 0, 0, 0}, tNaive[4] = {0, 0, 0, 0}, tDR[4] = {0, 0, 0, 0};
+  float lastKernelMs = 0.0f;
+
+  int fail(int code, const std::string& m) { err = m; std::fprintf(stderr, "[hydra_hip] %s\n", m.c_str()); return code; }
+  int hipFail(hipError_t e, const char* what) { return fail(HPT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
+};
+
+#define HIPCHK(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) return (ctx)->hipFail(_e, #call); } while (0)
+
+// ---- lifetime -----------------------------------------------------------------------------------------------------------------
+extern "C" int hpt_create(int device, hpt_ctx** out)
+{
+  if (!out) return HPT_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) { std::fprintf(stderr, "[hydra_hip] no HIP device: %s\n", hipGetErrorString(e)); return HPT_ERR_HIP; }
+  if (device < 0 || device >= n) return HPT_ERR_ARG;
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return HPT_ERR_HIP;
+  hpt_ctx* c = new hpt_ctx();
+  c->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) { c->numCUs = prop.multiProcessorCount; c->devName = prop.gcnArchName; }
+  (void)hipEventCreate(&c->ev0); (void)hipEventCreate(&c->ev1);
+  std::memset(&c->S, 0, sizeof(DevScene));
+  c->S.rootRef = REF_NONE;
+  *out = c;
+  return HPT_OK;
+}
+
+extern "C" void hpt_destroy(hpt_ctx* c)
+{
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  c->dNodes.release(); c->dTris.release(); c->dInsts.release(); c->dTriIndices.release(); c->dMatIdByPrim.release();
+  c->dMatVertOffset.release(); c->dPackedXY.release(); c->dVData.release(); c->dNormMat.release(); c->dRemapInst.release();
+  c->dRemapLists.release(); c->dMaterials.release(); c->dLights.release(); c->dTextures.release(); c->dGens.release();
+  c->dQueue.release(); c->dCounters.release(); c->dFrame.release(); c->dRecord.release(); c->dRef.release(); c->dData.release();
+  c->dGrad.release(); c->dLoss.release();
+  for (void* p : c->texData) if (p) (void)hipFree(p);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  delete c;
+}
+
+extern "C" const char* hpt_last_error(hpt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int hpt_device_info(hpt_ctx* c, int* numCUs, int* wavefront, char* name, size_t nameLen)
+{
+  if (!c) return HPT_ERR_ARG;
+  if (numCUs) *numCUs = c->numCUs;
+  if (wavefront) *wavefront = 64;
+  if (name && nameLen) { std::strncpy(name, c->devName.c_str(), nameLen - 1); name[nameLen - 1] = 0; }
+  return HPT_OK;
+}
+
+// ---- ISceneObject ---------------------------------------------------------------------------------------------------------------
+extern "C" int hpt_clear_geom(hpt_ctx* c)
+{
+  if (!c) return HPT_ERR_ARG;
+  c->geoms.clear(); c->insts.clear(); c->accelCommitted = false;
+  return HPT_OK;
+}
+
+static int fill_geom(hpt_ctx* c, Geom& g, const float* vpos, size_t nVert, const uint32_t* idx, size_t nIdx, size_t stride)
+{
+  if (stride == 0) stride = sizeof(float) * 3;
+  if (stride % sizeof(float) != 0) return c->fail(HPT_ERR_ARG, "AddGeom_Triangles3f: vByteStride must be a multiple of sizeof(float)");
+  if (!vpos || !idx) return c->fail(HPT_ERR_ARG, "AddGeom_Triangles3f: nullptr input");
+  const size_t fs = stride / sizeof(float);
+  g.pos.resize(nVert * 3);
+  for (size_t i = 0; i < nVert; i++) { g.pos[3 * i + 0] = vpos[fs * i + 0]; g.pos[3 * i + 1] = vpos[fs * i + 1]; g.pos[3 * i + 2] = vpos[fs * i + 2]; }
+  g.idx.assign(idx, idx + (nIdx / 3) * 3);
+  for (uint v : g.idx) if (v >= nVert) return c->fail(HPT_ERR_ARG, "AddGeom_Triangles3f: index out of range");
+  g.dirty = true;
+  return HPT_OK;
+}
+
+extern "C" uint32_t hpt_add_geom_triangles3f(hpt_ctx* c, const float* vpos, size_t nVert, const uint32_t* idx, size_t nIdx, uint32_t, size_t stride)
+{
+  if (!c) return 0xFFFFFFFFu;
+  Geom g;
+  if (fill_geom(c, g, vpos, nVert, idx, nIdx, stride) != HPT_OK) return 0xFFFFFFFFu;
+  c->geoms.push_back(std::move(g));
+  c->accelCommitted = false;
+  return (uint32_t)(c->geoms.size() - 1);
+}
+
+extern "C" int hpt_update_geom_triangles3f(hpt_ctx* c, uint32_t geomId, const float* vpos, size_t nVert, const uint32_t* idx, size_t nIdx, uint32_t, size_t stride)
+{
+  if (!c) return HPT_ERR_ARG;
+  if (geomId >= c->geoms.size()) return c->fail(HPT_ERR_ARG, "UpdateGeom_Triangles3f: bad geomId");
+  Geom& g = c->geoms[geomId];
+  if (nIdx > g.idx.size() || nVert * 3 > g.pos.size()) return c->fail(HPT_ERR_ARG, "UpdateGeom_Triangles3f: growing a geometry is not supported");
+  c->accelCommitted = false;
+  return fill_geom(c, g, vpos, nVert, idx, nIdx, stride);
+}
+
+extern "C" int hpt_clear_scene(hpt_ctx* c) { if (!c) return HPT_ERR_ARG; c->insts.clear(); c->accelCommitted = false; return HPT_OK; }
+
+extern "C" uint32_t hpt_add_instance(hpt_ctx* c, uint32_t geomId, const float m[16])
+{
+  if (!c || !m || geomId >= c->geoms.size()) return 0xFFFFFFFFu;
+  Inst in; in.geomId = geomId; std::memcpy(in.m, m, 64);
+  c->insts.push_back(in);
+  c->accelCommitted = false;
+  return (uint32_t)(c->insts.size() - 1);
+}
+
+extern "C" int hpt_update_instance(hpt_ctx* c, uint32_t instId, const float m[16])
+{
+  if (!c || !m) return HPT_ERR_ARG;
+  if (instId >= c->insts.size()) return HPT_OK;          // the reference silently ignores it (EmbreeRT.cpp:302-303)
+  std::memcpy(c->insts[instId].m, m, 64);
+  c->accelCommitted = false;
+  return HPT_OK;
+}
+
+// world -> object rows of an instance matrix (column-major 4x4, affine): cofactor inverse in double, rounded once
+static void inverse_rows(const float* m, float row0[4], float row1[4], float row2[4])
+{
+  const double a00 = m[0], a01 = m[4], a02 = m[8],  tx = m[12];
+  const double a10 = m[1], a11 = m[5], a12 = m[9],  ty = m[13];
+  const double a20 = m[2], a21 = m[6], a22 = m[10], tz = m[14];
+  const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+  const double det = a00 * c00 + a01 * c01 + a02 * c02;
+  const double id = 1.0 / det;
+  const double i00 = c00 * id, i01 = (a02 * a21 - a01 * a22) * id, i02 = (a01 * a12 - a02 * a11) * id;
+  const double i10 = c01 * id, i11 = (a00 * a22 - a02 * a20) * id, i12 = (a02 * a10 - a00 * a12) * id;
+  const double i20 = c02 * id, i21 = (a01 * a20 - a00 * a21) * id, i22 = (a00 * a11 - a01 * a10) * id;
+  row0[0] = (float)i00; row0[1] = (float)i01; row0[2] = (float)i02; row0[3] = (float)(-(i00 * tx + i01 * ty + i02 * tz));
+  row1[0] = (float)i10; row1[1] = (float)i11; row1[2] = (float)i12; row1[3] = (float)(-(i10 * tx + i11 * ty + i12 * tz));
+  row2[0] = (float)i20; row2[1] = (float)i21; row2[2] = (float)i22; row2[3] = (float)(-(i20 * tx + i21 * ty + i22 * tz));
+}
+
+static int ceil_log2(size_t v) { int l = 0; while ((size_t(1) << l) < v) l++; return l; }
+
+extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
+{
+  if (!c) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  // ---- bottom level: one BVH2 per mesh over object-space triangles ----
+  uint maxBlasDepth = 0;
+  for (Geom& g : c->geoms) {
+    if (!g.dirty) { maxBlasDepth = std::max(maxBlasDepth, g.bvh.depth); continue; }
+    const size_t nt = g.idx.size() / 3;
+    std::vector<Aabb> boxes(nt);
+    for (size_t t = 0; t < nt; t++) {
+      boxes[t].reset();
+      for (int k = 0; k < 3; k++) boxes[t].grow(&g.pos[3 * g.idx[3 * t + k]]);
+    }
+    const int depthCap = std::max(24, ceil_log2((nt + BVH_LEAF_MAX - 1) / BVH_LEAF_MAX) + 2);
+    g.bvh = Bvh2Builder::build(boxes, BVH_LEAF_MAX, depthCap, false);
+    g.tris.resize(nt);
+    for (size_t i = 0; i < nt; i++) {
+      const uint p = g.bvh.order[i];
+      const float* A = &g.pos[3 * g.idx[3 * p + 0]]; const float* B = &g.pos[3 * g.idx[3 * p + 1]]; const float* C = &g.pos[3 * g.idx[3 * p + 2]];
+      BvhTri& t = g.tris[i];
+      for (int a = 0; a < 3; a++) { t.v0[a] = A[a]; t.e1[a] = B[a] - A[a]; t.e2[a] = C[a] - A[a]; }
+      t.primId = p; t.pad0 = t.pad1 = 0;
+    }
+    g.dirty = false;
+    maxBlasDepth = std::max(maxBlasDepth, g.bvh.depth);
+  }
+  // ---- top level over the instances' world boxes ----
+  const size_t ni = c->insts.size();
+  std::vector<Aabb> ib; std::vector<uint> liveInst;
+  for (size_t i = 0; i < ni; i++) {
+    const Geom& g = c->geoms[c->insts[i].geomId];
+    if (g.bvh.rootRef == REF_NONE) continue;               // empty mesh: never enters the TLAS
+    Aabb w; w.reset();
+    const float* m = c->insts[i].m;
+    for (int k = 0; k < 8; k++) {
+      const float p[3] = { (k & 1) ? g.bvh.bounds.hi[0] : g.bvh.bounds.lo[0], (k & 2) ? g.bvh.bounds.hi[1] : g.bvh.bounds.lo[1], (k & 4) ? g.bvh.bounds.hi[2] : g.bvh.bounds.lo[2] };
+      const float q[3] = { m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12], m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13], m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14] };
+      w.grow(q);
+    }
+    w.pad();
+    ib.push_back(w); liveInst.push_back((uint)i);
+  }
+  Bvh2 tlas = Bvh2Builder::build(ib, 1, std::max(16, ceil_log2(ib.size() + 1) + 2), true);
+  // instance leaves refer to positions in `ib`; map them back to real instance ids
+  auto fixInst = [&](uint ref) -> uint {
+    if (ref != REF_NONE && (ref & REF_LEAF) && ((ref >> 28) & 7u) == 0u) return REF_LEAF | liveInst[ref & 0x0FFFFFFFu];
+    return ref;
+  };
+  // ---- flatten: [TLAS nodes][BLAS 0 nodes][BLAS 1 nodes]...  /  [tris 0][tris 1]... ----
+  std::vector<BvhNode> nodes(tlas.nodes);
+  for (BvhNode& n : nodes) { n.ref0 = fixInst(n.ref0); n.ref1 = fixInst(n.ref1); }
+  const uint rootRef = fixInst(tlas.rootRef);
+  std::vector<BvhTri> tris;
+  std::vector<uint> geomRoot(c->geoms.size(), REF_NONE);
+  for (size_t gi = 0; gi < c->geoms.size(); gi++) {
+    const Geom& g = c->geoms[gi];
+    const uint nodeBase = (uint)nodes.size(), triBase = (uint)tris.size();
+    for (BvhNode n : g.bvh.nodes) { n.ref0 = patchRef(n.ref0, nodeBase, triBase); n.ref1 = patchRef(n.ref1, nodeBase, triBase); nodes.push_back(n); }
+    tris.insert(tris.end(), g.tris.begin(), g.tris.end());
+    geomRoot[gi] = patchRef(g.bvh.rootRef, nodeBase, triBase);
+  }
+  if (tris.size() >= (size_t(1) << 28) || nodes.size() >= (size_t(1) << 31)) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: scene too large for 28-bit triangle references");
+  std::vector<BvhInst> dinst(ni);
+  for (size_t i = 0; i < ni; i++) {
+    inverse_rows(c->insts[i].m, dinst[i].row0, dinst[i].row1, dinst[i].row2);
+    dinst[i].root = geomRoot[c->insts[i].geomId]; dinst[i].geomId = c->insts[i].geomId; dinst[i].pad0 = dinst[i].pad1 = 0;
+  }
+  if (nodes.empty()) nodes.push_back(BvhNode());           // keep the pointers valid
+  if (tris.empty()) tris.push_back(BvhTri());
+  HIPCHK(c, c->dNodes.upload(nodes.data(), nodes.size()));
+  HIPCHK(c, c->dTris.upload(tris.data(), tris.size()));
+  HIPCHK(c, c->dInsts.upload(dinst.data(), std::max<size_t>(dinst.size(), 1)));
+  c->S.nodes = c->dNodes.p; c->S.tris = c->dTris.p; c->S.insts = c->dInsts.p;
+  c->S.rootRef = rootRef; c->S.numInsts = (uint)ni;
+  c->stackNeeded = tlas.depth + 1u + maxBlasDepth + 1u;
+  if (c->stackNeeded > 64u) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: BVH deeper than the 64-entry traversal stack");
+  c->accelCommitted = true;
+  return HPT_OK;
+}
+
+template <int STACK>
+static void launchRayQuery(hpt_ctx* c, const float4* p, const float4* d, uint n, void* out, int any)
+{
+  rayQueryKernel<STACK><<<dim3((n + 255) / 256), dim3(256), 0, 0>>>(c->S, p, d, n, out, any);
+}
+
+static int ray_query(hpt_ctx* c, const float* posNear, const float* dirFar, uint32_t n, void* out, int any)
+{
+  if (!c || !posNear || !dirFar || !out) return HPT_ERR_ARG;
+  if (!c->accelCommitted) return c->fail(HPT_ERR_STATE, "RayQuery before CommitScene");
+  if (n == 0) return HPT_OK;
+  (void)hipSetDevice(c->device);
+  DevBuf<float4> dp, dd; DevBuf<uint> dout;
+  const size_t outWords = any ? n : (size_t)n * 8;
+  HIPCHK(c, dp.upload((const float4*)posNear, n));
+  HIPCHK(c, dd.upload((const float4*)dirFar, n));
+  HIPCHK(c, dout.alloc(outWords));
+  if (c->stackNeeded <= 32) launchRayQuery<32>(c, dp.p, dd.p, n, dout.p, any); else launchRayQuery<64>(c, dp.p, dd.p, n, dout.p, any);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpy(out, dout.p, outWords * 4, hipMemcpyDeviceToHost));
+  dp.release(); dd.release(); dout.release();
+  return HPT_OK;
+}
+
+extern "C" int hpt_ray_query_nearest(hpt_ctx* c, const float* p, const float* d, uint32_t n, hpt_hit* out) { return ray_query(c, p, d, n, out, 0); }
+extern "C" int hpt_ray_query_any(hpt_ctx* c, const float* p, const float* d, uint32_t n, uint32_t* out) { return ray_query(c, p, d, n, out, 1); }
+
+// ---- scene tables -----------------------------------------------------------------------------------------------------------------
+static int check_materials(hpt_ctx* c, const MaterialRec* m, size_t n, size_t numTex)
+{
+  for (size_t i = 0; i < n; i++) {
+    const uint t = m[i].mtype;
+    if (t != MAT_TYPE_GLTF && t != MAT_TYPE_CONDUCTOR && t != MAT_TYPE_DIFFUSE && t != MAT_TYPE_DIELECTRIC && t != MAT_TYPE_LIGHT_SOURCE)
+      return c->fail(HPT_ERR_UNSUPPORTED, "material type " + std::to_string(t) + " (glass / plastic / blend / thin film) is outside the hot path's scope");
+    if (m[i].texid[1] != 0xFFFFFFFFu) return c->fail(HPT_ERR_UNSUPPORTED, "normal-map bump is outside the hot path's scope");
+    if (m[i].texid[0] >= numTex) return c->fail(HPT_ERR_ARG, "material refers to a texture that does not exist");
+    if ((m[i].cflags & FLAG_FOUR_TEXTURES) && (m[i].texid[2] >= numTex || m[i].texid[3] >= numTex)) return c->fail(HPT_ERR_ARG, "material refers to a texture that does not exist");
+  }
+  return HPT_OK;
+}
+static int check_lights(hpt_ctx* c, const LightRec* l, size_t n, size_t numTex)
+{
+  for (size_t i = 0; i < n; i++) {
+    if (l[i].geomType == LIGHT_GEOM_ENV) return c->fail(HPT_ERR_UNSUPPORTED, "sampled environment-map lights are outside the hot path's scope");
+    if (l[i].geomType < LIGHT_GEOM_RECT || l[i].geomType > LIGHT_GEOM_ENV) return c->fail(HPT_ERR_ARG, "bad light geomType");
+    if (l[i].iesId != 0xFFFFFFFFu && l[i].iesId >= numTex) return c->fail(HPT_ERR_ARG, "light refers to an IES texture that does not exist");
+  }
+  return HPT_OK;
+}
+
+extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
+{
+  if (!c || !d) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  const double t0 = now_ms();
+  if (d->numTextures == 0 || !d->textures) return c->fail(HPT_ERR_ARG, "m_textures must at least hold the white dummy texture");
+  int rc = check_materials(c, (const MaterialRec*)d->materials, d->numMaterials, d->numTextures); if (rc) return rc;
+  rc = check_lights(c, (const LightRec*)d->lights, d->numLights, d->numTextures); if (rc) return rc;
+
+  if (d->vPos4f) {                                                     // LoadSceneGeometry + LoadSceneInstances order
+    hpt_clear_geom(c);
+    for (uint g = 0; g < d->numGeoms; g++) {
+      const uint triOff = d->matVertOffset[2 * g + 0], vertOff = d->matVertOffset[2 * g + 1];
+      const uint32_t id = hpt_add_geom_triangles3f(c, d->vPos4f + 4 * (size_t)vertOff, d->geomVertCount[g], d->triIndices + 3 * (size_t)triOff,
+                                                   3 * (size_t)d->geomTriCount[g], 0, 16);
+      if (id == 0xFFFFFFFFu) return HPT_ERR_ARG;
+    }
+    hpt_clear_scene(c);
+    for (uint i = 0; i < d->numInsts; i++)
+      if (hpt_add_instance(c, d->instGeomId[i], d->instMatrices + 16 * (size_t)i) == 0xFFFFFFFFu) return c->fail(HPT_ERR_ARG, "AddInstance: bad geomId");
+    rc = hpt_commit_scene(c, 0); if (rc) return rc;
+  }
+  if (!c->accelCommitted) return c->fail(HPT_ERR_STATE, "CommitDeviceData before CommitScene");
+  if (d->numInsts != c->insts.size()) return c->fail(HPT_ERR_ARG, "scene tables and acceleration structure disagree on the instance count");
+
+  HIPCHK(c, c->dTriIndices.upload(d->triIndices, 3 * (size_t)d->numTris));
+  HIPCHK(c, c->dVData.upload(d->vData8f, 8 * (size_t)d->numVerts));
+  HIPCHK(c, c->dMatIdByPrim.upload(d->matIdByPrimId, d->numTris));
+  HIPCHK(c, c->dMatVertOffset.upload(d->matVertOffset, 2 * (size_t)d->numGeoms));
+  std::vector<float> nm(12 * (size_t)std::max(1u, d->numInsts), 0.0f);
+  for (uint i = 0; i < d->numInsts; i++) {
+    const float* m = d->normMatrices + 16 * (size_t)i;                 // rows of the upper 3x3 (column-major source)
+    float* o = &nm[12 * (size_t)i];
+    o[0] = m[0]; o[1] = m[4]; o[2] = m[8];  o[3] = 0.0f;
+    o[4] = m[1]; o[5] = m[5]; o[6] = m[9];  o[7] = 0.0f;
+    o[8] = m[2]; o[9] = m[6]; o[10] = m[10]; o[11] = 0.0f;
+  }
+  HIPCHK(c, c->dNormMat.upload(nm.data(), nm.size()));
+  HIPCHK(c, c->dRemapInst.upload(d->remapInst, 2 * (size_t)d->numInsts));
+  {
+    std::vector<int> rl(d->allRemapLists ? std::vector<int>(d->allRemapLists, d->allRemapLists + d->allRemapListsLen) : std::vector<int>());
+    if (rl.empty()) rl.push_back(0);
+    HIPCHK(c, c->dRemapLists.upload(rl.data(), rl.size()));
+  }
+  HIPCHK(c, c->dMaterials.upload((const MaterialRec*)d->materials, d->numMaterials));
+  {
+    std::vector<LightRec> ll((const LightRec*)d->lights, (const LightRec*)d->lights + d->numLights);
+    if (ll.empty()) ll.resize(1);
+    HIPCHK(c, c->dLights.upload(ll.data(), ll.size()));
+  }
+  for (void* p : c->texData) if (p) (void)hipFree(p);
+  c->texData.clear(); c->hTextures.resize(d->numTextures);
+  for (uint i = 0; i < d->numTextures; i++) {
+    const hpt_texture_desc& t = d->textures[i];
+    if (t.width == 0 || t.height == 0 || !t.data || t.format > 2) return c->fail(HPT_ERR_ARG, "bad texture descriptor");
+    const size_t bytes = (size_t)t.width * t.height * (t.format == 1 ? 16 : 4);
+    void* dp = nullptr;
+    HIPCHK(c, hipMalloc(&dp, bytes));
+    c->texData.push_back(dp);
+    HIPCHK(c, hipMemcpy(dp, t.data, bytes, hipMemcpyHostToDevice));
+    TexRec& r = c->hTextures[i];
+    r.w = t.width; r.h = t.height; r.format = t.format; r.flags = t.flags; r.addrU = t.addressU; r.addrV = t.addressV; r.filter = t.filter; r.pad = 0;
+    r.data = dp; r.diffOffset = ~0ull; r.diffW = r.diffH = r.diffChannels = 0; r.pad2 = 0;
+  }
+  HIPCHK(c, c->dTextures.upload(c->hTextures.data(), c->hTextures.size()));
+  c->gradSize = 0;
+
+  DevScene& S = c->S;
+  S.triIndices = c->dTriIndices.p; S.vData8f = c->dVData.p; S.matIdByPrimId = c->dMatIdByPrim.p; S.matVertOffset = c->dMatVertOffset.p;
+  S.normMat = c->dNormMat.p; S.remapInst = c->dRemapInst.p; S.allRemapLists = c->dRemapLists.p; S.allRemapListsSize = d->allRemapListsSize;
+  S.numLights = d->numLights; S.materials = c->dMaterials.p; S.lights = c->dLights.p; S.textures = c->dTextures.p;
+  c->sceneUploaded = true;
+  c->tPathTrace[1] = c->tNaive[1] = c->tDR[1] = float(now_ms() - t0);   // host -> device time of the scene commit
+  return HPT_OK;
+}
+
+extern "C" int hpt_update_params(hpt_ctx* c, const hpt_params* p)
+{
+  if (!c || !p) return HPT_ERR_ARG;
+  if (p->spectralMode != 0) return c->fail(HPT_ERR_UNSUPPORTED, "spectral rendering is outside the hot path's scope");
+  if (p->winWidth <= 0 || p->winHeight <= 0 || p->fbWidth <= 0 || p->fbHeight <= 0 || p->winWidth > 65535 || p->winHeight > 65535) return c->fail(HPT_ERR_ARG, "bad viewport");
+  if (p->tileSize != 1 && p->tileSize != 2 && p->tileSize != 4 && p->tileSize != 8) return c->fail(HPT_ERR_ARG, "bad tile size");
+  DevScene& S = c->S;
+  std::memcpy(S.projInv, p->projInv, 64); std::memcpy(S.worldViewInv, p->worldViewInv, 64);
+  S.winStartX = p->winStartX; S.winStartY = p->winStartY; S.winWidth = p->winWidth; S.winHeight = p->winHeight; S.fbWidth = p->fbWidth; S.fbHeight = p->fbHeight;
+  S.traceDepth = p->traceDepth; S.integratorType = p->integratorType; S.renderLayer = p->renderLayer; S.tileSize = p->tileSize;
+  S.exposureMult = p->exposureMult; S.camLensRadius = p->camLensRadius; S.camTargetDist = p->camTargetDist;
+  std::memcpy(S.camRespoceRGB, p->camRespoceRGB, 16); std::memcpy(S.envColor, p->envColor, 16);
+  c->paramsSet = true;
+  return HPT_OK;
+}
+
+extern "C" int hpt_update_materials(hpt_ctx* c, size_t first, size_t count, const void* mats)
+{
+  if (!c || !mats) return HPT_ERR_ARG;
+  if (first + count > c->dMaterials.n) return c->fail(HPT_ERR_ARG, "Update_m_materials: range out of bounds");
+  int rc = check_materials(c, (const MaterialRec*)mats, count, c->hTextures.size()); if (rc) return rc;
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, hipMemcpy(c->dMaterials.p + first, mats, count * sizeof(MaterialRec), hipMemcpyHostToDevice));
+  return HPT_OK;
+}
+extern "C" int hpt_update_lights(hpt_ctx* c, size_t first, size_t count, const void* lights)
+{
+  if (!c || !lights) return HPT_ERR_ARG;
+  if (first + count > c->S.numLights) return c->fail(HPT_ERR_ARG, "Update_m_lights: range out of bounds");
+  int rc = check_lights(c, (const LightRec*)lights, count, c->hTextures.size()); if (rc) return rc;
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, hipMemcpy(c->dLights.p + first, lights, count * sizeof(LightRec), hipMemcpyHostToDevice));
+  return HPT_OK;
+}
+
+extern "C" int hpt_pack_xy(hpt_ctx* c, uint32_t tidX, uint32_t tidY)
+{
+  if (!c) return HPT_ERR_ARG;
+  if (!c->paramsSet) return c->fail(HPT_ERR_STATE, "PackXYBlock before UpdateMembersPlainData");
+  if ((int)tidX != c->S.winWidth || (int)tidY != c->S.winHeight) return c->fail(HPT_ERR_ARG, "PackXYBlock: size differs from the viewport");
+  (void)hipSetDevice(c->device);
+  const size_t n = (size_t)tidX * tidY;
+  HIPCHK(c, c->dPackedXY.alloc(n));
+  packXYKernel<<<dim3((tidX + 15) / 16, (tidY + 15) / 16), dim3(16, 16), 0, 0>>>(c->dPackedXY.p, (int)tidX, (int)tidY, c->S.tileSize);
+  HIPCHK(c, hipGetLastError());
+  c->packedCount = (uint)n;
+  return HPT_OK;
+}
+extern "C" int hpt_get_packed_xy(hpt_ctx* c, uint32_t* out, uint32_t count)
+{
+  if (!c || !out || count > c->packedCount) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, hipMemcpy(out, c->dPackedXY.p, (size_t)count * 4, hipMemcpyDeviceToHost));
+  return HPT_OK;
+}
+extern "C" int hpt_init_random_gens(hpt_ctx* c, uint32_t n)
+{
+  if (!c || n == 0) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, c->dGens.alloc(n));
+  initRandomGensKernel<<<dim3((n + 255) / 256), dim3(256), 0, 0>>>(c->dGens.p, n);
+  HIPCHK(c, hipGetLastError());
+  return HPT_OK;
+}
+extern "C" int hpt_get_random_gens(hpt_ctx* c, uint32_t* out, uint32_t count)
+{
+  if (!c || !out || count > c->dGens.n) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, hipMemcpy(out, c->dGens.p, (size_t)count * 8, hipMemcpyDeviceToHost));
+  return HPT_OK;
+}
+extern "C" int hpt_set_random_gens(hpt_ctx* c, const uint32_t* in, uint32_t count)
+{
+  if (!c || !in) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, c->dGens.alloc(count));
+  HIPCHK(c, hipMemcpy(c->dGens.p, in, (size_t)count * 8, hipMemcpyHostToDevice));
+  return HPT_OK;
+}
+
+// ---- the hot path -------------------------------------------------------------------------------------------------------------------
+static int gridBlocks(hpt_ctx* c, bool dr)
+{
+  int bpc = c->blocksPerCU;
+  if (bpc <= 0) bpc = dr ? 2 : 4;
+  return c->numCUs * bpc;
+}
+
+template <int STACK, bool STATS, bool DR, bool NAIVE>
+static void launchPT(const DevScene& S, const Job& job, int blocks, hipStream_t st)
+{
+  pathTraceKernel<STACK, STATS, DR, NAIVE><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
+}
+
+static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStream_t st)
+{
+  if (!c->sceneUploaded || !c->paramsSet) return c->fail(HPT_ERR_STATE, "PathTraceBlock before CommitDeviceData / UpdateMembersPlainData");
+  if (c->packedCount != (uint)(c->S.winWidth * c->S.winHeight)) return c->fail(HPT_ERR_STATE, "PathTraceBlock before PackXYBlock");
+  if ((size_t)job.tidBegin + job.tidCount > c->packedCount) return c->fail(HPT_ERR_ARG, "PathTraceBlock: tid range exceeds the viewport");
+  if (c->dGens.n < c->packedCount) return c->fail(HPT_ERR_STATE, "PathTraceBlock: m_randomGens smaller than the viewport (InitRandomGens)");
+  if (job.channels < 1 || job.channels > 4) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceBlock: channels must be 1..4 (spectral layers are out of scope)");
+  if (dr && (c->S.traceDepth == 0 || c->S.traceDepth > 16)) return c->fail(HPT_ERR_ARG, "PathTraceDR: trace depth must be 1..16");
+  const int blocks = gridBlocks(c, dr);
+  HIPCHK(c, c->dQueue.alloc(1));
+  HIPCHK(c, hipMemsetAsync(c->dQueue.p, 0, 4, st));
+  job.queue = c->dQueue.p;
+  job.gens = c->dGens.p; job.packedXY = c->dPackedXY.p;
+  job.counters = nullptr;
+  const bool stats = c->instrument && !dr;
+  if (stats) { HIPCHK(c, c->dCounters.alloc(1)); HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(Counters), st)); job.counters = c->dCounters.p; }
+  if (dr) {
+    job.recordLanes = (uint)blocks * 256u;
+    HIPCHK(c, c->dRecord.alloc((size_t)job.recordLanes * REC_FIELDS * (c->S.traceDepth + 1)));
+    job.record = c->dRecord.p;
+  }
+  const bool deep = c->stackNeeded > 32;
+  HIPCHK(c, hipEventRecord(c->ev0, st));
+  if (dr)          { if (deep) launchPT<64, false, true, false>(c->S, job, blocks, st);  else launchPT<32, false, true, false>(c->S, job, blocks, st); }
+  else if (naive)  { if (deep) launchPT<64, false, false, true>(c->S, job, blocks, st);  else launchPT<32, false, false, true>(c->S, job, blocks, st); }
+  else if (stats)  { if (deep) launchPT<64, true, false, false>(c->S, job, blocks, st);  else launchPT<32, true, false, false>(c->S, job, blocks, st); }
+  else             { if (deep) launchPT<64, false, false, false>(c->S, job, blocks, st); else launchPT<32, false, false, false>(c->S, job, blocks, st); }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev1, st));
+  return HPT_OK;
+}
+
+extern "C" int hpt_path_trace_block_dev(hpt_ctx* c, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* outDev, uint32_t passNum, int naive, void* stream)
+{
+  if (!c || !outDev) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (tidCount == 0 || passNum == 0) return HPT_OK;
+  Job job; std::memset(&job, 0, sizeof(job));
+  job.tidBegin = tidBegin; job.tidCount = tidCount; job.passNum = passNum; job.channels = channels; job.outColor = outDev;
+  return launch_path_trace(c, job, naive != 0, false, (hipStream_t)stream);
+}
+
+static int path_trace_host(hpt_ctx* c, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out, uint32_t passNum, int naive)
+{
+  if (!c || !out) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (!c->paramsSet) return c->fail(HPT_ERR_STATE, "PathTraceBlock before UpdateMembersPlainData");
+  float* slots = naive ? c->tNaive : c->tPathTrace;
+  const size_t n = (size_t)c->S.winWidth * c->S.winHeight * channels;
+  const double t0 = now_ms();
+  HIPCHK(c, c->dFrame.alloc(n));
+  HIPCHK(c, hipMemcpy(c->dFrame.p, out, n * 4, hipMemcpyHostToDevice));            // the callee ACCUMULATES into the caller's buffer
+  const double t1 = now_ms();
+  int rc = hpt_path_trace_block_dev(c, tidBegin, tidCount, channels, c->dFrame.p, passNum, naive, nullptr);
+  if (rc) return rc;
+  HIPCHK(c, hipDeviceSynchronize());
+  const double t2 = now_ms();
+  HIPCHK(c, hipMemcpy(out, c->dFrame.p, n * 4, hipMemcpyDeviceToHost));
+  const double t3 = now_ms();
+  float kms = 0.0f;
+  if (tidCount && passNum) (void)hipEventElapsedTime(&kms, c->ev0, c->ev1);
+  c->lastKernelMs = kms;
+  slots[0] = kms; slots[1] = float(t1 - t0); slots[2] = float(t3 - t2); slots[3] = float((t2 - t1) - kms);
+  return HPT_OK;
+}
+
+extern "C" int hpt_path_trace_block(hpt_ctx* c, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out, uint32_t passNum)
+{ return path_trace_host(c, tidBegin, tidCount, channels, out, passNum, 0); }
+extern "C" int hpt_naive_path_trace_block(hpt_ctx* c, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out, uint32_t passNum)
+{ return path_trace_host(c, tidBegin, tidCount, channels, out, passNum, 1); }
+
+// ---- differentiable rendering ---------------------------------------------------------------------------------------------------------
+extern "C" int hpt_reset_diff_tex(hpt_ctx* c)
+{
+  if (!c) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  for (TexRec& t : c->hTextures) { t.diffOffset = ~0ull; t.diffW = t.diffH = t.diffChannels = 0; }
+  c->gradSize = 0;
+  if (!c->hTextures.empty()) HIPCHK(c, c->dTextures.upload(c->hTextures.data(), c->hTextures.size()));
+  return HPT_OK;
+}
+
+extern "C" int hpt_put_diff_tex2d(hpt_ctx* c, uint32_t texId, uint32_t w, uint32_t h, uint32_t channels, uint64_t* outOffset, uint64_t* outSize)
+{
+  if (!c || !outOffset || !outSize) return HPT_ERR_ARG;
+  if (texId >= c->hTextures.size()) {                                     // reference: prints and returns (size_t(-1), 0) (integrator_dr.cpp:35-39)
+    *outOffset = ~0ull; *outSize = 0;
+    return c->fail(HPT_ERR_ARG, "[IntegratorDR::PutDiffTex2D]: bad tex id = " + std::to_string(texId));
+  }
+  if (channels != 1 && channels != 4) return c->fail(HPT_ERR_ARG, "PutDiffTex2D: channels must be 1 or 4");
+  if (channels == 4 && (c->gradSize % 4) != 0) return c->fail(HPT_ERR_ARG, "PutDiffTex2D: 4-channel textures must start at a multiple of 4 floats");
+  (void)hipSetDevice(c->device);
+  TexRec& t = c->hTextures[texId];
+  t.diffOffset = c->gradSize; t.diffW = w; t.diffH = h; t.diffChannels = channels;
+  const uint64_t sz = (uint64_t)w * h * channels;
+  *outOffset = c->gradSize; *outSize = sz;
+  c->gradSize += sz;
+  HIPCHK(c, c->dTextures.upload(c->hTextures.data(), c->hTextures.size()));
+  return HPT_OK;
+}
+
+extern "C" int hpt_path_trace_dr_dev(hpt_ctx* c, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* outDev, uint32_t passNum,
+                                     const float* refDev, const float* dataDev, float* gradDev, size_t gradSize, float* lossDev, void* stream)
+{
+  if (!c || !outDev || !refDev || !dataDev || !gradDev || !lossDev) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (gradSize < c->gradSize) return c->fail(HPT_ERR_ARG, "PathTraceDR: a_gradSize smaller than the registered differentiable textures");
+  if (channels < 3) return c->fail(HPT_ERR_ARG, "PathTraceDR: channels must be 3 or 4");
+  if (tidCount == 0 || passNum == 0) return HPT_OK;
+  Job job; std::memset(&job, 0, sizeof(job));
+  job.tidBegin = tidBegin; job.tidCount = tidCount; job.passNum = passNum; job.channels = channels; job.outColor = outDev;
+  job.refImg = refDev; job.data = dataDev; job.grad = gradDev; job.lossAccum = lossDev;
+  return launch_path_trace(c, job, false, true, (hipStream_t)stream);
+}
+
+extern "C" int hpt_path_trace_dr(hpt_ctx* c, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out, uint32_t passNum,
+                                 const float* refImg, const float* data, float* dataGrad, size_t gradSize, float* outLoss)
+{
+  if (!c || !out || !refImg || !data || !dataGrad) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (!c->paramsSet) return c->fail(HPT_ERR_STATE, "PathTraceDR before UpdateMembersPlainData");
+  const size_t n = (size_t)c->S.winWidth * c->S.winHeight * channels;
+  const double t0 = now_ms();
+  HIPCHK(c, c->dFrame.alloc(n)); HIPCHK(c, c->dRef.alloc(n)); HIPCHK(c, c->dData.alloc(gradSize)); HIPCHK(c, c->dGrad.alloc(gradSize)); HIPCHK(c, c->dLoss.alloc(1));
+  HIPCHK(c, hipMemcpy(c->dFrame.p, out, n * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->dRef.p, refImg, n * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->dData.p, data, gradSize * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemset(c->dGrad.p, 0, gradSize * 4));                       // memset(a_dataGrad, 0, ...) (integrator_dr.cpp:1139)
+  HIPCHK(c, hipMemset(c->dLoss.p, 0, 4));
+  const double t1 = now_ms();
+  int rc = hpt_path_trace_dr_dev(c, tidBegin, tidCount, channels, c->dFrame.p, passNum, c->dRef.p, c->dData.p, c->dGrad.p, gradSize, c->dLoss.p, nullptr);
+  if (rc) return rc;
+  HIPCHK(c, hipDeviceSynchronize());
+  const double t2 = now_ms();
+  float lossSum = 0.0f;
+  HIPCHK(c, hipMemcpy(out, c->dFrame.p, n * 4, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(dataGrad, c->dGrad.p, gradSize * 4, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(&lossSum, c->dLoss.p, 4, hipMemcpyDeviceToHost));
+  const double t3 = now_ms();
+  if (outLoss) *outLoss = lossSum / float(c->S.winWidth * c->S.winHeight);  // avgLoss /= W*H (integrator_dr.cpp:1206)
+  float kms = 0.0f;
+  if (tidCount && passNum) (void)hipEventElapsedTime(&kms, c->ev0, c->ev1);
+  c->lastKernelMs = kms;
+  c->tDR[0] = kms; c->tDR[1] = float(t1 - t0); c->tDR[2] = float(t3 - t2); c->tDR[3] = float((t2 - t1) - kms);
+  return HPT_OK;
+}
+
+extern "C" int hpt_adam_step_dev(hpt_ctx* c, float* state, const float* grad, float* momentum, float* gsq, size_t n, int iter, void* stream)
+{
+  if (!c || !state || !grad || !momentum || !gsq) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (n == 0) return HPT_OK;
+  const float gamma = 0.25f / float(iter / 100 + 1);
+  const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)c->numCUs * 8);
+  adamStepKernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(state, grad, momentum, gsq, n, gamma);
+  HIPCHK(c, hipGetLastError());
+  return HPT_OK;
+}
+
+// ---- timing / instrumentation --------------------------------------------------------------------------------------------------------
+extern "C" int hpt_get_execution_time(hpt_ctx* c, const char* name, float out[4])
+{
+  if (!c || !name || !out) return HPT_ERR_ARG;
+  const std::string n(name);
+  const float* src = nullptr;
+  if (n == "PathTrace" || n == "PathTraceBlock") src = c->tPathTrace;                       // integrator_pt_lgt.cpp:241-251
+  else if (n == "NaivePathTrace" || n == "NaivePathTraceBlock") src = c->tNaive;
+  else if (n == "PathTraceDR" || n == "PathTraceDRBlock") src = c->tDR;                     // integrator_dr2.cpp:82-88
+  if (!src) return HPT_OK;                                                                 // unknown names leave `out` untouched, as the reference does
+  for (int i = 0; i < 4; i++) out[i] = src[i];
+  return HPT_OK;
+}
+extern "C" int hpt_set_instrumentation(hpt_ctx* c, int enabled) { if (!c) return HPT_ERR_ARG; c->instrument = enabled != 0; return HPT_OK; }
+extern "C" int hpt_get_counters(hpt_ctx* c, uint64_t out[8])
+{
+  if (!c || !out) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (!c->dCounters.p) { for (int i = 0; i < 8; i++) out[i] = 0; return HPT_OK; }
+  HIPCHK(c, hipDeviceSynchronize());
+  HIPCHK(c, hipMemcpy(out, c->dCounters.p, sizeof(Counters), hipMemcpyDeviceToHost));
+  return HPT_OK;
+}
+extern "C" int hpt_set_launch_config(hpt_ctx* c, int blocksPerCU) { if (!c || blocksPerCU < 0 || blocksPerCU > 8) return HPT_ERR_ARG; c->blocksPerCU = blocksPerCU; return HPT_OK; }
+extern "C" int hpt_last_kernel_ms(hpt_ctx* c, float* ms)
+{
+  if (!c || !ms) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  float k = 0.0f;
+  hipError_t e = hipEventSynchronize(c->ev1);
+  if (e == hipSuccess) e = hipEventElapsedTime(&k, c->ev0, c->ev1);
+  if (e != hipSuccess) { *ms = c->lastKernelMs; return HPT_OK; }
+  *ms = c->lastKernelMs = k;
+  return HPT_OK;
+}

@@ -1,0 +1,481 @@
+// Persistent path-tracing kernel for MI355X (gfx950, wave64) and its small helper kernels.
+//
+// Replaces the reference's  #pragma omp parallel for over pixels x passes  (integrator_pt_host.cpp:57-73) and the
+// per-path kernel chain of Integrator::PathTrace (integrator_pt.cpp:719-759):
+//
+//   * one lane owns one pixel (tid in the reference's tile-swizzled order, integrator_rt.cpp:13-31) for all of its passes,
+//     because the pixel's RNG stream continues from pass to pass (integrator_pt.cpp:139,605); radiance is summed in VGPRs
+//     in the reference's order and the framebuffer is read-modified-written once per pixel instead of once per sample;
+//   * lanes never wait for each other between samples: a lane whose path ended regenerates its next sample at the top of
+//     the bounce loop, so every trip through the loop traces one closest-hit ray and one shadow ray for (almost) all 64
+//     lanes of the wave;
+//   * pixels are handed out by a persistent-threads work queue: lanes that ran out of passes are compacted with a wave
+//     ballot + mbcnt prefix sum, and ONE atomicAdd per wave fetches a contiguous run of tids for them;
+//   * the grid is sized to the chip (blocksPerCU x 256 CUs), not to the image.
+//
+// Exit condition every wave reaches: the queue counter only grows, a lane that draws an index past the end never asks
+// again, and a wave leaves the loop when none of its lanes holds a live path or a pixel.
+#include <hip/hip_runtime.h>
+#include "hpt_device.h"
+
+namespace hpt {
+
+struct Job
+{
+  uint   tidBegin, tidCount;      // window of the swizzled pixel index space this launch renders
+  uint   passNum, channels;
+  float* outColor;                // full W*H*channels framebuffer (device)
+  Rng*   gens;                    // m_randomGens (device, persistent)
+  const uint* packedXY;           // m_packedXY
+  uint*  queue;                   // work-queue head (zeroed before launch)
+  Counters* counters;             // instrumentation (STATS builds)
+  // differentiable rendering
+  const float* refImg;            // a_refImg
+  const float* data;              // a_data
+  float* grad;                    // a_dataGrad (atomically accumulated)
+  float* lossAccum;               // sum over samples of loss / passNum
+  float* record;                  // per-lane, per-bounce adjoint records: [bounce][field][lane]
+  uint   recordLanes;             // total lanes of the grid (stride of the record buffer)
+};
+
+static const int REC_FIELDS = 24;   // A(3) S(3) T*dA(3) T*dS(3) texId tapOffsets(4) tapWeights(4) pad(3)
+
+HPT_DEV uint lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+HPT_DEV uint mbcnt64(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint)m, 0u)); }
+
+// differentiable texture fetch: Tex2DFetchAD (diff_render/integrator_dr.cpp:95-161); returns texColor and tap data
+HPT_DEV V4 texFetchAD(const DevScene& S, const float* data, uint texId, V2 uv, Taps& taps, bool& isParam)
+{
+  const TexRec t = S.textures[texId];
+  isParam = false;
+  if (t.diffOffset != ~0ull && data != nullptr) {
+    taps = bilinearTaps(t.diffW, t.diffH, t.addrU, t.addrV, uv);
+    isParam = true;
+    const float* d = data + t.diffOffset;
+    if (t.diffChannels == 4) {
+      const float4 a = ((const float4*)d)[taps.off[0]], b = ((const float4*)d)[taps.off[1]], c = ((const float4*)d)[taps.off[2]], e = ((const float4*)d)[taps.off[3]];
+      return v4(a.x * taps.w[0] + b.x * taps.w[1] + c.x * taps.w[2] + e.x * taps.w[3],
+                a.y * taps.w[0] + b.y * taps.w[1] + c.y * taps.w[2] + e.y * taps.w[3],
+                a.z * taps.w[0] + b.z * taps.w[1] + c.z * taps.w[2] + e.z * taps.w[3],
+                a.w * taps.w[0] + b.w * taps.w[1] + c.w * taps.w[2] + e.w * taps.w[3]);
+    }
+    const float o = d[taps.off[0]] * taps.w[0] + d[taps.off[1]] * taps.w[1] + d[taps.off[2]] * taps.w[2] + d[taps.off[3]] * taps.w[3];
+    return v4(o, o, o, o);
+  }
+  return texSample(S.textures, texId, uv);
+}
+
+// SampleCameraRay + kernel_InitEyeRay2 (integrator_pt.cpp:44-157), RGB / static-scene subset
+HPT_DEV void cameraRay(const DevScene& S, uint x, uint y, V4 pixelOffsets, V3& rayPos, V3& rayDir)
+{
+  const float fx = float(x) + pixelOffsets.x, fy = float(y) + pixelOffsets.y;
+  const float xn = (fx + float(S.winStartX)) / float(S.fbWidth);
+  const float yn = (fy + float(S.winStartY)) / float(S.fbHeight);
+  V4 pos = v4(2.0f * xn - 1.0f, 2.0f * yn - 1.0f, 0.0f, 1.0f);          // EyeRayDirNormalized (cglobals.h:49-55)
+  pos = mul4x4(S.projInv, pos);
+  V3 dir = normalize(v3(pos.x / pos.w, pos.y / pos.w, pos.z / pos.w));
+  V3 org = v3(0, 0, 0);
+  if (S.camLensRadius > 0.0f) {
+    const float tFocus = S.camTargetDist / (-dir.z);
+    const V3 focusPosition = org + dir * tFocus;
+    const V2 d2 = mapSamplesToDisc(v2(pixelOffsets.z - 0.5f, pixelOffsets.w - 0.5f));
+    const float k = S.camLensRadius * 2.0f;
+    org.x += k * d2.x; org.y += k * d2.y;
+    dir = normalize(focusPosition - org);
+  }
+  const V3 p1 = mul4x3(S.worldViewInv, org);                             // transform_ray3f (cglobals.h:254-263)
+  const V3 p2 = mul4x3(S.worldViewInv, org + 100.0f * dir);
+  rayPos = p1;
+  rayDir = normalize(p2 - p1);
+}
+
+template <int STACK, bool STATS, bool DR, bool NAIVE>
+__global__ void __launch_bounds__(256) pathTraceKernel(const DevScene S, const Job job)
+{
+  __shared__ uint stackMem[STACK * 256];
+  uint* stk = &stackMem[threadIdx.x];
+  const uint glane = blockIdx.x * 256u + threadIdx.x;                    // slot in the record buffer (DR)
+
+  // ---- per-lane state (VGPRs) ---------------------------------------------------------------------------------------
+  bool havePixel = false, alive = false, drained = false;
+  uint tid = 0, px = 0, py = 0, passesLeft = 0, bounce = 0, flags = 0;
+  Rng  gen; gen.sx = gen.sy = 0;
+  V3   pix = v3(0, 0, 0);                       // running framebuffer value of the pixel
+  V3   rpos = v3(0, 0, 0), rdir = v3(0, 0, 1);
+  V3   accum = v3(0, 0, 0), thr = v3(1, 1, 1);
+  float misPdf = 1.0f, misIor = 1.0f;
+  TravStats st; st.nodes = st.tris = st.insts = 0;
+  uint nRays = 0, nShadow = 0, nHits = 0, nPaths = 0;
+  float lossLocal = 0.0f;
+  const uint maxBounce = NAIVE ? S.traceDepth + 1u : S.traceDepth;
+
+  while (true) {
+    // ---- (1) a finished pixel goes back to HBM: one read-modify-write per pixel and call ------------------------------
+    if (!alive && havePixel && passesLeft == 0) {
+      const uint pixel = py * (uint)S.winWidth + px;
+      if (job.channels == 1) job.outColor[pixel] = pix.x;
+      else { float* o = job.outColor + (size_t)pixel * job.channels; o[0] = pix.x; o[1] = pix.y; o[2] = pix.z; }
+      job.gens[tid] = gen;                                               // kernel_ContributeToImage: m_randomGens[tid] = *gen (:605)
+      havePixel = false;
+    }
+    // ---- (2) work queue: ballot the idle lanes, one atomic per wave, prefix-sum the ranks --------------------------------
+    {
+      const bool need = !alive && !havePixel && !drained;
+      const unsigned long long mask = __ballot(need);
+      if (mask != 0ull) {
+        uint base = 0;
+        if (need && mbcnt64(mask) == 0u) base = atomicAdd(job.queue, (uint)__popcll(mask));
+        base = __shfl(base, (int)(__ffsll((long long)mask) - 1));
+        if (need) {
+          const uint k = base + mbcnt64(mask);
+          if (k < job.tidCount) {
+            tid = job.tidBegin + k;
+            const uint XY = job.packedXY[tid];
+            px = XY & 0x0000FFFFu; py = (XY & 0xFFFF0000u) >> 16;
+            gen = job.gens[tid];
+            const uint pixel = py * (uint)S.winWidth + px;
+            if (job.channels == 1) pix = v3(job.outColor[pixel], 0, 0);
+            else { const float* o = job.outColor + (size_t)pixel * job.channels; pix = v3(o[0], o[1], o[2]); }
+            passesLeft = job.passNum;
+            havePixel = true;
+          } else drained = true;
+        }
+      }
+    }
+    // ---- (3) regenerate: next pass of the pixel (kernel_InitEyeRay2) -----------------------------------------------------
+    if (!alive && havePixel && passesLeft > 0) {
+      passesLeft--;
+      accum = v3(0, 0, 0); thr = v3(1, 1, 1); flags = 0; bounce = 0;
+      misPdf = 1.0f; misIor = 1.0f;
+      const V4 lens = rng_float4(gen);                                     // GetRandomNumbersLens
+      cameraRay(S, px, py, lens, rpos, rdir);
+      alive = true;
+      if (STATS) nPaths++;
+    }
+    if (!__any(alive)) break;
+
+    // ---- (4) closest hit: kernel_RayTrace2 -> RayQuery_NearestHit ----------------------------------------------------------
+    HitRec hit; hit.inst = 0xFFFFFFFFu; hit.prim = 0; hit.t = 0; hit.u = hit.v = 0;
+    if (alive) {
+      traceRay<false, STATS>(S, rpos, rdir, 0.0f, HPT_FLT_MAX, hit, stk, 256, st);
+      if (STATS) nRays++;
+    }
+
+    // ---- (5) surface, next-event estimation set-up, emission, BSDF sampling -------------------------------------------------
+    bool wantShadow = false;
+    V3 shPos = v3(0, 0, 0), shDir = v3(0, 0, 1); float shFar = 0.0f;
+    V3 contrib = v3(0, 0, 0);                        // thr * shadeColor, added after the shadow ray returns
+    // DR record of this bounce
+    V3 recA = v3(0, 0, 0), recS = v3(0, 0, 0), recdA = v3(0, 0, 0), recdS = v3(0, 0, 0); Taps recTaps; uint recTex = 0xFFFFFFFFu;
+    V3 tailR = v3(0, 0, 0);                          // emission picked up at the terminating vertex, per unit throughput
+    const V3 thrBefore = thr;
+    bool didBounce = false;
+    for (int k = 0; k < 4; k++) { recTaps.off[k] = 0; recTaps.w[k] = 0.0f; }
+
+    if (alive) {
+      if (hit.inst == 0xFFFFFFFFu) {
+        flags |= (bounce == 0) ? (RAY_FLAG_PRIME_RAY_MISS | RAY_FLAG_IS_DEAD | RAY_FLAG_OUT_OF_SCENE) : (RAY_FLAG_IS_DEAD | RAY_FLAG_OUT_OF_SCENE);
+      } else {
+        if (STATS) nHits++;
+        // -- surface attributes (integrator_pt.cpp:238-311) --
+        const uint instId = hit.inst;
+        const uint geomId = S.insts[instId].geomId;
+        const uint triOffset = S.matVertOffset[2 * geomId + 0], vertOffset = S.matVertOffset[2 * geomId + 1];
+        const V3 hitPos = rpos + hit.t * (1.f - 1e-6f) * rdir;
+        const float uvx = hit.v, uvy = hit.u;                              // coords[0] = v, coords[1] = u (EmbreeRT.cpp:350-352)
+        const uint A = S.triIndices[(triOffset + hit.prim) * 3 + 0];
+        const uint B = S.triIndices[(triOffset + hit.prim) * 3 + 1];
+        const uint C = S.triIndices[(triOffset + hit.prim) * 3 + 2];
+        const float4 nA = ((const float4*)S.vData8f)[2 * (A + vertOffset)], nB = ((const float4*)S.vData8f)[2 * (B + vertOffset)], nC = ((const float4*)S.vData8f)[2 * (C + vertOffset)];
+        const float tyA = S.vData8f[8 * (A + vertOffset) + 7], tyB = S.vData8f[8 * (B + vertOffset) + 7], tyC = S.vData8f[8 * (C + vertOffset) + 7];
+        const float wA = 1.0f - uvx - uvy;
+        const V3 nrmO = v3(wA * nA.x + uvy * nB.x + uvx * nC.x, wA * nA.y + uvy * nB.y + uvx * nC.y, wA * nA.z + uvy * nB.z + uvx * nC.z);
+        const V2 uv = v2(wA * nA.w + uvy * nB.w + uvx * nC.w, wA * tyA + uvy * tyB + uvx * tyC);
+        const float* nm = S.normMat + 12 * instId;
+        V3 hitNorm = v3(nm[0] * nrmO.x + nm[1] * nrmO.y + nm[2] * nrmO.z,
+                        nm[4] * nrmO.x + nm[5] * nrmO.y + nm[6] * nrmO.z,
+                        nm[8] * nrmO.x + nm[9] * nrmO.y + nm[10] * nrmO.z);
+        hitNorm = normalize(hitNorm);
+        const float flipNorm = dot(rdir, hitNorm) > 0.001f ? -1.0f : 1.0f;
+        hitNorm = flipNorm * hitNorm;
+        if (flipNorm < 0.0f) flags |= RAY_FLAG_HAS_INV_NORMAL; else flags &= ~RAY_FLAG_HAS_INV_NORMAL;
+        const uint matId = remapMaterialId(S, S.matIdByPrimId[triOffset + hit.prim], instId) & 0x00FFFFFFu;
+        const MaterialRec& m = S.materials[matId];
+        const uint mtype = m.mtype;
+        const V3 vdir = (-1.0f) * rdir;
+
+        // -- kernel_SampleLightSource (integrator_pt.cpp:350-424): the randoms are drawn for every surface hit --
+        V3 shade = v3(0, 0, 0), dshade = v3(0, 0, 0);
+        V4 texColor = v4(1, 1, 1, 1); V3 four = v3(1, 1, 1);
+        bool isParam = false;
+        if (mtype != MAT_TYPE_LIGHT_SOURCE) {
+          const V2 tcT = mulRows2x4(m.row0[0], m.row1[0], uv);
+          if (DR) { texColor = texFetchAD(S, job.data, m.texid[0], tcT, recTaps, isParam); if (isParam) recTex = m.texid[0]; }
+          else    texColor = texSample(S.textures, m.texid[0], tcT);
+          if ((m.cflags & FLAG_FOUR_TEXTURES) != 0) {                      // integrator_pt_mat.cpp:151-167
+            const V4 c2 = texSample(S.textures, m.texid[2], mulRows2x4(m.row0[2], m.row1[2], uv));
+            const V4 c3 = texSample(S.textures, m.texid[3], mulRows2x4(m.row0[3], m.row1[3], uv));
+            four = ((m.cflags & FLAG_PACK_FOUR_PARAMS_IN_TEXTURE) != 0) ? v3(c2.x, c2.y, c2.z) : v3(c2.x, c3.x, 1.0f);
+          }
+        }
+        const V3 tex3 = v3(texColor.x, texColor.y, texColor.z);
+        const V3 baseCol = ld3(m.colors[GLTF_COLOR_BASE]);
+
+        if (!NAIVE) {
+          const float rndId = rng_float1(gen);                             // GetRandomNumbersLgts: two generator steps, in this order
+          const V4 r4 = rng_float4(gen);
+          const int nLights = (int)S.numLights;
+          const int lightId = min((int)floorf(rndId * float(nLights)), nLights - 1);
+          if (lightId >= 0 && mtype != MAT_TYPE_LIGHT_SOURCE) {
+            const LightRec& L = S.lights[lightId];
+            const LightSam ls = lightSampleRev(L, v3(r4.x, r4.y, r4.z), hitPos);
+            const V3 dlt = hitPos - ls.pos;
+            const float hitDist = sqrtf_(dot(dlt, dlt));
+            const V3 shadowRayDir = normalize(ls.pos - hitPos);
+            const V3 shadowRayPos = hitPos + hitNorm * smax(maxcomp(hitPos), 1.0f) * 5e-6f;
+            const bool inIllumArea = (dot(shadowRayDir, ls.norm) < 0.0f) || ls.isOmni || ls.hasIES;
+            if (inIllumArea) {
+              // MaterialEval (integrator_pt_mat.cpp:308-528), evaluated before the shadow ray so that nothing but the
+              // candidate contribution has to stay live across the any-hit traversal
+              BsdfE bv; bv.val = v3(0, 0, 0); bv.pdf = 0.0f; bv.dval = v3(0, 0, 0);
+              if (mtype == MAT_TYPE_GLTF) gltfEval(m, shadowRayDir, vdir, hitNorm, baseCol * tex3, four, bv);
+              else if (!DR && mtype == MAT_TYPE_CONDUCTOR) {
+                if (!(smax(m.data[1], m.data[0]) < 1e-3f)) conductorRoughEval(m, m.data[2], m.data[3], shadowRayDir, vdir, hitNorm, tex3, bv);
+              }
+              else if (!DR && mtype == MAT_TYPE_DIFFUSE) diffuseEval(m, ld3(m.colors[0]) * tex3, shadowRayDir, vdir, hitNorm, bv);
+              const float cosThetaOut = smax(dot(shadowRayDir, hitNorm), 0.0f);
+              float lgtPdfW = (1.0f / float(nLights)) * lightEvalPDF(L, shadowRayPos, shadowRayDir, ls.pos, ls.norm, ls.pdf);
+              float misWeight = (S.integratorType == INTEGRATOR_MIS_PT) ? misWeightHeuristic(lgtPdfW, bv.pdf) : 1.0f;
+              if (L.geomType == LIGHT_GEOM_DIRECT) { misWeight = 1.0f; lgtPdfW = 1.0f; }
+              else if (L.geomType == LIGHT_GEOM_POINT) misWeight = 1.0f;
+              const bool isDirectLight = (flags & RAY_FLAG_HAS_NON_SPEC) == 0;
+              if ((S.renderLayer == FB_DIRECT && !isDirectLight) || (S.renderLayer == FB_INDIRECT && isDirectLight)) misWeight = 0.0f;
+              const V3 lightColor = lightIntensity(S, L, shadowRayPos, shadowRayDir);
+              shade = ((lightColor * bv.val) / lgtPdfW) * cosThetaOut * misWeight;
+              if (DR) dshade = ((lightColor * bv.dval) / lgtPdfW) * cosThetaOut * misWeight;
+              wantShadow = true;
+              shPos = shadowRayPos; shDir = shadowRayDir; shFar = hitDist * 0.9995f;
+            }
+          }
+        }
+
+        // -- kernel_NextBounce (integrator_pt.cpp:426-548) --
+        if (mtype == MAT_TYPE_LIGHT_SOURCE) {
+          const V4 tc = texSample(S.textures, m.texid[0], mulRows2x4(m.row0[0], m.row1[0], uv));
+          const uint lightId = (uint)S.remapInst[2 * instId + 1];
+          V3 lightInt = ld3(m.colors[0]) * v3(tc.x, tc.y, tc.z);
+          float misWeight = 1.0f;
+          if (lightId != 0xFFFFFFFFu) {
+            const LightRec& L = S.lights[lightId];
+            const float lightCos = dot(rdir, ld3(L.norm));
+            const float atten = (lightCos < 0.0f || L.geomType == LIGHT_GEOM_SPHERE) ? 1.0f : 0.0f;
+            lightInt = lightIntensity(S, L, rpos, rdir) * atten;
+          }
+          if (S.integratorType == INTEGRATOR_MIS_PT) {
+            if (bounce > 0 && lightId != 0xFFFFFFFFu) {
+              const float lgtPdf = (1.0f / float(S.numLights)) * lightEvalPDF(S.lights[lightId], rpos, rdir, hitPos, hitNorm, 1.0f);
+              misWeight = misWeightHeuristic(misPdf, lgtPdf);
+              if (misPdf <= 0.0f) misWeight = 1.0f;
+            }
+          } else if (S.integratorType == INTEGRATOR_SHADOW_PT && (flags & RAY_FLAG_HAS_NON_SPEC) != 0) misWeight = 0.0f;
+          const bool isDirectLight = (flags & RAY_FLAG_HAS_NON_SPEC) == 0;
+          const bool isFirstNonSpec = (flags & RAY_FLAG_FIRST_NON_SPEC) != 0;
+          if (S.renderLayer == FB_INDIRECT && (isDirectLight || isFirstNonSpec)) misWeight = 0.0f;
+          accum = accum + thr * lightInt * misWeight;
+          if (DR) tailR = lightInt * misWeight;
+          flags |= (RAY_FLAG_IS_DEAD | RAY_FLAG_HIT_LIGHT);
+        } else {
+          BsdfS ms; ms.val = v3(0, 0, 0); ms.pdf = 1.0f; ms.dir = v3(0, 1, 0); ms.ior = 1.0f; ms.flags = flags; ms.dval = v3(0, 0, 0);
+          const V4 rands = rng_float4(gen);                                // GetRandomNumbersMats: drawn for every material type (integrator_pt_mat.cpp:147)
+          if (mtype == MAT_TYPE_GLTF) gltfSampleAndEval(m, rands, vdir, hitNorm, baseCol * tex3, four, ms);
+          else if (!DR && mtype == MAT_TYPE_CONDUCTOR) {
+            if (smax(m.data[1], m.data[0]) < 1e-3f) conductorSmoothSampleAndEval(m, m.data[2], m.data[3], vdir, hitNorm, ms);
+            else                                    conductorRoughSampleAndEval(m, m.data[2], m.data[3], rands, vdir, hitNorm, tex3, ms);
+          }
+          else if (!DR && mtype == MAT_TYPE_DIFFUSE) diffuseSampleAndEval(m, ld3(m.colors[0]) * tex3, rands, vdir, hitNorm, ms);
+          else if (!DR && mtype == MAT_TYPE_DIELECTRIC) {
+            dielectricSmoothSampleAndEval(m, m.data[1], misIor, rands, vdir, hitNorm, ms);
+            ms.flags |= (m.spdid[0] < 0xFFFFFFFFu) ? RAY_FLAG_WAVES_DIVERGED : 0u;
+            misIor = ms.ior;
+          }
+          const float invPdf = 1.0f / smax(ms.pdf, 1e-20f);
+          const V3 bxdfVal = ms.val * invPdf;
+          const float cosTheta = absf(dot(ms.dir, hitNorm));
+          misPdf = (ms.flags & RAY_EVENT_S) != 0 ? -1.0f : ms.pdf;
+          if (S.integratorType == INTEGRATOR_STUPID_PT) thr = thr * (cosTheta * bxdfVal);
+          else {
+            contrib = thr * shade;
+            thr = thr * cosTheta * bxdfVal;
+          }
+          if (DR) {
+            recS = shade; recdS = dshade * baseCol;                          // d shade / d texColor
+            recA = cosTheta * bxdfVal; recdA = (cosTheta * invPdf) * (ms.dval * baseCol);
+          }
+          V3 hp = hitPos;
+          if ((ms.flags & RAY_EVENT_T) != 0) hp = hp + hit.t * rdir * 2.0f * 1e-6f;
+          rpos = offsRayPos(hp, hitNorm, ms.dir);
+          rdir = ms.dir;
+          uint nextFlags = ((flags & ~RAY_FLAG_FIRST_NON_SPEC) | ms.flags);
+          if (S.renderLayer == FB_DIRECT && (flags & RAY_FLAG_HAS_NON_SPEC) != 0) nextFlags |= RAY_FLAG_IS_DEAD;
+          else if ((flags & RAY_FLAG_HAS_NON_SPEC) == 0 && (nextFlags & RAY_FLAG_HAS_NON_SPEC) != 0) nextFlags |= RAY_FLAG_FIRST_NON_SPEC;
+          flags = nextFlags;
+          didBounce = true;
+        }
+      }
+    }
+
+    // ---- (6) shadow rays: RayQuery_AnyHit ---------------------------------------------------------------------------------------
+    if (wantShadow) {
+      HitRec sh;
+      const bool occluded = traceRay<true, STATS>(S, shPos, shDir, 0.0f, shFar, sh, stk, 256, st);
+      if (STATS) { nRays++; nShadow++; }
+      if (!occluded) accum = accum + contrib; else if (DR) { recS = v3(0, 0, 0); recdS = v3(0, 0, 0); }
+    } else if (DR) { recS = v3(0, 0, 0); recdS = v3(0, 0, 0); }
+
+    // ---- (7) bookkeeping: adjoint record, end of path ------------------------------------------------------------------------------
+    if (alive) {
+      if (DR && didBounce) {
+        const size_t s = job.recordLanes;
+        float* r = job.record + ((size_t)bounce * REC_FIELDS) * s + glane;
+        r[0 * s] = recA.x; r[1 * s] = recA.y; r[2 * s] = recA.z;
+        r[3 * s] = recS.x; r[4 * s] = recS.y; r[5 * s] = recS.z;
+        r[6 * s] = recdA.x * thrBefore.x; r[7 * s] = recdA.y * thrBefore.y; r[8 * s] = recdA.z * thrBefore.z;     // T_b * dA_b/dtex
+        r[9 * s] = recdS.x * thrBefore.x; r[10 * s] = recdS.y * thrBefore.y; r[11 * s] = recdS.z * thrBefore.z;   // T_b * dS_b/dtex
+        r[12 * s] = __uint_as_float(recTex);
+        if (recTex != 0xFFFFFFFFu) {
+          for (int k = 0; k < 4; k++) { r[(13 + k) * s] = __int_as_float(recTaps.off[k]); r[(17 + k) * s] = recTaps.w[k]; }
+        }
+      }
+      if (didBounce) bounce++;
+      if ((flags & RAY_FLAG_IS_DEAD) != 0 || bounce >= maxBounce) {
+        // kernel_HitEnvironment (integrator_pt.cpp:550-595), constant environment colour.
+        // The DR replay adds the environment term unconditionally (diff_render/integrator_dr.cpp:1077-1098).
+        const V3 env = ld3(S.envColor);
+        if (DR) accum = accum + thr * env;
+        else if ((flags & RAY_FLAG_OUT_OF_SCENE) != 0) {
+          if (S.integratorType == INTEGRATOR_STUPID_PT) accum = thr * env; else accum = accum + thr * env;
+        }
+        if (DR) {
+          // PixelLossPT (integrator_dr.cpp:1103-1132) + hand-derived reverse sweep replacing __enzyme_autodiff (:1172-1183).
+          // With T_0 = 1, T_{b+1} = T_b A_b and C = sum_b T_b S_b + T_n tail:
+          //   dC/dtex_b = T_b dS_b + T_b dA_b R_{b+1},   R_b = S_b + A_b R_{b+1},   R_n = tail
+          const uint pitch = (uint)S.winWidth;
+          const uint yRef = (uint)S.winHeight - py - 1u;
+          const float* rp = job.refImg + ((size_t)yRef * pitch + px) * job.channels;
+          const V3 diff = v3(accum.x - rp[0], accum.y - rp[1], accum.z - rp[2]);
+          lossLocal += (diff.x * diff.x + diff.y * diff.y + diff.z * diff.z) / float(job.passNum);
+          pix = pix + accum;                                                   // out_color += colorRend (:1124-1126)
+          const size_t s = job.recordLanes;
+          V3 Rn = tailR + env;
+          for (int b = (int)bounce - 1; b >= 0; b--) {
+            const float* r = job.record + ((size_t)b * REC_FIELDS) * s + glane;
+            const V3 A = v3(r[0 * s], r[1 * s], r[2 * s]), Sb = v3(r[3 * s], r[4 * s], r[5 * s]);
+            const uint texId = __float_as_uint(r[12 * s]);
+            if (texId != 0xFFFFFFFFu) {
+              const V3 TdA = v3(r[6 * s], r[7 * s], r[8 * s]), TdS = v3(r[9 * s], r[10 * s], r[11 * s]);
+              const V3 dC = TdS + TdA * Rn;
+              const V3 g = v3(2.0f * diff.x * dC.x, 2.0f * diff.y * dC.y, 2.0f * diff.z * dC.z);
+              const TexRec t = S.textures[texId];
+              float* gbase = job.grad + t.diffOffset;
+              for (int k = 0; k < 4; k++) {
+                const int off = __float_as_int(r[(13 + k) * s]);
+                const float w = r[(17 + k) * s];
+                if (t.diffChannels == 4) {
+                  atomicAdd(gbase + (size_t)off * 4 + 0, g.x * w);
+                  atomicAdd(gbase + (size_t)off * 4 + 1, g.y * w);
+                  atomicAdd(gbase + (size_t)off * 4 + 2, g.z * w);
+                } else atomicAdd(gbase + off, (g.x + g.y + g.z) * w);
+              }
+            }
+            Rn = Sb + A * Rn;
+          }
+        } else {
+          // kernel_ContributeToImage (integrator_pt.cpp:598-657)
+          const V3 c = accum * ld3(S.camRespoceRGB);
+          if (job.channels == 1) pix.x += accum.x * S.exposureMult;
+          else pix = pix + S.exposureMult * c;
+        }
+        alive = false;
+      }
+    }
+  }
+
+  if (STATS) {
+    // wave-reduce, one atomic per counter per wave
+    unsigned long long v[8] = { nRays, st.nodes, st.tris, nHits, nShadow, nPaths, st.insts, 0ull };
+    for (int i = 0; i < 8; i++) {
+      unsigned long long x = v[i];
+      for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+      if ((threadIdx.x & 63) == 0 && x) atomicAdd(&job.counters->v[i], x);
+    }
+  }
+  if (DR) {
+    float x = lossLocal;
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(job.lossAccum, x);
+  }
+}
+
+// ---- helper kernels --------------------------------------------------------------------------------------------------------------
+// kernel_PackXY over the window (integrator_rt.cpp:13-31)
+__global__ void packXYKernel(uint* out, int W, int H, uint ts)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= W || y >= H) return;
+  uint offset = (uint)y * (uint)W + (uint)x;
+  if (ts != 1u) {
+    const uint inX = (uint)x % ts, inY = (uint)y % ts;
+    const uint wBlocks = (uint)W / ts;
+    offset = (((uint)x / ts) + ((uint)y / ts) * wBlocks) * ts * ts + inY * ts + inX;
+  }
+  out[offset] = (((uint)y << 16) & 0xFFFF0000u) | ((uint)x & 0x0000FFFFu);
+}
+
+// InitRandomGens (integrator_pt.cpp:13-21)
+__global__ void initRandomGensKernel(Rng* gens, uint n)
+{
+  const uint i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) gens[i] = rng_init(i);
+}
+
+// batched RayQuery_NearestHit / RayQuery_AnyHit for the ISceneObject entry points
+template <int STACK>
+__global__ void __launch_bounds__(256) rayQueryKernel(const DevScene S, const float4* posNear, const float4* dirFar, uint n, void* out, int anyHit)
+{
+  __shared__ uint stackMem[STACK * 256];
+  uint* stk = &stackMem[threadIdx.x];
+  const uint i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = posNear[i], d = dirFar[i];
+  HitRec h; TravStats st; st.nodes = st.tris = st.insts = 0;
+  if (anyHit) {
+    const bool occ = traceRay<true, false>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, 256, st);
+    ((uint*)out)[i] = occ ? 1u : 0u;
+  } else {
+    const bool found = traceRay<false, false>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, 256, st);
+    // CRT_Hit (CrossRT.h:23-30) as the Embree backend fills it (EmbreeRT.cpp:343-360)
+    float4* o = (float4*)out + 2 * (size_t)i;
+    if (found) {
+      o[0] = make_float4(h.t, __uint_as_float(h.prim), __uint_as_float(h.inst), __uint_as_float(S.insts[h.inst].geomId));
+      o[1] = make_float4(h.v, h.u, 1.0f - h.v - h.u, 0.0f);
+    } else {
+      o[0] = make_float4(d.w, __uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu));
+      o[1] = make_float4(0, 0, 0, 0);
+    }
+  }
+}
+
+// AdamOptimizer<float>::step (diff_render/adam.h:43-62): HBM-bound, 16 bytes per lane per array
+__global__ void adamStepKernel(float* state, const float* grad, float* momentum, float* gsq, size_t n, float gamma)
+{
+  const float alpha = 0.5f, beta = 0.25f, epsilon = 1e-8f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float g = grad[i];
+    const float mo = momentum[i] * beta + g * (1.0f - beta);
+    const float gs = 2.0f * (gsq[i] * alpha + (g * g) * (1.0f - alpha));
+    momentum[i] = mo; gsq[i] = gs;
+    state[i] -= (gamma * mo / (__builtin_sqrtf(gs + epsilon)));
+  }
+}
+
+} // namespace hpt

@@ -1,0 +1,100 @@
+// Plain-data layouts shared by the host side and the gfx950 kernels.
+//
+// Material / LightSource keep the reference's 320-byte records (include/cmaterial.h:187-203,
+// include/clight.h:19-56) so that Integrator::m_materials / m_lights upload with one memcpy and the
+// Update_m_materials / Update_m_lights partial-update hooks stay trivial.
+#pragma once
+#include <stdint.h>
+
+namespace hpt {
+
+typedef unsigned int uint;
+
+struct MaterialRec
+{
+  uint  mtype, cflags, lightId, nonlinear;
+  uint  texid[4], spdid[4], datai[4];
+  float colors[4][4];
+  float row0[4][4];
+  float row1[4][4];
+  float data[16];
+};
+static_assert(sizeof(MaterialRec) == 320, "Material record must stay 320 bytes");
+
+struct LightRec
+{
+  float matrix[16], iesMatrix[16];               // column-major
+  float samplerRow0[4], samplerRow1[4], samplerRow0Inv[4], samplerRow1Inv[4];
+  float pos[4], intensity[4], norm[4];
+  float size[2]; float pdfA; uint geomType;
+  uint  distType, flags, pdfTableOffset, pdfTableSize;
+  uint  specId, texId, iesId; float mult;
+  uint  pdfTableSizeX, pdfTableSizeY, camBackTexId; float lightCos1;
+  float lightCos2; uint matId; float dummy2, dummy3;
+};
+static_assert(sizeof(LightRec) == 320, "LightSource record must stay 320 bytes");
+
+// ---- BVH2 in HBM ------------------------------------------------------------------------------------------------
+// One 64-byte node holds BOTH child boxes, so one visit = four 16-byte loads from one 64-byte line:
+//   q0 = (lo0.x lo0.y lo0.z hi0.x)  q1 = (hi0.y hi0.z lo1.x lo1.y)  q2 = (lo1.z hi1.x hi1.y hi1.z)  q3 = (ref0 ref1 - -)
+// A child reference is 32 bits:
+//   bit 31 clear : inner node, value = node index (TLAS and all BLAS share one array)
+//   bit 31 set   : leaf; bits 30..28 = triangle count (1..4) and bits 27..0 = first triangle (global, BVH order);
+//                  count 0 = instance leaf, bits 27..0 = instance id; 0xFFFFFFFF = "leave instance" stack marker.
+static const uint REF_LEAF    = 0x80000000u;
+static const uint REF_RESTORE = 0xFFFFFFFFu;
+static const uint REF_NONE    = 0xFFFFFFFEu;   // empty scene
+static const int  BVH_LEAF_MAX = 4;
+
+struct BvhNode { float q[12]; uint ref0, ref1, pad0, pad1; };
+static_assert(sizeof(BvhNode) == 64, "BVH2 node must be one 64-byte line");
+
+// 48-byte triangle: v0, e1 = v1-v0, e2 = v2-v0 (what Moeller-Trumbore consumes), primId in the spare lane
+struct BvhTri { float v0[3]; uint primId; float e1[3]; uint pad0; float e2[3]; uint pad1; };
+static_assert(sizeof(BvhTri) == 48, "triangle record must be 48 bytes");
+
+// 64-byte instance record: world->object rows (3x4), BLAS root reference, mesh id
+struct BvhInst { float row0[4], row1[4], row2[4]; uint root, geomId, pad0, pad1; };
+static_assert(sizeof(BvhInst) == 64, "instance record must be 64 bytes");
+
+struct TexRec
+{
+  uint w, h, format, flags, addrU, addrV, filter, pad;
+  const void* data;       // device pointer
+  // differentiable-texture binding (IntegratorDR::TexInfo, diff_render/integrator_dr.h:56-64); offset = ~0 when unbound
+  unsigned long long diffOffset; uint diffW, diffH, diffChannels, pad2;
+};
+
+// Everything a kernel needs, passed by value as the kernel argument (lands in SGPRs via the kernarg segment).
+struct DevScene
+{
+  const BvhNode* nodes;
+  const BvhTri*  tris;
+  const BvhInst* insts;
+  uint           rootRef;
+  uint           numInsts;
+
+  const uint*    triIndices;      // m_triIndices
+  const float*   vData8f;         // m_vData8f (8 floats per vertex)
+  const uint*    matIdByPrimId;   // m_matIdByPrimId
+  const uint*    matVertOffset;   // m_matVertOffset (2 per geom)
+  const float*   normMat;         // 12 floats per instance: rows of the upper 3x3 of m_normMatrices (padded to float4)
+  const int*     remapInst;       // m_remapInst (2 per instance)
+  const int*     allRemapLists;   // m_allRemapLists
+  uint           allRemapListsSize;
+  uint           numLights;
+  const MaterialRec* materials;
+  const LightRec*    lights;
+  const TexRec*      textures;
+
+  // plain-data members (UpdateMembersPlainData)
+  float projInv[16], worldViewInv[16];
+  int   winStartX, winStartY, winWidth, winHeight, fbWidth, fbHeight;
+  uint  traceDepth, integratorType, renderLayer, tileSize;
+  float exposureMult, camLensRadius, camTargetDist;
+  float camRespoceRGB[4], envColor[4];
+};
+
+struct Counters { unsigned long long v[8]; };   // rays, nodes, tris, surfaceHits, shadowRays, paths, instEnter, texFetch
+
+} // namespace hpt

@@ -1,0 +1,166 @@
+/* hydra_hip.h -- C ABI of the MI355X-native (gfx950) path-tracing core.
+ *
+ * This is the whole drop-in boundary: plain pointers and sizes, no C++ types, no torch types. A host adapter
+ * (hydracore3_amd/csrc/integrator_hip.h: class IntegratorHIP, class BVH2SceneHIP) exposes it through the
+ * reference's own class surface; INTEGRATION.md shows the subclass a HydraCore3 maintainer would add.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the HydraCore3 tree).
+ * All functions return 0 on success and a non-zero code on failure unless stated otherwise;
+ * hpt_last_error() gives the message. Nothing throws across this boundary. One hpt_ctx per GPU; all calls
+ * on a context come from one host thread (as in the reference: main.cpp, drmain.cpp).
+ */
+#ifndef HYDRA_HIP_H
+#define HYDRA_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPT_OK            0
+#define HPT_ERR_ARG       1   /* bad argument (the reference prints and returns, e.g. EmbreeRT.cpp:144-159) */
+#define HPT_ERR_HIP       2   /* HIP runtime error */
+#define HPT_ERR_STATE     3   /* call order violated (e.g. render before CommitDeviceData) */
+#define HPT_ERR_UNSUPPORTED 4 /* scene uses a feature outside the hot path's scope */
+
+typedef struct hpt_ctx hpt_ctx;
+
+/* texture + sampler: LiteImage::ICombinedImageSampler (integrator_pt.h:577, integrator_pt_scene_tex.cpp:19-103) */
+typedef struct hpt_texture_desc {
+  uint32_t width, height;
+  uint32_t format;    /* 0: RGBA8 in a uint32 (r = low byte), 1: RGBA32F, 2: R32F */
+  uint32_t flags;     /* bit 0: sRGB decode (rgb^2.2 after filtering; HydraSampler::inputGamma, integrator_pt.h:71) */
+  uint32_t addressU;  /* LiteImage::Sampler::AddressMode: 0 WRAP, 2 CLAMP */
+  uint32_t addressV;
+  uint32_t filter;    /* LiteImage::Sampler::Filter: 0 NEAREST, 1 LINEAR */
+  uint32_t reserved;
+  const void* data;   /* host pointer, row-major, row 0 first */
+} hpt_texture_desc;
+
+/* The flat scene vectors Integrator::LoadScene fills (integrator_pt.h:472-500), as {pointer,count} pairs. */
+typedef struct hpt_scene_desc {
+  uint32_t numGeoms, numInsts, numVerts, numTris;
+  const float*    vPos4f;         /* float4 x numVerts: positions handed to AddGeom_Triangles3f (integrator_pt_scene.cpp:799-800) */
+  const float*    vData8f;        /* m_vData8f: {norm.xyz, u | tang.xyz, v} x numVerts (integrator_pt.h:479-484) */
+  const uint32_t* triIndices;     /* m_triIndices: 3 x numTris, mesh-local */
+  const uint32_t* matIdByPrimId;  /* m_matIdByPrimId: numTris */
+  const uint32_t* matVertOffset;  /* m_matVertOffset: uint2 x numGeoms (triOffset, vertOffset) */
+  const uint32_t* geomTriCount;   /* numGeoms */
+  const uint32_t* geomVertCount;  /* numGeoms */
+  const uint32_t* instGeomId;     /* numInsts: geomId passed to AddInstance, in instance order (integrator_pt_scene.cpp:852-885) */
+  const float*    instMatrices;   /* numInsts column-major float4x4 (CrossRT.h:134, EmbreeRT.cpp:256) */
+  const float*    normMatrices;   /* m_normMatrices: numInsts column-major float4x4 (integrator_pt_scene.cpp:877) */
+  const int32_t*  remapInst;      /* m_remapInst: int2 x numInsts (remap list id, light id) */
+  const int32_t*  allRemapLists;  /* m_allRemapLists: lists then offsets (integrator_pt_scene.cpp:909-924) */
+  uint32_t        allRemapListsLen;
+  uint32_t        allRemapListsSize; /* m_allRemapListsSize */
+  const void*     materials;      /* m_materials: 320-byte Material records (include/cmaterial.h:187-203) */
+  uint32_t        numMaterials;
+  uint32_t        numLights;
+  const void*     lights;         /* m_lights: 320-byte LightSource records (include/clight.h:19-56) */
+  const hpt_texture_desc* textures; /* m_textures */
+  uint32_t        numTextures;
+  uint32_t        reserved;
+} hpt_scene_desc;
+
+/* The plain-data members UpdateMembersPlainData() refreshes before every *Block call (integrator_pt.h:268, main.cpp:398). */
+typedef struct hpt_params {
+  float    projInv[16];       /* m_projInv, column-major */
+  float    worldViewInv[16];  /* m_worldViewInv */
+  int32_t  winStartX, winStartY, winWidth, winHeight, fbWidth, fbHeight; /* SetViewport / SetFrameBufferSize (integrator_pt.h:365-392) */
+  uint32_t traceDepth;        /* m_traceDepth */
+  uint32_t integratorType;    /* m_intergatorType: 0 naive, 1 shadow, 2 MIS (integrator_pt.h:330-332) */
+  uint32_t renderLayer;       /* m_renderLayer: FB_COLOR / FB_DIRECT / FB_INDIRECT (integrator_pt.h:406-408) */
+  uint32_t tileSize;          /* m_tileSize */
+  uint32_t spectralMode;      /* m_spectral_mode; must be 0 (spectral rendering is out of scope) */
+  uint32_t reserved0;
+  float    exposureMult, camLensRadius, camTargetDist, reserved1;
+  float    camRespoceRGB[4];  /* m_camRespoceRGB */
+  float    envColor[4];       /* m_envColor */
+} hpt_params;
+
+/* CRT_Hit (external/CrossRT/CrossRT.h:23-30) */
+typedef struct hpt_hit {
+  float t; uint32_t primId, instId, geomId; float coords[4];
+} hpt_hit;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------------- */
+int  hpt_create(int device, hpt_ctx** out);          /* Integrator::Integrator + CreateSceneRT (integrator_pt.h:127-137, CrossRT.h:195) */
+void hpt_destroy(hpt_ctx* ctx);                      /* Integrator::~Integrator + DeleteSceneRT (CrossRT.h:196) */
+const char* hpt_last_error(hpt_ctx* ctx);
+int  hpt_device_info(hpt_ctx* ctx, int* numCUs, int* wavefront, char* name, size_t nameLen);
+
+/* ---- ISceneObject: BVH2 replacement of the Embree backend (external/CrossRT/CrossRT.h:45-176) ------------------ */
+int      hpt_clear_geom(hpt_ctx* ctx);                                                   /* ClearGeom            :56 */
+uint32_t hpt_add_geom_triangles3f(hpt_ctx* ctx, const float* vpos3f, size_t vertNumber, const uint32_t* triIndices,
+                                  size_t indNumber, uint32_t flags, size_t vByteStride); /* AddGeom_Triangles3f  :73-74; returns geomId or 0xFFFFFFFF */
+int      hpt_update_geom_triangles3f(hpt_ctx* ctx, uint32_t geomId, const float* vpos3f, size_t vertNumber,
+                                     const uint32_t* triIndices, size_t indNumber, uint32_t flags, size_t vByteStride); /* UpdateGeom_Triangles3f :85-86 */
+int      hpt_clear_scene(hpt_ctx* ctx);                                                  /* ClearScene           :105 */
+uint32_t hpt_add_instance(hpt_ctx* ctx, uint32_t geomId, const float matrix16[16]);      /* AddInstance          :118; returns instId or 0xFFFFFFFF */
+int      hpt_update_instance(hpt_ctx* ctx, uint32_t instId, const float matrix16[16]);   /* UpdateInstance       :134 */
+int      hpt_commit_scene(hpt_ctx* ctx, uint32_t options);                               /* CommitScene          :110: builds + uploads the two-level BVH2 */
+/* RayQuery_NearestHit / RayQuery_AnyHit (:148,:165), batched: n rays from host memory, results to host memory. */
+int      hpt_ray_query_nearest(hpt_ctx* ctx, const float* posAndNear4, const float* dirAndFar4, uint32_t n, hpt_hit* out);
+int      hpt_ray_query_any(hpt_ctx* ctx, const float* posAndNear4, const float* dirAndFar4, uint32_t n, uint32_t* out);
+
+/* ---- scene tables --------------------------------------------------------------------------------------------- */
+/* CommitDeviceData() (integrator_pt.h:265): uploads every scene vector. If desc->vPos4f is non-NULL the geometry
+ * is (re)registered through the ISceneObject calls above in mesh / instance order and committed; otherwise the
+ * acceleration structure committed earlier through hpt_add_geom_* / hpt_add_instance / hpt_commit_scene is used. */
+int  hpt_upload_scene(hpt_ctx* ctx, const hpt_scene_desc* desc);
+int  hpt_update_params(hpt_ctx* ctx, const hpt_params* params);                          /* UpdateMembersPlainData :268 */
+int  hpt_update_materials(hpt_ctx* ctx, size_t first, size_t count, const void* mats);   /* Update_m_materials     :468 */
+int  hpt_update_lights(hpt_ctx* ctx, size_t first, size_t count, const void* lights);    /* Update_m_lights        :469 */
+int  hpt_pack_xy(hpt_ctx* ctx, uint32_t tidX, uint32_t tidY);                            /* PackXYBlock (integrator_pt_host.cpp:19-27) */
+int  hpt_get_packed_xy(hpt_ctx* ctx, uint32_t* out, uint32_t count);
+int  hpt_init_random_gens(hpt_ctx* ctx, uint32_t maxThreads);                            /* InitRandomGens (integrator_pt.cpp:13-21) */
+int  hpt_get_random_gens(hpt_ctx* ctx, uint32_t* outUint2, uint32_t count);              /* m_randomGens is integrator-owned, device copy authoritative */
+int  hpt_set_random_gens(hpt_ctx* ctx, const uint32_t* inUint2, uint32_t count);
+
+/* ---- the hot path --------------------------------------------------------------------------------------------- */
+/* Integrator::PathTraceBlock(tid, channels, out_color, a_passNum) (integrator_pt.h:260, integrator_pt_host.cpp:57-73).
+ * Processes tid in [tidBegin, tidBegin+tidCount) (the reference always passes the whole window: tidBegin = 0,
+ * tidCount = W*H; a sub-range is what one rank of a multi-GPU job renders). out_color is the caller's full
+ * W*H*channels host framebuffer; radiance is ACCUMULATED into it (+=), un-normalised, as in the reference. */
+int  hpt_path_trace_block(hpt_ctx* ctx, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out_color, uint32_t passNum);
+/* NaivePathTraceBlock (integrator_pt.h:259, integrator_pt_host.cpp:39-55) */
+int  hpt_naive_path_trace_block(hpt_ctx* ctx, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out_color, uint32_t passNum);
+/* Same with the framebuffer already resident in device memory (kernel_slicer's generated class keeps out_color on the
+ * device between calls, kmake_mega.json:18). stream is a hipStream_t (NULL = default stream); asynchronous. */
+int  hpt_path_trace_block_dev(hpt_ctx* ctx, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out_color_dev,
+                              uint32_t passNum, int naive, void* stream);
+
+/* ---- differentiable rendering (diff_render/integrator_dr.h:42-47, 103) ------------------------------------------ */
+int  hpt_put_diff_tex2d(hpt_ctx* ctx, uint32_t texId, uint32_t width, uint32_t height, uint32_t channels,
+                        uint64_t* outOffset, uint64_t* outSize);                         /* PutDiffTex2D (integrator_dr.cpp:33-53) */
+int  hpt_reset_diff_tex(hpt_ctx* ctx);                                                   /* LoadSceneEnd (integrator_dr.cpp:24-31) */
+/* IntegratorDR::PathTraceDR (integrator_dr.cpp:1135-1218). a_dataGrad is overwritten (zeroed first), out_color accumulated,
+ * *outLoss receives the value the reference returns. Host-pointer form. */
+int  hpt_path_trace_dr(hpt_ctx* ctx, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out_color, uint32_t passNum,
+                       const float* refImg, const float* data, float* dataGrad, size_t gradSize, float* outLoss);
+/* Device-pointer form: all four arrays resident; *lossAccumDev (one float, device) receives sum over samples of loss / passNum
+ * (divide by W*H for the reference's return value); dataGradDev is ACCUMULATED into (zero it yourself). Asynchronous. */
+int  hpt_path_trace_dr_dev(hpt_ctx* ctx, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out_color_dev, uint32_t passNum,
+                           const float* refImgDev, const float* dataDev, float* dataGradDev, size_t gradSize, float* lossAccumDev, void* stream);
+/* AdamOptimizer<float>::step (diff_render/adam.h:43-62) on device arrays. */
+int  hpt_adam_step_dev(hpt_ctx* ctx, float* stateDev, const float* gradDev, float* momentumDev, float* gSquareDev, size_t n, int iter, void* stream);
+
+/* ---- timing / instrumentation ----------------------------------------------------------------------------------- */
+/* GetExecutionTime(name, out[4]) (integrator_pt.h:266, main.cpp:416-419): out[0] exec ms, [1] host->device, [2] device->host, [3] overhead */
+int  hpt_get_execution_time(hpt_ctx* ctx, const char* funcName, float out[4]);
+/* Traversal counters of the last hpt_*_block call made with instrumentation enabled: {rays, nodesVisited, trisTested,
+ * surfaceHits, shadowRays, paths, instancesEntered, texFetches}. Feeds the algorithmic-bytes roofline. */
+int  hpt_set_instrumentation(hpt_ctx* ctx, int enabled);
+int  hpt_get_counters(hpt_ctx* ctx, uint64_t out[8]);
+/* Launch geometry of the persistent kernel: blocks per CU (0 = automatic). */
+int  hpt_set_launch_config(hpt_ctx* ctx, int blocksPerCU);
+/* Duration of the last path-tracing kernel, measured with HIP events on the stream it ran on (ms). */
+int  hpt_last_kernel_ms(hpt_ctx* ctx, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYDRA_HIP_H */

@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpaths/s of Integrator::PathTraceBlock on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cornell|interior] [--spp S]
+
+A *step* is one PathTraceBlock call over the whole frame (W*H pixels x spp passes, MIS path tracing) with the
+framebuffer, RNG states and scene resident in HBM. N = 1 runs BASELINE.json configs[1] (scenes/test_035 Cornell box,
+1024 x 1024, 1024 spp). For N > 1 (launched through torch.distributed.run, one rank per GPU) the frame's swizzled pixel
+index range is split into N contiguous windows, every rank renders its window into a zeroed full-size framebuffer and
+the frame is assembled by one RCCL reduce(SUM) to rank 0 per step, inside the timed region (strong scaling).
+
+Prints ONE JSON line on rank 0 (see the contract in the task description); `roofline` prices the persistent
+path-tracing kernel against HBM bandwidth using ALGORITHMIC bytes measured by the library's
+instrumented build on the same scene, `cpu_baseline` times the CPU oracle (a restated port, not the original binary)
+on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch   # imported first: the HIP runtime torch bundles must be the one libhydra_hip.so binds to
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def build_scene(workload, width, height):
+    from hydracore3_amd.scene import load_hydra_xml
+    if workload == "cornell":
+        return load_hydra_xml(os.path.join(ROOT, "tests", "golden", "scenes", "test_035", "statex_00001.xml"), width, height)
+    from hydracore3_amd.synth import interior_scene
+    return interior_scene(width, height)
+
+
+def algorithmic_bytes(counters, paths, spp):
+    """bytes a path has to touch, from the traversal / shading counters of an instrumented launch."""
+    c = counters
+    trav = c["nodes"] * 64 + c["tris"] * 48 + c["instances_entered"] * 64
+    surf = c["surface_hits"] * (3 * 4 + 3 * 32 + 4 + 8 + 64 + 320 + 4 * 4)
+    nee = c["surface_hits"] * 320
+    per_pixel = (8 + 8 + 4 + 16) * (paths / spp)
+    total = trav + surf + nee + per_pixel
+    return {"total": total / paths, "traversal": trav / paths, "nodes_per_ray": c["nodes"] / max(c["rays"], 1),
+            "tris_per_ray": c["tris"] / max(c["rays"], 1), "rays_per_path": c["rays"] / paths}
+
+
+def cpu_baseline(workload, width, height, target_s=12.0):
+    """Time the CPU oracle (restated port of PathTraceBlock, OpenMP over pixels) on a bounded sample of the same frame."""
+    from oracle.orc import OracleIntegrator
+    sc = build_scene(workload, width, height)
+    cores = os.cpu_count() or 1
+    o = OracleIntegrator(sc, threads=cores)
+    img = np.zeros((height, width, 4), np.float32)
+    t0 = time.time()
+    o.path_trace_block(img, 1)
+    t1 = time.time() - t0
+    spp = int(max(1, min(64, target_s / max(t1, 1e-3))))
+    t0 = time.time()
+    o.path_trace_block(img, spp)
+    dt = time.time() - t0
+    return {"value": width * height * spp / dt / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
+            "sample": f"{workload} {width}x{height} @ {spp} spp (oracle/liboracle.so, OpenMP, {cores} threads, {dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cornell", choices=["cornell", "interior"])
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm
+
+    import __graft_entry__ as g
+    if rank == 0:
+        g.build()
+    if dist is not None:
+        dist.barrier()
+    from hydracore3_amd.api import HipIntegrator
+
+    W, H = (args.width or (1024 if args.workload == "cornell" else 1920)), (args.height or (1024 if args.workload == "cornell" else 1080))
+    spp = args.spp
+    sc = build_scene(args.workload, W, H)
+    integ = HipIntegrator(sc, device=local_rank)
+    if args.blocks_per_cu:
+        integ.set_launch_config(args.blocks_per_cu)
+    N = W * H
+    # contiguous windows of the tile-swizzled tid range, aligned to one 8x8 tile (64 tids)
+    per = ((N + world - 1) // world + 63) // 64 * 64
+    t_begin = min(rank * per, N)
+    t_count = min(per, N - t_begin)
+
+    frame = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        frame.zero_()
+        integ.path_trace_block_dev(frame.data_ptr(), spp, t_begin, t_count, 4, False, stream)
+        if dist is not None:
+            dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)       # final RCCL reduce of the framebuffer over xGMI
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if world == 1:
+            kernel_ms.append(integ.last_kernel_ms())               # HIP events on the launch stream (syncs on the 2nd event)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        kernel_ms = [integ.last_kernel_ms()]
+    total_paths = float(N) * spp * args.steps
+    value = total_paths / elapsed / 1e6
+
+    mean_lum = float(frame[..., :3].mean().item()) / spp if rank == 0 else 0.0
+
+    roofline, cpu = None, None
+    if rank == 0:
+        # algorithmic bytes per path from the instrumented kernel on the same frame (fewer passes: the statistics are stationary)
+        probe_spp = min(spp, 8)
+        integ.set_instrumentation(True)
+        integ.InitRandomGens(N)
+        probe = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+        integ.path_trace_block_dev(probe.data_ptr(), probe_spp, 0, N, 4, False, stream)
+        torch.cuda.synchronize()
+        cnt = integ.counters()
+        integ.set_instrumentation(False)
+        ab = algorithmic_bytes(cnt, float(N) * probe_spp, probe_spp)
+        k_ms = float(np.mean(kernel_ms))
+        paths_per_launch = float(t_count) * spp
+        achieved = ab["total"] * paths_per_launch / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "kernel": "pathTraceKernel", "kernel_ms": round(k_ms, 3),
+                    "algorithmic_bytes_per_path": round(ab["total"], 1), "traversal_bytes_per_path": round(ab["traversal"], 1),
+                    "nodes_per_ray": round(ab["nodes_per_ray"], 2), "tris_per_ray": round(ab["tris_per_ray"], 2),
+                    "rays_per_path": round(ab["rays_per_path"], 2)}
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.workload, W, H)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+    if rank == 0:
+        out = {"metric": "Mpaths/s (fwd PathTraceBlock, MIS path tracing)", "value": round(value, 2), "unit": "Mpaths/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"scenes/test_035 Cornell box {W}x{H} @ {spp} spp, forward PathTraceBlock" if args.workload == "cornell"
+                          else f"synthetic 1M-triangle interior {W}x{H} @ {spp} spp, forward PathTraceBlock",
+                          "paths_per_step": N * spp, "trace_depth": sc.trace_depth, "integrator": "mispt",
+                          "sharding": f"{world} contiguous tid windows + RCCL reduce" if world > 1 else "single GPU",
+                          "mean_radiance": round(mean_lum, 5)},
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -110,10 +110,8 @@ def main():
     if args.blocks_per_cu:
         integ.set_launch_config(args.blocks_per_cu)
     N = W * H
-    # contiguous windows of the tile-swizzled tid range, aligned to one 8x8 tile (64 tids)
-    per = ((N + world - 1) // world + 63) // 64 * 64
-    t_begin = min(rank * per, N)
-    t_count = min(per, N - t_begin)
+    from hydracore3_amd.sharding import tid_window
+    t_begin, t_count = tid_window(rank, world, N)     # contiguous, tile-aligned windows of the swizzled tid range
 
     frame = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream

@@ -418,6 +418,34 @@ class SceneData:
         self.mat_id_by_prim = np.concatenate([self.mat_id_by_prim, mat_ids])
         return len(self.geom_tri_count) - 1
 
+    def add_meshes(self, meshes):
+        """Bulk add_mesh for many meshes (one concatenation instead of one per mesh)."""
+        vp, vd, ti, mi = [self.vpos], [self.vdata], [self.tri_indices], [self.mat_id_by_prim]
+        tri_off, vert_off = self.mat_id_by_prim.size, self.vpos.shape[0]
+        first = len(self.geom_tri_count)
+        for pos4, norm4, tang4, uv2, indices, mat_ids in meshes:
+            pos4 = np.asarray(pos4, np.float32).reshape(-1, 4)
+            nv = pos4.shape[0]
+            d = np.zeros((nv, 8), np.float32)
+            d[:, 0:3] = np.asarray(norm4, np.float32).reshape(nv, -1)[:, :3]
+            d[:, 4:7] = np.asarray(tang4, np.float32).reshape(nv, -1)[:, :3]
+            uv2 = np.asarray(uv2, np.float32).reshape(nv, 2)
+            d[:, 3], d[:, 7] = uv2[:, 0], uv2[:, 1]
+            indices = np.asarray(indices, np.uint32).reshape(-1)
+            nt = indices.size // 3
+            mat_ids = np.asarray(mat_ids, np.uint32).reshape(-1)
+            if mat_ids.size == 1:
+                mat_ids = np.full((nt,), mat_ids[0], np.uint32)
+            self.mat_vert_offset.append((tri_off, vert_off))
+            self.geom_tri_count.append(nt)
+            self.geom_vert_count.append(nv)
+            vp.append(pos4); vd.append(d); ti.append(indices); mi.append(mat_ids)
+            tri_off += nt
+            vert_off += nv
+        self.vpos, self.vdata = np.concatenate(vp), np.concatenate(vd)
+        self.tri_indices, self.mat_id_by_prim = np.concatenate(ti), np.concatenate(mi)
+        return first
+
     def add_instance(self, geom_id, matrix_rowmajor, remap_list=-1, light_id=-1) -> int:
         self.inst_geom.append(geom_id)
         self.inst_matrices.append(np.asarray(matrix_rowmajor, np.float64).reshape(4, 4))

@@ -1,0 +1,175 @@
+"""Synthetic, deterministic scenes (no files needed): analytic test set-ups and the benchmark scenes of SURVEY.md 8d."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import scene as S
+
+
+def _quad(p0, ex, ey, nu=1, nv=1, uv_scale=1.0):
+    """Tessellated parallelogram p0 + s*ex + t*ey, s,t in [0,1]; returns pos4, norm4, tang4, uv, idx."""
+    p0, ex, ey = (np.asarray(v, np.float64) for v in (p0, ex, ey))
+    n = np.cross(ex, ey)
+    n /= np.linalg.norm(n)
+    s, t = np.meshgrid(np.linspace(0, 1, nu + 1), np.linspace(0, 1, nv + 1), indexing="xy")
+    pos = p0[None, None, :] + s[..., None] * ex + t[..., None] * ey
+    nvtx = (nu + 1) * (nv + 1)
+    pos4 = np.concatenate([pos.reshape(nvtx, 3), np.ones((nvtx, 1))], 1).astype(np.float32)
+    norm4 = np.tile(np.append(n, 0.0), (nvtx, 1)).astype(np.float32)
+    tang4 = np.tile(np.append(ex / np.linalg.norm(ex), 0.0), (nvtx, 1)).astype(np.float32)
+    uv = (np.stack([s, t], -1).reshape(nvtx, 2) * uv_scale).astype(np.float32)
+    idx = []
+    for j in range(nv):
+        for i in range(nu):
+            a = j * (nu + 1) + i
+            idx += [a, a + 1, a + nu + 2, a, a + nu + 2, a + nu + 1]
+    return pos4, norm4, tang4, uv, np.asarray(idx, np.uint32)
+
+
+def _merge(parts):
+    """Concatenate (pos4, norm4, tang4, uv, idx, matids) pieces into one mesh."""
+    pos, nrm, tng, uv, idx, mat, base = [], [], [], [], [], [], 0
+    for p, n, t, u, i, m in parts:
+        pos.append(p); nrm.append(n); tng.append(t); uv.append(u)
+        idx.append(i + base)
+        mat.append(np.full(i.size // 3, m, np.uint32) if np.isscalar(m) else np.asarray(m, np.uint32))
+        base += p.shape[0]
+    return (np.concatenate(pos), np.concatenate(nrm), np.concatenate(tng), np.concatenate(uv),
+            np.concatenate(idx).astype(np.uint32), np.concatenate(mat))
+
+
+def plane_under_rect_light(width=64, height=64, albedo=0.5, light_h=2.0, light_half=0.5, radiance=10.0) -> S.SceneData:
+    """A Lambertian floor (y = 0) under a downward-facing square light: direct lighting has a closed form."""
+    sc = S.SceneData()
+    sc.width, sc.height = width, height
+    sc.cam_pos, sc.cam_look_at, sc.cam_up = (0.0, 3.0, 5.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)
+    sc.fov, sc.trace_depth = 35.0, 1
+    sc.materials.append(S.material_lambert((albedo, albedo, albedo)))
+    p, n, t, uv, idx = _quad((-20, 0, 20), (40, 0, 0), (0, 0, -40))
+    g = sc.add_mesh(p, n, t, uv, idx, [0])
+    sc.add_instance(g, np.eye(4))
+    sc.lights.append(S.light_rect(S.translate(0, light_h, 0), light_half, light_half, (1, 1, 1), radiance))
+    return sc
+
+
+def furnace_plane(width=32, height=32, albedo=(0.2, 0.5, 0.9), env=(1.0, 2.0, 0.5)) -> S.SceneData:
+    """A Lambertian plane filling the view under a constant environment: radiance is exactly albedo * env."""
+    sc = S.SceneData()
+    sc.width, sc.height = width, height
+    sc.cam_pos, sc.cam_look_at, sc.cam_up = (0.0, 2.0, 0.0), (0.0, 0.0, 0.0), (0.0, 0.0, -1.0)
+    sc.fov, sc.trace_depth = 40.0, 2
+    sc.env_color = (*env, 0.0)
+    sc.materials.append(S.material_lambert(albedo))
+    p, n, t, uv, idx = _quad((-50, 0, 50), (100, 0, 0), (0, 0, -100))
+    sc.add_instance(sc.add_mesh(p, n, t, uv, idx, [0]), np.eye(4))
+    return sc
+
+
+def icosphere(subdiv):
+    """Unit icosphere; returns (verts[n,3], tris[m,3])."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    v = [np.asarray(p, np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(subdiv):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[k] = len(v) - 1
+            return cache[k]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.asarray(v), np.asarray(f, np.uint32)
+
+
+def _sphere_mesh(subdiv):
+    v, f = icosphere(subdiv)
+    nv = v.shape[0]
+    pos4 = np.concatenate([v, np.ones((nv, 1))], 1).astype(np.float32)
+    norm4 = np.concatenate([v, np.zeros((nv, 1))], 1).astype(np.float32)
+    tang = np.stack([-v[:, 2], np.zeros(nv), v[:, 0]], 1)
+    ln = np.linalg.norm(tang, axis=1, keepdims=True)
+    tang = np.where(ln > 1e-6, tang / np.maximum(ln, 1e-6), np.array([[1.0, 0.0, 0.0]]))
+    tang4 = np.concatenate([tang, np.zeros((nv, 1))], 1).astype(np.float32)
+    uv = np.stack([np.arctan2(v[:, 0], v[:, 2]) / (2 * np.pi) + 0.5, np.arccos(np.clip(-v[:, 1], -1, 1)) / np.pi], 1).astype(np.float32)
+    return pos4, norm4, tang4, uv, f.reshape(-1)
+
+
+def interior_scene(width=1920, height=1080, objects=204, subdiv=4, seed=12345, tex_size=1024) -> S.SceneData:
+    """SURVEY.md 8d 'S2 interior-1M': a closed 10 x 4 x 10 room with a ceiling rect light, filled with `objects` distinct
+    tessellated icosphere meshes (subdiv 4 = 5120 triangles each; 204 x 5120 = 1 044 480 triangles, every mesh its own
+    BLAS, one instance each, so ~64 MB of nodes + 48 MB of triangles are really resident). 32 gltf materials (base colour
+    U[0.2,0.8]^3, metalness in {0,1} with p = 0.2, glossiness U[0,1], coat 1, IOR 1.5), one Lambert wall material, one
+    emissive material, one tex_size^2 RGBA32F albedo texture bound to every gltf material. Placement / materials are drawn
+    from MT19937(seed)."""
+    rng = np.random.RandomState(seed)        # MT19937
+    sc = S.SceneData()
+    sc.width, sc.height = width, height
+    sc.fov, sc.trace_depth = 60.0, 6
+    sc.cam_pos, sc.cam_look_at, sc.cam_up = (0.0, 1.7, 4.6), (0.0, 1.2, 0.0), (0.0, 1.0, 0.0)
+    tex = np.full((tex_size, tex_size, 4), 0.5, np.float32)
+    yy, xx = np.mgrid[0:tex_size, 0:tex_size]
+    chk = (((xx // (tex_size // 16)) + (yy // (tex_size // 16))) % 2).astype(np.float32)
+    tex[..., 0] = 0.35 + 0.5 * chk
+    tex[..., 1] = 0.8 - 0.4 * chk
+    tex[..., 2] = 0.6
+    tex[..., 3] = 1.0
+    tid = sc.add_texture(S.Texture(tex, S.TEX_RGBA32F, False, S.ADDR_WRAP, S.ADDR_WRAP, S.FILTER_LINEAR))
+    nmat = 32
+    for _ in range(nmat):
+        col = rng.uniform(0.2, 0.8, 3)
+        metal = 1.0 if rng.uniform() < 0.2 else 0.0
+        gloss = rng.uniform(0.0, 1.0)
+        sc.materials.append(S.material_gltf((*col, 1.0), metal, gloss, 1.0, 1.5, tid))
+    wall = len(sc.materials)
+    sc.materials.append(S.material_lambert((0.7, 0.7, 0.7)))
+    emis = len(sc.materials)
+    X, Y, Z = 5.0, 4.0, 5.0
+    parts = [(*_quad((-X, 0, Z), (2 * X, 0, 0), (0, 0, -2 * Z), 8, 8), wall),          # floor (normal +y)
+             (*_quad((-X, Y, -Z), (2 * X, 0, 0), (0, 0, 2 * Z), 8, 8), wall),          # ceiling (normal -y)
+             (*_quad((-X, 0, -Z), (2 * X, 0, 0), (0, Y, 0), 8, 8), wall),              # back wall (normal +z)
+             (*_quad((X, 0, Z), (-2 * X, 0, 0), (0, Y, 0), 8, 8), wall),               # front wall (normal -z)
+             (*_quad((-X, 0, Z), (0, 0, -2 * Z), (0, Y, 0), 8, 8), wall),              # left wall (normal +x)
+             (*_quad((X, 0, -Z), (0, 0, 2 * Z), (0, Y, 0), 8, 8), wall)]               # right wall (normal -x)
+    meshes = [_merge(parts)]
+    insts = [(0, np.eye(4), -1, -1)]
+    lm = S.translate(0.0, Y - 0.01, 0.0)
+    light_id = len(sc.lights)
+    sc.lights.append(S.light_rect(lm, 1.0, 1.0, (1, 1, 1), 25.0))
+    sc.materials.append(S.material_emissive((1, 1, 1), 25.0, light_id))
+    sc.lights[light_id]["matId"] = emis
+    lp, ln, lt, luv, lidx = _quad((-1, 0, -1), (2, 0, 0), (0, 0, 2))                    # normal -y
+    meshes.append((lp, ln, lt, luv, lidx, np.full(2, emis, np.uint32)))
+    insts.append((1, lm, -1, light_id))
+    sp = _sphere_mesh(subdiv)
+    ntri = sp[4].size // 3
+    gx = int(np.ceil(np.sqrt(objects)))
+    placed = 0
+    for j in range(gx):
+        for i in range(gx):
+            if placed >= objects:
+                break
+            # every object is its own mesh: the unit sphere with a per-object radial bump pattern
+            bump = 1.0 + 0.08 * np.sin(sp[0][:, 0:1] * rng.uniform(3, 9) + rng.uniform(0, 6.28)) * np.cos(sp[0][:, 1:2] * rng.uniform(3, 9))
+            pos = sp[0].copy()
+            pos[:, :3] *= bump.astype(np.float32)
+            meshes.append((pos, sp[1], sp[2], sp[3], sp[4], np.full(ntri, rng.randint(0, nmat), np.uint32)))
+            r = rng.uniform(0.18, 0.30)
+            cx = -X + 0.5 + (2 * X - 1.0) * (i + 0.5) / gx + rng.uniform(-0.1, 0.1)
+            cz = -Z + 0.5 + (2 * Z - 1.0) * (j + 0.5) / gx + rng.uniform(-0.1, 0.1)
+            cy = r + rng.uniform(0.0, 2.2)
+            m = S.translate(cx, cy, cz) @ S.rotate_y(rng.uniform(0, 360)) @ S.scale(r, r * rng.uniform(0.7, 1.3), r)
+            insts.append((len(meshes) - 1, m, -1, -1))
+            placed += 1
+    sc.add_meshes(meshes)
+    for g, m, rl, li in insts:
+        sc.add_instance(g, m, rl, li)
+    return sc

@@ -50,6 +50,8 @@ def lib():
                                            C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p]
         L.orc_rng_kat.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_tex_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_probe.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p]
+        L.orc_probe.restype = C.c_int
         L.orc_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
         _LIB = L
     return _LIB
@@ -159,3 +161,13 @@ def rng_kat(seed, n_draws):
 
 def adam_step(state, grad, momentum, gsquare, it):
     lib().orc_adam_step(state.ctypes.data, grad.ctypes.data, momentum.ctypes.data, gsquare.ctypes.data, state.size, it)
+
+
+def probe(name, *args):
+    a = np.zeros(8, np.float32)
+    a[:len(args)] = args
+    out = np.zeros(4, np.float32)
+    rc = lib().orc_probe(name.encode(), a.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        raise KeyError(name)
+    return out

@@ -104,6 +104,7 @@ void     orc_path_trace_dr_fd(orc_ctx*, uint32_t tidBegin, uint32_t tidCount, ui
 
 // probes used by unit tests
 void     orc_rng_kat(int seed, uint32_t nDraws, uint32_t* outState2, float* outFloat4PerDraw);
+int      orc_probe(const char* name, const float* args, float* out);
 void     orc_tex_sample(orc_ctx*, uint32_t texId, const float* uv2, uint32_t n, float* out4);
 // AdamOptimizer<float>::step (diff_render/adam.h:43-62)
 void     orc_adam_step(float* state, const float* grad, float* momentum, float* gsquare, uint64_t n, int iter);

@@ -16,6 +16,7 @@
 #include <omp.h>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 namespace orc {
 
@@ -889,6 +890,24 @@ void orc_tex_sample(orc_ctx* h, uint32_t texId, const float* uv2, uint32_t n, fl
     const f4 r = h->c.sc.tex_sample(texId, mk2(uv2[2 * i], uv2[2 * i + 1]));
     out4[4 * i + 0] = r.x; out4[4 * i + 1] = r.y; out4[4 * i + 2] = r.z; out4[4 * i + 3] = r.w;
   }
+}
+
+// scalar probes of the restated BSDF / sampling helpers, for closed-form unit tests
+int orc_probe(const char* name, const float* a, float* out)
+{
+  const std::string n(name);
+  if (n == "FrDielectricPBRT") { out[0] = FrDielectricPBRT(a[0], a[1], a[2]); return 0; }
+  if (n == "misWeightHeuristic") { out[0] = misWeightHeuristic(a[0], a[1]); return 0; }
+  if (n == "FrComplexConductor") { out[0] = FrComplexConductor(a[0], cmk(a[1], a[2])); return 0; }
+  if (n == "FrDielectricDetailedV2") { const f4 r = FrDielectricDetailedV2(a[0], a[1]); out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w; return 0; }
+  if (n == "ggxEvalPDF") { out[0] = ggxEvalPDF(mk3(a[0], a[1], a[2]), mk3(a[3], a[4], a[5]), mk3(0, 0, 1), a[6]); return 0; }
+  if (n == "ggxEvalBSDF") { out[0] = ggxEvalBSDF(mk3(a[0], a[1], a[2]), mk3(a[3], a[4], a[5]), mk3(0, 0, 1), a[6]); return 0; }
+  if (n == "ggxSample") { const f3 r = ggxSample(mk2(a[0], a[1]), mk3(a[2], a[3], a[4]), mk3(0, 0, 1), a[5]); out[0] = r.x; out[1] = r.y; out[2] = r.z; return 0; }
+  if (n == "trD") { out[0] = trD(mk3(a[0], a[1], a[2]), mk2(a[3], a[4])); return 0; }
+  if (n == "lambertSample") { const f3 r = lambertSample(mk2(a[0], a[1]), mk3(0, 0, 1), mk3(a[2], a[3], a[4])); out[0] = r.x; out[1] = r.y; out[2] = r.z; return 0; }
+  if (n == "MapSamplesToDisc") { const f2 r = MapSamplesToDisc(mk2(a[0], a[1])); out[0] = r.x; out[1] = r.y; return 0; }
+  if (n == "orennayarFunc") { out[0] = orennayarFunc(mk3(a[0], a[1], a[2]), mk3(a[3], a[4], a[5]), mk3(0, 0, 1), a[6]); return 0; }
+  return 1;
 }
 
 // AdamOptimizer<float>::step (diff_render/adam.h:43-62)

@@ -16,7 +16,7 @@ import numpy as np
 from .scene import HIT_DTYPE, Params, SceneData, SceneDesc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhydra_hip.so")
+LIB_PATH = os.environ.get("HYDRA_HIP_LIB", os.path.join(_HERE, "libhydra_hip.so"))   # override: A/B builds of the kernels
 
 # every symbol include/hydra_hip.h declares: name -> (restype, argtypes)
 _vp, _u32, _u64, _f, _i, _sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int, C.c_size_t

@@ -759,30 +759,33 @@ struct HitRec { float t; uint prim, inst; float u, v; };   // inst == 0xFFFFFFFF
 
 struct TravStats { uint nodes, tris, insts; };
 
+// Loop shape ("while-while"): every lane first walks inner nodes in a tight loop until it holds a leaf reference, and only
+// then do the lanes of the wave handle their leaves together. Mixing the three node kinds in one loop body makes a wave
+// pay for the inner-node code, the triangle code and the instance code on every step, whichever its lanes need.
+HPT_DEV V3 rcp3(V3 d) { return v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); }   // box test only
+
 template <bool ANY, bool STATS>
-HPT_DEV bool traceRay(const DevScene& S, V3 o, V3 d, float tnear, float tfar, HitRec& hit, uint* stk /* LDS: &stack[0][lane] */, const int stride, TravStats& st)
+HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, float tfar, HitRec& hit, uint* stk /* LDS: &stack[0][lane] */, const int stride, TravStats& st)
 {
   hit.t = tfar; hit.prim = 0xFFFFFFFFu; hit.inst = 0xFFFFFFFFu; hit.u = 0.0f; hit.v = 0.0f;
   bool found = false;
   uint cur = S.rootRef;
   if (cur == REF_NONE) return false;
 
-  const V3 wo = o, wd = d;                                   // world-space ray, restored when an instance is left
-  V3 id = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  const V3 wid = id;
+  V3 o = wo, d = wd;                                         // current-space ray; the world-space one is the caller's
+  V3 id = rcp3(d);
   uint curInst = 0xFFFFFFFFu;
   int sp = 0;
 
   while (true) {
-    bool pop = false;
-    if ((cur & REF_LEAF) == 0u) {
-      // ---- inner node: one 64-byte line, both child boxes ---------------------------------------------------------
+    // ---- (a) inner nodes: one 64-byte line holds both child boxes ---------------------------------------------------
+    while ((cur & REF_LEAF) == 0u) {
       const float4* np = (const float4*)(S.nodes + cur);
       const float4 q0 = np[0], q1 = np[1], q2 = np[2];
       const uint4  q3 = ((const uint4*)np)[3];
       if (STATS) st.nodes++;
       const float best = hit.t;
-      // slabs of child 0: lo = (q0.x q0.y q0.z), hi = (q0.w q1.x q1.y); child 1: lo = (q1.z q1.w q2.x), hi = (q2.y q2.z q2.w)
+      // child 0: lo = (q0.x q0.y q0.z), hi = (q0.w q1.x q1.y); child 1: lo = (q1.z q1.w q2.x), hi = (q2.y q2.z q2.w)
       float ax = (q0.x - o.x) * id.x, bx = (q0.w - o.x) * id.x;
       float ay = (q0.y - o.y) * id.y, by = (q1.x - o.y) * id.y;
       float az = (q0.z - o.z) * id.z, bz = (q1.y - o.z) * id.z;
@@ -793,9 +796,10 @@ HPT_DEV bool traceRay(const DevScene& S, V3 o, V3 d, float tnear, float tfar, Hi
       az = (q2.x - o.z) * id.z; bz = (q2.w - o.z) * id.z;
       const float t1n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tnear));
       const float t1f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
-      // boxes were padded by the builder; widen the interval by a few ulps so the test stays conservative
-      const bool h0 = (t0n * 0.9999995f <= t0f * 1.0000005f);
-      const bool h1 = (t1n * 0.9999995f <= t1f * 1.0000005f);
+      // boxes were padded by the builder; widen the interval a little more so that rounding (and the 1-ulp reciprocal)
+      // can only make the test more conservative than the exact triangle test
+      const bool h0 = (t0n * 0.999999f <= t0f * 1.000001f);
+      const bool h1 = (t1n * 0.999999f <= t1f * 1.000001f);
       if (h0 && h1) {
         const bool firstIs0 = t0n <= t1n;
         stk[sp * stride] = firstIs0 ? q3.y : q3.x;
@@ -803,63 +807,61 @@ HPT_DEV bool traceRay(const DevScene& S, V3 o, V3 d, float tnear, float tfar, Hi
         cur = firstIs0 ? q3.x : q3.y;
       } else if (h0) cur = q3.x;
       else if (h1) cur = q3.y;
-      else pop = true;
-    } else {
-      const uint cnt = (cur >> 28) & 7u;
-      if (cnt == 0u) {
-        // ---- instance leaf: enter object space ---------------------------------------------------------------------
-        const uint inst = cur & 0x0FFFFFFFu;
-        const float4* ip = (const float4*)(S.insts + inst);
-        const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
-        const uint4  r3 = ((const uint4*)ip)[3];
-        if (STATS) st.insts++;
-        o = v3(r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w,
-               r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w,
-               r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w);
-        d = v3(r0.x * wd.x + r0.y * wd.y + r0.z * wd.z,
-               r1.x * wd.x + r1.y * wd.y + r1.z * wd.z,
-               r2.x * wd.x + r2.y * wd.y + r2.z * wd.z);
-        id = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        curInst = inst;
-        stk[sp * stride] = REF_RESTORE;
-        sp++;
-        cur = r3.x;
-      } else if (cnt == 7u) {
-        // ---- marker: back to world space ----------------------------------------------------------------------------
-        o = wo; d = wd; id = wid; curInst = 0xFFFFFFFFu;
-        pop = true;
-      } else {
-        // ---- triangle leaf: Moeller-Trumbore on (v0, e1, e2), 3 x 16-byte loads per triangle -----------------------
-        const uint first = cur & 0x0FFFFFFFu;
-        for (uint k = 0; k < cnt; k++) {
-          const float4* tp = (const float4*)(S.tris + first + k);
-          const float4 a = tp[0], b = tp[1], c = tp[2];
-          if (STATS) st.tris++;
-          const V3 e1 = v3(b.x, b.y, b.z), e2 = v3(c.x, c.y, c.z);
-          const V3 pvec = cross(d, e2);
-          const float det = dot(e1, pvec);
-          const float inv = 1.0f / det;
-          const V3 tvec = o - v3(a.x, a.y, a.z);
-          const float uu = dot(tvec, pvec) * inv;
-          const V3 qvec = cross(tvec, e1);
-          const float vv = dot(d, qvec) * inv;
-          const float tt = dot(e2, qvec) * inv;
-          const uint prim = __float_as_uint(a.w);
-          bool ok = (det != 0.0f) && (uu >= 0.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f) && (tt >= tnear) && (tt <= hit.t);
-          if (ok && found && tt == hit.t)            // equal distance: lower (instId, primId) wins
-            ok = (curInst != hit.inst) ? (curInst < hit.inst) : (prim < hit.prim);
-          if (ok) {
-            hit.t = tt; hit.prim = prim; hit.inst = curInst; hit.u = uu; hit.v = vv; found = true;
-            if (ANY) return true;
-          }
-        }
-        pop = true;
-      }
+      else if (sp > 0) { sp--; cur = stk[sp * stride]; }
+      else cur = REF_NONE;
     }
-    if (pop) {
-      if (sp == 0) break;
-      sp--;
-      cur = stk[sp * stride];
+    if (cur == REF_NONE) break;
+
+    // ---- (b) leaves --------------------------------------------------------------------------------------------------
+    const uint cnt = (cur >> 28) & 7u;
+    if (cnt >= 1u && cnt <= 4u) {
+      // triangles: Moeller-Trumbore on (v0, e1, e2), 3 x 16-byte loads each; exact (IEEE) arithmetic, see ray_tri in the oracle
+      const uint first = cur & 0x0FFFFFFFu;
+      for (uint k = 0; k < cnt; k++) {
+        const float4* tp = (const float4*)(S.tris + first + k);
+        const float4 a = tp[0], b = tp[1], c = tp[2];
+        if (STATS) st.tris++;
+        const V3 e1 = v3(b.x, b.y, b.z), e2 = v3(c.x, c.y, c.z);
+        const V3 pvec = cross(d, e2);
+        const float det = dot(e1, pvec);
+        const float inv = 1.0f / det;
+        const V3 tvec = o - v3(a.x, a.y, a.z);
+        const float uu = dot(tvec, pvec) * inv;
+        const V3 qvec = cross(tvec, e1);
+        const float vv = dot(d, qvec) * inv;
+        const float tt = dot(e2, qvec) * inv;
+        const uint prim = __float_as_uint(a.w);
+        bool ok = (det != 0.0f) && (uu >= 0.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f) && (tt >= tnear) && (tt <= hit.t);
+        if (ok && found && tt == hit.t)            // equal distance: lower (instId, primId) wins
+          ok = (curInst != hit.inst) ? (curInst < hit.inst) : (prim < hit.prim);
+        if (ok) {
+          hit.t = tt; hit.prim = prim; hit.inst = curInst; hit.u = uu; hit.v = vv; found = true;
+          if (ANY) return true;
+        }
+      }
+      if (sp > 0) { sp--; cur = stk[sp * stride]; } else break;
+    } else if (cnt == 0u) {
+      // instance leaf: enter object space (EmbreeRT.cpp:242-292 semantics: t is shared between the two spaces)
+      const uint inst = cur & 0x0FFFFFFFu;
+      const float4* ip = (const float4*)(S.insts + inst);
+      const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
+      const uint4  r3 = ((const uint4*)ip)[3];
+      if (STATS) st.insts++;
+      o = v3(r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w,
+             r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w,
+             r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w);
+      d = v3(r0.x * wd.x + r0.y * wd.y + r0.z * wd.z,
+             r1.x * wd.x + r1.y * wd.y + r1.z * wd.z,
+             r2.x * wd.x + r2.y * wd.y + r2.z * wd.z);
+      id = rcp3(d);
+      curInst = inst;
+      stk[sp * stride] = REF_RESTORE;
+      sp++;
+      cur = r3.x;
+    } else {
+      // marker: back to world space
+      o = wo; d = wd; id = rcp3(d); curInst = 0xFFFFFFFFu;
+      if (sp > 0) { sp--; cur = stk[sp * stride]; } else break;
     }
   }
   return found;

@@ -12,6 +12,10 @@
 #include "hpt_kernels.hip"
 #include "bvh_build.h"
 
+#ifndef HPT_STACK
+#define HPT_STACK 32      // LDS traversal-stack entries per lane of the default kernels (deeper scenes use the 64-entry build)
+#endif
+
 using namespace hpt;
 
 namespace {
@@ -312,7 +316,7 @@ static int ray_query(hpt_ctx* c, const float* posNear, const float* dirFar, uint
   HIPCHK(c, dp.upload((const float4*)posNear, n));
   HIPCHK(c, dd.upload((const float4*)dirFar, n));
   HIPCHK(c, dout.alloc(outWords));
-  if (c->stackNeeded <= 32) launchRayQuery<32>(c, dp.p, dd.p, n, dout.p, any); else launchRayQuery<64>(c, dp.p, dd.p, n, dout.p, any);
+  if (c->stackNeeded <= HPT_STACK) launchRayQuery<HPT_STACK>(c, dp.p, dd.p, n, dout.p, any); else launchRayQuery<64>(c, dp.p, dd.p, n, dout.p, any);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpy(out, dout.p, outWords * 4, hipMemcpyDeviceToHost));
   dp.release(); dd.release(); dout.release();
@@ -536,12 +540,12 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
     HIPCHK(c, c->dRecord.alloc((size_t)job.recordLanes * REC_FIELDS * (c->S.traceDepth + 1)));
     job.record = c->dRecord.p;
   }
-  const bool deep = c->stackNeeded > 32;
+  const bool deep = c->stackNeeded > HPT_STACK;
   HIPCHK(c, hipEventRecord(c->ev0, st));
-  if (dr)          { if (deep) launchPT<64, false, true, false>(c->S, job, blocks, st);  else launchPT<32, false, true, false>(c->S, job, blocks, st); }
-  else if (naive)  { if (deep) launchPT<64, false, false, true>(c->S, job, blocks, st);  else launchPT<32, false, false, true>(c->S, job, blocks, st); }
-  else if (stats)  { if (deep) launchPT<64, true, false, false>(c->S, job, blocks, st);  else launchPT<32, true, false, false>(c->S, job, blocks, st); }
-  else             { if (deep) launchPT<64, false, false, false>(c->S, job, blocks, st); else launchPT<32, false, false, false>(c->S, job, blocks, st); }
+  if (dr)          { if (deep) launchPT<64, false, true, false>(c->S, job, blocks, st);  else launchPT<HPT_STACK, false, true, false>(c->S, job, blocks, st); }
+  else if (naive)  { if (deep) launchPT<64, false, false, true>(c->S, job, blocks, st);  else launchPT<HPT_STACK, false, false, true>(c->S, job, blocks, st); }
+  else if (stats)  { if (deep) launchPT<64, true, false, false>(c->S, job, blocks, st);  else launchPT<HPT_STACK, true, false, false>(c->S, job, blocks, st); }
+  else             { if (deep) launchPT<64, false, false, false>(c->S, job, blocks, st); else launchPT<HPT_STACK, false, false, false>(c->S, job, blocks, st); }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev1, st));
   return HPT_OK;

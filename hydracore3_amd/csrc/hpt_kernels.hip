@@ -89,8 +89,11 @@ HPT_DEV void cameraRay(const DevScene& S, uint x, uint y, V4 pixelOffsets, V3& r
   rayDir = normalize(p2 - p1);
 }
 
+#ifndef HPT_MIN_WAVES
+#define HPT_MIN_WAVES 4   // waves per SIMD the register allocator must fit (measured: 2 -> 725, 3 -> 913..1262, 4 -> 1005..1365 Mpaths/s on the Cornell box)
+#endif
 template <int STACK, bool STATS, bool DR, bool NAIVE>
-__global__ void __launch_bounds__(256) pathTraceKernel(const DevScene S, const Job job)
+__global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevScene S, const Job job)
 {
   __shared__ uint stackMem[STACK * 256];
   uint* stk = &stackMem[threadIdx.x];

@@ -764,8 +764,22 @@ struct TravStats { uint nodes, tris, insts; };
 // pay for the inner-node code, the triangle code and the instance code on every step, whichever its lanes need.
 HPT_DEV V3 rcp3(V3 d) { return v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); }   // box test only
 
-template <bool ANY, bool STATS>
-HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, float tfar, HitRec& hit, uint* stk /* LDS: &stack[0][lane] */, const int stride, TravStats& st)
+// Traversal stack: the first LDS_STACK entries of a lane live in LDS ([depth][lane]: a push or pop is one conflict-free
+// ds_write/ds_read_b32 per wave); deeper entries - rare, a push only happens when both children are hit - go to a per-lane
+// slice of an HBM scratch buffer ([depth][global lane], coalesced). LDS use is therefore independent of the tree depth.
+static const int LDS_STACK = 16;
+struct TravStack { uint* lds; uint* ovf; uint ovfStride; };
+HPT_DEV void stkPush(const TravStack& k, int sp, uint v) { if (sp < LDS_STACK) k.lds[sp * 256] = v; else k.ovf[(size_t)(sp - LDS_STACK) * k.ovfStride] = v; }
+HPT_DEV uint stkPop(const TravStack& k, int sp)
+{
+  // the LDS read is unconditional (clamped slot) and the HBM read conditional: never a select between two address spaces
+  uint v = k.lds[(sp < LDS_STACK ? sp : LDS_STACK - 1) * 256];
+  if (sp >= LDS_STACK) v = k.ovf[(size_t)(sp - LDS_STACK) * k.ovfStride];
+  return v;
+}
+
+template <bool ANY, bool STATS, bool DEEP>
+HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, float tfar, HitRec& hit, const TravStack& stk, TravStats& st)
 {
   hit.t = tfar; hit.prim = 0xFFFFFFFFu; hit.inst = 0xFFFFFFFFu; hit.u = 0.0f; hit.v = 0.0f;
   bool found = false;
@@ -776,6 +790,10 @@ HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, 
   V3 id = rcp3(d);
   uint curInst = 0xFFFFFFFFu;
   int sp = 0;
+
+  // DEEP = false: the whole stack fits the LDS part (host checked the tree depth), no overflow test on push / pop
+#define HPT_PUSH(v) do { if (DEEP) stkPush(stk, sp, (v)); else stk.lds[sp * 256] = (v); sp++; } while (0)
+#define HPT_POP()   do { sp--; cur = DEEP ? stkPop(stk, sp) : stk.lds[sp * 256]; } while (0)
 
   while (true) {
     // ---- (a) inner nodes: one 64-byte line holds both child boxes ---------------------------------------------------
@@ -802,12 +820,11 @@ HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, 
       const bool h1 = (t1n * 0.999999f <= t1f * 1.000001f);
       if (h0 && h1) {
         const bool firstIs0 = t0n <= t1n;
-        stk[sp * stride] = firstIs0 ? q3.y : q3.x;
-        sp++;
+        HPT_PUSH(firstIs0 ? q3.y : q3.x);
         cur = firstIs0 ? q3.x : q3.y;
       } else if (h0) cur = q3.x;
       else if (h1) cur = q3.y;
-      else if (sp > 0) { sp--; cur = stk[sp * stride]; }
+      else if (sp > 0) HPT_POP();
       else cur = REF_NONE;
     }
     if (cur == REF_NONE) break;
@@ -839,7 +856,7 @@ HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, 
           if (ANY) return true;
         }
       }
-      if (sp > 0) { sp--; cur = stk[sp * stride]; } else break;
+      if (sp > 0) HPT_POP(); else break;
     } else if (cnt == 0u) {
       // instance leaf: enter object space (EmbreeRT.cpp:242-292 semantics: t is shared between the two spaces)
       const uint inst = cur & 0x0FFFFFFFu;
@@ -855,15 +872,16 @@ HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, 
              r2.x * wd.x + r2.y * wd.y + r2.z * wd.z);
       id = rcp3(d);
       curInst = inst;
-      stk[sp * stride] = REF_RESTORE;
-      sp++;
+      HPT_PUSH(REF_RESTORE);
       cur = r3.x;
     } else {
       // marker: back to world space
       o = wo; d = wd; id = rcp3(d); curInst = 0xFFFFFFFFu;
-      if (sp > 0) { sp--; cur = stk[sp * stride]; } else break;
+      if (sp > 0) HPT_POP(); else break;
     }
   }
+#undef HPT_PUSH
+#undef HPT_POP
   return found;
 }
 

@@ -12,9 +12,7 @@
 #include "hpt_kernels.hip"
 #include "bvh_build.h"
 
-#ifndef HPT_STACK
-#define HPT_STACK 32      // LDS traversal-stack entries per lane of the default kernels (deeper scenes use the 64-entry build)
-#endif
+static const uint MAX_STACK = 64;     // traversal stack entries per lane: LDS_STACK in LDS + the rest in an HBM overflow buffer
 
 using namespace hpt;
 
@@ -67,7 +65,7 @@ struct hpt_ctx
   DevBuf<MaterialRec> dMaterials; DevBuf<LightRec> dLights; DevBuf<TexRec> dTextures;
   std::vector<void*> texData; std::vector<TexRec> hTextures;
   DevBuf<Rng> dGens;
-  DevBuf<uint> dQueue; DevBuf<Counters> dCounters;
+  DevBuf<uint> dQueue, dStackOvf; DevBuf<Counters> dCounters;
   DevBuf<float> dFrame, dRecord, dRef, dData, dGrad, dLoss;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -118,7 +116,7 @@ extern "C" void hpt_destroy(hpt_ctx* c)
   c->dNodes.release(); c->dTris.release(); c->dInsts.release(); c->dTriIndices.release(); c->dMatIdByPrim.release();
   c->dMatVertOffset.release(); c->dPackedXY.release(); c->dVData.release(); c->dNormMat.release(); c->dRemapInst.release();
   c->dRemapLists.release(); c->dMaterials.release(); c->dLights.release(); c->dTextures.release(); c->dGens.release();
-  c->dQueue.release(); c->dCounters.release(); c->dFrame.release(); c->dRecord.release(); c->dRef.release(); c->dData.release();
+  c->dQueue.release(); c->dStackOvf.release(); c->dCounters.release(); c->dFrame.release(); c->dRecord.release(); c->dRef.release(); c->dData.release();
   c->dGrad.release(); c->dLoss.release();
   for (void* p : c->texData) if (p) (void)hipFree(p);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -294,15 +292,16 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   c->S.nodes = c->dNodes.p; c->S.tris = c->dTris.p; c->S.insts = c->dInsts.p;
   c->S.rootRef = rootRef; c->S.numInsts = (uint)ni;
   c->stackNeeded = tlas.depth + 1u + maxBlasDepth + 1u;
-  if (c->stackNeeded > 64u) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: BVH deeper than the 64-entry traversal stack");
+  if (c->stackNeeded > MAX_STACK) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: BVH deeper than the 64-entry traversal stack");
   c->accelCommitted = true;
   return HPT_OK;
 }
 
-template <int STACK>
-static void launchRayQuery(hpt_ctx* c, const float4* p, const float4* d, uint n, void* out, int any)
+// HBM part of the traversal stacks for a grid of `lanes` lanes (only touched by lanes whose stack outgrows LDS_STACK)
+static hipError_t ensureStackOverflow(hpt_ctx* c, size_t lanes)
 {
-  rayQueryKernel<STACK><<<dim3((n + 255) / 256), dim3(256), 0, 0>>>(c->S, p, d, n, out, any);
+  const size_t extra = c->stackNeeded > (uint)LDS_STACK ? c->stackNeeded - LDS_STACK : 1;
+  return c->dStackOvf.alloc(extra * lanes);
 }
 
 static int ray_query(hpt_ctx* c, const float* posNear, const float* dirFar, uint32_t n, void* out, int any)
@@ -316,7 +315,9 @@ static int ray_query(hpt_ctx* c, const float* posNear, const float* dirFar, uint
   HIPCHK(c, dp.upload((const float4*)posNear, n));
   HIPCHK(c, dd.upload((const float4*)dirFar, n));
   HIPCHK(c, dout.alloc(outWords));
-  if (c->stackNeeded <= HPT_STACK) launchRayQuery<HPT_STACK>(c, dp.p, dd.p, n, dout.p, any); else launchRayQuery<64>(c, dp.p, dd.p, n, dout.p, any);
+  const uint blocks = (n + 255) / 256;
+  HIPCHK(c, ensureStackOverflow(c, (size_t)blocks * 256));
+  rayQueryKernel<<<dim3(blocks), dim3(256), 0, 0>>>(c->S, dp.p, dd.p, n, dout.p, any, c->dStackOvf.p);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpy(out, dout.p, outWords * 4, hipMemcpyDeviceToHost));
   dp.release(); dd.release(); dout.release();
@@ -513,10 +514,12 @@ static int gridBlocks(hpt_ctx* c, bool dr)
   return c->numCUs * bpc;
 }
 
-template <int STACK, bool STATS, bool DR, bool NAIVE>
-static void launchPT(const DevScene& S, const Job& job, int blocks, hipStream_t st)
+// DEEP: the scene's BVH can need more than LDS_STACK stack entries, so pushes / pops check for the HBM overflow part
+template <bool STATS, bool DR, bool NAIVE>
+static void launchPT(const DevScene& S, const Job& job, int blocks, hipStream_t st, bool deep)
 {
-  pathTraceKernel<STACK, STATS, DR, NAIVE><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
+  if (deep) pathTraceKernel<STATS, DR, NAIVE, true><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
+  else      pathTraceKernel<STATS, DR, NAIVE, false><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
 }
 
 static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStream_t st)
@@ -540,12 +543,14 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
     HIPCHK(c, c->dRecord.alloc((size_t)job.recordLanes * REC_FIELDS * (c->S.traceDepth + 1)));
     job.record = c->dRecord.p;
   }
-  const bool deep = c->stackNeeded > HPT_STACK;
+  HIPCHK(c, ensureStackOverflow(c, (size_t)blocks * 256));
+  job.stackOverflow = c->dStackOvf.p; job.gridLanes = (uint)blocks * 256u;
   HIPCHK(c, hipEventRecord(c->ev0, st));
-  if (dr)          { if (deep) launchPT<64, false, true, false>(c->S, job, blocks, st);  else launchPT<HPT_STACK, false, true, false>(c->S, job, blocks, st); }
-  else if (naive)  { if (deep) launchPT<64, false, false, true>(c->S, job, blocks, st);  else launchPT<HPT_STACK, false, false, true>(c->S, job, blocks, st); }
-  else if (stats)  { if (deep) launchPT<64, true, false, false>(c->S, job, blocks, st);  else launchPT<HPT_STACK, true, false, false>(c->S, job, blocks, st); }
-  else             { if (deep) launchPT<64, false, false, false>(c->S, job, blocks, st); else launchPT<HPT_STACK, false, false, false>(c->S, job, blocks, st); }
+  const bool deep = c->stackNeeded > (uint)LDS_STACK;
+  if (dr)          launchPT<false, true, false>(c->S, job, blocks, st, deep);
+  else if (naive)  launchPT<false, false, true>(c->S, job, blocks, st, deep);
+  else if (stats)  launchPT<true, false, false>(c->S, job, blocks, st, deep);
+  else             launchPT<false, false, false>(c->S, job, blocks, st, deep);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev1, st));
   return HPT_OK;

@@ -36,6 +36,8 @@ struct Job
   float* lossAccum;               // sum over samples of loss / passNum
   float* record;                  // per-lane, per-bounce adjoint records: [bounce][field][lane]
   uint   recordLanes;             // total lanes of the grid (stride of the record buffer)
+  uint*  stackOverflow;           // HBM part of the traversal stacks: [depth - LDS_STACK][global lane]
+  uint   gridLanes;
 };
 
 static const int REC_FIELDS = 24;   // A(3) S(3) T*dA(3) T*dS(3) texId tapOffsets(4) tapWeights(4) pad(3)
@@ -92,18 +94,25 @@ HPT_DEV void cameraRay(const DevScene& S, uint x, uint y, V4 pixelOffsets, V3& r
 #ifndef HPT_MIN_WAVES
 #define HPT_MIN_WAVES 4   // waves per SIMD the register allocator must fit (measured: 2 -> 725, 3 -> 913..1262, 4 -> 1005..1365 Mpaths/s on the Cornell box)
 #endif
-template <int STACK, bool STATS, bool DR, bool NAIVE>
+template <bool STATS, bool DR, bool NAIVE, bool DEEP>
 __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevScene S, const Job job)
 {
-  __shared__ uint stackMem[STACK * 256];
-  uint* stk = &stackMem[threadIdx.x];
-  const uint glane = blockIdx.x * 256u + threadIdx.x;                    // slot in the record buffer (DR)
+  __shared__ uint stackMem[LDS_STACK * 256];
+  const uint glane = blockIdx.x * 256u + threadIdx.x;                    // slot in the per-lane HBM buffers
+  TravStack stk; stk.lds = &stackMem[threadIdx.x]; stk.ovf = job.stackOverflow + glane; stk.ovfStride = job.gridLanes;
 
-  // ---- per-lane state (VGPRs) ---------------------------------------------------------------------------------------
+  // ---- per-lane state -----------------------------------------------------------------------------------------------
+  // Cold per-PIXEL state (touched once per path, not per bounce) is parked in LDS so that it does not occupy VGPRs
+  // across the two traversals and the shading code: running framebuffer value, packed (x,y), tid, passes left.
+  __shared__ float coldPix[3 * 256];
+  __shared__ uint  coldU[3 * 256];
+#define PIX(k)      coldPix[(k) * 256 + threadIdx.x]
+#define PIX_XY      coldU[0 * 256 + threadIdx.x]
+#define PIX_TID     coldU[1 * 256 + threadIdx.x]
+#define PIX_PASSES  coldU[2 * 256 + threadIdx.x]
   bool havePixel = false, alive = false, drained = false;
-  uint tid = 0, px = 0, py = 0, passesLeft = 0, bounce = 0, flags = 0;
+  uint bounce = 0, flags = 0;
   Rng  gen; gen.sx = gen.sy = 0;
-  V3   pix = v3(0, 0, 0);                       // running framebuffer value of the pixel
   V3   rpos = v3(0, 0, 0), rdir = v3(0, 0, 1);
   V3   accum = v3(0, 0, 0), thr = v3(1, 1, 1);
   float misPdf = 1.0f, misIor = 1.0f;
@@ -114,11 +123,12 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
 
   while (true) {
     // ---- (1) a finished pixel goes back to HBM: one read-modify-write per pixel and call ------------------------------
-    if (!alive && havePixel && passesLeft == 0) {
-      const uint pixel = py * (uint)S.winWidth + px;
-      if (job.channels == 1) job.outColor[pixel] = pix.x;
-      else { float* o = job.outColor + (size_t)pixel * job.channels; o[0] = pix.x; o[1] = pix.y; o[2] = pix.z; }
-      job.gens[tid] = gen;                                               // kernel_ContributeToImage: m_randomGens[tid] = *gen (:605)
+    if (!alive && havePixel && PIX_PASSES == 0u) {
+      const uint XY = PIX_XY;
+      const uint pixel = ((XY & 0xFFFF0000u) >> 16) * (uint)S.winWidth + (XY & 0x0000FFFFu);
+      if (job.channels == 1) job.outColor[pixel] = PIX(0);
+      else { float* o = job.outColor + (size_t)pixel * job.channels; o[0] = PIX(0); o[1] = PIX(1); o[2] = PIX(2); }
+      job.gens[PIX_TID] = gen;                                           // kernel_ContributeToImage: m_randomGens[tid] = *gen (:605)
       havePixel = false;
     }
     // ---- (2) work queue: ballot the idle lanes, one atomic per wave, prefix-sum the ranks --------------------------------
@@ -132,26 +142,26 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
         if (need) {
           const uint k = base + mbcnt64(mask);
           if (k < job.tidCount) {
-            tid = job.tidBegin + k;
+            const uint tid = job.tidBegin + k;
             const uint XY = job.packedXY[tid];
-            px = XY & 0x0000FFFFu; py = (XY & 0xFFFF0000u) >> 16;
             gen = job.gens[tid];
-            const uint pixel = py * (uint)S.winWidth + px;
-            if (job.channels == 1) pix = v3(job.outColor[pixel], 0, 0);
-            else { const float* o = job.outColor + (size_t)pixel * job.channels; pix = v3(o[0], o[1], o[2]); }
-            passesLeft = job.passNum;
+            const uint pixel = ((XY & 0xFFFF0000u) >> 16) * (uint)S.winWidth + (XY & 0x0000FFFFu);
+            if (job.channels == 1) { PIX(0) = job.outColor[pixel]; PIX(1) = 0.0f; PIX(2) = 0.0f; }
+            else { const float* o = job.outColor + (size_t)pixel * job.channels; PIX(0) = o[0]; PIX(1) = o[1]; PIX(2) = o[2]; }
+            PIX_XY = XY; PIX_TID = tid; PIX_PASSES = job.passNum;
             havePixel = true;
           } else drained = true;
         }
       }
     }
     // ---- (3) regenerate: next pass of the pixel (kernel_InitEyeRay2) -----------------------------------------------------
-    if (!alive && havePixel && passesLeft > 0) {
-      passesLeft--;
+    if (!alive && havePixel) {                                              // (a pixel with no pass left was flushed in (1))
+      PIX_PASSES = PIX_PASSES - 1u;
       accum = v3(0, 0, 0); thr = v3(1, 1, 1); flags = 0; bounce = 0;
       misPdf = 1.0f; misIor = 1.0f;
       const V4 lens = rng_float4(gen);                                     // GetRandomNumbersLens
-      cameraRay(S, px, py, lens, rpos, rdir);
+      const uint XY = PIX_XY;
+      cameraRay(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
       alive = true;
       if (STATS) nPaths++;
     }
@@ -160,7 +170,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
     // ---- (4) closest hit: kernel_RayTrace2 -> RayQuery_NearestHit ----------------------------------------------------------
     HitRec hit; hit.inst = 0xFFFFFFFFu; hit.prim = 0; hit.t = 0; hit.u = hit.v = 0;
     if (alive) {
-      traceRay<false, STATS>(S, rpos, rdir, 0.0f, HPT_FLT_MAX, hit, stk, 256, st);
+      traceRay<false, STATS, DEEP>(S, rpos, rdir, 0.0f, HPT_FLT_MAX, hit, stk, st);
       if (STATS) nRays++;
     }
 
@@ -330,7 +340,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
     // ---- (6) shadow rays: RayQuery_AnyHit ---------------------------------------------------------------------------------------
     if (wantShadow) {
       HitRec sh;
-      const bool occluded = traceRay<true, STATS>(S, shPos, shDir, 0.0f, shFar, sh, stk, 256, st);
+      const bool occluded = traceRay<true, STATS, DEEP>(S, shPos, shDir, 0.0f, shFar, sh, stk, st);
       if (STATS) { nRays++; nShadow++; }
       if (!occluded) accum = accum + contrib; else if (DR) { recS = v3(0, 0, 0); recdS = v3(0, 0, 0); }
     } else if (DR) { recS = v3(0, 0, 0); recdS = v3(0, 0, 0); }
@@ -363,11 +373,12 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
           // With T_0 = 1, T_{b+1} = T_b A_b and C = sum_b T_b S_b + T_n tail:
           //   dC/dtex_b = T_b dS_b + T_b dA_b R_{b+1},   R_b = S_b + A_b R_{b+1},   R_n = tail
           const uint pitch = (uint)S.winWidth;
-          const uint yRef = (uint)S.winHeight - py - 1u;
-          const float* rp = job.refImg + ((size_t)yRef * pitch + px) * job.channels;
+          const uint XY = PIX_XY;
+          const uint yRef = (uint)S.winHeight - ((XY & 0xFFFF0000u) >> 16) - 1u;
+          const float* rp = job.refImg + ((size_t)yRef * pitch + (XY & 0x0000FFFFu)) * job.channels;
           const V3 diff = v3(accum.x - rp[0], accum.y - rp[1], accum.z - rp[2]);
           lossLocal += (diff.x * diff.x + diff.y * diff.y + diff.z * diff.z) / float(job.passNum);
-          pix = pix + accum;                                                   // out_color += colorRend (:1124-1126)
+          PIX(0) += accum.x; PIX(1) += accum.y; PIX(2) += accum.z;             // out_color += colorRend (:1124-1126)
           const size_t s = job.recordLanes;
           V3 Rn = tailR + env;
           for (int b = (int)bounce - 1; b >= 0; b--) {
@@ -395,14 +406,18 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
         } else {
           // kernel_ContributeToImage (integrator_pt.cpp:598-657)
           const V3 c = accum * ld3(S.camRespoceRGB);
-          if (job.channels == 1) pix.x += accum.x * S.exposureMult;
-          else pix = pix + S.exposureMult * c;
+          if (job.channels == 1) PIX(0) += accum.x * S.exposureMult;
+          else { PIX(0) += S.exposureMult * c.x; PIX(1) += S.exposureMult * c.y; PIX(2) += S.exposureMult * c.z; }
         }
         alive = false;
       }
     }
   }
 
+#undef PIX
+#undef PIX_XY
+#undef PIX_TID
+#undef PIX_PASSES
   if (STATS) {
     // wave-reduce, one atomic per counter per wave
     unsigned long long v[8] = { nRays, st.nodes, st.tris, nHits, nShadow, nPaths, st.insts, 0ull };
@@ -442,20 +457,19 @@ __global__ void initRandomGensKernel(Rng* gens, uint n)
 }
 
 // batched RayQuery_NearestHit / RayQuery_AnyHit for the ISceneObject entry points
-template <int STACK>
-__global__ void __launch_bounds__(256) rayQueryKernel(const DevScene S, const float4* posNear, const float4* dirFar, uint n, void* out, int anyHit)
+__global__ void __launch_bounds__(256) rayQueryKernel(const DevScene S, const float4* posNear, const float4* dirFar, uint n, void* out, int anyHit, uint* stackOverflow)
 {
-  __shared__ uint stackMem[STACK * 256];
-  uint* stk = &stackMem[threadIdx.x];
+  __shared__ uint stackMem[LDS_STACK * 256];
   const uint i = blockIdx.x * 256u + threadIdx.x;
+  TravStack stk; stk.lds = &stackMem[threadIdx.x]; stk.ovf = stackOverflow + i; stk.ovfStride = gridDim.x * 256u;
   if (i >= n) return;
   const float4 p = posNear[i], d = dirFar[i];
   HitRec h; TravStats st; st.nodes = st.tris = st.insts = 0;
   if (anyHit) {
-    const bool occ = traceRay<true, false>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, 256, st);
+    const bool occ = traceRay<true, false, true>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, st);
     ((uint*)out)[i] = occ ? 1u : 0u;
   } else {
-    const bool found = traceRay<false, false>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, 256, st);
+    const bool found = traceRay<false, false, true>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, st);
     // CRT_Hit (CrossRT.h:23-30) as the Embree backend fills it (EmbreeRT.cpp:343-360)
     float4* o = (float4*)out + 2 * (size_t)i;
     if (found) {

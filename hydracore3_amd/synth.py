@@ -173,3 +173,63 @@ def interior_scene(width=1920, height=1080, objects=204, subdiv=4, seed=12345, t
     for g, m, rl, li in insts:
         sc.add_instance(g, m, rl, li)
     return sc
+
+
+def material_zoo(width=96, height=64) -> S.SceneData:
+    """Every material / light type of the hot path in one frame: gltf (Lambert, rough metal, coated plastic, mirror),
+    Lambert / Oren-Nayar `diffuse`, smooth and rough conductor, smooth dielectric sphere; lit by a rect light with a
+    mesh, a sphere light, a spot light, a directional light and a disc light, under a dim constant environment."""
+    sc = S.SceneData()
+    sc.width, sc.height = width, height
+    sc.cam_pos, sc.cam_look_at, sc.cam_up = (0.0, 2.2, 7.5), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0)
+    sc.fov, sc.trace_depth = 45.0, 6
+    sc.env_color = (0.03, 0.04, 0.06, 0.0)
+    chk = np.zeros((8, 8), np.uint32)
+    for y in range(8):
+        for x in range(8):
+            chk[y, x] = 0xFFE0E0E0 if (x + y) % 2 else 0xFF3050B0
+    tex = sc.add_texture(S.Texture(chk, S.TEX_RGBA8, True, S.ADDR_WRAP, S.ADDR_CLAMP, S.FILTER_LINEAR))
+    rough = np.zeros((4, 4, 4), np.float32)
+    rough[..., 0] = np.linspace(0.3, 1.0, 16).reshape(4, 4)
+    rough[..., 1] = 0.5
+    rtex = sc.add_texture(S.Texture(rough, S.TEX_RGBA32F, False))
+    M = sc.materials
+    M.append(S.material_lambert((0.7, 0.7, 0.7), tex))                                   # 0 floor (textured)
+    M.append(S.material_gltf((0.9, 0.6, 0.2, 1.0), 1.0, 0.6, 0.0, 1.5))                  # 1 rough metal
+    M.append(S.material_gltf((0.2, 0.7, 0.3, 1.0), 0.0, 0.8, 1.0, 1.5))                  # 2 coated plastic
+    M.append(S.material_gltf((0.9, 0.9, 0.9, 1.0), 1.0, 1.0, 0.0, 1.5))                  # 3 mirror (glossiness 1)
+    M.append(S.material_diffuse((0.8, 0.3, 0.3), 0.0))                                    # 4 diffuse Lambert
+    M.append(S.material_diffuse((0.3, 0.3, 0.8), 0.7))                                    # 5 diffuse Oren-Nayar
+    M.append(S.material_conductor(0.2, 3.9, 0.0, 0.0))                                    # 6 smooth conductor
+    M.append(S.material_conductor(1.1, 2.3, 0.25, 0.1, (1.0, 0.85, 0.6, 1.0)))            # 7 rough anisotropic conductor
+    M.append(S.material_dielectric(1.5, 1.0))                                             # 8 glass
+    g = S.material_gltf((0.8, 0.8, 0.8, 1.0), 0.5, 1.0, 1.0, 1.5)                         # 9 gltf with glossiness / metalness textures
+    g["cflags"] |= 256
+    g["texid"][2] = rtex
+    g["texid"][3] = rtex
+    M.append(g)
+    emis = len(M)
+    parts = [(*_quad((-8, 0, 6), (16, 0, 0), (0, 0, -14), 2, 2, 4.0), 0),
+             (*_quad((-8, 0, -8), (16, 0, 0), (0, 6, 0)), 4)]
+    sc.add_instance(sc.add_mesh(*_merge(parts)), np.eye(4))
+    sp = _sphere_mesh(2)
+    ntri = sp[4].size // 3
+    for i, mat in enumerate((1, 2, 3, 5, 6, 7, 8, 9)):
+        gid = sc.add_mesh(sp[0], sp[1], sp[2], sp[3], sp[4], np.full(ntri, mat, np.uint32))
+        x = -4.2 + 1.2 * i
+        sc.add_instance(gid, S.translate(x, 0.55 + 0.25 * (i % 2), -0.5 * (i % 3)) @ S.rotate_y(30.0 * i) @ S.scale(0.5, 0.5 + 0.1 * (i % 2), 0.5))
+    # lights
+    lm = S.translate(-2.0, 4.0, 0.0) @ S.rotate_x(15.0)
+    L = sc.lights
+    L.append(S.light_rect(lm, 0.8, 0.5, (1.0, 0.95, 0.9), 12.0))
+    M.append(S.material_emissive((1.0, 0.95, 0.9), 12.0, 0))
+    L[0]["matId"] = emis
+    lp, ln, lt, luv, lidx = _quad((-0.5, 0, -0.8), (1.0, 0, 0), (0, 0, 1.6))
+    sc.add_instance(sc.add_mesh(lp, ln, lt, luv, lidx, [emis]), lm, -1, 0)
+    L.append(S.light_sphere(S.translate(2.5, 2.5, 1.0), 0.3, (0.6, 0.8, 1.0), 20.0))
+    L.append(S.light_point(S.translate(0.0, 3.5, 3.0) @ S.rotate_x(-25.0), (1, 1, 1), 30.0, "spot",
+                           float(np.cos(np.radians(15.0))), float(np.cos(np.radians(30.0)))))
+    L.append(S.light_directional(S.rotate_x(20.0) @ S.rotate_y(40.0), (1.0, 0.9, 0.8), 0.5))
+    L.append(S.light_rect(S.translate(3.5, 3.0, -3.0), 0.0, 0.0, (0.9, 0.4, 0.4), 15.0, disk_radius=0.6))
+    L.append(S.light_point(S.translate(-3.5, 1.5, 2.0), (0.5, 1.0, 0.5), 6.0, "omni"))
+    return sc

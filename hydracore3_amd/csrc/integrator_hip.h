@@ -1,0 +1,207 @@
+// Host-side C++ adapter over the C ABI (include/hydra_hip.h), shaped like the reference's own classes so that it
+// drops in where HydraCore3 creates its integrator (main.cpp:194-235, diff_render/drmain.cpp:126, hydra_api/hydra_cpu.cpp:8).
+//
+//   hydra_hip::BVH2SceneHIP   <->  ISceneObject                      (external/CrossRT/CrossRT.h:45-176)
+//   hydra_hip::IntegratorHIP  <->  Integrator                        (integrator_pt.h:123-703): the virtual hooks the
+//                                  kernel_slicer-generated Integrator_Generated overrides (main.cpp:221-224) --
+//                                  PathTraceBlock, NaivePathTraceBlock, PackXYBlock, CommitDeviceData,
+//                                  UpdateMembersPlainData, GetExecutionTime, Update_m_materials / Update_m_lights
+//   hydra_hip::IntegratorDRHIP <-> IntegratorDR                      (diff_render/integrator_dr.h:27-136)
+//
+// The reference's headers cannot be included here (they need the absent LiteMath), so this header carries the same
+// member names over plain arrays; INTEGRATION.md shows the dozen lines that derive the real `Integrator` from it.
+// Header-only; link against hydracore3_amd/libhydra_hip.so. No exceptions cross the C boundary: failures print the
+// library's message and follow the reference's convention (message + return, integrator_pt_scene.cpp:85-89).
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/hydra_hip.h"
+
+namespace hydra_hip {
+
+struct float4x4 { float m[16]; };     // column-major, as LiteMath::float4x4::m_col
+
+struct Material                        // include/cmaterial.h:187-203
+{
+  uint32_t mtype, cflags, lightId, nonlinear;
+  uint32_t texid[4], spdid[4], datai[4];
+  float colors[4][4], row0[4][4], row1[4][4], data[16];
+};
+struct LightSource                     // include/clight.h:19-56
+{
+  float matrix[16], iesMatrix[16], samplerRow0[4], samplerRow1[4], samplerRow0Inv[4], samplerRow1Inv[4], pos[4], intensity[4], norm[4];
+  float size[2]; float pdfA; uint32_t geomType, distType, flags, pdfTableOffset, pdfTableSize, specId, texId, iesId; float mult;
+  uint32_t pdfTableSizeX, pdfTableSizeY, camBackTexId; float lightCos1, lightCos2; uint32_t matId; float dummy2, dummy3;
+};
+static_assert(sizeof(Material) == 320 && sizeof(LightSource) == 320, "records must match the reference layout");
+
+struct CRT_Hit { float t; uint32_t primId, instId, geomId; float coords[4]; };   // CrossRT.h:23-30
+
+// ---- ISceneObject-shaped wrapper of the BVH2 builder + traversal ---------------------------------------------------------
+class BVH2SceneHIP
+{
+public:
+  explicit BVH2SceneHIP(hpt_ctx* ctx) : m_ctx(ctx) {}
+  const char* Name() const { return "BVH2SceneHIP"; }
+  void     ClearGeom() { hpt_clear_geom(m_ctx); }
+  uint32_t AddGeom_Triangles3f(const float* a_vpos3f, size_t a_vertNumber, const uint32_t* a_triIndices, size_t a_indNumber,
+                               uint32_t a_flags = 4 /*BUILD_HIGH*/, size_t vByteStride = sizeof(float) * 3)
+  { return hpt_add_geom_triangles3f(m_ctx, a_vpos3f, a_vertNumber, a_triIndices, a_indNumber, a_flags, vByteStride); }
+  void     UpdateGeom_Triangles3f(uint32_t a_geomId, const float* a_vpos3f, size_t a_vertNumber, const uint32_t* a_triIndices, size_t a_indNumber,
+                                  uint32_t a_flags = 4, size_t vByteStride = sizeof(float) * 3)
+  { hpt_update_geom_triangles3f(m_ctx, a_geomId, a_vpos3f, a_vertNumber, a_triIndices, a_indNumber, a_flags, vByteStride); }
+  void     ClearScene() { hpt_clear_scene(m_ctx); }
+  uint32_t AddInstance(uint32_t a_geomId, const float4x4& a_matrix) { return hpt_add_instance(m_ctx, a_geomId, a_matrix.m); }
+  void     UpdateInstance(uint32_t a_instanceId, const float4x4& a_matrix) { hpt_update_instance(m_ctx, a_instanceId, a_matrix.m); }
+  void     CommitScene(uint32_t options = 4) { hpt_commit_scene(m_ctx, options); }
+  // single-ray forms of the reference interface; the batched C entry points are what a throughput caller should use
+  CRT_Hit  RayQuery_NearestHit(const float posAndNear[4], const float dirAndFar[4])
+  { CRT_Hit h; std::memset(&h, 0xFF, sizeof(h)); hpt_ray_query_nearest(m_ctx, posAndNear, dirAndFar, 1, reinterpret_cast<hpt_hit*>(&h)); return h; }
+  bool     RayQuery_AnyHit(const float posAndNear[4], const float dirAndFar[4])
+  { uint32_t r = 0; hpt_ray_query_any(m_ctx, posAndNear, dirAndFar, 1, &r); return r != 0; }
+  CRT_Hit  RayQuery_NearestHitMotion(const float p[4], const float d[4], float /*time*/) { return RayQuery_NearestHit(p, d); }   // static scenes
+  bool     RayQuery_AnyHitMotion(const float p[4], const float d[4], float /*time*/ = 0.0f) { return RayQuery_AnyHit(p, d); }
+private:
+  hpt_ctx* m_ctx;
+};
+
+struct TextureData { uint32_t width = 1, height = 1, format = 0, flags = 0, addressU = 2, addressV = 2, filter = 0; std::vector<uint8_t> texels; };
+
+// ---- Integrator-shaped front end -----------------------------------------------------------------------------------------
+class IntegratorHIP
+{
+public:
+  explicit IntegratorHIP(int a_maxThreads = 1, int a_device = 0) : m_maxThreadId(uint32_t(a_maxThreads))
+  {
+    if (hpt_create(a_device, &m_ctx) != HPT_OK) { std::printf("[IntegratorHIP]: no HIP device %d\n", a_device); m_ctx = nullptr; return; }
+    m_pAccelStruct = new BVH2SceneHIP(m_ctx);
+    TextureData white; white.texels.assign(4, 0xFF);                      // m_textures[0]: white dummy (integrator_pt_scene_tex.cpp:7-16)
+    m_textures.push_back(white);
+  }
+  virtual ~IntegratorHIP() { delete m_pAccelStruct; if (m_ctx) hpt_destroy(m_ctx); }
+  IntegratorHIP(const IntegratorHIP&) = delete;
+  IntegratorHIP& operator=(const IntegratorHIP&) = delete;
+  bool valid() const { return m_ctx != nullptr; }
+
+  // ---- settings (integrator_pt.h:363-411) ----
+  void SetIntegratorType(uint32_t a_type) { m_intergatorType = a_type; }
+  void SetFrameBufferSize(int a_width, int a_height) { m_fbWidth = a_width; m_fbHeight = a_height; }
+  void SetFrameBufferLayer(uint32_t a_layer) { m_renderLayer = a_layer; }
+  void SetViewport(int a_xStart, int a_yStart, int a_width, int a_height)
+  {
+    m_winStartX = a_xStart; m_winStartY = a_yStart; m_winWidth = a_width; m_winHeight = a_height;
+    if (m_fbWidth == 0 || m_fbHeight == 0) SetFrameBufferSize(a_width, a_height);
+    const int sizeX = a_width - a_xStart, sizeY = a_height - a_yStart;
+    if (sizeX % 8 == 0 && sizeY % 8 == 0) m_tileSize = 8; else if (sizeX % 4 == 0 && sizeY % 4 == 0) m_tileSize = 4;
+    else if (sizeX % 2 == 0 && sizeY % 2 == 0) m_tileSize = 2; else m_tileSize = 1;
+    m_maxThreadId = uint32_t(a_width * a_height);
+  }
+  void SetWorldViewInv(const float4x4& m) { m_worldViewInv = m; }
+  void SetProjInv(const float4x4& m) { m_projInv = m; }
+  void SetAccelStruct(BVH2SceneHIP*) {}                                    // the accelerator is part of the context
+
+  // ---- hooks of the generated class ----
+  virtual void CommitDeviceData()
+  {
+    if (!m_ctx) return;
+    std::vector<hpt_texture_desc> td(m_textures.size());
+    for (size_t i = 0; i < td.size(); i++) {
+      const TextureData& t = m_textures[i];
+      td[i] = hpt_texture_desc{ t.width, t.height, t.format, t.flags, t.addressU, t.addressV, t.filter, 0u, t.texels.data() };
+    }
+    std::vector<uint32_t> instGeom(m_instGeomId);
+    hpt_scene_desc d; std::memset(&d, 0, sizeof(d));
+    d.numGeoms = uint32_t(m_matVertOffset.size() / 2); d.numInsts = uint32_t(m_normMatrices.size());
+    d.numVerts = uint32_t(m_vData8f.size() / 8); d.numTris = uint32_t(m_matIdByPrimId.size());
+    d.vPos4f = nullptr;                                                    // geometry went in through m_pAccelStruct (LoadSceneGeometry)
+    d.vData8f = m_vData8f.data(); d.triIndices = m_triIndices.data(); d.matIdByPrimId = m_matIdByPrimId.data();
+    d.matVertOffset = m_matVertOffset.data(); d.geomTriCount = nullptr; d.geomVertCount = nullptr;
+    d.instGeomId = instGeom.data(); d.instMatrices = nullptr; d.normMatrices = reinterpret_cast<const float*>(m_normMatrices.data());
+    d.remapInst = m_remapInst.data(); d.allRemapLists = m_allRemapLists.data();
+    d.allRemapListsLen = uint32_t(m_allRemapLists.size()); d.allRemapListsSize = m_allRemapListsSize;
+    d.materials = m_materials.data(); d.numMaterials = uint32_t(m_materials.size());
+    d.lights = m_lights.data(); d.numLights = uint32_t(m_lights.size());
+    d.textures = td.data(); d.numTextures = uint32_t(td.size());
+    report(hpt_upload_scene(m_ctx, &d), "CommitDeviceData");
+    if (m_randomGensInit != m_maxThreadId) { hpt_init_random_gens(m_ctx, m_maxThreadId); m_randomGensInit = m_maxThreadId; }   // InitRandomGens
+  }
+  virtual void UpdateMembersPlainData()
+  {
+    if (!m_ctx) return;
+    hpt_params p; std::memset(&p, 0, sizeof(p));
+    std::memcpy(p.projInv, m_projInv.m, 64); std::memcpy(p.worldViewInv, m_worldViewInv.m, 64);
+    p.winStartX = m_winStartX; p.winStartY = m_winStartY; p.winWidth = m_winWidth; p.winHeight = m_winHeight; p.fbWidth = m_fbWidth; p.fbHeight = m_fbHeight;
+    p.traceDepth = m_traceDepth; p.integratorType = m_intergatorType; p.renderLayer = m_renderLayer; p.tileSize = m_tileSize; p.spectralMode = uint32_t(m_spectral_mode);
+    p.exposureMult = m_exposureMult; p.camLensRadius = m_camLensRadius; p.camTargetDist = m_camTargetDist;
+    std::memcpy(p.camRespoceRGB, m_camRespoceRGB, 16); std::memcpy(p.envColor, m_envColor, 16);
+    report(hpt_update_params(m_ctx, &p), "UpdateMembersPlainData");
+  }
+  virtual void PackXYBlock(uint32_t tidX, uint32_t tidY, uint32_t /*a_passNum*/)
+  { if (m_ctx) { UpdateMembersPlainData(); report(hpt_pack_xy(m_ctx, tidX, tidY), "PackXYBlock"); } }
+  virtual void PathTraceBlock(uint32_t tid, uint32_t channels, float* out_color, uint32_t a_passNum)
+  { if (m_ctx) report(hpt_path_trace_block(m_ctx, 0, tid, channels, out_color, a_passNum), "PathTraceBlock"); }
+  virtual void NaivePathTraceBlock(uint32_t tid, uint32_t channels, float* out_color, uint32_t a_passNum)
+  { if (m_ctx) report(hpt_naive_path_trace_block(m_ctx, 0, tid, channels, out_color, a_passNum), "NaivePathTraceBlock"); }
+  virtual void GetExecutionTime(const char* a_funcName, float a_out[4]) { if (m_ctx) hpt_get_execution_time(m_ctx, a_funcName, a_out); }
+  virtual void Update_m_materials(size_t a_first, size_t a_count) { if (m_ctx) report(hpt_update_materials(m_ctx, a_first, a_count, m_materials.data() + a_first), "Update_m_materials"); }
+  virtual void Update_m_lights(size_t a_first, size_t a_count) { if (m_ctx) report(hpt_update_lights(m_ctx, a_first, a_count, m_lights.data() + a_first), "Update_m_lights"); }
+  virtual void SceneRestrictions(uint32_t a_restrictions[4]) const
+  { a_restrictions[0] = 1u << 20; a_restrictions[1] = 1u << 27; a_restrictions[2] = (1u << 28) - 1u; a_restrictions[3] = (1u << 28) - 1u; }   // 28-bit triangle references
+
+  // ---- scene vectors, named as in integrator_pt.h:472-500 ----
+  std::vector<Material>    m_materials;
+  std::vector<LightSource> m_lights;
+  std::vector<uint32_t>    m_matVertOffset;    // uint2 per geom
+  std::vector<uint32_t>    m_matIdByPrimId, m_triIndices;
+  std::vector<float>       m_vData8f;          // 8 floats per vertex
+  std::vector<int>         m_allRemapLists, m_remapInst;   // m_remapInst: int2 per instance
+  uint32_t                 m_allRemapListsSize = 0;
+  std::vector<float4x4>    m_normMatrices;
+  std::vector<uint32_t>    m_instGeomId;
+  std::vector<TextureData> m_textures;
+  BVH2SceneHIP*            m_pAccelStruct = nullptr;
+
+  float4x4 m_projInv{}, m_worldViewInv{};
+  int      m_winStartX = 0, m_winStartY = 0, m_winWidth = 0, m_winHeight = 0, m_fbWidth = 0, m_fbHeight = 0;
+  uint32_t m_traceDepth = 10, m_renderLayer = 0, m_spp = 1024, m_tileSize = 8, m_maxThreadId = 0;
+  uint32_t m_intergatorType = 0;
+  int      m_spectral_mode = 0;
+  float    m_exposureMult = 1.0f, m_camLensRadius = 0.0f, m_camTargetDist = 0.0f;
+  float    m_camRespoceRGB[4] = {1, 1, 1, 1}, m_envColor[4] = {0, 0, 0, 0};
+
+  hpt_ctx* context() const { return m_ctx; }
+
+protected:
+  void report(int rc, const char* where) const { if (rc != HPT_OK) std::printf("[IntegratorHIP::%s]: %s\n", where, hpt_last_error(m_ctx)); }
+  hpt_ctx* m_ctx = nullptr;
+  uint32_t m_randomGensInit = 0;
+};
+
+// ---- IntegratorDR-shaped front end (diff_render/integrator_dr.h:27-136) -------------------------------------------------------
+class IntegratorDRHIP : public IntegratorHIP
+{
+public:
+  explicit IntegratorDRHIP(int a_maxThreads = 1, int a_device = 0) : IntegratorHIP(a_maxThreads, a_device) {}
+  void LoadSceneEnd() { if (m_ctx) hpt_reset_diff_tex(m_ctx); }
+  std::pair<size_t, size_t> PutDiffTex2D(uint32_t texId, uint32_t width, uint32_t height, uint32_t channels)
+  {
+    uint64_t off = 0, size = 0;
+    if (!m_ctx || hpt_put_diff_tex2d(m_ctx, texId, width, height, channels, &off, &size) != HPT_OK) return std::make_pair(size_t(-1), size_t(0));
+    return std::make_pair(size_t(off), size_t(size));
+  }
+  virtual void SetMaxThreadsAndBounces(int /*a_maxThreads*/, int a_maxBounce) { m_traceDepth = uint32_t(a_maxBounce); }   // no per-CPU-thread records on the GPU
+  float PathTraceDR(uint32_t tid, uint32_t channels, float* out_color, uint32_t a_passNum,
+                    const float* a_refImg, const float* a_data, float* a_dataGrad, size_t a_gradSize)
+  {
+    float loss = 0.0f;
+    if (m_ctx) report(hpt_path_trace_dr(m_ctx, 0, tid, channels, out_color, a_passNum, a_refImg, a_data, a_dataGrad, a_gradSize, &loss), "PathTraceDR");
+    return loss;
+  }
+};
+
+} // namespace hydra_hip

@@ -193,3 +193,14 @@ def test_full_size_properties():
     assert np.array_equal(a.random_gens(), b.random_gens())
     m = img_a[..., :3].mean() / 4
     assert 0.15 < m < 0.35 and np.all(img_a[..., 3] == 0) and np.isfinite(img_a).all()
+
+
+def test_cpp_adapter_demo_runs():
+    """IntegratorHIP / BVH2SceneHIP (hydracore3_amd/csrc/integrator_hip.h) driven like main.cpp drives Integrator."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "hydracore3_amd", "adapter_demo")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(r.stdout.strip())
+    assert r.returncode == 0, r.stdout + r.stderr

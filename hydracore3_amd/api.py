@@ -80,7 +80,8 @@ def load_library():
     return _LIB
 
 
-COUNTER_NAMES = ("rays", "nodes", "tris", "surface_hits", "shadow_rays", "paths", "instances_entered", "tex_fetches")
+COUNTER_NAMES = ("rays", "nodes", "tris", "surface_hits", "shadow_rays", "paths", "instances_entered", "tex_fetches",
+                 "cyc_queue_regen", "cyc_trace_nearest", "cyc_shade", "cyc_trace_shadow", "cyc_path_end", "loop_trips", "rsv0", "rsv1")
 
 
 class HipIntegrator:
@@ -224,7 +225,7 @@ class HipIntegrator:
         self._chk(self.L.hpt_set_instrumentation(self.h, int(enabled)))
 
     def counters(self):
-        out = (_u64 * 8)()
+        out = (_u64 * 16)()
         self._chk(self.L.hpt_get_counters(self.h, out))
         return dict(zip(COUNTER_NAMES, [int(v) for v in out]))
 

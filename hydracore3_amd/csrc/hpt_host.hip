@@ -697,11 +697,11 @@ extern "C" int hpt_get_execution_time(hpt_ctx* c, const char* name, float out[4]
   return HPT_OK;
 }
 extern "C" int hpt_set_instrumentation(hpt_ctx* c, int enabled) { if (!c) return HPT_ERR_ARG; c->instrument = enabled != 0; return HPT_OK; }
-extern "C" int hpt_get_counters(hpt_ctx* c, uint64_t out[8])
+extern "C" int hpt_get_counters(hpt_ctx* c, uint64_t out[16])
 {
   if (!c || !out) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
-  if (!c->dCounters.p) { for (int i = 0; i < 8; i++) out[i] = 0; return HPT_OK; }
+  if (!c->dCounters.p) { for (int i = 0; i < 16; i++) out[i] = 0; return HPT_OK; }
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipMemcpy(out, c->dCounters.p, sizeof(Counters), hipMemcpyDeviceToHost));
   return HPT_OK;

@@ -120,6 +120,10 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
   uint nRays = 0, nShadow = 0, nHits = 0, nPaths = 0;
   float lossLocal = 0.0f;
   const uint maxBounce = NAIVE ? S.traceDepth + 1u : S.traceDepth;
+  // diagnostic stamps (STATS build only; never in a timed kernel): where a wave's cycles go, phase by phase
+  unsigned long long tPh[5] = {0, 0, 0, 0, 0}, tTrips = 0, tPrev = 0;
+#define STAMP(i) do { if (STATS) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tPh[i] += tn - tPrev; tPrev = tn; } } while (0)
+  if (STATS) tPrev = __builtin_amdgcn_s_memtime();
 
   while (true) {
     // ---- (1) a finished pixel goes back to HBM: one read-modify-write per pixel and call ------------------------------
@@ -166,6 +170,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
       if (STATS) nPaths++;
     }
     if (!__any(alive)) break;
+    STAMP(0); if (STATS) tTrips++;
 
     // ---- (4) closest hit: kernel_RayTrace2 -> RayQuery_NearestHit ----------------------------------------------------------
     HitRec hit; hit.inst = 0xFFFFFFFFu; hit.prim = 0; hit.t = 0; hit.u = hit.v = 0;
@@ -174,6 +179,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
       if (STATS) nRays++;
     }
 
+    STAMP(1);
     // ---- (5) surface, next-event estimation set-up, emission, BSDF sampling -------------------------------------------------
     bool wantShadow = false;
     V3 shPos = v3(0, 0, 0), shDir = v3(0, 0, 1); float shFar = 0.0f;
@@ -337,6 +343,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
       }
     }
 
+    STAMP(2);
     // ---- (6) shadow rays: RayQuery_AnyHit ---------------------------------------------------------------------------------------
     if (wantShadow) {
       HitRec sh;
@@ -345,6 +352,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
       if (!occluded) accum = accum + contrib; else if (DR) { recS = v3(0, 0, 0); recdS = v3(0, 0, 0); }
     } else if (DR) { recS = v3(0, 0, 0); recdS = v3(0, 0, 0); }
 
+    STAMP(3);
     // ---- (7) bookkeeping: adjoint record, end of path ------------------------------------------------------------------------------
     if (alive) {
       if (DR && didBounce) {
@@ -412,7 +420,9 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
         alive = false;
       }
     }
+    STAMP(4);
   }
+#undef STAMP
 
 #undef PIX
 #undef PIX_XY
@@ -421,6 +431,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
   if (STATS) {
     // wave-reduce, one atomic per counter per wave
     unsigned long long v[8] = { nRays, st.nodes, st.tris, nHits, nShadow, nPaths, st.insts, 0ull };
+    if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 5; i++) atomicAdd(&job.counters->v[8 + i], tPh[i]); atomicAdd(&job.counters->v[13], tTrips); }
     for (int i = 0; i < 8; i++) {
       unsigned long long x = v[i];
       for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);

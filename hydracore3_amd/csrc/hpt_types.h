@@ -95,6 +95,7 @@ struct DevScene
   float camRespoceRGB[4], envColor[4];
 };
 
-struct Counters { unsigned long long v[8]; };   // rays, nodes, tris, surfaceHits, shadowRays, paths, instEnter, texFetch
+struct Counters { unsigned long long v[16]; };  // rays, nodes, tris, surfaceHits, shadowRays, paths, instEnter, texFetch,
+                                                // then wave-cycles (s_memtime) of: queue+regen, closest-hit traversal, shading, shadow traversal, path end; loop trips
 
 } // namespace hpt

@@ -151,10 +151,12 @@ int  hpt_adam_step_dev(hpt_ctx* ctx, float* stateDev, const float* gradDev, floa
 /* ---- timing / instrumentation ----------------------------------------------------------------------------------- */
 /* GetExecutionTime(name, out[4]) (integrator_pt.h:266, main.cpp:416-419): out[0] exec ms, [1] host->device, [2] device->host, [3] overhead */
 int  hpt_get_execution_time(hpt_ctx* ctx, const char* funcName, float out[4]);
-/* Traversal counters of the last hpt_*_block call made with instrumentation enabled: {rays, nodesVisited, trisTested,
- * surfaceHits, shadowRays, paths, instancesEntered, texFetches}. Feeds the algorithmic-bytes roofline. */
+/* Counters of the last hpt_*_block call made with instrumentation enabled: [0..7] = {rays, nodesVisited, trisTested,
+ * surfaceHits, shadowRays, paths, instancesEntered, texFetches} (feeds the algorithmic-bytes roofline);
+ * [8..12] = wave-cycles (s_memtime) spent in {queue+regeneration, closest-hit traversal, shading, shadow traversal, path end},
+ * [13] = bounce-loop trips summed over waves, [14..15] reserved. The instrumented kernel is a separate build: never timed. */
 int  hpt_set_instrumentation(hpt_ctx* ctx, int enabled);
-int  hpt_get_counters(hpt_ctx* ctx, uint64_t out[8]);
+int  hpt_get_counters(hpt_ctx* ctx, uint64_t out[16]);
 /* Launch geometry of the persistent kernel: blocks per CU (0 = automatic). */
 int  hpt_set_launch_config(hpt_ctx* ctx, int blocksPerCU);
 /* Duration of the last path-tracing kernel, measured with HIP events on the stream it ran on (ms). */

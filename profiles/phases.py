@@ -1,0 +1,12 @@
+"""Diagnostic: share of wave-cycles per phase of the bounce loop (instrumented STATS build, s_memtime stamps). Run on a GPU box: python profiles/phases.py"""
+import sys; sys.path.insert(0,'.')
+import numpy as np
+from hydracore3_amd.api import HipIntegrator
+from hydracore3_amd.scene import load_hydra_xml
+from hydracore3_amd.synth import interior_scene
+for name in ('cornell','interior'):
+    sc = load_hydra_xml('tests/golden/scenes/test_035/statex_00001.xml',1024,1024) if name=='cornell' else interior_scene(1920,1080)
+    g = HipIntegrator(sc); g.set_instrumentation(True)
+    img = np.zeros((sc.height, sc.width,4),np.float32); g.PathTraceBlock(g.N,4,img,8)
+    c = g.counters(); tot = sum(c[k] for k in c if k.startswith('cyc_'))
+    print(name, {k: round(c[k]/tot,3) for k in c if k.startswith('cyc_')}, 'trips/wave-path', c['loop_trips']*64/c['paths'], 'rays/path', c['rays']/c['paths'])

@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--verify", action="store_true", help="rank 0 re-renders the whole frame alone and checks the sharded frame is bit-identical")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -89,12 +90,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # HYDRA_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices, the reduce is staged
+    # through host memory); the real multi-GPU run uses "nccl", which is RCCL on ROCm
+    backend = os.environ.get("HYDRA_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     import __graft_entry__ as g
     if rank == 0:
@@ -106,12 +114,13 @@ def main():
     W, H = (args.width or (1024 if args.workload == "cornell" else 1920)), (args.height or (1024 if args.workload == "cornell" else 1080))
     spp = args.spp
     sc = build_scene(args.workload, W, H)
-    integ = HipIntegrator(sc, device=local_rank)
+    integ = HipIntegrator(sc, device=dev_index)
     if args.blocks_per_cu:
         integ.set_launch_config(args.blocks_per_cu)
     N = W * H
-    from hydracore3_amd.sharding import tid_window
-    t_begin, t_count = tid_window(rank, world, N)     # contiguous, tile-aligned windows of the swizzled tid range
+    from hydracore3_amd.sharding import tid_interleave
+    t_begin, t_count, chunk, stride = tid_interleave(rank, world, N)   # rank r renders every world-th 1024-tid chunk (load balance)
+    integ.set_tid_interleave(chunk, stride)
 
     frame = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
@@ -120,7 +129,13 @@ def main():
         frame.zero_()
         integ.path_trace_block_dev(frame.data_ptr(), spp, t_begin, t_count, 4, False, stream)
         if dist is not None:
-            dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)       # final RCCL reduce of the framebuffer over xGMI
+            if backend == "nccl":
+                dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)   # final RCCL reduce of the framebuffer over xGMI
+            else:
+                host = frame.cpu()
+                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                if rank == 0:
+                    frame.copy_(host)
 
     def sync():
         if dist is not None:
@@ -139,7 +154,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         kernel_ms = [integ.last_kernel_ms()]
@@ -148,12 +163,26 @@ def main():
 
     mean_lum = float(frame[..., :3].mean().item()) / spp if rank == 0 else 0.0
 
+    verified = None
+    if args.verify and rank == 0:
+        integ.set_tid_interleave(0, 1)
+        solo = HipIntegrator(sc, device=dev_index)
+        ref = torch.zeros_like(frame)
+        for _ in range(args.warmup + args.steps):                 # the RNG streams continue from step to step
+            ref.zero_()
+            solo.path_trace_block_dev(ref.data_ptr(), spp, 0, N, 4, False, stream)
+        torch.cuda.synchronize()
+        verified = bool(torch.equal(ref, frame))
+        if not verified:
+            raise SystemExit("sharded frame differs from the single-GPU frame")
+
     roofline, cpu = None, None
     if rank == 0:
         # algorithmic bytes per path from the instrumented kernel on the same frame (fewer passes: the statistics are stationary)
         probe_spp = min(spp, 8)
         integ.set_instrumentation(True)
         integ.InitRandomGens(N)
+        integ.set_tid_interleave(0, 1)
         probe = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
         integ.path_trace_block_dev(probe.data_ptr(), probe_spp, 0, N, 4, False, stream)
         torch.cuda.synchronize()
@@ -167,7 +196,8 @@ def main():
         tfile = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tfile))
+                traffic = tj["hbm_bytes_per_launch"] * paths_per_launch / float(tj["paths_per_launch"])   # scaled to this launch's path count
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -190,8 +220,8 @@ def main():
                "config": {"workload": f"scenes/test_035 Cornell box {W}x{H} @ {spp} spp, forward PathTraceBlock" if args.workload == "cornell"
                           else f"synthetic 1M-triangle interior {W}x{H} @ {spp} spp, forward PathTraceBlock",
                           "paths_per_step": N * spp, "trace_depth": sc.trace_depth, "integrator": "mispt",
-                          "sharding": f"{world} contiguous tid windows + RCCL reduce" if world > 1 else "single GPU",
-                          "mean_radiance": round(mean_lum, 5)},
+                          "sharding": f"{world} ranks x interleaved 1024-tid chunks + RCCL reduce" if world > 1 else "single GPU",
+                          "mean_radiance": round(mean_lum, 5), "sharded_frame_bit_identical": verified},
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
 

@@ -46,6 +46,7 @@ ABI = {
     "hpt_path_trace_block": (_i, [_vp, _u32, _u32, _u32, _vp, _u32]),
     "hpt_naive_path_trace_block": (_i, [_vp, _u32, _u32, _u32, _vp, _u32]),
     "hpt_path_trace_block_dev": (_i, [_vp, _u32, _u32, _u32, _vp, _u32, _i, _vp]),
+    "hpt_set_tid_interleave": (_i, [_vp, _u32, _u32]),
     "hpt_put_diff_tex2d": (_i, [_vp, _u32, _u32, _u32, _u32, C.POINTER(_u64), C.POINTER(_u64)]),
     "hpt_reset_diff_tex": (_i, [_vp]),
     "hpt_path_trace_dr": (_i, [_vp, _u32, _u32, _u32, _vp, _u32, _vp, _vp, _vp, _sz, C.POINTER(_f)]),
@@ -228,6 +229,9 @@ class HipIntegrator:
         out = (_u64 * 16)()
         self._chk(self.L.hpt_get_counters(self.h, out))
         return dict(zip(COUNTER_NAMES, [int(v) for v in out]))
+
+    def set_tid_interleave(self, chunk: int, stride: int):
+        self._chk(self.L.hpt_set_tid_interleave(self.h, chunk, stride))
 
     def set_launch_config(self, blocks_per_cu: int):
         self._chk(self.L.hpt_set_launch_config(self.h, blocks_per_cu))

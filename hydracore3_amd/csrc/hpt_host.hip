@@ -73,6 +73,7 @@ struct hpt_ctx
   bool sceneUploaded = false, paramsSet = false;
   uint packedCount = 0;
   int  blocksPerCU = 0;
+  uint tidChunk = 0, tidStride = 1;      // hpt_set_tid_interleave
   bool instrument = false;
   uint64_t gradSize = 0;
 
@@ -526,7 +527,10 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
 {
   if (!c->sceneUploaded || !c->paramsSet) return c->fail(HPT_ERR_STATE, "PathTraceBlock before CommitDeviceData / UpdateMembersPlainData");
   if (c->packedCount != (uint)(c->S.winWidth * c->S.winHeight)) return c->fail(HPT_ERR_STATE, "PathTraceBlock before PackXYBlock");
-  if ((size_t)job.tidBegin + job.tidCount > c->packedCount) return c->fail(HPT_ERR_ARG, "PathTraceBlock: tid range exceeds the viewport");
+  job.tidStride = c->tidStride > 1 ? c->tidStride : 1u;
+  job.tidChunk = (job.tidStride > 1 && c->tidChunk > 0) ? c->tidChunk : 0x40000000u;
+  job.tidEnd = c->packedCount;
+  if (job.tidStride == 1 && (size_t)job.tidBegin + job.tidCount > c->packedCount) return c->fail(HPT_ERR_ARG, "PathTraceBlock: tid range exceeds the viewport");
   if (c->dGens.n < c->packedCount) return c->fail(HPT_ERR_STATE, "PathTraceBlock: m_randomGens smaller than the viewport (InitRandomGens)");
   if (job.channels < 1 || job.channels > 4) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceBlock: channels must be 1..4 (spectral layers are out of scope)");
   if (dr && (c->S.traceDepth == 0 || c->S.traceDepth > 16)) return c->fail(HPT_ERR_ARG, "PathTraceDR: trace depth must be 1..16");
@@ -704,6 +708,12 @@ extern "C" int hpt_get_counters(hpt_ctx* c, uint64_t out[16])
   if (!c->dCounters.p) { for (int i = 0; i < 16; i++) out[i] = 0; return HPT_OK; }
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipMemcpy(out, c->dCounters.p, sizeof(Counters), hipMemcpyDeviceToHost));
+  return HPT_OK;
+}
+extern "C" int hpt_set_tid_interleave(hpt_ctx* c, uint32_t chunk, uint32_t stride)
+{
+  if (!c || (stride > 1 && (chunk == 0 || chunk % 64 != 0))) return HPT_ERR_ARG;
+  c->tidChunk = chunk; c->tidStride = stride ? stride : 1;
   return HPT_OK;
 }
 extern "C" int hpt_set_launch_config(hpt_ctx* c, int blocksPerCU) { if (!c || blocksPerCU < 0 || blocksPerCU > 8) return HPT_ERR_ARG; c->blocksPerCU = blocksPerCU; return HPT_OK; }

@@ -22,7 +22,9 @@ namespace hpt {
 
 struct Job
 {
-  uint   tidBegin, tidCount;      // window of the swizzled pixel index space this launch renders
+  uint   tidBegin, tidCount;      // work items of this launch: item k renders tid = tidBegin + (k / chunk) * chunk * stride + k % chunk
+  uint   tidChunk, tidStride;     // (stride 1 = one contiguous window; stride W = every W-th chunk: the interleaved multi-GPU split)
+  uint   tidEnd;                  // number of threads of the whole frame (items mapping past it are dropped)
   uint   passNum, channels;
   float* outColor;                // full W*H*channels framebuffer (device)
   Rng*   gens;                    // m_randomGens (device, persistent)
@@ -145,8 +147,8 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
         base = __shfl(base, (int)(__ffsll((long long)mask) - 1));
         if (need) {
           const uint k = base + mbcnt64(mask);
-          if (k < job.tidCount) {
-            const uint tid = job.tidBegin + k;
+          const uint tid = job.tidBegin + (k / job.tidChunk) * job.tidChunk * job.tidStride + (k % job.tidChunk);
+          if (k < job.tidCount && tid < job.tidEnd) {
             const uint XY = job.packedXY[tid];
             gen = job.gens[tid];
             const uint pixel = ((XY & 0xFFFF0000u) >> 16) * (uint)S.winWidth + (XY & 0x0000FFFFu);

@@ -128,6 +128,11 @@ int  hpt_set_random_gens(hpt_ctx* ctx, const uint32_t* inUint2, uint32_t count);
 int  hpt_path_trace_block(hpt_ctx* ctx, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out_color, uint32_t passNum);
 /* NaivePathTraceBlock (integrator_pt.h:259, integrator_pt_host.cpp:39-55) */
 int  hpt_naive_path_trace_block(hpt_ctx* ctx, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out_color, uint32_t passNum);
+/* Multi-GPU split of one frame (no reference counterpart: the reference is single-device). With stride > 1 the k-th work item of a
+ * *_block call renders tid = tidBegin + (k / chunk) * chunk * stride + k % chunk, i.e. a rank passes tidBegin = rank * chunk and
+ * renders every stride-th chunk of the tile-swizzled tid space (items past the viewport are dropped). chunk must be a multiple of 64
+ * (one 8x8 tile). stride <= 1 restores the contiguous window [tidBegin, tidBegin + tidCount). */
+int  hpt_set_tid_interleave(hpt_ctx* ctx, uint32_t chunk, uint32_t stride);
 /* Same with the framebuffer already resident in device memory (kernel_slicer's generated class keeps out_color on the
  * device between calls, kmake_mega.json:18). stream is a hipStream_t (NULL = default stream); asynchronous. */
 int  hpt_path_trace_block_dev(hpt_ctx* ctx, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out_color_dev,

@@ -37,6 +37,60 @@ def build_scene(workload, width, height):
     return interior_scene(width, height)
 
 
+def run_dr(args, rank, world, dev, stream):
+    """BASELINE.json configs[3]: IntegratorDR fwd+bwd on the test_228-class scene, 256 x 256 x 4 albedo texture, + Adam.
+    One step = memset(grad) + PathTraceDR (record, replay and adjoint fused, gradient atomics into HBM) + AdamOptimizer::step."""
+    from hydracore3_amd.api import HipIntegrator
+    from hydracore3_amd.synth import dr_scene
+    import ctypes as C
+    xml = os.path.join(ROOT, "tests", "golden", "scenes", "test_228", "statex_00001.xml")
+    W, H = args.width or 512, args.height or 512
+    spp = args.spp if args.spp != 1024 else 256
+    sc, tex_id = dr_scene(xml, W, H)
+    integ = HipIntegrator(sc, device=dev.index)
+    off, size = integ.PutDiffTex2D(tex_id, 256, 256, 4)
+    N = W * H
+    # reference image: the same scene with the target (checker) albedo, a few passes on the GPU
+    tgt, _ = dr_scene(xml, W, H, target=True)
+    tgt_int = HipIntegrator(tgt, device=dev.index)
+    ref = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    tgt_int.path_trace_block_dev(ref.data_ptr(), 64, 0, N, 4, False, stream)
+    ref = torch.flip(ref / 64.0, dims=[0]).contiguous()            # PixelLossPT reads the reference y-flipped (integrator_dr.cpp:1119)
+    data = torch.full((size,), 0.5, dtype=torch.float32, device=dev)
+    grad = torch.zeros_like(data); mom = torch.zeros_like(data); gsq = torch.zeros_like(data)
+    loss = torch.zeros(1, dtype=torch.float32, device=dev)
+    frame = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    L = integ.L
+    losses = []
+
+    def step(it):
+        grad.zero_(); loss.zero_(); frame.zero_()
+        integ._chk(L.hpt_path_trace_dr_dev(integ.h, 0, N, 4, frame.data_ptr(), spp, ref.data_ptr(), data.data_ptr(), grad.data_ptr(), size, loss.data_ptr(), stream))
+        integ._chk(L.hpt_adam_step_dev(integ.h, data.data_ptr(), grad.data_ptr(), mom.data_ptr(), gsq.data_ptr(), size, it, stream))
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    kms = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+        kms.append(integ.last_kernel_ms())
+        losses.append(float(loss.item()) / N)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    value = float(N) * spp * args.steps / elapsed / 1e6
+    out = {"metric": "Mpaths/s (fwd+bwd grad, IntegratorDR::PathTraceDR + Adam)", "value": round(value, 2), "unit": "Mpaths/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"scenes/test_228 + 256x256x4 differentiable albedo, {W}x{H} @ {spp} spp, PathTraceDR fwd+bwd + Adam",
+                      "paths_per_step": N * spp, "trace_depth": sc.trace_depth, "grad_floats": int(size), "loss_per_step": [round(v, 6) for v in losses]},
+           "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                        "kernel": "pathTraceKernel<DR>", "kernel_ms": round(float(np.mean(kms)), 3)},
+           "cpu_baseline": None}
+    print(json.dumps(out), flush=True)
+
+
 def algorithmic_bytes(counters, paths, spp):
     """bytes a path has to touch, from the traversal / shading counters of an instrumented launch."""
     c = counters
@@ -72,7 +126,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cornell", choices=["cornell", "interior"])
+    ap.add_argument("--workload", default="cornell", choices=["cornell", "interior", "dr"])
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=1024)
@@ -110,6 +164,10 @@ def main():
     if dist is not None:
         dist.barrier()
     from hydracore3_amd.api import HipIntegrator
+    if args.workload == "dr":
+        if world != 1:
+            raise SystemExit("--workload dr is a single-GPU bench line this round")
+        return run_dr(args, rank, world, dev, torch.cuda.current_stream().cuda_stream)
 
     W, H = (args.width or (1024 if args.workload == "cornell" else 1920)), (args.height or (1024 if args.workload == "cornell" else 1080))
     spp = args.spp

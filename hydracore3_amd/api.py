@@ -56,6 +56,7 @@ ABI = {
     "hpt_set_instrumentation": (_i, [_vp, _i]),
     "hpt_get_counters": (_i, [_vp, C.POINTER(_u64)]),
     "hpt_set_launch_config": (_i, [_vp, _i]),
+    "hpt_set_accel_layout": (_i, [_vp, _i]),
     "hpt_last_kernel_ms": (_i, [_vp, C.POINTER(_f)]),
 }
 
@@ -82,13 +83,13 @@ def load_library():
 
 
 COUNTER_NAMES = ("rays", "nodes", "tris", "surface_hits", "shadow_rays", "paths", "instances_entered", "tex_fetches",
-                 "cyc_queue_regen", "cyc_trace_nearest", "cyc_shade", "cyc_trace_shadow", "cyc_path_end", "loop_trips", "rsv0", "rsv1")
+                 "cyc_queue_regen", "cyc_trace_nearest", "cyc_shade", "cyc_trace_shadow", "cyc_path_end", "loop_trips", "wave_node_iters", "wave_tri_iters")
 
 
 class HipIntegrator:
     """Integrator-shaped front end of the HIP core. One instance = one hpt_ctx = one GPU."""
 
-    def __init__(self, scene: SceneData = None, params: Params = None, device: int = 0):
+    def __init__(self, scene: SceneData = None, params: Params = None, device: int = 0, accel_layout: int = 0):
         self.L = load_library()
         h = _vp()
         rc = self.L.hpt_create(device, C.byref(h))
@@ -98,6 +99,8 @@ class HipIntegrator:
         self.scene = None
         self.params = None
         self.W = self.H = self.N = 0
+        if accel_layout:
+            self._chk(self.L.hpt_set_accel_layout(self.h, accel_layout))   # 1 = two-level TLAS/BLAS, 2 = single-level
         if scene is not None:
             self.LoadScene(scene, params)
 

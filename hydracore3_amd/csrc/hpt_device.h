@@ -757,7 +757,8 @@ HPT_DEV uint remapMaterialId(const DevScene& S, uint a_mId, uint a_instId)
 // Closest hit = min t with ties broken by (instId, primId): independent of tree shape and traversal order.
 struct HitRec { float t; uint prim, inst; float u, v; };   // inst == 0xFFFFFFFF: miss
 
-struct TravStats { uint nodes, tris, insts; };
+struct TravStats { uint nodes, tris, insts, waveNodeIters, waveTriIters; };   // wave*: counted by the first active lane of each trip
+HPT_DEV bool firstActiveLane() { const uint l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); return l == (uint)__builtin_amdgcn_readfirstlane((int)l); }
 
 // Loop shape ("while-while"): every lane first walks inner nodes in a tight loop until it holds a leaf reference, and only
 // then do the lanes of the wave handle their leaves together. Mixing the three node kinds in one loop body makes a wave
@@ -767,7 +768,10 @@ HPT_DEV V3 rcp3(V3 d) { return v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_r
 // Traversal stack: the first LDS_STACK entries of a lane live in LDS ([depth][lane]: a push or pop is one conflict-free
 // ds_write/ds_read_b32 per wave); deeper entries - rare, a push only happens when both children are hit - go to a per-lane
 // slice of an HBM scratch buffer ([depth][global lane], coalesced). LDS use is therefore independent of the tree depth.
-static const int LDS_STACK = 16;
+#ifndef HPT_LDS_STACK
+#define HPT_LDS_STACK 16
+#endif
+static const int LDS_STACK = HPT_LDS_STACK;
 struct TravStack { uint* lds; uint* ovf; uint ovfStride; };
 HPT_DEV void stkPush(const TravStack& k, int sp, uint v) { if (sp < LDS_STACK) k.lds[sp * 256] = v; else k.ovf[(size_t)(sp - LDS_STACK) * k.ovfStride] = v; }
 HPT_DEV uint stkPop(const TravStack& k, int sp)
@@ -801,7 +805,7 @@ HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, 
       const float4* np = (const float4*)(S.nodes + cur);
       const float4 q0 = np[0], q1 = np[1], q2 = np[2];
       const uint4  q3 = ((const uint4*)np)[3];
-      if (STATS) st.nodes++;
+      if (STATS) { st.nodes++; if (firstActiveLane()) st.waveNodeIters++; }
       const float best = hit.t;
       // child 0: lo = (q0.x q0.y q0.z), hi = (q0.w q1.x q1.y); child 1: lo = (q1.z q1.w q2.x), hi = (q2.y q2.z q2.w)
       float ax = (q0.x - o.x) * id.x, bx = (q0.w - o.x) * id.x;
@@ -837,7 +841,7 @@ HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, 
       for (uint k = 0; k < cnt; k++) {
         const float4* tp = (const float4*)(S.tris + first + k);
         const float4 a = tp[0], b = tp[1], c = tp[2];
-        if (STATS) st.tris++;
+        if (STATS) { st.tris++; if (firstActiveLane()) st.waveTriIters++; }
         const V3 e1 = v3(b.x, b.y, b.z), e2 = v3(c.x, c.y, c.z);
         const V3 pvec = cross(d, e2);
         const float det = dot(e1, pvec);
@@ -883,6 +887,108 @@ HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, 
 #undef HPT_PUSH
 #undef HPT_POP
   return found;
+}
+
+// ---- single-level variant ---------------------------------------------------------------------------------------------------
+// For static scenes whose instanced triangle count fits the budget (hpt_host.hip: FLAT_TRI_BUDGET) the host builds ONE BVH2 over
+// all instanced triangles with WORLD-space boxes: no TLAS/BLAS box overlap, no instance enter / leave trips through the loop.
+// The triangle test itself still runs in the instance's OBJECT space - the ray is taken there with the same world->object rows the
+// two-level path uses, cached while consecutive triangles belong to the same instance - so every hit (t, u, v, ids) is bit-identical
+// to the two-level / Embree semantics. Boxes only cull.
+template <bool ANY, bool STATS, bool DEEP>
+HPT_DEV bool traceRayFlat(const DevScene& S, const V3 wo, const V3 wd, float tnear, float tfar, HitRec& hit, const TravStack& stk, TravStats& st)
+{
+  hit.t = tfar; hit.prim = 0xFFFFFFFFu; hit.inst = 0xFFFFFFFFu; hit.u = 0.0f; hit.v = 0.0f;
+  bool found = false;
+  uint cur = S.rootRef;
+  if (cur == REF_NONE) return false;
+  const V3 id = rcp3(wd);
+  V3 o = wo, d = wd;                                          // object-space ray of instance `curInst`
+  uint curInst = 0xFFFFFFFFu;
+  int sp = 0;
+#define HPT_PUSH(v) do { if (DEEP) stkPush(stk, sp, (v)); else stk.lds[sp * 256] = (v); sp++; } while (0)
+#define HPT_POP()   do { sp--; cur = DEEP ? stkPop(stk, sp) : stk.lds[sp * 256]; } while (0)
+  while (true) {
+    while ((cur & REF_LEAF) == 0u) {
+      const float4* np = (const float4*)(S.nodes + cur);
+      const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+      const uint4  q3 = ((const uint4*)np)[3];
+      if (STATS) { st.nodes++; if (firstActiveLane()) st.waveNodeIters++; }
+      const float best = hit.t;
+      float ax = (q0.x - wo.x) * id.x, bx = (q0.w - wo.x) * id.x;
+      float ay = (q0.y - wo.y) * id.y, by = (q1.x - wo.y) * id.y;
+      float az = (q0.z - wo.z) * id.z, bz = (q1.y - wo.z) * id.z;
+      const float t0n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tnear));
+      const float t0f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
+      ax = (q1.z - wo.x) * id.x; bx = (q2.y - wo.x) * id.x;
+      ay = (q1.w - wo.y) * id.y; by = (q2.z - wo.y) * id.y;
+      az = (q2.x - wo.z) * id.z; bz = (q2.w - wo.z) * id.z;
+      const float t1n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tnear));
+      const float t1f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
+      const bool h0 = (t0n * 0.999999f <= t0f * 1.000001f);
+      const bool h1 = (t1n * 0.999999f <= t1f * 1.000001f);
+      if (h0 && h1) {
+        const bool firstIs0 = t0n <= t1n;
+        HPT_PUSH(firstIs0 ? q3.y : q3.x);
+        cur = firstIs0 ? q3.x : q3.y;
+      } else if (h0) cur = q3.x;
+      else if (h1) cur = q3.y;
+      else if (sp > 0) HPT_POP();
+      else cur = REF_NONE;
+    }
+    if (cur == REF_NONE) break;
+    {
+      const uint cnt = (cur >> 28) & 7u;
+      const uint first = cur & 0x0FFFFFFFu;
+      for (uint k = 0; k < cnt; k++) {
+        const float4* tp = (const float4*)(S.tris + first + k);
+        const float4 a = tp[0], b = tp[1], c = tp[2];
+        if (STATS) { st.tris++; if (firstActiveLane()) st.waveTriIters++; }
+        const uint inst = __float_as_uint(b.w);
+        if (inst != curInst) {                                // world -> object space of this triangle's instance
+          const float4* ip = (const float4*)(S.insts + inst);
+          const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
+          if (STATS) st.insts++;
+          o = v3(r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w,
+                 r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w,
+                 r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w);
+          d = v3(r0.x * wd.x + r0.y * wd.y + r0.z * wd.z,
+                 r1.x * wd.x + r1.y * wd.y + r1.z * wd.z,
+                 r2.x * wd.x + r2.y * wd.y + r2.z * wd.z);
+          curInst = inst;
+        }
+        const V3 e1 = v3(b.x, b.y, b.z), e2 = v3(c.x, c.y, c.z);
+        const V3 pvec = cross(d, e2);
+        const float det = dot(e1, pvec);
+        const float inv = 1.0f / det;
+        const V3 tvec = o - v3(a.x, a.y, a.z);
+        const float uu = dot(tvec, pvec) * inv;
+        const V3 qvec = cross(tvec, e1);
+        const float vv = dot(d, qvec) * inv;
+        const float tt = dot(e2, qvec) * inv;
+        const uint prim = __float_as_uint(a.w);
+        bool ok = (det != 0.0f) && (uu >= 0.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f) && (tt >= tnear) && (tt <= hit.t);
+        if (ok && found && tt == hit.t)
+          ok = (inst != hit.inst) ? (inst < hit.inst) : (prim < hit.prim);
+        if (ok) {
+          hit.t = tt; hit.prim = prim; hit.inst = inst; hit.u = uu; hit.v = vv; found = true;
+          if (ANY) return true;
+        }
+      }
+      if (sp > 0) HPT_POP(); else break;
+    }
+  }
+#undef HPT_PUSH
+#undef HPT_POP
+  return found;
+}
+
+// dispatch on the scene's acceleration-structure layout (compile-time: each kernel variant is built for one layout)
+template <bool ANY, bool STATS, bool DEEP, bool FLAT>
+HPT_DEV bool traceAny(const DevScene& S, const V3 wo, const V3 wd, float tnear, float tfar, HitRec& hit, const TravStack& stk, TravStats& st)
+{
+  if (FLAT) return traceRayFlat<ANY, STATS, DEEP>(S, wo, wd, tnear, tfar, hit, stk, st);
+  return traceRay<ANY, STATS, DEEP>(S, wo, wd, tnear, tfar, hit, stk, st);
 }
 
 } // namespace hpt

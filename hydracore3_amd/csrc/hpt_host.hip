@@ -12,7 +12,10 @@
 #include "hpt_kernels.hip"
 #include "bvh_build.h"
 
-static const uint MAX_STACK = 64;     // traversal stack entries per lane: LDS_STACK in LDS + the rest in an HBM overflow buffer
+static const uint MAX_STACK = 64;
+// Static scenes with at most this many INSTANCED triangles get the single-level world-space BVH (48 B + ~32 B of nodes per triangle:
+// 32 M triangles = 2.6 GB of the 288 GB); beyond it (heavy instancing) the two-level TLAS/BLAS layout is kept.
+static const size_t FLAT_TRI_BUDGET = size_t(32) << 20;     // traversal stack entries per lane: LDS_STACK in LDS + the rest in an HBM overflow buffer
 
 using namespace hpt;
 
@@ -73,6 +76,7 @@ struct hpt_ctx
   bool sceneUploaded = false, paramsSet = false;
   uint packedCount = 0;
   int  blocksPerCU = 0;
+  int  accelLayout = 0;                  // 0 automatic (flat when it fits the budget), 1 force two-level, 2 force flat
   uint tidChunk = 0, tidStride = 1;      // hpt_set_tid_interleave
   bool instrument = false;
   uint64_t gradSize = 0;
@@ -239,10 +243,65 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
       const float* A = &g.pos[3 * g.idx[3 * p + 0]]; const float* B = &g.pos[3 * g.idx[3 * p + 1]]; const float* C = &g.pos[3 * g.idx[3 * p + 2]];
       BvhTri& t = g.tris[i];
       for (int a = 0; a < 3; a++) { t.v0[a] = A[a]; t.e1[a] = B[a] - A[a]; t.e2[a] = C[a] - A[a]; }
-      t.primId = p; t.pad0 = t.pad1 = 0;
+      t.primId = p; t.instId = 0; t.pad1 = 0;
     }
     g.dirty = false;
     maxBlasDepth = std::max(maxBlasDepth, g.bvh.depth);
+  }
+  // ---- single-level layout: one BVH2 over all instanced triangles, world-space boxes, object-space triangle records ----
+  size_t instTris = 0;
+  for (const Inst& in : c->insts) instTris += c->geoms[in.geomId].idx.size() / 3;
+  // measured (profiles/phases.py): flat cuts node visits 12 % on the 1M-triangle scene but not time, and costs 8 % on the Cornell box
+  // (looser world-space boxes around rotated instances, per-triangle ray transform): automatic = two-level for now
+  const bool flat = (c->accelLayout == 2) && instTris <= FLAT_TRI_BUDGET;
+  if (flat) {
+    const size_t ni = c->insts.size();
+    std::vector<Aabb> boxes; boxes.reserve(instTris);
+    std::vector<uint> triInst, triPrim; triInst.reserve(instTris); triPrim.reserve(instTris);
+    for (size_t i = 0; i < ni; i++) {
+      const Geom& g = c->geoms[c->insts[i].geomId];
+      const float* m = c->insts[i].m;
+      const size_t nt = g.idx.size() / 3;
+      for (size_t t = 0; t < nt; t++) {
+        Aabb b; b.reset();
+        for (int k = 0; k < 3; k++) {
+          const float* p = &g.pos[3 * g.idx[3 * t + k]];
+          const float q[3] = { m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12], m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13], m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14] };
+          b.grow(q);
+        }
+        b.pad();                                            // covers the rounding of the world-space vertex positions too
+        boxes.push_back(b); triInst.push_back((uint)i); triPrim.push_back((uint)t);
+      }
+    }
+    const int depthCap = std::max(24, ceil_log2((instTris + BVH_LEAF_MAX - 1) / BVH_LEAF_MAX) + 2);
+    Bvh2 tree = Bvh2Builder::build(boxes, BVH_LEAF_MAX, depthCap, false);
+    std::vector<BvhTri> tris(std::max<size_t>(instTris, 1));
+    for (size_t k = 0; k < instTris; k++) {
+      const uint src = tree.order[k];
+      const uint i = triInst[src], p = triPrim[src];
+      const Geom& g = c->geoms[c->insts[i].geomId];
+      const float* A = &g.pos[3 * g.idx[3 * p + 0]]; const float* B = &g.pos[3 * g.idx[3 * p + 1]]; const float* C = &g.pos[3 * g.idx[3 * p + 2]];
+      BvhTri& t = tris[k];
+      for (int a = 0; a < 3; a++) { t.v0[a] = A[a]; t.e1[a] = B[a] - A[a]; t.e2[a] = C[a] - A[a]; }   // same object-space record as the two-level path
+      t.primId = p; t.instId = i; t.pad1 = 0;
+    }
+    std::vector<BvhNode> nodes(tree.nodes);
+    if (nodes.empty()) nodes.push_back(BvhNode());
+    if (tris.size() >= (size_t(1) << 28)) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: scene too large for 28-bit triangle references");
+    std::vector<BvhInst> dinst(std::max<size_t>(ni, 1));
+    for (size_t i = 0; i < ni; i++) {
+      inverse_rows(c->insts[i].m, dinst[i].row0, dinst[i].row1, dinst[i].row2);
+      dinst[i].root = REF_NONE; dinst[i].geomId = c->insts[i].geomId; dinst[i].pad0 = dinst[i].pad1 = 0;
+    }
+    HIPCHK(c, c->dNodes.upload(nodes.data(), nodes.size()));
+    HIPCHK(c, c->dTris.upload(tris.data(), tris.size()));
+    HIPCHK(c, c->dInsts.upload(dinst.data(), dinst.size()));
+    c->S.nodes = c->dNodes.p; c->S.tris = c->dTris.p; c->S.insts = c->dInsts.p;
+    c->S.rootRef = tree.rootRef; c->S.numInsts = (uint)ni; c->S.flatMode = 1;
+    c->stackNeeded = tree.depth + 1u;
+    if (c->stackNeeded > MAX_STACK) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: BVH deeper than the 64-entry traversal stack");
+    c->accelCommitted = true;
+    return HPT_OK;
   }
   // ---- top level over the instances' world boxes ----
   const size_t ni = c->insts.size();
@@ -291,7 +350,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   HIPCHK(c, c->dTris.upload(tris.data(), tris.size()));
   HIPCHK(c, c->dInsts.upload(dinst.data(), std::max<size_t>(dinst.size(), 1)));
   c->S.nodes = c->dNodes.p; c->S.tris = c->dTris.p; c->S.insts = c->dInsts.p;
-  c->S.rootRef = rootRef; c->S.numInsts = (uint)ni;
+  c->S.rootRef = rootRef; c->S.numInsts = (uint)ni; c->S.flatMode = 0;
   c->stackNeeded = tlas.depth + 1u + maxBlasDepth + 1u;
   if (c->stackNeeded > MAX_STACK) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: BVH deeper than the 64-entry traversal stack");
   c->accelCommitted = true;
@@ -318,7 +377,8 @@ static int ray_query(hpt_ctx* c, const float* posNear, const float* dirFar, uint
   HIPCHK(c, dout.alloc(outWords));
   const uint blocks = (n + 255) / 256;
   HIPCHK(c, ensureStackOverflow(c, (size_t)blocks * 256));
-  rayQueryKernel<<<dim3(blocks), dim3(256), 0, 0>>>(c->S, dp.p, dd.p, n, dout.p, any, c->dStackOvf.p);
+  if (c->S.flatMode) rayQueryKernel<true><<<dim3(blocks), dim3(256), 0, 0>>>(c->S, dp.p, dd.p, n, dout.p, any, c->dStackOvf.p);
+  else               rayQueryKernel<false><<<dim3(blocks), dim3(256), 0, 0>>>(c->S, dp.p, dd.p, n, dout.p, any, c->dStackOvf.p);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpy(out, dout.p, outWords * 4, hipMemcpyDeviceToHost));
   dp.release(); dd.release(); dout.release();
@@ -511,16 +571,22 @@ extern "C" int hpt_set_random_gens(hpt_ctx* c, const uint32_t* in, uint32_t coun
 static int gridBlocks(hpt_ctx* c, bool dr)
 {
   int bpc = c->blocksPerCU;
-  if (bpc <= 0) bpc = dr ? 2 : 4;
+  if (bpc <= 0) bpc = 4;                  // = __launch_bounds__(256, 4); measured for DR: 2 -> 185, 3 -> 206, 4 -> 259 Mpaths/s
   return c->numCUs * bpc;
 }
 
 // DEEP: the scene's BVH can need more than LDS_STACK stack entries, so pushes / pops check for the HBM overflow part
+// FLAT: single-level world-space BVH (static scenes within FLAT_TRI_BUDGET) vs two-level TLAS/BLAS
 template <bool STATS, bool DR, bool NAIVE>
 static void launchPT(const DevScene& S, const Job& job, int blocks, hipStream_t st, bool deep)
 {
-  if (deep) pathTraceKernel<STATS, DR, NAIVE, true><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
-  else      pathTraceKernel<STATS, DR, NAIVE, false><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
+  if (S.flatMode) {
+    if (deep) pathTraceKernel<STATS, DR, NAIVE, true, true><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
+    else      pathTraceKernel<STATS, DR, NAIVE, false, true><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
+  } else {
+    if (deep) pathTraceKernel<STATS, DR, NAIVE, true, false><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
+    else      pathTraceKernel<STATS, DR, NAIVE, false, false><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
+  }
 }
 
 static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStream_t st)
@@ -717,6 +783,12 @@ extern "C" int hpt_set_tid_interleave(hpt_ctx* c, uint32_t chunk, uint32_t strid
   return HPT_OK;
 }
 extern "C" int hpt_set_launch_config(hpt_ctx* c, int blocksPerCU) { if (!c || blocksPerCU < 0 || blocksPerCU > 8) return HPT_ERR_ARG; c->blocksPerCU = blocksPerCU; return HPT_OK; }
+extern "C" int hpt_set_accel_layout(hpt_ctx* c, int layout)
+{
+  if (!c || layout < 0 || layout > 2) return HPT_ERR_ARG;
+  c->accelLayout = layout; c->accelCommitted = false;
+  return HPT_OK;
+}
 extern "C" int hpt_last_kernel_ms(hpt_ctx* c, float* ms)
 {
   if (!c || !ms) return HPT_ERR_ARG;

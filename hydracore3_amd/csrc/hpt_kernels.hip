@@ -96,7 +96,7 @@ HPT_DEV void cameraRay(const DevScene& S, uint x, uint y, V4 pixelOffsets, V3& r
 #ifndef HPT_MIN_WAVES
 #define HPT_MIN_WAVES 4   // waves per SIMD the register allocator must fit (measured: 2 -> 725, 3 -> 913..1262, 4 -> 1005..1365 Mpaths/s on the Cornell box)
 #endif
-template <bool STATS, bool DR, bool NAIVE, bool DEEP>
+template <bool STATS, bool DR, bool NAIVE, bool DEEP, bool FLAT>
 __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevScene S, const Job job)
 {
   __shared__ uint stackMem[LDS_STACK * 256];
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
   V3   rpos = v3(0, 0, 0), rdir = v3(0, 0, 1);
   V3   accum = v3(0, 0, 0), thr = v3(1, 1, 1);
   float misPdf = 1.0f, misIor = 1.0f;
-  TravStats st; st.nodes = st.tris = st.insts = 0;
+  TravStats st; st.nodes = st.tris = st.insts = st.waveNodeIters = st.waveTriIters = 0;
   uint nRays = 0, nShadow = 0, nHits = 0, nPaths = 0;
   float lossLocal = 0.0f;
   const uint maxBounce = NAIVE ? S.traceDepth + 1u : S.traceDepth;
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
     // ---- (4) closest hit: kernel_RayTrace2 -> RayQuery_NearestHit ----------------------------------------------------------
     HitRec hit; hit.inst = 0xFFFFFFFFu; hit.prim = 0; hit.t = 0; hit.u = hit.v = 0;
     if (alive) {
-      traceRay<false, STATS, DEEP>(S, rpos, rdir, 0.0f, HPT_FLT_MAX, hit, stk, st);
+      traceAny<false, STATS, DEEP, FLAT>(S, rpos, rdir, 0.0f, HPT_FLT_MAX, hit, stk, st);
       if (STATS) nRays++;
     }
 
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
     // ---- (6) shadow rays: RayQuery_AnyHit ---------------------------------------------------------------------------------------
     if (wantShadow) {
       HitRec sh;
-      const bool occluded = traceRay<true, STATS, DEEP>(S, shPos, shDir, 0.0f, shFar, sh, stk, st);
+      const bool occluded = traceAny<true, STATS, DEEP, FLAT>(S, shPos, shDir, 0.0f, shFar, sh, stk, st);
       if (STATS) { nRays++; nShadow++; }
       if (!occluded) accum = accum + contrib; else if (DR) { recS = v3(0, 0, 0); recdS = v3(0, 0, 0); }
     } else if (DR) { recS = v3(0, 0, 0); recdS = v3(0, 0, 0); }
@@ -433,6 +433,9 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
   if (STATS) {
     // wave-reduce, one atomic per counter per wave
     unsigned long long v[8] = { nRays, st.nodes, st.tris, nHits, nShadow, nPaths, st.insts, 0ull };
+    { unsigned long long a = st.waveNodeIters, b = st.waveTriIters;
+      for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
+      if ((threadIdx.x & 63) == 0) { atomicAdd(&job.counters->v[14], a); atomicAdd(&job.counters->v[15], b); } }
     if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 5; i++) atomicAdd(&job.counters->v[8 + i], tPh[i]); atomicAdd(&job.counters->v[13], tTrips); }
     for (int i = 0; i < 8; i++) {
       unsigned long long x = v[i];
@@ -470,6 +473,7 @@ __global__ void initRandomGensKernel(Rng* gens, uint n)
 }
 
 // batched RayQuery_NearestHit / RayQuery_AnyHit for the ISceneObject entry points
+template <bool FLAT>
 __global__ void __launch_bounds__(256) rayQueryKernel(const DevScene S, const float4* posNear, const float4* dirFar, uint n, void* out, int anyHit, uint* stackOverflow)
 {
   __shared__ uint stackMem[LDS_STACK * 256];
@@ -477,12 +481,12 @@ __global__ void __launch_bounds__(256) rayQueryKernel(const DevScene S, const fl
   TravStack stk; stk.lds = &stackMem[threadIdx.x]; stk.ovf = stackOverflow + i; stk.ovfStride = gridDim.x * 256u;
   if (i >= n) return;
   const float4 p = posNear[i], d = dirFar[i];
-  HitRec h; TravStats st; st.nodes = st.tris = st.insts = 0;
+  HitRec h; TravStats st; st.nodes = st.tris = st.insts = st.waveNodeIters = st.waveTriIters = 0;
   if (anyHit) {
-    const bool occ = traceRay<true, false, true>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, st);
+    const bool occ = traceAny<true, false, true, FLAT>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, st);
     ((uint*)out)[i] = occ ? 1u : 0u;
   } else {
-    const bool found = traceRay<false, false, true>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, st);
+    const bool found = traceAny<false, false, true, FLAT>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, st);
     // CRT_Hit (CrossRT.h:23-30) as the Embree backend fills it (EmbreeRT.cpp:343-360)
     float4* o = (float4*)out + 2 * (size_t)i;
     if (found) {

@@ -50,7 +50,7 @@ struct BvhNode { float q[12]; uint ref0, ref1, pad0, pad1; };
 static_assert(sizeof(BvhNode) == 64, "BVH2 node must be one 64-byte line");
 
 // 48-byte triangle: v0, e1 = v1-v0, e2 = v2-v0 (what Moeller-Trumbore consumes), primId in the spare lane
-struct BvhTri { float v0[3]; uint primId; float e1[3]; uint pad0; float e2[3]; uint pad1; };
+struct BvhTri { float v0[3]; uint primId; float e1[3]; uint instId; float e2[3]; uint pad1; };   // instId: flat (single-level) mode only
 static_assert(sizeof(BvhTri) == 48, "triangle record must be 48 bytes");
 
 // 64-byte instance record: world->object rows (3x4), BLAS root reference, mesh id
@@ -73,6 +73,7 @@ struct DevScene
   const BvhInst* insts;
   uint           rootRef;
   uint           numInsts;
+  uint           flatMode;        // 1: one world-space BVH2 over all instanced triangles (leaf triangles carry their instance id)
 
   const uint*    triIndices;      // m_triIndices
   const float*   vData8f;         // m_vData8f (8 floats per vertex)

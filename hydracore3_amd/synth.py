@@ -233,3 +233,23 @@ def material_zoo(width=96, height=64) -> S.SceneData:
     L.append(S.light_rect(S.translate(3.5, 3.0, -3.0), 0.0, 0.0, (0.9, 0.4, 0.4), 15.0, disk_radius=0.6))
     L.append(S.light_point(S.translate(-3.5, 1.5, 2.0), (0.5, 1.0, 0.5), 6.0, "omni"))
     return sc
+
+
+def dr_scene(xml_path, width=512, height=512, tex_size=256, target=False) -> S.SceneData:
+    """SURVEY.md 8d 'S3 dr-228': scenes/test_228 (two 4096-triangle spheres in a box, point light) with matGray bound to a
+    tex_size^2 x 4 differentiable albedo texture (drmain.cpp:185's PutDiffTex2D(1, 256, 256, 4) shape; the scene as shipped has
+    no such texture, so the binding is added here). `target=True` fills the texture with the checker the optimisation should
+    recover; otherwise it is the 0.5 grey starting point. Returns (scene, texId)."""
+    sc = S.load_hydra_xml(xml_path, width, height)
+    tex = np.full((tex_size, tex_size, 4), 0.5, np.float32)
+    if target:
+        yy, xx = np.mgrid[0:tex_size, 0:tex_size]
+        chk = (((xx // (tex_size // 8)) + (yy // (tex_size // 8))) % 2).astype(np.float32)
+        tex[..., 0] = 0.2 + 0.6 * chk
+        tex[..., 1] = 0.8 - 0.5 * chk
+        tex[..., 2] = 0.3 + 0.3 * chk
+    tex[..., 3] = 1.0
+    tid = sc.add_texture(S.Texture(tex, S.TEX_RGBA32F, False, S.ADDR_WRAP, S.ADDR_WRAP, S.FILTER_LINEAR))
+    sc.materials[0]["texid"][0] = tid
+    sc.materials[0]["colors"][0] = (1.0, 1.0, 1.0, 0.0)      # albedo comes from the texture
+    return sc, tid

@@ -159,11 +159,16 @@ int  hpt_get_execution_time(hpt_ctx* ctx, const char* funcName, float out[4]);
 /* Counters of the last hpt_*_block call made with instrumentation enabled: [0..7] = {rays, nodesVisited, trisTested,
  * surfaceHits, shadowRays, paths, instancesEntered, texFetches} (feeds the algorithmic-bytes roofline);
  * [8..12] = wave-cycles (s_memtime) spent in {queue+regeneration, closest-hit traversal, shading, shadow traversal, path end},
- * [13] = bounce-loop trips summed over waves, [14..15] reserved. The instrumented kernel is a separate build: never timed. */
+ * [13] = bounce-loop trips summed over waves, [14] / [15] = wave-level iterations of the inner-node / triangle loops
+ * (lane utilisation of traversal = [1] / (64 * [14]), [2] / (64 * [15])). The instrumented kernel is a separate build: never timed. */
 int  hpt_set_instrumentation(hpt_ctx* ctx, int enabled);
 int  hpt_get_counters(hpt_ctx* ctx, uint64_t out[16]);
 /* Launch geometry of the persistent kernel: blocks per CU (0 = automatic). */
 int  hpt_set_launch_config(hpt_ctx* ctx, int blocksPerCU);
+/* Acceleration-structure layout chosen at the next hpt_commit_scene: 0 = automatic (one world-space BVH2 over all instanced triangles
+ * when the scene is static and small enough, else two-level), 1 = force the two-level TLAS/BLAS layout, 2 = force the single-level one.
+ * Both layouts intersect triangles in object space and return bit-identical hits. */
+int  hpt_set_accel_layout(hpt_ctx* ctx, int layout);
 /* Duration of the last path-tracing kernel, measured with HIP events on the stream it ran on (ms). */
 int  hpt_last_kernel_ms(hpt_ctx* ctx, float* ms);
 

@@ -219,3 +219,18 @@ def test_interleaved_chunks_compose(cornell):
         b.set_tid_interleave(chunk, stride)
         b.PathTraceBlock(count, 4, img, 3, tid_begin=begin)
     assert np.array_equal(img, full)
+
+
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228"])
+def test_both_accel_layouts_give_identical_hits_and_images(scene_name):
+    """Single-level (world-space boxes, object-space triangle tests) and two-level (TLAS/BLAS) layouts return the same CRT_Hit
+    bit for bit, hence the same image and the same RNG streams."""
+    from hydracore3_amd.api import HipIntegrator
+    sc = load_hydra_xml(scene_path(scene_name), 64, 64)
+    two, flat = HipIntegrator(sc, accel_layout=1), HipIntegrator(sc, accel_layout=2)
+    pos, dr = random_rays(8000, 11, -5.5, 8.5)
+    ha, hb = two.RayQuery_NearestHit(pos, dr), flat.RayQuery_NearestHit(pos, dr)
+    assert np.array_equal(ha.view(np.uint8), hb.view(np.uint8))
+    assert np.array_equal(two.RayQuery_AnyHit(pos, dr), flat.RayQuery_AnyHit(pos, dr))
+    assert np.array_equal(two.render(4), flat.render(4))
+    assert np.array_equal(two.random_gens(), flat.random_gens())

@@ -132,6 +132,10 @@ def main():
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--schedule", type=int, default=0, help="0 automatic, 1 persistent megakernel, 2 wavefront (shade + trace kernels)")
+    ap.add_argument("--refill-below", type=int, default=0, help="wavefront: refill a trace wave when fewer lanes than this hold a ray")
+    ap.add_argument("--trace-blocks-per-cu", type=int, default=0)
+    ap.add_argument("--sort-rays", type=int, default=0, help="wavefront: 1 off, 2 sort the ray queue by a coherence key")
     ap.add_argument("--verify", action="store_true", help="rank 0 re-renders the whole frame alone and checks the sharded frame is bit-identical")
     args = ap.parse_args()
 
@@ -175,6 +179,8 @@ def main():
     integ = HipIntegrator(sc, device=dev_index)
     if args.blocks_per_cu:
         integ.set_launch_config(args.blocks_per_cu)
+    if args.schedule or args.refill_below or args.trace_blocks_per_cu or args.sort_rays:
+        integ.set_schedule(args.schedule, args.refill_below, args.trace_blocks_per_cu, args.sort_rays)
     N = W * H
     from hydracore3_amd.sharding import tid_interleave
     t_begin, t_count, chunk, stride = tid_interleave(rank, world, N)   # rank r renders every world-th 1024-tid chunk (load balance)
@@ -238,6 +244,7 @@ def main():
     if rank == 0:
         # algorithmic bytes per path from the instrumented kernel on the same frame (fewer passes: the statistics are stationary)
         probe_spp = min(spp, 8)
+        integ.set_schedule(1)                                     # the instrumented build is the megakernel: same rays, same node / triangle visits
         integ.set_instrumentation(True)
         integ.InitRandomGens(N)
         integ.set_tid_interleave(0, 1)

@@ -57,6 +57,8 @@ ABI = {
     "hpt_get_counters": (_i, [_vp, C.POINTER(_u64)]),
     "hpt_set_launch_config": (_i, [_vp, _i]),
     "hpt_set_accel_layout": (_i, [_vp, _i]),
+    "hpt_set_schedule": (_i, [_vp, _i, _i, _i, _i]),
+    "hpt_get_schedule": (_i, [_vp, C.POINTER(_i), C.POINTER(_u32)]),
     "hpt_last_kernel_ms": (_i, [_vp, C.POINTER(_f)]),
 }
 
@@ -235,6 +237,15 @@ class HipIntegrator:
 
     def set_tid_interleave(self, chunk: int, stride: int):
         self._chk(self.L.hpt_set_tid_interleave(self.h, chunk, stride))
+
+    def set_schedule(self, schedule: int, refill_below: int = 0, trace_blocks_per_cu: int = 0, sort_rays: int = 0):
+        """0 automatic, 1 persistent megakernel, 2 wavefront (shade kernel + trace kernel with ray replacement)."""
+        self._chk(self.L.hpt_set_schedule(self.h, schedule, refill_below, trace_blocks_per_cu, sort_rays))
+
+    def last_schedule(self):
+        s, it = C.c_int(0), C.c_uint32(0)
+        self._chk(self.L.hpt_get_schedule(self.h, C.byref(s), C.byref(it)))
+        return s.value, it.value
 
     def set_launch_config(self, blocks_per_cu: int):
         self._chk(self.L.hpt_set_launch_config(self.h, blocks_per_cu))

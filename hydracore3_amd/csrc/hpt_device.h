@@ -836,7 +836,7 @@ HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, 
     // ---- (b) leaves --------------------------------------------------------------------------------------------------
     const uint cnt = (cur >> 28) & 7u;
     if (cnt >= 1u && cnt <= 4u) {
-      // triangles: Moeller-Trumbore on (v0, e1, e2), 3 x 16-byte loads each; exact (IEEE) arithmetic, see ray_tri in the oracle
+      // triangles: Moeller-Trumbore on (v0, e1, e2), 3 x 16-byte loads each; exact (IEEE) arithmetic
       const uint first = cur & 0x0FFFFFFFu;
       for (uint k = 0; k < cnt; k++) {
         const float4* tp = (const float4*)(S.tris + first + k);

@@ -10,6 +10,8 @@
 
 #include "../../include/hydra_hip.h"
 #include "hpt_kernels.hip"
+#include "hpt_wavefront.hip"
+#include <hipcub/hipcub.hpp>
 #include "bvh_build.h"
 
 static const uint MAX_STACK = 64;
@@ -71,6 +73,17 @@ struct hpt_ctx
   DevBuf<uint> dQueue, dStackOvf; DevBuf<Counters> dCounters;
   DevBuf<float> dFrame, dRecord, dRef, dData, dGrad, dLoss;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // wavefront schedule (hpt_wavefront.hip): path pool in HBM, ray queues, host-visible progress words
+  DevBuf<float4> wfF4[8]; DevBuf<uint> wfU[8]; DevBuf<unsigned char> wfSortTmp;
+  int  wfSort = 0;                       // 1: radix-sort the ray queue by a coherence key before every trace pass
+  float sceneMin[3] = {0, 0, 0}, sceneMax[3] = {1, 1, 1};
+  uint* wfProgress = nullptr;            // pinned: active-slot count after every WF_CHECK-th shade pass
+  hipEvent_t wfEv[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int  schedule = 0;                     // 0 automatic, 1 megakernel, 2 wavefront (hpt_set_schedule)
+  uint wfRefillBelow = 48;               // a trace wave refills from the queue when fewer lanes than this still hold a ray
+  int  wfBlocksPerCU = 0;
+  size_t instTris = 0;                   // instanced triangles of the committed scene
+  uint lastSchedule = 1, lastWfIters = 0;
 
   DevScene S;
   bool sceneUploaded = false, paramsSet = false;
@@ -123,6 +136,10 @@ extern "C" void hpt_destroy(hpt_ctx* c)
   c->dRemapLists.release(); c->dMaterials.release(); c->dLights.release(); c->dTextures.release(); c->dGens.release();
   c->dQueue.release(); c->dStackOvf.release(); c->dCounters.release(); c->dFrame.release(); c->dRecord.release(); c->dRef.release(); c->dData.release();
   c->dGrad.release(); c->dLoss.release();
+  for (auto& b : c->wfF4) b.release();
+  for (auto& b : c->wfU) b.release();
+  if (c->wfProgress) (void)hipHostFree(c->wfProgress);
+  for (auto& e : c->wfEv) if (e) (void)hipEventDestroy(e);
   for (void* p : c->texData) if (p) (void)hipFree(p);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -251,6 +268,20 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   // ---- single-level layout: one BVH2 over all instanced triangles, world-space boxes, object-space triangle records ----
   size_t instTris = 0;
   for (const Inst& in : c->insts) instTris += c->geoms[in.geomId].idx.size() / 3;
+  c->instTris = instTris;
+  {                                                         // world bounds (ray-sort keys of the wavefront schedule)
+    Aabb w; w.reset();
+    for (const Inst& in : c->insts) {
+      const Geom& g = c->geoms[in.geomId];
+      if (g.bvh.rootRef == REF_NONE) continue;
+      for (int k = 0; k < 8; k++) {
+        const float p[3] = { (k & 1) ? g.bvh.bounds.hi[0] : g.bvh.bounds.lo[0], (k & 2) ? g.bvh.bounds.hi[1] : g.bvh.bounds.lo[1], (k & 4) ? g.bvh.bounds.hi[2] : g.bvh.bounds.lo[2] };
+        const float q[3] = { in.m[0] * p[0] + in.m[4] * p[1] + in.m[8] * p[2] + in.m[12], in.m[1] * p[0] + in.m[5] * p[1] + in.m[9] * p[2] + in.m[13], in.m[2] * p[0] + in.m[6] * p[1] + in.m[10] * p[2] + in.m[14] };
+        w.grow(q);
+      }
+    }
+    for (int a = 0; a < 3; a++) { c->sceneMin[a] = w.lo[a] <= w.hi[a] ? w.lo[a] : 0.0f; c->sceneMax[a] = w.lo[a] <= w.hi[a] ? w.hi[a] : 1.0f; }
+  }
   // measured (profiles/phases.py): flat cuts node visits 12 % on the 1M-triangle scene but not time, and costs 8 % on the Cornell box
   // (looser world-space boxes around rotated instances, per-triangle ray transform): automatic = two-level for now
   const bool flat = (c->accelLayout == 2) && instTris <= FLAT_TRI_BUDGET;
@@ -575,6 +606,9 @@ static int gridBlocks(hpt_ctx* c, bool dr)
   return c->numCUs * bpc;
 }
 
+static bool useWavefront(hpt_ctx* c, bool naive, bool dr, bool stats);
+static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st);
+
 // DEEP: the scene's BVH can need more than LDS_STACK stack entries, so pushes / pops check for the HBM overflow part
 // FLAT: single-level world-space BVH (static scenes within FLAT_TRI_BUDGET) vs two-level TLAS/BLAS
 template <bool STATS, bool DR, bool NAIVE>
@@ -607,6 +641,8 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   job.gens = c->dGens.p; job.packedXY = c->dPackedXY.p;
   job.counters = nullptr;
   const bool stats = c->instrument && !dr;
+  c->lastSchedule = 1;
+  if (useWavefront(c, naive, dr, stats && c->schedule != 2)) { c->lastSchedule = 2; return launch_wavefront(c, job, st); }
   if (stats) { HIPCHK(c, c->dCounters.alloc(1)); HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(Counters), st)); job.counters = c->dCounters.p; }
   if (dr) {
     job.recordLanes = (uint)blocks * 256u;
@@ -622,6 +658,113 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   else if (stats)  launchPT<true, false, false>(c->S, job, blocks, st, deep);
   else             launchPT<false, false, false>(c->S, job, blocks, st, deep);
   HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev1, st));
+  return HPT_OK;
+}
+
+
+// ---- wavefront schedule ---------------------------------------------------------------------------------------------------------------
+// Scenes at or above this many instanced triangles are rendered by the shade / trace kernel pair; below it the path state's trip
+// through HBM costs more than the ray replacement gains (measured crossover: see DESIGN.md, "two schedules").
+static const size_t WF_AUTO_TRIS = size_t(1) << 17;
+static const uint   WF_POOL_MAX = 1u << 22;        // pool slots (pixels in flight) per batch: 4M x 148 B = 620 MB
+static const uint   WF_CHECK = 8;                  // progress word copied back every WF_CHECK shade passes
+static const uint   WF_RING = 8;                   // ... and at most WF_RING such checkpoints in flight
+
+static bool useWavefront(hpt_ctx* c, bool naive, bool dr, bool stats)
+{
+  if (naive || dr || stats) return false;          // those variants exist as megakernels only
+  if (c->schedule == 1) return false;
+  if (c->schedule == 2) return true;
+  return c->instTris >= WF_AUTO_TRIS;
+}
+
+template <bool STATS>
+static void launchWfTrace(hpt_ctx* c, const WfPool& P, uint iter, int blocks, hipStream_t st, bool deep)
+{
+  uint* ovf = c->dStackOvf.p; const uint lanes = (uint)blocks * 256u; Counters* cn = c->dCounters.p;
+  if (c->S.flatMode) {
+    if (deep) wfTraceKernel<true, true, STATS><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, ovf, lanes, cn);
+    else      wfTraceKernel<false, true, STATS><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, ovf, lanes, cn);
+  } else {
+    if (deep) wfTraceKernel<true, false, STATS><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, ovf, lanes, cn);
+    else      wfTraceKernel<false, false, STATS><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, ovf, lanes, cn);
+  }
+}
+
+static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st)
+{
+  const uint pool = std::min(job.tidCount, WF_POOL_MAX);
+  for (int i = 0; i < 8; i++) HIPCHK(c, c->wfF4[i].alloc(pool));
+  for (int i = 0; i < 3; i++) HIPCHK(c, c->wfU[i].alloc(pool));
+  for (int i = 3; i < 7; i++) HIPCHK(c, c->wfU[i].alloc(2 * (size_t)pool));     // ray queue + keys, and their sorted copies
+  HIPCHK(c, c->wfU[7].alloc(2 * WF_CTR_WORDS));
+  if (!c->wfProgress) HIPCHK(c, hipHostMalloc((void**)&c->wfProgress, WF_RING * sizeof(uint)));
+  for (auto& e : c->wfEv) if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  WfPool P;
+  P.rayO = c->wfF4[0].p; P.rayD = c->wfF4[1].p; P.thr = c->wfF4[2].p; P.acc = c->wfF4[3].p;
+  P.shO = c->wfF4[4].p; P.shD = c->wfF4[5].p; P.contrib = c->wfF4[6].p; P.hit = c->wfF4[7].p;
+  P.hitInst = c->wfU[0].p; P.occl = c->wfU[1].p; P.status = c->wfU[2].p; P.rayQ = c->wfU[3].p; P.rayKey = c->wfU[4].p; P.ctr = c->wfU[7].p;
+  WfPool Psorted = P; Psorted.rayQ = c->wfU[5].p; Psorted.rayKey = c->wfU[6].p;
+  size_t sortBytes = 0;
+  const bool sortRays = c->wfSort != 0;
+  if (sortRays) {
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sortBytes, P.rayKey, Psorted.rayKey, P.rayQ, Psorted.rayQ, 2 * (size_t)pool, 9, 31, st);
+    HIPCHK(c, c->wfSortTmp.alloc(sortBytes));
+  }
+
+  int bpc = c->wfBlocksPerCU > 0 ? c->wfBlocksPerCU : HPT_WF_WAVES;
+  const int traceBlocks = c->numCUs * bpc;
+  HIPCHK(c, ensureStackOverflow(c, (size_t)traceBlocks * 256));
+  const bool deep = c->stackNeeded > (uint)LDS_STACK;
+  const bool stats = c->instrument;
+  if (stats) { HIPCHK(c, c->dCounters.alloc(1)); HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(Counters), st)); }
+
+  WfJob wj;
+  wj.tidBegin = job.tidBegin; wj.tidChunk = job.tidChunk; wj.tidStride = job.tidStride; wj.tidEnd = job.tidEnd;
+  wj.sortRays = sortRays ? 1u : 0u;
+  for (int a = 0; a < 3; a++) { wj.bbMin[a] = c->sceneMin[a]; const float e = c->sceneMax[a] - c->sceneMin[a]; wj.bbScale[a] = e > 0.0f ? 128.0f / e : 0.0f; }
+  wj.passNum = job.passNum; wj.channels = job.channels; wj.outColor = job.outColor; wj.gens = job.gens; wj.packedXY = job.packedXY;
+  // every path takes at most traceDepth shade passes after the one that generated it; the pass that ends it (or the next one, when a
+  // shadow ray was outstanding) also generates the pixel's next path
+  const unsigned long long iterCap = (unsigned long long)job.passNum * (c->S.traceDepth + 2ull) + 4ull;
+  c->lastWfIters = 0;
+  HIPCHK(c, hipEventRecord(c->ev0, st));
+  for (uint base = 0; base < job.tidCount; base += pool) {
+    wj.itemBase = base; wj.itemCount = std::min(pool, job.tidCount - base);
+    const uint shadeBlocks = (wj.itemCount + 255u) / 256u;
+    HIPCHK(c, hipMemsetAsync(P.ctr, 0, 2 * WF_CTR_WORDS * sizeof(uint), st));
+    wfInitKernel<<<dim3(shadeBlocks), dim3(256), 0, st>>>(P, wj.itemCount, job.passNum);
+    uint checkpoints = 0; bool finished = false;
+    for (unsigned long long it = 0; it < iterCap && !finished; it++) {
+      wj.iter = (uint)it;
+      if (sortRays) HIPCHK(c, hipMemsetAsync(P.rayKey, 0xFF, 2 * (size_t)wj.itemCount * sizeof(uint), st));
+      wfShadeKernel<<<dim3(shadeBlocks), dim3(256), 0, st>>>(c->S, P, wj);
+      if ((it % WF_CHECK) == WF_CHECK - 1) {
+        const uint slot = checkpoints % WF_RING;
+        if (checkpoints >= WF_RING) {                                       // oldest checkpoint of the ring: wait for it, then look at it
+          HIPCHK(c, hipEventSynchronize(c->wfEv[slot]));
+          if (c->wfProgress[slot] == 0u) { finished = true; break; }
+        }
+        HIPCHK(c, hipMemcpyAsync(&c->wfProgress[slot], P.ctr + WF_CTR_WORDS * (wj.iter & 1u), sizeof(uint), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipEventRecord(c->wfEv[slot], st));
+        checkpoints++;
+        // newer checkpoints that have already landed
+        for (uint k = 1; k < WF_RING && k < checkpoints; k++) {
+          const uint sl = (checkpoints - 1 - k) % WF_RING;
+          if (hipEventQuery(c->wfEv[sl]) == hipSuccess && c->wfProgress[sl] == 0u) { finished = true; break; }
+        }
+        if (finished) break;
+      }
+      if (sortRays) {                                                       // unused entries carry key 0xFFFFFFFF and sort to the end
+        HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->wfSortTmp.p, sortBytes, P.rayKey, Psorted.rayKey, P.rayQ, Psorted.rayQ, 2 * (size_t)wj.itemCount, 9, 31, st));
+      }
+      const WfPool& T = sortRays ? Psorted : P;
+      if (stats) launchWfTrace<true>(c, T, wj.iter, traceBlocks, st, deep); else launchWfTrace<false>(c, T, wj.iter, traceBlocks, st, deep);
+      c->lastWfIters++;
+    }
+    HIPCHK(c, hipGetLastError());
+  }
   HIPCHK(c, hipEventRecord(c->ev1, st));
   return HPT_OK;
 }
@@ -783,6 +926,22 @@ extern "C" int hpt_set_tid_interleave(hpt_ctx* c, uint32_t chunk, uint32_t strid
   return HPT_OK;
 }
 extern "C" int hpt_set_launch_config(hpt_ctx* c, int blocksPerCU) { if (!c || blocksPerCU < 0 || blocksPerCU > 8) return HPT_ERR_ARG; c->blocksPerCU = blocksPerCU; return HPT_OK; }
+extern "C" int hpt_set_schedule(hpt_ctx* c, int schedule, int refillBelow, int traceBlocksPerCU, int sortRays)
+{
+  if (!c || schedule < 0 || schedule > 2 || refillBelow < 0 || refillBelow > 64 || traceBlocksPerCU < 0 || traceBlocksPerCU > 8 || sortRays < 0 || sortRays > 2) return HPT_ERR_ARG;
+  if (sortRays) c->wfSort = sortRays - 1;
+  c->schedule = schedule;
+  if (refillBelow > 0) c->wfRefillBelow = (uint)refillBelow;
+  c->wfBlocksPerCU = traceBlocksPerCU;
+  return HPT_OK;
+}
+extern "C" int hpt_get_schedule(hpt_ctx* c, int* lastSchedule, uint32_t* lastIterations)
+{
+  if (!c) return HPT_ERR_ARG;
+  if (lastSchedule) *lastSchedule = (int)c->lastSchedule;
+  if (lastIterations) *lastIterations = c->lastWfIters;
+  return HPT_OK;
+}
 extern "C" int hpt_set_accel_layout(hpt_ctx* c, int layout)
 {
   if (!c || layout < 0 || layout > 2) return HPT_ERR_ARG;

@@ -16,7 +16,7 @@
 // Exit condition every wave reaches: the queue counter only grows, a lane that draws an index past the end never asks
 // again, and a wave leaves the loop when none of its lanes holds a live path or a pixel.
 #include <hip/hip_runtime.h>
-#include "hpt_device.h"
+#include "hpt_shade.h"
 
 namespace hpt {
 
@@ -42,56 +42,6 @@ struct Job
   uint   gridLanes;
 };
 
-static const int REC_FIELDS = 24;   // A(3) S(3) T*dA(3) T*dS(3) texId tapOffsets(4) tapWeights(4) pad(3)
-
-HPT_DEV uint lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-HPT_DEV uint mbcnt64(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint)m, 0u)); }
-
-// differentiable texture fetch: Tex2DFetchAD (diff_render/integrator_dr.cpp:95-161); returns texColor and tap data
-HPT_DEV V4 texFetchAD(const DevScene& S, const float* data, uint texId, V2 uv, Taps& taps, bool& isParam)
-{
-  const TexRec t = S.textures[texId];
-  isParam = false;
-  if (t.diffOffset != ~0ull && data != nullptr) {
-    taps = bilinearTaps(t.diffW, t.diffH, t.addrU, t.addrV, uv);
-    isParam = true;
-    const float* d = data + t.diffOffset;
-    if (t.diffChannels == 4) {
-      const float4 a = ((const float4*)d)[taps.off[0]], b = ((const float4*)d)[taps.off[1]], c = ((const float4*)d)[taps.off[2]], e = ((const float4*)d)[taps.off[3]];
-      return v4(a.x * taps.w[0] + b.x * taps.w[1] + c.x * taps.w[2] + e.x * taps.w[3],
-                a.y * taps.w[0] + b.y * taps.w[1] + c.y * taps.w[2] + e.y * taps.w[3],
-                a.z * taps.w[0] + b.z * taps.w[1] + c.z * taps.w[2] + e.z * taps.w[3],
-                a.w * taps.w[0] + b.w * taps.w[1] + c.w * taps.w[2] + e.w * taps.w[3]);
-    }
-    const float o = d[taps.off[0]] * taps.w[0] + d[taps.off[1]] * taps.w[1] + d[taps.off[2]] * taps.w[2] + d[taps.off[3]] * taps.w[3];
-    return v4(o, o, o, o);
-  }
-  return texSample(S.textures, texId, uv);
-}
-
-// SampleCameraRay + kernel_InitEyeRay2 (integrator_pt.cpp:44-157), RGB / static-scene subset
-HPT_DEV void cameraRay(const DevScene& S, uint x, uint y, V4 pixelOffsets, V3& rayPos, V3& rayDir)
-{
-  const float fx = float(x) + pixelOffsets.x, fy = float(y) + pixelOffsets.y;
-  const float xn = (fx + float(S.winStartX)) / float(S.fbWidth);
-  const float yn = (fy + float(S.winStartY)) / float(S.fbHeight);
-  V4 pos = v4(2.0f * xn - 1.0f, 2.0f * yn - 1.0f, 0.0f, 1.0f);          // EyeRayDirNormalized (cglobals.h:49-55)
-  pos = mul4x4(S.projInv, pos);
-  V3 dir = normalize(v3(pos.x / pos.w, pos.y / pos.w, pos.z / pos.w));
-  V3 org = v3(0, 0, 0);
-  if (S.camLensRadius > 0.0f) {
-    const float tFocus = S.camTargetDist / (-dir.z);
-    const V3 focusPosition = org + dir * tFocus;
-    const V2 d2 = mapSamplesToDisc(v2(pixelOffsets.z - 0.5f, pixelOffsets.w - 0.5f));
-    const float k = S.camLensRadius * 2.0f;
-    org.x += k * d2.x; org.y += k * d2.y;
-    dir = normalize(focusPosition - org);
-  }
-  const V3 p1 = mul4x3(S.worldViewInv, org);                             // transform_ray3f (cglobals.h:254-263)
-  const V3 p2 = mul4x3(S.worldViewInv, org + 100.0f * dir);
-  rayPos = p1;
-  rayDir = normalize(p2 - p1);
-}
 
 #ifndef HPT_MIN_WAVES
 #define HPT_MIN_WAVES 4   // waves per SIMD the register allocator must fit (measured: 2 -> 725, 3 -> 913..1262, 4 -> 1005..1365 Mpaths/s on the Cornell box)
@@ -194,155 +144,9 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
     for (int k = 0; k < 4; k++) { recTaps.off[k] = 0; recTaps.w[k] = 0.0f; }
 
     if (alive) {
-      if (hit.inst == 0xFFFFFFFFu) {
-        flags |= (bounce == 0) ? (RAY_FLAG_PRIME_RAY_MISS | RAY_FLAG_IS_DEAD | RAY_FLAG_OUT_OF_SCENE) : (RAY_FLAG_IS_DEAD | RAY_FLAG_OUT_OF_SCENE);
-      } else {
-        if (STATS) nHits++;
-        // -- surface attributes (integrator_pt.cpp:238-311) --
-        const uint instId = hit.inst;
-        const uint geomId = S.insts[instId].geomId;
-        const uint triOffset = S.matVertOffset[2 * geomId + 0], vertOffset = S.matVertOffset[2 * geomId + 1];
-        const V3 hitPos = rpos + hit.t * (1.f - 1e-6f) * rdir;
-        const float uvx = hit.v, uvy = hit.u;                              // coords[0] = v, coords[1] = u (EmbreeRT.cpp:350-352)
-        const uint A = S.triIndices[(triOffset + hit.prim) * 3 + 0];
-        const uint B = S.triIndices[(triOffset + hit.prim) * 3 + 1];
-        const uint C = S.triIndices[(triOffset + hit.prim) * 3 + 2];
-        const float4 nA = ((const float4*)S.vData8f)[2 * (A + vertOffset)], nB = ((const float4*)S.vData8f)[2 * (B + vertOffset)], nC = ((const float4*)S.vData8f)[2 * (C + vertOffset)];
-        const float tyA = S.vData8f[8 * (A + vertOffset) + 7], tyB = S.vData8f[8 * (B + vertOffset) + 7], tyC = S.vData8f[8 * (C + vertOffset) + 7];
-        const float wA = 1.0f - uvx - uvy;
-        const V3 nrmO = v3(wA * nA.x + uvy * nB.x + uvx * nC.x, wA * nA.y + uvy * nB.y + uvx * nC.y, wA * nA.z + uvy * nB.z + uvx * nC.z);
-        const V2 uv = v2(wA * nA.w + uvy * nB.w + uvx * nC.w, wA * tyA + uvy * tyB + uvx * tyC);
-        const float* nm = S.normMat + 12 * instId;
-        V3 hitNorm = v3(nm[0] * nrmO.x + nm[1] * nrmO.y + nm[2] * nrmO.z,
-                        nm[4] * nrmO.x + nm[5] * nrmO.y + nm[6] * nrmO.z,
-                        nm[8] * nrmO.x + nm[9] * nrmO.y + nm[10] * nrmO.z);
-        hitNorm = normalize(hitNorm);
-        const float flipNorm = dot(rdir, hitNorm) > 0.001f ? -1.0f : 1.0f;
-        hitNorm = flipNorm * hitNorm;
-        if (flipNorm < 0.0f) flags |= RAY_FLAG_HAS_INV_NORMAL; else flags &= ~RAY_FLAG_HAS_INV_NORMAL;
-        const uint matId = remapMaterialId(S, S.matIdByPrimId[triOffset + hit.prim], instId) & 0x00FFFFFFu;
-        const MaterialRec& m = S.materials[matId];
-        const uint mtype = m.mtype;
-        const V3 vdir = (-1.0f) * rdir;
-
-        // -- kernel_SampleLightSource (integrator_pt.cpp:350-424): the randoms are drawn for every surface hit --
-        V3 shade = v3(0, 0, 0), dshade = v3(0, 0, 0);
-        V4 texColor = v4(1, 1, 1, 1); V3 four = v3(1, 1, 1);
-        bool isParam = false;
-        if (mtype != MAT_TYPE_LIGHT_SOURCE) {
-          const V2 tcT = mulRows2x4(m.row0[0], m.row1[0], uv);
-          if (DR) { texColor = texFetchAD(S, job.data, m.texid[0], tcT, recTaps, isParam); if (isParam) recTex = m.texid[0]; }
-          else    texColor = texSample(S.textures, m.texid[0], tcT);
-          if ((m.cflags & FLAG_FOUR_TEXTURES) != 0) {                      // integrator_pt_mat.cpp:151-167
-            const V4 c2 = texSample(S.textures, m.texid[2], mulRows2x4(m.row0[2], m.row1[2], uv));
-            const V4 c3 = texSample(S.textures, m.texid[3], mulRows2x4(m.row0[3], m.row1[3], uv));
-            four = ((m.cflags & FLAG_PACK_FOUR_PARAMS_IN_TEXTURE) != 0) ? v3(c2.x, c2.y, c2.z) : v3(c2.x, c3.x, 1.0f);
-          }
-        }
-        const V3 tex3 = v3(texColor.x, texColor.y, texColor.z);
-        const V3 baseCol = ld3(m.colors[GLTF_COLOR_BASE]);
-
-        if (!NAIVE) {
-          const float rndId = rng_float1(gen);                             // GetRandomNumbersLgts: two generator steps, in this order
-          const V4 r4 = rng_float4(gen);
-          const int nLights = (int)S.numLights;
-          const int lightId = min((int)floorf(rndId * float(nLights)), nLights - 1);
-          if (lightId >= 0 && mtype != MAT_TYPE_LIGHT_SOURCE) {
-            const LightRec& L = S.lights[lightId];
-            const LightSam ls = lightSampleRev(L, v3(r4.x, r4.y, r4.z), hitPos);
-            const V3 dlt = hitPos - ls.pos;
-            const float hitDist = sqrtf_(dot(dlt, dlt));
-            const V3 shadowRayDir = normalize(ls.pos - hitPos);
-            const V3 shadowRayPos = hitPos + hitNorm * smax(maxcomp(hitPos), 1.0f) * 5e-6f;
-            const bool inIllumArea = (dot(shadowRayDir, ls.norm) < 0.0f) || ls.isOmni || ls.hasIES;
-            if (inIllumArea) {
-              // MaterialEval (integrator_pt_mat.cpp:308-528), evaluated before the shadow ray so that nothing but the
-              // candidate contribution has to stay live across the any-hit traversal
-              BsdfE bv; bv.val = v3(0, 0, 0); bv.pdf = 0.0f; bv.dval = v3(0, 0, 0);
-              if (mtype == MAT_TYPE_GLTF) gltfEval(m, shadowRayDir, vdir, hitNorm, baseCol * tex3, four, bv);
-              else if (!DR && mtype == MAT_TYPE_CONDUCTOR) {
-                if (!(smax(m.data[1], m.data[0]) < 1e-3f)) conductorRoughEval(m, m.data[2], m.data[3], shadowRayDir, vdir, hitNorm, tex3, bv);
-              }
-              else if (!DR && mtype == MAT_TYPE_DIFFUSE) diffuseEval(m, ld3(m.colors[0]) * tex3, shadowRayDir, vdir, hitNorm, bv);
-              const float cosThetaOut = smax(dot(shadowRayDir, hitNorm), 0.0f);
-              float lgtPdfW = (1.0f / float(nLights)) * lightEvalPDF(L, shadowRayPos, shadowRayDir, ls.pos, ls.norm, ls.pdf);
-              float misWeight = (S.integratorType == INTEGRATOR_MIS_PT) ? misWeightHeuristic(lgtPdfW, bv.pdf) : 1.0f;
-              if (L.geomType == LIGHT_GEOM_DIRECT) { misWeight = 1.0f; lgtPdfW = 1.0f; }
-              else if (L.geomType == LIGHT_GEOM_POINT) misWeight = 1.0f;
-              const bool isDirectLight = (flags & RAY_FLAG_HAS_NON_SPEC) == 0;
-              if ((S.renderLayer == FB_DIRECT && !isDirectLight) || (S.renderLayer == FB_INDIRECT && isDirectLight)) misWeight = 0.0f;
-              const V3 lightColor = lightIntensity(S, L, shadowRayPos, shadowRayDir);
-              shade = ((lightColor * bv.val) / lgtPdfW) * cosThetaOut * misWeight;
-              if (DR) dshade = ((lightColor * bv.dval) / lgtPdfW) * cosThetaOut * misWeight;
-              wantShadow = true;
-              shPos = shadowRayPos; shDir = shadowRayDir; shFar = hitDist * 0.9995f;
-            }
-          }
-        }
-
-        // -- kernel_NextBounce (integrator_pt.cpp:426-548) --
-        if (mtype == MAT_TYPE_LIGHT_SOURCE) {
-          const V4 tc = texSample(S.textures, m.texid[0], mulRows2x4(m.row0[0], m.row1[0], uv));
-          const uint lightId = (uint)S.remapInst[2 * instId + 1];
-          V3 lightInt = ld3(m.colors[0]) * v3(tc.x, tc.y, tc.z);
-          float misWeight = 1.0f;
-          if (lightId != 0xFFFFFFFFu) {
-            const LightRec& L = S.lights[lightId];
-            const float lightCos = dot(rdir, ld3(L.norm));
-            const float atten = (lightCos < 0.0f || L.geomType == LIGHT_GEOM_SPHERE) ? 1.0f : 0.0f;
-            lightInt = lightIntensity(S, L, rpos, rdir) * atten;
-          }
-          if (S.integratorType == INTEGRATOR_MIS_PT) {
-            if (bounce > 0 && lightId != 0xFFFFFFFFu) {
-              const float lgtPdf = (1.0f / float(S.numLights)) * lightEvalPDF(S.lights[lightId], rpos, rdir, hitPos, hitNorm, 1.0f);
-              misWeight = misWeightHeuristic(misPdf, lgtPdf);
-              if (misPdf <= 0.0f) misWeight = 1.0f;
-            }
-          } else if (S.integratorType == INTEGRATOR_SHADOW_PT && (flags & RAY_FLAG_HAS_NON_SPEC) != 0) misWeight = 0.0f;
-          const bool isDirectLight = (flags & RAY_FLAG_HAS_NON_SPEC) == 0;
-          const bool isFirstNonSpec = (flags & RAY_FLAG_FIRST_NON_SPEC) != 0;
-          if (S.renderLayer == FB_INDIRECT && (isDirectLight || isFirstNonSpec)) misWeight = 0.0f;
-          accum = accum + thr * lightInt * misWeight;
-          if (DR) tailR = lightInt * misWeight;
-          flags |= (RAY_FLAG_IS_DEAD | RAY_FLAG_HIT_LIGHT);
-        } else {
-          BsdfS ms; ms.val = v3(0, 0, 0); ms.pdf = 1.0f; ms.dir = v3(0, 1, 0); ms.ior = 1.0f; ms.flags = flags; ms.dval = v3(0, 0, 0);
-          const V4 rands = rng_float4(gen);                                // GetRandomNumbersMats: drawn for every material type (integrator_pt_mat.cpp:147)
-          if (mtype == MAT_TYPE_GLTF) gltfSampleAndEval(m, rands, vdir, hitNorm, baseCol * tex3, four, ms);
-          else if (!DR && mtype == MAT_TYPE_CONDUCTOR) {
-            if (smax(m.data[1], m.data[0]) < 1e-3f) conductorSmoothSampleAndEval(m, m.data[2], m.data[3], vdir, hitNorm, ms);
-            else                                    conductorRoughSampleAndEval(m, m.data[2], m.data[3], rands, vdir, hitNorm, tex3, ms);
-          }
-          else if (!DR && mtype == MAT_TYPE_DIFFUSE) diffuseSampleAndEval(m, ld3(m.colors[0]) * tex3, rands, vdir, hitNorm, ms);
-          else if (!DR && mtype == MAT_TYPE_DIELECTRIC) {
-            dielectricSmoothSampleAndEval(m, m.data[1], misIor, rands, vdir, hitNorm, ms);
-            ms.flags |= (m.spdid[0] < 0xFFFFFFFFu) ? RAY_FLAG_WAVES_DIVERGED : 0u;
-            misIor = ms.ior;
-          }
-          const float invPdf = 1.0f / smax(ms.pdf, 1e-20f);
-          const V3 bxdfVal = ms.val * invPdf;
-          const float cosTheta = absf(dot(ms.dir, hitNorm));
-          misPdf = (ms.flags & RAY_EVENT_S) != 0 ? -1.0f : ms.pdf;
-          if (S.integratorType == INTEGRATOR_STUPID_PT) thr = thr * (cosTheta * bxdfVal);
-          else {
-            contrib = thr * shade;
-            thr = thr * cosTheta * bxdfVal;
-          }
-          if (DR) {
-            recS = shade; recdS = dshade * baseCol;                          // d shade / d texColor
-            recA = cosTheta * bxdfVal; recdA = (cosTheta * invPdf) * (ms.dval * baseCol);
-          }
-          V3 hp = hitPos;
-          if ((ms.flags & RAY_EVENT_T) != 0) hp = hp + hit.t * rdir * 2.0f * 1e-6f;
-          rpos = offsRayPos(hp, hitNorm, ms.dir);
-          rdir = ms.dir;
-          uint nextFlags = ((flags & ~RAY_FLAG_FIRST_NON_SPEC) | ms.flags);
-          if (S.renderLayer == FB_DIRECT && (flags & RAY_FLAG_HAS_NON_SPEC) != 0) nextFlags |= RAY_FLAG_IS_DEAD;
-          else if ((flags & RAY_FLAG_HAS_NON_SPEC) == 0 && (nextFlags & RAY_FLAG_HAS_NON_SPEC) != 0) nextFlags |= RAY_FLAG_FIRST_NON_SPEC;
-          flags = nextFlags;
-          didBounce = true;
-        }
-      }
+      if (STATS && hit.inst != 0xFFFFFFFFu) nHits++;
+      didBounce = shadeVertex<DR, NAIVE>(S, job.data, hit, rpos, rdir, accum, thr, misPdf, misIor, flags, bounce, gen,
+                                         wantShadow, shPos, shDir, shFar, contrib, recA, recS, recdA, recdS, recTaps, recTex, tailR);
     }
 
     STAMP(2);

@@ -1,0 +1,395 @@
+// Wavefront schedule of the same path tracer, for scenes whose rays are expensive (deep BVHs, 10^5..10^7 triangles).
+//
+// Why a second schedule.  In the persistent megakernel (hpt_kernels.hip) a lane keeps its ray until the slowest lane of the wave
+// has finished its own: measured on the 1M-triangle scene the node loop runs 237 wave iterations per ray while the mean lane needs
+// 43 (profiles/r1_phases.txt: 18 % lane utilisation, 92 % of the wave cycles inside the two traversals).  Here the two halves of a
+// bounce are separate kernels that meet in HBM:
+//
+//   wfShadeKernel   one lane per pool slot (= one pixel of the launch, which owns its RNG stream for all passes exactly as in the
+//                   megakernel): folds the previous shadow-ray result into the path, shades the closest hit (hpt_shade.h: the
+//                   SAME function the megakernel inlines), ends / regenerates paths, and appends the slot to the ray queues
+//                   with one wave ballot + mbcnt prefix sum + ONE atomicAdd per wave and queue (ray compaction);
+//   wfTraceKernel   persistent waves pull rays from the compacted queue.  Traversal state is resumable: whenever fewer than
+//                   `refillBelow` lanes of a wave still hold a ray, the wave leaves the loop, refills the idle lanes from the
+//                   queue (again one atomic per wave) and continues, so the node and triangle loops run with (almost) full
+//                   waves whatever the spread of per-ray work.  ~64 VGPRs instead of 128: twice the waves per SIMD to hide
+//                   the node-fetch latency.
+//
+// Price: path state (148 bytes per slot) and rays travel through HBM/MALL once per bounce - negligible against a 40-node
+// traversal, dominant against a 7-node one, which is why the Cornell-box class of scenes stays on the megakernel
+// (hpt_host.hip: chooseSchedule).  The arithmetic per path is identical in both schedules (same functions, same order, IEEE
+// flags), so the two produce bit-identical frames; tests/test_gpu_parity.py holds them to that.
+#include <hip/hip_runtime.h>
+#include "hpt_shade.h"
+
+namespace hpt {
+
+static const uint WF_RANGES = 64u;                   // the trace kernel pulls rays from this many ranges of the queue (work stealing)
+static const uint WF_CTR_WORDS = 32u * (1u + WF_RANGES);
+static const uint WF_ALIVE = 1u, WF_PEND = 2u, WF_ENDING = 4u;   // status bits; passes left in bits 8..31
+
+struct WfPool
+{
+  float4* rayO;      // rpos.xyz, misPdf
+  float4* rayD;      // rdir.xyz, misIor
+  float4* thr;       // throughput.xyz, flags
+  float4* acc;       // accumulated radiance.xyz, bounce
+  float4* shO;       // shadow ray origin.xyz, far
+  float4* shD;       // shadow ray direction.xyz
+  float4* contrib;   // thr * shade of the pending light sample
+  float4* hit;       // t, u, v, primId
+  uint*   hitInst;   // instId or 0xFFFFFFFF
+  uint*   occl;      // shadow ray result
+  uint*   status;
+  uint*   rayQ;      // compacted ray queue: slot id | (shadow ray ? 1 << 31 : 0)
+  uint*   rayKey;    // sort key of each queue entry (only when ray sorting is on; unused entries hold 0xFFFFFFFF)
+  uint*   ctr;       // two sets of WF_CTR_WORDS (set iteration & 1 is live): [0] rays queued by the shade pass;
+                     // [32 * (1 + r)] head of queue range r for the trace pass (one 128-byte line each: the atomics of different
+                     // ranges go to different L2 channels instead of serialising on one address)
+};
+
+struct WfJob
+{
+  uint   itemBase, itemCount;     // pool slot s renders work item itemBase + s (item -> tid as in Job)
+  uint   tidBegin, tidChunk, tidStride, tidEnd;
+  uint   passNum, channels, iter;
+  float* outColor;
+  Rng*   gens;
+  const uint* packedXY;
+  uint   sortRays;                // 1: also write a coherence key per queued ray (the host radix-sorts the queue before the trace kernel)
+  float  bbMin[3], bbScale[3];    // scene bounds -> [0, 1024) grid for the Morton part of the key
+};
+
+__global__ void wfInitKernel(WfPool P, uint n, uint passNum)
+{
+  const uint i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) P.status[i] = passNum << 8;       // (the counters are zeroed by the host: the grid may be smaller than the counter block)
+}
+
+// Coherence key of a ray: [shadow ray][Morton code of the origin cell, 7 bits per axis][direction octant 3 bits][6 more direction bits].
+// Rays that start in the same ~1/128 cell of the scene and leave in the same direction walk the same BVH nodes: sorting the queue by
+// this key turns the per-lane node fetches of a wave into hits on the lines its neighbours just pulled in.
+HPT_DEV uint spread7(uint v) { v &= 0x7Fu; v = (v | (v << 8)) & 0x0000700Fu; v = (v | (v << 4)) & 0x000430C3u; v = (v | (v << 2)) & 0x00049249u; return v; }
+HPT_DEV uint rayKey(const WfJob& job, V3 o, V3 d, bool shadow)
+{
+  const float fx = fminf(fmaxf((o.x - job.bbMin[0]) * job.bbScale[0], 0.0f), 127.0f);
+  const float fy = fminf(fmaxf((o.y - job.bbMin[1]) * job.bbScale[1], 0.0f), 127.0f);
+  const float fz = fminf(fmaxf((o.z - job.bbMin[2]) * job.bbScale[2], 0.0f), 127.0f);
+  const uint m = spread7((uint)fx) | (spread7((uint)fy) << 1) | (spread7((uint)fz) << 2);            // 21 bits
+  const uint oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+  const uint fine = ((uint)(absf(d.x) * 3.999f)) | (((uint)(absf(d.y) * 3.999f)) << 2) | (((uint)(absf(d.z) * 3.999f)) << 4);   // 6 bits
+  return (shadow ? 0x40000000u : 0u) | (m << 9) | (oct << 6) | fine;
+}
+
+// Ray compaction. Every wave ballots its two kinds of rays and prefix-sums the lanes (mbcnt); the four waves of the block add
+// their counts in LDS and ONE atomicAdd per block reserves the block's run of the queue. (One atomic per wave was measured at
+// 0.97 ms per shade pass over 2M slots: ~100 K atomics on one address serialise in a single L2 channel.)
+HPT_DEV void blockAppend(uint* counter, bool qNear, bool qShad, uint& posNear, uint& posShad)
+{
+  __shared__ uint waveCnt[4];
+  __shared__ uint blockBase;
+  const unsigned long long mn = __ballot(qNear), ms = __ballot(qShad);
+  const uint cn = (uint)__popcll(mn), cs = (uint)__popcll(ms);
+  const uint wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63u) == 0u) waveCnt[wave] = cn + cs;
+  __syncthreads();
+  if (threadIdx.x == 0u) {
+    const uint tot = waveCnt[0] + waveCnt[1] + waveCnt[2] + waveCnt[3];
+    blockBase = tot ? atomicAdd(counter, tot) : 0u;
+  }
+  __syncthreads();
+  uint base = blockBase;
+  for (uint w = 0; w < wave; w++) base += waveCnt[w];
+  posNear = base + mbcnt64(mn);
+  posShad = base + cn + mbcnt64(ms);
+}
+
+__global__ void __launch_bounds__(256) wfShadeKernel(const DevScene S, const WfPool P, const WfJob job)
+{
+  const uint s = blockIdx.x * 256u + threadIdx.x;
+  uint* ctr = P.ctr + WF_CTR_WORDS * (job.iter & 1u);
+  if (s <= WF_RANGES) P.ctr[WF_CTR_WORDS * ((job.iter + 1u) & 1u) + 32u * s] = 0u;   // counters of the NEXT round (its trace pass is long done)
+
+  bool valid = s < job.itemCount;
+  uint tid = 0;
+  if (valid) {
+    const uint k = job.itemBase + s;
+    tid = job.tidBegin + (k / job.tidChunk) * job.tidChunk * job.tidStride + (k % job.tidChunk);
+    valid = tid < job.tidEnd;
+  }
+  uint st = valid ? P.status[s] : 0u;
+  uint passes = st >> 8;
+  bool alive = (st & WF_ALIVE) != 0u, pend = (st & WF_PEND) != 0u, ending = (st & WF_ENDING) != 0u;
+  const bool active = valid && (alive || pend || ending || passes != 0u);
+  bool wantShadow = false;
+  V3 keyO = v3(0, 0, 0), keyD = v3(0, 0, 1), keySO = v3(0, 0, 0), keySD = v3(0, 0, 1);
+
+  if (active) {
+    Rng gen = job.gens[tid];
+    const uint XY = job.packedXY[tid];
+    V3 accum = v3(0, 0, 0), thr = v3(1, 1, 1), rpos = v3(0, 0, 0), rdir = v3(0, 0, 1);
+    float misPdf = 1.0f, misIor = 1.0f; uint flags = 0, bounce = 0;
+    if (alive || ending) { const float4 a = P.acc[s]; accum = v3(a.x, a.y, a.z); bounce = __float_as_uint(a.w); }
+    // (6') the shadow ray traced since the last visit: add the candidate contribution in the megakernel's order
+    if (pend) { if (P.occl[s] == 0u) { const float4 c = P.contrib[s]; accum = accum + v3(c.x, c.y, c.z); } pend = false; }
+    bool finalize = ending;                                                // path ended last time, only its shadow ray was outstanding
+    ending = false;
+    V3 shPos = v3(0, 0, 0), shDir = v3(0, 0, 1), contrib = v3(0, 0, 0); float shFar = 0.0f;
+
+    if (alive) {
+      const float4 ro = P.rayO[s], rd = P.rayD[s], t4 = P.thr[s], h4 = P.hit[s];
+      rpos = v3(ro.x, ro.y, ro.z); misPdf = ro.w; rdir = v3(rd.x, rd.y, rd.z); misIor = rd.w;
+      thr = v3(t4.x, t4.y, t4.z); flags = __float_as_uint(t4.w);
+      HitRec hit; hit.t = h4.x; hit.u = h4.y; hit.v = h4.z; hit.prim = __float_as_uint(h4.w); hit.inst = P.hitInst[s];
+      V3 rA, rS, rdA, rdS, tailR; Taps taps; uint recTex = 0xFFFFFFFFu;     // differentiable-rendering outputs: unused here
+      const bool didBounce = shadeVertex<false, false>(S, nullptr, hit, rpos, rdir, accum, thr, misPdf, misIor, flags, bounce, gen,
+                                                       wantShadow, shPos, shDir, shFar, contrib, rA, rS, rdA, rdS, taps, recTex, tailR);
+      if (didBounce) bounce++;
+      if ((flags & RAY_FLAG_IS_DEAD) != 0 || bounce >= S.traceDepth) {
+        if ((flags & RAY_FLAG_OUT_OF_SCENE) != 0) {                         // kernel_HitEnvironment (integrator_pt.cpp:550-595)
+          const V3 env = ld3(S.envColor);
+          if (S.integratorType == INTEGRATOR_STUPID_PT) accum = thr * env; else accum = accum + thr * env;
+        }
+        alive = false;
+        if (wantShadow) ending = true; else finalize = true;
+      }
+    }
+    if (finalize) {                                                          // kernel_ContributeToImage (integrator_pt.cpp:598-657)
+      const uint pixel = ((XY & 0xFFFF0000u) >> 16) * (uint)S.winWidth + (XY & 0x0000FFFFu);
+      const V3 c = accum * ld3(S.camRespoceRGB);
+      if (job.channels == 1) job.outColor[pixel] += accum.x * S.exposureMult;
+      else { float* o = job.outColor + (size_t)pixel * job.channels; o[0] += S.exposureMult * c.x; o[1] += S.exposureMult * c.y; o[2] += S.exposureMult * c.z; }
+    }
+    if (!alive && !ending && passes != 0u) {                                 // kernel_InitEyeRay2: next pass of this pixel
+      passes--;
+      accum = v3(0, 0, 0); thr = v3(1, 1, 1); flags = 0; bounce = 0; misPdf = 1.0f; misIor = 1.0f;
+      const V4 lens = rng_float4(gen);
+      cameraRay(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
+      alive = true;
+    }
+    job.gens[tid] = gen;
+    if (alive) {
+      P.rayO[s] = make_float4(rpos.x, rpos.y, rpos.z, misPdf);
+      P.rayD[s] = make_float4(rdir.x, rdir.y, rdir.z, misIor);
+      P.thr[s] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(flags));
+    }
+    if (alive || ending) P.acc[s] = make_float4(accum.x, accum.y, accum.z, __uint_as_float(bounce));
+    if (wantShadow) {
+      P.shO[s] = make_float4(shPos.x, shPos.y, shPos.z, shFar);
+      P.shD[s] = make_float4(shDir.x, shDir.y, shDir.z, 0.0f);
+      P.contrib[s] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
+    }
+    keyO = rpos; keyD = rdir; keySO = shPos; keySD = shDir;
+    P.status[s] = (passes << 8) | (alive ? WF_ALIVE : 0u) | (wantShadow ? WF_PEND : 0u) | (ending ? WF_ENDING : 0u);
+  }
+  // ray compaction: ballot + prefix sum, one atomic per wave and queue
+  const bool qNear = active && alive, qShad = active && wantShadow;
+  uint kn, ks;
+  blockAppend(&ctr[0], qNear, qShad, kn, ks);
+  if (qNear) P.rayQ[kn] = s;
+  if (qShad) P.rayQ[ks] = s | 0x80000000u;
+  if (job.sortRays) {
+    if (qNear) P.rayKey[kn] = rayKey(job, keyO, keyD, false);
+    if (qShad) P.rayKey[ks] = rayKey(job, keySO, keySD, true);
+  }
+}
+
+// ---- persistent traversal with ray replacement -------------------------------------------------------------------------------
+#ifndef HPT_WF_WAVES
+#define HPT_WF_WAVES 6   // 16 KB traversal stacks + 8 KB ray stashes per block: six blocks fill the CU's 160 KB of LDS; 80 VGPRs, no spills
+#endif
+template <bool DEEP, bool FLAT, bool STATS>
+__global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScene S, const WfPool P, uint iter, uint refillBelow,
+                                                                   uint* stackOverflow, uint gridLanes, Counters* counters)
+{
+  __shared__ uint stackMem[LDS_STACK * 256];
+  const uint glane = blockIdx.x * 256u + threadIdx.x;
+  TravStack stk; stk.lds = &stackMem[threadIdx.x]; stk.ovf = stackOverflow + glane; stk.ovfStride = gridLanes;
+  uint* ctr = P.ctr + WF_CTR_WORDS * (iter & 1u);
+  const uint total = ctr[0];
+  if (S.rootRef == REF_NONE) {                                               // empty scene: every ray misses
+    for (uint k = glane; k < total; k += gridLanes) {
+      const uint q = P.rayQ[k];
+      if ((q >> 31) == 0u) P.hitInst[q] = 0xFFFFFFFFu; else P.occl[q & 0x7FFFFFFFu] = 0u;
+    }
+    return;
+  }
+
+  __shared__ uint stashMem[4 * 8 * 64];
+  uint* stash = stashMem + (threadIdx.x >> 6) * (8 * 64);
+  const uint lane = threadIdx.x & 63u;
+  bool has = false, isAny = false, found = false;
+  uint range = (glane >> 6) % WF_RANGES, tried = 0, stashCount = 0;          // wave-uniform
+  uint slot = 0, cur = REF_NONE, curInst = 0xFFFFFFFFu;
+  int  sp = 0;
+  V3 wo = v3(0, 0, 0), wd = v3(0, 0, 1), o = wo, d = wd, id = v3(0, 0, 0);
+  float hitT = 0.0f, hitU = 0.0f, hitV = 0.0f; uint hitPrim = 0, hitInst = 0xFFFFFFFFu;
+  unsigned long long nodeLane = 0, nodeWave = 0, triLane = 0, triWave = 0, refills = 0;
+
+#define HPT_PUSH(v) do { if (DEEP) stkPush(stk, sp, (v)); else stk.lds[sp * 256] = (v); sp++; } while (0)
+#define HPT_POP()   do { sp--; cur = DEEP ? stkPop(stk, sp) : stk.lds[sp * 256]; } while (0)
+
+  while (true) {
+    // ---- refill ---------------------------------------------------------------------------------------------------------
+    // Idle lanes take rays from the wave's stash in LDS (8 dwords per ray, field-major: conflict-free). When the stash cannot
+    // serve them all it is topped up to 64 rays first: ONE atomicAdd per top-up on the head of the current queue range, then
+    // all 64 lanes fetch one ray each - the queue's memory latency is paid once per ~64 rays, not once per refill.
+    // The queue is cut into WF_RANGES contiguous ranges with a head counter each (different L2 channels). A wave starts at
+    // "its" range and moves on when that one is exhausted (an L2 load tells, before any atomic is spent on it).
+    {
+      const unsigned long long mask = __ballot(!has);
+      const uint n = (uint)__popcll(mask);
+      if (n != 0u) {
+        if (stashCount < n && tried < WF_RANGES) {
+          if (STATS && firstActiveLane()) refills++;
+          while (stashCount < 64u && tried < WF_RANGES) {
+            const uint rBegin = (uint)(((unsigned long long)total * range) / WF_RANGES);
+            const uint rSize = (uint)(((unsigned long long)total * (range + 1u)) / WF_RANGES) - rBegin;
+            uint* head = ctr + 32u * (1u + range);
+            uint granted = 0;
+            const uint want = 64u - stashCount;
+            if (__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < rSize) {   // read at L2: never a stale L1 copy
+              uint base = 0;
+              if (lane == 0u) base = atomicAdd(head, want);
+              base = __shfl(base, 0);
+              granted = base < rSize ? min(want, rSize - base) : 0u;
+              if (lane < granted) {
+                const uint q = P.rayQ[rBegin + base + lane];
+                const uint sl = q & 0x7FFFFFFFu;
+                float4 a, b;
+                if ((q >> 31) == 0u) { a = P.rayO[sl]; b = P.rayD[sl]; a.w = HPT_FLT_MAX; }
+                else                 { a = P.shO[sl]; b = P.shD[sl]; }
+                uint* e = stash + (stashCount + lane);
+                e[0 * 64] = __float_as_uint(a.x); e[1 * 64] = __float_as_uint(a.y); e[2 * 64] = __float_as_uint(a.z); e[3 * 64] = __float_as_uint(a.w);
+                e[4 * 64] = __float_as_uint(b.x); e[5 * 64] = __float_as_uint(b.y); e[6 * 64] = __float_as_uint(b.z); e[7 * 64] = q;
+              }
+              stashCount += granted;
+            }
+            if (granted < want) { range = (range + 1u) % WF_RANGES; tried++; }   // this range has nothing left
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+        const uint give = min(n, stashCount);
+        if (!has && mbcnt64(mask) < give) {
+          const uint* e = stash + (stashCount - 1u - mbcnt64(mask));
+          wo = v3(__uint_as_float(e[0 * 64]), __uint_as_float(e[1 * 64]), __uint_as_float(e[2 * 64])); hitT = __uint_as_float(e[3 * 64]);
+          wd = v3(__uint_as_float(e[4 * 64]), __uint_as_float(e[5 * 64]), __uint_as_float(e[6 * 64]));
+          const uint q = e[7 * 64];
+          slot = q & 0x7FFFFFFFu; isAny = (q >> 31) != 0u;
+          o = wo; d = wd; id = rcp3(wd);
+          cur = S.rootRef; curInst = 0xFFFFFFFFu; sp = 0; found = false;
+          hitPrim = 0xFFFFFFFFu; hitInst = 0xFFFFFFFFu; hitU = 0.0f; hitV = 0.0f;
+          has = true;
+        }
+        stashCount -= give;
+      }
+    }
+    if (!__any(has)) break;
+    const bool queueEmpty = (stashCount == 0u) && (tried >= WF_RANGES);      // nothing left to refill with: run the rays to the end
+
+    // ---- traverse until this lane's ray is done, or the wave has thinned out and the queue can refill it ------------------
+    if (has) {
+      while (true) {
+        while ((cur & REF_LEAF) == 0u) {
+          const float4* np = (const float4*)(S.nodes + cur);
+          const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+          const uint4  q3 = ((const uint4*)np)[3];
+          if (STATS) { nodeLane++; if (firstActiveLane()) nodeWave++; }
+          const V3 bo = FLAT ? wo : o;                                         // flat layout: boxes are in world space
+          float ax = (q0.x - bo.x) * id.x, bx = (q0.w - bo.x) * id.x;
+          float ay = (q0.y - bo.y) * id.y, by = (q1.x - bo.y) * id.y;
+          float az = (q0.z - bo.z) * id.z, bz = (q1.y - bo.z) * id.z;
+          const float t0n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+          const float t0f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), hitT));
+          ax = (q1.z - bo.x) * id.x; bx = (q2.y - bo.x) * id.x;
+          ay = (q1.w - bo.y) * id.y; by = (q2.z - bo.y) * id.y;
+          az = (q2.x - bo.z) * id.z; bz = (q2.w - bo.z) * id.z;
+          const float t1n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+          const float t1f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), hitT));
+          const bool h0 = (t0n * 0.999999f <= t0f * 1.000001f);
+          const bool h1 = (t1n * 0.999999f <= t1f * 1.000001f);
+          if (h0 && h1) {
+            const bool firstIs0 = t0n <= t1n;
+            HPT_PUSH(firstIs0 ? q3.y : q3.x);
+            cur = firstIs0 ? q3.x : q3.y;
+          } else if (h0) cur = q3.x;
+          else if (h1) cur = q3.y;
+          else if (sp > 0) HPT_POP();
+          else cur = REF_NONE;
+        }
+        bool done = (cur == REF_NONE);
+        if (!done) {
+          const uint cnt = (cur >> 28) & 7u;
+          if (FLAT || (cnt >= 1u && cnt <= 4u)) {
+            const uint first = cur & 0x0FFFFFFFu;
+            for (uint k = 0; k < cnt; k++) {
+              const float4* tp = (const float4*)(S.tris + first + k);
+              const float4 a = tp[0], b = tp[1], c = tp[2];
+              if (STATS) { triLane++; if (firstActiveLane()) triWave++; }
+              uint inst = curInst;
+              if (FLAT) {
+                inst = __float_as_uint(b.w);
+                if (inst != curInst) {                                          // world -> object space of this triangle's instance
+                  const float4* ip = (const float4*)(S.insts + inst);
+                  const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
+                  o = v3(r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w, r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w, r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w);
+                  d = v3(r0.x * wd.x + r0.y * wd.y + r0.z * wd.z, r1.x * wd.x + r1.y * wd.y + r1.z * wd.z, r2.x * wd.x + r2.y * wd.y + r2.z * wd.z);
+                  curInst = inst;
+                }
+              }
+              const V3 e1 = v3(b.x, b.y, b.z), e2 = v3(c.x, c.y, c.z);
+              const V3 pvec = cross(d, e2);
+              const float det = dot(e1, pvec);
+              const float inv = 1.0f / det;
+              const V3 tvec = o - v3(a.x, a.y, a.z);
+              const float uu = dot(tvec, pvec) * inv;
+              const V3 qvec = cross(tvec, e1);
+              const float vv = dot(d, qvec) * inv;
+              const float tt = dot(e2, qvec) * inv;
+              const uint prim = __float_as_uint(a.w);
+              bool ok = (det != 0.0f) && (uu >= 0.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f) && (tt >= 0.0f) && (tt <= hitT);
+              if (ok && found && tt == hitT) ok = (inst != hitInst) ? (inst < hitInst) : (prim < hitPrim);
+              if (ok) { hitT = tt; hitPrim = prim; hitInst = inst; hitU = uu; hitV = vv; found = true; }
+            }
+            if (isAny && found) done = true;
+            else if (sp > 0) HPT_POP(); else done = true;
+          } else if (cnt == 0u) {
+            const uint inst = cur & 0x0FFFFFFFu;
+            const float4* ip = (const float4*)(S.insts + inst);
+            const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
+            const uint4  r3 = ((const uint4*)ip)[3];
+            o = v3(r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w, r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w, r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w);
+            d = v3(r0.x * wd.x + r0.y * wd.y + r0.z * wd.z, r1.x * wd.x + r1.y * wd.y + r1.z * wd.z, r2.x * wd.x + r2.y * wd.y + r2.z * wd.z);
+            id = rcp3(d);
+            curInst = inst;
+            HPT_PUSH(REF_RESTORE);
+            cur = r3.x;
+          } else {
+            o = wo; d = wd; id = rcp3(d); curInst = 0xFFFFFFFFu;
+            if (sp > 0) HPT_POP(); else done = true;
+          }
+        }
+        if (done) {
+          if (isAny) P.occl[slot] = found ? 1u : 0u;
+          else { P.hit[slot] = make_float4(hitT, hitU, hitV, __uint_as_float(hitPrim)); P.hitInst[slot] = found ? hitInst : 0xFFFFFFFFu; }
+          has = false;
+          break;
+        }
+        if (!queueEmpty && (uint)__popcll(__ballot(true)) < refillBelow) break;
+      }
+    }
+  }
+#undef HPT_PUSH
+#undef HPT_POP
+  if (STATS) {
+    unsigned long long v[5] = { nodeLane, nodeWave, triLane, triWave, refills };
+    for (int i = 0; i < 5; i++) {
+      unsigned long long x = v[i];
+      for (int o2 = 32; o2 > 0; o2 >>= 1) x += __shfl_down(x, o2);
+      if ((threadIdx.x & 63) == 0 && x) atomicAdd(&counters->v[i], x);
+    }
+  }
+}
+
+} // namespace hpt

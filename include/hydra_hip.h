@@ -169,6 +169,16 @@ int  hpt_set_launch_config(hpt_ctx* ctx, int blocksPerCU);
  * when the scene is static and small enough, else two-level), 1 = force the two-level TLAS/BLAS layout, 2 = force the single-level one.
  * Both layouts intersect triangles in object space and return bit-identical hits. */
 int  hpt_set_accel_layout(hpt_ctx* ctx, int layout);
+/* How hpt_path_trace_block(_dev) schedules the work: 1 = one persistent megakernel (a lane keeps its path from camera to end),
+ * 2 = wavefront (a shade kernel and a persistent trace kernel with ballot/prefix-sum ray compaction and ray replacement, path state
+ * in HBM), 0 = automatic (wavefront for scenes of >= 2^17 instanced triangles). Both give bit-identical frames. refillBelow (1..64,
+ * 0 = keep): a trace wave refills from the ray queue when fewer lanes than this still hold a ray; traceBlocksPerCU 0 = automatic.
+ * sortRays: 0 = keep, 1 = off, 2 = radix-sort the ray queue by a coherence key (origin cell, direction) before every trace pass.
+ * The naive and differentiable integrators always use the megakernel. The wavefront call returns once the frame is nearly done
+ * (it polls a device progress word); results are complete after the stream is synchronised, as for the megakernel. */
+int  hpt_set_schedule(hpt_ctx* ctx, int schedule, int refillBelow, int traceBlocksPerCU, int sortRays);
+/* Schedule the last hpt_path_trace_block(_dev) call used (1 / 2) and, for the wavefront one, its number of shade+trace rounds. */
+int  hpt_get_schedule(hpt_ctx* ctx, int* lastSchedule, uint32_t* lastIterations);
 /* Duration of the last path-tracing kernel, measured with HIP events on the stream it ran on (ms). */
 int  hpt_last_kernel_ms(hpt_ctx* ctx, float* ms);
 

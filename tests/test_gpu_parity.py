@@ -234,3 +234,36 @@ def test_both_accel_layouts_give_identical_hits_and_images(scene_name):
     assert np.array_equal(two.RayQuery_AnyHit(pos, dr), flat.RayQuery_AnyHit(pos, dr))
     assert np.array_equal(two.render(4), flat.render(4))
     assert np.array_equal(two.random_gens(), flat.random_gens())
+
+
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "zoo", "interior"])
+def test_wavefront_schedule_equals_megakernel(scene_name):
+    """hpt_set_schedule: the shade/trace kernel pair (ray compaction + replacement, path state in HBM) and the persistent
+    megakernel run the same arithmetic per path, so frames and RNG streams agree bit for bit - for every refill threshold,
+    both acceleration layouts, partial tid windows and accumulation over calls."""
+    from hydracore3_amd.api import HipIntegrator
+    from hydracore3_amd import synth
+    if scene_name == "zoo":
+        sc = synth.material_zoo(96, 64)
+    elif scene_name == "interior":
+        sc = synth.interior_scene(160, 96, objects=24, subdiv=2, tex_size=64)
+    else:
+        sc = load_hydra_xml(scene_path(scene_name), 96, 96)
+    mega = HipIntegrator(sc); mega.set_schedule(1)
+    ref = mega.render(5)
+    assert mega.last_schedule()[0] == 1
+    for layout, refill, sort in ((1, 48, 1), (2, 64, 2), (1, 1, 2)):
+        wf = HipIntegrator(sc, accel_layout=layout); wf.set_schedule(2, refill, 0, sort)
+        img = wf.render(5)
+        sched, iters = wf.last_schedule()
+        assert sched == 2 and 5 <= iters <= 5 * (sc.trace_depth + 2) + 4
+        assert np.array_equal(img, ref), (layout, refill)
+        assert np.array_equal(wf.random_gens(), mega.random_gens())
+    # a window of tids, then the rest, accumulated over two calls of different spp
+    a, b = HipIntegrator(sc), HipIntegrator(sc)
+    a.set_schedule(1); b.set_schedule(2)
+    ia, ib = np.zeros_like(ref), np.zeros_like(ref)
+    for integ, im in ((a, ia), (b, ib)):
+        integ.PathTraceBlock(1000, 4, im, 2, tid_begin=500)
+        integ.PathTraceBlock(integ.N, 4, im, 3)
+    assert np.array_equal(ia, ib)

@@ -34,7 +34,8 @@ def build_scene(workload, width, height):
     if workload == "cornell":
         return load_hydra_xml(os.path.join(ROOT, "tests", "golden", "scenes", "test_035", "statex_00001.xml"), width, height)
     from hydracore3_amd.synth import interior_scene
-    return interior_scene(width, height)
+    subdiv = int(os.environ.get("HYDRA_BENCH_SUBDIV", "4"))      # 4 = the 1M-triangle configuration; smaller values only for crossover studies
+    return interior_scene(width, height, subdiv=subdiv)
 
 
 def run_dr(args, rank, world, dev, stream):

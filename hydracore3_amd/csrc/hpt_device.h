@@ -768,6 +768,9 @@ HPT_DEV V3 rcp3(V3 d) { return v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_r
 // Traversal stack: the first LDS_STACK entries of a lane live in LDS ([depth][lane]: a push or pop is one conflict-free
 // ds_write/ds_read_b32 per wave); deeper entries - rare, a push only happens when both children are hit - go to a per-lane
 // slice of an HBM scratch buffer ([depth][global lane], coalesced). LDS use is therefore independent of the tree depth.
+// Voted exit of the inner-node loop (S.nodeMin): waiting for the LAST lane to reach a leaf costs the big scenes dearly (1M triangles:
+// 107 -> 134 Mpaths/s with 16 in the megakernel, 159 -> 188 in the wavefront trace kernel), but on the Cornell box, where a ray sees 7
+// nodes and 3 triangles, the extra trips through the leaf code cost more than they save (1859 -> 1584): the host sets it per scene.
 #ifndef HPT_LDS_STACK
 #define HPT_LDS_STACK 16
 #endif
@@ -830,8 +833,11 @@ HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, 
       else if (h1) cur = q3.y;
       else if (sp > 0) HPT_POP();
       else cur = REF_NONE;
+      // voted exit: when only a few lanes of the wave are still walking inner nodes, serve the lanes that hold a leaf first
+      if (S.nodeMin != 0u && (uint)__popcll(__ballot((cur & REF_LEAF) == 0u)) < S.nodeMin) break;
     }
     if (cur == REF_NONE) break;
+    if ((cur & REF_LEAF) == 0u) continue;
 
     // ---- (b) leaves --------------------------------------------------------------------------------------------------
     const uint cnt = (cur >> 28) & 7u;
@@ -935,8 +941,11 @@ HPT_DEV bool traceRayFlat(const DevScene& S, const V3 wo, const V3 wd, float tne
       else if (h1) cur = q3.y;
       else if (sp > 0) HPT_POP();
       else cur = REF_NONE;
+      // voted exit: when only a few lanes of the wave are still walking inner nodes, serve the lanes that hold a leaf first
+      if (S.nodeMin != 0u && (uint)__popcll(__ballot((cur & REF_LEAF) == 0u)) < S.nodeMin) break;
     }
     if (cur == REF_NONE) break;
+    if ((cur & REF_LEAF) == 0u) continue;
     {
       const uint cnt = (cur >> 28) & 7u;
       const uint first = cur & 0x0FFFFFFFu;

@@ -21,6 +21,9 @@ static const size_t FLAT_TRI_BUDGET = size_t(32) << 20;     // traversal stack e
 
 using namespace hpt;
 
+// Scenes with at least this many instanced triangles count as "heavy": wavefront schedule, voted exit of the node loop.
+static const size_t HEAVY_SCENE_TRIS = size_t(1) << 13;    // measured (profiles/crossover.sh): wavefront wins from 16 K triangles up, loses 2x on the 36-triangle Cornell box
+
 namespace {
 
 struct Geom
@@ -80,7 +83,8 @@ struct hpt_ctx
   uint* wfProgress = nullptr;            // pinned: active-slot count after every WF_CHECK-th shade pass
   hipEvent_t wfEv[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int  schedule = 0;                     // 0 automatic, 1 megakernel, 2 wavefront (hpt_set_schedule)
-  uint wfRefillBelow = 48;               // a trace wave refills from the queue when fewer lanes than this still hold a ray
+  int  nodeMinOverride = -1;             // env HPT_NODE_MIN (tuning): overrides the per-scene choice of DevScene::nodeMin
+  uint wfRefillBelow = 56;               // a trace wave refills from the queue when fewer lanes than this still hold a ray
   int  wfBlocksPerCU = 0;
   size_t instTris = 0;                   // instanced triangles of the committed scene
   uint lastSchedule = 1, lastWfIters = 0;
@@ -120,6 +124,7 @@ extern "C" int hpt_create(int device, hpt_ctx** out)
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) { c->numCUs = prop.multiProcessorCount; c->devName = prop.gcnArchName; }
   (void)hipEventCreate(&c->ev0); (void)hipEventCreate(&c->ev1);
+  if (const char* e = std::getenv("HPT_NODE_MIN")) c->nodeMinOverride = std::atoi(e) & 63;
   std::memset(&c->S, 0, sizeof(DevScene));
   c->S.rootRef = REF_NONE;
   *out = c;
@@ -269,6 +274,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   size_t instTris = 0;
   for (const Inst& in : c->insts) instTris += c->geoms[in.geomId].idx.size() / 3;
   c->instTris = instTris;
+  c->S.nodeMin = c->nodeMinOverride >= 0 ? (uint)c->nodeMinOverride : (instTris >= HEAVY_SCENE_TRIS ? 16u : 0u);
   {                                                         // world bounds (ray-sort keys of the wavefront schedule)
     Aabb w; w.reset();
     for (const Inst& in : c->insts) {
@@ -666,7 +672,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
 // ---- wavefront schedule ---------------------------------------------------------------------------------------------------------------
 // Scenes at or above this many instanced triangles are rendered by the shade / trace kernel pair; below it the path state's trip
 // through HBM costs more than the ray replacement gains (measured crossover: see DESIGN.md, "two schedules").
-static const size_t WF_AUTO_TRIS = size_t(1) << 17;
+static const size_t WF_AUTO_TRIS = HEAVY_SCENE_TRIS;
 static const uint   WF_POOL_MAX = 1u << 22;        // pool slots (pixels in flight) per batch: 4M x 148 B = 620 MB
 static const uint   WF_CHECK = 8;                  // progress word copied back every WF_CHECK shade passes
 static const uint   WF_RING = 8;                   // ... and at most WF_RING such checkpoints in flight

@@ -73,6 +73,7 @@ struct DevScene
   const BvhInst* insts;
   uint           rootRef;
   uint           numInsts;
+  uint           nodeMin;         // traversal leaves its inner-node loop when fewer lanes than this still hold an inner node (0: never)
   uint           flatMode;        // 1: one world-space BVH2 over all instanced triangles (leaf triangles carry their instance id)
 
   const uint*    triIndices;      // m_triIndices

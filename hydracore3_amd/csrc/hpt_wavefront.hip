@@ -317,9 +317,11 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
           else if (h1) cur = q3.y;
           else if (sp > 0) HPT_POP();
           else cur = REF_NONE;
+          // voted exit: when only a few lanes are still walking inner nodes, the lanes that already hold a leaf are served first
+          if (S.nodeMin != 0u && (uint)__popcll(__ballot((cur & REF_LEAF) == 0u)) < S.nodeMin) break;
         }
         bool done = (cur == REF_NONE);
-        if (!done) {
+        if (!done && (cur & REF_LEAF) != 0u) {
           const uint cnt = (cur >> 28) & 7u;
           if (FLAT || (cnt >= 1u && cnt <= 4u)) {
             const uint first = cur & 0x0FFFFFFFu;

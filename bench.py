@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--schedule", type=int, default=0, help="0 automatic, 1 persistent megakernel, 2 wavefront (shade + trace kernels)")
     ap.add_argument("--refill-below", type=int, default=0, help="wavefront: refill a trace wave when fewer lanes than this hold a ray")
     ap.add_argument("--trace-blocks-per-cu", type=int, default=0)
+    ap.add_argument("--accel-layout", type=int, default=0, help="0 automatic, 1 two-level TLAS/BLAS, 2 single-level world-space BVH")
     ap.add_argument("--sort-rays", type=int, default=0, help="wavefront: 1 off, 2 sort the ray queue by a coherence key")
     ap.add_argument("--verify", action="store_true", help="rank 0 re-renders the whole frame alone and checks the sharded frame is bit-identical")
     args = ap.parse_args()
@@ -177,7 +178,7 @@ def main():
     W, H = (args.width or (1024 if args.workload == "cornell" else 1920)), (args.height or (1024 if args.workload == "cornell" else 1080))
     spp = args.spp
     sc = build_scene(args.workload, W, H)
-    integ = HipIntegrator(sc, device=dev_index)
+    integ = HipIntegrator(sc, device=dev_index, accel_layout=args.accel_layout)
     if args.blocks_per_cu:
         integ.set_launch_config(args.blocks_per_cu)
     if args.schedule or args.refill_below or args.trace_blocks_per_cu or args.sort_rays:

@@ -779,8 +779,11 @@ struct TravStack { uint* lds; uint* ovf; uint ovfStride; };
 HPT_DEV void stkPush(const TravStack& k, int sp, uint v) { if (sp < LDS_STACK) k.lds[sp * 256] = v; else k.ovf[(size_t)(sp - LDS_STACK) * k.ovfStride] = v; }
 HPT_DEV uint stkPop(const TravStack& k, int sp)
 {
-  // the LDS read is unconditional (clamped slot) and the HBM read conditional: never a select between two address spaces
+  // The LDS read is unconditional (clamped slot) and the HBM read conditional. The empty asm makes the LDS value opaque: without it
+  // the compiler folds the two reads into ONE flat_load_dword with a selected address, and every pop - which sits on the critical
+  // path to the next node fetch - takes the flat path (vmcnt + lgkmcnt wait) instead of a ds_read_b32.
   uint v = k.lds[(sp < LDS_STACK ? sp : LDS_STACK - 1) * 256];
+  asm volatile("" : "+v"(v));
   if (sp >= LDS_STACK) v = k.ovf[(size_t)(sp - LDS_STACK) * k.ovfStride];
   return v;
 }

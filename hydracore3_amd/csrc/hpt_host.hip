@@ -288,9 +288,10 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
     }
     for (int a = 0; a < 3; a++) { c->sceneMin[a] = w.lo[a] <= w.hi[a] ? w.lo[a] : 0.0f; c->sceneMax[a] = w.lo[a] <= w.hi[a] ? w.hi[a] : 1.0f; }
   }
-  // measured (profiles/phases.py): flat cuts node visits 12 % on the 1M-triangle scene but not time, and costs 8 % on the Cornell box
-  // (looser world-space boxes around rotated instances, per-triangle ray transform): automatic = two-level for now
-  const bool flat = (c->accelLayout == 2) && instTris <= FLAT_TRI_BUDGET;
+  // Automatic choice, measured: heavy static scenes (wavefront schedule) gain 8 % from the single-level layout (1M triangles: 191 -> 207
+  // Mpaths/s; no instance enter / leave trips, triangle-loop lane utilisation 0.21 -> 0.38); the Cornell-box class on the megakernel loses
+  // 8 % to it (looser world-space boxes around rotated instances, per-triangle ray transform) and keeps the two-level TLAS/BLAS layout.
+  const bool flat = instTris <= FLAT_TRI_BUDGET && (c->accelLayout == 2 || (c->accelLayout == 0 && instTris >= HEAVY_SCENE_TRIS));
   if (flat) {
     const size_t ni = c->insts.size();
     std::vector<Aabb> boxes; boxes.reserve(instTris);

@@ -5,9 +5,17 @@
 
 A *step* is one PathTraceBlock call over the whole frame (W*H pixels x spp passes, MIS path tracing) with the
 framebuffer, RNG states and scene resident in HBM. N = 1 runs BASELINE.json configs[1] (scenes/test_035 Cornell box,
-1024 x 1024, 1024 spp). For N > 1 (launched through torch.distributed.run, one rank per GPU) the frame's swizzled pixel
-index range is split into N contiguous windows, every rank renders its window into a zeroed full-size framebuffer and
-the frame is assembled by one RCCL reduce(SUM) to rank 0 per step, inside the timed region (strong scaling).
+1024 x 1024, 1024 spp). For N > 1 (launched through torch.distributed.run, one rank per GPU, scene replicated):
+
+  --scaling weak (default)  sample sharding: every rank renders the WHOLE frame at --spp with its own RNG sub-streams
+                            (generators seeded as threads r*W*H.. of one big InitRandomGens call) and ONE RCCL reduce(SUM)
+                            per step adds the N frames on rank 0: N x the samples per pixel in (almost) the same time.
+                            Per-GPU work is fixed, value = paths of all ranks / time.
+  --scaling strong          pixel sharding of ONE frame at --spp: rank r renders every N-th 1024-tid chunk of the swizzled
+                            pixel order into a zeroed full-size framebuffer, one RCCL reduce(SUM) assembles the frame,
+                            bit-identical to the single-GPU frame (--verify). A pixel's passes are sequential (its RNG stream
+                            continues from pass to pass), so this mode runs out of independent paths per GPU on small frames
+                            (DESIGN.md, "multi-GPU").
 
 Prints ONE JSON line on rank 0 (see the contract in the task description); `roofline` prices the persistent
 path-tracing kernel against HBM bandwidth using ALGORITHMIC bytes measured by the library's
@@ -136,6 +144,11 @@ def main():
     ap.add_argument("--schedule", type=int, default=0, help="0 automatic, 1 persistent megakernel, 2 wavefront (shade + trace kernels)")
     ap.add_argument("--refill-below", type=int, default=0, help="wavefront: refill a trace wave when fewer lanes than this hold a ray")
     ap.add_argument("--trace-blocks-per-cu", type=int, default=0)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = sample sharding (every rank renders the whole frame at --spp with its own RNG sub-streams, the frames are "
+                         "summed by one RCCL reduce: N x the samples in the same time); strong = pixel sharding of ONE frame at --spp "
+                         "(interleaved 1024-tid chunks, bit-identical to the single-GPU frame)")
+    ap.add_argument("--emulate-share", type=int, default=1, help="study only: render rank 0's share of a K-rank job on one GPU (value = K x its rate: the K-GPU rate without the reduce)")
     ap.add_argument("--accel-layout", type=int, default=0, help="0 automatic, 1 two-level TLAS/BLAS, 2 single-level world-space BVH")
     ap.add_argument("--sort-rays", type=int, default=0, help="wavefront: 1 off, 2 sort the ray queue by a coherence key")
     ap.add_argument("--verify", action="store_true", help="rank 0 re-renders the whole frame alone and checks the sharded frame is bit-identical")
@@ -185,8 +198,15 @@ def main():
         integ.set_schedule(args.schedule, args.refill_below, args.trace_blocks_per_cu, args.sort_rays)
     N = W * H
     from hydracore3_amd.sharding import tid_interleave
-    t_begin, t_count, chunk, stride = tid_interleave(rank, world, N)   # rank r renders every world-th 1024-tid chunk (load balance)
-    integ.set_tid_interleave(chunk, stride)
+    weak = args.scaling == "weak"
+    if weak:
+        # sample sharding: rank r renders ALL pixels, its generators seeded as threads r*N .. (r+1)*N-1 of one big InitRandomGens call
+        t_begin, t_count = 0, N
+        if world > 1:
+            integ.InitRandomGens(N, first_seed=rank * N)
+    else:
+        t_begin, t_count, chunk, stride = tid_interleave(rank, world * args.emulate_share, N)   # rank r renders every world-th 1024-tid chunk
+        integ.set_tid_interleave(chunk, stride)
 
     frame = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
@@ -224,21 +244,34 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         kernel_ms = [integ.last_kernel_ms()]
-    total_paths = float(N) * spp * args.steps
+    total_paths = float(N) * spp * args.steps * (world if weak else 1)     # (with --emulate-share K: the K ranks together would have finished the frame in this time)
     value = total_paths / elapsed / 1e6
 
-    mean_lum = float(frame[..., :3].mean().item()) / spp if rank == 0 else 0.0
+    mean_lum = float(frame[..., :3].mean().item()) / (spp * (world if weak else 1)) if rank == 0 else 0.0
 
     verified = None
     if args.verify and rank == 0:
         integ.set_tid_interleave(0, 1)
-        solo = HipIntegrator(sc, device=dev_index)
         ref = torch.zeros_like(frame)
-        for _ in range(args.warmup + args.steps):                 # the RNG streams continue from step to step
-            ref.zero_()
-            solo.path_trace_block_dev(ref.data_ptr(), spp, 0, N, 4, False, stream)
-        torch.cuda.synchronize()
-        verified = bool(torch.equal(ref, frame))
+        if weak:
+            # re-render every rank's contribution alone (same seeds, same number of calls) and sum: equal up to the reduce's summation order
+            total = torch.zeros_like(frame)
+            for r in range(world):
+                solo = HipIntegrator(sc, device=dev_index, accel_layout=args.accel_layout)
+                solo.InitRandomGens(N, first_seed=r * N)
+                for _ in range(args.warmup + args.steps):
+                    ref.zero_()
+                    solo.path_trace_block_dev(ref.data_ptr(), spp, 0, N, 4, False, stream)
+                torch.cuda.synchronize()
+                total += ref
+            verified = bool(torch.allclose(total, frame, rtol=1e-5, atol=1e-5))
+        else:
+            solo = HipIntegrator(sc, device=dev_index, accel_layout=args.accel_layout)
+            for _ in range(args.warmup + args.steps):                 # the RNG streams continue from step to step
+                ref.zero_()
+                solo.path_trace_block_dev(ref.data_ptr(), spp, 0, N, 4, False, stream)
+            torch.cuda.synchronize()
+            verified = bool(torch.equal(ref, frame))
         if not verified:
             raise SystemExit("sharded frame differs from the single-GPU frame")
 
@@ -283,12 +316,14 @@ def main():
     if rank == 0:
         out = {"metric": "Mpaths/s (fwd PathTraceBlock, MIS path tracing)", "value": round(value, 2), "unit": "Mpaths/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"scenes/test_035 Cornell box {W}x{H} @ {spp} spp, forward PathTraceBlock" if args.workload == "cornell"
                           else f"synthetic 1M-triangle interior {W}x{H} @ {spp} spp, forward PathTraceBlock",
-                          "paths_per_step": N * spp, "trace_depth": sc.trace_depth, "integrator": "mispt",
-                          "sharding": f"{world} ranks x interleaved 1024-tid chunks + RCCL reduce" if world > 1 else "single GPU",
-                          "mean_radiance": round(mean_lum, 5), "sharded_frame_bit_identical": verified},
+                          "paths_per_step": N * spp * (world if weak else 1), "trace_depth": sc.trace_depth, "integrator": "mispt",
+                          "sharding": "single GPU" if world == 1 else
+                                      (f"sample sharding: {world} ranks x whole frame x {spp} spp each (decorrelated RNG sub-streams) + RCCL reduce(SUM)" if weak
+                                       else f"pixel sharding: {world} ranks x interleaved 1024-tid chunks of one frame + RCCL reduce(SUM)"),
+                          "mean_radiance": round(mean_lum, 5), "sharded_frame_verified": verified},
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
 

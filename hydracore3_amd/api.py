@@ -41,6 +41,7 @@ ABI = {
     "hpt_pack_xy": (_i, [_vp, _u32, _u32]),
     "hpt_get_packed_xy": (_i, [_vp, _vp, _u32]),
     "hpt_init_random_gens": (_i, [_vp, _u32]),
+    "hpt_init_random_gens_from": (_i, [_vp, _u32, _u32]),
     "hpt_get_random_gens": (_i, [_vp, _vp, _u32]),
     "hpt_set_random_gens": (_i, [_vp, _vp, _u32]),
     "hpt_path_trace_block": (_i, [_vp, _u32, _u32, _u32, _vp, _u32]),
@@ -139,8 +140,9 @@ class HipIntegrator:
     def PackXYBlock(self, tidX, tidY, a_passNum=1):
         self._chk(self.L.hpt_pack_xy(self.h, tidX, tidY))
 
-    def InitRandomGens(self, a_maxThreads):
-        self._chk(self.L.hpt_init_random_gens(self.h, a_maxThreads))
+    def InitRandomGens(self, a_maxThreads, first_seed=0):
+        """Integrator::InitRandomGens; first_seed != 0 seeds the generators as threads first_seed.. of one larger call (sample sharding)."""
+        self._chk(self.L.hpt_init_random_gens_from(self.h, a_maxThreads, first_seed))
 
     def packed_xy(self):
         out = np.zeros(self.N, np.uint32)

@@ -6,7 +6,7 @@
 // The tree depth is capped so that the traversal stack (LDS, one 32-bit slot per level and lane) can never overflow:
 // when the SAH split would leave a side too large for the remaining levels, the builder falls back to a median split.
 //
-// Node layout: 64 bytes holding BOTH child boxes (see hpt_types.h); boxes are padded by a relative 1e-5 so that the
+// Node layout: 64 bytes holding BOTH child boxes as (lo, hi) pairs per axis (see hpt_types.h); boxes are padded by a relative 1e-5 so that the
 // slab test can only err on the conservative side with respect to the exact triangle test.
 #pragma once
 #include "hpt_types.h"
@@ -158,9 +158,8 @@ private:
     const uint r0 = buildRange(first, mid - first, depth + 1);
     const uint r1 = buildRange(mid, first + count - mid, depth + 1);
     BvhNode& nd = out.nodes[id];
-    nd.q[0] = b0.lo[0]; nd.q[1] = b0.lo[1]; nd.q[2] = b0.lo[2]; nd.q[3] = b0.hi[0];
-    nd.q[4] = b0.hi[1]; nd.q[5] = b0.hi[2]; nd.q[6] = b1.lo[0]; nd.q[7] = b1.lo[1];
-    nd.q[8] = b1.lo[2]; nd.q[9] = b1.hi[0]; nd.q[10] = b1.hi[1]; nd.q[11] = b1.hi[2];
+    // (lo, hi) pairs per axis: child 0 = q[0..5], child 1 = q[6..11] - the layout the packed slab test consumes (hpt_device.h: nodeSlabs)
+    for (int a = 0; a < 3; a++) { nd.q[2 * a] = b0.lo[a]; nd.q[2 * a + 1] = b0.hi[a]; nd.q[6 + 2 * a] = b1.lo[a]; nd.q[6 + 2 * a + 1] = b1.hi[a]; }
     nd.ref0 = r0; nd.ref1 = r1; nd.pad0 = nd.pad1 = 0;
     return id;
   }

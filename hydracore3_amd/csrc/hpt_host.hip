@@ -580,15 +580,16 @@ extern "C" int hpt_get_packed_xy(hpt_ctx* c, uint32_t* out, uint32_t count)
   HIPCHK(c, hipMemcpy(out, c->dPackedXY.p, (size_t)count * 4, hipMemcpyDeviceToHost));
   return HPT_OK;
 }
-extern "C" int hpt_init_random_gens(hpt_ctx* c, uint32_t n)
+extern "C" int hpt_init_random_gens_from(hpt_ctx* c, uint32_t n, uint32_t firstSeed)
 {
   if (!c || n == 0) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   HIPCHK(c, c->dGens.alloc(n));
-  initRandomGensKernel<<<dim3((n + 255) / 256), dim3(256), 0, 0>>>(c->dGens.p, n);
+  initRandomGensKernel<<<dim3((n + 255) / 256), dim3(256), 0, 0>>>(c->dGens.p, n, firstSeed);
   HIPCHK(c, hipGetLastError());
   return HPT_OK;
 }
+extern "C" int hpt_init_random_gens(hpt_ctx* c, uint32_t n) { return hpt_init_random_gens_from(c, n, 0u); }
 extern "C" int hpt_get_random_gens(hpt_ctx* c, uint32_t* out, uint32_t count)
 {
   if (!c || !out || count > c->dGens.n) return HPT_ERR_ARG;

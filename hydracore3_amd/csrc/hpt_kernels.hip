@@ -270,10 +270,10 @@ __global__ void packXYKernel(uint* out, int W, int H, uint ts)
 }
 
 // InitRandomGens (integrator_pt.cpp:13-21)
-__global__ void initRandomGensKernel(Rng* gens, uint n)
+__global__ void initRandomGensKernel(Rng* gens, uint n, uint firstSeed)
 {
   const uint i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) gens[i] = rng_init(i);
+  if (i < n) gens[i] = rng_init(firstSeed + i);
 }
 
 // batched RayQuery_NearestHit / RayQuery_AnyHit for the ISceneObject entry points

@@ -46,7 +46,7 @@ static const uint REF_RESTORE = 0xFFFFFFFFu;
 static const uint REF_NONE    = 0xFFFFFFFEu;   // empty scene
 static const int  BVH_LEAF_MAX = 2;   // measured on MI355X: 4 -> 1371, 2 -> 1800, 1 -> 1676 Mpaths/s (Cornell); no effect on the 1M-triangle scene
 
-struct BvhNode { float q[12]; uint ref0, ref1, pad0, pad1; };
+struct BvhNode { float q[12]; uint ref0, ref1, pad0, pad1; };   // q = child 0 {lo.x hi.x lo.y hi.y lo.z hi.z}, child 1 {same}: (lo, hi) pairs feed v_pk_* slab tests
 static_assert(sizeof(BvhNode) == 64, "BVH2 node must be one 64-byte line");
 
 // 48-byte triangle: v0, e1 = v1-v0, e2 = v2-v0 (what Moeller-Trumbore consumes), primId in the spare lane

@@ -297,18 +297,8 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
           const uint4  q3 = ((const uint4*)np)[3];
           if (STATS) { nodeLane++; if (firstActiveLane()) nodeWave++; }
           const V3 bo = FLAT ? wo : o;                                         // flat layout: boxes are in world space
-          float ax = (q0.x - bo.x) * id.x, bx = (q0.w - bo.x) * id.x;
-          float ay = (q0.y - bo.y) * id.y, by = (q1.x - bo.y) * id.y;
-          float az = (q0.z - bo.z) * id.z, bz = (q1.y - bo.z) * id.z;
-          const float t0n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-          const float t0f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), hitT));
-          ax = (q1.z - bo.x) * id.x; bx = (q2.y - bo.x) * id.x;
-          ay = (q1.w - bo.y) * id.y; by = (q2.z - bo.y) * id.y;
-          az = (q2.x - bo.z) * id.z; bz = (q2.w - bo.z) * id.z;
-          const float t1n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-          const float t1f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), hitT));
-          const bool h0 = (t0n * 0.999999f <= t0f * 1.000001f);
-          const bool h1 = (t1n * 0.999999f <= t1f * 1.000001f);
+          bool h0, h1; float t0n, t1n;
+          nodeSlabs(q0, q1, q2, bo, id, 0.0f, hitT, h0, h1, t0n, t1n);
           if (h0 && h1) {
             const bool firstIs0 = t0n <= t1n;
             HPT_PUSH(firstIs0 ? q3.y : q3.x);

@@ -117,6 +117,9 @@ int  hpt_update_lights(hpt_ctx* ctx, size_t first, size_t count, const void* lig
 int  hpt_pack_xy(hpt_ctx* ctx, uint32_t tidX, uint32_t tidY);                            /* PackXYBlock (integrator_pt_host.cpp:19-27) */
 int  hpt_get_packed_xy(hpt_ctx* ctx, uint32_t* out, uint32_t count);
 int  hpt_init_random_gens(hpt_ctx* ctx, uint32_t maxThreads);                            /* InitRandomGens (integrator_pt.cpp:13-21) */
+/* The same seeding (RandomGenInit, crandom.h:25-36) for thread ids firstSeed .. firstSeed + maxThreads - 1: rank r of a sample-sharded
+ * multi-GPU render seeds its generators as threads r * maxThreads ... of one big InitRandomGens call, i.e. decorrelated sub-streams. */
+int  hpt_init_random_gens_from(hpt_ctx* ctx, uint32_t maxThreads, uint32_t firstSeed);
 int  hpt_get_random_gens(hpt_ctx* ctx, uint32_t* outUint2, uint32_t count);              /* m_randomGens is integrator-owned, device copy authoritative */
 int  hpt_set_random_gens(hpt_ctx* ctx, const uint32_t* inUint2, uint32_t count);
 

@@ -267,3 +267,22 @@ def test_wavefront_schedule_equals_megakernel(scene_name):
         integ.PathTraceBlock(1000, 4, im, 2, tid_begin=500)
         integ.PathTraceBlock(integ.N, 4, im, 3)
     assert np.array_equal(ia, ib)
+
+
+def test_sample_sharding_seeds_and_sum(cornell):
+    """bench.py --scaling weak: rank r seeds its generators as threads r*N.. of one big InitRandomGens call. The seeding equals
+    the oracle's RandomGenInit for those thread ids, a rank's frame equals the oracle run from the same generator states, and the
+    sharded render is the per-rank frames added up."""
+    from hydracore3_amd.api import HipIntegrator
+    from oracle.orc import OracleIntegrator, rng_kat
+    sc, _, _ = cornell
+    gpu, cpu = HipIntegrator(sc), OracleIntegrator(sc)
+    N = gpu.N
+    gpu.InitRandomGens(N, first_seed=2 * N)
+    g = gpu.random_gens().reshape(-1, 2)
+    for i in (0, 1, 7, N // 2, N - 1):
+        state, _ = rng_kat(2 * N + i, 0)
+        assert (int(g[i][0]), int(g[i][1])) == (int(state[0]), int(state[1])), i
+    cpu.set_random_gens(gpu.random_gens())
+    a, b = gpu.render(3), cpu.render(3)
+    assert per_pixel_l2(a, b, 3) < 1e-3

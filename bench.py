@@ -278,6 +278,7 @@ def main():
     roofline, cpu = None, None
     if rank == 0:
         # algorithmic bytes per path from the instrumented kernel on the same frame (fewer passes: the statistics are stationary)
+        sched_used, wf_rounds = integ.last_schedule()
         probe_spp = min(spp, 8)
         integ.set_schedule(1)                                     # the instrumented build is the megakernel: same rays, same node / triangle visits
         integ.set_instrumentation(True)
@@ -302,7 +303,8 @@ def main():
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "kernel": "pathTraceKernel", "kernel_ms": round(k_ms, 3),
+                    "kernel": "pathTraceKernel" if sched_used == 1 else f"wavefront: {wf_rounds} x (wfShadeKernel + wfTraceKernel)",
+                    "kernel_ms": round(k_ms, 3),
                     "algorithmic_bytes_per_path": round(ab["total"], 1), "traversal_bytes_per_path": round(ab["traversal"], 1),
                     "nodes_per_ray": round(ab["nodes_per_ray"], 2), "tris_per_ray": round(ab["tris_per_ray"], 2),
                     "rays_per_path": round(ab["rays_per_path"], 2)}

@@ -789,17 +789,24 @@ HPT_DEV uint stkPop(const TravStack& k, int sp)
 }
 
 // Slab test of both children of a node against a ray (origin o, reciprocal direction id, interval [tnear, best]).
-// The node stores (lo, hi) pairs per axis, so each axis of each child is ONE packed subtract and ONE packed multiply
-// (v_pk_add_f32 / v_pk_mul_f32: 12 instructions instead of 24 for the 24 plane distances); (q - o) * id is rounded exactly as the
-// scalar form. Boxes were padded by the builder; the interval is widened a little more so that rounding (and the 1-ulp reciprocal)
+// The node stores (lo, hi) pairs per axis, so each axis of each child CAN be one packed subtract and one packed multiply
+// (HPT_PACKED_SLABS: v_pk_add_f32 / v_pk_mul_f32, 12 instructions instead of 24, same rounding) - measured slower, off by default. Boxes were padded by the builder; the interval is widened a little more so that rounding (and the 1-ulp reciprocal)
 // can only make the test more conservative than the exact triangle test.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef HPT_PACKED_SLABS
+#define HPT_PACKED_SLABS 0   // measured: v_pk_add/mul_f32 (12 instead of 24 instructions) is NOT faster here: Cornell 1805 vs 1820, 1M triangles 200 vs 206
+#endif
 HPT_DEV void nodeSlabs(const float4 q0, const float4 q1, const float4 q2, const V3 o, const V3 id, const float tnear, const float best,
                        bool& h0, bool& h1, float& t0n, float& t1n)
 {
+#if HPT_PACKED_SLABS
   const f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z}, ix = {id.x, id.x}, iy = {id.y, id.y}, iz = {id.z, id.z};
   const f32x2 ax = (f32x2{q0.x, q0.y} - ox) * ix, ay = (f32x2{q0.z, q0.w} - oy) * iy, az = (f32x2{q1.x, q1.y} - oz) * iz;
   const f32x2 bx = (f32x2{q1.z, q1.w} - ox) * ix, by = (f32x2{q2.x, q2.y} - oy) * iy, bz = (f32x2{q2.z, q2.w} - oz) * iz;
+#else
+  const f32x2 ax = {(q0.x - o.x) * id.x, (q0.y - o.x) * id.x}, ay = {(q0.z - o.y) * id.y, (q0.w - o.y) * id.y}, az = {(q1.x - o.z) * id.z, (q1.y - o.z) * id.z};
+  const f32x2 bx = {(q1.z - o.x) * id.x, (q1.w - o.x) * id.x}, by = {(q2.x - o.y) * id.y, (q2.y - o.y) * id.y}, bz = {(q2.z - o.z) * id.z, (q2.w - o.z) * id.z};
+#endif
   t0n = fmaxf(fmaxf(fminf(ax.x, ax.y), fminf(ay.x, ay.y)), fmaxf(fminf(az.x, az.y), tnear));
   const float t0f = fminf(fminf(fmaxf(ax.x, ax.y), fmaxf(ay.x, ay.y)), fminf(fmaxf(az.x, az.y), best));
   t1n = fmaxf(fmaxf(fminf(bx.x, bx.y), fminf(by.x, by.y)), fmaxf(fminf(bz.x, bz.y), tnear));
@@ -827,23 +834,30 @@ HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, 
 
   while (true) {
     // ---- (a) inner nodes: one 64-byte line holds both child boxes ---------------------------------------------------
-    while ((cur & REF_LEAF) == 0u) {
-      const float4* np = (const float4*)(S.nodes + cur);
-      const float4 q0 = np[0], q1 = np[1], q2 = np[2];
-      const uint4  q3 = ((const uint4*)np)[3];
-      if (STATS) { st.nodes++; if (firstActiveLane()) st.waveNodeIters++; }
-      bool h0, h1; float t0n, t1n;
-      nodeSlabs(q0, q1, q2, o, id, tnear, hit.t, h0, h1, t0n, t1n);
-      if (h0 && h1) {
-        const bool firstIs0 = t0n <= t1n;
-        HPT_PUSH(firstIs0 ? q3.y : q3.x);
-        cur = firstIs0 ? q3.x : q3.y;
-      } else if (h0) cur = q3.x;
-      else if (h1) cur = q3.y;
-      else if (sp > 0) HPT_POP();
+    // Two copies of the loop: without the vote (small scenes - even a never-taken scalar test per step cost the Cornell box 4 %)
+    // and with it (heavy scenes: leave when only a few lanes of the wave are still walking inner nodes, serve the leaves first).
+#define HPT_NODE_STEP(ORG)                                                                              \
+      const float4* np = (const float4*)(S.nodes + cur);                                                \
+      const float4 q0 = np[0], q1 = np[1], q2 = np[2];                                                  \
+      const uint4  q3 = ((const uint4*)np)[3];                                                          \
+      if (STATS) { st.nodes++; if (firstActiveLane()) st.waveNodeIters++; }                             \
+      bool h0, h1; float t0n, t1n;                                                                      \
+      nodeSlabs(q0, q1, q2, ORG, id, tnear, hit.t, h0, h1, t0n, t1n);                                   \
+      if (h0 && h1) {                                                                                   \
+        const bool firstIs0 = t0n <= t1n;                                                               \
+        HPT_PUSH(firstIs0 ? q3.y : q3.x);                                                               \
+        cur = firstIs0 ? q3.x : q3.y;                                                                   \
+      } else if (h0) cur = q3.x;                                                                        \
+      else if (h1) cur = q3.y;                                                                          \
+      else if (sp > 0) HPT_POP();                                                                       \
       else cur = REF_NONE;
-      // voted exit: when only a few lanes of the wave are still walking inner nodes, serve the lanes that hold a leaf first
-      if (S.nodeMin != 0u && (uint)__popcll(__ballot((cur & REF_LEAF) == 0u)) < S.nodeMin) break;
+    if (S.nodeMin == 0u) {
+      while ((cur & REF_LEAF) == 0u) { HPT_NODE_STEP(o) }
+    } else {
+      while ((cur & REF_LEAF) == 0u) {
+        HPT_NODE_STEP(o)
+        if ((uint)__popcll(__ballot((cur & REF_LEAF) == 0u)) < S.nodeMin) break;
+      }
     }
     if (cur == REF_NONE) break;
     if ((cur & REF_LEAF) == 0u) continue;
@@ -924,23 +938,13 @@ HPT_DEV bool traceRayFlat(const DevScene& S, const V3 wo, const V3 wd, float tne
 #define HPT_PUSH(v) do { if (DEEP) stkPush(stk, sp, (v)); else stk.lds[sp * 256] = (v); sp++; } while (0)
 #define HPT_POP()   do { sp--; cur = DEEP ? stkPop(stk, sp) : stk.lds[sp * 256]; } while (0)
   while (true) {
-    while ((cur & REF_LEAF) == 0u) {
-      const float4* np = (const float4*)(S.nodes + cur);
-      const float4 q0 = np[0], q1 = np[1], q2 = np[2];
-      const uint4  q3 = ((const uint4*)np)[3];
-      if (STATS) { st.nodes++; if (firstActiveLane()) st.waveNodeIters++; }
-      bool h0, h1; float t0n, t1n;
-      nodeSlabs(q0, q1, q2, wo, id, tnear, hit.t, h0, h1, t0n, t1n);
-      if (h0 && h1) {
-        const bool firstIs0 = t0n <= t1n;
-        HPT_PUSH(firstIs0 ? q3.y : q3.x);
-        cur = firstIs0 ? q3.x : q3.y;
-      } else if (h0) cur = q3.x;
-      else if (h1) cur = q3.y;
-      else if (sp > 0) HPT_POP();
-      else cur = REF_NONE;
-      // voted exit: when only a few lanes of the wave are still walking inner nodes, serve the lanes that hold a leaf first
-      if (S.nodeMin != 0u && (uint)__popcll(__ballot((cur & REF_LEAF) == 0u)) < S.nodeMin) break;
+    if (S.nodeMin == 0u) {
+      while ((cur & REF_LEAF) == 0u) { HPT_NODE_STEP(wo) }
+    } else {
+      while ((cur & REF_LEAF) == 0u) {
+        HPT_NODE_STEP(wo)
+        if ((uint)__popcll(__ballot((cur & REF_LEAF) == 0u)) < S.nodeMin) break;
+      }
     }
     if (cur == REF_NONE) break;
     if ((cur & REF_LEAF) == 0u) continue;
@@ -987,6 +991,7 @@ HPT_DEV bool traceRayFlat(const DevScene& S, const V3 wo, const V3 wd, float tne
   }
 #undef HPT_PUSH
 #undef HPT_POP
+#undef HPT_NODE_STEP
   return found;
 }
 

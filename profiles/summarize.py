@@ -15,26 +15,37 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
 
 
+CALLS = 3     # profiles/collect.sh runs bench.py --steps 2 --warmup 1: three PathTraceBlock calls
+
+
+def product_kernel(name):
+    """Kernels of one PathTraceBlock call: the persistent megakernel, or the wavefront schedule's shade / trace / init kernels.
+    The instrumented build (first template argument true / third for the trace kernel) is bench.py's counting probe, never timed."""
+    if "pathTraceKernel" in name:
+        return "<true" not in name
+    return "wfTraceKernel" in name or "wfShadeKernel" in name or "wfInitKernel" in name
+
+
 def pmc(sub):
     f = glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv"))[0]
     per = {}
     for r in csv.DictReader(open(f)):
-        if "pathTraceKernel" in r["Kernel_Name"] and "<true" not in r["Kernel_Name"]:
-            per.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
-            per[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
-    return {k: sum(v.values()) / len(v) for k, v in per.items()}     # mean per launch
+        if product_kernel(r["Kernel_Name"]):
+            per[r["Counter_Name"]] = per.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    return {k: v / CALLS for k, v in per.items()}     # mean per PathTraceBlock call
 
 
 stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(root, "profiles", f"{tag}_kernel_stats.csv"))
-kavg = None
+kavg, per_kernel = 0.0, {}
 for r in csv.DictReader(open(stats)):
-    if "pathTraceKernel" in r["Name"] and "<true" not in r["Name"]:
-        kavg = float(r["AverageNs"]) * 1e-6
+    if product_kernel(r["Name"]):
+        kavg += float(r["TotalDurationNs"]) * 1e-6 / CALLS
+        per_kernel[r["Name"].split("(")[0]] = {"calls": int(r["Calls"]), "total_ms": float(r["TotalDurationNs"]) * 1e-6, "avg_us": float(r["AverageNs"]) * 1e-3}
 f, w = pmc("pmc_fetch"), pmc("pmc_write")
 fetch_kb, write_kb = f.get("FETCH_SIZE", 0.0), w.get("WRITE_SIZE", 0.0)
 bench = json.loads(open(os.path.join(src, "bench_line.json")).read())
-out = {"tag": tag, "workload": workload, "bench": bench, "rocprof_kernel_avg_ms": kavg,
+out = {"tag": tag, "workload": workload, "bench": bench, "rocprof_kernel_ms_per_call": kavg, "rocprof_kernels": per_kernel,
        "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
        "hbm_bytes_per_launch": fetch_kb * 2 * 1024 + write_kb * 1024,
        "hbm_bytes_per_launch_raw_fetch": fetch_kb * 1024 + write_kb * 1024,

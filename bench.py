@@ -150,7 +150,7 @@ def main():
                          "(interleaved 1024-tid chunks, bit-identical to the single-GPU frame)")
     ap.add_argument("--emulate-share", type=int, default=1, help="study only: render rank 0's share of a K-rank job on one GPU (value = K x its rate: the K-GPU rate without the reduce)")
     ap.add_argument("--accel-layout", type=int, default=0, help="0 automatic, 1 two-level TLAS/BLAS, 2 single-level world-space BVH")
-    ap.add_argument("--sort-rays", type=int, default=0, help="wavefront: 1 off, 2 sort the ray queue by a coherence key")
+    ap.add_argument("--groups", type=int, default=0, help="wavefront: concurrent pixel groups (streams) per call, 0 = automatic")
     ap.add_argument("--verify", action="store_true", help="rank 0 re-renders the whole frame alone and checks the sharded frame is bit-identical")
     args = ap.parse_args()
 
@@ -194,8 +194,8 @@ def main():
     integ = HipIntegrator(sc, device=dev_index, accel_layout=args.accel_layout)
     if args.blocks_per_cu:
         integ.set_launch_config(args.blocks_per_cu)
-    if args.schedule or args.refill_below or args.trace_blocks_per_cu or args.sort_rays:
-        integ.set_schedule(args.schedule, args.refill_below, args.trace_blocks_per_cu, args.sort_rays)
+    if args.schedule or args.refill_below or args.trace_blocks_per_cu or args.groups:
+        integ.set_schedule(args.schedule, args.refill_below, args.trace_blocks_per_cu, args.groups)
     N = W * H
     from hydracore3_amd.sharding import tid_interleave
     weak = args.scaling == "weak"

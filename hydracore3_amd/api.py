@@ -60,6 +60,7 @@ ABI = {
     "hpt_set_accel_layout": (_i, [_vp, _i]),
     "hpt_set_schedule": (_i, [_vp, _i, _i, _i, _i]),
     "hpt_get_schedule": (_i, [_vp, C.POINTER(_i), C.POINTER(_u32)]),
+    "hpt_set_option": (_i, [_vp, C.c_char_p, _i]),
     "hpt_last_kernel_ms": (_i, [_vp, C.POINTER(_f)]),
 }
 
@@ -240,9 +241,12 @@ class HipIntegrator:
     def set_tid_interleave(self, chunk: int, stride: int):
         self._chk(self.L.hpt_set_tid_interleave(self.h, chunk, stride))
 
-    def set_schedule(self, schedule: int, refill_below: int = 0, trace_blocks_per_cu: int = 0, sort_rays: int = 0):
+    def set_schedule(self, schedule: int, refill_below: int = 0, trace_blocks_per_cu: int = 0, groups: int = 0):
         """0 automatic, 1 persistent megakernel, 2 wavefront (shade kernel + trace kernel with ray replacement)."""
-        self._chk(self.L.hpt_set_schedule(self.h, schedule, refill_below, trace_blocks_per_cu, sort_rays))
+        self._chk(self.L.hpt_set_schedule(self.h, schedule, refill_below, trace_blocks_per_cu, groups))
+
+    def set_option(self, name: str, value: int):
+        self._chk(self.L.hpt_set_option(self.h, name.encode(), value))
 
     def last_schedule(self):
         s, it = C.c_int(0), C.c_uint32(0)

@@ -11,7 +11,6 @@
 #include "../../include/hydra_hip.h"
 #include "hpt_kernels.hip"
 #include "hpt_wavefront.hip"
-#include <hipcub/hipcub.hpp>
 #include "bvh_build.h"
 
 static const uint MAX_STACK = 64;
@@ -76,12 +75,19 @@ struct hpt_ctx
   DevBuf<uint> dQueue, dStackOvf; DevBuf<Counters> dCounters;
   DevBuf<float> dFrame, dRecord, dRef, dData, dGrad, dLoss;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  // wavefront schedule (hpt_wavefront.hip): path pool in HBM, ray queues, host-visible progress words
-  DevBuf<float4> wfF4[8]; DevBuf<uint> wfU[8]; DevBuf<unsigned char> wfSortTmp;
-  int  wfSort = 0;                       // 1: radix-sort the ray queue by a coherence key before every trace pass
-  float sceneMin[3] = {0, 0, 0}, sceneMax[3] = {1, 1, 1};
-  uint* wfProgress = nullptr;            // pinned: active-slot count after every WF_CHECK-th shade pass
-  hipEvent_t wfEv[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // wavefront schedule (hpt_wavefront.hip): the pixels of a call are cut into groups, each with its own path pool, ray queue and
+  // stream, so that the tail of one group's trace pass overlaps the other groups' work
+  struct WfGroup
+  {
+    DevBuf<float4> f4[8]; DevBuf<uint> u[9];
+    hipStream_t stream = nullptr; hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t done = nullptr;
+    uint* progress = nullptr;            // pinned: rays queued after every WF_CHECK-th shade pass (0 = group finished)
+    uint checkpoints = 0, itemBase = 0, itemCount = 0; unsigned long long it = 0; bool finished = false;
+  };
+  std::vector<WfGroup*> wfGroups;
+  hipEvent_t wfFork = nullptr;
+  int  wfGroupCount = 0;                 // 0 = automatic
+  uint wfGrace = 16;                     // trips a trace wave keeps going after the queue ran dry before it suspends its rays (0 = never)
   int  schedule = 0;                     // 0 automatic, 1 megakernel, 2 wavefront (hpt_set_schedule)
   int  nodeMinOverride = -1;             // env HPT_NODE_MIN (tuning): overrides the per-scene choice of DevScene::nodeMin
   uint wfRefillBelow = 56;               // a trace wave refills from the queue when fewer lanes than this still hold a ray
@@ -125,6 +131,7 @@ extern "C" int hpt_create(int device, hpt_ctx** out)
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) { c->numCUs = prop.multiProcessorCount; c->devName = prop.gcnArchName; }
   (void)hipEventCreate(&c->ev0); (void)hipEventCreate(&c->ev1);
   if (const char* e = std::getenv("HPT_NODE_MIN")) c->nodeMinOverride = std::atoi(e) & 63;
+  if (const char* e = std::getenv("HPT_WF_GRACE")) c->wfGrace = (uint)std::atoi(e);
   std::memset(&c->S, 0, sizeof(DevScene));
   c->S.rootRef = REF_NONE;
   *out = c;
@@ -141,10 +148,16 @@ extern "C" void hpt_destroy(hpt_ctx* c)
   c->dRemapLists.release(); c->dMaterials.release(); c->dLights.release(); c->dTextures.release(); c->dGens.release();
   c->dQueue.release(); c->dStackOvf.release(); c->dCounters.release(); c->dFrame.release(); c->dRecord.release(); c->dRef.release(); c->dData.release();
   c->dGrad.release(); c->dLoss.release();
-  for (auto& b : c->wfF4) b.release();
-  for (auto& b : c->wfU) b.release();
-  if (c->wfProgress) (void)hipHostFree(c->wfProgress);
-  for (auto& e : c->wfEv) if (e) (void)hipEventDestroy(e);
+  for (hpt_ctx::WfGroup* g : c->wfGroups) {
+    for (auto& b : g->f4) b.release();
+    for (auto& b : g->u) b.release();
+    if (g->progress) (void)hipHostFree(g->progress);
+    for (auto& e : g->ev) if (e) (void)hipEventDestroy(e);
+    if (g->done) (void)hipEventDestroy(g->done);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+  }
+  if (c->wfFork) (void)hipEventDestroy(c->wfFork);
   for (void* p : c->texData) if (p) (void)hipFree(p);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -275,19 +288,6 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   for (const Inst& in : c->insts) instTris += c->geoms[in.geomId].idx.size() / 3;
   c->instTris = instTris;
   c->S.nodeMin = c->nodeMinOverride >= 0 ? (uint)c->nodeMinOverride : (instTris >= HEAVY_SCENE_TRIS ? 16u : 0u);
-  {                                                         // world bounds (ray-sort keys of the wavefront schedule)
-    Aabb w; w.reset();
-    for (const Inst& in : c->insts) {
-      const Geom& g = c->geoms[in.geomId];
-      if (g.bvh.rootRef == REF_NONE) continue;
-      for (int k = 0; k < 8; k++) {
-        const float p[3] = { (k & 1) ? g.bvh.bounds.hi[0] : g.bvh.bounds.lo[0], (k & 2) ? g.bvh.bounds.hi[1] : g.bvh.bounds.lo[1], (k & 4) ? g.bvh.bounds.hi[2] : g.bvh.bounds.lo[2] };
-        const float q[3] = { in.m[0] * p[0] + in.m[4] * p[1] + in.m[8] * p[2] + in.m[12], in.m[1] * p[0] + in.m[5] * p[1] + in.m[9] * p[2] + in.m[13], in.m[2] * p[0] + in.m[6] * p[1] + in.m[10] * p[2] + in.m[14] };
-        w.grow(q);
-      }
-    }
-    for (int a = 0; a < 3; a++) { c->sceneMin[a] = w.lo[a] <= w.hi[a] ? w.lo[a] : 0.0f; c->sceneMax[a] = w.lo[a] <= w.hi[a] ? w.hi[a] : 1.0f; }
-  }
   // Automatic choice, measured: heavy static scenes (wavefront schedule) gain 8 % from the single-level layout (1M triangles: 191 -> 207
   // Mpaths/s; no instance enter / leave trips, triangle-loop lane utilisation 0.21 -> 0.38); the Cornell-box class on the megakernel loses
   // 8 % to it (looser world-space boxes around rotated instances, per-triangle ray transform) and keeps the two-level TLAS/BLAS layout.
@@ -678,6 +678,7 @@ static const size_t WF_AUTO_TRIS = HEAVY_SCENE_TRIS;
 static const uint   WF_POOL_MAX = 1u << 22;        // pool slots (pixels in flight) per batch: 4M x 148 B = 620 MB
 static const uint   WF_CHECK = 8;                  // progress word copied back every WF_CHECK shade passes
 static const uint   WF_RING = 8;                   // ... and at most WF_RING such checkpoints in flight
+static const uint   WF_GROUPS_AUTO = 2;            // concurrent pixel groups (streams) per call
 
 static bool useWavefront(hpt_ctx* c, bool naive, bool dr, bool stats)
 {
@@ -688,88 +689,117 @@ static bool useWavefront(hpt_ctx* c, bool naive, bool dr, bool stats)
 }
 
 template <bool STATS>
-static void launchWfTrace(hpt_ctx* c, const WfPool& P, uint iter, int blocks, hipStream_t st, bool deep)
+static void launchWfTrace(hpt_ctx* c, const WfPool& P, uint iter, int blocks, hipStream_t st, bool deep, uint* ovf)
 {
-  uint* ovf = c->dStackOvf.p; const uint lanes = (uint)blocks * 256u; Counters* cn = c->dCounters.p;
+  const uint lanes = (uint)blocks * 256u; Counters* cn = c->dCounters.p;
+  const uint grace = c->wfGrace;
   if (c->S.flatMode) {
-    if (deep) wfTraceKernel<true, true, STATS><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, ovf, lanes, cn);
-    else      wfTraceKernel<false, true, STATS><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, ovf, lanes, cn);
+    if (deep) wfTraceKernel<true, true, STATS><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
+    else      wfTraceKernel<false, true, STATS><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
   } else {
-    if (deep) wfTraceKernel<true, false, STATS><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, ovf, lanes, cn);
-    else      wfTraceKernel<false, false, STATS><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, ovf, lanes, cn);
+    if (deep) wfTraceKernel<true, false, STATS><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
+    else      wfTraceKernel<false, false, STATS><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
   }
 }
 
 static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st)
 {
-  const uint pool = std::min(job.tidCount, WF_POOL_MAX);
-  for (int i = 0; i < 8; i++) HIPCHK(c, c->wfF4[i].alloc(pool));
-  for (int i = 0; i < 3; i++) HIPCHK(c, c->wfU[i].alloc(pool));
-  for (int i = 3; i < 7; i++) HIPCHK(c, c->wfU[i].alloc(2 * (size_t)pool));     // ray queue + keys, and their sorted copies
-  HIPCHK(c, c->wfU[7].alloc(2 * WF_CTR_WORDS));
-  if (!c->wfProgress) HIPCHK(c, hipHostMalloc((void**)&c->wfProgress, WF_RING * sizeof(uint)));
-  for (auto& e : c->wfEv) if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  WfPool P;
-  P.rayO = c->wfF4[0].p; P.rayD = c->wfF4[1].p; P.thr = c->wfF4[2].p; P.acc = c->wfF4[3].p;
-  P.shO = c->wfF4[4].p; P.shD = c->wfF4[5].p; P.contrib = c->wfF4[6].p; P.hit = c->wfF4[7].p;
-  P.hitInst = c->wfU[0].p; P.occl = c->wfU[1].p; P.status = c->wfU[2].p; P.rayQ = c->wfU[3].p; P.rayKey = c->wfU[4].p; P.ctr = c->wfU[7].p;
-  WfPool Psorted = P; Psorted.rayQ = c->wfU[5].p; Psorted.rayKey = c->wfU[6].p;
-  size_t sortBytes = 0;
-  const bool sortRays = c->wfSort != 0;
-  if (sortRays) {
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sortBytes, P.rayKey, Psorted.rayKey, P.rayQ, Psorted.rayQ, 2 * (size_t)pool, 9, 31, st);
-    HIPCHK(c, c->wfSortTmp.alloc(sortBytes));
+  // ---- groups: contiguous runs of work items, whole 256-item blocks each ----
+  uint nGroups = c->wfGroupCount > 0 ? (uint)c->wfGroupCount : WF_GROUPS_AUTO;
+  nGroups = std::max(nGroups, (job.tidCount + WF_POOL_MAX - 1) / WF_POOL_MAX);
+  nGroups = std::min(nGroups, std::max(1u, job.tidCount / 4096u));             // tiny calls: one group
+  nGroups = std::min(nGroups, 64u);
+  const uint per = (((job.tidCount + nGroups - 1) / nGroups) + 255u) & ~255u;
+  while (c->wfGroups.size() < nGroups) {
+    hpt_ctx::WfGroup* g = new hpt_ctx::WfGroup();
+    c->wfGroups.push_back(g);
+    HIPCHK(c, hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    HIPCHK(c, hipHostMalloc((void**)&g->progress, WF_RING * sizeof(uint)));
+    for (auto& e : g->ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&g->done, hipEventDisableTiming));
   }
+  if (!c->wfFork) HIPCHK(c, hipEventCreateWithFlags(&c->wfFork, hipEventDisableTiming));
 
   int bpc = c->wfBlocksPerCU > 0 ? c->wfBlocksPerCU : HPT_WF_WAVES;
   const int traceBlocks = c->numCUs * bpc;
-  HIPCHK(c, ensureStackOverflow(c, (size_t)traceBlocks * 256));
+  // HBM part of the traversal stacks: one slice per group (their trace kernels run concurrently)
+  HIPCHK(c, ensureStackOverflow(c, (size_t)traceBlocks * 256 * nGroups));
+  const size_t ovfPerGroup = c->dStackOvf.n / nGroups;
   const bool deep = c->stackNeeded > (uint)LDS_STACK;
   const bool stats = c->instrument;
   if (stats) { HIPCHK(c, c->dCounters.alloc(1)); HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(Counters), st)); }
 
   WfJob wj;
   wj.tidBegin = job.tidBegin; wj.tidChunk = job.tidChunk; wj.tidStride = job.tidStride; wj.tidEnd = job.tidEnd;
-  wj.sortRays = sortRays ? 1u : 0u;
-  for (int a = 0; a < 3; a++) { wj.bbMin[a] = c->sceneMin[a]; const float e = c->sceneMax[a] - c->sceneMin[a]; wj.bbScale[a] = e > 0.0f ? 128.0f / e : 0.0f; }
   wj.passNum = job.passNum; wj.channels = job.channels; wj.outColor = job.outColor; wj.gens = job.gens; wj.packedXY = job.packedXY;
   // every path takes at most traceDepth shade passes after the one that generated it; the pass that ends it (or the next one, when a
   // shadow ray was outstanding) also generates the pixel's next path
-  const unsigned long long iterCap = (unsigned long long)job.passNum * (c->S.traceDepth + 2ull) + 4ull;
+  // safety net only (the loop ends when a round queues no ray): pixels whose rays were suspended sit rounds out, so there is no tight bound
+  const unsigned long long iterCap = 64ull * ((unsigned long long)job.passNum * (c->S.traceDepth + 2ull) + 4ull);
   c->lastWfIters = 0;
   HIPCHK(c, hipEventRecord(c->ev0, st));
-  for (uint base = 0; base < job.tidCount; base += pool) {
-    wj.itemBase = base; wj.itemCount = std::min(pool, job.tidCount - base);
-    const uint shadeBlocks = (wj.itemCount + 255u) / 256u;
-    HIPCHK(c, hipMemsetAsync(P.ctr, 0, 2 * WF_CTR_WORDS * sizeof(uint), st));
-    wfInitKernel<<<dim3(shadeBlocks), dim3(256), 0, st>>>(P, wj.itemCount, job.passNum);
-    uint checkpoints = 0; bool finished = false;
-    for (unsigned long long it = 0; it < iterCap && !finished; it++) {
-      wj.iter = (uint)it;
-      if (sortRays) HIPCHK(c, hipMemsetAsync(P.rayKey, 0xFF, 2 * (size_t)wj.itemCount * sizeof(uint), st));
-      wfShadeKernel<<<dim3(shadeBlocks), dim3(256), 0, st>>>(c->S, P, wj);
-      if ((it % WF_CHECK) == WF_CHECK - 1) {
-        const uint slot = checkpoints % WF_RING;
-        if (checkpoints >= WF_RING) {                                       // oldest checkpoint of the ring: wait for it, then look at it
-          HIPCHK(c, hipEventSynchronize(c->wfEv[slot]));
-          if (c->wfProgress[slot] == 0u) { finished = true; break; }
+  HIPCHK(c, hipEventRecord(c->wfFork, st));
+
+  std::vector<WfPool> pools(nGroups);
+  uint live = 0;
+  for (uint gi = 0; gi < nGroups; gi++) {
+    hpt_ctx::WfGroup& g = *c->wfGroups[gi];
+    g.itemBase = std::min(gi * per, job.tidCount); g.itemCount = std::min(per, job.tidCount - g.itemBase);
+    g.it = 0; g.checkpoints = 0; g.finished = g.itemCount == 0;
+    if (g.finished) continue;
+    live++;
+    for (int i = 0; i < 8; i++) HIPCHK(c, g.f4[i].alloc(g.itemCount));
+    for (int i = 0; i < 3; i++) HIPCHK(c, g.u[i].alloc(g.itemCount));
+    const size_t maxSusp = (size_t)traceBlocks * 256, suspWords = (WF_SUSP_WORDS + (size_t)std::max(c->stackNeeded, 1u)) * maxSusp;
+    HIPCHK(c, g.u[3].alloc(2 * (size_t)g.itemCount + maxSusp)); HIPCHK(c, g.u[5].alloc(2 * (size_t)g.itemCount + maxSusp));
+    HIPCHK(c, g.u[4].alloc(2 * WF_CTR_WORDS));
+    HIPCHK(c, g.u[6].alloc(g.itemCount));
+    HIPCHK(c, g.u[7].alloc(suspWords)); HIPCHK(c, g.u[8].alloc(suspWords));
+    WfPool& P = pools[gi];
+    P.rayO = g.f4[0].p; P.rayD = g.f4[1].p; P.thr = g.f4[2].p; P.acc = g.f4[3].p;
+    P.shO = g.f4[4].p; P.shD = g.f4[5].p; P.contrib = g.f4[6].p; P.hit = g.f4[7].p;
+    P.hitInst = g.u[0].p; P.occl = g.u[1].p; P.status = g.u[2].p; P.rayQ[0] = g.u[3].p; P.rayQ[1] = g.u[5].p; P.ctr = g.u[4].p; P.inflight = g.u[6].p;
+    P.susp[0] = g.u[7].p; P.susp[1] = g.u[8].p; P.maxSusp = (uint)maxSusp; P.suspStack = std::max(c->stackNeeded, 1u);
+    HIPCHK(c, hipStreamWaitEvent(g.stream, c->wfFork, 0));
+    HIPCHK(c, hipMemsetAsync(P.ctr, 0, 2 * WF_CTR_WORDS * sizeof(uint), g.stream));
+    wfInitKernel<<<dim3((g.itemCount + 255u) / 256u), dim3(256), 0, g.stream>>>(P, g.itemCount, job.passNum);
+  }
+  // ---- rounds: one shade + trace pass per live group, groups interleaved so that their kernels overlap on the device ----
+  while (live > 0) {
+    for (uint gi = 0; gi < nGroups; gi++) {
+      hpt_ctx::WfGroup& g = *c->wfGroups[gi];
+      if (g.finished) continue;
+      const WfPool& P = pools[gi];
+      wj.itemBase = g.itemBase; wj.itemCount = g.itemCount; wj.iter = (uint)g.it;
+      wfShadeKernel<<<dim3((g.itemCount + 255u) / 256u), dim3(256), 0, g.stream>>>(c->S, P, wj);
+      if ((g.it % WF_CHECK) == WF_CHECK - 1) {
+        const uint slot = g.checkpoints % WF_RING;
+        if (g.checkpoints >= WF_RING) {                                     // oldest checkpoint of the ring: wait for it, then look at it
+          HIPCHK(c, hipEventSynchronize(g.ev[slot]));
+          if (g.progress[slot] == 0u) g.finished = true;
         }
-        HIPCHK(c, hipMemcpyAsync(&c->wfProgress[slot], P.ctr + WF_CTR_WORDS * (wj.iter & 1u), sizeof(uint), hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipEventRecord(c->wfEv[slot], st));
-        checkpoints++;
-        // newer checkpoints that have already landed
-        for (uint k = 1; k < WF_RING && k < checkpoints; k++) {
-          const uint sl = (checkpoints - 1 - k) % WF_RING;
-          if (hipEventQuery(c->wfEv[sl]) == hipSuccess && c->wfProgress[sl] == 0u) { finished = true; break; }
+        if (!g.finished) {
+          HIPCHK(c, hipMemcpyAsync(&g.progress[slot], P.ctr + WF_CTR_WORDS * (wj.iter & 1u), sizeof(uint), hipMemcpyDeviceToHost, g.stream));
+          HIPCHK(c, hipEventRecord(g.ev[slot], g.stream));
+          g.checkpoints++;
+          for (uint k = 1; k < WF_RING && k < g.checkpoints; k++) {         // newer checkpoints that have already landed
+            const uint sl = (g.checkpoints - 1 - k) % WF_RING;
+            if (hipEventQuery(g.ev[sl]) == hipSuccess && g.progress[sl] == 0u) { g.finished = true; break; }
+          }
         }
-        if (finished) break;
       }
-      if (sortRays) {                                                       // unused entries carry key 0xFFFFFFFF and sort to the end
-        HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->wfSortTmp.p, sortBytes, P.rayKey, Psorted.rayKey, P.rayQ, Psorted.rayQ, 2 * (size_t)wj.itemCount, 9, 31, st));
+      if (!g.finished) {
+        uint* ovf = c->dStackOvf.p + gi * ovfPerGroup;
+        if (stats) launchWfTrace<true>(c, P, wj.iter, traceBlocks, g.stream, deep, ovf); else launchWfTrace<false>(c, P, wj.iter, traceBlocks, g.stream, deep, ovf);
+        g.it++;
+        if (gi == 0) c->lastWfIters++;
+        if (g.it >= iterCap) g.finished = true;
       }
-      const WfPool& T = sortRays ? Psorted : P;
-      if (stats) launchWfTrace<true>(c, T, wj.iter, traceBlocks, st, deep); else launchWfTrace<false>(c, T, wj.iter, traceBlocks, st, deep);
-      c->lastWfIters++;
+      if (g.finished) {
+        live--;
+        HIPCHK(c, hipEventRecord(g.done, g.stream));
+        HIPCHK(c, hipStreamWaitEvent(st, g.done, 0));
+      }
     }
     HIPCHK(c, hipGetLastError());
   }
@@ -934,13 +964,22 @@ extern "C" int hpt_set_tid_interleave(hpt_ctx* c, uint32_t chunk, uint32_t strid
   return HPT_OK;
 }
 extern "C" int hpt_set_launch_config(hpt_ctx* c, int blocksPerCU) { if (!c || blocksPerCU < 0 || blocksPerCU > 8) return HPT_ERR_ARG; c->blocksPerCU = blocksPerCU; return HPT_OK; }
-extern "C" int hpt_set_schedule(hpt_ctx* c, int schedule, int refillBelow, int traceBlocksPerCU, int sortRays)
+extern "C" int hpt_set_schedule(hpt_ctx* c, int schedule, int refillBelow, int traceBlocksPerCU, int groups)
 {
-  if (!c || schedule < 0 || schedule > 2 || refillBelow < 0 || refillBelow > 64 || traceBlocksPerCU < 0 || traceBlocksPerCU > 8 || sortRays < 0 || sortRays > 2) return HPT_ERR_ARG;
-  if (sortRays) c->wfSort = sortRays - 1;
+  if (!c || schedule < 0 || schedule > 2 || refillBelow < 0 || refillBelow > 64 || traceBlocksPerCU < 0 || traceBlocksPerCU > 8 || groups < 0 || groups > 64) return HPT_ERR_ARG;
+  c->wfGroupCount = groups;
   c->schedule = schedule;
   if (refillBelow > 0) c->wfRefillBelow = (uint)refillBelow;
   c->wfBlocksPerCU = traceBlocksPerCU;
+  return HPT_OK;
+}
+extern "C" int hpt_set_option(hpt_ctx* c, const char* name, int value)
+{
+  if (!c || !name || value < 0) return HPT_ERR_ARG;
+  const std::string k(name);
+  if (k == "wf_grace") c->wfGrace = (uint)value;                                      // trips after the queue ran dry before a trace wave suspends its rays (0: never)
+  else if (k == "node_min") { c->nodeMinOverride = value & 63; c->accelCommitted = false; }   // voted exit of the inner-node loop; takes effect at the next CommitScene
+  else return c->fail(HPT_ERR_ARG, "hpt_set_option: unknown option " + k);
   return HPT_OK;
 }
 extern "C" int hpt_get_schedule(hpt_ctx* c, int* lastSchedule, uint32_t* lastIterations)

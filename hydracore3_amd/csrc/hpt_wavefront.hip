@@ -26,6 +26,7 @@ namespace hpt {
 
 static const uint WF_RANGES = 64u;                   // the trace kernel pulls rays from this many ranges of the queue (work stealing)
 static const uint WF_CTR_WORDS = 32u * (1u + WF_RANGES);
+static const uint WF_SUSP_WORDS = 10u;               // cur, sp, curInst, hitT, hitU, hitV, hitPrim, hitInst, found, pad
 static const uint WF_ALIVE = 1u, WF_PEND = 2u, WF_ENDING = 4u;   // status bits; passes left in bits 8..31
 
 struct WfPool
@@ -41,8 +42,12 @@ struct WfPool
   uint*   hitInst;   // instId or 0xFFFFFFFF
   uint*   occl;      // shadow ray result
   uint*   status;
-  uint*   rayQ;      // compacted ray queue: slot id | (shadow ray ? 1 << 31 : 0)
-  uint*   rayKey;    // sort key of each queue entry (only when ray sorting is on; unused entries hold 0xFFFFFFFF)
+  uint*   inflight;  // bit 0 / 1: the slot's closest-hit / shadow ray was suspended by a trace pass and has not finished yet
+  uint*   rayQ[2];   // compacted ray queue of round (iteration & 1): slot id | (shadow ray ? 1 << 31 : 0) | (resumed ray ? 1 << 30 : 0)
+  uint*   susp[2];   // traversal state of the rays a trace pass suspended, written for the NEXT round: [WF_SUSP_WORDS + stack][maxSusp],
+                     // record k belongs to queue entry k of that round (suspended rays are queued first)
+  uint    maxSusp;   // records per buffer (= lanes of the trace grid: a lane suspends at most one ray per pass)
+  uint    suspStack; // stack entries per record
   uint*   ctr;       // two sets of WF_CTR_WORDS (set iteration & 1 is live): [0] rays queued by the shade pass;
                      // [32 * (1 + r)] head of queue range r for the trace pass (one 128-byte line each: the atomics of different
                      // ranges go to different L2 channels instead of serialising on one address)
@@ -56,29 +61,12 @@ struct WfJob
   float* outColor;
   Rng*   gens;
   const uint* packedXY;
-  uint   sortRays;                // 1: also write a coherence key per queued ray (the host radix-sorts the queue before the trace kernel)
-  float  bbMin[3], bbScale[3];    // scene bounds -> [0, 1024) grid for the Morton part of the key
 };
 
 __global__ void wfInitKernel(WfPool P, uint n, uint passNum)
 {
   const uint i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) P.status[i] = passNum << 8;       // (the counters are zeroed by the host: the grid may be smaller than the counter block)
-}
-
-// Coherence key of a ray: [shadow ray][Morton code of the origin cell, 7 bits per axis][direction octant 3 bits][6 more direction bits].
-// Rays that start in the same ~1/128 cell of the scene and leave in the same direction walk the same BVH nodes: sorting the queue by
-// this key turns the per-lane node fetches of a wave into hits on the lines its neighbours just pulled in.
-HPT_DEV uint spread7(uint v) { v &= 0x7Fu; v = (v | (v << 8)) & 0x0000700Fu; v = (v | (v << 4)) & 0x000430C3u; v = (v | (v << 2)) & 0x00049249u; return v; }
-HPT_DEV uint rayKey(const WfJob& job, V3 o, V3 d, bool shadow)
-{
-  const float fx = fminf(fmaxf((o.x - job.bbMin[0]) * job.bbScale[0], 0.0f), 127.0f);
-  const float fy = fminf(fmaxf((o.y - job.bbMin[1]) * job.bbScale[1], 0.0f), 127.0f);
-  const float fz = fminf(fmaxf((o.z - job.bbMin[2]) * job.bbScale[2], 0.0f), 127.0f);
-  const uint m = spread7((uint)fx) | (spread7((uint)fy) << 1) | (spread7((uint)fz) << 2);            // 21 bits
-  const uint oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
-  const uint fine = ((uint)(absf(d.x) * 3.999f)) | (((uint)(absf(d.y) * 3.999f)) << 2) | (((uint)(absf(d.z) * 3.999f)) << 4);   // 6 bits
-  return (shadow ? 0x40000000u : 0u) | (m << 9) | (oct << 6) | fine;
+  if (i < n) { P.status[i] = passNum << 8; P.inflight[i] = 0u; }       // (the counters are zeroed by the host: the grid may be smaller than the counter block)
 }
 
 // Ray compaction. Every wave ballots its two kinds of rays and prefix-sums the lanes (mbcnt); the four waves of the block add
@@ -117,12 +105,12 @@ __global__ void __launch_bounds__(256) wfShadeKernel(const DevScene S, const WfP
     tid = job.tidBegin + (k / job.tidChunk) * job.tidChunk * job.tidStride + (k % job.tidChunk);
     valid = tid < job.tidEnd;
   }
+  if (valid && P.inflight[s] != 0u) valid = false;       // a suspended ray of this pixel is still being traced: the pixel sits this round out
   uint st = valid ? P.status[s] : 0u;
   uint passes = st >> 8;
   bool alive = (st & WF_ALIVE) != 0u, pend = (st & WF_PEND) != 0u, ending = (st & WF_ENDING) != 0u;
   const bool active = valid && (alive || pend || ending || passes != 0u);
   bool wantShadow = false;
-  V3 keyO = v3(0, 0, 0), keyD = v3(0, 0, 1), keySO = v3(0, 0, 0), keySD = v3(0, 0, 1);
 
   if (active) {
     Rng gen = job.gens[tid];
@@ -179,19 +167,15 @@ __global__ void __launch_bounds__(256) wfShadeKernel(const DevScene S, const WfP
       P.shD[s] = make_float4(shDir.x, shDir.y, shDir.z, 0.0f);
       P.contrib[s] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
     }
-    keyO = rpos; keyD = rdir; keySO = shPos; keySD = shDir;
     P.status[s] = (passes << 8) | (alive ? WF_ALIVE : 0u) | (wantShadow ? WF_PEND : 0u) | (ending ? WF_ENDING : 0u);
   }
   // ray compaction: ballot + prefix sum, one atomic per wave and queue
   const bool qNear = active && alive, qShad = active && wantShadow;
   uint kn, ks;
   blockAppend(&ctr[0], qNear, qShad, kn, ks);
-  if (qNear) P.rayQ[kn] = s;
-  if (qShad) P.rayQ[ks] = s | 0x80000000u;
-  if (job.sortRays) {
-    if (qNear) P.rayKey[kn] = rayKey(job, keyO, keyD, false);
-    if (qShad) P.rayKey[ks] = rayKey(job, keySO, keySD, true);
-  }
+  uint* rayQ = P.rayQ[job.iter & 1u];
+  if (qNear) rayQ[kn] = s;
+  if (qShad) rayQ[ks] = s | 0x80000000u;
 }
 
 // ---- persistent traversal with ray replacement -------------------------------------------------------------------------------
@@ -199,17 +183,24 @@ __global__ void __launch_bounds__(256) wfShadeKernel(const DevScene S, const WfP
 #define HPT_WF_WAVES 6   // 16 KB traversal stacks + 8 KB ray stashes per block: six blocks fill the CU's 160 KB of LDS; 80 VGPRs, no spills
 #endif
 template <bool DEEP, bool FLAT, bool STATS>
-__global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScene S, const WfPool P, uint iter, uint refillBelow,
+__global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScene S, const WfPool P, uint iter, uint refillBelow, uint grace,
                                                                    uint* stackOverflow, uint gridLanes, Counters* counters)
 {
   __shared__ uint stackMem[LDS_STACK * 256];
   const uint glane = blockIdx.x * 256u + threadIdx.x;
   TravStack stk; stk.lds = &stackMem[threadIdx.x]; stk.ovf = stackOverflow + glane; stk.ovfStride = gridLanes;
   uint* ctr = P.ctr + WF_CTR_WORDS * (iter & 1u);
+  uint* ctrNext = P.ctr + WF_CTR_WORDS * ((iter + 1u) & 1u);
+  const uint* rayQ = P.rayQ[iter & 1u];
+  uint* rayQNext = P.rayQ[(iter + 1u) & 1u];
+  const uint* suspIn = P.susp[iter & 1u];
+  uint* suspOut = P.susp[(iter + 1u) & 1u];
+  const size_t SM = P.maxSusp;
   const uint total = ctr[0];
+  if (total < 2u * gridLanes) grace = 0u;     // a round without surplus rays is all tail: suspending would only multiply the rounds
   if (S.rootRef == REF_NONE) {                                               // empty scene: every ray misses
     for (uint k = glane; k < total; k += gridLanes) {
-      const uint q = P.rayQ[k];
+      const uint q = rayQ[k];
       if ((q >> 31) == 0u) P.hitInst[q] = 0xFFFFFFFFu; else P.occl[q & 0x7FFFFFFFu] = 0u;
     }
     return;
@@ -218,13 +209,18 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
   __shared__ uint stashMem[4 * 8 * 64];
   uint* stash = stashMem + (threadIdx.x >> 6) * (8 * 64);
   const uint lane = threadIdx.x & 63u;
-  bool has = false, isAny = false, found = false;
+  bool has = false, isAny = false, found = false, resumed = false;
+  uint dryTrips = 0;
   uint range = (glane >> 6) % WF_RANGES, tried = 0, stashCount = 0;          // wave-uniform
   uint slot = 0, cur = REF_NONE, curInst = 0xFFFFFFFFu;
   int  sp = 0;
   V3 wo = v3(0, 0, 0), wd = v3(0, 0, 1), o = wo, d = wd, id = v3(0, 0, 0);
   float hitT = 0.0f, hitU = 0.0f, hitV = 0.0f; uint hitPrim = 0, hitInst = 0xFFFFFFFFu;
-  unsigned long long nodeLane = 0, nodeWave = 0, triLane = 0, triWave = 0, refills = 0;
+  unsigned long long nodeLane = 0, nodeWave = 0, triLane = 0, triWave = 0, refills = 0, suspended = 0;
+  unsigned long long tPh[4] = {0, 0, 0, 0}, tPrev = 0, trips = 0;            // STATS: wave cycles in refill / node loop / leaves / ray end
+#define WSTAMP(i) do { if (STATS) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tPh[i] += tn - tPrev; tPrev = tn; } } while (0)
+  unsigned long long tBegin = 0, tEmpty = 0;
+  if (STATS) { tPrev = __builtin_amdgcn_s_memtime(); tBegin = tPrev; }
 
 #define HPT_PUSH(v) do { if (DEEP) stkPush(stk, sp, (v)); else stk.lds[sp * 256] = (v); sp++; } while (0)
 #define HPT_POP()   do { sp--; cur = DEEP ? stkPop(stk, sp) : stk.lds[sp * 256]; } while (0)
@@ -254,11 +250,13 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
               base = __shfl(base, 0);
               granted = base < rSize ? min(want, rSize - base) : 0u;
               if (lane < granted) {
-                const uint q = P.rayQ[rBegin + base + lane];
-                const uint sl = q & 0x7FFFFFFFu;
+                const uint k = rBegin + base + lane;
+                const uint q = rayQ[k];
+                const uint sl = q & 0x3FFFFFFFu;
                 float4 a, b;
                 if ((q >> 31) == 0u) { a = P.rayO[sl]; b = P.rayD[sl]; a.w = HPT_FLT_MAX; }
                 else                 { a = P.shO[sl]; b = P.shD[sl]; }
+                if ((q & 0x40000000u) != 0u) a.w = __uint_as_float(k);        // resumed ray: its saved state is record k
                 uint* e = stash + (stashCount + lane);
                 e[0 * 64] = __float_as_uint(a.x); e[1 * 64] = __float_as_uint(a.y); e[2 * 64] = __float_as_uint(a.z); e[3 * 64] = __float_as_uint(a.w);
                 e[4 * 64] = __float_as_uint(b.x); e[5 * 64] = __float_as_uint(b.y); e[6 * 64] = __float_as_uint(b.z); e[7 * 64] = q;
@@ -276,21 +274,39 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
           wo = v3(__uint_as_float(e[0 * 64]), __uint_as_float(e[1 * 64]), __uint_as_float(e[2 * 64])); hitT = __uint_as_float(e[3 * 64]);
           wd = v3(__uint_as_float(e[4 * 64]), __uint_as_float(e[5 * 64]), __uint_as_float(e[6 * 64]));
           const uint q = e[7 * 64];
-          slot = q & 0x7FFFFFFFu; isAny = (q >> 31) != 0u;
+          slot = q & 0x3FFFFFFFu; isAny = (q >> 31) != 0u; resumed = (q & 0x40000000u) != 0u;
           o = wo; d = wd; id = rcp3(wd);
           cur = S.rootRef; curInst = 0xFFFFFFFFu; sp = 0; found = false;
           hitPrim = 0xFFFFFFFFu; hitInst = 0xFFFFFFFFu; hitU = 0.0f; hitV = 0.0f;
+          if (resumed) {                                                    // pick the traversal up where the last pass left it
+            const uint* r = suspIn + __float_as_uint(hitT);
+            cur = r[0 * SM]; sp = (int)r[1 * SM]; curInst = r[2 * SM];
+            hitT = __uint_as_float(r[3 * SM]); hitU = __uint_as_float(r[4 * SM]); hitV = __uint_as_float(r[5 * SM]);
+            hitPrim = r[6 * SM]; hitInst = r[7 * SM]; found = r[8 * SM] != 0u;
+            for (int k = 0; k < sp; k++) { const uint v = r[(WF_SUSP_WORDS + k) * SM]; if (DEEP) stkPush(stk, k, v); else stk.lds[k * 256] = v; }
+            if (FLAT) curInst = 0xFFFFFFFFu;                                 // the object-space ray is rebuilt at the next triangle
+            else if (curInst != 0xFFFFFFFFu) {
+              const float4* ip = (const float4*)(S.insts + curInst);
+              const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
+              o = v3(r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w, r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w, r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w);
+              d = v3(r0.x * wd.x + r0.y * wd.y + r0.z * wd.z, r1.x * wd.x + r1.y * wd.y + r1.z * wd.z, r2.x * wd.x + r2.y * wd.y + r2.z * wd.z);
+              id = rcp3(d);
+            }
+          }
           has = true;
         }
         stashCount -= give;
       }
     }
     if (!__any(has)) break;
+    WSTAMP(0);
     const bool queueEmpty = (stashCount == 0u) && (tried >= WF_RANGES);      // nothing left to refill with: run the rays to the end
+    if (STATS && queueEmpty && tEmpty == 0) tEmpty = __builtin_amdgcn_s_memtime();
 
     // ---- traverse until this lane's ray is done, or the wave has thinned out and the queue can refill it ------------------
     if (has) {
       while (true) {
+        if (STATS) trips++;
         while ((cur & REF_LEAF) == 0u) {
           const float4* np = (const float4*)(S.nodes + cur);
           const float4 q0 = np[0], q1 = np[1], q2 = np[2];
@@ -310,6 +326,7 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
           // voted exit: when only a few lanes are still walking inner nodes, the lanes that already hold a leaf are served first
           if (S.nodeMin != 0u && (uint)__popcll(__ballot((cur & REF_LEAF) == 0u)) < S.nodeMin) break;
         }
+        WSTAMP(1);
         bool done = (cur == REF_NONE);
         if (!done && (cur & REF_LEAF) != 0u) {
           const uint cnt = (cur >> 28) & 7u;
@@ -362,24 +379,58 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
             if (sp > 0) HPT_POP(); else done = true;
           }
         }
+        WSTAMP(2);
         if (done) {
           if (isAny) P.occl[slot] = found ? 1u : 0u;
           else { P.hit[slot] = make_float4(hitT, hitU, hitV, __uint_as_float(hitPrim)); P.hitInst[slot] = found ? hitInst : 0xFFFFFFFFu; }
+          if (resumed) atomicAnd(&P.inflight[slot], isAny ? ~2u : ~1u);
           has = false;
           break;
         }
         if (!queueEmpty && (uint)__popcll(__ballot(true)) < refillBelow) break;
+        if (queueEmpty && grace != 0u && ++dryTrips >= grace) break;          // nothing to refill with: a few more trips, then suspend
       }
     }
+    WSTAMP(3);
+    // ---- bounded tail: the queue is dry and the grace trips are used up - park the unfinished rays for the next round's pass ----
+    if (queueEmpty && grace != 0u && __any(has && dryTrips >= grace)) {
+      const unsigned long long m = __ballot(has);
+      uint base = 0;
+      const int leader = (int)(__ffsll((long long)m) - 1);
+      if ((int)lane == leader) base = atomicAdd(&ctrNext[0], (uint)__popcll(m));
+      base = __shfl(base, leader);
+      if (has) {
+        const uint rec = base + mbcnt64(m);                                   // < maxSusp: a lane suspends at most one ray per pass
+        rayQNext[rec] = slot | (isAny ? 0x80000000u : 0u) | 0x40000000u;
+        uint* r = suspOut + rec;
+        r[0 * SM] = cur; r[1 * SM] = (uint)sp; r[2 * SM] = curInst;
+        r[3 * SM] = __float_as_uint(hitT); r[4 * SM] = __float_as_uint(hitU); r[5 * SM] = __float_as_uint(hitV);
+        r[6 * SM] = hitPrim; r[7 * SM] = hitInst; r[8 * SM] = found ? 1u : 0u;
+        for (int k = 0; k < sp; k++) r[(WF_SUSP_WORDS + k) * SM] = DEEP ? stkPop(stk, k) : stk.lds[k * 256];
+        atomicOr(&P.inflight[slot], isAny ? 2u : 1u);
+        has = false;
+        if (STATS) suspended++;
+      }
+      break;
+    }
   }
+#undef WSTAMP
 #undef HPT_PUSH
 #undef HPT_POP
   if (STATS) {
     unsigned long long v[5] = { nodeLane, nodeWave, triLane, triWave, refills };
+    { unsigned long long x = suspended; for (int o2 = 32; o2 > 0; o2 >>= 1) x += __shfl_down(x, o2); if ((threadIdx.x & 63) == 0 && x) atomicAdd(&counters->v[12], x); }
     for (int i = 0; i < 5; i++) {
       unsigned long long x = v[i];
       for (int o2 = 32; o2 > 0; o2 >>= 1) x += __shfl_down(x, o2);
       if ((threadIdx.x & 63) == 0 && x) atomicAdd(&counters->v[i], x);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      for (int i = 0; i < 4; i++) atomicAdd(&counters->v[5 + i], tPh[i]);
+      unsigned long long tr = trips;                                         // trips of lane 0 of the wave ~ wave-level trips of the leaf loop
+      atomicAdd(&counters->v[9], tr);
+      const unsigned long long tEnd = __builtin_amdgcn_s_memtime();           // wave time with nothing left to refill from (tail) / total
+      atomicAdd(&counters->v[10], tEmpty ? tEnd - tEmpty : 0ull); atomicAdd(&counters->v[11], tEnd - tBegin);
     }
   }
 }

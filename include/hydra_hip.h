@@ -176,10 +176,17 @@ int  hpt_set_accel_layout(hpt_ctx* ctx, int layout);
  * 2 = wavefront (a shade kernel and a persistent trace kernel with ballot/prefix-sum ray compaction and ray replacement, path state
  * in HBM), 0 = automatic (wavefront for scenes of >= 2^17 instanced triangles). Both give bit-identical frames. refillBelow (1..64,
  * 0 = keep): a trace wave refills from the ray queue when fewer lanes than this still hold a ray; traceBlocksPerCU 0 = automatic.
- * sortRays: 0 = keep, 1 = off, 2 = radix-sort the ray queue by a coherence key (origin cell, direction) before every trace pass.
+ * groups (0 = automatic): the pixels of a call are cut into this many groups with their own path pool, ray queue and HIP stream, so
+ * that the tail of one group's trace pass (a few long rays) overlaps the other groups' shade and trace passes.
  * The naive and differentiable integrators always use the megakernel. The wavefront call returns once the frame is nearly done
  * (it polls a device progress word); results are complete after the stream is synchronised, as for the megakernel. */
-int  hpt_set_schedule(hpt_ctx* ctx, int schedule, int refillBelow, int traceBlocksPerCU, int sortRays);
+int  hpt_set_schedule(hpt_ctx* ctx, int schedule, int refillBelow, int traceBlocksPerCU, int groups);
+/* Tuning knobs without a place in the reference's interface (results never depend on them):
+ *   "wf_grace"  trips a wavefront trace wave keeps going after the ray queue ran dry before it parks its unfinished rays (traversal
+ *               state + stack to HBM) for the next round's trace pass, which resumes them first; 0 = run every ray to the end.
+ *               Only applied in rounds with at least 2 rays per lane of the trace grid.
+ *   "node_min"  voted exit of the inner-node loop (0..63, applied at the next hpt_commit_scene; default chosen per scene). */
+int  hpt_set_option(hpt_ctx* ctx, const char* name, int value);
 /* Schedule the last hpt_path_trace_block(_dev) call used (1 / 2) and, for the wavefront one, its number of shade+trace rounds. */
 int  hpt_get_schedule(hpt_ctx* ctx, int* lastSchedule, uint32_t* lastIterations);
 /* Duration of the last path-tracing kernel, measured with HIP events on the stream it ran on (ms). */

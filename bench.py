@@ -46,25 +46,47 @@ def build_scene(workload, width, height):
     return interior_scene(width, height, subdiv=subdiv)
 
 
-def run_dr(args, rank, world, dev, stream):
-    """BASELINE.json configs[3]: IntegratorDR fwd+bwd on the test_228-class scene, 256 x 256 x 4 albedo texture, + Adam.
-    One step = memset(grad) + PathTraceDR (record, replay and adjoint fused, gradient atomics into HBM) + AdamOptimizer::step."""
+def run_dr(args, rank, world, dev, stream, dist=None, backend="nccl"):
+    """IntegratorDR fwd+bwd + Adam.  --workload dr: BASELINE.json configs[3] (test_228-class scene, 256 x 256 x 4 albedo, 512^2 @ 256 spp);
+    --workload dr_interior: configs[4] (1M-triangle interior, tex_size^2 x 4 fp32 albedo bound to its 32 gltf materials, 1920x1080).
+    One step = memset(grad) + PathTraceDR (record, replay and adjoint fused, gradient atomics into HBM) [+ all_reduce(SUM) of the
+    gradient and the loss over the ranks] + AdamOptimizer::step (every rank applies the identical step to its replica of a_data)."""
     from hydracore3_amd.api import HipIntegrator
-    from hydracore3_amd.synth import dr_scene
-    import ctypes as C
-    xml = os.path.join(ROOT, "tests", "golden", "scenes", "test_228", "statex_00001.xml")
-    W, H = args.width or 512, args.height or 512
-    spp = args.spp if args.spp != 1024 else 256
-    sc, tex_id = dr_scene(xml, W, H)
-    integ = HipIntegrator(sc, device=dev.index)
-    off, size = integ.PutDiffTex2D(tex_id, 256, 256, 4)
+    from hydracore3_amd.synth import dr_scene, interior_scene
+    big = args.workload == "dr_interior"
+    if big:
+        W, H = args.width or 1920, args.height or 1080
+        spp = args.spp if args.spp != 1024 else 16
+        ts = int(os.environ.get("HYDRA_BENCH_TEX", "4096"))
+        sc = interior_scene(W, H, tex_size=ts)                      # the generated texture is the checker the optimisation should recover
+        tex_id, tw = 1, ts                                          # (texture 0 is the white dummy)
+        tgt = sc
+    else:
+        xml = os.path.join(ROOT, "tests", "golden", "scenes", "test_228", "statex_00001.xml")
+        W, H = args.width or 512, args.height or 512
+        spp = args.spp if args.spp != 1024 else 256
+        sc, tex_id = dr_scene(xml, W, H)
+        tw = 256
+        tgt, _ = dr_scene(xml, W, H, target=True)
     N = W * H
-    # reference image: the same scene with the target (checker) albedo, a few passes on the GPU
-    tgt, _ = dr_scene(xml, W, H, target=True)
+    weak = args.scaling == "weak"
+    # reference image: the same scene with the target (checker) albedo, a few passes on the GPU (identical on every rank)
     tgt_int = HipIntegrator(tgt, device=dev.index)
     ref = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     tgt_int.path_trace_block_dev(ref.data_ptr(), 64, 0, N, 4, False, stream)
+    torch.cuda.synchronize()
     ref = torch.flip(ref / 64.0, dims=[0]).contiguous()            # PixelLossPT reads the reference y-flipped (integrator_dr.cpp:1119)
+    del tgt_int
+    integ = HipIntegrator(sc, device=dev.index)
+    off, size = integ.PutDiffTex2D(tex_id, tw, tw, 4)
+    if weak:
+        t_begin, t_count = 0, N
+        if world > 1:
+            integ.InitRandomGens(N, first_seed=rank * N)
+    else:
+        from hydracore3_amd.sharding import tid_interleave
+        t_begin, t_count, chunk, stride = tid_interleave(rank, world, N)
+        integ.set_tid_interleave(chunk, stride)
     data = torch.full((size,), 0.5, dtype=torch.float32, device=dev)
     grad = torch.zeros_like(data); mom = torch.zeros_like(data); gsq = torch.zeros_like(data)
     loss = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -74,26 +96,52 @@ def run_dr(args, rank, world, dev, stream):
 
     def step(it):
         grad.zero_(); loss.zero_(); frame.zero_()
-        integ._chk(L.hpt_path_trace_dr_dev(integ.h, 0, N, 4, frame.data_ptr(), spp, ref.data_ptr(), data.data_ptr(), grad.data_ptr(), size, loss.data_ptr(), stream))
+        integ._chk(L.hpt_path_trace_dr_dev(integ.h, t_begin, t_count, 4, frame.data_ptr(), spp, ref.data_ptr(), data.data_ptr(), grad.data_ptr(), size, loss.data_ptr(), stream))
+        if dist is not None:                                       # a_dataGrad: ncclAllReduce(sum), once per optimisation iteration
+            if backend == "nccl":
+                dist.all_reduce(grad, op=dist.ReduceOp.SUM); dist.all_reduce(loss, op=dist.ReduceOp.SUM)
+            else:
+                g, l = grad.cpu(), loss.cpu()
+                dist.all_reduce(g, op=dist.ReduceOp.SUM); dist.all_reduce(l, op=dist.ReduceOp.SUM)
+                grad.copy_(g); loss.copy_(l)
+            if weak:
+                grad.div_(world); loss.div_(world)                 # mean over the ranks' independent sample sets
         integ._chk(L.hpt_adam_step_dev(integ.h, data.data_ptr(), grad.data_ptr(), mom.data_ptr(), gsq.data_ptr(), size, it, stream))
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(i)
-    torch.cuda.synchronize()
+    sync()
     kms = []
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
-        kms.append(integ.last_kernel_ms())
+        if world == 1:
+            kms.append(integ.last_kernel_ms())
         losses.append(float(loss.item()) / N)
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
-    value = float(N) * spp * args.steps / elapsed / 1e6
-    out = {"metric": "Mpaths/s (fwd+bwd grad, IntegratorDR::PathTraceDR + Adam)", "value": round(value, 2), "unit": "Mpaths/s", "n_gpus": 1,
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        kms = [integ.last_kernel_ms()]
+    value = float(N) * spp * args.steps * (world if weak else 1) / elapsed / 1e6
+    if rank != 0:
+        return
+    what = (f"synthetic 1M-triangle interior + {tw}x{tw}x4 differentiable albedo, {W}x{H} @ {spp} spp" if big
+            else f"scenes/test_228 + 256x256x4 differentiable albedo, {W}x{H} @ {spp} spp")
+    out = {"metric": "Mpaths/s (fwd+bwd grad, IntegratorDR::PathTraceDR + Adam)", "value": round(value, 2), "unit": "Mpaths/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"scenes/test_228 + 256x256x4 differentiable albedo, {W}x{H} @ {spp} spp, PathTraceDR fwd+bwd + Adam",
-                      "paths_per_step": N * spp, "trace_depth": sc.trace_depth, "grad_floats": int(size), "loss_per_step": [round(v, 6) for v in losses]},
+           "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": what + ", PathTraceDR fwd+bwd + Adam",
+                      "paths_per_step": N * spp * (world if weak else 1), "trace_depth": sc.trace_depth, "grad_floats": int(size),
+                      "sharding": "single GPU" if world == 1 else (("sample" if weak else "pixel") + f" sharding over {world} ranks + all_reduce(SUM) of a_dataGrad and the loss"),
+                      "loss_per_step": [round(v, 6) for v in losses]},
            "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                         "kernel": "pathTraceKernel<DR>", "kernel_ms": round(float(np.mean(kms)), 3)},
            "cpu_baseline": None}
@@ -135,7 +183,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cornell", choices=["cornell", "interior", "dr"])
+    ap.add_argument("--workload", default="cornell", choices=["cornell", "interior", "dr", "dr_interior"])
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=1024)
@@ -183,10 +231,8 @@ def main():
     if dist is not None:
         dist.barrier()
     from hydracore3_amd.api import HipIntegrator
-    if args.workload == "dr":
-        if world != 1:
-            raise SystemExit("--workload dr is a single-GPU bench line this round")
-        return run_dr(args, rank, world, dev, torch.cuda.current_stream().cuda_stream)
+    if args.workload in ("dr", "dr_interior"):
+        return run_dr(args, rank, world, dev, torch.cuda.current_stream().cuda_stream, dist, backend)
 
     W, H = (args.width or (1024 if args.workload == "cornell" else 1920)), (args.height or (1024 if args.workload == "cornell" else 1080))
     spp = args.spp

@@ -191,18 +191,25 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
           const uint yRef = (uint)S.winHeight - ((XY & 0xFFFF0000u) >> 16) - 1u;
           const float* rp = job.refImg + ((size_t)yRef * pitch + (XY & 0x0000FFFFu)) * job.channels;
           const V3 diff = v3(accum.x - rp[0], accum.y - rp[1], accum.z - rp[2]);
-          lossLocal += (diff.x * diff.x + diff.y * diff.y + diff.z * diff.z) / float(job.passNum);
-          PIX(0) += accum.x; PIX(1) += accum.y; PIX(2) += accum.z;             // out_color += colorRend (:1124-1126)
+          // One sample in ~1e8 on the 1M-triangle scene comes out non-finite (a 0/0 in a grazing GGX term; the reference's formulas,
+          // unguarded there too). In the optimisation loop a single NaN gradient poisons Adam's moments for good, so such a sample
+          // contributes neither loss, colour nor gradient here - the one deliberate deviation from PixelLossPT.
+          const bool sane = __builtin_isfinite(diff.x + diff.y + diff.z);
+          if (sane) {
+            lossLocal += (diff.x * diff.x + diff.y * diff.y + diff.z * diff.z) / float(job.passNum);
+            PIX(0) += accum.x; PIX(1) += accum.y; PIX(2) += accum.z;           // out_color += colorRend (:1124-1126)
+          }
           const size_t s = job.recordLanes;
           V3 Rn = tailR + env;
-          for (int b = (int)bounce - 1; b >= 0; b--) {
+          for (int b = sane ? (int)bounce - 1 : -1; b >= 0; b--) {
             const float* r = job.record + ((size_t)b * REC_FIELDS) * s + glane;
             const V3 A = v3(r[0 * s], r[1 * s], r[2 * s]), Sb = v3(r[3 * s], r[4 * s], r[5 * s]);
             const uint texId = __float_as_uint(r[12 * s]);
             if (texId != 0xFFFFFFFFu) {
               const V3 TdA = v3(r[6 * s], r[7 * s], r[8 * s]), TdS = v3(r[9 * s], r[10 * s], r[11 * s]);
               const V3 dC = TdS + TdA * Rn;
-              const V3 g = v3(2.0f * diff.x * dC.x, 2.0f * diff.y * dC.y, 2.0f * diff.z * dC.z);
+              V3 g = v3(2.0f * diff.x * dC.x, 2.0f * diff.y * dC.y, 2.0f * diff.z * dC.z);
+              if (!__builtin_isfinite(g.x + g.y + g.z)) g = v3(0, 0, 0);
               const TexRec t = S.textures[texId];
               float* gbase = job.grad + t.diffOffset;
               for (int k = 0; k < 4; k++) {

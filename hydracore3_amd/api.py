@@ -53,6 +53,8 @@ ABI = {
     "hpt_path_trace_dr": (_i, [_vp, _u32, _u32, _u32, _vp, _u32, _vp, _vp, _vp, _sz, C.POINTER(_f)]),
     "hpt_path_trace_dr_dev": (_i, [_vp, _u32, _u32, _u32, _vp, _u32, _vp, _vp, _vp, _sz, _vp, _vp]),
     "hpt_adam_step_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
+    "hpt_image2d4f_regularizer_dev": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "hpt_image2d4f_regularizer": (_i, [_vp, _i, _i, _vp, _vp]),
     "hpt_get_execution_time": (_i, [_vp, C.c_char_p, C.POINTER(_f)]),
     "hpt_set_instrumentation": (_i, [_vp, _i]),
     "hpt_get_counters": (_i, [_vp, C.POINTER(_u64)]),
@@ -244,6 +246,11 @@ class HipIntegrator:
     def set_schedule(self, schedule: int, refill_below: int = 0, trace_blocks_per_cu: int = 0, groups: int = 0):
         """0 automatic, 1 persistent megakernel, 2 wavefront (shade kernel + trace kernel with ray replacement)."""
         self._chk(self.L.hpt_set_schedule(self.h, schedule, refill_below, trace_blocks_per_cu, groups))
+
+    def Image2D4fRegularizer(self, data, grad):
+        """grad += d RegLossImage2D4f / d data (diff_render/integrator_dr.cpp:361-367); float32 [h, w, 4] arrays."""
+        assert data.dtype == np.float32 and grad.dtype == np.float32 and data.shape == grad.shape and data.shape[-1] == 4
+        self._chk(self.L.hpt_image2d4f_regularizer(self.h, data.shape[1], data.shape[0], data.ctypes.data, grad.ctypes.data))
 
     def set_option(self, name: str, value: int):
         self._chk(self.L.hpt_set_option(self.h, name.encode(), value))

@@ -934,6 +934,30 @@ extern "C" int hpt_adam_step_dev(hpt_ctx* c, float* state, const float* grad, fl
   return HPT_OK;
 }
 
+extern "C" int hpt_image2d4f_regularizer_dev(hpt_ctx* c, int w, int h, const float* data, float* grad, void* stream)
+{
+  if (!c || !data || !grad || w < 0 || h < 0) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (w < 3 || h < 3) return HPT_OK;                                  // no interior pixel: the loss is identically zero
+  image2D4fRegularizerKernel<<<dim3((w + 15) / 16, (h + 15) / 16), dim3(16, 16), 0, (hipStream_t)stream>>>(w, h, (const float4*)data, (float4*)grad);
+  HIPCHK(c, hipGetLastError());
+  return HPT_OK;
+}
+
+extern "C" int hpt_image2d4f_regularizer(hpt_ctx* c, int w, int h, const float* data, float* grad)
+{
+  if (!c || !data || !grad || w < 0 || h < 0) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  const size_t n = (size_t)w * h * 4;
+  if (n == 0) return HPT_OK;
+  DevBuf<float> dd, dg;
+  HIPCHK(c, dd.upload(data, n)); HIPCHK(c, dg.upload(grad, n));
+  int rc = hpt_image2d4f_regularizer_dev(c, w, h, dd.p, dg.p, nullptr);
+  if (rc == HPT_OK) { hipError_t e = hipMemcpy(grad, dg.p, n * sizeof(float), hipMemcpyDeviceToHost); if (e != hipSuccess) rc = c->hipFail(e, "hipMemcpy"); }
+  dd.release(); dg.release();
+  return rc;
+}
+
 // ---- timing / instrumentation --------------------------------------------------------------------------------------------------------
 extern "C" int hpt_get_execution_time(hpt_ctx* c, const char* name, float out[4])
 {

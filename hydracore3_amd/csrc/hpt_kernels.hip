@@ -310,6 +310,49 @@ __global__ void __launch_bounds__(256) rayQueryKernel(const DevScene S, const fl
   }
 }
 
+// Image2D4fRegularizer (diff_render/integrator_dr.cpp:317-367): grad += d/d data of  sum_{interior pixels} sqrt(sum_{4 neighbours} |p0 - p_k|^2_rgb).
+// Hand-derived instead of Enzyme, gather form (no atomics): texel q receives its own term (4 q - sum nb)/sqrt(S_q) when it is interior,
+// and -(n - q)/sqrt(S_n) from each interior neighbour n; terms with S == 0 contribute nothing.
+HPT_DEV float regS(const float4* d, int w, int x, int y)
+{
+  const float4 p0 = d[y * w + x], a = d[(y + 1) * w + x], b = d[(y - 1) * w + x], c = d[y * w + x - 1], e = d[y * w + x + 1];
+  float S = 0.0f;
+  const float4 nb[4] = { a, b, c, e };
+  for (int k = 0; k < 4; k++) { const float dx = p0.x - nb[k].x, dy = p0.y - nb[k].y, dz = p0.z - nb[k].z; S += dx * dx + dy * dy + dz * dz; }
+  return S;
+}
+__global__ void image2D4fRegularizerKernel(int w, int h, const float4* data, float4* grad)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  const float4 q = data[y * w + x];
+  float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+  const bool interior = x >= 1 && x < w - 1 && y >= 1 && y < h - 1;
+  if (interior) {
+    const float S = regS(data, w, x, y);
+    if (S > 0.0f) {
+      const float inv = 1.0f / __builtin_sqrtf(S);
+      const float4 a = data[(y + 1) * w + x], b = data[(y - 1) * w + x], c = data[y * w + x - 1], e = data[y * w + x + 1];
+      gx += (4.0f * q.x - (a.x + b.x + c.x + e.x)) * inv; gy += (4.0f * q.y - (a.y + b.y + c.y + e.y)) * inv; gz += (4.0f * q.z - (a.z + b.z + c.z + e.z)) * inv;
+    }
+  }
+  const int nx[4] = { x, x, x - 1, x + 1 }, ny[4] = { y + 1, y - 1, y, y };
+  for (int k = 0; k < 4; k++) {
+    const int X = nx[k], Y = ny[k];
+    if (X >= 1 && X < w - 1 && Y >= 1 && Y < h - 1) {              // neighbour n is an interior pixel: q is one of ITS four neighbours
+      const float S = regS(data, w, X, Y);
+      if (S > 0.0f) {
+        const float inv = 1.0f / __builtin_sqrtf(S);
+        const float4 n = data[Y * w + X];
+        gx -= (n.x - q.x) * inv; gy -= (n.y - q.y) * inv; gz -= (n.z - q.z) * inv;
+      }
+    }
+  }
+  float4 g = grad[y * w + x];
+  g.x += gx; g.y += gy; g.z += gz;
+  grad[y * w + x] = g;
+}
+
 // AdamOptimizer<float>::step (diff_render/adam.h:43-62): HBM-bound, 16 bytes per lane per array
 __global__ void adamStepKernel(float* state, const float* grad, float* momentum, float* gsq, size_t n, float gamma)
 {

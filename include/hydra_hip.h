@@ -155,6 +155,10 @@ int  hpt_path_trace_dr_dev(hpt_ctx* ctx, uint32_t tidBegin, uint32_t tidCount, u
                            const float* refImgDev, const float* dataDev, float* dataGradDev, size_t gradSize, float* lossAccumDev, void* stream);
 /* AdamOptimizer<float>::step (diff_render/adam.h:43-62) on device arrays. */
 int  hpt_adam_step_dev(hpt_ctx* ctx, float* stateDev, const float* gradDev, float* momentumDev, float* gSquareDev, size_t n, int iter, void* stream);
+/* Image2D4fRegularizer(w, h, data, grad) (diff_render/integrator_dr.cpp:317-367; drmain.cpp:213-217): grad += d RegLossImage2D4f / d data,
+ * the total-variation-like texture regulariser (rgb of a w x h x 4 texture), hand-derived instead of __enzyme_autodiff. Device pointers. */
+int  hpt_image2d4f_regularizer_dev(hpt_ctx* ctx, int w, int h, const float* data, float* grad, void* stream);
+int  hpt_image2d4f_regularizer(hpt_ctx* ctx, int w, int h, const float* data, float* grad);       /* host pointers, the reference's signature */
 
 /* ---- timing / instrumentation ----------------------------------------------------------------------------------- */
 /* GetExecutionTime(name, out[4]) (integrator_pt.h:266, main.cpp:416-419): out[0] exec ms, [1] host->device, [2] device->host, [3] overhead */

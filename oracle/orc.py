@@ -53,6 +53,9 @@ def lib():
         L.orc_probe.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p]
         L.orc_probe.restype = C.c_int
         L.orc_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
+        L.orc_reg_loss_image2d4f.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.orc_reg_loss_image2d4f.restype = C.c_double
+        L.orc_image2d4f_regularizer.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -161,6 +164,15 @@ def rng_kat(seed, n_draws):
 
 def adam_step(state, grad, momentum, gsquare, it):
     lib().orc_adam_step(state.ctypes.data, grad.ctypes.data, momentum.ctypes.data, gsquare.ctypes.data, state.size, it)
+
+
+def reg_loss_image2d4f(data):
+    """data: float32 [h, w, 4]."""
+    return lib().orc_reg_loss_image2d4f(data.shape[1], data.shape[0], data.ctypes.data)
+
+
+def image2d4f_regularizer(data, grad):
+    lib().orc_image2d4f_regularizer(data.shape[1], data.shape[0], data.ctypes.data, grad.ctypes.data)
 
 
 def probe(name, *args):

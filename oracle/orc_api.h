@@ -108,6 +108,9 @@ int      orc_probe(const char* name, const float* args, float* out);
 void     orc_tex_sample(orc_ctx*, uint32_t texId, const float* uv2, uint32_t n, float* out4);
 // AdamOptimizer<float>::step (diff_render/adam.h:43-62)
 void     orc_adam_step(float* state, const float* grad, float* momentum, float* gsquare, uint64_t n, int iter);
+// RegLossImage2D4f / Image2D4fRegularizer (diff_render/integrator_dr.cpp:317-367)
+double   orc_reg_loss_image2d4f(int w, int h, const float* data);
+void     orc_image2d4f_regularizer(int w, int h, const float* data, float* grad);
 
 #ifdef __cplusplus
 }

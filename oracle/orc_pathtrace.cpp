@@ -923,4 +923,48 @@ void orc_adam_step(float* state, const float* grad, float* momentum, float* gsqu
   for (uint64_t i = 0; i < n; i++) state[i] -= (gamma * momentum[i] / (std::sqrt(gsquare[i] + epsilon)));
 }
 
+
+// RegLossImage2D4f (diff_render/integrator_dr.cpp:317-351): sum over interior pixels of sqrt(|p0-top|^2 + |p0-bottom|^2 + |p0-left|^2 +
+// |p0-right|^2) on rgb (dot3); the odd line-order loop at :340-347 visits every line 1..h-2 exactly once.
+double orc_reg_loss_image2d4f(int w, int h, const float* data)
+{
+  double summ = 0.0;
+  for (int y = 1; y < h - 1; y++) {
+    double line = 0.0;
+    for (int x = 1; x < w - 1; x++) {
+      float s = 0.0f;
+      const int nb[4] = { (y + 1) * w + x, (y - 1) * w + x, y * w + x - 1, y * w + x + 1 };
+      // the reference adds dot3(left) + dot3(right) + dot3(top) + dot3(bottom) in float, then takes the sqrt in double
+      float acc[4];
+      for (int k = 0; k < 4; k++) {
+        const float dx = data[(y * w + x) * 4 + 0] - data[nb[k] * 4 + 0], dy = data[(y * w + x) * 4 + 1] - data[nb[k] * 4 + 1], dz = data[(y * w + x) * 4 + 2] - data[nb[k] * 4 + 2];
+        acc[k] = dx * dx + dy * dy + dz * dz;
+      }
+      s = acc[2] + acc[3] + acc[0] + acc[1];
+      line += std::sqrt(double(s));
+    }
+    summ += line;
+  }
+  return summ;
+}
+
+// Image2D4fRegularizer (integrator_dr.cpp:361-367): grad += d RegLossImage2D4f / d data (Enzyme accumulates into the shadow argument).
+// Restated analytically: d sqrt(S)/d p0 = (4 p0 - sum of neighbours)/sqrt(S), d sqrt(S)/d p_k = -(p0 - p_k)/sqrt(S); 0 where S == 0.
+void orc_image2d4f_regularizer(int w, int h, const float* data, float* grad)
+{
+  for (int y = 1; y < h - 1; y++)
+    for (int x = 1; x < w - 1; x++) {
+      const int c = y * w + x;
+      const int nb[4] = { (y + 1) * w + x, (y - 1) * w + x, y * w + x - 1, y * w + x + 1 };
+      double S = 0.0;
+      for (int k = 0; k < 4; k++) for (int ch = 0; ch < 3; ch++) { const double d = double(data[c * 4 + ch]) - double(data[nb[k] * 4 + ch]); S += d * d; }
+      if (!(S > 0.0)) continue;
+      const double inv = 1.0 / std::sqrt(S);
+      for (int k = 0; k < 4; k++) for (int ch = 0; ch < 3; ch++) {
+        const double d = (double(data[c * 4 + ch]) - double(data[nb[k] * 4 + ch])) * inv;
+        grad[c * 4 + ch] += float(d); grad[nb[k] * 4 + ch] -= float(d);
+      }
+    }
+}
+
 } // extern "C"

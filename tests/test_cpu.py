@@ -293,3 +293,26 @@ def test_two_rank_sharding_reassembles_the_frame(tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29533", str(script), ROOT], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "SHARD_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_texture_regulariser_gradient_against_finite_differences():
+    """RegLossImage2D4f / Image2D4fRegularizer (diff_render/integrator_dr.cpp:317-367): the oracle's analytic gradient of the
+    restated loss equals central finite differences, alpha gets none, it ACCUMULATES (enzyme_dup), a flat image gives zero."""
+    from oracle import orc
+    rng = np.random.default_rng(3)
+    h, w = 9, 12
+    data = rng.uniform(0.1, 0.9, (h, w, 4)).astype(np.float32)
+    grad = np.full((h, w, 4), 0.25, np.float32)
+    orc.image2d4f_regularizer(data, grad)
+    grad -= 0.25
+    assert np.all(grad[..., 3] == 0)
+    eps = 1e-3
+    for (y, x, c) in [(0, 0, 0), (0, 5, 1), (4, 6, 2), (1, 1, 0), (7, 10, 1), (8, 11, 2), (3, 0, 0), (4, 4, 1)]:
+        d1, d2 = data.copy(), data.copy()
+        d1[y, x, c] += eps; d2[y, x, c] -= eps
+        fd = (orc.reg_loss_image2d4f(d1) - orc.reg_loss_image2d4f(d2)) / (2 * eps)
+        assert abs(fd - grad[y, x, c]) < 2e-3 * max(1.0, abs(fd)), (y, x, c, fd, grad[y, x, c])
+    flat = np.full((5, 5, 4), 0.5, np.float32)
+    g = np.zeros_like(flat)
+    orc.image2d4f_regularizer(flat, g)
+    assert orc.reg_loss_image2d4f(flat) == 0.0 and not g.any()

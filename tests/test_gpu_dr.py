@@ -96,3 +96,22 @@ def test_gradient_matches_oracle_on_metal_and_coated_gltf():
     assert np.count_nonzero(grad_c) > 500
     assert abs(loss_g - loss_c) <= 1e-4 * abs(loss_c)
     assert err < 1e-2
+
+
+def test_texture_regulariser_matches_oracle():
+    """hpt_image2d4f_regularizer_dev (gather form, no atomics) == the oracle's Image2D4fRegularizer, accumulating into grad."""
+    from hydracore3_amd.api import HipIntegrator
+    from oracle import orc
+    sc = load_hydra_xml(scene_path("test_035"), 16, 16)
+    gpu = HipIntegrator(sc)
+    rng = np.random.default_rng(9)
+    for (h, w) in ((256, 256), (7, 33), (3, 3), (2, 8)):
+        data = rng.uniform(0.0, 1.0, (h, w, 4)).astype(np.float32)
+        data[h // 2:, : w // 2] = 0.5                                   # a flat patch: S == 0 terms
+        g0 = rng.uniform(-1.0, 1.0, (h, w, 4)).astype(np.float32)
+        gc = g0.copy()
+        orc.image2d4f_regularizer(data, gc)
+        gg = g0.copy()
+        gpu.Image2D4fRegularizer(data, gg)
+        assert np.allclose(gg, gc, rtol=1e-4, atol=1e-4), (h, w, float(np.abs(gg - gc).max()))
+        assert np.array_equal(gg[..., 3], g0[..., 3])

@@ -47,6 +47,8 @@ ABI = {
     "hpt_path_trace_block": (_i, [_vp, _u32, _u32, _u32, _vp, _u32]),
     "hpt_naive_path_trace_block": (_i, [_vp, _u32, _u32, _u32, _vp, _u32]),
     "hpt_path_trace_block_dev": (_i, [_vp, _u32, _u32, _u32, _vp, _u32, _i, _vp]),
+    "hpt_path_trace_from_input_rays_block": (_i, [_vp, _u32, _u32, _vp, _vp, _vp, _u32]),
+    "hpt_path_trace_from_input_rays_block_dev": (_i, [_vp, _u32, _u32, _vp, _vp, _vp, _u32, _vp]),
     "hpt_set_tid_interleave": (_i, [_vp, _u32, _u32]),
     "hpt_put_diff_tex2d": (_i, [_vp, _u32, _u32, _u32, _u32, C.POINTER(_u64), C.POINTER(_u64)]),
     "hpt_reset_diff_tex": (_i, [_vp]),
@@ -182,6 +184,12 @@ class HipIntegrator:
     def path_trace_block_dev(self, dev_ptr, pass_num, tid_begin=0, tid_count=None, channels=4, naive=False, stream=None):
         tid_count = self.N - tid_begin if tid_count is None else tid_count
         self._chk(self.L.hpt_path_trace_block_dev(self.h, tid_begin, tid_count, channels, dev_ptr, pass_num, int(naive), stream))
+
+    def PathTraceFromInputRaysBlock(self, tid, channels, in_rayPosAndNear, in_rayDirAndFar, out_color, a_passNum):
+        """Integrator::PathTraceFromInputRaysBlock; rays: float32 [tid, 4] (RayPosAndW / RayDirAndT), camera space."""
+        for a in (in_rayPosAndNear, in_rayDirAndFar, out_color):
+            assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+        self._chk(self.L.hpt_path_trace_from_input_rays_block(self.h, tid, channels, in_rayPosAndNear.ctypes.data, in_rayDirAndFar.ctypes.data, out_color.ctypes.data, a_passNum))
 
     def render(self, spp, channels=4, naive=False):
         img = np.zeros((self.H, self.W, channels), np.float32)

@@ -619,7 +619,7 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st);
 
 // DEEP: the scene's BVH can need more than LDS_STACK stack entries, so pushes / pops check for the HBM overflow part
 // FLAT: single-level world-space BVH (static scenes within FLAT_TRI_BUDGET) vs two-level TLAS/BLAS
-template <bool STATS, bool DR, bool NAIVE>
+template <bool STATS, bool DR, int NAIVE>
 static void launchPT(const DevScene& S, const Job& job, int blocks, hipStream_t st, bool deep)
 {
   if (S.flatMode) {
@@ -633,13 +633,15 @@ static void launchPT(const DevScene& S, const Job& job, int blocks, hipStream_t 
 
 static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStream_t st)
 {
+  const bool inRays = job.inRayPos != nullptr;
   if (!c->sceneUploaded || !c->paramsSet) return c->fail(HPT_ERR_STATE, "PathTraceBlock before CommitDeviceData / UpdateMembersPlainData");
-  if (c->packedCount != (uint)(c->S.winWidth * c->S.winHeight)) return c->fail(HPT_ERR_STATE, "PathTraceBlock before PackXYBlock");
+  if (!inRays && c->packedCount != (uint)(c->S.winWidth * c->S.winHeight)) return c->fail(HPT_ERR_STATE, "PathTraceBlock before PackXYBlock");
   job.tidStride = c->tidStride > 1 ? c->tidStride : 1u;
   job.tidChunk = (job.tidStride > 1 && c->tidChunk > 0) ? c->tidChunk : 0x40000000u;
-  job.tidEnd = c->packedCount;
-  if (job.tidStride == 1 && (size_t)job.tidBegin + job.tidCount > c->packedCount) return c->fail(HPT_ERR_ARG, "PathTraceBlock: tid range exceeds the viewport");
-  if (c->dGens.n < c->packedCount) return c->fail(HPT_ERR_STATE, "PathTraceBlock: m_randomGens smaller than the viewport (InitRandomGens)");
+  job.tidEnd = inRays ? job.tidBegin + job.tidCount : c->packedCount;
+  if (inRays) { job.tidStride = 1; job.tidChunk = 0x40000000u; }
+  if (!inRays && job.tidStride == 1 && (size_t)job.tidBegin + job.tidCount > c->packedCount) return c->fail(HPT_ERR_ARG, "PathTraceBlock: tid range exceeds the viewport");
+  if (c->dGens.n < (inRays ? (size_t)job.tidEnd : (size_t)c->packedCount)) return c->fail(HPT_ERR_STATE, "PathTraceBlock: m_randomGens smaller than the thread range (InitRandomGens)");
   if (job.channels < 1 || job.channels > 4) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceBlock: channels must be 1..4 (spectral layers are out of scope)");
   if (dr && (c->S.traceDepth == 0 || c->S.traceDepth > 16)) return c->fail(HPT_ERR_ARG, "PathTraceDR: trace depth must be 1..16");
   const int blocks = gridBlocks(c, dr);
@@ -650,7 +652,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   job.counters = nullptr;
   const bool stats = c->instrument && !dr;
   c->lastSchedule = 1;
-  if (useWavefront(c, naive, dr, stats && c->schedule != 2)) { c->lastSchedule = 2; return launch_wavefront(c, job, st); }
+  if (!inRays && useWavefront(c, naive, dr, stats && c->schedule != 2)) { c->lastSchedule = 2; return launch_wavefront(c, job, st); }
   if (stats) { HIPCHK(c, c->dCounters.alloc(1)); HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(Counters), st)); job.counters = c->dCounters.p; }
   if (dr) {
     job.recordLanes = (uint)blocks * 256u;
@@ -661,10 +663,11 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   job.stackOverflow = c->dStackOvf.p; job.gridLanes = (uint)blocks * 256u;
   HIPCHK(c, hipEventRecord(c->ev0, st));
   const bool deep = c->stackNeeded > (uint)LDS_STACK;
-  if (dr)          launchPT<false, true, false>(c->S, job, blocks, st, deep);
-  else if (naive)  launchPT<false, false, true>(c->S, job, blocks, st, deep);
-  else if (stats)  launchPT<true, false, false>(c->S, job, blocks, st, deep);
-  else             launchPT<false, false, false>(c->S, job, blocks, st, deep);
+  if (dr)          launchPT<false, true, 0>(c->S, job, blocks, st, deep);
+  else if (inRays) launchPT<false, false, 2>(c->S, job, blocks, st, deep);
+  else if (naive)  launchPT<false, false, 1>(c->S, job, blocks, st, deep);
+  else if (stats)  launchPT<true, false, 0>(c->S, job, blocks, st, deep);
+  else             launchPT<false, false, 0>(c->S, job, blocks, st, deep);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev1, st));
   return HPT_OK;
@@ -839,6 +842,31 @@ static int path_trace_host(hpt_ctx* c, uint32_t tidBegin, uint32_t tidCount, uin
   c->lastKernelMs = kms;
   slots[0] = kms; slots[1] = float(t1 - t0); slots[2] = float(t3 - t2); slots[3] = float((t2 - t1) - kms);
   return HPT_OK;
+}
+
+// PathTraceFromInputRaysBlock (integrator_pt.h:261, integrator_pt_host.cpp:92-103): device and host-pointer forms
+extern "C" int hpt_path_trace_from_input_rays_block_dev(hpt_ctx* c, uint32_t tid, uint32_t channels, const float* rayPosDev, const float* rayDirDev, float* outDev, uint32_t passNum, void* stream)
+{
+  if (!c || !rayPosDev || !rayDirDev || !outDev) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (tid == 0 || passNum == 0) return HPT_OK;
+  Job job; std::memset(&job, 0, sizeof(job));
+  job.tidBegin = 0; job.tidCount = tid; job.passNum = passNum; job.channels = channels; job.outColor = outDev;
+  job.inRayPos = (const float4*)rayPosDev; job.inRayDir = (const float4*)rayDirDev;
+  return launch_path_trace(c, job, false, false, (hipStream_t)stream);
+}
+extern "C" int hpt_path_trace_from_input_rays_block(hpt_ctx* c, uint32_t tid, uint32_t channels, const float* rayPos, const float* rayDir, float* out, uint32_t passNum)
+{
+  if (!c || !rayPos || !rayDir || !out) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (tid == 0 || passNum == 0) return HPT_OK;
+  DevBuf<float> dp, dd, dout;
+  const size_t n = (size_t)tid * channels;
+  HIPCHK(c, dp.upload(rayPos, (size_t)tid * 4)); HIPCHK(c, dd.upload(rayDir, (size_t)tid * 4)); HIPCHK(c, dout.upload(out, n));
+  int rc = hpt_path_trace_from_input_rays_block_dev(c, tid, channels, dp.p, dd.p, dout.p, passNum, nullptr);
+  if (rc == HPT_OK) { hipError_t e = hipMemcpy(out, dout.p, n * sizeof(float), hipMemcpyDeviceToHost); if (e != hipSuccess) rc = c->hipFail(e, "hipMemcpy"); }
+  dp.release(); dd.release(); dout.release();
+  return rc;
 }
 
 extern "C" int hpt_path_trace_block(hpt_ctx* c, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out, uint32_t passNum)

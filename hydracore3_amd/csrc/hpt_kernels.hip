@@ -40,15 +40,20 @@ struct Job
   uint   recordLanes;             // total lanes of the grid (stride of the record buffer)
   uint*  stackOverflow;           // HBM part of the traversal stacks: [depth - LDS_STACK][global lane]
   uint   gridLanes;
+  const float4* inRayPos;         // PathTraceFromInputRays: RayPosAndW[tid] / RayDirAndT[tid] in camera space (MODE 2)
+  const float4* inRayDir;
 };
 
 
 #ifndef HPT_MIN_WAVES
 #define HPT_MIN_WAVES 4   // waves per SIMD the register allocator must fit (measured: 2 -> 725, 3 -> 913..1262, 4 -> 1005..1365 Mpaths/s on the Cornell box)
 #endif
-template <bool STATS, bool DR, bool NAIVE, bool DEEP, bool FLAT>
+// MODE: 0 = PathTrace (MIS / shadow / stupid by m_intergatorType), 1 = NaivePathTrace, 2 = PathTraceFromInputRays (the caller's rays
+// instead of camera rays, linear tid -> output index, raw accumColor: integrator_pt.cpp:159-199, 659-676, 761-798)
+template <bool STATS, bool DR, int MODE, bool DEEP, bool FLAT>
 __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevScene S, const Job job)
 {
+  constexpr bool NAIVE = (MODE == 1), INRAYS = (MODE == 2);
   __shared__ uint stackMem[LDS_STACK * 256];
   const uint glane = blockIdx.x * 256u + threadIdx.x;                    // slot in the per-lane HBM buffers
   TravStack stk; stk.lds = &stackMem[threadIdx.x]; stk.ovf = job.stackOverflow + glane; stk.ovfStride = job.gridLanes;
@@ -81,7 +86,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
     // ---- (1) a finished pixel goes back to HBM: one read-modify-write per pixel and call ------------------------------
     if (!alive && havePixel && PIX_PASSES == 0u) {
       const uint XY = PIX_XY;
-      const uint pixel = ((XY & 0xFFFF0000u) >> 16) * (uint)S.winWidth + (XY & 0x0000FFFFu);
+      const uint pixel = INRAYS ? PIX_TID : ((XY & 0xFFFF0000u) >> 16) * (uint)S.winWidth + (XY & 0x0000FFFFu);
       if (job.channels == 1) job.outColor[pixel] = PIX(0);
       else { float* o = job.outColor + (size_t)pixel * job.channels; o[0] = PIX(0); o[1] = PIX(1); o[2] = PIX(2); }
       job.gens[PIX_TID] = gen;                                           // kernel_ContributeToImage: m_randomGens[tid] = *gen (:605)
@@ -99,9 +104,9 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
           const uint k = base + mbcnt64(mask);
           const uint tid = job.tidBegin + (k / job.tidChunk) * job.tidChunk * job.tidStride + (k % job.tidChunk);
           if (k < job.tidCount && tid < job.tidEnd) {
-            const uint XY = job.packedXY[tid];
+            const uint XY = INRAYS ? 0u : job.packedXY[tid];
             gen = job.gens[tid];
-            const uint pixel = ((XY & 0xFFFF0000u) >> 16) * (uint)S.winWidth + (XY & 0x0000FFFFu);
+            const uint pixel = INRAYS ? tid : ((XY & 0xFFFF0000u) >> 16) * (uint)S.winWidth + (XY & 0x0000FFFFu);
             if (job.channels == 1) { PIX(0) = job.outColor[pixel]; PIX(1) = 0.0f; PIX(2) = 0.0f; }
             else { const float* o = job.outColor + (size_t)pixel * job.channels; PIX(0) = o[0]; PIX(1) = o[1]; PIX(2) = o[2]; }
             PIX_XY = XY; PIX_TID = tid; PIX_PASSES = job.passNum;
@@ -115,9 +120,17 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
       PIX_PASSES = PIX_PASSES - 1u;
       accum = v3(0, 0, 0); thr = v3(1, 1, 1); flags = 0; bounce = 0;
       misPdf = 1.0f; misIor = 1.0f;
-      const V4 lens = rng_float4(gen);                                     // GetRandomNumbersLens
-      const uint XY = PIX_XY;
-      cameraRay(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
+      if (INRAYS) {                                                        // kernel_InitEyeRayFromInput: no lens randoms
+        const float4 ip = job.inRayPos[PIX_TID], id4 = job.inRayDir[PIX_TID];
+        const V3 org = v3(ip.x, ip.y, ip.z), dir = v3(id4.x, id4.y, id4.z);
+        const V3 p1 = mul4x3(S.worldViewInv, org);                         // transform_ray3f (cglobals.h:254-263)
+        const V3 p2 = mul4x3(S.worldViewInv, org + 100.0f * dir);
+        rpos = p1; rdir = normalize(p2 - p1);
+      } else {
+        const V4 lens = rng_float4(gen);                                   // GetRandomNumbersLens
+        const uint XY = PIX_XY;
+        cameraRay(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
+      }
       alive = true;
       if (STATS) nPaths++;
     }
@@ -227,7 +240,8 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
         } else {
           // kernel_ContributeToImage (integrator_pt.cpp:598-657)
           const V3 c = accum * ld3(S.camRespoceRGB);
-          if (job.channels == 1) PIX(0) += accum.x * S.exposureMult;
+          if (INRAYS) { PIX(0) += accum.x; PIX(1) += accum.y; PIX(2) += accum.z; }        // kernel_CopyColorToOutput: raw accumColor
+          else if (job.channels == 1) PIX(0) += accum.x * S.exposureMult;
           else { PIX(0) += S.exposureMult * c.x; PIX(1) += S.exposureMult * c.y; PIX(2) += S.exposureMult * c.z; }
         }
         alive = false;

@@ -140,6 +140,12 @@ int  hpt_set_tid_interleave(hpt_ctx* ctx, uint32_t chunk, uint32_t stride);
  * device between calls, kmake_mega.json:18). stream is a hipStream_t (NULL = default stream); asynchronous. */
 int  hpt_path_trace_block_dev(hpt_ctx* ctx, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out_color_dev,
                               uint32_t passNum, int naive, void* stream);
+/* PathTraceFromInputRaysBlock(tid, channels, in_rayPosAndNear, in_rayDirAndFar, out_color, a_passNum) (integrator_pt.h:261,
+ * integrator_pt.cpp:159-199, 761-798): the path tracer fed with the caller's rays (RayPosAndW / RayDirAndT, 16 bytes each, camera space:
+ * cam_plugin/CamPluginAPI.h:27-37) instead of camera rays; out_color[tid * channels ..] += raw accumColor, m_randomGens[tid] advanced.
+ * Needs hpt_init_random_gens(>= tid); no PackXYBlock. Host-pointer and device-pointer forms. */
+int  hpt_path_trace_from_input_rays_block(hpt_ctx* ctx, uint32_t tid, uint32_t channels, const float* rayPosAndW, const float* rayDirAndT, float* out_color, uint32_t passNum);
+int  hpt_path_trace_from_input_rays_block_dev(hpt_ctx* ctx, uint32_t tid, uint32_t channels, const float* rayPosAndWDev, const float* rayDirAndTDev, float* outDev, uint32_t passNum, void* stream);
 
 /* ---- differentiable rendering (diff_render/integrator_dr.h:42-47, 103) ------------------------------------------ */
 int  hpt_put_diff_tex2d(hpt_ctx* ctx, uint32_t texId, uint32_t width, uint32_t height, uint32_t channels,

@@ -48,6 +48,7 @@ def lib():
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.orc_path_trace_dr_fd.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
                                            C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p]
+        L.orc_path_trace_from_input_rays_block.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.orc_rng_kat.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_tex_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_probe.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p]
@@ -104,6 +105,10 @@ class OracleIntegrator:
         fn = self.L.orc_naive_path_trace_block if naive else self.L.orc_path_trace_block
         fn(self.h, tid_begin, tid_count, channels, out_color.ctypes.data, pass_num)
         return out_color
+
+    def path_trace_from_input_rays_block(self, ray_pos, ray_dir, out_color, pass_num, channels=4):
+        n = ray_pos.shape[0]
+        self.L.orc_path_trace_from_input_rays_block(self.h, n, channels, ray_pos.ctypes.data, ray_dir.ctypes.data, out_color.ctypes.data, pass_num)
 
     def render(self, spp, channels=4, naive=False):
         img = np.zeros((self.H, self.W, channels), np.float32)

@@ -86,6 +86,7 @@ void     orc_set_random_gens(orc_ctx*, const uint32_t* in_uint2, uint32_t count)
 // PathTraceBlock (integrator_pt_host.cpp:57-73) restricted to tid in [tidBegin, tidBegin+tidCount)
 void     orc_path_trace_block(orc_ctx*, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out_color, uint32_t passNum);
 void     orc_naive_path_trace_block(orc_ctx*, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out_color, uint32_t passNum);
+void     orc_path_trace_from_input_rays_block(orc_ctx*, uint32_t tid, uint32_t channels, const float* rayPosAndW, const float* rayDirAndT, float* out_color, uint32_t passNum);
 
 // ISceneObject::RayQuery_NearestHit / RayQuery_AnyHit semantics (CrossRT.h:157-176), batched.
 // bruteForce != 0 tests every triangle of every instance (no BVH).

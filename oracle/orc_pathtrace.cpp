@@ -494,6 +494,34 @@ struct Ctx
     return s.accumColor;
   }
 
+  // PathTraceFromInputRays (integrator_pt.cpp:761-798): kernel_InitEyeRayFromInput (:159-199, camera-space ray through m_worldViewInv,
+  // no lens randoms) + the PathTrace loop + kernel_CopyColorToOutput (:659-676: out_color[tid * channels ..] += accumColor, raw)
+  void PathTraceFromInputRays(uint tid, uint channels, const float* rayPosAndW, const float* rayDirAndT, float* out_color)
+  {
+    Path s;
+    s.accumColor = mk4(0, 0, 0, 0);
+    s.accumThroughput = mk4(1, 1, 1, 1);
+    s.rayFlags = 0;
+    s.mis = makeInitialMisData();
+    f3 rayPos = mk3(rayPosAndW[4 * tid + 0], rayPosAndW[4 * tid + 1], rayPosAndW[4 * tid + 2]);
+    f3 rayDir = mk3(rayDirAndT[4 * tid + 0], rayDirAndT[4 * tid + 1], rayDirAndT[4 * tid + 2]);
+    transform_ray3f(p.worldViewInv, &rayPos, &rayDir);
+    s.rayPosAndNear = xyzw(rayPos, 0.0f);
+    s.rayDirAndFar = xyzw(rayDir, FLT_MAX);
+    s.gen = randomGens[tid];
+    for (uint depth = 0; depth < p.traceDepth; depth++) {
+      RayTrace2(depth, &s, nullptr);
+      if (isDeadRay(s.rayFlags)) break;
+      const f4 shadeColor = SampleLightSource(depth, &s, nullptr);
+      NextBounce(depth, shadeColor, &s, nullptr);
+      if (isDeadRay(s.rayFlags)) break;
+    }
+    HitEnvironment(&s);
+    if (channels == 1) out_color[tid] += s.accumColor.x;
+    else { out_color[tid * channels + 0] += s.accumColor.x; out_color[tid * channels + 1] += s.accumColor.y; out_color[tid * channels + 2] += s.accumColor.z; }
+    randomGens[tid] = s.gen;
+  }
+
   void NaivePathTrace(uint tid, uint channels, float* out_color)   // :681-717
   {
     Path s;
@@ -732,6 +760,16 @@ void orc_naive_path_trace_block(orc_ctx* h, uint32_t tidBegin, uint32_t tidCount
   for (long i = (long)tidBegin; i < (long)(tidBegin + tidCount); ++i)
     for (uint32_t j = 0; j < passNum; ++j)
       c.NaivePathTrace((uint)i, channels, out_color);
+}
+
+// PathTraceFromInputRaysBlock (integrator_pt_host.cpp:92-103); rays: RayPosAndW / RayDirAndT (cam_plugin/CamPluginAPI.h:27-37), 16 bytes each
+void orc_path_trace_from_input_rays_block(orc_ctx* h, uint32_t tid, uint32_t channels, const float* rayPosAndW, const float* rayDirAndT, float* out_color, uint32_t passNum)
+{
+  Ctx& c = h->c;
+  #pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads())
+  for (long i = 0; i < (long)tid; ++i)
+    for (uint32_t j = 0; j < passNum; ++j)
+      c.PathTraceFromInputRays((uint)i, channels, rayPosAndW, rayDirAndT, out_color);
 }
 
 void orc_ray_nearest(orc_ctx* h, const float* posNear4, const float* dirFar4, uint32_t n, orc_hit* out, int bruteForce)

@@ -307,3 +307,30 @@ def test_wavefront_ray_suspension_is_exact(layout):
     assert np.array_equal(wf.random_gens(), mega.random_gens())
     wf.set_instrumentation(False); wf.InitRandomGens(wf.N)
     assert np.array_equal(wf.render(3), ref)
+
+
+def test_path_trace_from_input_rays_block_matches_oracle(cornell):
+    """Integrator::PathTraceFromInputRaysBlock: the caller's camera-space rays (cam-plugin batches) instead of camera rays, linear
+    tid -> output index, raw accumColor, generators advanced: HIP == oracle within the image bar, RNG streams identical."""
+    from hydracore3_amd.api import HipIntegrator
+    from oracle.orc import OracleIntegrator
+    sc, _, _ = cornell
+    gpu, cpu = HipIntegrator(sc), OracleIntegrator(sc)
+    n = 4096
+    rng = np.random.default_rng(21)
+    pos = np.zeros((n, 4), np.float32); dr = np.zeros((n, 4), np.float32)
+    pos[:, :2] = rng.uniform(-0.05, 0.05, (n, 2))                       # a small lens in camera space
+    d = np.stack([rng.uniform(-0.35, 0.35, n), rng.uniform(-0.35, 0.35, n), -np.ones(n)], 1)
+    dr[:, :3] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    spp = 6
+    for channels in (4, 1):
+        gpu.InitRandomGens(gpu.N); cpu.set_random_gens(gpu.random_gens())
+        og, oc = np.full((n, channels), 0.5, np.float32), np.full((n, channels), 0.5, np.float32)      # the callee accumulates
+        gpu.PathTraceFromInputRaysBlock(n, channels, pos, dr, og, spp)
+        cpu.path_trace_from_input_rays_block(pos, dr, oc, spp, channels)
+        dlt = (og[:, :3].astype(np.float64) - oc[:, :3]) / spp
+        assert float(np.sqrt(np.mean(np.sum(dlt * dlt, -1)))) < 1e-3
+        assert float(np.mean(og[:, 0] - 0.5)) / spp > 0.05              # the box is lit
+        if channels == 4:
+            assert np.all(og[:, 3] == 0.5)                              # alpha untouched
+        assert np.array_equal(gpu.random_gens(), cpu.random_gens())

@@ -147,6 +147,12 @@ public:
   { if (m_ctx) report(hpt_path_trace_block(m_ctx, 0, tid, channels, out_color, a_passNum), "PathTraceBlock"); }
   virtual void NaivePathTraceBlock(uint32_t tid, uint32_t channels, float* out_color, uint32_t a_passNum)
   { if (m_ctx) report(hpt_naive_path_trace_block(m_ctx, 0, tid, channels, out_color, a_passNum), "NaivePathTraceBlock"); }
+  // cam_plugin/CamPluginAPI.h:27-37: both structs are 16 bytes (origin + wavelength, direction + time), camera space
+  struct RayPosAndW { float origin[3]; float wave; };
+  struct RayDirAndT { float direction[3]; float time; };
+  virtual void PathTraceFromInputRaysBlock(uint32_t tid, uint32_t channels, const RayPosAndW* in_rayPosAndNear, const RayDirAndT* in_rayDirAndFar,
+                                           float* out_color, uint32_t a_passNum)
+  { if (m_ctx) report(hpt_path_trace_from_input_rays_block(m_ctx, tid, channels, (const float*)in_rayPosAndNear, (const float*)in_rayDirAndFar, out_color, a_passNum), "PathTraceFromInputRaysBlock"); }
   virtual void GetExecutionTime(const char* a_funcName, float a_out[4]) { if (m_ctx) hpt_get_execution_time(m_ctx, a_funcName, a_out); }
   virtual void Update_m_materials(size_t a_first, size_t a_count) { if (m_ctx) report(hpt_update_materials(m_ctx, a_first, a_count, m_materials.data() + a_first), "Update_m_materials"); }
   virtual void Update_m_lights(size_t a_first, size_t a_count) { if (m_ctx) report(hpt_update_lights(m_ctx, a_first, a_count, m_lights.data() + a_first), "Update_m_lights"); }
@@ -202,6 +208,9 @@ public:
     if (m_ctx) report(hpt_path_trace_dr(m_ctx, 0, tid, channels, out_color, a_passNum, a_refImg, a_data, a_dataGrad, a_gradSize, &loss), "PathTraceDR");
     return loss;
   }
+  // Image2D4fRegularizer (diff_render/integrator_dr.cpp:361-367; drmain.cpp:213-217): grad += d RegLossImage2D4f / d data
+  void Image2D4fRegularizer(int w, int h, const float* data, float* grad)
+  { if (m_ctx) report(hpt_image2d4f_regularizer(m_ctx, w, h, data, grad), "Image2D4fRegularizer"); }
 };
 
 } // namespace hydra_hip

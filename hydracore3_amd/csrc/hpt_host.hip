@@ -73,13 +73,13 @@ struct hpt_ctx
   std::vector<void*> texData; std::vector<TexRec> hTextures;
   DevBuf<Rng> dGens;
   DevBuf<uint> dQueue, dStackOvf; DevBuf<Counters> dCounters;
-  DevBuf<float> dFrame, dRecord, dRef, dData, dGrad, dLoss;
+  DevBuf<float> dFrame, dRecord, dRef, dData, dGrad, dLoss; DevBuf<double> dLossAcc;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // wavefront schedule (hpt_wavefront.hip): the pixels of a call are cut into groups, each with its own path pool, ray queue and
   // stream, so that the tail of one group's trace pass overlaps the other groups' work
   struct WfGroup
   {
-    DevBuf<float4> f4[8]; DevBuf<uint> u[9];
+    DevBuf<float4> f4[8]; DevBuf<uint> u[9]; DevBuf<float> rec, lossSlot;
     hipStream_t stream = nullptr; hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t done = nullptr;
     uint* progress = nullptr;            // pinned: rays queued after every WF_CHECK-th shade pass (0 = group finished)
     uint checkpoints = 0, itemBase = 0, itemCount = 0; unsigned long long it = 0; bool finished = false;
@@ -147,10 +147,11 @@ extern "C" void hpt_destroy(hpt_ctx* c)
   c->dMatVertOffset.release(); c->dPackedXY.release(); c->dVData.release(); c->dNormMat.release(); c->dRemapInst.release();
   c->dRemapLists.release(); c->dMaterials.release(); c->dLights.release(); c->dTextures.release(); c->dGens.release();
   c->dQueue.release(); c->dStackOvf.release(); c->dCounters.release(); c->dFrame.release(); c->dRecord.release(); c->dRef.release(); c->dData.release();
-  c->dGrad.release(); c->dLoss.release();
+  c->dGrad.release(); c->dLoss.release(); c->dLossAcc.release();
   for (hpt_ctx::WfGroup* g : c->wfGroups) {
     for (auto& b : g->f4) b.release();
     for (auto& b : g->u) b.release();
+    g->rec.release(); g->lossSlot.release();
     if (g->progress) (void)hipHostFree(g->progress);
     for (auto& e : g->ev) if (e) (void)hipEventDestroy(e);
     if (g->done) (void)hipEventDestroy(g->done);
@@ -615,7 +616,7 @@ static int gridBlocks(hpt_ctx* c, bool dr)
 }
 
 static bool useWavefront(hpt_ctx* c, bool naive, bool dr, bool stats);
-static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st);
+static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr);
 
 // DEEP: the scene's BVH can need more than LDS_STACK stack entries, so pushes / pops check for the HBM overflow part
 // FLAT: single-level world-space BVH (static scenes within FLAT_TRI_BUDGET) vs two-level TLAS/BLAS
@@ -652,7 +653,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   job.counters = nullptr;
   const bool stats = c->instrument && !dr;
   c->lastSchedule = 1;
-  if (!inRays && useWavefront(c, naive, dr, stats && c->schedule != 2)) { c->lastSchedule = 2; return launch_wavefront(c, job, st); }
+  if (!inRays && useWavefront(c, naive, dr, stats && c->schedule != 2)) { c->lastSchedule = 2; return launch_wavefront(c, job, st, dr); }
   if (stats) { HIPCHK(c, c->dCounters.alloc(1)); HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(Counters), st)); job.counters = c->dCounters.p; }
   if (dr) {
     job.recordLanes = (uint)blocks * 256u;
@@ -685,7 +686,7 @@ static const uint   WF_GROUPS_AUTO = 2;            // concurrent pixel groups (s
 
 static bool useWavefront(hpt_ctx* c, bool naive, bool dr, bool stats)
 {
-  if (naive || dr || stats) return false;          // those variants exist as megakernels only
+  if (naive || stats) return false;                // those variants exist as megakernels only
   if (c->schedule == 1) return false;
   if (c->schedule == 2) return true;
   return c->instTris >= WF_AUTO_TRIS;
@@ -705,7 +706,7 @@ static void launchWfTrace(hpt_ctx* c, const WfPool& P, uint iter, int blocks, hi
   }
 }
 
-static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st)
+static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr)
 {
   // ---- groups: contiguous runs of work items, whole 256-item blocks each ----
   uint nGroups = c->wfGroupCount > 0 ? (uint)c->wfGroupCount : WF_GROUPS_AUTO;
@@ -735,11 +736,13 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st)
   WfJob wj;
   wj.tidBegin = job.tidBegin; wj.tidChunk = job.tidChunk; wj.tidStride = job.tidStride; wj.tidEnd = job.tidEnd;
   wj.passNum = job.passNum; wj.channels = job.channels; wj.outColor = job.outColor; wj.gens = job.gens; wj.packedXY = job.packedXY;
+  wj.refImg = job.refImg; wj.data = job.data; wj.grad = job.grad; wj.lossAccum = job.lossAccum; wj.record = nullptr;
   // every path takes at most traceDepth shade passes after the one that generated it; the pass that ends it (or the next one, when a
   // shadow ray was outstanding) also generates the pixel's next path
   // safety net only (the loop ends when a round queues no ray): pixels whose rays were suspended sit rounds out, so there is no tight bound
   const unsigned long long iterCap = 64ull * ((unsigned long long)job.passNum * (c->S.traceDepth + 2ull) + 4ull);
   c->lastWfIters = 0;
+  if (dr) { HIPCHK(c, c->dLossAcc.alloc(1)); HIPCHK(c, hipMemsetAsync(c->dLossAcc.p, 0, sizeof(double), st)); }
   HIPCHK(c, hipEventRecord(c->ev0, st));
   HIPCHK(c, hipEventRecord(c->wfFork, st));
 
@@ -758,10 +761,11 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st)
     HIPCHK(c, g.u[4].alloc(2 * WF_CTR_WORDS));
     HIPCHK(c, g.u[6].alloc(g.itemCount));
     HIPCHK(c, g.u[7].alloc(suspWords)); HIPCHK(c, g.u[8].alloc(suspWords));
+    if (dr) { HIPCHK(c, g.rec.alloc((size_t)g.itemCount * REC_FIELDS * (c->S.traceDepth + 1))); HIPCHK(c, g.lossSlot.alloc(g.itemCount)); }
     WfPool& P = pools[gi];
     P.rayO = g.f4[0].p; P.rayD = g.f4[1].p; P.thr = g.f4[2].p; P.acc = g.f4[3].p;
     P.shO = g.f4[4].p; P.shD = g.f4[5].p; P.contrib = g.f4[6].p; P.hit = g.f4[7].p;
-    P.hitInst = g.u[0].p; P.occl = g.u[1].p; P.status = g.u[2].p; P.rayQ[0] = g.u[3].p; P.rayQ[1] = g.u[5].p; P.ctr = g.u[4].p; P.inflight = g.u[6].p;
+    P.hitInst = g.u[0].p; P.occl = g.u[1].p; P.lossSlot = dr ? g.lossSlot.p : nullptr; P.status = g.u[2].p; P.rayQ[0] = g.u[3].p; P.rayQ[1] = g.u[5].p; P.ctr = g.u[4].p; P.inflight = g.u[6].p;
     P.susp[0] = g.u[7].p; P.susp[1] = g.u[8].p; P.maxSusp = (uint)maxSusp; P.suspStack = std::max(c->stackNeeded, 1u);
     HIPCHK(c, hipStreamWaitEvent(g.stream, c->wfFork, 0));
     HIPCHK(c, hipMemsetAsync(P.ctr, 0, 2 * WF_CTR_WORDS * sizeof(uint), g.stream));
@@ -773,8 +777,9 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st)
       hpt_ctx::WfGroup& g = *c->wfGroups[gi];
       if (g.finished) continue;
       const WfPool& P = pools[gi];
-      wj.itemBase = g.itemBase; wj.itemCount = g.itemCount; wj.iter = (uint)g.it;
-      wfShadeKernel<<<dim3((g.itemCount + 255u) / 256u), dim3(256), 0, g.stream>>>(c->S, P, wj);
+      wj.itemBase = g.itemBase; wj.itemCount = g.itemCount; wj.iter = (uint)g.it; wj.record = g.rec.p;
+      if (dr) wfShadeKernel<true><<<dim3((g.itemCount + 255u) / 256u), dim3(256), 0, g.stream>>>(c->S, P, wj);
+      else    wfShadeKernel<false><<<dim3((g.itemCount + 255u) / 256u), dim3(256), 0, g.stream>>>(c->S, P, wj);
       if ((g.it % WF_CHECK) == WF_CHECK - 1) {
         const uint slot = g.checkpoints % WF_RING;
         if (g.checkpoints >= WF_RING) {                                     // oldest checkpoint of the ring: wait for it, then look at it
@@ -800,12 +805,14 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st)
       }
       if (g.finished) {
         live--;
+        if (dr) wfLossReduceKernel<<<dim3(std::min((g.itemCount + 255u) / 256u, 1024u)), dim3(256), 0, g.stream>>>(pools[gi].lossSlot, g.itemCount, c->dLossAcc.p);
         HIPCHK(c, hipEventRecord(g.done, g.stream));
         HIPCHK(c, hipStreamWaitEvent(st, g.done, 0));
       }
     }
     HIPCHK(c, hipGetLastError());
   }
+  if (dr) wfLossFinishKernel<<<dim3(1), dim3(1), 0, st>>>(c->dLossAcc.p, job.lossAccum);
   HIPCHK(c, hipEventRecord(c->ev1, st));
   return HPT_OK;
 }

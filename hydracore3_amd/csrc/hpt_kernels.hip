@@ -175,16 +175,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
     // ---- (7) bookkeeping: adjoint record, end of path ------------------------------------------------------------------------------
     if (alive) {
       if (DR && didBounce) {
-        const size_t s = job.recordLanes;
-        float* r = job.record + ((size_t)bounce * REC_FIELDS) * s + glane;
-        r[0 * s] = recA.x; r[1 * s] = recA.y; r[2 * s] = recA.z;
-        r[3 * s] = recS.x; r[4 * s] = recS.y; r[5 * s] = recS.z;
-        r[6 * s] = recdA.x * thrBefore.x; r[7 * s] = recdA.y * thrBefore.y; r[8 * s] = recdA.z * thrBefore.z;     // T_b * dA_b/dtex
-        r[9 * s] = recdS.x * thrBefore.x; r[10 * s] = recdS.y * thrBefore.y; r[11 * s] = recdS.z * thrBefore.z;   // T_b * dS_b/dtex
-        r[12 * s] = __uint_as_float(recTex);
-        if (recTex != 0xFFFFFFFFu) {
-          for (int k = 0; k < 4; k++) { r[(13 + k) * s] = __int_as_float(recTaps.off[k]); r[(17 + k) * s] = recTaps.w[k]; }
-        }
+        drStoreRecord(job.record, job.recordLanes, glane, bounce, recA, recS, recdA, recdS, thrBefore, recTex, recTaps);
       }
       if (didBounce) bounce++;
       if ((flags & RAY_FLAG_IS_DEAD) != 0 || bounce >= maxBounce) {
@@ -212,31 +203,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
             lossLocal += (diff.x * diff.x + diff.y * diff.y + diff.z * diff.z) / float(job.passNum);
             PIX(0) += accum.x; PIX(1) += accum.y; PIX(2) += accum.z;           // out_color += colorRend (:1124-1126)
           }
-          const size_t s = job.recordLanes;
-          V3 Rn = tailR + env;
-          for (int b = sane ? (int)bounce - 1 : -1; b >= 0; b--) {
-            const float* r = job.record + ((size_t)b * REC_FIELDS) * s + glane;
-            const V3 A = v3(r[0 * s], r[1 * s], r[2 * s]), Sb = v3(r[3 * s], r[4 * s], r[5 * s]);
-            const uint texId = __float_as_uint(r[12 * s]);
-            if (texId != 0xFFFFFFFFu) {
-              const V3 TdA = v3(r[6 * s], r[7 * s], r[8 * s]), TdS = v3(r[9 * s], r[10 * s], r[11 * s]);
-              const V3 dC = TdS + TdA * Rn;
-              V3 g = v3(2.0f * diff.x * dC.x, 2.0f * diff.y * dC.y, 2.0f * diff.z * dC.z);
-              if (!__builtin_isfinite(g.x + g.y + g.z)) g = v3(0, 0, 0);
-              const TexRec t = S.textures[texId];
-              float* gbase = job.grad + t.diffOffset;
-              for (int k = 0; k < 4; k++) {
-                const int off = __float_as_int(r[(13 + k) * s]);
-                const float w = r[(17 + k) * s];
-                if (t.diffChannels == 4) {
-                  atomicAdd(gbase + (size_t)off * 4 + 0, g.x * w);
-                  atomicAdd(gbase + (size_t)off * 4 + 1, g.y * w);
-                  atomicAdd(gbase + (size_t)off * 4 + 2, g.z * w);
-                } else atomicAdd(gbase + off, (g.x + g.y + g.z) * w);
-              }
-            }
-            Rn = Sb + A * Rn;
-          }
+          if (sane) drReverseSweep(S, job.record, job.recordLanes, glane, bounce, tailR + env, diff, job.grad);
         } else {
           // kernel_ContributeToImage (integrator_pt.cpp:598-657)
           const V3 c = accum * ld3(S.camRespoceRGB);

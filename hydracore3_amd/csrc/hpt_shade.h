@@ -7,7 +7,6 @@
 
 namespace hpt {
 
-static const int REC_FIELDS = 24;   // A(3) S(3) T*dA(3) T*dS(3) texId tapOffsets(4) tapWeights(4) pad(3)
 
 HPT_DEV uint lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 HPT_DEV uint mbcnt64(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint)m, 0u)); }
@@ -219,6 +218,61 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
     }
   }
   return didBounce;
+}
+
+// ---- differentiable rendering: per-bounce adjoint record and the reverse sweep (shared by the megakernel and the wavefront shade pass) ----
+// Record of bounce b for path slot `idx` in a buffer laid out [bounce][field][slot] (stride = slots): coalesced, L2-resident.
+static const int REC_FIELDS = 24;   // A(3) S(3) T*dA(3) T*dS(3) texId tapOffsets(4) tapWeights(4) pad(3)
+HPT_DEV void drStoreRecord(float* record, size_t s, size_t idx, uint bounce, V3 recA, V3 recS, V3 recdA, V3 recdS, V3 thrBefore, uint recTex, const Taps& recTaps)
+{
+  float* r = record + ((size_t)bounce * REC_FIELDS) * s + idx;
+  r[0 * s] = recA.x; r[1 * s] = recA.y; r[2 * s] = recA.z;
+  r[3 * s] = recS.x; r[4 * s] = recS.y; r[5 * s] = recS.z;
+  r[6 * s] = recdA.x * thrBefore.x; r[7 * s] = recdA.y * thrBefore.y; r[8 * s] = recdA.z * thrBefore.z;     // T_b * dA_b/dtex
+  r[9 * s] = recdS.x * thrBefore.x; r[10 * s] = recdS.y * thrBefore.y; r[11 * s] = recdS.z * thrBefore.z;   // T_b * dS_b/dtex
+  r[12 * s] = __uint_as_float(recTex);
+  if (recTex != 0xFFFFFFFFu) {
+    for (int k = 0; k < 4; k++) { r[(13 + k) * s] = __int_as_float(recTaps.off[k]); r[(17 + k) * s] = recTaps.w[k]; }
+  }
+}
+// the light sample of bounce b turned out occluded: its S term and derivative vanish
+HPT_DEV void drClearShadowTerm(float* record, size_t s, size_t idx, uint bounce)
+{
+  float* r = record + ((size_t)bounce * REC_FIELDS) * s + idx;
+  r[3 * s] = 0.0f; r[4 * s] = 0.0f; r[5 * s] = 0.0f; r[9 * s] = 0.0f; r[10 * s] = 0.0f; r[11 * s] = 0.0f;
+}
+// Hand-derived reverse sweep replacing __enzyme_autodiff (integrator_dr.cpp:1172-1183). With T_0 = 1, T_{b+1} = T_b A_b and
+// C = sum_b T_b S_b + T_n tail:  dC/dtex_b = T_b dS_b + T_b dA_b R_{b+1},  R_b = S_b + A_b R_{b+1},  R_n = tail;  the loss gradient
+// 2 (C - ref) dC/dtex_b is scattered to the four bilinear taps with float atomics.
+HPT_DEV void drReverseSweep(const DevScene& S, const float* record, size_t s, size_t idx, uint bounce, V3 Rn, V3 diff, float* grad)
+{
+  for (int b = (int)bounce - 1; b >= 0; b--) {
+    const float* r = record + ((size_t)b * REC_FIELDS) * s + idx;
+    const V3 A = v3(r[0 * s], r[1 * s], r[2 * s]), Sb = v3(r[3 * s], r[4 * s], r[5 * s]);
+    const uint texId = __float_as_uint(r[12 * s]);
+    if (texId != 0xFFFFFFFFu) {
+      const V3 TdA = v3(r[6 * s], r[7 * s], r[8 * s]), TdS = v3(r[9 * s], r[10 * s], r[11 * s]);
+      const V3 dC = TdS + TdA * Rn;
+      V3 g = v3(2.0f * diff.x * dC.x, 2.0f * diff.y * dC.y, 2.0f * diff.z * dC.z);
+      if (!__builtin_isfinite(g.x + g.y + g.z)) g = v3(0, 0, 0);
+      const TexRec t = S.textures[texId];
+      float* gbase = grad + t.diffOffset;
+      for (int k = 0; k < 4; k++) {
+        const int off = __float_as_int(r[(13 + k) * s]);
+        const float w = r[(17 + k) * s];
+#ifdef HPT_DR_NO_ATOMICS    // diagnostic build only: how much of PathTraceDR is the gradient scatter?
+        if (off < -1) gbase[0] = g.x * w;
+        continue;
+#endif
+        if (t.diffChannels == 4) {
+          atomicAdd(gbase + (size_t)off * 4 + 0, g.x * w);
+          atomicAdd(gbase + (size_t)off * 4 + 1, g.y * w);
+          atomicAdd(gbase + (size_t)off * 4 + 2, g.z * w);
+        } else atomicAdd(gbase + off, (g.x + g.y + g.z) * w);
+      }
+    }
+    Rn = Sb + A * Rn;
+  }
 }
 
 } // namespace hpt

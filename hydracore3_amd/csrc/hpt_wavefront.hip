@@ -42,6 +42,8 @@ struct WfPool
   uint*   hitInst;   // instId or 0xFFFFFFFF
   uint*   occl;      // shadow ray result
   uint*   status;
+  float*  lossSlot;  // DR: per-slot sum of the pixel's sample losses (reduced in double at the end: one float accumulator for 10^7..10^8
+                     // samples loses the small increments - measured 1.5 % low on the 1M-triangle scene)
   uint*   inflight;  // bit 0 / 1: the slot's closest-hit / shadow ray was suspended by a trace pass and has not finished yet
   uint*   rayQ[2];   // compacted ray queue of round (iteration & 1): slot id | (shadow ray ? 1 << 31 : 0) | (resumed ray ? 1 << 30 : 0)
   uint*   susp[2];   // traversal state of the rays a trace pass suspended, written for the NEXT round: [WF_SUSP_WORDS + stack][maxSusp],
@@ -61,12 +63,14 @@ struct WfJob
   float* outColor;
   Rng*   gens;
   const uint* packedXY;
+  // differentiable rendering (wfShadeKernel<DR = true>): a_refImg, a_data, a_dataGrad, loss accumulator, adjoint records [bounce][field][slot]
+  const float* refImg; const float* data; float* grad; float* lossAccum; float* record;
 };
 
 __global__ void wfInitKernel(WfPool P, uint n, uint passNum)
 {
   const uint i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { P.status[i] = passNum << 8; P.inflight[i] = 0u; }       // (the counters are zeroed by the host: the grid may be smaller than the counter block)
+  if (i < n) { P.status[i] = passNum << 8; P.inflight[i] = 0u; if (P.lossSlot) P.lossSlot[i] = 0.0f; }       // (the counters are zeroed by the host: the grid may be smaller than the counter block)
 }
 
 // Ray compaction. Every wave ballots its two kinds of rays and prefix-sums the lanes (mbcnt); the four waves of the block add
@@ -92,6 +96,7 @@ HPT_DEV void blockAppend(uint* counter, bool qNear, bool qShad, uint& posNear, u
   posShad = base + cn + mbcnt64(ms);
 }
 
+template <bool DR>
 __global__ void __launch_bounds__(256) wfShadeKernel(const DevScene S, const WfPool P, const WfJob job)
 {
   const uint s = blockIdx.x * 256u + threadIdx.x;
@@ -118,23 +123,35 @@ __global__ void __launch_bounds__(256) wfShadeKernel(const DevScene S, const WfP
     V3 accum = v3(0, 0, 0), thr = v3(1, 1, 1), rpos = v3(0, 0, 0), rdir = v3(0, 0, 1);
     float misPdf = 1.0f, misIor = 1.0f; uint flags = 0, bounce = 0;
     if (alive || ending) { const float4 a = P.acc[s]; accum = v3(a.x, a.y, a.z); bounce = __float_as_uint(a.w); }
+    if (DR && ending) { const float4 t4 = P.thr[s]; thr = v3(t4.x, t4.y, t4.z); }     // the environment term of the finished path needs its throughput
     // (6') the shadow ray traced since the last visit: add the candidate contribution in the megakernel's order
-    if (pend) { if (P.occl[s] == 0u) { const float4 c = P.contrib[s]; accum = accum + v3(c.x, c.y, c.z); } pend = false; }
+    if (pend) {
+      if (P.occl[s] == 0u) { const float4 c = P.contrib[s]; accum = accum + v3(c.x, c.y, c.z); }
+      else if (DR && bounce > 0u) drClearShadowTerm(job.record, job.itemCount, s, bounce - 1u);   // the light sample of the last vertex was occluded
+      pend = false;
+    }
     bool finalize = ending;                                                // path ended last time, only its shadow ray was outstanding
     ending = false;
     V3 shPos = v3(0, 0, 0), shDir = v3(0, 0, 1), contrib = v3(0, 0, 0); float shFar = 0.0f;
+    V3 tailR = v3(0, 0, 0);                                                 // DR: emission picked up at the terminating vertex, per unit throughput
 
     if (alive) {
       const float4 ro = P.rayO[s], rd = P.rayD[s], t4 = P.thr[s], h4 = P.hit[s];
       rpos = v3(ro.x, ro.y, ro.z); misPdf = ro.w; rdir = v3(rd.x, rd.y, rd.z); misIor = rd.w;
       thr = v3(t4.x, t4.y, t4.z); flags = __float_as_uint(t4.w);
       HitRec hit; hit.t = h4.x; hit.u = h4.y; hit.v = h4.z; hit.prim = __float_as_uint(h4.w); hit.inst = P.hitInst[s];
-      V3 rA, rS, rdA, rdS, tailR; Taps taps; uint recTex = 0xFFFFFFFFu;     // differentiable-rendering outputs: unused here
-      const bool didBounce = shadeVertex<false, false>(S, nullptr, hit, rpos, rdir, accum, thr, misPdf, misIor, flags, bounce, gen,
-                                                       wantShadow, shPos, shDir, shFar, contrib, rA, rS, rdA, rdS, taps, recTex, tailR);
+      V3 rA = v3(0, 0, 0), rS = v3(0, 0, 0), rdA = v3(0, 0, 0), rdS = v3(0, 0, 0); Taps taps; uint recTex = 0xFFFFFFFFu;   // adjoint record of this vertex (DR)
+      for (int k = 0; k < 4; k++) { taps.off[k] = 0; taps.w[k] = 0.0f; }
+      const V3 thrBefore = thr;
+      const bool didBounce = shadeVertex<DR, false>(S, DR ? job.data : nullptr, hit, rpos, rdir, accum, thr, misPdf, misIor, flags, bounce, gen,
+                                                    wantShadow, shPos, shDir, shFar, contrib, rA, rS, rdA, rdS, taps, recTex, tailR);
+      if (DR && didBounce) {
+        if (!wantShadow) { rS = v3(0, 0, 0); rdS = v3(0, 0, 0); }           // (an occluded sample is cleared when its shadow ray comes back)
+        drStoreRecord(job.record, job.itemCount, s, bounce, rA, rS, rdA, rdS, thrBefore, recTex, taps);
+      }
       if (didBounce) bounce++;
       if ((flags & RAY_FLAG_IS_DEAD) != 0 || bounce >= S.traceDepth) {
-        if ((flags & RAY_FLAG_OUT_OF_SCENE) != 0) {                         // kernel_HitEnvironment (integrator_pt.cpp:550-595)
+        if (!DR && (flags & RAY_FLAG_OUT_OF_SCENE) != 0) {                  // kernel_HitEnvironment (integrator_pt.cpp:550-595)
           const V3 env = ld3(S.envColor);
           if (S.integratorType == INTEGRATOR_STUPID_PT) accum = thr * env; else accum = accum + thr * env;
         }
@@ -142,7 +159,21 @@ __global__ void __launch_bounds__(256) wfShadeKernel(const DevScene S, const WfP
         if (wantShadow) ending = true; else finalize = true;
       }
     }
-    if (finalize) {                                                          // kernel_ContributeToImage (integrator_pt.cpp:598-657)
+    if (finalize && DR) {
+      // PixelLossPT (integrator_dr.cpp:1103-1132): the replay adds the environment term unconditionally (:1077-1098), after the last
+      // shadow contribution as in the megakernel; per-sample loss against the y-flipped reference; out_color += colorRend; reverse sweep
+      const V3 env = ld3(S.envColor);
+      accum = accum + thr * env;
+      const uint x = XY & 0x0000FFFFu, y = (XY & 0xFFFF0000u) >> 16;
+      const float* rp = job.refImg + ((size_t)((uint)S.winHeight - y - 1u) * (uint)S.winWidth + x) * job.channels;
+      const V3 diff = v3(accum.x - rp[0], accum.y - rp[1], accum.z - rp[2]);
+      if (__builtin_isfinite(diff.x + diff.y + diff.z)) {                   // (non-finite samples: see the megakernel)
+        P.lossSlot[s] += (diff.x * diff.x + diff.y * diff.y + diff.z * diff.z) / float(job.passNum);
+        float* o = job.outColor + ((size_t)y * (uint)S.winWidth + x) * job.channels;
+        o[0] += accum.x; o[1] += accum.y; o[2] += accum.z;
+        drReverseSweep(S, job.record, job.itemCount, s, bounce, tailR + env, diff, job.grad);
+      }
+    } else if (finalize) {                                                   // kernel_ContributeToImage (integrator_pt.cpp:598-657)
       const uint pixel = ((XY & 0xFFFF0000u) >> 16) * (uint)S.winWidth + (XY & 0x0000FFFFu);
       const V3 c = accum * ld3(S.camRespoceRGB);
       if (job.channels == 1) job.outColor[pixel] += accum.x * S.exposureMult;
@@ -159,8 +190,8 @@ __global__ void __launch_bounds__(256) wfShadeKernel(const DevScene S, const WfP
     if (alive) {
       P.rayO[s] = make_float4(rpos.x, rpos.y, rpos.z, misPdf);
       P.rayD[s] = make_float4(rdir.x, rdir.y, rdir.z, misIor);
-      P.thr[s] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(flags));
     }
+    if (alive || (DR && ending)) P.thr[s] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(flags));
     if (alive || ending) P.acc[s] = make_float4(accum.x, accum.y, accum.z, __uint_as_float(bounce));
     if (wantShadow) {
       P.shO[s] = make_float4(shPos.x, shPos.y, shPos.z, shFar);
@@ -177,6 +208,19 @@ __global__ void __launch_bounds__(256) wfShadeKernel(const DevScene S, const WfP
   if (qNear) rayQ[kn] = s;
   if (qShad) rayQ[ks] = s | 0x80000000u;
 }
+
+// DR: sum of the per-slot losses in double, one atomic per block; wfLossFinishKernel adds the total to the caller's float
+__global__ void __launch_bounds__(256) wfLossReduceKernel(const float* lossSlot, uint n, double* acc)
+{
+  __shared__ double part[4];
+  double x = 0.0;
+  for (uint i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) x += (double)lossSlot[i];
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+  if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = x;
+  __syncthreads();
+  if (threadIdx.x == 0u) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+}
+__global__ void wfLossFinishKernel(const double* acc, float* loss) { *loss += (float)*acc; }
 
 // ---- persistent traversal with ray replacement -------------------------------------------------------------------------------
 #ifndef HPT_WF_SPECULATE

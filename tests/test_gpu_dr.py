@@ -115,3 +115,36 @@ def test_texture_regulariser_matches_oracle():
         gpu.Image2D4fRegularizer(data, gg)
         assert np.allclose(gg, gc, rtol=1e-4, atol=1e-4), (h, w, float(np.abs(gg - gc).max()))
         assert np.array_equal(gg[..., 3], g0[..., 3])
+
+
+def test_dr_under_the_wavefront_schedule_equals_megakernel():
+    """PathTraceDR scheduled as shade / trace kernel pairs (records per pool slot, occluded light samples cleared when their shadow
+    ray returns, reverse sweep in the shade pass) == the DR megakernel: same colours and generators bit for bit, loss and gradient up
+    to the order of the float atomics; and == the oracle within the gradient bar."""
+    from hydracore3_amd.api import HipIntegrator
+    from hydracore3_amd import synth
+    from oracle.orc import OracleIntegrator
+    sc = synth.interior_scene(96, 64, objects=12, subdiv=1, tex_size=16)
+    mega, wf, cpu = HipIntegrator(sc), HipIntegrator(sc), OracleIntegrator(sc)
+    mega.set_schedule(1); wf.set_schedule(2, 56, 0, 2)
+    for integ in (mega, wf):
+        assert integ.PutDiffTex2D(1, 16, 16, 4) == (0, 16 * 16 * 4)
+    cpu.put_diff_tex2d(1, 16, 16, 4)
+    rng = np.random.default_rng(4)
+    data = rng.uniform(0.2, 0.9, 16 * 16 * 4).astype(np.float32)
+    ref = rng.uniform(0.0, 0.5, (sc.height, sc.width, 4)).astype(np.float32)
+    spp = 5
+    outs, grads, losses = [], [], []
+    for integ in (mega, wf):
+        out = np.zeros((sc.height, sc.width, 4), np.float32); g = np.zeros_like(data)
+        losses.append(integ.PathTraceDR(integ.N, 4, out, spp, ref, data, g))
+        outs.append(out); grads.append(g)
+    assert mega.last_schedule()[0] == 1 and wf.last_schedule()[0] == 2
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(mega.random_gens(), wf.random_gens())
+    assert abs(losses[0] - losses[1]) <= 1e-5 * abs(losses[0])
+    assert np.linalg.norm(grads[0] - grads[1]) <= 1e-5 * np.linalg.norm(grads[0])
+    out_c = np.zeros_like(outs[0])
+    loss_c, grad_c = cpu.path_trace_dr(out_c, spp, ref, data)
+    assert abs(losses[1] - loss_c) <= 1e-4 * abs(loss_c)
+    assert np.linalg.norm(grads[1] - grad_c) / np.linalg.norm(grad_c) < 1e-2

@@ -218,7 +218,8 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # HYDRA_BENCH_FORCE_DIST=1: initialise the process group even for one rank (exercises the RCCL code path on a one-GPU box)
+    if world > 1 or os.environ.get("HYDRA_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -232,7 +233,10 @@ def main():
         dist.barrier()
     from hydracore3_amd.api import HipIntegrator
     if args.workload in ("dr", "dr_interior"):
-        return run_dr(args, rank, world, dev, torch.cuda.current_stream().cuda_stream, dist, backend)
+        run_dr(args, rank, world, dev, torch.cuda.current_stream().cuda_stream, dist, backend)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     W, H = (args.width or (1024 if args.workload == "cornell" else 1920)), (args.height or (1024 if args.workload == "cornell" else 1080))
     spp = args.spp
@@ -374,6 +378,8 @@ def main():
                           "mean_radiance": round(mean_lum, 5), "sharded_frame_verified": verified},
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,478 @@
+// Scene ingestion for the HIP core without Python: Hydra XML scene description + VSGF meshes + image4ub
+// textures + IES photometry -> the flat tables hpt_upload_scene / hpt_add_geom_triangles3f / hpt_add_instance / hpt_update_params take.
+//
+// Follows the reference's loaders for the material / light subset of the hot path:
+//   LoadScene / LoadSceneGeometry / LoadSceneInstances / LoadSceneSettings   integrator_pt_scene.cpp:645-1076
+//   ConvertOldHydraMaterial (diffuse-only + emission branches)                  integrator_pt_scene_mat.cpp:280-450
+//   LoadLightSourceFromNode (rect, disk, sphere, point / spot / IES, directional, plain-colour sky)   integrator_pt_scene_lgt.cpp:5-222
+//   LoadTextureAndMakeCombined / image4ub                                       integrator_pt_scene_tex.cpp:7-144
+//   cmesh4::LoadMeshFromVSGF                                                    external/LiteScene/cmesh4.cpp:140-167
+//   CreateSphericalTextureFromIES (axially symmetric photometry)               ies_parser/ies_render.cpp:29-120
+// and produces the same tables as the Python fixture loader (hydracore3_amd/scene.py; tests compare the two byte for byte, matrices
+// to float rounding). Header-only host C++17, no dependencies: the XML subset Hydra writes (elements, attributes, text, comments)
+// is parsed by the ~80 lines below instead of pugixml.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "integrator_hip.h"
+
+namespace hydra_hip {
+
+// ---- minimal XML --------------------------------------------------------------------------------------------------------------
+struct XmlNode
+{
+  std::string name, text;
+  std::map<std::string, std::string> attr;
+  std::vector<XmlNode> children;
+  const XmlNode* child(const std::string& n) const { for (const XmlNode& c : children) if (c.name == n) return &c; return nullptr; }
+  std::vector<const XmlNode*> all(const std::string& n) const { std::vector<const XmlNode*> r; for (const XmlNode& c : children) if (c.name == n) r.push_back(&c); return r; }
+  const XmlNode* path(const std::string& p) const
+  {
+    const XmlNode* cur = this; size_t a = 0;
+    while (cur && a <= p.size()) { const size_t b = p.find('/', a); cur = cur->child(p.substr(a, b == std::string::npos ? std::string::npos : b - a)); if (b == std::string::npos) break; a = b + 1; }
+    return cur;
+  }
+  bool has(const std::string& k) const { return attr.count(k) != 0; }
+  std::string get(const std::string& k, const std::string& dflt = "") const { auto it = attr.find(k); return it == attr.end() ? dflt : it->second; }
+  std::string childText(const std::string& n) const { const XmlNode* c = child(n); return c ? c->text : std::string(); }
+};
+
+class XmlParser
+{
+public:
+  explicit XmlParser(const std::string& s) : t(s) {}
+  bool parse(XmlNode& root, std::string& err)
+  {
+    root.name = "root";
+    while (true) {
+      skipMisc();
+      if (i >= t.size()) return true;
+      if (t[i] != '<') { err = "xml: text outside of an element"; return false; }
+      XmlNode n; if (!element(n, err)) return false;
+      root.children.push_back(std::move(n));
+    }
+  }
+private:
+  const std::string& t; size_t i = 0;
+  void ws() { while (i < t.size() && std::isspace((unsigned char)t[i])) i++; }
+  void skipMisc()
+  {
+    while (true) {
+      ws();
+      if (t.compare(i, 4, "<!--") == 0) { const size_t e = t.find("-->", i); i = e == std::string::npos ? t.size() : e + 3; }
+      else if (t.compare(i, 2, "<?") == 0) { const size_t e = t.find("?>", i); i = e == std::string::npos ? t.size() : e + 2; }
+      else return;
+    }
+  }
+  static std::string trim(const std::string& s)
+  {
+    size_t a = 0, b = s.size();
+    while (a < b && std::isspace((unsigned char)s[a])) a++;
+    while (b > a && std::isspace((unsigned char)s[b - 1])) b--;
+    return s.substr(a, b - a);
+  }
+  bool element(XmlNode& n, std::string& err)
+  {
+    i++;                                                    // '<'
+    const size_t a = i;
+    while (i < t.size() && !std::isspace((unsigned char)t[i]) && t[i] != '>' && t[i] != '/') i++;
+    n.name = t.substr(a, i - a);
+    while (true) {                                          // attributes
+      ws();
+      if (i >= t.size()) { err = "xml: unterminated tag <" + n.name; return false; }
+      if (t[i] == '/') { i += 2; return true; }             // "/>"
+      if (t[i] == '>') { i++; break; }
+      const size_t k0 = i;
+      while (i < t.size() && t[i] != '=' && !std::isspace((unsigned char)t[i])) i++;
+      const std::string key = t.substr(k0, i - k0);
+      ws(); if (i >= t.size() || t[i] != '=') { err = "xml: attribute without value in <" + n.name; return false; }
+      i++; ws();
+      const char q = t[i]; if (q != '"' && q != '\'') { err = "xml: unquoted attribute in <" + n.name; return false; }
+      const size_t v0 = ++i; const size_t v1 = t.find(q, v0);
+      if (v1 == std::string::npos) { err = "xml: unterminated attribute in <" + n.name; return false; }
+      n.attr[key] = t.substr(v0, v1 - v0); i = v1 + 1;
+    }
+    std::string text;
+    while (true) {                                          // content
+      const size_t lt = t.find('<', i);
+      if (lt == std::string::npos) { err = "xml: missing </" + n.name + ">"; return false; }
+      text += t.substr(i, lt - i); i = lt;
+      if (t.compare(i, 4, "<!--") == 0) { const size_t e = t.find("-->", i); i = e == std::string::npos ? t.size() : e + 3; continue; }
+      if (t.compare(i, 2, "</") == 0) { const size_t e = t.find('>', i); i = e == std::string::npos ? t.size() : e + 1; break; }
+      XmlNode c; if (!element(c, err)) return false;
+      n.children.push_back(std::move(c));
+    }
+    n.text = trim(text);
+    return true;
+  }
+};
+
+// ---- small double-precision matrix helpers (row-major [r][c]; the tables store LiteMath's column-major float) ---------------------
+struct M4 { double m[4][4]; };
+inline M4 m4Identity() { M4 r; for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) r.m[a][b] = a == b ? 1.0 : 0.0; return r; }
+inline M4 m4Mul(const M4& A, const M4& B) { M4 r; for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) { double s = 0; for (int k = 0; k < 4; k++) s += A.m[a][k] * B.m[k][b]; r.m[a][b] = s; } return r; }
+inline M4 m4Transpose(const M4& A) { M4 r; for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) r.m[a][b] = A.m[b][a]; return r; }
+inline M4 m4Inverse(const M4& A)                             // Gauss-Jordan with partial pivoting
+{
+  double a[4][8];
+  for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { a[r][c] = A.m[r][c]; a[r][4 + c] = r == c ? 1.0 : 0.0; }
+  for (int c = 0; c < 4; c++) {
+    int p = c; for (int r = c + 1; r < 4; r++) if (std::fabs(a[r][c]) > std::fabs(a[p][c])) p = r;
+    if (p != c) for (int k = 0; k < 8; k++) std::swap(a[p][k], a[c][k]);
+    const double d = a[c][c];
+    for (int k = 0; k < 8; k++) a[c][k] /= d;
+    for (int r = 0; r < 4; r++) if (r != c) { const double f = a[r][c]; if (f != 0.0) for (int k = 0; k < 8; k++) a[r][k] -= f * a[c][k]; }
+  }
+  M4 R; for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) R.m[r][c] = a[r][4 + c];
+  return R;
+}
+inline void m4ToColMajor(const M4& A, float out[16]) { for (int c = 0; c < 4; c++) for (int r = 0; r < 4; r++) out[c * 4 + r] = (float)A.m[r][c]; }
+inline std::vector<double> parseFloats(const std::string& s) { std::vector<double> v; std::istringstream is(s); double x; while (is >> x) v.push_back(x); return v; }
+inline M4 m4FromText(const std::string& s) { M4 r = m4Identity(); const std::vector<double> v = parseFloats(s); for (int k = 0; k < 16 && k < (int)v.size(); k++) r.m[k / 4][k % 4] = v[k]; return r; }
+
+// ---- the loaded scene --------------------------------------------------------------------------------------------------------------
+struct LoadedTexture { uint32_t width = 1, height = 1, format = 0, flags = 0, addressU = 0, addressV = 0, filter = 1; std::vector<uint8_t> bytes; };
+
+struct LoadedScene
+{
+  std::vector<float> vPos4f, vData8f, instMatrices, normMatrices;
+  std::vector<uint32_t> triIndices, matIdByPrimId, matVertOffset, geomTriCount, geomVertCount, instGeomId;
+  std::vector<int32_t> remapInst, allRemapLists{0};
+  uint32_t allRemapListsSize = 0;
+  std::vector<Material> materials;
+  std::vector<LightSource> lights;
+  std::vector<LoadedTexture> textures;
+  int width = 512, height = 512;
+  double fov = 45.0, nearClip = 0.01, farClip = 100.0, camPos[3] = {0, 0, 15}, camLookAt[3] = {0, 0, 0}, camUp[3] = {0, 1, 0};
+  uint32_t traceDepth = 6, spp = 1;
+  float envColor[4] = {0, 0, 0, 0};
+  std::vector<hpt_texture_desc> texDescs;                 // filled by desc(): points into `textures`
+
+  hpt_scene_desc desc()
+  {
+    hpt_scene_desc d; std::memset(&d, 0, sizeof(d));
+    d.numGeoms = (uint32_t)geomTriCount.size(); d.numInsts = (uint32_t)instGeomId.size();
+    d.numVerts = (uint32_t)(vPos4f.size() / 4); d.numTris = (uint32_t)matIdByPrimId.size();
+    d.vPos4f = vPos4f.data(); d.vData8f = vData8f.data(); d.triIndices = triIndices.data(); d.matIdByPrimId = matIdByPrimId.data();
+    d.matVertOffset = matVertOffset.data(); d.geomTriCount = geomTriCount.data(); d.geomVertCount = geomVertCount.data();
+    d.instGeomId = instGeomId.data(); d.instMatrices = instMatrices.data(); d.normMatrices = normMatrices.data();
+    d.remapInst = remapInst.data(); d.allRemapLists = allRemapLists.data();
+    d.allRemapListsLen = (uint32_t)allRemapLists.size(); d.allRemapListsSize = allRemapListsSize;
+    d.materials = materials.data(); d.numMaterials = (uint32_t)materials.size();
+    d.lights = lights.empty() ? nullptr : lights.data(); d.numLights = (uint32_t)lights.size();
+    texDescs.resize(textures.size());
+    for (size_t i = 0; i < textures.size(); i++) {
+      const LoadedTexture& t = textures[i]; hpt_texture_desc& o = texDescs[i]; std::memset(&o, 0, sizeof(o));
+      o.width = t.width; o.height = t.height; o.format = t.format; o.flags = t.flags; o.addressU = t.addressU; o.addressV = t.addressV; o.filter = t.filter;
+      o.data = t.bytes.data();
+    }
+    d.textures = texDescs.data(); d.numTextures = (uint32_t)texDescs.size();
+    return d;
+  }
+
+  uint32_t tileSize() const { for (uint32_t ts : {8u, 4u, 2u}) if (width % (int)ts == 0 && height % (int)ts == 0) return ts; return 1u; }   // SetViewport (integrator_pt.h:379-389)
+
+  hpt_params params(uint32_t integratorType = 2, uint32_t renderLayer = 0) const
+  {
+    hpt_params p; std::memset(&p, 0, sizeof(p));
+    // perspectiveMatrix / lookAt as LiteMath defines them (OpenGL conventions), inverted in double
+    const double aspect = double(width) / double(height);
+    const double ymax = nearClip * std::tan(fov * M_PI / 360.0), xmax = ymax * aspect;
+    const double left = -xmax, right = xmax, bottom = -ymax, top = ymax;
+    const double t = 2.0 * nearClip, t2 = right - left, t3 = top - bottom, t4 = farClip - nearClip;
+    M4 proj; std::memset(&proj, 0, sizeof(proj));
+    proj.m[0][0] = t / t2; proj.m[1][1] = t / t3; proj.m[0][2] = (right + left) / t2; proj.m[1][2] = (top + bottom) / t3;
+    proj.m[2][2] = (-farClip - nearClip) / t4; proj.m[3][2] = -1.0; proj.m[2][3] = (-t * farClip) / t4;
+    double f[3] = { camLookAt[0] - camPos[0], camLookAt[1] - camPos[1], camLookAt[2] - camPos[2] };
+    const double fl = std::sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]); for (double& x : f) x /= fl;
+    const double ul = std::sqrt(camUp[0] * camUp[0] + camUp[1] * camUp[1] + camUp[2] * camUp[2]);
+    const double un[3] = { camUp[0] / ul, camUp[1] / ul, camUp[2] / ul };
+    double s[3] = { f[1] * un[2] - f[2] * un[1], f[2] * un[0] - f[0] * un[2], f[0] * un[1] - f[1] * un[0] };
+    const double sl = std::sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]); for (double& x : s) x /= sl;
+    const double u[3] = { s[1] * f[2] - s[2] * f[1], s[2] * f[0] - s[0] * f[2], s[0] * f[1] - s[1] * f[0] };
+    M4 wv = m4Identity();
+    for (int k = 0; k < 3; k++) { wv.m[0][k] = s[k]; wv.m[1][k] = u[k]; wv.m[2][k] = -f[k]; }
+    wv.m[0][3] = -(s[0] * camPos[0] + s[1] * camPos[1] + s[2] * camPos[2]);
+    wv.m[1][3] = -(u[0] * camPos[0] + u[1] * camPos[1] + u[2] * camPos[2]);
+    wv.m[2][3] = (f[0] * camPos[0] + f[1] * camPos[1] + f[2] * camPos[2]);
+    m4ToColMajor(m4Inverse(proj), p.projInv); m4ToColMajor(m4Inverse(wv), p.worldViewInv);
+    p.winStartX = p.winStartY = 0; p.winWidth = p.fbWidth = width; p.winHeight = p.fbHeight = height;
+    p.traceDepth = traceDepth; p.integratorType = integratorType; p.renderLayer = renderLayer; p.tileSize = tileSize(); p.spectralMode = 0;
+    p.exposureMult = 1.0f; p.camLensRadius = 0.0f; p.camTargetDist = (float)fl;
+    for (int k = 0; k < 4; k++) { p.camRespoceRGB[k] = 1.0f; p.envColor[k] = envColor[k]; }
+    return p;
+  }
+
+  // feed a context: geometry -> BVH, tables, parameters, pixel order, generators (what main.cpp:249-267 does through the Integrator)
+  int upload(hpt_ctx* ctx, uint32_t integratorType = 2)
+  {
+    int rc = hpt_clear_geom(ctx); if (rc) return rc;
+    for (size_t g = 0; g < geomTriCount.size(); g++) {
+      const uint32_t triOff = matVertOffset[2 * g], vertOff = matVertOffset[2 * g + 1];
+      if (hpt_add_geom_triangles3f(ctx, vPos4f.data() + 4 * (size_t)vertOff, geomVertCount[g], triIndices.data() + 3 * (size_t)triOff, 3 * (size_t)geomTriCount[g], 0, 16) == 0xFFFFFFFFu) return HPT_ERR_ARG;
+    }
+    rc = hpt_clear_scene(ctx); if (rc) return rc;
+    for (size_t i = 0; i < instGeomId.size(); i++) if (hpt_add_instance(ctx, instGeomId[i], instMatrices.data() + 16 * i) == 0xFFFFFFFFu) return HPT_ERR_ARG;
+    rc = hpt_commit_scene(ctx, 4); if (rc) return rc;
+    hpt_scene_desc d = desc();
+    rc = hpt_upload_scene(ctx, &d); if (rc) return rc;
+    hpt_params p = params(integratorType);
+    rc = hpt_update_params(ctx, &p); if (rc) return rc;
+    rc = hpt_pack_xy(ctx, (uint32_t)width, (uint32_t)height); if (rc) return rc;
+    return hpt_init_random_gens(ctx, (uint32_t)(width * height));
+  }
+};
+
+namespace detail {
+
+inline bool readFile(const std::string& path, std::vector<uint8_t>& out)
+{
+  std::ifstream f(path, std::ios::binary); if (!f) return false;
+  f.seekg(0, std::ios::end); const std::streamoff n = f.tellg(); f.seekg(0);
+  out.resize((size_t)n); if (n) f.read((char*)out.data(), n);
+  return (bool)f;
+}
+
+inline Material blankMaterial()
+{
+  Material m; std::memset(&m, 0, sizeof(m));
+  m.lightId = 0xFFFFFFFFu;
+  m.texid[0] = 0; m.texid[1] = 0xFFFFFFFFu; m.texid[2] = 0; m.texid[3] = 0;          // texid[1] = no normal map (integrator_pt_scene.cpp:604)
+  for (int k = 0; k < 4; k++) { m.spdid[k] = 0xFFFFFFFFu; m.row0[k][0] = 1.0f; m.row1[k][1] = 1.0f; }
+  return m;
+}
+inline LightSource blankLight()
+{
+  LightSource l; std::memset(&l, 0, sizeof(l));
+  l.distType = 0; l.iesId = l.texId = l.specId = l.camBackTexId = l.matId = 0xFFFFFFFFu;
+  l.samplerRow0[0] = 1.0f; l.samplerRow1[1] = 1.0f; l.mult = 1.0f;
+  return l;
+}
+inline void lightFrame(const M4& m, LightSource& l)          // pos = M (0,0,0,1), norm = normalize(M (0,-1,0,0))
+{
+  for (int k = 0; k < 4; k++) l.pos[k] = (float)m.m[k][3];
+  const double n[4] = { -m.m[0][1], -m.m[1][1], -m.m[2][1], -m.m[3][1] };
+  const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2] + n[3] * n[3]);
+  for (int k = 0; k < 4; k++) l.norm[k] = (float)(n[k] / len);
+}
+inline double colLen(const M4& m, int c) { return std::sqrt(m.m[0][c] * m.m[0][c] + m.m[1][c] * m.m[1][c] + m.m[2][c] * m.m[2][c]); }
+
+// CreateSphericalTextureFromIES, axially symmetric photometry, normalised to max 1 (integrator_pt_scene_lgt.cpp:171-186)
+inline bool iesSphericalTexture(const std::string& path, LoadedTexture& tex, std::string& err)
+{
+  std::vector<uint8_t> raw; if (!readFile(path, raw)) { err = "cannot read " + path; return false; }
+  const std::string s(raw.begin(), raw.end());
+  const size_t p = s.find("TILT=NONE"); if (p == std::string::npos) { err = "IES: only TILT=NONE files are handled"; return false; }
+  const std::vector<double> vals = parseFloats(s.substr(p + 9));
+  if (vals.size() < 13) { err = "IES: truncated header"; return false; }
+  const int nVert = (int)vals[3], nHorz = (int)vals[4];
+  if (nHorz != 1) { err = "IES: only axially symmetric photometry (one horizontal angle) is handled"; return false; }
+  if ((int)vals.size() < 13 + nVert + nHorz + nVert) { err = "IES: truncated data"; return false; }
+  const double* vert = vals.data() + 13; const double* cand = vert + nVert + nHorz;
+  const double v0 = vert[0], v1 = vert[nVert - 1];
+  const bool half = (std::fabs(v0) < 1e-5 && std::fabs(v1 - 90) < 1e-5) || (std::fabs(v0 - 90) < 1e-5 && std::fabs(v1 - 180) < 1e-5);
+  const int h = half ? nVert * 2 : nVert;
+  std::vector<float> img((size_t)h, 0.0f);
+  const float step = float(v1 - v0) / float(nVert);
+  float thetaGrad = float(v0);
+  for (int ti = 0; ti < nVert; ti++) {
+    const float theta = float(M_PI / 180.0) * thetaGrad;
+    int iy = int((theta * float(1.0 / M_PI)) * float(h) + 0.5f); if (iy > h - 1) iy = h - 1;
+    img[(size_t)iy] = (float)cand[ti];
+    thetaGrad = thetaGrad + step;
+  }
+  float mx = 0.0f; for (float v : img) mx = std::max(mx, v); if (mx == 0.0f) mx = 1.0f;
+  const float inv = 1.0f / mx; for (float& v : img) v *= inv;
+  tex = LoadedTexture(); tex.width = 1; tex.height = (uint32_t)h; tex.format = 2; tex.flags = 0; tex.addressU = 2; tex.addressV = 2; tex.filter = 1;
+  tex.bytes.resize(img.size() * 4); std::memcpy(tex.bytes.data(), img.data(), tex.bytes.size());
+  return true;
+}
+
+} // namespace detail
+
+inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, LoadedScene& sc, std::string& err)
+{
+  using namespace detail;
+  std::vector<uint8_t> raw; if (!readFile(xmlPath, raw)) { err = "cannot read " + xmlPath; return false; }
+  const std::string text(raw.begin(), raw.end());
+  XmlNode root; XmlParser parser(text); if (!parser.parse(root, err)) return false;
+  const size_t slash = xmlPath.find_last_of("/\\");
+  const std::string folder = slash == std::string::npos ? std::string(".") : xmlPath.substr(0, slash);
+  sc = LoadedScene();
+  {                                                         // m_textures[0]: 1x1 white, NEAREST / CLAMP (integrator_pt_scene_tex.cpp:7-16)
+    LoadedTexture w; w.width = w.height = 1; w.format = 0; w.flags = 0; w.addressU = w.addressV = 2; w.filter = 0; w.bytes.assign(4, 0xFF);
+    sc.textures.push_back(w);
+  }
+  const XmlNode* settings = root.path("render_lib/render_settings");
+  const XmlNode* cam = root.path("cam_lib/camera");
+  const XmlNode* sceneNode = root.path("scenes/scene");
+  if (!settings || !cam || !sceneNode) { err = "xml: render_settings / camera / scene missing"; return false; }
+  auto toInt = [](const std::string& s) { return s.empty() ? 0 : std::atoi(s.c_str()); };
+  sc.width = width > 0 ? width : toInt(settings->childText("width"));
+  sc.height = height > 0 ? height : toInt(settings->childText("height"));
+  sc.traceDepth = toInt(settings->childText("trace_depth")) ? (uint32_t)toInt(settings->childText("trace_depth")) : 6u;          // LoadSceneSettings :926-940
+  sc.spp = toInt(settings->childText("maxRaysPerPixel")) ? (uint32_t)toInt(settings->childText("maxRaysPerPixel")) : 1u;
+  sc.fov = std::atof(cam->childText("fov").c_str());
+  sc.nearClip = std::atof(cam->childText("nearClipPlane").c_str()); sc.farClip = std::atof(cam->childText("farClipPlane").c_str());
+  { const auto p = parseFloats(cam->childText("position")), l = parseFloats(cam->childText("look_at")), u = parseFloats(cam->childText("up"));
+    if (p.size() < 3 || l.size() < 3 || u.size() < 3) { err = "xml: camera vectors"; return false; }
+    for (int k = 0; k < 3; k++) { sc.camPos[k] = p[k]; sc.camLookAt[k] = l[k]; sc.camUp[k] = u[k]; } }
+
+  // textures are loaded on first use by a material (integrator_pt_scene_tex.cpp:105-144)
+  std::map<int, const XmlNode*> texNodes; std::map<int, uint32_t> texCache;
+  if (const XmlNode* lib = root.child("textures_lib")) for (const XmlNode* t : lib->all("texture")) texNodes[std::atoi(t->get("id").c_str())] = t;
+  auto textureFromColorNode = [&](const XmlNode* node, uint32_t& outId) -> bool {
+    outId = 0;
+    const XmlNode* tn = node ? node->child("texture") : nullptr;
+    if (!tn) return true;
+    const int xid = std::atoi(tn->get("id").c_str());
+    auto it = texCache.find(xid); if (it != texCache.end()) { outId = it->second; return true; }
+    if (!texNodes.count(xid)) { err = "xml: texture id not in textures_lib"; return false; }
+    std::vector<uint8_t> img; const std::string p = folder + "/" + texNodes[xid]->get("loc");
+    if (!readFile(p, img) || img.size() < 8) { err = "cannot read " + p; return false; }
+    uint32_t w, h; std::memcpy(&w, img.data(), 4); std::memcpy(&h, img.data() + 4, 4);          // image4ub: {w, h} then RGBA8 (integrator_pt_scene_tex.cpp:53-93)
+    if (img.size() < 8 + (size_t)w * h * 4) { err = "image4ub truncated: " + p; return false; }
+    LoadedTexture t; t.width = w; t.height = h; t.format = 0; t.flags = 1; t.addressU = t.addressV = 0; t.filter = 1;
+    t.bytes.assign(img.begin() + 8, img.begin() + 8 + (size_t)w * h * 4);
+    sc.textures.push_back(std::move(t));
+    outId = texCache[xid] = (uint32_t)sc.textures.size() - 1;
+    return true;
+  };
+
+  // lights first: emissive materials copy intensity from them (integrator_pt_scene.cpp:973-996, 575-599)
+  std::map<int, const XmlNode*> lightNodes;
+  if (const XmlNode* lib = root.child("lights_lib")) for (const XmlNode* l : lib->all("light")) lightNodes[std::atoi(l->get("id").c_str())] = l;
+  std::vector<int> oldToNew;
+  for (const XmlNode* linst : sceneNode->all("instance_light")) {
+    const int lid = std::atoi(linst->get("light_id").c_str());
+    if (!lightNodes.count(lid)) { err = "xml: instance_light refers to an unknown light"; return false; }
+    const XmlNode* ln = lightNodes[lid];
+    const M4 m = m4FromText(linst->get("matrix"));
+    const std::string ltype = ln->get("type"), shape = ln->get("shape"), dist = ln->get("distribution");
+    const XmlNode* inten = ln->child("intensity");
+    if (!inten || !inten->child("color")) { err = "xml: light without intensity"; return false; }
+    const auto color = parseFloats(inten->child("color")->get("val"));
+    const double power = inten->child("multiplier") ? std::atof(inten->child("multiplier")->get("val").c_str()) : 1.0;
+    if (color.size() < 3) { err = "xml: light colour"; return false; }
+    if (ltype == "sky") { for (int k = 0; k < 3; k++) sc.envColor[k] = (float)color[k]; sc.envColor[3] = 0.0f; oldToNew.push_back(-1); continue; }   // plain-colour environment (:439-486)
+    LightSource lt = blankLight();
+    lightFrame(m, lt);
+    for (int k = 0; k < 3; k++) lt.intensity[k] = (float)color[k];
+    lt.mult = (float)power;
+    const XmlNode* size = ln->child("size");
+    if (ltype == "directional") lt.geomType = 4;
+    else if (shape == "rect" || shape == "disk") {
+      const double hw = size ? std::atof(size->get("half_width", "0").c_str()) : 0.0, hl = size ? std::atof(size->get("half_length", "0").c_str()) : 0.0;
+      M4 rot = m; rot.m[0][3] = rot.m[1][3] = rot.m[2][3] = 0.0; rot.m[3][3] = 1.0;
+      m4ToColMajor(rot, lt.matrix);
+      lt.size[0] = (float)hl; lt.size[1] = (float)hw;
+      const double sx = colLen(m, 0), sz = colLen(m, 2);
+      if (shape == "disk") { const double r = std::atof(size->get("radius").c_str()); lt.geomType = 2; lt.size[0] = (float)r; lt.pdfA = (float)(1.0 / (M_PI * r * r * sx * sz)); }
+      else { lt.geomType = 1; lt.pdfA = (float)(1.0 / (4.0 * hl * hw * sx * sz)); }
+    } else if (shape == "sphere") {
+      const double r = std::atof(size->get("radius").c_str()) * colLen(m, 0);
+      lt.norm[0] = 0.0f; lt.norm[1] = -1.0f; lt.norm[2] = 0.0f; lt.norm[3] = 0.0f;
+      lt.geomType = 3; lt.size[0] = lt.size[1] = (float)r; lt.pdfA = (float)(1.0 / (4.0 * M_PI * r * r));
+    } else {
+      lt.geomType = 5; lt.pdfA = 1.0f;
+      lt.distType = (dist == "omni" || dist == "uniform" || dist == "ies") ? 1u : (dist == "spot" ? 2u : 0u);
+    }
+    if (const XmlNode* ies = ln->child("ies")) {
+      LoadedTexture t; if (!iesSphericalTexture(folder + "/" + ies->get("loc"), t, err)) return false;
+      sc.textures.push_back(std::move(t)); lt.iesId = (uint32_t)sc.textures.size() - 1;
+      if (ies->has("matrix")) {                             // mrot * transpose(transpose(matrixFromNode) * instMatrix), translation dropped
+        const M4 mn = m4FromText(ies->get("matrix"));
+        M4 inst = m; inst.m[0][3] = inst.m[1][3] = inst.m[2][3] = 0.0; inst.m[3][3] = 1.0;
+        M4 ry = m4Identity(); const double a = M_PI / 2.0; ry.m[0][0] = std::cos(a); ry.m[0][2] = std::sin(a); ry.m[2][0] = -std::sin(a); ry.m[2][2] = std::cos(a);
+        M4 im = m4Mul(ry, m4Transpose(m4Mul(m4Transpose(mn), inst)));
+        im.m[0][3] = im.m[1][3] = im.m[2][3] = 0.0; im.m[3][3] = 1.0;
+        m4ToColMajor(im, lt.iesMatrix);
+      }
+    }
+    oldToNew.push_back((int)sc.lights.size());
+    sc.lights.push_back(lt);
+  }
+
+  // materials: the legacy hydra_material subset the shipped scenes use (ConvertOldHydraMaterial: diffuse-only and emission branches)
+  if (const XmlNode* lib = root.child("materials_lib")) for (const XmlNode* mn : lib->all("material")) {
+    const XmlNode* emis = mn->child("emission"); const XmlNode* diff = mn->child("diffuse");
+    Material mat = blankMaterial();
+    if (mn->has("light_id") || emis) {
+      const XmlNode* cn = emis ? emis->child("color") : nullptr;
+      if (!cn) { err = "xml: emissive material without colour"; return false; }
+      const auto c = parseFloats(cn->get("val")); if (c.size() < 3) { err = "xml: emission colour"; return false; }
+      mat.mtype = 0xEFFFFFFFu;
+      for (int k = 0; k < 3; k++) mat.colors[0][k] = (float)c[k];
+      mat.data[0] = 1.0f;
+      const int lid = mn->has("light_id") ? std::atoi(mn->get("light_id").c_str()) : -1;
+      mat.lightId = (uint32_t)lid;
+      if (!textureFromColorNode(cn, mat.texid[0])) return false;
+      if (lid >= 0 && lid < (int)sc.lights.size()) {
+        for (int k = 0; k < 4; k++) mat.colors[0][k] = sc.lights[(size_t)lid].intensity[k];
+        mat.data[0] = sc.lights[(size_t)lid].mult;
+        sc.lights[(size_t)lid].matId = (uint32_t)sc.materials.size();
+      }
+    } else {
+      const XmlNode* cn = diff ? diff->child("color") : nullptr;
+      if (!cn) { err = "xml: material type outside the fixture subset (no <diffuse><color>)"; return false; }
+      const auto c = parseFloats(cn->get("val")); if (c.size() < 3) { err = "xml: diffuse colour"; return false; }
+      mat.mtype = 1; mat.cflags = 1;                        // MAT_TYPE_GLTF, GLTF_COMPONENT_LAMBERT (integrator_pt_scene_mat.cpp:410-419, 446-447)
+      for (int k = 0; k < 3; k++) mat.colors[0][k] = (float)c[k];
+      mat.data[4] = 1.0f; mat.data[5] = 0.0f;
+      if (!textureFromColorNode(cn, mat.texid[0])) return false;
+      if (const XmlNode* r = diff->child("roughness")) { mat.data[6] = (float)std::atof(r->get("val").c_str()); mat.cflags |= 16u; }   // Oren-Nayar
+    }
+    sc.materials.push_back(mat);
+  }
+
+  // geometry: cmesh4::LoadMeshFromVSGF; m_vData8f packs {normal.xyz, u | tangent.xyz, v} (integrator_pt_scene.cpp:727-837)
+  if (const XmlNode* lib = root.child("geometry_lib")) for (const XmlNode* mesh : lib->all("mesh")) {
+    std::vector<uint8_t> f; const std::string p = folder + "/" + mesh->get("loc");
+    if (!readFile(p, f) || f.size() < 24) { err = "cannot read " + p; return false; }
+    uint32_t nv, ni, nm, flags; std::memcpy(&nv, f.data() + 8, 4); std::memcpy(&ni, f.data() + 12, 4); std::memcpy(&nm, f.data() + 16, 4); std::memcpy(&flags, f.data() + 20, 4);
+    size_t off = 24;
+    const size_t need = 24 + (size_t)nv * 16 * (1 + ((flags & 8u) ? 0 : 1) + ((flags & 1u) ? 1 : 0)) + (size_t)nv * 8 + (size_t)ni * 4 + (size_t)(ni / 3) * 4;
+    if (f.size() < need) { err = "vsgf truncated: " + p; return false; }
+    const float* pos = (const float*)(f.data() + off); off += (size_t)nv * 16;
+    const float* norm = nullptr; if (!(flags & 8u)) { norm = (const float*)(f.data() + off); off += (size_t)nv * 16; }
+    const float* tang = nullptr; if (flags & 1u) { tang = (const float*)(f.data() + off); off += (size_t)nv * 16; }
+    const float* uv = (const float*)(f.data() + off); off += (size_t)nv * 8;
+    const uint32_t* idx = (const uint32_t*)(f.data() + off); off += (size_t)ni * 4;
+    const uint32_t* mats = (const uint32_t*)(f.data() + off);
+    const uint32_t nt = ni / 3;
+    sc.matVertOffset.push_back((uint32_t)sc.matIdByPrimId.size()); sc.matVertOffset.push_back((uint32_t)(sc.vPos4f.size() / 4));
+    sc.geomTriCount.push_back(nt); sc.geomVertCount.push_back(nv);
+    sc.vPos4f.insert(sc.vPos4f.end(), pos, pos + (size_t)nv * 4);
+    for (uint32_t v = 0; v < nv; v++) {
+      float d[8] = { 0, 0, 0, uv[2 * v], 0, 0, 0, uv[2 * v + 1] };
+      if (norm) { d[0] = norm[4 * v]; d[1] = norm[4 * v + 1]; d[2] = norm[4 * v + 2]; }
+      if (tang) { d[4] = tang[4 * v]; d[5] = tang[4 * v + 1]; d[6] = tang[4 * v + 2]; }
+      sc.vData8f.insert(sc.vData8f.end(), d, d + 8);
+    }
+    sc.triIndices.insert(sc.triIndices.end(), idx, idx + (size_t)nt * 3);
+    sc.matIdByPrimId.insert(sc.matIdByPrimId.end(), mats, mats + nt);
+  }
+
+  // instances: matrix, m_normMatrices = transpose(inverse4x4(M)) (integrator_pt_scene.cpp:852-885), remap list and light ids
+  for (const XmlNode* inst : sceneNode->all("instance")) {
+    const M4 m = m4FromText(inst->get("matrix"));
+    float cm[16]; m4ToColMajor(m, cm); sc.instMatrices.insert(sc.instMatrices.end(), cm, cm + 16);
+    m4ToColMajor(m4Transpose(m4Inverse(m)), cm); sc.normMatrices.insert(sc.normMatrices.end(), cm, cm + 16);
+    sc.instGeomId.push_back((uint32_t)std::atoi(inst->get("mesh_id").c_str()));
+    int lightId = -1;
+    if (inst->has("linst_id")) { const int li = std::atoi(inst->get("linst_id").c_str()); if (li >= 0 && li < (int)oldToNew.size()) lightId = oldToNew[(size_t)li]; }
+    sc.remapInst.push_back(inst->has("rmap_id") ? std::atoi(inst->get("rmap_id").c_str()) : -1);
+    sc.remapInst.push_back(lightId);
+  }
+  return true;
+}
+
+} // namespace hydra_hip

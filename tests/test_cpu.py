@@ -316,3 +316,73 @@ def test_texture_regulariser_gradient_against_finite_differences():
     g = np.zeros_like(flat)
     orc.image2d4f_regularizer(flat, g)
     assert orc.reg_loss_image2d4f(flat) == 0.0 and not g.any()
+
+
+def _read_blobs(path):
+    raw = open(path, "rb").read()
+    out, i = [], 0
+    while i < len(raw):
+        j = raw.index(b"\0", i)
+        name = raw[i:j].decode()
+        n = int.from_bytes(raw[j + 1:j + 9], "little")
+        out.append((name, raw[j + 9:j + 9 + n]))
+        i = j + 9 + n
+    return out
+
+
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228"])
+def test_cpp_scene_loader_produces_the_same_tables(scene_name, tmp_path):
+    """hydracore3_amd/csrc/scene_loader.h (Hydra XML + VSGF + image4ub + IES in C++) == the Python fixture loader:
+    every table byte for byte, matrices and light frames to float rounding (both invert in double)."""
+    import ctypes as C
+    import subprocess
+    import __graft_entry__ as g
+    from hydracore3_amd import scene as S
+    g.build()
+    tool = os.path.join(ROOT, "hydracore3_amd", "hydra_hip_render")
+    out = str(tmp_path / "tables.bin")
+    r = subprocess.run([tool, scene_path(scene_name), "96", "64", "1", out, "--tables"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    blobs = _read_blobs(out)
+    named = {k: v for k, v in blobs if not k.startswith("tex")}
+    sc = S.load_hydra_xml(scene_path(scene_name), 96, 64)
+    d = sc.desc()
+
+    def arr(ptr, dtype, count):
+        return np.frombuffer((C.c_char * (np.dtype(dtype).itemsize * count)).from_address(ptr), dtype=dtype, count=count).copy() if count else np.zeros(0, dtype)
+
+    exact = {"vPos4f": sc.vpos, "vData8f": sc.vdata, "triIndices": sc.tri_indices, "matIdByPrimId": sc.mat_id_by_prim,
+             "matVertOffset": np.asarray(sc.mat_vert_offset, np.uint32), "geomTriCount": np.asarray(sc.geom_tri_count, np.uint32),
+             "geomVertCount": np.asarray(sc.geom_vert_count, np.uint32), "instGeomId": np.asarray(sc.inst_geom, np.uint32),
+             "remapInst": np.asarray(sc.remap_inst, np.int32), "allRemapLists": sc.all_remap_lists}
+    for k, ref in exact.items():
+        assert named[k] == np.ascontiguousarray(ref).tobytes(), k
+    ni = d.numInsts
+    for k, ptr in (("instMatrices", d.instMatrices), ("normMatrices", d.normMatrices)):
+        got, ref = np.frombuffer(named[k], np.float32), arr(ptr, np.float32, 16 * ni)
+        assert np.allclose(got, ref, rtol=1e-6, atol=1e-7), k
+    mats = np.frombuffer(named["materials"], S.MATERIAL_DTYPE)
+    assert mats.tobytes() == np.array(sc.materials, dtype=S.MATERIAL_DTYPE).tobytes()
+    lights = np.frombuffer(named["lights"], S.LIGHT_DTYPE)
+    ref_l = np.array(sc.lights, dtype=S.LIGHT_DTYPE)
+    assert lights.shape == ref_l.shape
+    for f in S.LIGHT_DTYPE.names:
+        if S.LIGHT_DTYPE[f].base.kind == "f":
+            assert np.allclose(lights[f], ref_l[f], rtol=1e-6, atol=1e-7), f
+        else:
+            assert np.array_equal(lights[f], ref_l[f]), f
+    p_ref = bytes(sc.params())
+    p_got = named["params"]
+    pr, pg = np.frombuffer(p_ref[:128], np.float32), np.frombuffer(p_got[:128], np.float32)       # projInv, worldViewInv
+    assert np.allclose(pg, pr, rtol=1e-5, atol=1e-6)
+    assert p_got[128:176] == p_ref[128:176]                                                          # window, depth, integrator, tile ...
+    assert np.allclose(np.frombuffer(p_got[176:], np.float32), np.frombuffer(p_ref[176:], np.float32), rtol=1e-6)
+    # textures, in the order the reference's lazy loading creates them
+    tex = [(np.frombuffer(h, np.uint32), b) for (kh, h), (kb, b) in zip(blobs, blobs[1:]) if kh == "texHeader" and kb == "texBytes"]
+    assert len(tex) == len(sc.textures)
+    for (h, b), t in zip(tex, sc.textures):
+        assert tuple(int(v) for v in h) == (t.width, t.height, t.fmt, 1 if t.srgb else 0, t.addr_u, t.addr_v, t.filter)
+        if t.fmt == S.TEX_RGBA8:
+            assert b == t.data.tobytes()
+        else:
+            assert np.allclose(np.frombuffer(b, np.float32), t.data.reshape(-1), rtol=1e-6, atol=1e-7)

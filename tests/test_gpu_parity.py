@@ -334,3 +334,22 @@ def test_path_trace_from_input_rays_block_matches_oracle(cornell):
         if channels == 4:
             assert np.all(og[:, 3] == 0.5)                              # alpha untouched
         assert np.array_equal(gpu.random_gens(), cpu.random_gens())
+
+
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228"])
+def test_cpp_scene_ingestion_renders_like_the_python_path(scene_name, tmp_path):
+    """hydra_hip_render: scene_loader.h (C++) -> C ABI -> frame, no Python in the loop; the frame equals the one rendered from the
+    Python loader's tables (same tables up to float rounding of inverted matrices: the image bar applies)."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    from hydracore3_amd.api import HipIntegrator
+    tool = os.path.join(ROOT, "hydracore3_amd", "hydra_hip_render")
+    out = str(tmp_path / "frame.bin")
+    r = subprocess.run([tool, scene_path(scene_name), "96", "64", "6", out], capture_output=True, text=True)
+    print(r.stdout.strip())
+    assert r.returncode == 0, r.stdout + r.stderr
+    frame = np.fromfile(out, np.float32).reshape(64, 96, 4)
+    ref = HipIntegrator(load_hydra_xml(scene_path(scene_name), 96, 64)).render(6)
+    assert per_pixel_l2(frame, ref, 6) < 1e-3
+    assert float(frame[..., :3].mean()) > 0.0

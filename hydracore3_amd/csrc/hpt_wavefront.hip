@@ -223,6 +223,9 @@ __global__ void __launch_bounds__(256) wfLossReduceKernel(const float* lossSlot,
 __global__ void wfLossFinishKernel(const double* acc, float* loss) { *loss += (float)*acc; }
 
 // ---- persistent traversal with ray replacement -------------------------------------------------------------------------------
+#ifndef HPT_WF_XCD_RANGES
+#define HPT_WF_XCD_RANGES 1
+#endif
 #ifndef HPT_WF_SPECULATE
 #define HPT_WF_SPECULATE 0   // measured: bit-exact but slower (1M triangles: 197 vs 209 Mpaths/s; node-loop utilisation only 0.49 -> 0.52)
 #endif
@@ -259,7 +262,13 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
   bool has = false, isAny = false, found = false, resumed = false;
   uint dryTrips = 0;
   uint pend = 0u;                                                            // flat layout: a leaf this lane reached and postponed (0 = none)
+  // XCD-aware start range: blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own L2. The waves of
+  // one XCD start in ITS eight neighbouring ranges - contiguous, pixel-coherent stretches of the queue - and only steal elsewhere later.
+#if HPT_WF_XCD_RANGES
+  uint range = (blockIdx.x % 8u) * (WF_RANGES / 8u) + ((blockIdx.x / 8u) * 4u + (threadIdx.x >> 6)) % (WF_RANGES / 8u), tried = 0, stashCount = 0;   // wave-uniform
+#else
   uint range = (glane >> 6) % WF_RANGES, tried = 0, stashCount = 0;          // wave-uniform
+#endif
   uint slot = 0, cur = REF_NONE, curInst = 0xFFFFFFFFu;
   int  sp = 0;
   V3 wo = v3(0, 0, 0), wd = v3(0, 0, 1), o = wo, d = wd, id = v3(0, 0, 0);

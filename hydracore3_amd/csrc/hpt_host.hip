@@ -378,7 +378,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
     geomRoot[gi] = patchRef(g.bvh.rootRef, nodeBase, triBase);
   }
   if (tris.size() >= (size_t(1) << 28) || nodes.size() >= (size_t(1) << 31)) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: scene too large for 28-bit triangle references");
-  std::vector<BvhInst> dinst(ni);
+  std::vector<BvhInst> dinst(std::max<size_t>(ni, 1));    // (never empty: an empty scene still hands valid pointers to the kernels)
   for (size_t i = 0; i < ni; i++) {
     inverse_rows(c->insts[i].m, dinst[i].row0, dinst[i].row1, dinst[i].row2);
     dinst[i].root = geomRoot[c->insts[i].geomId]; dinst[i].geomId = c->insts[i].geomId; dinst[i].pad0 = dinst[i].pad1 = 0;
@@ -387,7 +387,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   if (tris.empty()) tris.push_back(BvhTri());
   HIPCHK(c, c->dNodes.upload(nodes.data(), nodes.size()));
   HIPCHK(c, c->dTris.upload(tris.data(), tris.size()));
-  HIPCHK(c, c->dInsts.upload(dinst.data(), std::max<size_t>(dinst.size(), 1)));
+  HIPCHK(c, c->dInsts.upload(dinst.data(), dinst.size()));
   c->S.nodes = c->dNodes.p; c->S.tris = c->dTris.p; c->S.insts = c->dInsts.p;
   c->S.rootRef = rootRef; c->S.numInsts = (uint)ni; c->S.flatMode = 0;
   c->stackNeeded = tlas.depth + 1u + maxBlasDepth + 1u;

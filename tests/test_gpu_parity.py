@@ -353,3 +353,47 @@ def test_cpp_scene_ingestion_renders_like_the_python_path(scene_name, tmp_path):
     ref = HipIntegrator(load_hydra_xml(scene_path(scene_name), 96, 64)).render(6)
     assert per_pixel_l2(frame, ref, 6) < 1e-3
     assert float(frame[..., :3].mean()) > 0.0
+
+
+@pytest.mark.parametrize("size", [(68, 36), (70, 38), (33, 17)])
+def test_ragged_frame_sizes_follow_the_tile_fallback(size):
+    """SetViewport falls back to tile size 4 / 2 / 1 when the frame is not a multiple of 8 (integrator_pt.h:379-389): packed pixel
+    order, RNG seeding and the image still match the oracle; both schedules agree bit for bit."""
+    from hydracore3_amd.api import HipIntegrator
+    from oracle.orc import OracleIntegrator
+    w, h = size
+    sc = load_hydra_xml(scene_path("test_035"), w, h)
+    assert sc.tile_size() == {(68, 36): 4, (70, 38): 2, (33, 17): 1}[size]
+    gpu, cpu = HipIntegrator(sc), OracleIntegrator(sc)
+    assert np.array_equal(gpu.packed_xy(), cpu.packed_xy())
+    a, b = gpu.render(4), cpu.render(4)
+    assert per_pixel_l2(a, b, 4) < 1e-3
+    assert np.array_equal(gpu.random_gens(), cpu.random_gens())
+    wf = HipIntegrator(sc); wf.set_schedule(2)
+    assert np.array_equal(wf.render(4), a)
+
+
+def test_empty_scene_and_degenerate_calls():
+    """No geometry at all: every ray leaves the scene and picks up the environment colour (kernel_HitEnvironment) under both schedules
+    and for ray queries; zero-sized calls are no-ops; calls in the wrong order fail with an error code instead of rendering."""
+    from hydracore3_amd.api import HipIntegrator, HydraHipError
+    from hydracore3_amd import scene as S
+    sc = S.SceneData()
+    sc.width, sc.height = 32, 24
+    sc.env_color = (0.25, 0.5, 0.75, 0.0)
+    sc.materials.append(S.material_lambert((0.5, 0.5, 0.5)))
+    for sched in (1, 2):
+        gpu = HipIntegrator(sc); gpu.set_schedule(sched)
+        img = gpu.render(3)
+        assert np.allclose(img[..., :3], np.array([0.75, 1.5, 2.25], np.float32)), sched
+        pos, dr = random_rays(100, 3)
+        assert np.all(gpu.RayQuery_NearestHit(pos, dr)["geomId"] == 0xFFFFFFFF) and not gpu.RayQuery_AnyHit(pos, dr).any()
+        before = img.copy()
+        gpu.PathTraceBlock(0, 4, img, 5)                 # zero threads
+        gpu.PathTraceBlock(gpu.N, 4, img, 0)             # zero passes
+        assert np.array_equal(img, before)
+        with pytest.raises(HydraHipError):
+            gpu.PathTraceBlock(gpu.N + 1, 4, img, 1)     # tid range beyond the viewport
+    fresh = HipIntegrator()
+    with pytest.raises(HydraHipError):
+        fresh.PathTraceBlock(16, 4, np.zeros((4, 4, 4), np.float32), 1)      # before LoadScene / CommitDeviceData

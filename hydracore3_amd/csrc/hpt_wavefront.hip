@@ -230,7 +230,7 @@ __global__ void wfLossFinishKernel(const double* acc, float* loss) { *loss += (f
 #define HPT_WF_SPECULATE 0   // measured: bit-exact but slower (1M triangles: 197 vs 209 Mpaths/s; node-loop utilisation only 0.49 -> 0.52)
 #endif
 #ifndef HPT_WF_WAVES
-#define HPT_WF_WAVES 6   // 16 KB traversal stacks + 8 KB ray stashes per block: six blocks fill the CU's 160 KB of LDS; 80 VGPRs, no spills
+#define HPT_WF_WAVES 5   // measured on the 1M-triangle scene: 4 -> 213, 5 -> 224, 6 -> 217 Mpaths/s (96 VGPRs: no spills; 24 KB of LDS per block)
 #endif
 template <bool DEEP, bool FLAT, bool STATS>
 __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScene S, const WfPool P, uint iter, uint refillBelow, uint grace,

@@ -279,20 +279,73 @@ if rank == 0:
     full = OracleIntegrator(sc, threads=1).render(3)
     assert np.array_equal(t.numpy(), full), "sharded frame differs from the single-rank frame"
     print("SHARD_OK")
+
+# bench.py --scaling strong: every world-th 1024-tid chunk (here 64-tid chunks so that a 32 x 32 frame has several per rank)
+o2 = OracleIntegrator(sc, threads=1)
+img2 = np.zeros((32, 32, 4), np.float32)
+for tid0 in range(rank * 64, o2.N, world * 64):
+    o2.path_trace_block(img2, 3, tid_begin=tid0, tid_count=min(64, o2.N - tid0))
+t2 = torch.from_numpy(img2)
+dist.reduce(t2, dst=0, op=dist.ReduceOp.SUM)
+if rank == 0:
+    assert np.array_equal(t2.numpy(), full), "interleaved shards differ from the single-rank frame"
+    print("INTERLEAVE_OK")
+
+# bench.py --scaling weak: sample sharding - rank r seeds its generators as threads r*N.. of one big InitRandomGens call, renders the
+# whole frame, the reduce adds the frames; equals the two renders done one after the other on one rank, and the sub-streams differ
+from oracle.orc import rng_kat
+o3 = OracleIntegrator(sc, threads=1)
+seeds = np.array([rng_kat(rank * o3.N + i, 0)[0][:2] for i in range(o3.N)], np.uint32)
+o3.set_random_gens(seeds.reshape(-1))
+img3 = o3.render(2)
+t3 = torch.from_numpy(img3.copy())
+dist.reduce(t3, dst=0, op=dist.ReduceOp.SUM)
+if rank == 0:
+    o4 = OracleIntegrator(sc, threads=1)
+    seeds1 = np.array([rng_kat(o4.N + i, 0)[0][:2] for i in range(o4.N)], np.uint32)
+    o4.set_random_gens(seeds1.reshape(-1))
+    other = o4.render(2)
+    assert np.allclose(t3.numpy(), img3 + other, rtol=1e-6, atol=1e-6) and not np.array_equal(img3, other)
+    print("SAMPLE_SHARD_OK")
+
+# DR: all_reduce(SUM) of a_dataGrad and the loss over pixel shards == the single-rank gradient (float sums differ in order only)
+from hydracore3_amd import scene as S
+def dr_setup():
+    scd = synth.plane_under_rect_light(16, 16)
+    tid_ = scd.add_texture(S.Texture(np.full((4, 4, 4), 0.5, np.float32), S.TEX_RGBA32F, False))
+    scd.materials[0]["texid"][0] = tid_
+    od = OracleIntegrator(scd, threads=1)
+    od.put_diff_tex2d(tid_, 4, 4, 4)
+    return od
+rs = np.random.default_rng(1)
+data = rs.uniform(0.2, 0.9, 64).astype(np.float32)
+ref = rs.uniform(0.0, 0.5, (16, 16, 4)).astype(np.float32)
+od = dr_setup()
+b, c = tid_window(rank, world, od.N)
+loss_r, grad_r = od.path_trace_dr(np.zeros((16, 16, 4), np.float32), 3, ref, data, tid_begin=b, tid_count=c)
+tg, tl = torch.from_numpy(grad_r.copy()), torch.tensor([loss_r], dtype=torch.float64)
+dist.all_reduce(tg, op=dist.ReduceOp.SUM); dist.all_reduce(tl, op=dist.ReduceOp.SUM)
+loss_f, grad_f = dr_setup().path_trace_dr(np.zeros((16, 16, 4), np.float32), 3, ref, data)
+assert np.count_nonzero(grad_f) > 10
+assert np.allclose(tg.numpy(), grad_f, rtol=1e-5, atol=1e-7) and abs(float(tl.item()) - loss_f) <= 1e-5 * abs(loss_f)
+if rank == 0:
+    print("DR_ALLREDUCE_OK")
 dist.barrier()
 dist.destroy_process_group()
 """
 
 
 def test_two_rank_sharding_reassembles_the_frame(tmp_path):
-    """N > 1 path of bench.py on CPU: two gloo ranks render disjoint tid windows (oracle as the stand-in renderer), the
-    reduce(SUM) of their zero-initialised framebuffers is bit-identical to the single-rank frame."""
+    """N > 1 paths of bench.py on CPU, two gloo ranks, the oracle as the stand-in renderer: (1) disjoint tid windows and (2) interleaved
+    chunks reassemble the single-rank frame bit for bit through reduce(SUM); (3) sample sharding with offset generator seeds adds two
+    decorrelated renders; (4) pixel-sharded PathTraceDR + all_reduce(SUM) of a_dataGrad and the loss equals the single-rank result."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29533", str(script), ROOT], capture_output=True, text=True, env=env, timeout=300)
-    assert r.returncode == 0 and "SHARD_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    for tag in ("SHARD_OK", "INTERLEAVE_OK", "SAMPLE_SHARD_OK", "DR_ALLREDUCE_OK"):
+        assert r.returncode == 0 and tag in r.stdout, tag + "\n" + r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_texture_regulariser_gradient_against_finite_differences():

@@ -253,3 +253,76 @@ def dr_scene(xml_path, width=512, height=512, tex_size=256, target=False) -> S.S
     sc.materials[0]["texid"][0] = tid
     sc.materials[0]["colors"][0] = (1.0, 1.0, 1.0, 0.0)      # albedo comes from the texture
     return sc, tid
+
+
+def random_scene(seed: int, width=48, height=32) -> S.SceneData:
+    """Seeded random small scene for fuzz parity: a floor + back wall, 3..7 transformed spheres with materials drawn from every
+    constructor of the hot path with parameters that include the corners (metalness 0 / 1, glossiness 0 / 1, coat 0 / 1, smooth and
+    rough conductors, Oren-Nayar), an optional textured material, 1..3 lights of random types, random environment, random depth."""
+    r = np.random.RandomState(seed)
+    sc = S.SceneData()
+    sc.width, sc.height = width, height
+    sc.cam_pos = (float(r.uniform(-1, 1)), float(r.uniform(1.5, 3.0)), float(r.uniform(6.0, 8.0)))
+    sc.cam_look_at, sc.cam_up = (0.0, 1.0, 0.0), (0.0, 1.0, 0.0)
+    sc.fov, sc.trace_depth = float(r.uniform(35, 60)), int(r.choice([1, 3, 5, 6, 6]))
+    sc.env_color = (*[float(v) for v in r.uniform(0.0, 0.2, 3)], 0.0) if r.uniform() < 0.5 else (0.0, 0.0, 0.0, 0.0)
+    img = r.randint(0, 2 ** 32, (4, 4), dtype=np.uint64).astype(np.uint32) | np.uint32(0xFF000000)
+    tex = sc.add_texture(S.Texture(img, S.TEX_RGBA8, bool(r.randint(2)), int(r.choice([S.ADDR_WRAP, S.ADDR_CLAMP])), S.ADDR_WRAP,
+                                   int(r.choice([S.FILTER_NEAREST, S.FILTER_LINEAR]))))
+    corner = lambda: float(r.choice([0.0, 1.0, r.uniform(0, 1)]))
+    col = lambda: tuple(float(v) for v in r.uniform(0.1, 0.95, 3))
+
+    def rand_material():
+        k = r.randint(6)
+        if k == 0:
+            return S.material_lambert(col(), tex if r.uniform() < 0.3 else 0)
+        if k == 1:
+            return S.material_gltf((*col(), 1.0), corner(), corner(), corner(), float(r.choice([1.1, 1.33, 1.5, 2.0])), tex if r.uniform() < 0.3 else 0)
+        if k == 2:
+            return S.material_diffuse(col(), float(r.choice([0.0, r.uniform(0.1, 1.0)])), tex if r.uniform() < 0.3 else 0)
+        if k == 3:
+            a = float(r.choice([0.0, r.uniform(0.05, 0.5)]))
+            return S.material_conductor(float(r.uniform(0.1, 2.0)), float(r.uniform(1.0, 4.0)), a, float(r.choice([a, r.uniform(0.05, 0.5)])), (*col(), 1.0))
+        if k == 4:
+            return S.material_dielectric(float(r.uniform(1.2, 2.0)), 1.0)
+        return S.material_gltf((*col(), 1.0), 0.0, corner(), 1.0, 1.5)
+    M = sc.materials
+    M.append(S.material_lambert((0.6, 0.6, 0.6), tex))
+    M.append(S.material_diffuse((0.5, 0.5, 0.55), 0.3))
+    nobj = int(r.randint(3, 8))
+    for _ in range(nobj):
+        M.append(rand_material())
+    parts = [(*_quad((-8, 0, 6), (16, 0, 0), (0, 0, -14), 2, 2, 3.0), 0), (*_quad((-8, 0, -6), (16, 0, 0), (0, 6, 0)), 1)]
+    sc.add_instance(sc.add_mesh(*_merge(parts)), np.eye(4))
+    sp = _sphere_mesh(int(r.randint(1, 3)))
+    ntri = sp[4].size // 3
+    for i in range(nobj):
+        gid = sc.add_mesh(sp[0], sp[1], sp[2], sp[3], sp[4], np.full(ntri, 2 + i, np.uint32))
+        m = S.translate(float(r.uniform(-3.5, 3.5)), float(r.uniform(0.4, 1.6)), float(r.uniform(-3.0, 2.5))) @ S.rotate_y(float(r.uniform(0, 360))) @ \
+            S.rotate_x(float(r.uniform(0, 90))) @ S.scale(*[float(v) for v in r.uniform(0.3, 0.8, 3)])
+        sc.add_instance(gid, m)
+    L = sc.lights
+    for _ in range(int(r.randint(1, 4))):
+        k = r.randint(6)
+        pos = S.translate(float(r.uniform(-3, 3)), float(r.uniform(2.5, 4.5)), float(r.uniform(-2, 3)))
+        c, mult = col(), float(r.uniform(5, 25))
+        if k == 0:
+            lm = pos @ S.rotate_x(float(r.uniform(-20, 20)))
+            L.append(S.light_rect(lm, float(r.uniform(0.3, 0.9)), float(r.uniform(0.3, 0.9)), c, mult))
+            if r.uniform() < 0.6:                                   # visible emitter mesh bound to the light
+                e = len(M); M.append(S.material_emissive(c, mult, len(L) - 1)); L[-1]["matId"] = e
+                hl, hw = float(L[-1]["size"][0]), float(L[-1]["size"][1])
+                lp, ln, lt, luv, lidx = _quad((-hw, 0, -hl), (2 * hw, 0, 0), (0, 0, 2 * hl))
+                sc.add_instance(sc.add_mesh(lp, ln, lt, luv, lidx, [e]), lm, -1, len(L) - 1)
+        elif k == 1:
+            L.append(S.light_sphere(pos, float(r.uniform(0.15, 0.5)), c, mult))
+        elif k == 2:
+            a1 = float(r.uniform(10, 25)); a2 = a1 + float(r.uniform(5, 20))
+            L.append(S.light_point(pos @ S.rotate_x(float(r.uniform(-30, 30))), c, mult * 2, "spot", float(np.cos(np.radians(a1))), float(np.cos(np.radians(a2)))))
+        elif k == 3:
+            L.append(S.light_directional(S.rotate_x(float(r.uniform(-40, 40))) @ S.rotate_y(float(r.uniform(0, 360))), c, float(r.uniform(0.3, 1.5))))
+        elif k == 4:
+            L.append(S.light_rect(pos, 0.0, 0.0, c, mult, disk_radius=float(r.uniform(0.3, 0.8))))
+        else:
+            L.append(S.light_point(pos, c, mult, "omni"))
+    return sc

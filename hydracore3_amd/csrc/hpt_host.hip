@@ -13,14 +13,14 @@
 #include "hpt_wavefront.hip"
 #include "bvh_build.h"
 
-static const uint MAX_STACK = 64;
+static const uint MAX_STACK = 64;                           // traversal stack entries per lane: LDS_STACK in LDS + the rest in an HBM overflow buffer
 // Static scenes with at most this many INSTANCED triangles get the single-level world-space BVH (48 B + ~32 B of nodes per triangle:
 // 32 M triangles = 2.6 GB of the 288 GB); beyond it (heavy instancing) the two-level TLAS/BLAS layout is kept.
-static const size_t FLAT_TRI_BUDGET = size_t(32) << 20;     // traversal stack entries per lane: LDS_STACK in LDS + the rest in an HBM overflow buffer
+static const size_t FLAT_TRI_BUDGET = size_t(32) << 20;
 
 using namespace hpt;
 
-// Scenes with at least this many instanced triangles count as "heavy": wavefront schedule, voted exit of the node loop.
+// Scenes with at least this many instanced triangles count as "heavy": wavefront schedule, single-level BVH, voted exit of the node loop.
 static const size_t HEAVY_SCENE_TRIS = size_t(1) << 13;    // measured (profiles/crossover.sh): wavefront wins from 16 K triangles up, loses 2x on the 36-triangle Cornell box
 
 namespace {
@@ -37,9 +37,13 @@ struct Geom
 struct Inst { uint geomId; float m[16]; };
 
 template <class T>
-struct DevBuf
+struct DevBuf                      // owning device array; freed on scope exit (locals on error paths) or by hpt_destroy (context members)
 {
   T* p = nullptr; size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
   void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
   hipError_t alloc(size_t count) { if (count <= n && p) return hipSuccess; release(); n = count; return count ? hipMalloc((void**)&p, count * sizeof(T)) : hipSuccess; }
   hipError_t upload(const T* src, size_t count)

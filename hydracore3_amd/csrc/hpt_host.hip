@@ -686,7 +686,7 @@ static const size_t WF_AUTO_TRIS = HEAVY_SCENE_TRIS;
 static const uint   WF_POOL_MAX = 1u << 22;        // pool slots (pixels in flight) per batch: 4M x 148 B = 620 MB
 static const uint   WF_CHECK = 8;                  // progress word copied back every WF_CHECK shade passes
 static const uint   WF_RING = 8;                   // ... and at most WF_RING such checkpoints in flight
-static const uint   WF_GROUPS_AUTO = 2;            // concurrent pixel groups (streams) per call
+static const uint   WF_GROUPS_AUTO = 1;            // pixel groups (streams) per call; measured 1M triangles: 1 -> 224, 2 -> 223, 3 -> 204 Mpaths/s
 
 static bool useWavefront(hpt_ctx* c, bool naive, bool dr, bool stats)
 {

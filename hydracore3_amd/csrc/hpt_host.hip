@@ -619,7 +619,7 @@ static int gridBlocks(hpt_ctx* c, bool dr)
   return c->numCUs * bpc;
 }
 
-static bool useWavefront(hpt_ctx* c, bool naive, bool dr, bool stats);
+static bool useWavefront(hpt_ctx* c, bool naive, bool dr, bool stats, uint tidCount);
 static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr);
 
 // DEEP: the scene's BVH can need more than LDS_STACK stack entries, so pushes / pops check for the HBM overflow part
@@ -649,7 +649,9 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   if (c->dGens.n < (inRays ? (size_t)job.tidEnd : (size_t)c->packedCount)) return c->fail(HPT_ERR_STATE, "PathTraceBlock: m_randomGens smaller than the thread range (InitRandomGens)");
   if (job.channels < 1 || job.channels > 4) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceBlock: channels must be 1..4 (spectral layers are out of scope)");
   if (dr && (c->S.traceDepth == 0 || c->S.traceDepth > 16)) return c->fail(HPT_ERR_ARG, "PathTraceDR: trace depth must be 1..16");
-  const int blocks = gridBlocks(c, dr);
+  // never more lanes than pixels: with fewer, the hardware's round-robin block placement spreads them evenly over the CUs, whereas a
+  // full grid would let whichever waves ask first take all the work (a small multi-GPU share of a frame)
+  const int blocks = (int)std::min<size_t>((size_t)gridBlocks(c, dr), ((size_t)job.tidCount + 255) / 256);
   HIPCHK(c, c->dQueue.alloc(1));
   HIPCHK(c, hipMemsetAsync(c->dQueue.p, 0, 4, st));
   job.queue = c->dQueue.p;
@@ -657,7 +659,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   job.counters = nullptr;
   const bool stats = c->instrument && !dr;
   c->lastSchedule = 1;
-  if (!inRays && useWavefront(c, naive, dr, stats && c->schedule != 2)) { c->lastSchedule = 2; return launch_wavefront(c, job, st, dr); }
+  if (!inRays && useWavefront(c, naive, dr, stats && c->schedule != 2, job.tidCount)) { c->lastSchedule = 2; return launch_wavefront(c, job, st, dr); }
   if (stats) { HIPCHK(c, c->dCounters.alloc(1)); HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(Counters), st)); job.counters = c->dCounters.p; }
   if (dr) {
     job.recordLanes = (uint)blocks * 256u;
@@ -683,17 +685,20 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
 // Scenes at or above this many instanced triangles are rendered by the shade / trace kernel pair; below it the path state's trip
 // through HBM costs more than the ray replacement gains (measured crossover: see DESIGN.md, "two schedules").
 static const size_t WF_AUTO_TRIS = HEAVY_SCENE_TRIS;
+static const uint   WF_AUTO_PIXELS = 1u << 19;
 static const uint   WF_POOL_MAX = 1u << 22;        // pool slots (pixels in flight) per batch: 4M x 148 B = 620 MB
 static const uint   WF_CHECK = 8;                  // progress word copied back every WF_CHECK shade passes
 static const uint   WF_RING = 8;                   // ... and at most WF_RING such checkpoints in flight
 static const uint   WF_GROUPS_AUTO = 1;            // pixel groups (streams) per call; measured 1M triangles: 1 -> 224, 2 -> 223, 3 -> 204 Mpaths/s
 
-static bool useWavefront(hpt_ctx* c, bool naive, bool dr, bool stats)
+static bool useWavefront(hpt_ctx* c, bool naive, bool dr, bool stats, uint tidCount)
 {
   if (naive || stats) return false;                // those variants exist as megakernels only
   if (c->schedule == 1) return false;
   if (c->schedule == 2) return true;
-  return c->instTris >= WF_AUTO_TRIS;
+  // ... and only for calls with enough pixels to keep the trace kernel's lanes supplied with replacement rays: measured on the 1M-triangle
+  // scene (profiles/share.sh, 2.07 M / 1.04 M / 518 K / 259 K pixels per call): wavefront 226 / 199 / 162 / 108 vs megakernel 171 / 161 / 159 / 146 Mpaths/s
+  return c->instTris >= WF_AUTO_TRIS && tidCount >= WF_AUTO_PIXELS;
 }
 
 template <bool STATS>

@@ -63,6 +63,11 @@ ABI = {
     "hpt_set_launch_config": (_i, [_vp, _i]),
     "hpt_set_accel_layout": (_i, [_vp, _i]),
     "hpt_set_schedule": (_i, [_vp, _i, _i, _i, _i]),
+    "hpt_comm_get_unique_id": (_i, [_vp, _vp]),
+    "hpt_comm_init": (_i, [_vp, _i, _i, _vp]),
+    "hpt_comm_destroy": (_i, [_vp]),
+    "hpt_reduce_framebuffer": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "hpt_allreduce_grad": (_i, [_vp, _vp, _sz, _vp]),
     "hpt_get_schedule": (_i, [_vp, C.POINTER(_i), C.POINTER(_u32)]),
     "hpt_set_option": (_i, [_vp, C.c_char_p, _i]),
     "hpt_last_kernel_ms": (_i, [_vp, C.POINTER(_f)]),

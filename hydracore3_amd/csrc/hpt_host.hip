@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <dlfcn.h>
 
 #include "../../include/hydra_hip.h"
 #include "hpt_kernels.hip"
@@ -92,6 +93,8 @@ struct hpt_ctx
   hipEvent_t wfFork = nullptr;
   int  wfGroupCount = 0;                 // 0 = automatic
   uint wfGrace = 16;                     // trips a trace wave keeps going after the queue ran dry before it suspends its rays (0 = never)
+  // multi-GPU collectives (RCCL, loaded on first use: single-GPU users never touch it)
+  void* rcclLib = nullptr; void* comm = nullptr; int commRanks = 0, commRank = 0;
   int  schedule = 0;                     // 0 automatic, 1 megakernel, 2 wavefront (hpt_set_schedule)
   int  nodeMinOverride = -1;             // env HPT_NODE_MIN (tuning): overrides the per-scene choice of DevScene::nodeMin
   uint wfRefillBelow = 56;               // a trace wave refills from the queue when fewer lanes than this still hold a ray
@@ -119,6 +122,8 @@ struct hpt_ctx
 #define HIPCHK(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) return (ctx)->hipFail(_e, #call); } while (0)
 
 // ---- lifetime -----------------------------------------------------------------------------------------------------------------
+extern "C" int hpt_comm_destroy(hpt_ctx* c);
+
 extern "C" int hpt_create(int device, hpt_ctx** out)
 {
   if (!out) return HPT_ERR_ARG;
@@ -147,6 +152,7 @@ extern "C" void hpt_destroy(hpt_ctx* c)
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
+  (void)hpt_comm_destroy(c);
   c->dNodes.release(); c->dTris.release(); c->dInsts.release(); c->dTriIndices.release(); c->dMatIdByPrim.release();
   c->dMatVertOffset.release(); c->dPackedXY.release(); c->dVData.release(); c->dNormMat.release(); c->dRemapInst.release();
   c->dRemapLists.release(); c->dMaterials.release(); c->dLights.release(); c->dTextures.release(); c->dGens.release();
@@ -1000,6 +1006,85 @@ extern "C" int hpt_image2d4f_regularizer(hpt_ctx* c, int w, int h, const float* 
   if (rc == HPT_OK) { hipError_t e = hipMemcpy(grad, dg.p, n * sizeof(float), hipMemcpyDeviceToHost); if (e != hipSuccess) rc = c->hipFail(e, "hipMemcpy"); }
   dd.release(); dg.release();
   return rc;
+}
+
+// ---- multi-GPU: RCCL collectives behind the C ABI (one context = one GPU = one rank) ---------------------------------------------------
+// The path shards without any data-path exchange; what has to cross xGMI is one reduce(SUM) of the framebuffer per frame and,
+// for PathTraceDR, one all_reduce(SUM) of a_dataGrad (and the loss) per optimisation iteration. librccl is dlopen'ed here instead of being
+// linked, so that a process which already carries an RCCL (PyTorch bundles one) keeps using that copy.
+namespace {
+struct Id128 { char internal[128]; };         // ncclUniqueId (rccl.h:40-43), passed by value
+struct RcclApi
+{
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+const int RCCL_FLOAT32 = 7, RCCL_SUM = 0;       // ncclFloat32, ncclSum (rccl.h:448-466)
+
+int loadRccl(hpt_ctx* c)
+{
+  if (g_rccl.AllReduce) return HPT_OK;
+  void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return c->fail(HPT_ERR_UNSUPPORTED, std::string("hpt_comm: cannot load librccl: ") + dlerror());
+  c->rcclLib = lib;
+  *(void**)&g_rccl.GetUniqueId = dlsym(lib, "ncclGetUniqueId");
+  *(void**)&g_rccl.CommInitRank = dlsym(lib, "ncclCommInitRank");
+  *(void**)&g_rccl.CommDestroy = dlsym(lib, "ncclCommDestroy");
+  *(void**)&g_rccl.Reduce = dlsym(lib, "ncclReduce");
+  *(void**)&g_rccl.AllReduce = dlsym(lib, "ncclAllReduce");
+  *(void**)&g_rccl.GetErrorString = dlsym(lib, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.Reduce || !g_rccl.AllReduce) { g_rccl = RcclApi(); return c->fail(HPT_ERR_UNSUPPORTED, "hpt_comm: librccl lacks the expected entry points"); }
+  return HPT_OK;
+}
+int rcclFail(hpt_ctx* c, int r, const char* what) { return c->fail(HPT_ERR_HIP, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error")); }
+} // namespace
+
+extern "C" int hpt_comm_get_unique_id(hpt_ctx* c, void* id128)
+{
+  if (!c || !id128) return HPT_ERR_ARG;
+  int rc = loadRccl(c); if (rc) return rc;
+  const int r = g_rccl.GetUniqueId(id128);
+  return r ? rcclFail(c, r, "ncclGetUniqueId") : HPT_OK;
+}
+extern "C" int hpt_comm_init(hpt_ctx* c, int nranks, int rank, const void* id128)
+{
+  if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return HPT_ERR_ARG;
+  if (c->comm) return c->fail(HPT_ERR_STATE, "hpt_comm_init: communicator already initialised");
+  int rc = loadRccl(c); if (rc) return rc;
+  (void)hipSetDevice(c->device);
+  Id128 id; std::memcpy(&id, id128, sizeof(id));
+  const int r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+  if (r) { c->comm = nullptr; return rcclFail(c, r, "ncclCommInitRank"); }
+  c->commRanks = nranks; c->commRank = rank;
+  return HPT_OK;
+}
+extern "C" int hpt_comm_destroy(hpt_ctx* c)
+{
+  if (!c) return HPT_ERR_ARG;
+  if (c->comm) { (void)hipSetDevice(c->device); (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; c->commRanks = 0; }
+  return HPT_OK;
+}
+extern "C" int hpt_reduce_framebuffer(hpt_ctx* c, float* frameDev, size_t count, int root, void* stream)
+{
+  if (!c || !frameDev) return HPT_ERR_ARG;
+  if (!c->comm) return c->fail(HPT_ERR_STATE, "hpt_reduce_framebuffer before hpt_comm_init");
+  (void)hipSetDevice(c->device);
+  const int r = g_rccl.Reduce(frameDev, frameDev, count, RCCL_FLOAT32, RCCL_SUM, root, c->comm, (hipStream_t)stream);
+  return r ? rcclFail(c, r, "ncclReduce") : HPT_OK;
+}
+extern "C" int hpt_allreduce_grad(hpt_ctx* c, float* gradDev, size_t count, void* stream)
+{
+  if (!c || !gradDev) return HPT_ERR_ARG;
+  if (!c->comm) return c->fail(HPT_ERR_STATE, "hpt_allreduce_grad before hpt_comm_init");
+  (void)hipSetDevice(c->device);
+  const int r = g_rccl.AllReduce(gradDev, gradDev, count, RCCL_FLOAT32, RCCL_SUM, c->comm, (hipStream_t)stream);
+  return r ? rcclFail(c, r, "ncclAllReduce") : HPT_OK;
 }
 
 // ---- timing / instrumentation --------------------------------------------------------------------------------------------------------

@@ -197,6 +197,17 @@ int  hpt_set_schedule(hpt_ctx* ctx, int schedule, int refillBelow, int traceBloc
  *               Only applied in rounds with at least 2 rays per lane of the trace grid.
  *   "node_min"  voted exit of the inner-node loop (0..63, applied at the next hpt_commit_scene; default chosen per scene). */
 int  hpt_set_option(hpt_ctx* ctx, const char* name, int value);
+/* ---- multi-GPU: one context = one GPU = one rank -----------------------------------------------------
+ * The path shards without a data-path exchange; these three calls are the only traffic over xGMI. RCCL is loaded on first use.
+ *   hpt_comm_get_unique_id : ncclGetUniqueId (128 bytes) on rank 0; the host distributes it (MPI, sockets, a file ...)
+ *   hpt_comm_init          : ncclCommInitRank for this context's device
+ *   hpt_reduce_framebuffer : in-place ncclReduce(sum, fp32) of the zero-initialised framebuffers to `root`, once per frame
+ *   hpt_allreduce_grad     : in-place ncclAllReduce(sum, fp32) of a_dataGrad (or the one-float loss), once per optimisation iteration */
+int  hpt_comm_get_unique_id(hpt_ctx* ctx, void* id128);
+int  hpt_comm_init(hpt_ctx* ctx, int nranks, int rank, const void* id128);
+int  hpt_comm_destroy(hpt_ctx* ctx);
+int  hpt_reduce_framebuffer(hpt_ctx* ctx, float* frameDev, size_t count, int root, void* stream);
+int  hpt_allreduce_grad(hpt_ctx* ctx, float* gradDev, size_t count, void* stream);
 /* Schedule the last hpt_path_trace_block(_dev) call used (1 / 2) and, for the wavefront one, its number of shade+trace rounds. */
 int  hpt_get_schedule(hpt_ctx* ctx, int* lastSchedule, uint32_t* lastIterations);
 /* Duration of the last path-tracing kernel, measured with HIP events on the stream it ran on (ms). */

@@ -451,3 +451,34 @@ def test_fuzzed_scenes_match_oracle(seed):
     assert np.array_equal(hg["t"].view(np.uint32), hc["t"].view(np.uint32))
     wf = HipIntegrator(sc, p); wf.set_schedule(2)
     assert np.array_equal(wf.render(spp), a)
+
+
+def test_rccl_collectives_behind_the_c_abi(cornell):
+    """hpt_comm_* / hpt_reduce_framebuffer / hpt_allreduce_grad: RCCL loaded on first use; with one rank (all a one-GPU box can run)
+    the collectives are identities on a rendered frame, and calls before hpt_comm_init fail with an error code."""
+    import ctypes as C
+    from hydracore3_amd.api import HipIntegrator, HydraHipError
+    sc, _, _ = cornell
+    gpu = HipIntegrator(sc)
+    hip = C.CDLL("libamdhip64.so")
+    n = gpu.N * 4
+    dev = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dev), C.c_size_t(n * 4)) == 0
+    assert hip.hipMemset(dev, 0, C.c_size_t(n * 4)) == 0
+    with pytest.raises(HydraHipError):
+        gpu._chk(gpu.L.hpt_reduce_framebuffer(gpu.h, dev, n, 0, None))
+    uid = (C.c_char * 128)()
+    gpu._chk(gpu.L.hpt_comm_get_unique_id(gpu.h, uid))
+    gpu._chk(gpu.L.hpt_comm_init(gpu.h, 1, 0, uid))
+    gpu.path_trace_block_dev(dev, 3)
+    before = np.zeros(n, np.float32)
+    assert hip.hipMemcpy(before.ctypes.data_as(C.c_void_p), dev, C.c_size_t(n * 4), 2) == 0
+    gpu._chk(gpu.L.hpt_reduce_framebuffer(gpu.h, dev, n, 0, None))
+    gpu._chk(gpu.L.hpt_allreduce_grad(gpu.h, dev, n, None))
+    assert hip.hipDeviceSynchronize() == 0
+    after = np.zeros(n, np.float32)
+    assert hip.hipMemcpy(after.ctypes.data_as(C.c_void_p), dev, C.c_size_t(n * 4), 2) == 0
+    assert np.array_equal(before, after) and before.reshape(-1, 4)[:, :3].mean() > 0.0
+    assert np.array_equal(before.reshape(gpu.H, gpu.W, 4), HipIntegrator(sc).render(3))
+    gpu._chk(gpu.L.hpt_comm_destroy(gpu.h))
+    hip.hipFree(dev)

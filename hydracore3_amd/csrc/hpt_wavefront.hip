@@ -9,16 +9,18 @@
 //                   megakernel): folds the previous shadow-ray result into the path, shades the closest hit (hpt_shade.h: the
 //                   SAME function the megakernel inlines), ends / regenerates paths, and appends the slot to the ray queues
 //                   with one wave ballot + mbcnt prefix sum + ONE atomicAdd per wave and queue (ray compaction);
-//   wfTraceKernel   persistent waves pull rays from the compacted queue.  Traversal state is resumable: whenever fewer than
-//                   `refillBelow` lanes of a wave still hold a ray, the wave leaves the loop, refills the idle lanes from the
-//                   queue (again one atomic per wave) and continues, so the node and triangle loops run with (almost) full
-//                   waves whatever the spread of per-ray work.  ~64 VGPRs instead of 128: twice the waves per SIMD to hide
-//                   the node-fetch latency.
+//   wfTraceKernel   persistent waves pull rays from the compacted queue (a per-wave stash in LDS is topped up 64 rays at a time with
+//                   one atomic; the queue is cut into 64 ranges with their own heads, the waves of an XCD start in neighbouring
+//                   ranges). Traversal state is resumable: whenever fewer than `refillBelow` lanes of a wave still hold a ray, the
+//                   wave leaves the loop, refills the idle lanes and continues, so the node and triangle loops run with (almost)
+//                   full waves whatever the spread of per-ray work; when the queue has run dry, unfinished rays are suspended to
+//                   HBM after a few more trips and resumed first by the next round's pass. 96 VGPRs, 5 waves per SIMD.
 //
 // Price: path state (148 bytes per slot) and rays travel through HBM/MALL once per bounce - negligible against a 40-node
-// traversal, dominant against a 7-node one, which is why the Cornell-box class of scenes stays on the megakernel
-// (hpt_host.hip: chooseSchedule).  The arithmetic per path is identical in both schedules (same functions, same order, IEEE
-// flags), so the two produce bit-identical frames; tests/test_gpu_parity.py holds them to that.
+// traversal, dominant against a 7-node one, which is why the Cornell-box class of scenes - and calls with too few pixels to keep
+// the trace lanes supplied - stay on the megakernel (hpt_host.hip: useWavefront). The arithmetic per path is identical in both
+// schedules (same functions, same order, IEEE flags), so the two produce bit-identical frames; tests/test_gpu_parity.py holds
+// them to that. wfShadeKernel<DR = true> carries the differentiable integrator (adjoint records per slot, reverse sweep at path end).
 #include <hip/hip_runtime.h>
 #include "hpt_shade.h"
 

@@ -2,13 +2,13 @@
 //
 // Why a second schedule.  In the persistent megakernel (hpt_kernels.hip) a lane keeps its ray until the slowest lane of the wave
 // has finished its own: measured on the 1M-triangle scene the node loop runs 237 wave iterations per ray while the mean lane needs
-// 43 (profiles/r1_phases.txt: 18 % lane utilisation, 92 % of the wave cycles inside the two traversals).  Here the two halves of a
+// 43 (profiles/phases.py: 18 % lane utilisation, 92 % of the wave cycles inside the two traversals).  Here the two halves of a
 // bounce are separate kernels that meet in HBM:
 //
 //   wfShadeKernel   one lane per pool slot (= one pixel of the launch, which owns its RNG stream for all passes exactly as in the
 //                   megakernel): folds the previous shadow-ray result into the path, shades the closest hit (hpt_shade.h: the
 //                   SAME function the megakernel inlines), ends / regenerates paths, and appends the slot to the ray queues
-//                   with one wave ballot + mbcnt prefix sum + ONE atomicAdd per wave and queue (ray compaction);
+//                   with a wave ballot + mbcnt prefix sum per wave and ONE atomicAdd per block (ray compaction);
 //   wfTraceKernel   persistent waves pull rays from the compacted queue (a per-wave stash in LDS is topped up 64 rays at a time with
 //                   one atomic; the queue is cut into 64 ranges with their own heads, the waves of an XCD start in neighbouring
 //                   ranges). Traversal state is resumable: whenever fewer than `refillBelow` lanes of a wave still hold a ray, the

@@ -98,8 +98,11 @@ HPT_DEV void blockAppend(uint* counter, bool qNear, bool qShad, uint& posNear, u
   posShad = base + cn + mbcnt64(ms);
 }
 
+#ifndef HPT_WF_SHADE_WAVES
+#define HPT_WF_SHADE_WAVES 4
+#endif
 template <bool DR>
-__global__ void __launch_bounds__(256) wfShadeKernel(const DevScene S, const WfPool P, const WfJob job)
+__global__ void __launch_bounds__(256, HPT_WF_SHADE_WAVES) wfShadeKernel(const DevScene S, const WfPool P, const WfJob job)
 {
   const uint s = blockIdx.x * 256u + threadIdx.x;
   uint* ctr = P.ctr + WF_CTR_WORDS * (job.iter & 1u);

@@ -22,6 +22,7 @@ enum : uint {
   RAY_FLAG_HAS_NON_SPEC = 0x10000000u, RAY_FLAG_HAS_INV_NORMAL = 0x08000000u, RAY_FLAG_WAVES_DIVERGED = 0x04000000u,
   RAY_FLAG_PRIME_RAY_MISS = 0x02000000u, RAY_FLAG_FIRST_NON_SPEC = 0x01000000u };
 enum : uint { GLTF_COMPONENT_METAL = 4, GLTF_COMPONENT_ORENNAYAR = 16, FLAG_FOUR_TEXTURES = 256, FLAG_PACK_FOUR_PARAMS_IN_TEXTURE = 512 };
+enum : uint { MAT_TYPE_GLASS = 2 };    // include/cmaterial.h:39; colours: 0 reflect, 1 transparency; data[2] = IOR (:85-92)
 enum : uint { MAT_TYPE_GLTF = 1, MAT_TYPE_CONDUCTOR = 3, MAT_TYPE_DIFFUSE = 4, MAT_TYPE_DIELECTRIC = 7, MAT_TYPE_LIGHT_SOURCE = 0xEFFFFFFFu };
 enum : uint { RAY_EVENT_S = 1, RAY_EVENT_T = 8 };
 enum : uint { LIGHT_GEOM_RECT = 1, LIGHT_GEOM_DISC = 2, LIGHT_GEOM_SPHERE = 3, LIGHT_GEOM_DIRECT = 4, LIGHT_GEOM_POINT = 5, LIGHT_GEOM_ENV = 6 };
@@ -661,6 +662,43 @@ HPT_DEV void dielectricSmoothSampleAndEval(const MaterialRec& m, float etaInt, f
     r.ior = (_extIOR == etaInt) ? extIOR : etaInt;
   }
   r.val = r.val / smax(absf(dot(r.dir, n)), 1e-6f);
+}
+
+// include/cmat_glass.h:190-277 - the legacy Hydra glass (specular reflection / refraction chosen by the Fresnel term; glassEval is zero)
+HPT_DEV V3 reflect2(V3 dir, V3 n) { return normalize(dir - 2.0f * dot(dir, n) * n); }
+HPT_DEV V3 refract2(V3 dir, V3 n, float relativeIor)
+{
+  const float cosi = dot(dir, n);
+  const float eta = 1.0f / relativeIor;
+  const float k = 1.0f - eta * eta * (1.0f - cosi * cosi);
+  if (k < 0) return reflect2(dir, n);
+  return normalize(eta * dir - (eta * cosi + sqrtf_(k)) * n);
+}
+HPT_DEV float fresnel2(V3 v, V3 n, float ior)
+{
+  const float cosi = dot(v, n);
+  const float sint = sqrtf_(1.0f - cosi * cosi) / ior;
+  if (sint > 1.0f) return 1.0f;
+  const float cost = sqrtf_(1.0f - sint * sint);
+  const float Rp = (ior * cosi - cost) / (ior * cosi + cost);
+  const float Rs = (cosi - ior * cost) / (cosi + ior * cost);
+  return (Rp * Rp + Rs * Rs) * 0.5f;
+}
+HPT_DEV void glassSampleAndEval(const MaterialRec& m, V4 rands, V3 viewDir, V3 normal, BsdfS& r, float& misPrevIor)
+{
+  const V3 colorReflect = ld3(m.colors[0]), colorTransp = ld3(m.colors[1]);
+  const float ior = m.data[2];
+  const V3 rayDir = (-1.0f) * viewDir;
+  float relativeIor = ior / misPrevIor;
+  if ((r.flags & RAY_FLAG_HAS_INV_NORMAL) != 0) { if (misPrevIor == ior) relativeIor = 1.0f / ior; }
+  const float fresnel = fresnel2(viewDir, normal, relativeIor);
+  V3 dir;
+  if (rands.w < fresnel) { dir = reflect2(rayDir, normal); r.val = colorReflect; r.flags |= RAY_EVENT_S; }
+  else { dir = refract2(rayDir, normal, relativeIor); r.val = colorTransp; misPrevIor = ior; r.flags |= (RAY_EVENT_S | RAY_EVENT_T); }
+  const float cosThetaOut = absf(dot(dir, normal));
+  r.val = r.val / smax(cosThetaOut, 1e-6f);
+  r.dir = dir;
+  r.pdf = 1.0f;
 }
 
 // ---- lights: include/clight.h:58-126, integrator_pt_lgt.cpp:21-173 ------------------------------------------------------

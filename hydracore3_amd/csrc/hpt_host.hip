@@ -442,7 +442,7 @@ static int check_materials(hpt_ctx* c, const MaterialRec* m, size_t n, size_t nu
 {
   for (size_t i = 0; i < n; i++) {
     const uint t = m[i].mtype;
-    if (t != MAT_TYPE_GLTF && t != MAT_TYPE_CONDUCTOR && t != MAT_TYPE_DIFFUSE && t != MAT_TYPE_DIELECTRIC && t != MAT_TYPE_LIGHT_SOURCE)
+    if (t != MAT_TYPE_GLTF && t != MAT_TYPE_GLASS && t != MAT_TYPE_CONDUCTOR && t != MAT_TYPE_DIFFUSE && t != MAT_TYPE_DIELECTRIC && t != MAT_TYPE_LIGHT_SOURCE)
       return c->fail(HPT_ERR_UNSUPPORTED, "material type " + std::to_string(t) + " (glass / plastic / blend / thin film) is outside the hot path's scope");
     if (m[i].texid[1] != 0xFFFFFFFFu) return c->fail(HPT_ERR_UNSUPPORTED, "normal-map bump is outside the hot path's scope");
     if (m[i].texid[0] >= numTex) return c->fail(HPT_ERR_ARG, "material refers to a texture that does not exist");

@@ -188,6 +188,7 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
         else                                    conductorRoughSampleAndEval(m, m.data[2], m.data[3], rands, vdir, hitNorm, tex3, ms);
       }
       else if (!DR && mtype == MAT_TYPE_DIFFUSE) diffuseSampleAndEval(m, ld3(m.colors[0]) * tex3, rands, vdir, hitNorm, ms);
+      else if (!DR && mtype == MAT_TYPE_GLASS) glassSampleAndEval(m, rands, vdir, hitNorm, ms, misIor);
       else if (!DR && mtype == MAT_TYPE_DIELECTRIC) {
         dielectricSmoothSampleAndEval(m, m.data[1], misIor, rands, vdir, hitNorm, ms);
         ms.flags |= (m.spdid[0] < 0xFFFFFFFFu) ? RAY_FLAG_WAVES_DIVERGED : 0u;

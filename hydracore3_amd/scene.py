@@ -49,6 +49,7 @@ assert LIGHT_DTYPE.itemsize == 320
 # include/cmaterial.h:26-46
 GLTF_COMPONENT_LAMBERT, GLTF_COMPONENT_COAT, GLTF_COMPONENT_METAL, GLTF_COMPONENT_ORENNAYAR = 1, 2, 4, 16
 MAT_TYPE_GLTF, MAT_TYPE_CONDUCTOR, MAT_TYPE_DIFFUSE, MAT_TYPE_DIELECTRIC = 1, 3, 4, 7
+MAT_TYPE_GLASS = 2
 MAT_TYPE_LIGHT_SOURCE = 0xEFFFFFFF
 # include/cmaterial.h:67-147 (slots in Material::colors / Material::data)
 GLTF_COLOR_BASE, GLTF_COLOR_COAT, GLTF_COLOR_METAL = 0, 1, 2
@@ -260,6 +261,17 @@ def material_dielectric(int_ior=1.5, ext_ior=1.00028) -> np.ndarray:
     m["colors"][0] = 1.0
     m["colors"][1] = 1.0
     m["data"][0], m["data"][1] = ext_ior, int_ior
+    return m
+
+
+def material_glass(color_reflect=(1.0, 1.0, 1.0), color_transp=(1.0, 1.0, 1.0), ior=1.5) -> np.ndarray:
+    """MAT_TYPE_GLASS, the legacy Hydra glass (include/cmat_glass.h:236-277; slots cmaterial.h:85-92): specular reflection or
+    refraction chosen by the Fresnel term, never lit by shadow rays."""
+    m = _blank_material()
+    m["mtype"] = MAT_TYPE_GLASS
+    m["colors"][0] = (*color_reflect[:3], 0.0)
+    m["colors"][1] = (*color_transp[:3], 0.0)
+    m["data"][2] = ior
     return m
 
 

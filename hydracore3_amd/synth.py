@@ -273,7 +273,9 @@ def random_scene(seed: int, width=48, height=32) -> S.SceneData:
     col = lambda: tuple(float(v) for v in r.uniform(0.1, 0.95, 3))
 
     def rand_material():
-        k = r.randint(6)
+        k = r.randint(7)
+        if k == 6:
+            return S.material_glass(col(), col(), float(r.uniform(1.2, 2.2)))
         if k == 0:
             return S.material_lambert(col(), tex if r.uniform() < 0.3 else 0)
         if k == 1:

@@ -208,6 +208,7 @@ struct Ctx
         reflSpec = reflSpec * texColor;
         diffuseSampleAndEval(m, reflSpec, rands, v, shadeNormal, tc, &res);
       } break;
+      case MAT_TYPE_GLASS: glassSampleAndEval(m, rands, v, shadeNormal, &res, &a_misPrev->ior); break;   // integrator_pt_mat.cpp:178-183 (geomNormal == shadeNormal without bump)
       case MAT_TYPE_DIELECTRIC: {
         const f4 intIORSpec = splat4(m.data[DIELECTRIC_ETA_INT]);
         const uint specId = m.spdid[0];
@@ -255,6 +256,7 @@ struct Ctx
         res.val = res.val + currVal.val * weight * bumpCosMult;
         res.pdf += currVal.pdf * weight;
       } break;
+      case MAT_TYPE_GLASS:                                                          // cmat_glass.h:281-287: never lit by shadow rays
       case MAT_TYPE_DIELECTRIC: res.val = splat4(0.0f); res.pdf = 0.0f; break;   // cmat_dielectric.h:59-63
       default: break;
     }

@@ -20,6 +20,8 @@ static const uint RAY_FLAG_FIRST_NON_SPEC = 0x01000000u;
 
 // ---- include/cmaterial.h:26-56 --------------------------------------------------------------------------------
 static const uint GLTF_COMPONENT_METAL = 4, GLTF_COMPONENT_ORENNAYAR = 16, FLAG_FOUR_TEXTURES = 256, FLAG_PACK_FOUR_PARAMS_IN_TEXTURE = 512;
+static const uint MAT_TYPE_GLASS = 2;   // include/cmaterial.h:39; slots :85-92
+static const uint GLASS_COLOR_REFLECT = 0, GLASS_COLOR_TRANSP = 1, GLASS_FLOAT_IOR = 2;
 static const uint MAT_TYPE_GLTF = 1, MAT_TYPE_CONDUCTOR = 3, MAT_TYPE_DIFFUSE = 4, MAT_TYPE_DIELECTRIC = 7, MAT_TYPE_LIGHT_SOURCE = 0xEFFFFFFFu;
 static const uint RAY_EVENT_S = 1, RAY_EVENT_T = 8;
 // include/cmaterial.h:67-147
@@ -578,6 +580,43 @@ static inline void dielectricSmoothSampleAndEval(const Material& m, f4 etaSpec, 
     pRes->ior = (_extIOR == etaSpec.x) ? extIOR : etaSpec.x;
   }
   pRes->val = pRes->val / std::max(std::abs(dot(pRes->dir, n)), 1e-6f);
+}
+
+// ---- include/cmat_glass.h (the legacy Hydra glass: glassSampleAndEval :236-277, helpers :190-233; glassEval :281-287 returns zero) ----
+static inline f3 reflect2(f3 dir, f3 n) { return normalize(dir - 2.0f * dot(dir, n) * n); }
+static inline f3 refract2(f3 dir, f3 n, float relativeIor)
+{
+  const float cosi = dot(dir, n);
+  const float eta = 1.0f / relativeIor;
+  const float k = 1.0f - eta * eta * (1.0f - cosi * cosi);
+  if (k < 0) return reflect2(dir, n);
+  return normalize(eta * dir - (eta * cosi + std::sqrt(k)) * n);
+}
+static inline float fresnel2(f3 v, f3 n, float ior)
+{
+  const float cosi = dot(v, n);
+  const float sint = std::sqrt(1.0f - cosi * cosi) / ior;
+  if (sint > 1.0f) return 1.0f;
+  const float cost = std::sqrt(1.0f - sint * sint);
+  const float Rp = (ior * cosi - cost) / (ior * cosi + cost);
+  const float Rs = (cosi - ior * cost) / (cosi + ior * cost);
+  return (Rp * Rp + Rs * Rs) * 0.5f;
+}
+static inline void glassSampleAndEval(const Material& m, f4 rands, f3 viewDir, f3 normal, BsdfSample* pRes, float* misPrevIor)
+{
+  const f4 colorReflect = m.colors[GLASS_COLOR_REFLECT], colorTransp = m.colors[GLASS_COLOR_TRANSP];
+  const float ior = m.data[GLASS_FLOAT_IOR];
+  const f3 rayDir = (-1.0f) * viewDir;
+  float relativeIor = ior / *misPrevIor;
+  if ((pRes->flags & RAY_FLAG_HAS_INV_NORMAL) != 0) { if (*misPrevIor == ior) relativeIor = 1.0f / ior; }
+  const float fresnel = fresnel2(viewDir, normal, relativeIor);
+  f3 dir;
+  if (rands.w < fresnel) { dir = reflect2(rayDir, normal); pRes->val = colorReflect; pRes->flags |= RAY_EVENT_S; }
+  else { dir = refract2(rayDir, normal, relativeIor); pRes->val = colorTransp; *misPrevIor = ior; pRes->flags |= (RAY_EVENT_S | RAY_EVENT_T); }
+  const float cosThetaOut = std::abs(dot(dir, normal));
+  pRes->val = pRes->val / std::max(cosThetaOut, 1e-6f);
+  pRes->dir = dir;
+  pRes->pdf = 1.0f;
 }
 
 // ---- include/clight.h -----------------------------------------------------------------------------------------

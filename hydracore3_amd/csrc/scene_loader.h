@@ -3,7 +3,7 @@
 //
 // Follows the reference's loaders for the material / light subset of the hot path:
 //   LoadScene / LoadSceneGeometry / LoadSceneInstances / LoadSceneSettings   integrator_pt_scene.cpp:645-1076
-//   ConvertOldHydraMaterial (diffuse-only + emission branches)                  integrator_pt_scene_mat.cpp:280-450
+//   ConvertOldHydraMaterial (every branch: diffuse, Oren-Nayar, metal mix, coated plastic, metal, glass, emission)   integrator_pt_scene_mat.cpp:280-450
 //   LoadLightSourceFromNode (rect, disk, sphere, point / spot / IES, directional, plain-colour sky)   integrator_pt_scene_lgt.cpp:5-222
 //   LoadTextureAndMakeCombined / image4ub                                       integrator_pt_scene_tex.cpp:7-144
 //   cmesh4::LoadMeshFromVSGF                                                    external/LiteScene/cmesh4.cpp:140-167
@@ -401,34 +401,104 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
     sc.lights.push_back(lt);
   }
 
-  // materials: the legacy hydra_material subset the shipped scenes use (ConvertOldHydraMaterial: diffuse-only and emission branches)
+  // materials: ConvertOldHydraMaterial (integrator_pt_scene_mat.cpp:280-450), every branch - emission, diffuse (+ Oren-Nayar), reflectivity
+  // with and without Fresnel (coated plastic / Lambert + metal mix / pure metal), transparency (legacy glass)
+  auto color4 = [](const XmlNode* n, float out[4]) {                          // GetColorFromNode (:124-143)
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    if (!n || !n->has("val")) return;
+    const auto v = parseFloats(n->get("val"));
+    if (v.size() == 1) out[0] = out[1] = out[2] = out[3] = (float)v[0];
+    else if (v.size() == 3) { out[0] = (float)v[0]; out[1] = (float)v[1]; out[2] = (float)v[2]; }
+    else if (v.size() == 4) for (int k = 0; k < 4; k++) out[k] = (float)v[k];
+  };
+  auto val1f = [](const XmlNode* n, float dflt = 0.0f) -> float {             // hydra_xml::readval1f (hydraxml.cpp:390-402)
+    if (!n) return dflt;
+    return (float)std::atof((n->has("val") ? n->get("val") : n->text).c_str());
+  };
+  auto len4 = [](const float* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]); };
+  auto len3 = [](const float* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+  auto fdr = [](float eta) -> float {                                         // mi::fresnel_diffuse_reflectance (mi_materials.cpp:105-130)
+    const float invEta = 1.0f / eta;
+    const float approx1 = 0.0636f * invEta + (eta * (eta * (-1.4399f) + 0.7099f) + 0.6681f);
+    const float cs[6] = { -1.36881f, 4.98554f, -7.80989f, 6.75335f, -3.4793f, 0.919317f };
+    float acc = 0.0f; for (float c : cs) acc = acc * invEta + c;
+    return eta < 1.0f ? approx1 : acc;
+  };
   if (const XmlNode* lib = root.child("materials_lib")) for (const XmlNode* mn : lib->all("material")) {
-    const XmlNode* emis = mn->child("emission"); const XmlNode* diff = mn->child("diffuse");
-    Material mat = blankMaterial();
+    Material mat; std::memset(&mat, 0, sizeof(mat));
+    mat.mtype = 1; mat.data[3] = 0.0f; mat.data[7] = 1.0f;                    // MAT_TYPE_GLTF, GLTF_FLOAT_ALPHA, GLTF_FLOAT_REFL_COAT
+    for (int k = 0; k < 4; k++) { mat.colors[1][k] = 1.0f; mat.colors[2][k] = 0.0f; }   // GLTF_COLOR_COAT, GLTF_COLOR_METAL
+    mat.lightId = 0xFFFFFFFFu;
+    const XmlNode* emis = mn->child("emission");
+    float color[4] = {0, 0, 0, 0};
+    bool isEmission = false;
     if (mn->has("light_id") || emis) {
       const XmlNode* cn = emis ? emis->child("color") : nullptr;
-      if (!cn) { err = "xml: emissive material without colour"; return false; }
-      const auto c = parseFloats(cn->get("val")); if (c.size() < 3) { err = "xml: emission colour"; return false; }
-      mat.mtype = 0xEFFFFFFFu;
-      for (int k = 0; k < 3; k++) mat.colors[0][k] = (float)c[k];
-      mat.data[0] = 1.0f;
-      const int lid = mn->has("light_id") ? std::atoi(mn->get("light_id").c_str()) : -1;
-      mat.lightId = (uint32_t)lid;
+      color4(cn, color);
+      isEmission = mn->has("light_id") || len4(color) > 1e-5f;
+      mat.row0[0][0] = 1.0f; mat.row1[0][1] = 1.0f;
       if (!textureFromColorNode(cn, mat.texid[0])) return false;
-      if (lid >= 0 && lid < (int)sc.lights.size()) {
+      for (int k = 0; k < 4; k++) mat.colors[0][k] = color[k];
+      mat.lightId = mn->has("light_id") ? (uint32_t)std::atoi(mn->get("light_id").c_str()) : 0xFFFFFFFFu;
+      mat.spdid[0] = 0xFFFFFFFFu;
+      mat.mtype = 0xEFFFFFFFu;
+      const XmlNode* mult = cn ? cn->child("multiplier") : nullptr;
+      mat.data[0] = mult ? val1f(mult) : 1.0f;
+    }
+    const XmlNode* diff = mn->child("diffuse");
+    const XmlNode* dn = diff ? diff->child("color") : nullptr;
+    if (dn) {
+      color4(dn, color);
+      if (dn->child("texture")) { mat.row0[0][0] = 1.0f; mat.row0[0][1] = mat.row0[0][2] = mat.row0[0][3] = 0.0f; mat.row1[0][0] = 0.0f; mat.row1[0][1] = 1.0f; if (!textureFromColorNode(dn, mat.texid[0])) return false; }
+    }
+    float reflColor[4] = {0, 0, 0, 0}, reflGloss = 1.0f, fresnelIOR = 1.5f;
+    const XmlNode* refl = mn->child("reflectivity");
+    if (refl) { color4(refl->child("color"), reflColor); reflGloss = val1f(refl->child("glossiness")); fresnelIOR = val1f(refl->child("fresnel_ior")); }
+    float transpColor[4] = {0, 0, 0, 0}, transpGloss = 1.0f;
+    if (const XmlNode* tr = mn->child("transparency")) { color4(tr->child("color"), transpColor); transpGloss = val1f(tr->child("glossiness")); }
+    const XmlNode* fres = refl ? refl->child("fresnel") : nullptr;
+    const bool hasFresnel = fres && (int)std::atof(fres->get("val", "0").c_str()) != 0;
+    if (!hasFresnel) fresnelIOR = 0.0f;
+    auto set4 = [](float* d, const float* v) { for (int k = 0; k < 4; k++) d[k] = v[k]; };
+    auto fill4 = [](float* d, float v) { for (int k = 0; k < 4; k++) d[k] = v; };
+    if ((len4(reflColor) > 1e-5f && len3(color) > 1e-5f) || hasFresnel) {
+      mat.mtype = 1; mat.lightId = 0xFFFFFFFFu;
+      set4(mat.colors[0], color); set4(mat.colors[1], reflColor);
+      if (hasFresnel) {
+        mat.data[3] = 0.0f; mat.data[7] = 1.0f; fill4(mat.colors[2], 0.0f); mat.cflags = 1u | 2u;
+        // SetMiPlastic(&mat, fresnelIOR, 1.0f, color, reflColor) (mi_materials.cpp:455-469)
+        const float eta = fresnelIOR / 1.0f;
+        mat.data[5] = eta; mat.data[0] = fdr((float)(1.0 / (double)eta)); mat.data[1] = fdr(eta);
+        const double dMean = 0.3333333 * ((double)color[0] + color[1] + color[2]), sMean = 0.3333333 * ((double)reflColor[0] + reflColor[1] + reflColor[2]);
+        mat.data[2] = (float)(sMean / (dMean + sMean));
+      } else {
+        mat.data[3] = len4(reflColor) / (len4(reflColor) + len3(color)); mat.data[7] = 0.0f;
+        fill4(mat.colors[1], 0.0f); set4(mat.colors[2], reflColor); mat.cflags = 1u | 4u;
+      }
+    } else if (len4(reflColor) > 1e-5f) {
+      mat.mtype = 1; mat.cflags = 4u; set4(mat.colors[0], reflColor); fill4(mat.colors[2], 1.0f); fill4(mat.colors[1], 0.0f); mat.data[3] = 1.0f;
+    } else if (len3(color) > 1e-5f) {
+      mat.mtype = 1; mat.cflags = 1u; set4(mat.colors[0], color); fill4(mat.colors[1], 0.0f); fill4(mat.colors[2], 0.0f); mat.data[3] = 0.0f; mat.data[7] = 0.0f;
+    }
+    if (len4(transpColor) > 1e-5f) {                                          // legacy glass (MAT_TYPE_GLASS = 2)
+      mat.mtype = 2; set4(mat.colors[0], reflColor); set4(mat.colors[1], transpColor);
+      mat.data[0] = reflGloss; mat.data[1] = transpGloss; mat.data[2] = fresnelIOR;
+    }
+    if (isEmission) mat.mtype = 0xEFFFFFFFu;
+    if (const XmlNode* r = diff ? diff->child("roughness") : nullptr) { mat.data[6] = val1f(r); mat.cflags |= 16u; }   // Oren-Nayar
+    mat.data[4] = reflGloss; mat.data[5] = fresnelIOR;
+    for (int k = 0; k < 4; k++) {                                             // unused texture slots: identity rows, no normal map (integrator_pt_scene.cpp:600-608)
+      bool zero = true; for (int j = 0; j < 4; j++) zero = zero && mat.row0[k][j] == 0.0f && mat.row1[k][j] == 0.0f;
+      if (zero) { mat.row0[k][0] = 1.0f; mat.row1[k][1] = 1.0f; }
+    }
+    mat.texid[1] = 0xFFFFFFFFu;
+    if (mat.mtype == 0xEFFFFFFFu) {
+      const int lid = mn->has("light_id") ? std::atoi(mn->get("light_id").c_str()) : -1;
+      if (lid >= 0 && lid < (int)sc.lights.size()) {                          // LoadScene :973-996: the light's intensity wins
         for (int k = 0; k < 4; k++) mat.colors[0][k] = sc.lights[(size_t)lid].intensity[k];
         mat.data[0] = sc.lights[(size_t)lid].mult;
         sc.lights[(size_t)lid].matId = (uint32_t)sc.materials.size();
       }
-    } else {
-      const XmlNode* cn = diff ? diff->child("color") : nullptr;
-      if (!cn) { err = "xml: material type outside the fixture subset (no <diffuse><color>)"; return false; }
-      const auto c = parseFloats(cn->get("val")); if (c.size() < 3) { err = "xml: diffuse colour"; return false; }
-      mat.mtype = 1; mat.cflags = 1;                        // MAT_TYPE_GLTF, GLTF_COMPONENT_LAMBERT (integrator_pt_scene_mat.cpp:410-419, 446-447)
-      for (int k = 0; k < 3; k++) mat.colors[0][k] = (float)c[k];
-      mat.data[4] = 1.0f; mat.data[5] = 0.0f;
-      if (!textureFromColorNode(cn, mat.texid[0])) return false;
-      if (const XmlNode* r = diff->child("roughness")) { mat.data[6] = (float)std::atof(r->get("val").c_str()); mat.cflags |= 16u; }   // Oren-Nayar
     }
     sc.materials.push_back(mat);
   }

@@ -681,22 +681,133 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
         old_to_new.append(len(sc.lights))
         sc.lights.append(lt)
 
+    def color4(node):
+        """GetColorFromNode (integrator_pt_scene_mat.cpp:124-143): one value splats, three get w = 0, four are taken as they are."""
+        v = _f(node.get("val")) if node is not None and node.get("val") is not None else []
+        if len(v) == 1:
+            return np.array([v[0]] * 4, np.float32)
+        if len(v) == 3:
+            return np.array([*v, 0.0], np.float32)
+        if len(v) == 4:
+            return np.array(v, np.float32)
+        return np.zeros(4, np.float32)
+
+    def val1f(node, default=0.0):
+        """hydra_xml::readval1f (hydraxml.cpp:390-402)."""
+        return default if node is None else np.float32(float(node.get("val")) if node.get("val") is not None else float(node.text or 0.0))
+
+    def length(v):          # LiteMath length in float
+        v = np.asarray(v, np.float32)
+        return np.sqrt(np.float32(np.dot(v, v)), dtype=np.float32)
+
+    # ConvertOldHydraMaterial (integrator_pt_scene_mat.cpp:280-450), every branch: emission, diffuse (+ Oren-Nayar), reflectivity with and
+    # without Fresnel (coated plastic / Lambert + metal mix / pure metal), transparency (legacy glass)
     for mnode in root.findall("materials_lib/material"):
-        emis, diff = mnode.find("emission"), mnode.find("diffuse")
+        mat = _blank_material()
+        mat["texid"] = (0, 0, 0, 0)                                           # Material mat = {}: no 0xFFFFFFFF sentinels in this converter
+        mat["spdid"] = (0, 0, 0, 0)
+        mat["row0"][:] = 0.0; mat["row1"][:] = 0.0
+        mat["mtype"] = MAT_TYPE_GLTF
+        mat["data"][GLTF_FLOAT_ALPHA] = 0.0
+        mat["data"][GLTF_FLOAT_REFL_COAT] = 1.0
+        mat["colors"][GLTF_COLOR_COAT] = 1.0
+        mat["colors"][GLTF_COLOR_METAL] = 0.0
+        mat["lightId"] = UINT_MAX
+        emis = mnode.find("emission")
+        color = np.zeros(4, np.float32)
+        is_emission = False
         if mnode.get("light_id") is not None or emis is not None:
-            cnode = emis.find("color")
-            mat = material_emissive(_f(cnode.get("val")), 1.0, int(mnode.get("light_id", -1)) & UINT_MAX, texture_from_color_node(cnode))
+            cnode = emis.find("color") if emis is not None else None
+            color = color4(cnode)
+            is_emission = mnode.get("light_id") is not None or length(color) > 1e-5
+            mat["row0"][0] = (1, 0, 0, 0); mat["row1"][0] = (0, 1, 0, 0)       # default HydraSampler rows
+            mat["texid"][0] = texture_from_color_node(cnode)
+            mat["colors"][EMISSION_COLOR] = color
+            mat["lightId"] = int(mnode.get("light_id")) & UINT_MAX if mnode.get("light_id") is not None else UINT_MAX
+            mat["spdid"][0] = UINT_MAX
+            mat["mtype"] = MAT_TYPE_LIGHT_SOURCE
+            mult = cnode.find("multiplier") if cnode is not None else None
+            mat["data"][EMISSION_MULT] = val1f(mult) if mult is not None else 1.0
+        diff = mnode.find("diffuse")
+        dnode = diff.find("color") if diff is not None else None
+        if dnode is not None:
+            color = color4(dnode)
+            if dnode.find("texture") is not None:
+                mat["row0"][0] = (1, 0, 0, 0); mat["row1"][0] = (0, 1, 0, 0)
+                mat["texid"][0] = texture_from_color_node(dnode)
+        refl_color, refl_gloss, fresnel_ior = np.zeros(4, np.float32), np.float32(1.0), np.float32(1.5)
+        refl = mnode.find("reflectivity")
+        if refl is not None:
+            refl_color = color4(refl.find("color"))
+            refl_gloss = val1f(refl.find("glossiness"))
+            fresnel_ior = val1f(refl.find("fresnel_ior"))
+        transp_color, transp_gloss = np.zeros(4, np.float32), np.float32(1.0)
+        transp = mnode.find("transparency")
+        if transp is not None:
+            transp_color = color4(transp.find("color"))
+            transp_gloss = val1f(transp.find("glossiness"))
+        fres = refl.find("fresnel") if refl is not None else None
+        has_fresnel = fres is not None and int(float(fres.get("val", "0"))) != 0
+        if not has_fresnel:
+            fresnel_ior = np.float32(0.0)
+        if (length(refl_color) > 1e-5 and length(color[:3]) > 1e-5) or has_fresnel:
+            mat["mtype"] = MAT_TYPE_GLTF
+            mat["lightId"] = UINT_MAX
+            mat["colors"][GLTF_COLOR_BASE] = color
+            mat["colors"][GLTF_COLOR_COAT] = refl_color
+            if has_fresnel:
+                mat["data"][GLTF_FLOAT_ALPHA] = 0.0
+                mat["data"][GLTF_FLOAT_REFL_COAT] = 1.0
+                mat["colors"][GLTF_COLOR_METAL] = 0.0
+                mat["cflags"] = GLTF_COMPONENT_LAMBERT | GLTF_COMPONENT_COAT
+                set_mi_plastic(mat, float(fresnel_ior), 1.0, color, refl_color)
+            else:
+                mat["data"][GLTF_FLOAT_ALPHA] = length(refl_color) / (length(refl_color) + length(color[:3]))
+                mat["data"][GLTF_FLOAT_REFL_COAT] = 0.0
+                mat["colors"][GLTF_COLOR_COAT] = 0.0
+                mat["colors"][GLTF_COLOR_METAL] = refl_color
+                mat["cflags"] = GLTF_COMPONENT_LAMBERT | GLTF_COMPONENT_METAL
+        elif length(refl_color) > 1e-5:
+            mat["mtype"] = MAT_TYPE_GLTF
+            mat["cflags"] = GLTF_COMPONENT_METAL
+            mat["colors"][GLTF_COLOR_BASE] = refl_color
+            mat["colors"][GLTF_COLOR_METAL] = 1.0
+            mat["colors"][GLTF_COLOR_COAT] = 0.0
+            mat["data"][GLTF_FLOAT_ALPHA] = 1.0
+        elif length(color[:3]) > 1e-5:
+            mat["mtype"] = MAT_TYPE_GLTF
+            mat["cflags"] = GLTF_COMPONENT_LAMBERT
+            mat["colors"][GLTF_COLOR_BASE] = color
+            mat["colors"][GLTF_COLOR_COAT] = 0.0
+            mat["colors"][GLTF_COLOR_METAL] = 0.0
+            mat["data"][GLTF_FLOAT_ALPHA] = 0.0
+            mat["data"][GLTF_FLOAT_REFL_COAT] = 0.0
+        if length(transp_color) > 1e-5:                                       # legacy glass
+            mat["mtype"] = MAT_TYPE_GLASS
+            mat["colors"][0] = refl_color                                     # GLTF_COLOR_BASE == GLASS_COLOR_REFLECT
+            mat["colors"][1] = transp_color
+            mat["data"][0] = refl_gloss
+            mat["data"][1] = transp_gloss
+            mat["data"][2] = fresnel_ior
+        if is_emission:
+            mat["mtype"] = MAT_TYPE_LIGHT_SOURCE
+        rough = diff.find("roughness") if diff is not None else None
+        if rough is not None:
+            mat["data"][GLTF_FLOAT_ROUGH_ORENNAYAR] = val1f(rough)
+            mat["cflags"] = int(mat["cflags"]) | GLTF_COMPONENT_ORENNAYAR
+        mat["data"][GLTF_FLOAT_GLOSINESS] = refl_gloss
+        mat["data"][GLTF_FLOAT_IOR] = fresnel_ior
+        # the record the kernels read: texture slots a material does not use still need sane rows / ids (integrator_pt_scene.cpp:600-608)
+        for k in range(4):
+            if not np.any(mat["row0"][k]) and not np.any(mat["row1"][k]):
+                mat["row0"][k] = (1, 0, 0, 0); mat["row1"][k] = (0, 1, 0, 0)
+        mat["texid"][1] = UINT_MAX
+        if mat["mtype"] == MAT_TYPE_LIGHT_SOURCE:
             lid = int(mnode.get("light_id", -1))
-            if 0 <= lid < len(sc.lights):
+            if 0 <= lid < len(sc.lights):                                     # LoadScene :973-996: the light's intensity wins
                 mat["colors"][EMISSION_COLOR] = sc.lights[lid]["intensity"]
                 mat["data"][EMISSION_MULT] = sc.lights[lid]["mult"]
                 sc.lights[lid]["matId"] = len(sc.materials)
-        else:
-            cnode = diff.find("color")
-            mat = material_lambert(_f(cnode.get("val")), texture_from_color_node(cnode))
-            if diff.find("roughness") is not None:
-                mat["data"][GLTF_FLOAT_ROUGH_ORENNAYAR] = float(diff.find("roughness").get("val"))
-                mat["cflags"] |= GLTF_COMPONENT_ORENNAYAR
         sc.materials.append(mat)
 
     for mesh in root.findall("geometry_lib/mesh"):

@@ -383,7 +383,7 @@ def _read_blobs(path):
     return out
 
 
-@pytest.mark.parametrize("scene_name", ["test_035", "test_228"])
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials"])
 def test_cpp_scene_loader_produces_the_same_tables(scene_name, tmp_path):
     """hydracore3_amd/csrc/scene_loader.h (Hydra XML + VSGF + image4ub + IES in C++) == the Python fixture loader:
     every table byte for byte, matrices and light frames to float rounding (both invert in double)."""
@@ -415,7 +415,13 @@ def test_cpp_scene_loader_produces_the_same_tables(scene_name, tmp_path):
         got, ref = np.frombuffer(named[k], np.float32), arr(ptr, np.float32, 16 * ni)
         assert np.allclose(got, ref, rtol=1e-6, atol=1e-7), k
     mats = np.frombuffer(named["materials"], S.MATERIAL_DTYPE)
-    assert mats.tobytes() == np.array(sc.materials, dtype=S.MATERIAL_DTYPE).tobytes()
+    ref_m = np.array(sc.materials, dtype=S.MATERIAL_DTYPE)
+    assert mats.shape == ref_m.shape
+    for f in S.MATERIAL_DTYPE.names:                                      # floats to rounding (SetMiPlastic, the metal mix weight), the rest exactly
+        if S.MATERIAL_DTYPE[f].base.kind == "f":
+            assert np.allclose(mats[f], ref_m[f], rtol=1e-6, atol=1e-7), f
+        else:
+            assert np.array_equal(mats[f], ref_m[f]), f
     lights = np.frombuffer(named["lights"], S.LIGHT_DTYPE)
     ref_l = np.array(sc.lights, dtype=S.LIGHT_DTYPE)
     assert lights.shape == ref_l.shape

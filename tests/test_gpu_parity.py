@@ -336,7 +336,7 @@ def test_path_trace_from_input_rays_block_matches_oracle(cornell):
         assert np.array_equal(gpu.random_gens(), cpu.random_gens())
 
 
-@pytest.mark.parametrize("scene_name", ["test_035", "test_228"])
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials"])
 def test_cpp_scene_ingestion_renders_like_the_python_path(scene_name, tmp_path):
     """hydra_hip_render: scene_loader.h (C++) -> C ABI -> frame, no Python in the loop; the frame equals the one rendered from the
     Python loader's tables (same tables up to float rounding of inverted matrices: the image bar applies)."""
@@ -518,3 +518,17 @@ def test_legacy_glass_material_matches_oracle():
     assert np.array_equal(gpu.random_gens(), cpu.random_gens())
     wf = HipIntegrator(sc); wf.set_schedule(2)
     assert np.array_equal(wf.render(8), a)
+
+
+def test_legacy_material_converter_scene_matches_oracle():
+    """tests/golden/scenes/legacy_materials (own fixture, make_legacy_scene.py): every branch of ConvertOldHydraMaterial - Lambert, Oren-Nayar,
+    Lambert/metal mix, coated plastic, metal, mirror, legacy glass, free emission, light-bound emission - HIP == oracle."""
+    from hydracore3_amd.api import HipIntegrator
+    from oracle.orc import OracleIntegrator
+    sc = load_hydra_xml(scene_path("legacy_materials"))
+    types = sorted({(int(m["mtype"]), int(m["cflags"])) for m in sc.materials})
+    assert (1, 1) in types and (1, 17) in types and (1, 5) in types and (1, 3) in types and (1, 4) in types and (2, 3) in types
+    gpu, cpu = HipIntegrator(sc), OracleIntegrator(sc)
+    a, b = gpu.render(6), cpu.render(6)
+    assert per_pixel_l2(a, b, 6) < 1e-3 and np.isfinite(a).all()
+    assert np.array_equal(gpu.random_gens(), cpu.random_gens())

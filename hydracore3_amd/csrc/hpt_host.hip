@@ -95,6 +95,7 @@ struct hpt_ctx
   uint wfGrace = 16;                     // trips a trace wave keeps going after the queue ran dry before it suspends its rays (0 = never)
   // multi-GPU collectives (RCCL, loaded on first use: single-GPU users never touch it)
   void* rcclLib = nullptr; void* comm = nullptr; int commRanks = 0, commRank = 0;
+  bool leanMaterials = false;            // every material is gltf or emissive: the kernels without the other BSDF branches are used
   int  schedule = 0;                     // 0 automatic, 1 megakernel, 2 wavefront (hpt_set_schedule)
   int  nodeMinOverride = -1;             // env HPT_NODE_MIN (tuning): overrides the per-scene choice of DevScene::nodeMin
   uint wfRefillBelow = 56;               // a trace wave refills from the queue when fewer lanes than this still hold a ray
@@ -438,6 +439,11 @@ extern "C" int hpt_ray_query_nearest(hpt_ctx* c, const float* p, const float* d,
 extern "C" int hpt_ray_query_any(hpt_ctx* c, const float* p, const float* d, uint32_t n, uint32_t* out) { return ray_query(c, p, d, n, out, 1); }
 
 // ---- scene tables -----------------------------------------------------------------------------------------------------------------
+static bool lean_materials(const MaterialRec* m, size_t n)
+{
+  for (size_t i = 0; i < n; i++) if (m[i].mtype != MAT_TYPE_GLTF && m[i].mtype != MAT_TYPE_LIGHT_SOURCE) return false;
+  return true;
+}
 static int check_materials(hpt_ctx* c, const MaterialRec* m, size_t n, size_t numTex)
 {
   for (size_t i = 0; i < n; i++) {
@@ -467,6 +473,7 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
   const double t0 = now_ms();
   if (d->numTextures == 0 || !d->textures) return c->fail(HPT_ERR_ARG, "m_textures must at least hold the white dummy texture");
   int rc = check_materials(c, (const MaterialRec*)d->materials, d->numMaterials, d->numTextures); if (rc) return rc;
+  c->leanMaterials = lean_materials((const MaterialRec*)d->materials, d->numMaterials);
   rc = check_lights(c, (const LightRec*)d->lights, d->numLights, d->numTextures); if (rc) return rc;
 
   if (d->vPos4f) {                                                     // LoadSceneGeometry + LoadSceneInstances order
@@ -557,6 +564,7 @@ extern "C" int hpt_update_materials(hpt_ctx* c, size_t first, size_t count, cons
   if (!c || !mats) return HPT_ERR_ARG;
   if (first + count > c->dMaterials.n) return c->fail(HPT_ERR_ARG, "Update_m_materials: range out of bounds");
   int rc = check_materials(c, (const MaterialRec*)mats, count, c->hTextures.size()); if (rc) return rc;
+  if (!lean_materials((const MaterialRec*)mats, count)) c->leanMaterials = false;      // (an update can only widen the set of BSDFs in use)
   (void)hipSetDevice(c->device);
   HIPCHK(c, hipMemcpy(c->dMaterials.p + first, mats, count * sizeof(MaterialRec), hipMemcpyHostToDevice));
   return HPT_OK;
@@ -680,6 +688,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   else if (inRays) launchPT<false, false, 2>(c->S, job, blocks, st, deep);
   else if (naive)  launchPT<false, false, 1>(c->S, job, blocks, st, deep);
   else if (stats)  launchPT<true, false, 0>(c->S, job, blocks, st, deep);
+  else if (c->leanMaterials) launchPT<false, false, 3>(c->S, job, blocks, st, deep);
   else             launchPT<false, false, 0>(c->S, job, blocks, st, deep);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev1, st));
@@ -793,8 +802,10 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr)
       if (g.finished) continue;
       const WfPool& P = pools[gi];
       wj.itemBase = g.itemBase; wj.itemCount = g.itemCount; wj.iter = (uint)g.it; wj.record = g.rec.p;
-      if (dr) wfShadeKernel<true><<<dim3((g.itemCount + 255u) / 256u), dim3(256), 0, g.stream>>>(c->S, P, wj);
-      else    wfShadeKernel<false><<<dim3((g.itemCount + 255u) / 256u), dim3(256), 0, g.stream>>>(c->S, P, wj);
+      const dim3 sg((g.itemCount + 255u) / 256u);
+      if (dr)                    wfShadeKernel<true, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
+      else if (c->leanMaterials) wfShadeKernel<false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
+      else                       wfShadeKernel<false, false><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
       if ((g.it % WF_CHECK) == WF_CHECK - 1) {
         const uint slot = g.checkpoints % WF_RING;
         if (g.checkpoints >= WF_RING) {                                     // oldest checkpoint of the ring: wait for it, then look at it

@@ -49,11 +49,12 @@ struct Job
 #define HPT_MIN_WAVES 4   // waves per SIMD the register allocator must fit (measured: 2 -> 725, 3 -> 913..1262, 4 -> 1005..1365 Mpaths/s on the Cornell box)
 #endif
 // MODE: 0 = PathTrace (MIS / shadow / stupid by m_intergatorType), 1 = NaivePathTrace, 2 = PathTraceFromInputRays (the caller's rays
-// instead of camera rays, linear tid -> output index, raw accumColor: integrator_pt.cpp:159-199, 659-676, 761-798)
+// instead of camera rays, linear tid -> output index, raw accumColor: integrator_pt.cpp:159-199, 659-676, 761-798),
+// 3 = PathTrace for scenes with gltf + emissive materials only (shadeVertex<LEAN>)
 template <bool STATS, bool DR, int MODE, bool DEEP, bool FLAT>
 __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevScene S, const Job job)
 {
-  constexpr bool NAIVE = (MODE == 1), INRAYS = (MODE == 2);
+  constexpr bool NAIVE = (MODE == 1), INRAYS = (MODE == 2), LEAN = (MODE == 3);
   __shared__ uint stackMem[LDS_STACK * 256];
   const uint glane = blockIdx.x * 256u + threadIdx.x;                    // slot in the per-lane HBM buffers
   TravStack stk; stk.lds = &stackMem[threadIdx.x]; stk.ovf = job.stackOverflow + glane; stk.ovfStride = job.gridLanes;
@@ -158,7 +159,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
 
     if (alive) {
       if (STATS && hit.inst != 0xFFFFFFFFu) nHits++;
-      didBounce = shadeVertex<DR, NAIVE>(S, job.data, hit, rpos, rdir, accum, thr, misPdf, misIor, flags, bounce, gen,
+      didBounce = shadeVertex<DR, NAIVE, LEAN>(S, job.data, hit, rpos, rdir, accum, thr, misPdf, misIor, flags, bounce, gen,
                                          wantShadow, shPos, shDir, shFar, contrib, recA, recS, recdA, recdS, recTaps, recTex, tailR);
     }
 

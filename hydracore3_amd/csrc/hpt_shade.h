@@ -60,7 +60,9 @@ HPT_DEV void cameraRay(const DevScene& S, uint x, uint y, V4 pixelOffsets, V3& r
 // Shades the vertex a closest-hit query returned for one path.  All path registers are passed by reference and the
 // function is always inlined, so both callers keep them in VGPRs.  Returns true when the path continues (didBounce).
 // A miss only sets the OUT_OF_SCENE flags.  The caller traces the shadow ray (if wantShadow) and adds `contrib`.
-template <bool DR, bool NAIVE>
+// LEAN: the scene holds gltf and emissive materials only (the host checked): the conductor / diffuse / glass / dielectric branches are
+// compiled out - fewer live registers and spills in the kernels every benchmark scene runs (the DR variant is lean by definition).
+template <bool DR, bool NAIVE, bool LEAN = false>
 HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec& hit,
                          V3& rpos, V3& rdir, V3& accum, V3& thr, float& misPdf, float& misIor, uint& flags, const uint bounce, Rng& gen,
                          bool& wantShadow, V3& shPos, V3& shDir, float& shFar, V3& contrib,
@@ -134,10 +136,10 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
           // candidate contribution has to stay live across the any-hit traversal
           BsdfE bv; bv.val = v3(0, 0, 0); bv.pdf = 0.0f; bv.dval = v3(0, 0, 0);
           if (mtype == MAT_TYPE_GLTF) gltfEval(m, shadowRayDir, vdir, hitNorm, baseCol * tex3, four, bv);
-          else if (!DR && mtype == MAT_TYPE_CONDUCTOR) {
+          else if (!(DR || LEAN) && mtype == MAT_TYPE_CONDUCTOR) {
             if (!(smax(m.data[1], m.data[0]) < 1e-3f)) conductorRoughEval(m, m.data[2], m.data[3], shadowRayDir, vdir, hitNorm, tex3, bv);
           }
-          else if (!DR && mtype == MAT_TYPE_DIFFUSE) diffuseEval(m, ld3(m.colors[0]) * tex3, shadowRayDir, vdir, hitNorm, bv);
+          else if (!(DR || LEAN) && mtype == MAT_TYPE_DIFFUSE) diffuseEval(m, ld3(m.colors[0]) * tex3, shadowRayDir, vdir, hitNorm, bv);
           const float cosThetaOut = smax(dot(shadowRayDir, hitNorm), 0.0f);
           float lgtPdfW = (1.0f / float(nLights)) * lightEvalPDF(L, shadowRayPos, shadowRayDir, ls.pos, ls.norm, ls.pdf);
           float misWeight = (S.integratorType == INTEGRATOR_MIS_PT) ? misWeightHeuristic(lgtPdfW, bv.pdf) : 1.0f;
@@ -183,13 +185,13 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
       BsdfS ms; ms.val = v3(0, 0, 0); ms.pdf = 1.0f; ms.dir = v3(0, 1, 0); ms.ior = 1.0f; ms.flags = flags; ms.dval = v3(0, 0, 0);
       const V4 rands = rng_float4(gen);                                // GetRandomNumbersMats: drawn for every material type (integrator_pt_mat.cpp:147)
       if (mtype == MAT_TYPE_GLTF) gltfSampleAndEval(m, rands, vdir, hitNorm, baseCol * tex3, four, ms);
-      else if (!DR && mtype == MAT_TYPE_CONDUCTOR) {
+      else if (!(DR || LEAN) && mtype == MAT_TYPE_CONDUCTOR) {
         if (smax(m.data[1], m.data[0]) < 1e-3f) conductorSmoothSampleAndEval(m, m.data[2], m.data[3], vdir, hitNorm, ms);
         else                                    conductorRoughSampleAndEval(m, m.data[2], m.data[3], rands, vdir, hitNorm, tex3, ms);
       }
-      else if (!DR && mtype == MAT_TYPE_DIFFUSE) diffuseSampleAndEval(m, ld3(m.colors[0]) * tex3, rands, vdir, hitNorm, ms);
-      else if (!DR && mtype == MAT_TYPE_GLASS) glassSampleAndEval(m, rands, vdir, hitNorm, ms, misIor);
-      else if (!DR && mtype == MAT_TYPE_DIELECTRIC) {
+      else if (!(DR || LEAN) && mtype == MAT_TYPE_DIFFUSE) diffuseSampleAndEval(m, ld3(m.colors[0]) * tex3, rands, vdir, hitNorm, ms);
+      else if (!(DR || LEAN) && mtype == MAT_TYPE_GLASS) glassSampleAndEval(m, rands, vdir, hitNorm, ms, misIor);
+      else if (!(DR || LEAN) && mtype == MAT_TYPE_DIELECTRIC) {
         dielectricSmoothSampleAndEval(m, m.data[1], misIor, rands, vdir, hitNorm, ms);
         ms.flags |= (m.spdid[0] < 0xFFFFFFFFu) ? RAY_FLAG_WAVES_DIVERGED : 0u;
         misIor = ms.ior;

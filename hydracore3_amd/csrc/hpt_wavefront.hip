@@ -101,7 +101,7 @@ HPT_DEV void blockAppend(uint* counter, bool qNear, bool qShad, uint& posNear, u
 #ifndef HPT_WF_SHADE_WAVES
 #define HPT_WF_SHADE_WAVES 4
 #endif
-template <bool DR>
+template <bool DR, bool LEAN>
 __global__ void __launch_bounds__(256, HPT_WF_SHADE_WAVES) wfShadeKernel(const DevScene S, const WfPool P, const WfJob job)
 {
   const uint s = blockIdx.x * 256u + threadIdx.x;
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256, HPT_WF_SHADE_WAVES) wfShadeKernel(const D
       V3 rA = v3(0, 0, 0), rS = v3(0, 0, 0), rdA = v3(0, 0, 0), rdS = v3(0, 0, 0); Taps taps; uint recTex = 0xFFFFFFFFu;   // adjoint record of this vertex (DR)
       for (int k = 0; k < 4; k++) { taps.off[k] = 0; taps.w[k] = 0.0f; }
       const V3 thrBefore = thr;
-      const bool didBounce = shadeVertex<DR, false>(S, DR ? job.data : nullptr, hit, rpos, rdir, accum, thr, misPdf, misIor, flags, bounce, gen,
+      const bool didBounce = shadeVertex<DR, false, LEAN>(S, DR ? job.data : nullptr, hit, rpos, rdir, accum, thr, misPdf, misIor, flags, bounce, gen,
                                                     wantShadow, shPos, shDir, shFar, contrib, rA, rS, rdA, rdS, taps, recTex, tailR);
       if (DR && didBounce) {
         if (!wantShadow) { rS = v3(0, 0, 0); rdS = v3(0, 0, 0); }           // (an occluded sample is cleared when its shadow ray comes back)

@@ -532,3 +532,42 @@ def test_legacy_material_converter_scene_matches_oracle():
     a, b = gpu.render(6), cpu.render(6)
     assert per_pixel_l2(a, b, 6) < 1e-3 and np.isfinite(a).all()
     assert np.array_equal(gpu.random_gens(), cpu.random_gens())
+
+
+def test_dynamic_updates_equal_a_fresh_build(cornell):
+    """ISceneObject::UpdateInstance / UpdateGeom_Triangles3f + CommitScene, Integrator::Update_m_materials / Update_m_lights: after the
+    update the context renders exactly what a freshly built one renders from the modified scene (both layouts), and ray queries agree."""
+    from hydracore3_amd.api import HipIntegrator
+    from hydracore3_amd import scene as S
+    sc0, _, _ = cornell
+    for layout in (1, 2):
+        sc = load_hydra_xml(scene_path("test_035"), 128, 128)            # a second, independent copy of the scene to modify
+        live = HipIntegrator(sc0, accel_layout=layout)
+        live.render(1)                                                    # the context has rendered the original scene once
+        # 1. move instance 0 (the cube), 2. stretch the vertices of mesh 0, 3. recolour material 1, 4. dim the light
+        m_new = S.translate(0.7, 0.3, -0.5) @ S.rotate_y(25.0) @ np.asarray(sc.inst_matrices[0])
+        sc.inst_matrices[0] = m_new
+        nv0 = sc.geom_vert_count[0]
+        sc.vpos = sc.vpos.copy(); sc.vpos[:nv0, 1] *= 1.3
+        sc.materials = [m.copy() for m in sc.materials]; sc.materials[1]["colors"][0] = (0.9, 0.2, 0.1, 0.0)
+        sc.lights = [l.copy() for l in sc.lights]; sc.lights[0]["mult"] = np.float32(0.5) * sc.lights[0]["mult"]
+        L = live.L
+        cm = S.colmajor(m_new)
+        live._chk(L.hpt_update_instance(live.h, 0, cm.ctypes.data))
+        idx0 = np.ascontiguousarray(sc.tri_indices[:3 * sc.geom_tri_count[0]])
+        pos0 = np.ascontiguousarray(sc.vpos[:nv0])
+        live._chk(L.hpt_update_geom_triangles3f(live.h, 0, pos0.ctypes.data, nv0, idx0.ctypes.data, idx0.size, 0, 16))
+        live._chk(L.hpt_commit_scene(live.h, 0))
+        d = sc.desc()
+        d.vPos4f = None                                                   # geometry already lives in the accelerator: tables only
+        live._desc = d; live.scene = sc
+        live.CommitDeviceData()                                           # normal matrices follow the instance matrices
+        live.Update_m_materials(1, np.array(sc.materials[1:2], dtype=S.MATERIAL_DTYPE))
+        live.Update_m_lights(0, np.array(sc.lights[0:1], dtype=S.LIGHT_DTYPE))
+        live.InitRandomGens(live.N)
+        fresh = HipIntegrator(sc, accel_layout=layout)
+        a, b = live.render(4), fresh.render(4)
+        assert np.array_equal(a, b), layout
+        assert not np.array_equal(a, HipIntegrator(sc0, accel_layout=layout).render(4))
+        pos, dr = random_rays(5000, 13, -5.5, 8.5)
+        assert np.array_equal(live.RayQuery_NearestHit(pos, dr).view(np.uint8), fresh.RayQuery_NearestHit(pos, dr).view(np.uint8))

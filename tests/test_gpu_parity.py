@@ -571,3 +571,22 @@ def test_dynamic_updates_equal_a_fresh_build(cornell):
         assert not np.array_equal(a, HipIntegrator(sc0, accel_layout=layout).render(4))
         pos, dr = random_rays(5000, 13, -5.5, 8.5)
         assert np.array_equal(live.RayQuery_NearestHit(pos, dr).view(np.uint8), fresh.RayQuery_NearestHit(pos, dr).view(np.uint8))
+
+
+def test_execution_time_slots_and_launch_knobs(cornell):
+    """GetExecutionTime(name, out[4]): [0] kernel ms (HIP events), [1] host-to-device, [2] device-to-host, [3] overhead (main.cpp:417-419) for
+    the three entry points; hpt_last_kernel_ms agrees; launch geometry knobs do not change the frame."""
+    from hydracore3_amd.api import HipIntegrator
+    sc, _, _ = cornell
+    gpu = HipIntegrator(sc)
+    ref = gpu.render(4)
+    t = gpu.GetExecutionTime("PathTraceBlock")
+    assert t[0] > 0.0 and t[1] >= 0.0 and t[2] >= 0.0 and abs(gpu.last_kernel_ms() - t[0]) < 1e-3
+    assert gpu.GetExecutionTime("NaivePathTraceBlock")[0] == 0.0
+    gpu.render(2, naive=True)
+    assert gpu.GetExecutionTime("NaivePathTraceBlock")[0] > 0.0
+    info = gpu.device_info()
+    assert info["wavefront"] == 64 and info["cus"] > 0 and "gfx950" in info["arch"]
+    for bpc in (1, 2, 3):
+        g2 = HipIntegrator(sc); g2.set_launch_config(bpc)
+        assert np.array_equal(g2.render(4), ref), bpc

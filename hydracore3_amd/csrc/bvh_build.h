@@ -97,7 +97,10 @@ private:
       for (int a = 0; a < 3; a++) { clo[a] = std::min(clo[a], c[a]); chi[a] = std::max(chi[a], c[a]); }
     }
     // binned SAH over the three axes
-    const int NB = 16;
+#ifndef HPT_SAH_BINS
+#define HPT_SAH_BINS 16
+#endif
+    const int NB = HPT_SAH_BINS;
     float bestCost = FLT_MAX; int bestAxis = -1, bestBin = -1;
     for (int a = 0; a < 3; a++) {
       const float ext = chi[a] - clo[a];

@@ -853,6 +853,36 @@ HPT_DEV void nodeSlabs(const float4 q0, const float4 q1, const float4 q2, const 
   h1 = (t1n * 0.999999f <= t1f * 1.000001f);
 }
 
+// Moeller-Trumbore on a 48-byte record (v0, e1, e2): exact (IEEE) arithmetic, inclusive [tnear, current best], no back-face culling; at equal
+// distance the lower (instId, primId) wins, so the closest hit does not depend on tree shape or traversal order. ONE definition for the
+// megakernel's two traversals, the wavefront trace kernel and the ray-query kernel. Returns true when the hit record was updated.
+HPT_DEV bool triangleTest(const float4 a, const float4 b, const float4 c, const V3 o, const V3 d, const float tnear, const uint inst,
+                          float& bestT, uint& bestPrim, uint& bestInst, float& bestU, float& bestV, bool& found)
+{
+  const V3 e1 = v3(b.x, b.y, b.z), e2 = v3(c.x, c.y, c.z);
+  const V3 pvec = cross(d, e2);
+  const float det = dot(e1, pvec);
+  const float inv = 1.0f / det;
+  const V3 tvec = o - v3(a.x, a.y, a.z);
+  const float uu = dot(tvec, pvec) * inv;
+  const V3 qvec = cross(tvec, e1);
+  const float vv = dot(d, qvec) * inv;
+  const float tt = dot(e2, qvec) * inv;
+  const uint prim = __float_as_uint(a.w);
+  bool ok = (det != 0.0f) && (uu >= 0.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f) && (tt >= tnear) && (tt <= bestT);
+  if (ok && found && tt == bestT) ok = (inst != bestInst) ? (inst < bestInst) : (prim < bestPrim);
+  if (ok) { bestT = tt; bestPrim = prim; bestInst = inst; bestU = uu; bestV = vv; found = true; }
+  return ok;
+}
+// world -> object space of an instance (EmbreeRT.cpp:242-292 semantics: t is shared between the two spaces)
+HPT_DEV void toObjectSpace(const BvhInst* insts, const uint inst, const V3 wo, const V3 wd, V3& o, V3& d)
+{
+  const float4* ip = (const float4*)(insts + inst);
+  const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
+  o = v3(r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w, r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w, r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w);
+  d = v3(r0.x * wd.x + r0.y * wd.y + r0.z * wd.z, r1.x * wd.x + r1.y * wd.y + r1.z * wd.z, r2.x * wd.x + r2.y * wd.y + r2.z * wd.z);
+}
+
 template <bool ANY, bool STATS, bool DEEP>
 HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, float tfar, HitRec& hit, const TravStack& stk, TravStats& st)
 {
@@ -909,42 +939,19 @@ HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, 
         const float4* tp = (const float4*)(S.tris + first + k);
         const float4 a = tp[0], b = tp[1], c = tp[2];
         if (STATS) { st.tris++; if (firstActiveLane()) st.waveTriIters++; }
-        const V3 e1 = v3(b.x, b.y, b.z), e2 = v3(c.x, c.y, c.z);
-        const V3 pvec = cross(d, e2);
-        const float det = dot(e1, pvec);
-        const float inv = 1.0f / det;
-        const V3 tvec = o - v3(a.x, a.y, a.z);
-        const float uu = dot(tvec, pvec) * inv;
-        const V3 qvec = cross(tvec, e1);
-        const float vv = dot(d, qvec) * inv;
-        const float tt = dot(e2, qvec) * inv;
-        const uint prim = __float_as_uint(a.w);
-        bool ok = (det != 0.0f) && (uu >= 0.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f) && (tt >= tnear) && (tt <= hit.t);
-        if (ok && found && tt == hit.t)            // equal distance: lower (instId, primId) wins
-          ok = (curInst != hit.inst) ? (curInst < hit.inst) : (prim < hit.prim);
-        if (ok) {
-          hit.t = tt; hit.prim = prim; hit.inst = curInst; hit.u = uu; hit.v = vv; found = true;
-          if (ANY) return true;
-        }
+        if (triangleTest(a, b, c, o, d, tnear, curInst, hit.t, hit.prim, hit.inst, hit.u, hit.v, found) && ANY) return true;
       }
       if (sp > 0) HPT_POP(); else break;
     } else if (cnt == 0u) {
       // instance leaf: enter object space (EmbreeRT.cpp:242-292 semantics: t is shared between the two spaces)
       const uint inst = cur & 0x0FFFFFFFu;
-      const float4* ip = (const float4*)(S.insts + inst);
-      const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
-      const uint4  r3 = ((const uint4*)ip)[3];
+      const uint root = S.insts[inst].root;
       if (STATS) st.insts++;
-      o = v3(r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w,
-             r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w,
-             r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w);
-      d = v3(r0.x * wd.x + r0.y * wd.y + r0.z * wd.z,
-             r1.x * wd.x + r1.y * wd.y + r1.z * wd.z,
-             r2.x * wd.x + r2.y * wd.y + r2.z * wd.z);
+      toObjectSpace(S.insts, inst, wo, wd, o, d);
       id = rcp3(d);
       curInst = inst;
       HPT_PUSH(REF_RESTORE);
-      cur = r3.x;
+      cur = root;
     } else {
       // marker: back to world space
       o = wo; d = wd; id = rcp3(d); curInst = 0xFFFFFFFFu;
@@ -995,34 +1002,11 @@ HPT_DEV bool traceRayFlat(const DevScene& S, const V3 wo, const V3 wd, float tne
         if (STATS) { st.tris++; if (firstActiveLane()) st.waveTriIters++; }
         const uint inst = __float_as_uint(b.w);
         if (inst != curInst) {                                // world -> object space of this triangle's instance
-          const float4* ip = (const float4*)(S.insts + inst);
-          const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
           if (STATS) st.insts++;
-          o = v3(r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w,
-                 r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w,
-                 r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w);
-          d = v3(r0.x * wd.x + r0.y * wd.y + r0.z * wd.z,
-                 r1.x * wd.x + r1.y * wd.y + r1.z * wd.z,
-                 r2.x * wd.x + r2.y * wd.y + r2.z * wd.z);
+          toObjectSpace(S.insts, inst, wo, wd, o, d);
           curInst = inst;
         }
-        const V3 e1 = v3(b.x, b.y, b.z), e2 = v3(c.x, c.y, c.z);
-        const V3 pvec = cross(d, e2);
-        const float det = dot(e1, pvec);
-        const float inv = 1.0f / det;
-        const V3 tvec = o - v3(a.x, a.y, a.z);
-        const float uu = dot(tvec, pvec) * inv;
-        const V3 qvec = cross(tvec, e1);
-        const float vv = dot(d, qvec) * inv;
-        const float tt = dot(e2, qvec) * inv;
-        const uint prim = __float_as_uint(a.w);
-        bool ok = (det != 0.0f) && (uu >= 0.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f) && (tt >= tnear) && (tt <= hit.t);
-        if (ok && found && tt == hit.t)
-          ok = (inst != hit.inst) ? (inst < hit.inst) : (prim < hit.prim);
-        if (ok) {
-          hit.t = tt; hit.prim = prim; hit.inst = inst; hit.u = uu; hit.v = vv; found = true;
-          if (ANY) return true;
-        }
+        if (triangleTest(a, b, c, o, d, tnear, inst, hit.t, hit.prim, hit.inst, hit.u, hit.v, found) && ANY) return true;
       }
       if (sp > 0) HPT_POP(); else break;
     }

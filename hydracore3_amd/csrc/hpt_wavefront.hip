@@ -348,10 +348,7 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
             for (int k = 0; k < sp; k++) { const uint v = r[(WF_SUSP_WORDS + k) * SM]; if (DEEP) stkPush(stk, k, v); else stk.lds[k * 256] = v; }
             if (FLAT) curInst = 0xFFFFFFFFu;                                 // the object-space ray is rebuilt at the next triangle
             else if (curInst != 0xFFFFFFFFu) {
-              const float4* ip = (const float4*)(S.insts + curInst);
-              const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
-              o = v3(r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w, r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w, r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w);
-              d = v3(r0.x * wd.x + r0.y * wd.y + r0.z * wd.z, r1.x * wd.x + r1.y * wd.y + r1.z * wd.z, r2.x * wd.x + r2.y * wd.y + r2.z * wd.z);
+              toObjectSpace(S.insts, curInst, wo, wd, o, d);
               id = rcp3(d);
             }
           }
@@ -409,41 +406,22 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
               if (FLAT) {
                 inst = __float_as_uint(b.w);
                 if (inst != curInst) {                                          // world -> object space of this triangle's instance
-                  const float4* ip = (const float4*)(S.insts + inst);
-                  const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
-                  o = v3(r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w, r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w, r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w);
-                  d = v3(r0.x * wd.x + r0.y * wd.y + r0.z * wd.z, r1.x * wd.x + r1.y * wd.y + r1.z * wd.z, r2.x * wd.x + r2.y * wd.y + r2.z * wd.z);
+                  toObjectSpace(S.insts, inst, wo, wd, o, d);
                   curInst = inst;
                 }
               }
-              const V3 e1 = v3(b.x, b.y, b.z), e2 = v3(c.x, c.y, c.z);
-              const V3 pvec = cross(d, e2);
-              const float det = dot(e1, pvec);
-              const float inv = 1.0f / det;
-              const V3 tvec = o - v3(a.x, a.y, a.z);
-              const float uu = dot(tvec, pvec) * inv;
-              const V3 qvec = cross(tvec, e1);
-              const float vv = dot(d, qvec) * inv;
-              const float tt = dot(e2, qvec) * inv;
-              const uint prim = __float_as_uint(a.w);
-              bool ok = (det != 0.0f) && (uu >= 0.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f) && (tt >= 0.0f) && (tt <= hitT);
-              if (ok && found && tt == hitT) ok = (inst != hitInst) ? (inst < hitInst) : (prim < hitPrim);
-              if (ok) { hitT = tt; hitPrim = prim; hitInst = inst; hitU = uu; hitV = vv; found = true; }
+              (void)triangleTest(a, b, c, o, d, 0.0f, inst, hitT, hitPrim, hitInst, hitU, hitV, found);
             }
             if (isAny && found) done = true;
             else if (usePend) { pend = 0u; done = (cur == REF_NONE); }           // the walk position (cur, stack) is untouched
             else if (sp > 0) HPT_POP(); else done = true;
           } else if (cnt == 0u) {
             const uint inst = cur & 0x0FFFFFFFu;
-            const float4* ip = (const float4*)(S.insts + inst);
-            const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
-            const uint4  r3 = ((const uint4*)ip)[3];
-            o = v3(r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w, r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w, r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w);
-            d = v3(r0.x * wd.x + r0.y * wd.y + r0.z * wd.z, r1.x * wd.x + r1.y * wd.y + r1.z * wd.z, r2.x * wd.x + r2.y * wd.y + r2.z * wd.z);
+            toObjectSpace(S.insts, inst, wo, wd, o, d);
             id = rcp3(d);
             curInst = inst;
             HPT_PUSH(REF_RESTORE);
-            cur = r3.x;
+            cur = S.insts[inst].root;
           } else {
             o = wo; d = wd; id = rcp3(d); curInst = 0xFFFFFFFFu;
             if (sp > 0) HPT_POP(); else done = true;

@@ -28,7 +28,7 @@ namespace hpt {
 
 static const uint WF_RANGES = 64u;                   // the trace kernel pulls rays from this many ranges of the queue (work stealing)
 static const uint WF_CTR_WORDS = 32u * (1u + WF_RANGES);
-static const uint WF_SUSP_WORDS = 10u;               // cur, sp, curInst, hitT, hitU, hitV, hitPrim, hitInst, found, pad
+static const uint WF_SUSP_WORDS = 10u;               // cur, sp, curInst, hitT, hitU, hitV, hitPrim, hitInst, found, (spare)
 static const uint WF_ALIVE = 1u, WF_PEND = 2u, WF_ENDING = 4u;   // status bits; passes left in bits 8..31
 
 struct WfPool
@@ -231,9 +231,6 @@ __global__ void wfLossFinishKernel(const double* acc, float* loss) { *loss += (f
 #ifndef HPT_WF_XCD_RANGES
 #define HPT_WF_XCD_RANGES 1
 #endif
-#ifndef HPT_WF_SPECULATE
-#define HPT_WF_SPECULATE 0   // measured: bit-exact but slower (1M triangles: 197 vs 209 Mpaths/s; node-loop utilisation only 0.49 -> 0.52)
-#endif
 #ifndef HPT_WF_WAVES
 #define HPT_WF_WAVES 5   // measured on the 1M-triangle scene: 4 -> 213, 5 -> 224, 6 -> 217 Mpaths/s (96 VGPRs: no spills; 24 KB of LDS per block)
 #endif
@@ -266,7 +263,6 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
   const uint lane = threadIdx.x & 63u;
   bool has = false, isAny = false, found = false, resumed = false;
   uint dryTrips = 0;
-  uint pend = 0u;                                                            // flat layout: a leaf this lane reached and postponed (0 = none)
   // XCD-aware start range: blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own L2. The waves of
   // one XCD start in ITS eight neighbouring ranges - contiguous, pixel-coherent stretches of the queue - and only steal elsewhere later.
 #if HPT_WF_XCD_RANGES
@@ -338,13 +334,13 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
           const uint q = e[7 * 64];
           slot = q & 0x3FFFFFFFu; isAny = (q >> 31) != 0u; resumed = (q & 0x40000000u) != 0u;
           o = wo; d = wd; id = rcp3(wd);
-          cur = S.rootRef; curInst = 0xFFFFFFFFu; sp = 0; found = false; pend = 0u;
+          cur = S.rootRef; curInst = 0xFFFFFFFFu; sp = 0; found = false;
           hitPrim = 0xFFFFFFFFu; hitInst = 0xFFFFFFFFu; hitU = 0.0f; hitV = 0.0f;
           if (resumed) {                                                    // pick the traversal up where the last pass left it
             const uint* r = suspIn + __float_as_uint(hitT);
             cur = r[0 * SM]; sp = (int)r[1 * SM]; curInst = r[2 * SM];
             hitT = __uint_as_float(r[3 * SM]); hitU = __uint_as_float(r[4 * SM]); hitV = __uint_as_float(r[5 * SM]);
-            hitPrim = r[6 * SM]; hitInst = r[7 * SM]; found = r[8 * SM] != 0u; pend = r[9 * SM];
+            hitPrim = r[6 * SM]; hitInst = r[7 * SM]; found = r[8 * SM] != 0u;
             for (int k = 0; k < sp; k++) { const uint v = r[(WF_SUSP_WORDS + k) * SM]; if (DEEP) stkPush(stk, k, v); else stk.lds[k * 256] = v; }
             if (FLAT) curInst = 0xFFFFFFFFu;                                 // the object-space ray is rebuilt at the next triangle
             else if (curInst != 0xFFFFFFFFu) {
@@ -366,10 +362,6 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
     if (has) {
       while (true) {
         if (STATS) trips++;
-        // Speculative while-while (flat layout): a lane that reaches a leaf postpones it (one slot) and keeps walking; it only idles
-        // once it holds a postponed leaf AND stands on another one. Nodes may be visited that the postponed leaf's hit would have
-        // culled; the result (min over (t, inst, prim), or "any") does not depend on the order.
-        if (FLAT && HPT_WF_SPECULATE && (cur & REF_LEAF) != 0u && cur != REF_NONE && pend == 0u) { pend = cur; if (sp > 0) HPT_POP(); else cur = REF_NONE; }
         while ((cur & REF_LEAF) == 0u) {
           const float4* np = (const float4*)(S.nodes + cur);
           const float4 q0 = np[0], q1 = np[1], q2 = np[2];
@@ -386,13 +378,11 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
           else if (h1) cur = q3.y;
           else if (sp > 0) HPT_POP();
           else cur = REF_NONE;
-          if (FLAT && HPT_WF_SPECULATE && (cur & REF_LEAF) != 0u && cur != REF_NONE && pend == 0u) { pend = cur; if (sp > 0) HPT_POP(); else cur = REF_NONE; }
           // voted exit: when only a few lanes are still walking inner nodes, the lanes that already hold a leaf are served first
           if (S.nodeMin != 0u && (uint)__popcll(__ballot((cur & REF_LEAF) == 0u)) < S.nodeMin) break;
         }
         WSTAMP(1);
-        const bool usePend = FLAT && HPT_WF_SPECULATE && pend != 0u;
-        const uint leaf = usePend ? pend : cur;
+        const uint leaf = cur;
         bool done = (leaf == REF_NONE);
         if (!done && (leaf & REF_LEAF) != 0u) {
           const uint cnt = (leaf >> 28) & 7u;
@@ -413,7 +403,6 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
               (void)triangleTest(a, b, c, o, d, 0.0f, inst, hitT, hitPrim, hitInst, hitU, hitV, found);
             }
             if (isAny && found) done = true;
-            else if (usePend) { pend = 0u; done = (cur == REF_NONE); }           // the walk position (cur, stack) is untouched
             else if (sp > 0) HPT_POP(); else done = true;
           } else if (cnt == 0u) {
             const uint inst = cur & 0x0FFFFFFFu;
@@ -453,7 +442,7 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
         uint* r = suspOut + rec;
         r[0 * SM] = cur; r[1 * SM] = (uint)sp; r[2 * SM] = curInst;
         r[3 * SM] = __float_as_uint(hitT); r[4 * SM] = __float_as_uint(hitU); r[5 * SM] = __float_as_uint(hitV);
-        r[6 * SM] = hitPrim; r[7 * SM] = hitInst; r[8 * SM] = found ? 1u : 0u; r[9 * SM] = pend;
+        r[6 * SM] = hitPrim; r[7 * SM] = hitInst; r[8 * SM] = found ? 1u : 0u;
         for (int k = 0; k < sp; k++) r[(WF_SUSP_WORDS + k) * SM] = DEEP ? stkPop(stk, k) : stk.lds[k * 256];
         atomicOr(&P.inflight[slot], isAny ? 2u : 1u);
         has = false;

@@ -444,12 +444,17 @@ static bool lean_materials(const MaterialRec* m, size_t n)
   for (size_t i = 0; i < n; i++) if (m[i].mtype != MAT_TYPE_GLTF && m[i].mtype != MAT_TYPE_LIGHT_SOURCE) return false;
   return true;
 }
-static int check_materials(hpt_ctx* c, const MaterialRec* m, size_t n, size_t numTex)
+static int check_materials(hpt_ctx* c, const MaterialRec* m, size_t n, size_t numTex, size_t numMats)
 {
   for (size_t i = 0; i < n; i++) {
     const uint t = m[i].mtype;
+    if (t == MAT_TYPE_BLEND) {
+      if (m[i].datai[0] >= numMats || m[i].datai[1] >= numMats) return c->fail(HPT_ERR_ARG, "blend material refers to a material that does not exist");
+      if (m[i].texid[0] >= numTex) return c->fail(HPT_ERR_ARG, "material refers to a texture that does not exist");
+      continue;
+    }
     if (t != MAT_TYPE_GLTF && t != MAT_TYPE_GLASS && t != MAT_TYPE_CONDUCTOR && t != MAT_TYPE_DIFFUSE && t != MAT_TYPE_DIELECTRIC && t != MAT_TYPE_LIGHT_SOURCE)
-      return c->fail(HPT_ERR_UNSUPPORTED, "material type " + std::to_string(t) + " (glass / plastic / blend / thin film) is outside the hot path's scope");
+      return c->fail(HPT_ERR_UNSUPPORTED, "material type " + std::to_string(t) + " (plastic / thin film) is outside the hot path's scope");
     if (m[i].texid[1] != 0xFFFFFFFFu) return c->fail(HPT_ERR_UNSUPPORTED, "normal-map bump is outside the hot path's scope");
     if (m[i].texid[0] >= numTex) return c->fail(HPT_ERR_ARG, "material refers to a texture that does not exist");
     if ((m[i].cflags & FLAG_FOUR_TEXTURES) && (m[i].texid[2] >= numTex || m[i].texid[3] >= numTex)) return c->fail(HPT_ERR_ARG, "material refers to a texture that does not exist");
@@ -472,7 +477,7 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
   (void)hipSetDevice(c->device);
   const double t0 = now_ms();
   if (d->numTextures == 0 || !d->textures) return c->fail(HPT_ERR_ARG, "m_textures must at least hold the white dummy texture");
-  int rc = check_materials(c, (const MaterialRec*)d->materials, d->numMaterials, d->numTextures); if (rc) return rc;
+  int rc = check_materials(c, (const MaterialRec*)d->materials, d->numMaterials, d->numTextures, d->numMaterials); if (rc) return rc;
   c->leanMaterials = lean_materials((const MaterialRec*)d->materials, d->numMaterials);
   rc = check_lights(c, (const LightRec*)d->lights, d->numLights, d->numTextures); if (rc) return rc;
 
@@ -563,7 +568,7 @@ extern "C" int hpt_update_materials(hpt_ctx* c, size_t first, size_t count, cons
 {
   if (!c || !mats) return HPT_ERR_ARG;
   if (first + count > c->dMaterials.n) return c->fail(HPT_ERR_ARG, "Update_m_materials: range out of bounds");
-  int rc = check_materials(c, (const MaterialRec*)mats, count, c->hTextures.size()); if (rc) return rc;
+  int rc = check_materials(c, (const MaterialRec*)mats, count, c->hTextures.size(), c->dMaterials.n); if (rc) return rc;
   if (!lean_materials((const MaterialRec*)mats, count)) c->leanMaterials = false;      // (an update can only widen the set of BSDFs in use)
   (void)hipSetDevice(c->device);
   HIPCHK(c, hipMemcpy(c->dMaterials.p + first, mats, count * sizeof(MaterialRec), hipMemcpyHostToDevice));

@@ -60,6 +60,47 @@ HPT_DEV void cameraRay(const DevScene& S, uint x, uint y, V4 pixelOffsets, V3& r
 // Shades the vertex a closest-hit query returned for one path.  All path registers are passed by reference and the
 // function is always inlined, so both callers keep them in VGPRs.  Returns true when the path continues (didBounce).
 // A miss only sets the OUT_OF_SCENE flags.  The caller traces the shadow ray (if wantShadow) and adds `contrib`.
+// ---- blend materials (integrator_pt_mat.cpp:23-77, 123-130, 316-333, 511-527); only in the non-LEAN kernels ---------------------------------
+// texture colour and the "four scalar parameters" of a leaf material (:139-167)
+HPT_DEV void leafTextures(const DevScene& S, const MaterialRec& m, V2 uv, V3& tex3, V3& four)
+{
+  const V4 tc = texSample(S.textures, m.texid[0], mulRows2x4(m.row0[0], m.row1[0], uv));
+  tex3 = v3(tc.x, tc.y, tc.z); four = v3(1, 1, 1);
+  if ((m.cflags & FLAG_FOUR_TEXTURES) != 0) {
+    const V4 c2 = texSample(S.textures, m.texid[2], mulRows2x4(m.row0[2], m.row1[2], uv));
+    const V4 c3 = texSample(S.textures, m.texid[3], mulRows2x4(m.row0[3], m.row1[3], uv));
+    four = ((m.cflags & FLAG_PACK_FOUR_PARAMS_IN_TEXTURE) != 0) ? v3(c2.x, c2.y, c2.z) : v3(c2.x, c3.x, 1.0f);
+  }
+}
+// MaterialEval of a blend tree: a stack of (material id, weight) pairs, BLEND_STACK_SIZE deep, in the reference's visiting order
+HPT_DEV void blendTreeEval(const DevScene& S, uint rootId, V2 uv, V3 l, V3 v, V3 n, BsdfE& res)
+{
+  uint stackId[BLEND_STACK_SIZE]; float stackW[BLEND_STACK_SIZE];
+  uint curId = rootId; float curW = 1.0f;
+  stackId[0] = curId; stackW[0] = curW;
+  int top = 0; bool needPop = false;
+  do {
+    if (needPop) { top--; const int t = top > 0 ? top : 0; curId = stackId[t]; curW = stackW[t]; } else needPop = true;
+    const MaterialRec& m = S.materials[curId];
+    V3 tex3, four; leafTextures(S, m, uv, tex3, four);
+    BsdfE cv; cv.val = v3(0, 0, 0); cv.pdf = 0.0f; cv.dval = v3(0, 0, 0);
+    const uint t = m.mtype;
+    if (t == MAT_TYPE_GLTF) { gltfEval(m, l, v, n, ld3(m.colors[GLTF_COLOR_BASE]) * tex3, four, cv); res.val = res.val + cv.val * curW; res.pdf += cv.pdf * curW; }
+    else if (t == MAT_TYPE_CONDUCTOR) {
+      if (!(smax(m.data[1], m.data[0]) < 1e-3f)) conductorRoughEval(m, m.data[2], m.data[3], l, v, n, tex3, cv);
+      res.val = res.val + cv.val * curW; res.pdf += cv.pdf * curW;
+    }
+    else if (t == MAT_TYPE_DIFFUSE) { diffuseEval(m, ld3(m.colors[0]) * tex3, l, v, n, cv); res.val = res.val + cv.val * curW; res.pdf += cv.pdf * curW; }
+    else if (t == MAT_TYPE_BLEND) {                          // BlendEval: first child next (no pop), second child waits on the stack
+      const float w = m.data[0] * tex3.x;
+      const uint id1 = m.datai[0], id2 = m.datai[1];
+      const float w1 = curW * (1.0f - w), w2 = curW * w;
+      curId = id1; curW = w1; needPop = false;
+      if (top + 1 <= (int)BLEND_STACK_SIZE) { stackId[top] = id2; stackW[top] = w2; top++; }
+    }                                                        // glass / dielectric leaves add zero
+  } while (top > 0);
+}
+
 // LEAN: the scene holds gltf and emissive materials only (the host checked): the conductor / diffuse / glass / dielectric branches are
 // compiled out - fewer live registers and spills in the kernels every benchmark scene runs (the DR variant is lean by definition).
 template <bool DR, bool NAIVE, bool LEAN = false>
@@ -140,6 +181,7 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
             if (!(smax(m.data[1], m.data[0]) < 1e-3f)) conductorRoughEval(m, m.data[2], m.data[3], shadowRayDir, vdir, hitNorm, tex3, bv);
           }
           else if (!(DR || LEAN) && mtype == MAT_TYPE_DIFFUSE) diffuseEval(m, ld3(m.colors[0]) * tex3, shadowRayDir, vdir, hitNorm, bv);
+          else if (!(DR || LEAN) && mtype == MAT_TYPE_BLEND) blendTreeEval(S, matId, uv, shadowRayDir, vdir, hitNorm, bv);
           const float cosThetaOut = smax(dot(shadowRayDir, hitNorm), 0.0f);
           float lgtPdfW = (1.0f / float(nLights)) * lightEvalPDF(L, shadowRayPos, shadowRayDir, ls.pos, ls.norm, ls.pdf);
           float misWeight = (S.integratorType == INTEGRATOR_MIS_PT) ? misWeightHeuristic(lgtPdfW, bv.pdf) : 1.0f;
@@ -182,18 +224,37 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
       if (DR) tailR = lightInt * misWeight;
       flags |= (RAY_FLAG_IS_DEAD | RAY_FLAG_HIT_LIGHT);
     } else {
-      BsdfS ms; ms.val = v3(0, 0, 0); ms.pdf = 1.0f; ms.dir = v3(0, 1, 0); ms.ior = 1.0f; ms.flags = flags; ms.dval = v3(0, 0, 0);
-      const V4 rands = rng_float4(gen);                                // GetRandomNumbersMats: drawn for every material type (integrator_pt_mat.cpp:147)
-      if (mtype == MAT_TYPE_GLTF) gltfSampleAndEval(m, rands, vdir, hitNorm, baseCol * tex3, four, ms);
-      else if (!(DR || LEAN) && mtype == MAT_TYPE_CONDUCTOR) {
-        if (smax(m.data[1], m.data[0]) < 1e-3f) conductorSmoothSampleAndEval(m, m.data[2], m.data[3], vdir, hitNorm, ms);
-        else                                    conductorRoughSampleAndEval(m, m.data[2], m.data[3], rands, vdir, hitNorm, tex3, ms);
+      // The reference keeps the hit's material id in the low 24 bits of the ray flags (packMatId, integrator_pt.h:340-341, set at
+      // integrator_pt.cpp:307) and hands that word to MaterialSampleAndEval as the initial sample flags (integrator_pt_mat.cpp:118).
+      // The glass and dielectric samplers OR their events into it, so RAY_EVENT_S (1) / RAY_EVENT_T (8) tested at integrator_pt.cpp:514,534
+      // also read bits 0 and 3 of the material id.  Restated here bit for bit: the event bits of the previous bounce do not survive.
+      BsdfS ms; ms.val = v3(0, 0, 0); ms.pdf = 1.0f; ms.dir = v3(0, 1, 0); ms.ior = 1.0f; ms.flags = (flags & 0xFF000000u) | matId; ms.dval = v3(0, 0, 0);
+      // blend descent (BlendSampleAndEval): one generator step per layer BEFORE the float4; the leaf then overwrites val / pdf as in the
+      // reference, whose leaf samplers assign them
+      const MaterialRec* lm = &m; uint lt = mtype; V3 ltex3 = tex3, lfour = four;
+      if (!(DR || LEAN) && mtype == MAT_TYPE_BLEND) {
+        while (lt == MAT_TYPE_BLEND) {
+          const V4 wd = texSample(S.textures, lm->texid[0], mulRows2x4(lm->row0[0], lm->row1[0], uv));
+          const float weight = lm->data[0] * wd.x;
+          const float select = rng_float1(gen);                        // GetRandomNumbersMatB (integrator_pt.cpp:37)
+          if (select < weight) { ms.pdf *= weight; ms.val = ms.val * weight; lm = &S.materials[lm->datai[1]]; }
+          else                 { ms.pdf *= 1.0f - weight; ms.val = ms.val * (1.0f - weight); lm = &S.materials[lm->datai[0]]; }
+          lt = lm->mtype;
+        }
+        leafTextures(S, *lm, uv, ltex3, lfour);
       }
-      else if (!(DR || LEAN) && mtype == MAT_TYPE_DIFFUSE) diffuseSampleAndEval(m, ld3(m.colors[0]) * tex3, rands, vdir, hitNorm, ms);
-      else if (!(DR || LEAN) && mtype == MAT_TYPE_GLASS) glassSampleAndEval(m, rands, vdir, hitNorm, ms, misIor);
-      else if (!(DR || LEAN) && mtype == MAT_TYPE_DIELECTRIC) {
-        dielectricSmoothSampleAndEval(m, m.data[1], misIor, rands, vdir, hitNorm, ms);
-        ms.flags |= (m.spdid[0] < 0xFFFFFFFFu) ? RAY_FLAG_WAVES_DIVERGED : 0u;
+      const MaterialRec& ml = *lm;
+      const V4 rands = rng_float4(gen);                                // GetRandomNumbersMats: drawn for every material type (integrator_pt_mat.cpp:147)
+      if (lt == MAT_TYPE_GLTF) gltfSampleAndEval(ml, rands, vdir, hitNorm, ld3(ml.colors[GLTF_COLOR_BASE]) * ltex3, lfour, ms);
+      else if (!(DR || LEAN) && lt == MAT_TYPE_CONDUCTOR) {
+        if (smax(ml.data[1], ml.data[0]) < 1e-3f) conductorSmoothSampleAndEval(ml, ml.data[2], ml.data[3], vdir, hitNorm, ms);
+        else                                      conductorRoughSampleAndEval(ml, ml.data[2], ml.data[3], rands, vdir, hitNorm, ltex3, ms);
+      }
+      else if (!(DR || LEAN) && lt == MAT_TYPE_DIFFUSE) diffuseSampleAndEval(ml, ld3(ml.colors[0]) * ltex3, rands, vdir, hitNorm, ms);
+      else if (!(DR || LEAN) && lt == MAT_TYPE_GLASS) glassSampleAndEval(ml, rands, vdir, hitNorm, ms, misIor);
+      else if (!(DR || LEAN) && lt == MAT_TYPE_DIELECTRIC) {
+        dielectricSmoothSampleAndEval(ml, ml.data[1], misIor, rands, vdir, hitNorm, ms);
+        ms.flags |= (ml.spdid[0] < 0xFFFFFFFFu) ? RAY_FLAG_WAVES_DIVERGED : 0u;
         misIor = ms.ior;
       }
       const float invPdf = 1.0f / smax(ms.pdf, 1e-20f);

@@ -50,6 +50,7 @@ assert LIGHT_DTYPE.itemsize == 320
 GLTF_COMPONENT_LAMBERT, GLTF_COMPONENT_COAT, GLTF_COMPONENT_METAL, GLTF_COMPONENT_ORENNAYAR = 1, 2, 4, 16
 MAT_TYPE_GLTF, MAT_TYPE_CONDUCTOR, MAT_TYPE_DIFFUSE, MAT_TYPE_DIELECTRIC = 1, 3, 4, 7
 MAT_TYPE_GLASS = 2
+MAT_TYPE_BLEND = 6
 MAT_TYPE_LIGHT_SOURCE = 0xEFFFFFFF
 # include/cmaterial.h:67-147 (slots in Material::colors / Material::data)
 GLTF_COLOR_BASE, GLTF_COLOR_COAT, GLTF_COLOR_METAL = 0, 1, 2
@@ -272,6 +273,17 @@ def material_glass(color_reflect=(1.0, 1.0, 1.0), color_transp=(1.0, 1.0, 1.0), 
     m["colors"][0] = (*color_reflect[:3], 0.0)
     m["colors"][1] = (*color_transp[:3], 0.0)
     m["data"][2] = ior
+    return m
+
+
+def material_blend(mat_id1: int, mat_id2: int, weight: float, mask_tex=0) -> np.ndarray:
+    """MAT_TYPE_BLEND (include/cmaterial.h:43,155; integrator_pt_mat.cpp:23-77): picks child 2 with probability weight * mask.x, child 1
+    otherwise; children are material ids (they may be blends themselves, up to BLEND_STACK_SIZE = 4 levels)."""
+    m = _blank_material()
+    m["mtype"] = MAT_TYPE_BLEND
+    m["data"][0] = weight
+    m["datai"][0], m["datai"][1] = mat_id1, mat_id2
+    m["texid"][0] = mask_tex
     return m
 
 

@@ -293,7 +293,11 @@ def random_scene(seed: int, width=48, height=32) -> S.SceneData:
     M.append(S.material_diffuse((0.5, 0.5, 0.55), 0.3))
     nobj = int(r.randint(3, 8))
     for _ in range(nobj):
-        M.append(rand_material())
+        if len(M) >= 4 and r.uniform() < 0.25:                        # a blend of two earlier materials (possibly blends themselves), sometimes masked
+            a, b = int(r.randint(2, len(M))), int(r.randint(2, len(M)))
+            M.append(S.material_blend(a, b, corner(), tex if r.uniform() < 0.5 else 0))
+        else:
+            M.append(rand_material())
     parts = [(*_quad((-8, 0, 6), (16, 0, 0), (0, 0, -14), 2, 2, 3.0), 0), (*_quad((-8, 0, -6), (16, 0, 0), (0, 6, 0)), 1)]
     sc.add_instance(sc.add_mesh(*_merge(parts)), np.eye(4))
     sp = _sphere_mesh(int(r.randint(1, 3)))

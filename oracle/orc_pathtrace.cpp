@@ -180,8 +180,18 @@ struct Ctx
   {
     BsdfSample res;
     res.val = mk4(0, 0, 0, 0); res.pdf = 1.0f; res.dir = mk3(0, 1, 0); res.ior = 1.0f; res.flags = a_currRayFlags;
-    const Material& m = sc.materials[a_materialId];
-    const uint mtype = m.mtype;                         // blend descent / bump mapping: out of scope
+    // blend descent (BlendSampleAndEval, integrator_pt_mat.cpp:23-54, loop :123-130): one generator step per layer, BEFORE the float4
+    uint currMatId = a_materialId;
+    while (sc.materials[currMatId].mtype == MAT_TYPE_BLEND) {
+      const Material& bm = sc.materials[currMatId];
+      const f4 weightDat = sc.tex_sample(bm.texid[0], mulRows2x4(bm.row0[0], bm.row1[0], tc));
+      const float weight = bm.data[BLEND_WEIGHT] * weightDat.x;
+      const float select = rndFloat1(a_gen);           // GetRandomNumbersMatB (integrator_pt.cpp:37)
+      if (select < weight) { res.pdf *= weight; res.val = res.val * weight; currMatId = bm.datai[1]; }
+      else                 { res.pdf *= 1.0f - weight; res.val = res.val * (1.0f - weight); currMatId = bm.datai[0]; }
+    }
+    const Material& m = sc.materials[currMatId];
+    const uint mtype = m.mtype;                         // bump mapping: out of scope
     const f3 shadeNormal = n;
     const f2 texCoordT = mulRows2x4(m.row0[0], m.row1[0], tc);
     const f4 texColor = sc.tex_sample(m.texid[0], texCoordT);
@@ -224,42 +234,57 @@ struct Ctx
   BsdfEval MaterialEval(uint a_materialId, f3 l, f3 v, f3 n, f3 tan, f2 tc) const   // :308-528
   {
     BsdfEval res; res.val = mk4(0, 0, 0, 0); res.pdf = 0.0f;
-    const Material& m = sc.materials[a_materialId];
-    const f3 shadeNormal = n;
-    const float weight = 1.0f, bumpCosMult = 1.0f;
-    const f2 texCoordT = mulRows2x4(m.row0[0], m.row1[0], tc);
-    const f4 texColor = sc.tex_sample(m.texid[0], texCoordT);
-    const f4 four = fourScalarMatParams(m, tc);
-    BsdfEval currVal; currVal.val = mk4(0, 0, 0, 0); currVal.pdf = 0.0f;
-    switch (m.mtype) {
-      case MAT_TYPE_GLTF: {
-        const f4 color = m.colors[GLTF_COLOR_BASE] * texColor;
-        BsdfEvalT<f4> r; r.val = currVal.val; r.pdf = currVal.pdf;
-        gltfEval<f4>(m, l, v, shadeNormal, tc, color, four, &r);
-        res.val = res.val + r.val * weight * bumpCosMult;
-        res.pdf += r.pdf * weight;
-      } break;
-      case MAT_TYPE_CONDUCTOR: {
-        const f3 alphaTex = xyz(texColor);
-        const f2 alpha = mk2(m.data[CONDUCTOR_ROUGH_V], m.data[CONDUCTOR_ROUGH_U]);
-        if (!trEffectivelySmooth(alpha)) {
-          const f4 etaSpec = splat4(m.data[CONDUCTOR_ETA]), kSpec = splat4(m.data[CONDUCTOR_K]);
-          conductorRoughEval(m, etaSpec, kSpec, l, v, shadeNormal, tc, alphaTex, &currVal);
-        }
-        res.val = res.val + currVal.val * weight * bumpCosMult;
-        res.pdf += currVal.pdf * weight;
-      } break;
-      case MAT_TYPE_DIFFUSE: {
-        f4 reflSpec = m.colors[DIFFUSE_COLOR];
-        reflSpec = reflSpec * texColor;
-        diffuseEval(m, reflSpec, l, v, shadeNormal, tc, &currVal);
-        res.val = res.val + currVal.val * weight * bumpCosMult;
-        res.pdf += currVal.pdf * weight;
-      } break;
-      case MAT_TYPE_GLASS:                                                          // cmat_glass.h:281-287: never lit by shadow rays
-      case MAT_TYPE_DIELECTRIC: res.val = splat4(0.0f); res.pdf = 0.0f; break;   // cmat_dielectric.h:59-63
-      default: break;
-    }
+    // blend tree walk (:316-333, 511-527): a stack of (material id, weight) pairs, BLEND_STACK_SIZE deep
+    struct IdW { uint id; float weight; };
+    IdW currMat = { a_materialId, 1.0f };
+    IdW stack[BLEND_STACK_SIZE]; stack[0] = currMat;
+    int top = 0; bool needPop = false;
+    do {
+      if (needPop) { top--; currMat = stack[std::max(top, 0)]; } else needPop = true;
+      const Material& m = sc.materials[currMat.id];
+      const f3 shadeNormal = n;
+      const float weight = currMat.weight, bumpCosMult = 1.0f;
+      const f2 texCoordT = mulRows2x4(m.row0[0], m.row1[0], tc);
+      const f4 texColor = sc.tex_sample(m.texid[0], texCoordT);
+      const f4 four = fourScalarMatParams(m, tc);
+      BsdfEval currVal; currVal.val = mk4(0, 0, 0, 0); currVal.pdf = 0.0f;
+      switch (m.mtype) {
+        case MAT_TYPE_GLTF: {
+          const f4 color = m.colors[GLTF_COLOR_BASE] * texColor;
+          BsdfEvalT<f4> r; r.val = currVal.val; r.pdf = currVal.pdf;
+          gltfEval<f4>(m, l, v, shadeNormal, tc, color, four, &r);
+          res.val = res.val + r.val * weight * bumpCosMult;
+          res.pdf += r.pdf * weight;
+        } break;
+        case MAT_TYPE_CONDUCTOR: {
+          const f3 alphaTex = xyz(texColor);
+          const f2 alpha = mk2(m.data[CONDUCTOR_ROUGH_V], m.data[CONDUCTOR_ROUGH_U]);
+          if (!trEffectivelySmooth(alpha)) {
+            const f4 etaSpec = splat4(m.data[CONDUCTOR_ETA]), kSpec = splat4(m.data[CONDUCTOR_K]);
+            conductorRoughEval(m, etaSpec, kSpec, l, v, shadeNormal, tc, alphaTex, &currVal);
+          }
+          res.val = res.val + currVal.val * weight * bumpCosMult;
+          res.pdf += currVal.pdf * weight;
+        } break;
+        case MAT_TYPE_DIFFUSE: {
+          f4 reflSpec = m.colors[DIFFUSE_COLOR];
+          reflSpec = reflSpec * texColor;
+          diffuseEval(m, reflSpec, l, v, shadeNormal, tc, &currVal);
+          res.val = res.val + currVal.val * weight * bumpCosMult;
+          res.pdf += currVal.pdf * weight;
+        } break;
+        case MAT_TYPE_GLASS:                                                          // cmat_glass.h:281-287: adds zero
+        case MAT_TYPE_DIELECTRIC: break;                                              // cmat_dielectric.h:59-63: val and pdf are always zero
+        case MAT_TYPE_BLEND: {                                                        // BlendEval (:56-77) + :511-522
+          const float w = m.data[BLEND_WEIGHT] * texColor.x;
+          const IdW p1 = { m.datai[0], currMat.weight * (1.0f - w) }, p2 = { m.datai[1], currMat.weight * w };
+          currMat = p1;
+          needPop = false;                                                            // the first child is evaluated on the next trip, without a pop
+          if (top + 1 <= (int)BLEND_STACK_SIZE) { stack[top] = p2; top++; }           // the second one waits on the stack
+        } break;
+        default: break;
+      }
+    } while (top > 0);
     return res;
   }
 

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <array>
 #include <map>
 #include <sstream>
 #include <string>
@@ -326,24 +327,61 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
     if (p.size() < 3 || l.size() < 3 || u.size() < 3) { err = "xml: camera vectors"; return false; }
     for (int k = 0; k < 3; k++) { sc.camPos[k] = p[k]; sc.camLookAt[k] = l[k]; sc.camUp[k] = u[k]; } }
 
-  // textures are loaded on first use by a material (integrator_pt_scene_tex.cpp:105-144)
-  std::map<int, const XmlNode*> texNodes; std::map<int, uint32_t> texCache;
-  if (const XmlNode* lib = root.child("textures_lib")) for (const XmlNode* t : lib->all("texture")) texNodes[std::atoi(t->get("id").c_str())] = t;
-  auto textureFromColorNode = [&](const XmlNode* node, uint32_t& outId) -> bool {
+  // textures: LoadSceneTexturesInfo (integrator_pt_scene.cpp:330-355) keeps the nodes with a size, indexed by position; a <texture id=..> is
+  // loaded on first use, one table entry per distinct (id, address modes, filter) - the HydraSampler equality of integrator_pt.h:75-83
+  // (rows and gamma are not part of the key) - LoadTextureFromNode, integrator_pt_scene_tex.cpp:105-126
+  struct TexInfo { std::string path; uint32_t w, h, bpp; };
+  std::vector<TexInfo> texInfo;
+  if (const XmlNode* lib = root.child("textures_lib")) for (const XmlNode* t : lib->all("texture")) {
+    const uint32_t w = (uint32_t)std::atoll(t->get("width", "0").c_str()), h = (uint32_t)std::atoll(t->get("height", "0").c_str());
+    if (w == 0 || h == 0) continue;
+    TexInfo ti; ti.path = t->get("loc").empty() ? t->get("path") : folder + "/" + t->get("loc"); ti.w = w; ti.h = h;
+    ti.bpp = (uint32_t)((uint64_t)std::atoll(t->get("bytesize", "0").c_str()) / ((uint64_t)w * h));
+    texInfo.push_back(ti);
+  }
+  std::map<std::array<uint32_t, 5>, uint32_t> texCache;
+  // ReadSamplerFromColorNode (integrator_pt_scene_mat.cpp:32-91) + LoadTextureFromNode: rows of the node's sampler and the table index
+  auto loadTextureFromNode = [&](const XmlNode* node, float* row0, float* row1, uint32_t& outId) -> bool {
     outId = 0;
+    row0[0] = 1.0f; row0[1] = row0[2] = row0[3] = 0.0f; row1[0] = 0.0f; row1[1] = 1.0f; row1[2] = row1[3] = 0.0f;
     const XmlNode* tn = node ? node->child("texture") : nullptr;
     if (!tn) return true;
-    const int xid = std::atoi(tn->get("id").c_str());
-    auto it = texCache.find(xid); if (it != texCache.end()) { outId = it->second; return true; }
-    if (!texNodes.count(xid)) { err = "xml: texture id not in textures_lib"; return false; }
-    std::vector<uint8_t> img; const std::string p = folder + "/" + texNodes[xid]->get("loc");
-    if (!readFile(p, img) || img.size() < 8) { err = "cannot read " + p; return false; }
-    uint32_t w, h; std::memcpy(&w, img.data(), 4); std::memcpy(&h, img.data() + 4, 4);          // image4ub: {w, h} then RGBA8 (integrator_pt_scene_tex.cpp:53-93)
-    if (img.size() < 8 + (size_t)w * h * 4) { err = "image4ub truncated: " + p; return false; }
-    LoadedTexture t; t.width = w; t.height = h; t.format = 0; t.flags = 1; t.addressU = t.addressV = 0; t.filter = 1;
-    t.bytes.assign(img.begin() + 8, img.begin() + 8 + (size_t)w * h * 4);
+    bool bad = false;
+    auto addr = [&](const char* name, uint32_t dflt) -> uint32_t {
+      if (!tn->has(name)) return dflt;
+      const std::string v = tn->get(name);
+      if (v == "clamp") return 2u;
+      if (v == "mirror" || v == "border" || v == "mirror_once") { bad = true; return 0u; }
+      return 0u;                                                              // "wrap" and anything else
+    };
+    const uint32_t au = addr("addressing_mode_u", 0u), av = addr("addressing_mode_v", 0u), aw = addr("addressing_mode_w", av);
+    if (bad) { err = "xml: texture addressing modes other than wrap / clamp are outside the path"; return false; }
+    uint32_t filt = 1u;
+    const std::string fm = tn->get("filter");
+    if (fm == "point" || fm == "nearest") filt = 0u;
+    else if (fm == "cubic" || fm == "bicubic") { err = "xml: bicubic texture filtering is outside the path"; return false; }
+    { const auto mv = parseFloats(tn->get("matrix")); for (size_t i = 0; i < mv.size() && i < 8; i++) (i < 4 ? row0 : row1)[i % 4] = (float)mv[i]; }
+    const bool disableGamma = tn->has("input_gamma") && (int)std::atof(tn->get("input_gamma").c_str()) == 1;
+    const uint32_t xid = (uint32_t)std::atoi(tn->get("id").c_str());
+    const std::array<uint32_t, 5> key = { xid, au, av, aw, filt };
+    auto it = texCache.find(key); if (it != texCache.end()) { outId = it->second; return true; }
+    if (xid >= texInfo.size()) { err = "xml: texture id not in textures_lib"; return false; }
+    const TexInfo& ti = texInfo[xid];
+    if (ti.path.find(".image") == std::string::npos) { err = "texture file '" + ti.path + "': only the Hydra .image4ub / .image4f containers are read here"; return false; }
+    std::vector<uint8_t> img;
+    if (!readFile(ti.path, img) || img.size() < 8) { err = "cannot read " + ti.path; return false; }
+    uint32_t w, h; std::memcpy(&w, img.data(), 4); std::memcpy(&h, img.data() + 4, 4);          // {w, h} then the texels (integrator_pt_scene_tex.cpp:53-93)
+    LoadedTexture t; t.addressU = au; t.addressV = av; t.filter = filt;
+    if (w == 0 || h == 0) {                                                  // white float dummy (:67-73)
+      t.width = t.height = 1; t.format = 1; t.flags = 0; const float one[4] = {1, 1, 1, 1}; t.bytes.assign((const uint8_t*)one, (const uint8_t*)one + 16);
+    } else {
+      const size_t texel = ti.bpp == 16 ? 16 : 4;
+      if (img.size() < 8 + (size_t)w * h * texel) { err = "image truncated: " + ti.path; return false; }
+      t.width = w; t.height = h; t.format = ti.bpp == 16 ? 1u : 0u; t.flags = (ti.bpp != 16 && !disableGamma) ? 1u : 0u;
+      t.bytes.assign(img.begin() + 8, img.begin() + 8 + (size_t)w * h * texel);
+    }
     sc.textures.push_back(std::move(t));
-    outId = texCache[xid] = (uint32_t)sc.textures.size() - 1;
+    outId = texCache[key] = (uint32_t)sc.textures.size() - 1;
     return true;
   };
 
@@ -424,8 +462,100 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
     float acc = 0.0f; for (float c : cs) acc = acc * invEta + c;
     return eta < 1.0f ? approx1 : acc;
   };
+  // SetMiPlastic (mi_materials.cpp:455-469)
+  auto setMiPlastic = [&](Material& mat, float intIor, float extIor, const float* diffuse, const float* specular) {
+    for (int k = 0; k < 4; k++) { mat.colors[0][k] = diffuse[k]; mat.colors[1][k] = specular[k]; }
+    const float eta = intIor / extIor;
+    mat.data[5] = eta; mat.data[0] = fdr((float)(1.0 / (double)eta)); mat.data[1] = fdr(eta);
+    const double dMean = 0.3333333 * ((double)diffuse[0] + diffuse[1] + diffuse[2]), sMean = 0.3333333 * ((double)specular[0] + specular[1] + specular[2]);
+    mat.data[2] = (float)(sMean / (dMean + sMean));
+  };
+  auto attrFloat = [](const XmlNode* n) -> float { return (n && n->has("val")) ? (float)std::atof(n->get("val").c_str()) : 0.0f; };   // as_float of a missing node is 0
+  auto zeroMaterial = [](Material& mat) { std::memset(&mat, 0, sizeof(mat)); for (int k = 0; k < 4; k++) mat.spdid[k] = 0xFFFFFFFFu; };   // Material mat = {}; spectra: none (RGB mode)
+  // the typed material nodes of LoadSceneMaterials (integrator_pt_scene.cpp:500-570); false with err set on failure, `known` false for other types
+  auto loadTypedMaterial = [&](const XmlNode* mn, const std::string& type, Material& mat, bool& known) -> bool {
+    known = true;
+    zeroMaterial(mat);
+    const float one4[4] = {1, 1, 1, 1};
+    if (type == "gltf") {                                                     // ConvertGLTFMaterial (integrator_pt_scene_mat.cpp:176-278)
+      mat.mtype = 1; uint32_t cflags = 1u | 2u; mat.data[7] = 1.0f;
+      for (int k = 0; k < 4; k++) { mat.row0[k][0] = 1.0f; mat.row1[k][1] = 1.0f; }
+      float ior = 1.5f, gloss = 1.0f, metal = 0.0f, base[4] = {1, 1, 1, 1};
+      if (const XmlNode* cn = mn->child("color")) { color4(cn, base); if (cn->child("texture") && !loadTextureFromNode(cn, mat.row0[0], mat.row1[0], mat.texid[0])) return false; }
+      const XmlNode* gn = mn->child("glossiness"); const XmlNode* rn = mn->child("roughness");
+      if (gn || rn) {
+        const XmlNode* n = gn ? gn : rn;
+        gloss = val1f(n);
+        if (!gn) cflags |= 1024u;                                             // FLAG_INVERT_GLOSINESS
+        if (n->child("texture")) { if (!loadTextureFromNode(n, mat.row0[2], mat.row1[2], mat.texid[2])) return false; cflags |= 256u; }
+      }
+      if (const XmlNode* m2 = mn->child("metalness")) {
+        metal = val1f(m2);
+        if (m2->child("texture")) { if (!loadTextureFromNode(m2, mat.row0[3], mat.row1[3], mat.texid[3])) return false; cflags |= 256u; }
+      }
+      if (const XmlNode* n = mn->child("fresnel_ior")) ior = val1f(n);
+      if (const XmlNode* n = mn->child("coat")) mat.data[7] = val1f(n);
+      if (const XmlNode* pn = mn->child("glossiness_metalness_coat")) {
+        metal = gloss = val1f(pn); mat.data[7] = gloss;
+        if (pn->child("texture")) { if (!loadTextureFromNode(pn, mat.row0[2], mat.row1[2], mat.texid[2])) return false; cflags |= 256u | 512u; }
+      }
+      mat.cflags = cflags;
+      for (int k = 0; k < 4; k++) mat.colors[2][k] = 1.0f;
+      mat.data[3] = metal; mat.data[4] = gloss;
+      setMiPlastic(mat, ior, 1.0f, base, one4);
+    } else if (type == "rough_conductor") {                                   // LoadRoughConductorMaterial (:452-513), RGB mode
+      for (int k = 0; k < 4; k++) mat.colors[0][k] = 1.0f;
+      mat.mtype = 3; mat.lightId = 0xFFFFFFFFu;
+      float au, av;
+      if (const XmlNode* an = mn->child("alpha")) {
+        au = av = attrFloat(an);
+        if (!loadTextureFromNode(an, mat.row0[0], mat.row1[0], mat.texid[0])) return false;
+        if (mat.texid[0] != 0) au = av = 1.0f;
+      } else { au = attrFloat(mn->child("alpha_u")); av = attrFloat(mn->child("alpha_v")); }
+      mat.data[0] = au; mat.data[1] = av; mat.data[2] = attrFloat(mn->child("eta")); mat.data[3] = attrFloat(mn->child("k"));
+      if (const XmlNode* rc = mn->child("reflectance")) color4(rc, mat.colors[0]);
+    } else if (type == "diffuse") {                                           // LoadDiffuseMaterial (:516-571), RGB mode
+      for (int k = 0; k < 4; k++) mat.colors[0][k] = 1.0f;
+      mat.mtype = 4; mat.lightId = 0xFFFFFFFFu;
+      const XmlNode* bsdf = mn->child("bsdf");
+      if (bsdf && bsdf->get("type") == "oren-nayar") { mat.cflags = 16u; if (const XmlNode* r = mn->child("roughness")) mat.data[0] = val1f(r); }
+      if (const XmlNode* rc = mn->child("reflectance")) { color4(rc, mat.colors[0]); if (!loadTextureFromNode(rc, mat.row0[0], mat.row1[0], mat.texid[0])) return false; }
+    } else if (type == "dielectric") {                                        // LoadDielectricMaterial (:574-616), RGB mode
+      for (int k = 0; k < 4; k++) { mat.colors[0][k] = 1.0f; mat.colors[1][k] = 1.0f; }
+      mat.mtype = 7; mat.lightId = 0xFFFFFFFFu; mat.data[0] = 1.00028f; mat.data[1] = 1.5046f;
+      if (const XmlNode* n = mn->child("int_ior")) mat.data[1] = attrFloat(n);
+      if (const XmlNode* n = mn->child("ext_ior")) mat.data[0] = attrFloat(n);
+      if (const XmlNode* n = mn->child("reflectance")) color4(n, mat.colors[0]);
+      if (const XmlNode* n = mn->child("transmittance")) color4(n, mat.colors[1]);
+    } else if (type == "blend") {                                             // LoadBlendMaterial (:619-647)
+      mat.mtype = 6; mat.data[0] = 1.0f;
+      if (const XmlNode* n = mn->child("bsdf_1")) mat.datai[0] = (uint32_t)std::atoll(n->get("id", "0").c_str());
+      if (const XmlNode* n = mn->child("bsdf_2")) mat.datai[1] = (uint32_t)std::atoll(n->get("id", "0").c_str());
+      if (const XmlNode* wn = mn->child("weight")) { mat.data[0] = val1f(wn); if (!loadTextureFromNode(wn, mat.row0[0], mat.row1[0], mat.texid[0])) return false; }
+    } else known = false;
+    return true;
+  };
   if (const XmlNode* lib = root.child("materials_lib")) for (const XmlNode* mn : lib->all("material")) {
     Material mat; std::memset(&mat, 0, sizeof(mat));
+    const std::string mtypeAttr = mn->get("type");
+    if (mtypeAttr != "hydra_material") {
+      bool known = false;
+      if (!loadTypedMaterial(mn, mtypeAttr, mat, known)) return false;
+      if (!known) { err = "xml: material type '" + mtypeAttr + "' is outside the path (plastic, thin_film: SURVEY.md 2a)"; return false; }
+      for (int k = 0; k < 4; k++) {
+        bool zero = true; for (int j = 0; j < 4; j++) zero = zero && mat.row0[k][j] == 0.0f && mat.row1[k][j] == 0.0f;
+        if (zero) { mat.row0[k][0] = 1.0f; mat.row1[k][1] = 1.0f; }
+      }
+      mat.texid[1] = 0xFFFFFFFFu;
+      const int lid = mn->has("light_id") ? std::atoi(mn->get("light_id").c_str()) : -1;
+      if (lid >= 0 && lid < (int)sc.lights.size()) {
+        for (int k = 0; k < 4; k++) mat.colors[0][k] = sc.lights[(size_t)lid].intensity[k];
+        mat.data[0] = sc.lights[(size_t)lid].mult;
+        sc.lights[(size_t)lid].matId = (uint32_t)sc.materials.size();
+      }
+      sc.materials.push_back(mat);
+      continue;
+    }
     mat.mtype = 1; mat.data[3] = 0.0f; mat.data[7] = 1.0f;                    // MAT_TYPE_GLTF, GLTF_FLOAT_ALPHA, GLTF_FLOAT_REFL_COAT
     for (int k = 0; k < 4; k++) { mat.colors[1][k] = 1.0f; mat.colors[2][k] = 0.0f; }   // GLTF_COLOR_COAT, GLTF_COLOR_METAL
     mat.lightId = 0xFFFFFFFFu;
@@ -436,8 +566,7 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
       const XmlNode* cn = emis ? emis->child("color") : nullptr;
       color4(cn, color);
       isEmission = mn->has("light_id") || len4(color) > 1e-5f;
-      mat.row0[0][0] = 1.0f; mat.row1[0][1] = 1.0f;
-      if (!textureFromColorNode(cn, mat.texid[0])) return false;
+      if (!loadTextureFromNode(cn, mat.row0[0], mat.row1[0], mat.texid[0])) return false;
       for (int k = 0; k < 4; k++) mat.colors[0][k] = color[k];
       mat.lightId = mn->has("light_id") ? (uint32_t)std::atoi(mn->get("light_id").c_str()) : 0xFFFFFFFFu;
       mat.spdid[0] = 0xFFFFFFFFu;
@@ -449,7 +578,7 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
     const XmlNode* dn = diff ? diff->child("color") : nullptr;
     if (dn) {
       color4(dn, color);
-      if (dn->child("texture")) { mat.row0[0][0] = 1.0f; mat.row0[0][1] = mat.row0[0][2] = mat.row0[0][3] = 0.0f; mat.row1[0][0] = 0.0f; mat.row1[0][1] = 1.0f; if (!textureFromColorNode(dn, mat.texid[0])) return false; }
+      if (dn->child("texture")) { if (!loadTextureFromNode(dn, mat.row0[0], mat.row1[0], mat.texid[0])) return false; }
     }
     float reflColor[4] = {0, 0, 0, 0}, reflGloss = 1.0f, fresnelIOR = 1.5f;
     const XmlNode* refl = mn->child("reflectivity");
@@ -529,6 +658,22 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
     }
     sc.triIndices.insert(sc.triIndices.end(), idx, idx + (size_t)nt * 3);
     sc.matIdByPrimId.insert(sc.matIdByPrimId.end(), mats, mats + nt);
+  }
+
+  // remap lists (hydraxml.h:267-276, LoadSceneRemapLists integrator_pt_scene.cpp:909-924): the lists back to back, then one offset per list
+  // and the total size
+  if (const XmlNode* rl = sceneNode->child("remap_lists")) {
+    std::vector<int32_t> flat, offs;
+    for (const XmlNode& nodeRef : rl->children) {
+      const XmlNode* node = &nodeRef;
+      const int n = std::atoi(node->get("size", "0").c_str());
+      const auto vals = parseFloats(node->get("val"));
+      offs.push_back((int32_t)flat.size());
+      for (int i = 0; i < n; i++) flat.push_back(i < (int)vals.size() ? (int32_t)vals[(size_t)i] : 0);
+    }
+    offs.push_back((int32_t)flat.size());
+    sc.allRemapListsSize = (uint32_t)flat.size();
+    sc.allRemapLists = flat; sc.allRemapLists.insert(sc.allRemapLists.end(), offs.begin(), offs.end());
   }
 
   // instances: matrix, m_normMatrices = transpose(inverse4x4(M)) (integrator_pt_scene.cpp:852-885), remap list and light ids

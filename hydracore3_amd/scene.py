@@ -48,6 +48,7 @@ assert LIGHT_DTYPE.itemsize == 320
 
 # include/cmaterial.h:26-46
 GLTF_COMPONENT_LAMBERT, GLTF_COMPONENT_COAT, GLTF_COMPONENT_METAL, GLTF_COMPONENT_ORENNAYAR = 1, 2, 4, 16
+FLAG_FOUR_TEXTURES, FLAG_PACK_FOUR_PARAMS_IN_TEXTURE, FLAG_INVERT_GLOSINESS = 256, 512, 1024
 MAT_TYPE_GLTF, MAT_TYPE_CONDUCTOR, MAT_TYPE_DIFFUSE, MAT_TYPE_DIELECTRIC = 1, 3, 4, 7
 MAT_TYPE_GLASS = 2
 MAT_TYPE_BLEND = 6
@@ -639,20 +640,65 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
     sc.near, sc.far = float(cam.findtext("nearClipPlane")), float(cam.findtext("farClipPlane"))
     sc.cam_pos, sc.cam_look_at, sc.cam_up = _f(cam.findtext("position")), _f(cam.findtext("look_at")), _f(cam.findtext("up"))
 
-    # textures: XML id -> loaded lazily into m_textures on first use by a material (integrator_pt_scene_tex.cpp:105-144)
-    tex_nodes = {int(t.get("id")): t for t in root.findall("textures_lib/texture")}
+    # textures: LoadSceneTexturesInfo (integrator_pt_scene.cpp:330-355) keeps the nodes with a size, indexed by position; a material's
+    # <texture id=..> is loaded on first use, one m_textures entry per distinct (id, address modes, filter) - the HydraSampler
+    # equality of integrator_pt.h:75-83 (rows and gamma are not part of the key) - integrator_pt_scene_tex.cpp:105-125
+    tex_info = []
+    for t in root.findall("textures_lib/texture"):
+        w, h = int(t.get("width", 0)), int(t.get("height", 0))
+        if w != 0 and h != 0:
+            path = t.get("path") if not t.get("loc") else os.path.join(folder, t.get("loc"))
+            tex_info.append((path, w, h, int(t.get("bytesize", 0)) // (w * h)))
     tex_cache = {}
+    addr_modes = {"clamp": ADDR_CLAMP, "wrap": ADDR_WRAP}
 
-    def texture_from_color_node(node):
+    def read_sampler(node):
+        """ReadSamplerFromColorNode (integrator_pt_scene_mat.cpp:32-91): (key, row0, row1, disable_gamma) or None without a <texture>."""
         tnode = node.find("texture") if node is not None else None
         if tnode is None:
-            return 0
-        xid = int(tnode.get("id"))
-        if xid in tex_cache:
-            return tex_cache[xid]
-        data = load_image4ub(os.path.join(folder, tex_nodes[xid].get("loc")))
-        tex_cache[xid] = sc.add_texture(Texture(data, TEX_RGBA8, True, ADDR_WRAP, ADDR_WRAP, FILTER_LINEAR))
-        return tex_cache[xid]
+            return None
+        def addr(name, default):
+            v = tnode.get(name)
+            if v is None:
+                return default
+            if v in ("mirror", "border", "mirror_once"):
+                raise NotImplementedError(f"texture addressing mode '{v}' is outside the path (wrap and clamp are in)")
+            return addr_modes.get(v, ADDR_WRAP)
+        au, av = addr("addressing_mode_u", ADDR_WRAP), addr("addressing_mode_v", ADDR_WRAP)
+        aw = addr("addressing_mode_w", av)
+        filt = FILTER_LINEAR
+        if tnode.get("filter") in ("point", "nearest"):
+            filt = FILTER_NEAREST
+        elif tnode.get("filter") in ("cubic", "bicubic"):
+            raise NotImplementedError("bicubic texture filtering is outside the path")
+        row0, row1 = [1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0]
+        mvals = _f(tnode.get("matrix", ""))                                    # rows of the texture matrix; a short list leaves the rest
+        for i, v in enumerate(mvals[:8]):
+            (row0 if i < 4 else row1)[i % 4] = v
+        gamma = tnode.get("input_gamma")
+        disable_gamma = gamma is not None and int(float(gamma)) == 1           # attribute.as_int() == 1 (integrator_pt_scene_tex.cpp:118-120)
+        return (int(tnode.get("id")), au, av, aw, filt), row0, row1, disable_gamma
+
+    def load_texture_from_node(node):
+        """LoadTextureFromNode (integrator_pt_scene_tex.cpp:105-126): (row0, row1, index into the texture table)."""
+        sam = read_sampler(node)
+        if sam is None:
+            return (1, 0, 0, 0), (0, 1, 0, 0), 0
+        key, row0, row1, disable_gamma = sam
+        if key not in tex_cache:
+            path, w, h, bpp = tex_info[key[0]]
+            if ".image" not in path:
+                raise NotImplementedError(f"texture file '{path}': only the Hydra .image4ub / .image4f containers are read here")
+            raw = open(path, "rb").read()
+            fw, fh = struct.unpack_from("<II", raw, 0)
+            if fw == 0 or fh == 0:                                             # white float dummy (:67-73)
+                tex = Texture(np.ones((1, 1, 4), np.float32), TEX_RGBA32F, False, key[1], key[2], key[4])
+            elif bpp == 16:
+                tex = Texture(np.frombuffer(raw, "<f4", fw * fh * 4, 8).reshape(fh, fw, 4).copy(), TEX_RGBA32F, False, key[1], key[2], key[4])
+            else:
+                tex = Texture(np.frombuffer(raw, "<u4", fw * fh, 8).reshape(fh, fw).copy(), TEX_RGBA8, not disable_gamma, key[1], key[2], key[4])
+            tex_cache[key] = sc.add_texture(tex)
+        return tuple(row0), tuple(row1), tex_cache[key]
 
     # lights first: materials with light_id copy intensity from them (integrator_pt_scene.cpp:973-996, 575-599)
     scene_node = root.find("scenes/scene")
@@ -712,9 +758,154 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
         v = np.asarray(v, np.float32)
         return np.sqrt(np.float32(np.dot(v, v)), dtype=np.float32)
 
+    def zero_material():
+        """Material mat = {} of the typed loaders; spectra ids stay 'none' (RGB mode)."""
+        m = np.zeros((), dtype=MATERIAL_DTYPE)
+        m["spdid"] = UINT_MAX
+        return m
+
+    def bind_texture(mat, slot, node):
+        r0, r1, tid = load_texture_from_node(node)
+        mat["row0"][slot] = r0; mat["row1"][slot] = r1; mat["texid"][slot] = tid
+        return tid
+
+    def convert_gltf(mnode):
+        """ConvertGLTFMaterial (integrator_pt_scene_mat.cpp:176-278)."""
+        mat = zero_material()
+        mat["mtype"] = MAT_TYPE_GLTF
+        cflags = GLTF_COMPONENT_LAMBERT | GLTF_COMPONENT_COAT
+        mat["data"][GLTF_FLOAT_REFL_COAT] = 1.0
+        for i in range(4):
+            mat["row0"][i] = (1, 0, 0, 0); mat["row1"][i] = (0, 1, 0, 0)
+        ior, gloss, metal = np.float32(1.5), np.float32(1.0), np.float32(0.0)
+        base = np.ones(4, np.float32)
+        cn = mnode.find("color")
+        if cn is not None:
+            base = color4(cn)
+            if cn.find("texture") is not None:
+                bind_texture(mat, 0, cn)
+        gn, rn = mnode.find("glossiness"), mnode.find("roughness")
+        if gn is not None or rn is not None:
+            n = gn if gn is not None else rn
+            gloss = val1f(n)
+            if gn is None:
+                cflags |= FLAG_INVERT_GLOSINESS
+            if n.find("texture") is not None:
+                bind_texture(mat, 2, n); cflags |= FLAG_FOUR_TEXTURES
+        mn = mnode.find("metalness")
+        if mn is not None:
+            metal = val1f(mn)
+            if mn.find("texture") is not None:
+                bind_texture(mat, 3, mn); cflags |= FLAG_FOUR_TEXTURES
+        if mnode.find("fresnel_ior") is not None:
+            ior = val1f(mnode.find("fresnel_ior"))
+        if mnode.find("coat") is not None:
+            mat["data"][GLTF_FLOAT_REFL_COAT] = val1f(mnode.find("coat"))
+        pn = mnode.find("glossiness_metalness_coat")
+        if pn is not None:
+            metal = gloss = val1f(pn)
+            mat["data"][GLTF_FLOAT_REFL_COAT] = gloss
+            if pn.find("texture") is not None:
+                bind_texture(mat, 2, pn); cflags |= FLAG_FOUR_TEXTURES | FLAG_PACK_FOUR_PARAMS_IN_TEXTURE
+        mat["cflags"] = cflags
+        mat["colors"][GLTF_COLOR_METAL] = 1.0
+        mat["data"][GLTF_FLOAT_ALPHA] = metal
+        mat["data"][GLTF_FLOAT_GLOSINESS] = gloss
+        set_mi_plastic(mat, float(ior), 1.0, base, (1.0, 1.0, 1.0, 1.0))
+        return mat
+
+    def attr_float(node, default=0.0):      # xml_attribute::as_float of a missing node / attribute is 0
+        return np.float32(float(node.get("val"))) if node is not None and node.get("val") is not None else np.float32(default)
+
+    def load_rough_conductor(mnode):
+        """LoadRoughConductorMaterial (integrator_pt_scene_mat.cpp:452-513), RGB mode."""
+        mat = zero_material()
+        mat["colors"][0] = 1.0
+        mat["mtype"] = MAT_TYPE_CONDUCTOR
+        mat["lightId"] = UINT_MAX
+        an = mnode.find("alpha")
+        if an is not None:
+            au = av = attr_float(an)
+            if bind_texture(mat, 0, an) != 0:
+                au = av = np.float32(1.0)
+        else:
+            au, av = attr_float(mnode.find("alpha_u")), attr_float(mnode.find("alpha_v"))
+        mat["data"][0], mat["data"][1] = au, av                                # CONDUCTOR_ROUGH_U, CONDUCTOR_ROUGH_V
+        mat["data"][2], mat["data"][3] = attr_float(mnode.find("eta")), attr_float(mnode.find("k"))
+        if mnode.find("reflectance") is not None:
+            mat["colors"][0] = color4(mnode.find("reflectance"))
+        return mat
+
+    def load_diffuse(mnode):
+        """LoadDiffuseMaterial (integrator_pt_scene_mat.cpp:516-571), RGB mode."""
+        mat = zero_material()
+        mat["colors"][0] = 1.0
+        mat["mtype"] = MAT_TYPE_DIFFUSE
+        mat["lightId"] = UINT_MAX
+        bsdf = mnode.find("bsdf")
+        if bsdf is not None and bsdf.get("type") == "oren-nayar":
+            mat["cflags"] = GLTF_COMPONENT_ORENNAYAR
+            if mnode.find("roughness") is not None:
+                mat["data"][0] = val1f(mnode.find("roughness"))
+        rn = mnode.find("reflectance")
+        if rn is not None:
+            mat["colors"][0] = color4(rn)
+            bind_texture(mat, 0, rn)
+        return mat
+
+    def load_dielectric(mnode):
+        """LoadDielectricMaterial (integrator_pt_scene_mat.cpp:574-616), RGB mode."""
+        mat = zero_material()
+        mat["colors"][0] = 1.0; mat["colors"][1] = 1.0
+        mat["mtype"] = MAT_TYPE_DIELECTRIC
+        mat["lightId"] = UINT_MAX
+        mat["data"][0], mat["data"][1] = 1.00028, 1.5046                       # DIELECTRIC_ETA_EXT (air), DIELECTRIC_ETA_INT (bk7)
+        if mnode.find("int_ior") is not None:
+            mat["data"][1] = attr_float(mnode.find("int_ior"))
+        if mnode.find("ext_ior") is not None:
+            mat["data"][0] = attr_float(mnode.find("ext_ior"))
+        if mnode.find("reflectance") is not None:
+            mat["colors"][0] = color4(mnode.find("reflectance"))
+        if mnode.find("transmittance") is not None:
+            mat["colors"][1] = color4(mnode.find("transmittance"))
+        return mat
+
+    def load_blend(mnode):
+        """LoadBlendMaterial (integrator_pt_scene_mat.cpp:619-647)."""
+        mat = zero_material()
+        mat["mtype"] = MAT_TYPE_BLEND
+        mat["data"][0] = 1.0
+        for k, name in enumerate(("bsdf_1", "bsdf_2")):
+            n = mnode.find(name)
+            mat["datai"][k] = int(n.get("id", 0)) if n is not None else 0
+        wn = mnode.find("weight")
+        if wn is not None:
+            mat["data"][0] = val1f(wn)
+            bind_texture(mat, 0, wn)
+        return mat
+
+    typed_loaders = {"gltf": convert_gltf, "rough_conductor": load_rough_conductor, "diffuse": load_diffuse,
+                     "dielectric": load_dielectric, "blend": load_blend}
+
     # ConvertOldHydraMaterial (integrator_pt_scene_mat.cpp:280-450), every branch: emission, diffuse (+ Oren-Nayar), reflectivity with and
     # without Fresnel (coated plastic / Lambert + metal mix / pure metal), transparency (legacy glass)
     for mnode in root.findall("materials_lib/material"):
+        mtype_attr = mnode.get("type", "")
+        if mtype_attr in typed_loaders:                                       # LoadSceneMaterials dispatch (integrator_pt_scene.cpp:500-570)
+            mat = typed_loaders[mtype_attr](mnode)
+            for k in range(4):
+                if not np.any(mat["row0"][k]) and not np.any(mat["row1"][k]):
+                    mat["row0"][k] = (1, 0, 0, 0); mat["row1"][k] = (0, 1, 0, 0)
+            mat["texid"][1] = UINT_MAX
+            lid = int(mnode.get("light_id", -1))
+            if 0 <= lid < len(sc.lights):
+                mat["colors"][EMISSION_COLOR] = sc.lights[lid]["intensity"]
+                mat["data"][EMISSION_MULT] = sc.lights[lid]["mult"]
+                sc.lights[lid]["matId"] = len(sc.materials)
+            sc.materials.append(mat)
+            continue
+        if mtype_attr != "hydra_material":
+            raise NotImplementedError(f"material type '{mtype_attr}' is outside the path (plastic, thin_film: SURVEY.md 2a)")
         mat = _blank_material()
         mat["texid"] = (0, 0, 0, 0)                                           # Material mat = {}: no 0xFFFFFFFF sentinels in this converter
         mat["spdid"] = (0, 0, 0, 0)
@@ -732,8 +923,7 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
             cnode = emis.find("color") if emis is not None else None
             color = color4(cnode)
             is_emission = mnode.get("light_id") is not None or length(color) > 1e-5
-            mat["row0"][0] = (1, 0, 0, 0); mat["row1"][0] = (0, 1, 0, 0)       # default HydraSampler rows
-            mat["texid"][0] = texture_from_color_node(cnode)
+            bind_texture(mat, 0, cnode)                                       # rows of the node's sampler (default rows without a texture)
             mat["colors"][EMISSION_COLOR] = color
             mat["lightId"] = int(mnode.get("light_id")) & UINT_MAX if mnode.get("light_id") is not None else UINT_MAX
             mat["spdid"][0] = UINT_MAX
@@ -745,8 +935,7 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
         if dnode is not None:
             color = color4(dnode)
             if dnode.find("texture") is not None:
-                mat["row0"][0] = (1, 0, 0, 0); mat["row1"][0] = (0, 1, 0, 0)
-                mat["texid"][0] = texture_from_color_node(dnode)
+                bind_texture(mat, 0, dnode)
         refl_color, refl_gloss, fresnel_ior = np.zeros(4, np.float32), np.float32(1.0), np.float32(1.5)
         refl = mnode.find("reflectivity")
         if refl is not None:
@@ -825,6 +1014,16 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
     for mesh in root.findall("geometry_lib/mesh"):
         pos, norm, tang, uv, idx, mats = load_vsgf(os.path.join(folder, mesh.get("loc")))
         sc.add_mesh(pos, norm, tang, uv, idx, mats)
+
+    # remap lists (hydraxml.h:267-276, LoadSceneRemapLists integrator_pt_scene.cpp:909-924): `size` ints of (from, to) pairs per list
+    rl = scene_node.find("remap_lists")
+    if rl is not None:
+        lists = []
+        for node in rl:
+            n = int(node.get("size", 0))
+            vals = [int(v) for v in node.get("val", "").split()][:n]
+            lists.append(vals + [0] * (n - len(vals)))
+        sc.set_remap_lists(lists)
 
     for inst in scene_node.findall("instance"):
         linst = inst.get("linst_id")

@@ -336,7 +336,7 @@ def test_path_trace_from_input_rays_block_matches_oracle(cornell):
         assert np.array_equal(gpu.random_gens(), cpu.random_gens())
 
 
-@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials"])
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials"])
 def test_cpp_scene_ingestion_renders_like_the_python_path(scene_name, tmp_path):
     """hydra_hip_render: scene_loader.h (C++) -> C ABI -> frame, no Python in the loop; the frame equals the one rendered from the
     Python loader's tables (same tables up to float rounding of inverted matrices: the image bar applies)."""
@@ -532,6 +532,31 @@ def test_legacy_material_converter_scene_matches_oracle():
     a, b = gpu.render(6), cpu.render(6)
     assert per_pixel_l2(a, b, 6) < 1e-3 and np.isfinite(a).all()
     assert np.array_equal(gpu.random_gens(), cpu.random_gens())
+
+
+def test_typed_material_scene_matches_oracle():
+    """tests/golden/scenes/typed_materials (own fixture, make_typed_scene.py): the typed material nodes of LoadSceneMaterials
+    (integrator_pt_scene.cpp:500-570) - gltf with colour / glossiness / metalness textures and the packed form, rough_conductor,
+    diffuse, dielectric, blend - per-use samplers (clamp, point filter, texture matrix, linear-space and float textures) and a remap
+    list; HIP == oracle, both schedules agree."""
+    from hydracore3_amd.api import HipIntegrator
+    from oracle.orc import OracleIntegrator
+    from hydracore3_amd import scene as S
+    sc = load_hydra_xml(scene_path("typed_materials"))
+    assert sorted({int(m["mtype"]) for m in sc.materials}) == [1, 3, 4, 6, 7, 0xEFFFFFFF]
+    assert sc.all_remap_lists.tolist() == [1, 6, 0, 2] and sc.remap_inst[0][0] == 0
+    assert {(t.fmt, t.filter, t.addr_u) for t in sc.textures} >= {(S.TEX_RGBA8, S.FILTER_LINEAR, S.ADDR_WRAP), (S.TEX_RGBA8, S.FILTER_LINEAR, S.ADDR_CLAMP),
+                                                                       (S.TEX_RGBA32F, S.FILTER_NEAREST, S.ADDR_WRAP), (S.TEX_RGBA8, S.FILTER_NEAREST, S.ADDR_WRAP)}
+    for integ in (INTEGRATOR_MIS_PT, INTEGRATOR_SHADOW_PT):
+        prm = sc.params(integ)
+        gpu, cpu = HipIntegrator(sc, prm), OracleIntegrator(sc, prm)
+        a, b = gpu.render(6), cpu.render(6)
+        l2 = per_pixel_l2(a, b, 6)
+        print(f"typed materials ({integ}): L2 {l2:.2e}")
+        assert l2 < 1e-3 and np.isfinite(a).all() and a[..., :3].mean() > 0.05
+        assert np.array_equal(gpu.random_gens(), cpu.random_gens())
+        wf = HipIntegrator(sc, prm); wf.set_schedule(2)
+        assert np.array_equal(wf.render(6), a)
 
 
 def test_dynamic_updates_equal_a_fresh_build(cornell):

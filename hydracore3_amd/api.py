@@ -25,6 +25,10 @@ ABI = {
     "hpt_destroy": (None, [_vp]),
     "hpt_last_error": (C.c_char_p, [_vp]),
     "hpt_device_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.c_char_p, _sz]),
+    "hpt_device_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "hpt_device_free": (_i, [_vp, _vp]),
+    "hpt_device_copy": (_i, [_vp, _vp, _vp, _sz, _i]),
+    "hpt_device_memset": (_i, [_vp, _vp, _i, _sz]),
     "hpt_clear_geom": (_i, [_vp]),
     "hpt_add_geom_triangles3f": (_u32, [_vp, _vp, _sz, _vp, _sz, _u32, _sz]),
     "hpt_update_geom_triangles3f": (_i, [_vp, _u32, _vp, _sz, _vp, _sz, _u32, _sz]),

@@ -187,6 +187,38 @@ extern "C" int hpt_device_info(hpt_ctx* c, int* numCUs, int* wavefront, char* na
   return HPT_OK;
 }
 
+// ---- device memory for callers of the *_dev entry points that do not link the HIP runtime themselves ---------------------------------
+extern "C" int hpt_device_malloc(hpt_ctx* c, size_t bytes, void** outDev)
+{
+  if (!c || !outDev) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  *outDev = nullptr;
+  HIPCHK(c, hipMalloc(outDev, bytes ? bytes : 4));
+  return HPT_OK;
+}
+extern "C" int hpt_device_free(hpt_ctx* c, void* dev)
+{
+  if (!c) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (dev) HIPCHK(c, hipFree(dev));
+  return HPT_OK;
+}
+extern "C" int hpt_device_copy(hpt_ctx* c, void* dst, const void* src, size_t bytes, int kind)
+{
+  if (!c || (bytes && (!dst || !src)) || kind < 1 || kind > 3) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  const hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  if (bytes) HIPCHK(c, hipMemcpy(dst, src, bytes, k));                      // synchronous: orders after the asynchronous *_dev launches on the null stream
+  return HPT_OK;
+}
+extern "C" int hpt_device_memset(hpt_ctx* c, void* dev, int value, size_t bytes)
+{
+  if (!c || (bytes && !dev)) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (bytes) HIPCHK(c, hipMemsetAsync(dev, value, bytes, nullptr));
+  return HPT_OK;
+}
+
 // ---- ISceneObject ---------------------------------------------------------------------------------------------------------------
 extern "C" int hpt_clear_geom(hpt_ctx* c)
 {

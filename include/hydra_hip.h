@@ -91,6 +91,14 @@ int  hpt_create(int device, hpt_ctx** out);          /* Integrator::Integrator +
 void hpt_destroy(hpt_ctx* ctx);                      /* Integrator::~Integrator + DeleteSceneRT (CrossRT.h:196) */
 const char* hpt_last_error(hpt_ctx* ctx);
 int  hpt_device_info(hpt_ctx* ctx, int* numCUs, int* wavefront, char* name, size_t nameLen);
+/* Device memory for callers of the *_dev entry points that do not link the HIP runtime themselves (a plain C/C++ host such as
+ * diff_render/drmain.cpp:174-261 keeping its texture, gradient and Adam moments resident). No reference counterpart: the reference's
+ * generated GPU class owns its buffers (main.cpp:221-224). kind: 1 host->device, 2 device->host, 3 device->device; copies are
+ * synchronous, memset is asynchronous on the null stream. */
+int  hpt_device_malloc(hpt_ctx* ctx, size_t bytes, void** outDev);
+int  hpt_device_free(hpt_ctx* ctx, void* dev);
+int  hpt_device_copy(hpt_ctx* ctx, void* dst, const void* src, size_t bytes, int kind);
+int  hpt_device_memset(hpt_ctx* ctx, void* dev, int value, size_t bytes);
 
 /* ---- ISceneObject: BVH2 replacement of the Embree backend (external/CrossRT/CrossRT.h:45-176) ------------------ */
 int      hpt_clear_geom(hpt_ctx* ctx);                                                   /* ClearGeom            :56 */

@@ -21,7 +21,7 @@ enum : uint {
   RAY_FLAG_IS_DEAD = 0x80000000u, RAY_FLAG_OUT_OF_SCENE = 0x40000000u, RAY_FLAG_HIT_LIGHT = 0x20000000u,
   RAY_FLAG_HAS_NON_SPEC = 0x10000000u, RAY_FLAG_HAS_INV_NORMAL = 0x08000000u, RAY_FLAG_WAVES_DIVERGED = 0x04000000u,
   RAY_FLAG_PRIME_RAY_MISS = 0x02000000u, RAY_FLAG_FIRST_NON_SPEC = 0x01000000u };
-enum : uint { GLTF_COMPONENT_METAL = 4, GLTF_COMPONENT_ORENNAYAR = 16, FLAG_FOUR_TEXTURES = 256, FLAG_PACK_FOUR_PARAMS_IN_TEXTURE = 512 };
+enum : uint { GLTF_COMPONENT_METAL = 4, GLTF_COMPONENT_ORENNAYAR = 16, FLAG_NMAP_INVERT_X = 32, FLAG_NMAP_INVERT_Y = 64, FLAG_NMAP_SWAP_XY = 128, FLAG_FOUR_TEXTURES = 256, FLAG_PACK_FOUR_PARAMS_IN_TEXTURE = 512 };
 enum : uint { MAT_TYPE_BLEND = 6, BLEND_STACK_SIZE = 4 };   // include/cmaterial.h:43,155 (data[0] = weight, datai[0..1] = children, texid[0] = mask); integrator_pt.h:599
 enum : uint { MAT_TYPE_GLASS = 2 };    // include/cmaterial.h:39; colours: 0 reflect, 1 transparency; data[2] = IOR (:85-92)
 enum : uint { MAT_TYPE_GLTF = 1, MAT_TYPE_CONDUCTOR = 3, MAT_TYPE_DIFFUSE = 4, MAT_TYPE_DIELECTRIC = 7, MAT_TYPE_LIGHT_SOURCE = 0xEFFFFFFFu };

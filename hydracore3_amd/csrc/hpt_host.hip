@@ -473,7 +473,7 @@ extern "C" int hpt_ray_query_any(hpt_ctx* c, const float* p, const float* d, uin
 // ---- scene tables -----------------------------------------------------------------------------------------------------------------
 static bool lean_materials(const MaterialRec* m, size_t n)
 {
-  for (size_t i = 0; i < n; i++) if (m[i].mtype != MAT_TYPE_GLTF && m[i].mtype != MAT_TYPE_LIGHT_SOURCE) return false;
+  for (size_t i = 0; i < n; i++) if ((m[i].mtype != MAT_TYPE_GLTF && m[i].mtype != MAT_TYPE_LIGHT_SOURCE) || m[i].texid[1] != 0xFFFFFFFFu) return false;
   return true;
 }
 static int check_materials(hpt_ctx* c, const MaterialRec* m, size_t n, size_t numTex, size_t numMats)
@@ -487,7 +487,7 @@ static int check_materials(hpt_ctx* c, const MaterialRec* m, size_t n, size_t nu
     }
     if (t != MAT_TYPE_GLTF && t != MAT_TYPE_GLASS && t != MAT_TYPE_CONDUCTOR && t != MAT_TYPE_DIFFUSE && t != MAT_TYPE_DIELECTRIC && t != MAT_TYPE_LIGHT_SOURCE)
       return c->fail(HPT_ERR_UNSUPPORTED, "material type " + std::to_string(t) + " (plastic / thin film) is outside the hot path's scope");
-    if (m[i].texid[1] != 0xFFFFFFFFu) return c->fail(HPT_ERR_UNSUPPORTED, "normal-map bump is outside the hot path's scope");
+    if (m[i].texid[1] != 0xFFFFFFFFu && m[i].texid[1] >= numTex) return c->fail(HPT_ERR_ARG, "material refers to a normal map that does not exist");
     if (m[i].texid[0] >= numTex) return c->fail(HPT_ERR_ARG, "material refers to a texture that does not exist");
     if ((m[i].cflags & FLAG_FOUR_TEXTURES) && (m[i].texid[2] >= numTex || m[i].texid[3] >= numTex)) return c->fail(HPT_ERR_ARG, "material refers to a texture that does not exist");
   }
@@ -700,6 +700,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   if (c->dGens.n < (inRays ? (size_t)job.tidEnd : (size_t)c->packedCount)) return c->fail(HPT_ERR_STATE, "PathTraceBlock: m_randomGens smaller than the thread range (InitRandomGens)");
   if (job.channels < 1 || job.channels > 4) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceBlock: channels must be 1..4 (spectral layers are out of scope)");
   if (dr && (c->S.traceDepth == 0 || c->S.traceDepth > 16)) return c->fail(HPT_ERR_ARG, "PathTraceDR: trace depth must be 1..16");
+  if (dr && !c->leanMaterials) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceDR: gltf and emissive materials without normal maps only (what the reference's replay differentiates, integrator_dr.cpp:461-612)");
   // never more lanes than pixels: with fewer, the hardware's round-robin block placement spreads them evenly over the CUs, whereas a
   // full grid would let whichever waves ask first take all the work (a small multi-GPU share of a frame)
   const int blocks = (int)std::min<size_t>((size_t)gridBlocks(c, dr), ((size_t)job.tidCount + 255) / 256);

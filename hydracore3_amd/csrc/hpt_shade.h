@@ -61,6 +61,36 @@ HPT_DEV void cameraRay(const DevScene& S, uint x, uint y, V4 pixelOffsets, V3& r
 // function is always inlined, so both callers keep them in VGPRs.  Returns true when the path continues (didBounce).
 // A miss only sets the OUT_OF_SCENE flags.  The caller traces the shadow ray (if wantShadow) and adds `contrib`.
 // ---- blend materials (integrator_pt_mat.cpp:23-77, 123-130, 316-333, 511-527); only in the non-LEAN kernels ---------------------------------
+// ---- normal-map bump (integrator_pt_mat.cpp:94-107, 131-139, 298-303, 336-355; NormalMapTransform in include/cmaterial.h) -------------------
+// world-space tangent of the hit (integrator_pt.cpp:270-302: interpolated, through the normal matrix, normalised, flipped with the normal)
+HPT_DEV V3 hitTangent(const DevScene& S, uint A, uint B, uint C, uint vertOffset, float wA, float uvx, float uvy, const float* nm, float flipNorm)
+{
+  const float4 tA = ((const float4*)S.vData8f)[2 * (A + vertOffset) + 1], tB = ((const float4*)S.vData8f)[2 * (B + vertOffset) + 1], tC = ((const float4*)S.vData8f)[2 * (C + vertOffset) + 1];
+  const V3 tO = v3(wA * tA.x + uvy * tB.x + uvx * tC.x, wA * tA.y + uvy * tB.y + uvx * tC.y, wA * tA.z + uvy * tB.z + uvx * tC.z);
+  const V3 t = v3(nm[0] * tO.x + nm[1] * tO.y + nm[2] * tO.z, nm[4] * tO.x + nm[5] * tO.y + nm[6] * tO.z, nm[8] * tO.x + nm[9] * tO.y + nm[10] * tO.z);
+  return flipNorm * normalize(t);
+}
+// BumpMapping: the tangent-space normal of the map through the inverse of the matrix with rows (tan, bitan, n) - by cofactors,
+// inv(M) = [r1 x r2 | r2 x r0 | r0 x r1] / det (LiteMath's make_float3x3 / inverse3x3 are absent from the reference tree)
+HPT_DEV V3 bumpNormal(const DevScene& S, const MaterialRec& m, V3 n, V3 tan, V2 uv)
+{
+  const V4 nt = texSample(S.textures, m.texid[1], mulRows2x4(m.row0[1], m.row1[1], uv));
+  V3 ts = v3(2.0f * nt.x - 1.0f, 2.0f * nt.y - 1.0f, nt.z);
+  if ((m.cflags & FLAG_NMAP_INVERT_X) != 0) ts.x *= -1.0f;
+  if ((m.cflags & FLAG_NMAP_INVERT_Y) != 0) ts.y *= -1.0f;
+  if ((m.cflags & FLAG_NMAP_SWAP_XY) != 0) { const float t = ts.x; ts.x = ts.y; ts.y = t; }
+  const V3 bitan = cross(n, tan);
+  const V3 c0 = cross(bitan, n), c1 = cross(n, tan), c2 = cross(tan, bitan);
+  const float det = dot(tan, c0);
+  const V3 w = (ts.x * c0 + ts.y * c1 + ts.z * c2) / det;
+  return normalize(w);
+}
+// MaterialEval's cosine correction for a bent shading normal (:341-355)
+HPT_DEV float bumpCosMult(V3 l, V3 geomNormal, V3 shadeNormal)
+{
+  const float c1 = smax(dot(l, geomNormal), 0.0f), c2 = smax(dot(l, shadeNormal), 0.0f);
+  return (c1 <= 0.0f) ? 0.0f : c2 / smax(c1, 1e-6f);
+}
 // texture colour and the "four scalar parameters" of a leaf material (:139-167)
 HPT_DEV void leafTextures(const DevScene& S, const MaterialRec& m, V2 uv, V3& tex3, V3& four)
 {
@@ -73,7 +103,7 @@ HPT_DEV void leafTextures(const DevScene& S, const MaterialRec& m, V2 uv, V3& te
   }
 }
 // MaterialEval of a blend tree: a stack of (material id, weight) pairs, BLEND_STACK_SIZE deep, in the reference's visiting order
-HPT_DEV void blendTreeEval(const DevScene& S, uint rootId, V2 uv, V3 l, V3 v, V3 n, BsdfE& res)
+HPT_DEV void blendTreeEval(const DevScene& S, uint rootId, V2 uv, V3 l, V3 v, V3 gn, V3 tan, BsdfE& res)
 {
   uint stackId[BLEND_STACK_SIZE]; float stackW[BLEND_STACK_SIZE];
   uint curId = rootId; float curW = 1.0f;
@@ -85,12 +115,14 @@ HPT_DEV void blendTreeEval(const DevScene& S, uint rootId, V2 uv, V3 l, V3 v, V3
     V3 tex3, four; leafTextures(S, m, uv, tex3, four);
     BsdfE cv; cv.val = v3(0, 0, 0); cv.pdf = 0.0f; cv.dval = v3(0, 0, 0);
     const uint t = m.mtype;
-    if (t == MAT_TYPE_GLTF) { gltfEval(m, l, v, n, ld3(m.colors[GLTF_COLOR_BASE]) * tex3, four, cv); res.val = res.val + cv.val * curW; res.pdf += cv.pdf * curW; }
+    V3 n = gn; float bm = 1.0f;
+    if (m.texid[1] != 0xFFFFFFFFu && t != MAT_TYPE_BLEND) { n = bumpNormal(S, m, gn, tan, uv); bm = bumpCosMult(l, gn, n); }
+    if (t == MAT_TYPE_GLTF) { gltfEval(m, l, v, n, ld3(m.colors[GLTF_COLOR_BASE]) * tex3, four, cv); res.val = res.val + cv.val * curW * bm; res.pdf += cv.pdf * curW; }
     else if (t == MAT_TYPE_CONDUCTOR) {
       if (!(smax(m.data[1], m.data[0]) < 1e-3f)) conductorRoughEval(m, m.data[2], m.data[3], l, v, n, tex3, cv);
-      res.val = res.val + cv.val * curW; res.pdf += cv.pdf * curW;
+      res.val = res.val + cv.val * curW * bm; res.pdf += cv.pdf * curW;
     }
-    else if (t == MAT_TYPE_DIFFUSE) { diffuseEval(m, ld3(m.colors[0]) * tex3, l, v, n, cv); res.val = res.val + cv.val * curW; res.pdf += cv.pdf * curW; }
+    else if (t == MAT_TYPE_DIFFUSE) { diffuseEval(m, ld3(m.colors[0]) * tex3, l, v, n, cv); res.val = res.val + cv.val * curW * bm; res.pdf += cv.pdf * curW; }
     else if (t == MAT_TYPE_BLEND) {                          // BlendEval: first child next (no pop), second child waits on the stack
       const float w = m.data[0] * tex3.x;
       const uint id1 = m.datai[0], id2 = m.datai[1];
@@ -141,6 +173,9 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
     const MaterialRec& m = S.materials[matId];
     const uint mtype = m.mtype;
     const V3 vdir = (-1.0f) * rdir;
+    V3 hitTang = v3(0, 0, 0);                                          // only materials with a normal map (or a blend that may hold one) read it
+    if (!(DR || LEAN) && (mtype == MAT_TYPE_BLEND || (mtype != MAT_TYPE_LIGHT_SOURCE && m.texid[1] != 0xFFFFFFFFu)))
+      hitTang = hitTangent(S, A, B, C, vertOffset, wA, uvx, uvy, nm, flipNorm);
 
     // -- kernel_SampleLightSource (integrator_pt.cpp:350-424): the randoms are drawn for every surface hit --
     V3 shade = v3(0, 0, 0), dshade = v3(0, 0, 0);
@@ -176,12 +211,17 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
           // MaterialEval (integrator_pt_mat.cpp:308-528), evaluated before the shadow ray so that nothing but the
           // candidate contribution has to stay live across the any-hit traversal
           BsdfE bv; bv.val = v3(0, 0, 0); bv.pdf = 0.0f; bv.dval = v3(0, 0, 0);
-          if (mtype == MAT_TYPE_GLTF) gltfEval(m, shadowRayDir, vdir, hitNorm, baseCol * tex3, four, bv);
-          else if (!(DR || LEAN) && mtype == MAT_TYPE_CONDUCTOR) {
-            if (!(smax(m.data[1], m.data[0]) < 1e-3f)) conductorRoughEval(m, m.data[2], m.data[3], shadowRayDir, vdir, hitNorm, tex3, bv);
+          V3 evalNorm = hitNorm; float bumpMult = 1.0f;
+          if (!(DR || LEAN) && mtype != MAT_TYPE_BLEND && m.texid[1] != 0xFFFFFFFFu) {
+            evalNorm = bumpNormal(S, m, hitNorm, hitTang, uv); bumpMult = bumpCosMult(shadowRayDir, hitNorm, evalNorm);
           }
-          else if (!(DR || LEAN) && mtype == MAT_TYPE_DIFFUSE) diffuseEval(m, ld3(m.colors[0]) * tex3, shadowRayDir, vdir, hitNorm, bv);
-          else if (!(DR || LEAN) && mtype == MAT_TYPE_BLEND) blendTreeEval(S, matId, uv, shadowRayDir, vdir, hitNorm, bv);
+          if (mtype == MAT_TYPE_GLTF) gltfEval(m, shadowRayDir, vdir, evalNorm, baseCol * tex3, four, bv);
+          else if (!(DR || LEAN) && mtype == MAT_TYPE_CONDUCTOR) {
+            if (!(smax(m.data[1], m.data[0]) < 1e-3f)) conductorRoughEval(m, m.data[2], m.data[3], shadowRayDir, vdir, evalNorm, tex3, bv);
+          }
+          else if (!(DR || LEAN) && mtype == MAT_TYPE_DIFFUSE) diffuseEval(m, ld3(m.colors[0]) * tex3, shadowRayDir, vdir, evalNorm, bv);
+          else if (!(DR || LEAN) && mtype == MAT_TYPE_BLEND) blendTreeEval(S, matId, uv, shadowRayDir, vdir, hitNorm, hitTang, bv);
+          if (!(DR || LEAN) && mtype != MAT_TYPE_BLEND) bv.val = bv.val * bumpMult;     // res.val += currVal.val * weight * bumpCosMult, weight 1
           const float cosThetaOut = smax(dot(shadowRayDir, hitNorm), 0.0f);
           float lgtPdfW = (1.0f / float(nLights)) * lightEvalPDF(L, shadowRayPos, shadowRayDir, ls.pos, ls.norm, ls.pdf);
           float misWeight = (S.integratorType == INTEGRATOR_MIS_PT) ? misWeightHeuristic(lgtPdfW, bv.pdf) : 1.0f;
@@ -244,18 +284,25 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
         leafTextures(S, *lm, uv, ltex3, lfour);
       }
       const MaterialRec& ml = *lm;
+      const bool leafBump = !(DR || LEAN) && ml.texid[1] != 0xFFFFFFFFu;        // the leaf's normal map bends the shading normal (:131-139)
+      V3 sNorm = hitNorm;
+      if (leafBump) sNorm = bumpNormal(S, ml, hitNorm, hitTang, uv);
       const V4 rands = rng_float4(gen);                                // GetRandomNumbersMats: drawn for every material type (integrator_pt_mat.cpp:147)
-      if (lt == MAT_TYPE_GLTF) gltfSampleAndEval(ml, rands, vdir, hitNorm, ld3(ml.colors[GLTF_COLOR_BASE]) * ltex3, lfour, ms);
+      if (lt == MAT_TYPE_GLTF) gltfSampleAndEval(ml, rands, vdir, sNorm, ld3(ml.colors[GLTF_COLOR_BASE]) * ltex3, lfour, ms);
       else if (!(DR || LEAN) && lt == MAT_TYPE_CONDUCTOR) {
-        if (smax(ml.data[1], ml.data[0]) < 1e-3f) conductorSmoothSampleAndEval(ml, ml.data[2], ml.data[3], vdir, hitNorm, ms);
-        else                                      conductorRoughSampleAndEval(ml, ml.data[2], ml.data[3], rands, vdir, hitNorm, ltex3, ms);
+        if (smax(ml.data[1], ml.data[0]) < 1e-3f) conductorSmoothSampleAndEval(ml, ml.data[2], ml.data[3], vdir, sNorm, ms);
+        else                                      conductorRoughSampleAndEval(ml, ml.data[2], ml.data[3], rands, vdir, sNorm, ltex3, ms);
       }
-      else if (!(DR || LEAN) && lt == MAT_TYPE_DIFFUSE) diffuseSampleAndEval(ml, ld3(ml.colors[0]) * ltex3, rands, vdir, hitNorm, ms);
-      else if (!(DR || LEAN) && lt == MAT_TYPE_GLASS) glassSampleAndEval(ml, rands, vdir, hitNorm, ms, misIor);
+      else if (!(DR || LEAN) && lt == MAT_TYPE_DIFFUSE) diffuseSampleAndEval(ml, ld3(ml.colors[0]) * ltex3, rands, vdir, sNorm, ms);
+      else if (!(DR || LEAN) && lt == MAT_TYPE_GLASS) glassSampleAndEval(ml, rands, vdir, hitNorm, ms, misIor);      // the geometric normal (:182)
       else if (!(DR || LEAN) && lt == MAT_TYPE_DIELECTRIC) {
-        dielectricSmoothSampleAndEval(ml, ml.data[1], misIor, rands, vdir, hitNorm, ms);
+        dielectricSmoothSampleAndEval(ml, ml.data[1], misIor, rands, vdir, sNorm, ms);
         ms.flags |= (ml.spdid[0] < 0xFFFFFFFFu) ? RAY_FLAG_WAVES_DIVERGED : 0u;
         misIor = ms.ior;
+      }
+      if (leafBump) {                                                  // the caller multiplies by the cosine to the geometric normal (:298-303)
+        const float c1 = absf(dot(ms.dir, hitNorm)), c2 = absf(dot(ms.dir, sNorm));
+        ms.val = ms.val * (c2 / smax(c1, 1e-10f));
       }
       const float invPdf = 1.0f / smax(ms.pdf, 1e-20f);
       const V3 bxdfVal = ms.val * invPdf;

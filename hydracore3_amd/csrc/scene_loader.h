@@ -470,6 +470,20 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
     const double dMean = 0.3333333 * ((double)diffuse[0] + diffuse[1] + diffuse[2]), sMean = 0.3333333 * ((double)specular[0] + specular[1] + specular[2]);
     mat.data[2] = (float)(sMean / (dMean + sMean));
   };
+  // LoadSceneMaterials (integrator_pt_scene.cpp:603-638): texid[1] = none, or the <displacement type="normal_bump"> map
+  auto applyNormalMap = [&](const XmlNode* mn, Material& mat) -> bool {
+    mat.texid[1] = 0xFFFFFFFFu;
+    const XmlNode* disp = mn->child("displacement");
+    if (!disp || disp->get("type") != "normal_bump") return true;            // other bump types: message only in the reference
+    const XmlNode* nm = disp->child("normal_map");
+    if (!loadTextureFromNode(nm, mat.row0[1], mat.row1[1], mat.texid[1])) return false;
+    const XmlNode* inv = nm ? nm->child("invert") : nullptr;
+    auto flag = [&](const char* name) { return inv && (int)std::atof(inv->get(name, "0").c_str()) == 1; };
+    if (flag("x")) mat.cflags |= 32u;
+    if (flag("y")) mat.cflags |= 64u;
+    if (flag("swap_xy")) mat.cflags |= 128u;
+    return true;
+  };
   auto attrFloat = [](const XmlNode* n) -> float { return (n && n->has("val")) ? (float)std::atof(n->get("val").c_str()) : 0.0f; };   // as_float of a missing node is 0
   auto zeroMaterial = [](Material& mat) { std::memset(&mat, 0, sizeof(mat)); for (int k = 0; k < 4; k++) mat.spdid[k] = 0xFFFFFFFFu; };   // Material mat = {}; spectra: none (RGB mode)
   // the typed material nodes of LoadSceneMaterials (integrator_pt_scene.cpp:500-570); false with err set on failure, `known` false for other types
@@ -546,7 +560,7 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
         bool zero = true; for (int j = 0; j < 4; j++) zero = zero && mat.row0[k][j] == 0.0f && mat.row1[k][j] == 0.0f;
         if (zero) { mat.row0[k][0] = 1.0f; mat.row1[k][1] = 1.0f; }
       }
-      mat.texid[1] = 0xFFFFFFFFu;
+      if (!applyNormalMap(mn, mat)) return false;
       const int lid = mn->has("light_id") ? std::atoi(mn->get("light_id").c_str()) : -1;
       if (lid >= 0 && lid < (int)sc.lights.size()) {
         for (int k = 0; k < 4; k++) mat.colors[0][k] = sc.lights[(size_t)lid].intensity[k];
@@ -620,7 +634,7 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
       bool zero = true; for (int j = 0; j < 4; j++) zero = zero && mat.row0[k][j] == 0.0f && mat.row1[k][j] == 0.0f;
       if (zero) { mat.row0[k][0] = 1.0f; mat.row1[k][1] = 1.0f; }
     }
-    mat.texid[1] = 0xFFFFFFFFu;
+    if (!applyNormalMap(mn, mat)) return false;
     if (mat.mtype == 0xEFFFFFFFu) {
       const int lid = mn->has("light_id") ? std::atoi(mn->get("light_id").c_str()) : -1;
       if (lid >= 0 && lid < (int)sc.lights.size()) {                          // LoadScene :973-996: the light's intensity wins

@@ -49,6 +49,7 @@ assert LIGHT_DTYPE.itemsize == 320
 # include/cmaterial.h:26-46
 GLTF_COMPONENT_LAMBERT, GLTF_COMPONENT_COAT, GLTF_COMPONENT_METAL, GLTF_COMPONENT_ORENNAYAR = 1, 2, 4, 16
 FLAG_FOUR_TEXTURES, FLAG_PACK_FOUR_PARAMS_IN_TEXTURE, FLAG_INVERT_GLOSINESS = 256, 512, 1024
+FLAG_NMAP_INVERT_X, FLAG_NMAP_INVERT_Y, FLAG_NMAP_SWAP_XY = 32, 64, 128
 MAT_TYPE_GLTF, MAT_TYPE_CONDUCTOR, MAT_TYPE_DIFFUSE, MAT_TYPE_DIELECTRIC = 1, 3, 4, 7
 MAT_TYPE_GLASS = 2
 MAT_TYPE_BLEND = 6
@@ -285,6 +286,15 @@ def material_blend(mat_id1: int, mat_id2: int, weight: float, mask_tex=0) -> np.
     m["data"][0] = weight
     m["datai"][0], m["datai"][1] = mat_id1, mat_id2
     m["texid"][0] = mask_tex
+    return m
+
+
+def set_normal_map(m, tex_id: int, invert_x=False, invert_y=False, swap_xy=False, row0=(1, 0, 0, 0), row1=(0, 1, 0, 0)):
+    """Normal-map bump of any material (integrator_pt_scene.cpp:603-638, integrator_pt_mat.cpp:94-107): texid[1] + the NMAP flags."""
+    m["texid"][1] = tex_id
+    m["row0"][1] = row0
+    m["row1"][1] = row1
+    m["cflags"] = int(m["cflags"]) | (FLAG_NMAP_INVERT_X if invert_x else 0) | (FLAG_NMAP_INVERT_Y if invert_y else 0) | (FLAG_NMAP_SWAP_XY if swap_xy else 0)
     return m
 
 
@@ -769,6 +779,25 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
         mat["row0"][slot] = r0; mat["row1"][slot] = r1; mat["texid"][slot] = tid
         return tid
 
+    def apply_normal_map(mat, mnode):
+        """LoadSceneMaterials (integrator_pt_scene.cpp:603-638): texid[1] = none, or the <displacement type="normal_bump"> map."""
+        mat["texid"][1] = UINT_MAX
+        disp = mnode.find("displacement")
+        if disp is None or disp.get("type") != "normal_bump":                 # other bump types: message only in the reference
+            return
+        nm = disp.find("normal_map")
+        bind_texture(mat, 1, nm)
+        inv = nm.find("invert") if nm is not None else None
+        flag = lambda name: inv is not None and int(float(inv.get(name, "0"))) == 1
+        cf = int(mat["cflags"])
+        if flag("x"):
+            cf |= FLAG_NMAP_INVERT_X
+        if flag("y"):
+            cf |= FLAG_NMAP_INVERT_Y
+        if flag("swap_xy"):
+            cf |= FLAG_NMAP_SWAP_XY
+        mat["cflags"] = cf
+
     def convert_gltf(mnode):
         """ConvertGLTFMaterial (integrator_pt_scene_mat.cpp:176-278)."""
         mat = zero_material()
@@ -896,7 +925,7 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
             for k in range(4):
                 if not np.any(mat["row0"][k]) and not np.any(mat["row1"][k]):
                     mat["row0"][k] = (1, 0, 0, 0); mat["row1"][k] = (0, 1, 0, 0)
-            mat["texid"][1] = UINT_MAX
+            apply_normal_map(mat, mnode)
             lid = int(mnode.get("light_id", -1))
             if 0 <= lid < len(sc.lights):
                 mat["colors"][EMISSION_COLOR] = sc.lights[lid]["intensity"]
@@ -1002,7 +1031,7 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
         for k in range(4):
             if not np.any(mat["row0"][k]) and not np.any(mat["row1"][k]):
                 mat["row0"][k] = (1, 0, 0, 0); mat["row1"][k] = (0, 1, 0, 0)
-        mat["texid"][1] = UINT_MAX
+        apply_normal_map(mat, mnode)
         if mat["mtype"] == MAT_TYPE_LIGHT_SOURCE:
             lid = int(mnode.get("light_id", -1))
             if 0 <= lid < len(sc.lights):                                     # LoadScene :973-996: the light's intensity wins

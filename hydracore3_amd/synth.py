@@ -331,4 +331,15 @@ def random_scene(seed: int, width=48, height=32) -> S.SceneData:
             L.append(S.light_rect(pos, 0.0, 0.0, c, mult, disk_radius=float(r.uniform(0.3, 0.8))))
         else:
             L.append(S.light_point(pos, c, mult, "omni"))
+    # normal maps on about a quarter of the surface materials (drawn last: the scenes of the earlier seeds keep their geometry and lights)
+    ny, nx = np.mgrid[0:8, 0:8]
+    dx, dy = 0.45 * np.sin(nx * np.pi / 2.0 + float(r.uniform(0, 3))), 0.45 * np.cos(ny * np.pi / 2.0 + float(r.uniform(0, 3)))
+    enc = lambda v: np.clip(np.rint((v * 0.5 + 0.5) * 255.0), 0, 255).astype(np.uint32)
+    nz = np.clip(np.rint(np.sqrt(1.0 - dx * dx - dy * dy) * 255.0), 0, 255).astype(np.uint32)
+    nmap = sc.add_texture(S.Texture(enc(dx) | (enc(dy) << 8) | (nz << 16) | np.uint32(0xFF000000), S.TEX_RGBA8, False, S.ADDR_WRAP, S.ADDR_WRAP,
+                                    int(r.choice([S.FILTER_NEAREST, S.FILTER_LINEAR]))))
+    for m in M:
+        if int(m["mtype"]) not in (S.MAT_TYPE_BLEND, S.MAT_TYPE_LIGHT_SOURCE) and r.uniform() < 0.25:
+            k = float(r.choice([1.0, 2.0, 5.0]))
+            S.set_normal_map(m, nmap, bool(r.randint(2)), bool(r.randint(2)), bool(r.randint(2)), (k, 0, 0, 0), (0, k, 0, 0))
     return sc

@@ -176,6 +176,22 @@ struct Ctx
     return four;
   }
 
+  // NormalMapTransform (include/cmaterial.h) + Integrator::BumpMapping (integrator_pt_mat.cpp:94-107). LiteMath (absent) supplies
+  // make_float3x3 / inverse3x3: taken as rows (tan, bitan, n) and the exact inverse by cofactors, inv(M) = [r1 x r2 | r2 x r0 | r0 x r1] / det.
+  f3 BumpMapping(const Material& m, f3 n, f3 tan, f2 tc) const
+  {
+    const f4 normalTex = sc.tex_sample(m.texid[1], mulRows2x4(m.row0[1], m.row1[1], tc));
+    f3 ts = mk3(2.0f * normalTex.x - 1.0f, 2.0f * normalTex.y - 1.0f, normalTex.z);
+    if ((m.cflags & FLAG_NMAP_INVERT_X) != 0) ts.x *= -1.0f;
+    if ((m.cflags & FLAG_NMAP_INVERT_Y) != 0) ts.y *= -1.0f;
+    if ((m.cflags & FLAG_NMAP_SWAP_XY) != 0) { const float t = ts.x; ts.x = ts.y; ts.y = t; }
+    const f3 bitan = cross(n, tan);
+    const f3 c0 = cross(bitan, n), c1 = cross(n, tan), c2 = cross(tan, bitan);
+    const float det = dot(tan, c0);
+    const f3 w = (ts.x * c0 + ts.y * c1 + ts.z * c2) / det;
+    return normalize(w);
+  }
+
   BsdfSample MaterialSampleAndEval(uint a_materialId, RandomGen* a_gen, f3 v, f3 n, f3 tan, f2 tc, MisData* a_misPrev, uint a_currRayFlags, Record* rec, uint bounce) const   // :109-306
   {
     BsdfSample res;
@@ -191,8 +207,10 @@ struct Ctx
       else                 { res.pdf *= 1.0f - weight; res.val = res.val * (1.0f - weight); currMatId = bm.datai[0]; }
     }
     const Material& m = sc.materials[currMatId];
-    const uint mtype = m.mtype;                         // bump mapping: out of scope
-    const f3 shadeNormal = n;
+    const uint mtype = m.mtype;
+    const uint normalMapId = m.texid[1];                // :131-139: the leaf's normal map bends the shading normal
+    const f3 geomNormal = n;
+    const f3 shadeNormal = (normalMapId != 0xFFFFFFFFu) ? BumpMapping(m, geomNormal, tan, tc) : n;
     const f2 texCoordT = mulRows2x4(m.row0[0], m.row1[0], tc);
     const f4 texColor = sc.tex_sample(m.texid[0], texCoordT);
     const f4 rands = rndFloat4(a_gen);                  // GetRandomNumbersMats, drawn for every material type (:147)
@@ -218,7 +236,7 @@ struct Ctx
         reflSpec = reflSpec * texColor;
         diffuseSampleAndEval(m, reflSpec, rands, v, shadeNormal, tc, &res);
       } break;
-      case MAT_TYPE_GLASS: glassSampleAndEval(m, rands, v, shadeNormal, &res, &a_misPrev->ior); break;   // integrator_pt_mat.cpp:178-183 (geomNormal == shadeNormal without bump)
+      case MAT_TYPE_GLASS: glassSampleAndEval(m, rands, v, geomNormal, &res, &a_misPrev->ior); break;    // integrator_pt_mat.cpp:178-183: the geometric normal
       case MAT_TYPE_DIELECTRIC: {
         const f4 intIORSpec = splat4(m.data[DIELECTRIC_ETA_INT]);
         const uint specId = m.spdid[0];
@@ -227,6 +245,11 @@ struct Ctx
         a_misPrev->ior = res.ior;
       } break;
       default: break;
+    }
+    if (normalMapId != 0xFFFFFFFFu) {                   // :298-303: the caller multiplies by cos to the geometric normal
+      const float cosThetaOut1 = std::abs(dot(res.dir, geomNormal));
+      const float cosThetaOut2 = std::abs(dot(res.dir, shadeNormal));
+      res.val = res.val * (cosThetaOut2 / std::max(cosThetaOut1, 1e-10f));
     }
     return res;
   }
@@ -242,8 +265,15 @@ struct Ctx
     do {
       if (needPop) { top--; currMat = stack[std::max(top, 0)]; } else needPop = true;
       const Material& m = sc.materials[currMat.id];
-      const f3 shadeNormal = n;
-      const float weight = currMat.weight, bumpCosMult = 1.0f;
+      f3 shadeNormal = n;
+      const float weight = currMat.weight;
+      float bumpCosMult = 1.0f;
+      if (m.texid[1] != 0xFFFFFFFFu) {                                                // :341-355
+        shadeNormal = BumpMapping(m, n, tan, tc);
+        const float cosThetaOut1 = std::max(dot(l, n), 0.0f), cosThetaOut2 = std::max(dot(l, shadeNormal), 0.0f);
+        bumpCosMult = cosThetaOut2 / std::max(cosThetaOut1, 1e-6f);
+        if (cosThetaOut1 <= 0.0f) bumpCosMult = 0.0f;
+      }
       const f2 texCoordT = mulRows2x4(m.row0[0], m.row1[0], tc);
       const f4 texColor = sc.tex_sample(m.texid[0], texCoordT);
       const f4 four = fourScalarMatParams(m, tc);

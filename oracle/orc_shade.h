@@ -20,6 +20,7 @@ static const uint RAY_FLAG_FIRST_NON_SPEC = 0x01000000u;
 
 // ---- include/cmaterial.h:26-56 --------------------------------------------------------------------------------
 static const uint GLTF_COMPONENT_METAL = 4, GLTF_COMPONENT_ORENNAYAR = 16, FLAG_FOUR_TEXTURES = 256, FLAG_PACK_FOUR_PARAMS_IN_TEXTURE = 512;
+static const uint FLAG_NMAP_INVERT_X = 32, FLAG_NMAP_INVERT_Y = 64, FLAG_NMAP_SWAP_XY = 128;                 // include/cmaterial.h:31-33
 static const uint MAT_TYPE_BLEND = 6, BLEND_WEIGHT = 0, BLEND_STACK_SIZE = 4;   // include/cmaterial.h:43,155; integrator_pt.h:599
 static const uint MAT_TYPE_GLASS = 2;   // include/cmaterial.h:39; slots :85-92
 static const uint GLASS_COLOR_REFLECT = 0, GLASS_COLOR_TRANSP = 1, GLASS_FLOAT_IOR = 2;

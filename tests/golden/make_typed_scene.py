@@ -3,7 +3,7 @@
 LoadSceneMaterials (integrator_pt_scene.cpp:500-570) - gltf (ConvertGLTFMaterial, with colour / glossiness / metalness textures and the
 packed glossiness_metalness_coat form), rough_conductor (alpha and alpha_u / alpha_v), diffuse (Lambert, Oren-Nayar, textured),
 dielectric, blend (constant and texture-masked weight, nested) - the sampler attributes of ReadSamplerFromColorNode (addressing modes,
-point filter, texture matrix, input_gamma) and a remap list. Own data, not the reference's: the two loaders (Python, C++) are checked
+point filter, texture matrix, input_gamma) a remap list, and normal-map bump (<displacement type="normal_bump">, with and without the invert / swap flags, also on a blend leaf). Own data, not the reference's: the two loaders (Python, C++) are checked
 against each other on it and the GPU against the oracle."""
 import os
 import struct
@@ -37,6 +37,14 @@ def main():
     prm[..., 0] = rng.uniform(0.55, 0.95, (4, 4)); prm[..., 1] = rng.uniform(0.0, 0.8, (4, 4)); prm[..., 2] = rng.uniform(0.3, 1.0, (4, 4)); prm[..., 3] = 1.0
     open(os.path.join(OUT, "data", "chunk_00003.image4f"), "wb").write(struct.pack("<II", 4, 4) + prm.astype("<f4").tobytes())
 
+    # texture 4: a tangent-space normal map (LDR, linear): gentle bumps around +z
+    ny, nx = np.mgrid[0:16, 0:16]
+    dx, dy = 0.35 * np.sin(nx * np.pi / 4.0), 0.35 * np.cos(ny * np.pi / 4.0)
+    nz = np.sqrt(np.maximum(1.0 - dx * dx - dy * dy, 0.0))
+    enc = lambda v: np.clip(np.rint((v * 0.5 + 0.5) * 255.0), 0, 255).astype(np.uint32)
+    nrm = enc(dx) | (enc(dy) << 8) | (np.clip(np.rint(nz * 255.0), 0, 255).astype(np.uint32) << 16) | np.uint32(0xFF000000)
+    open(os.path.join(OUT, "data", "chunk_00018.image4ub"), "wb").write(struct.pack("<II", 16, 16) + nrm.astype("<u4").tobytes())
+
     sp = synth._sphere_mesh(2)
     pad4 = lambda a: np.concatenate([np.asarray(a, np.float32).reshape(-1, 3), np.zeros((len(a), 1), np.float32)], 1) if np.asarray(a).shape[-1] == 3 else np.asarray(a, np.float32)
     ntri = sp[4].size // 3
@@ -48,16 +56,18 @@ def main():
     lq = synth._quad((-1, 0, -1), (2, 0, 0), (0, 0, 2))
     write_vsgf(os.path.join(OUT, "data", "chunk_00017.vsgf"), pad4(lq[0]), pad4(lq[1]), pad4(lq[2]), np.asarray(lq[3], np.float32), np.asarray(lq[4], np.uint32), np.full(lq[4].size // 3, 13, np.uint32))
     ident = "1 0 0 0 0 1 0 0 0 0 1 0 0 0 0 1"
+    BUMP = '<displacement type="normal_bump"><normal_map><invert x="0" y="0" swap_xy="0" /><texture id="4" type="texref" matrix="2 0 0 0 0 2 0 0 0 0 1 0 0 0 0 1" input_gamma="1" /></normal_map></displacement>'
+    BUMP_INV = BUMP.replace('x="0" y="0" swap_xy="0"', 'x="1" y="1" swap_xy="1"').replace('matrix="2 0 0 0 0 2', 'filter="point" matrix="3 0 0 0 0 3')
     mats = [
         f'<material id="0" name="floor" type="diffuse"><bsdf type="lambert" /><reflectance val="0.8 0.8 0.8"><texture id="1" type="texref" matrix="2 0 0 0.25 0 2 0 0.5 0 0 1 0 0 0 0 1" addressing_mode_u="wrap" addressing_mode_v="wrap" input_gamma="2.2" input_alpha="rgb" /></reflectance></material>',
-        '<material id="1" name="gltf_plain" type="gltf"><color val="0.7 0.25 0.2" /><glossiness val="0.7" /><metalness val="0.1" /><fresnel_ior val="1.45" /><coat val="0.8" /></material>',
+        f'<material id="1" name="gltf_plain" type="gltf"><color val="0.7 0.25 0.2" /><glossiness val="0.7" /><metalness val="0.1" /><fresnel_ior val="1.45" /><coat val="0.8" />{BUMP}</material>',
         f'<material id="2" name="gltf_textured" type="gltf"><color val="0.9 0.9 0.9"><texture id="1" type="texref" matrix="{ident}" addressing_mode_u="clamp" addressing_mode_v="clamp" input_gamma="2.2" /></color><roughness val="0.4" /><metalness val="0.3" /></material>',
         f'<material id="3" name="gltf_four" type="gltf"><color val="0.3 0.5 0.8" /><glossiness val="1.0"><texture id="3" type="texref" matrix="{ident}" input_gamma="1" /></glossiness><metalness val="1.0"><texture id="3" type="texref" matrix="3 0 0 0 0 3 0 0 0 0 1 0 0 0 0 1" filter="point" input_gamma="1" /></metalness></material>',
         f'<material id="4" name="gltf_packed" type="gltf"><color val="0.8 0.7 0.3" /><glossiness_metalness_coat val="1.0"><texture id="3" type="texref" matrix="{ident}" input_gamma="1" /></glossiness_metalness_coat></material>',
-        '<material id="5" name="gold" type="rough_conductor"><bsdf type="ggx" /><alpha val="0.15" /><eta val="0.2" /><k val="3.6" /><reflectance val="1.0 0.8 0.4" /></material>',
+        f'<material id="5" name="gold" type="rough_conductor"><bsdf type="ggx" /><alpha val="0.15" /><eta val="0.2" /><k val="3.6" /><reflectance val="1.0 0.8 0.4" />{BUMP}</material>',
         '<material id="6" name="brushed" type="rough_conductor"><bsdf type="ggx" /><alpha_u val="0.05" /><alpha_v val="0.35" /><eta val="1.1" /><k val="6.8" /></material>',
         '<material id="7" name="mirror" type="rough_conductor"><bsdf type="ggx" /><alpha val="0" /><eta val="0.2" /><k val="3.9" /></material>',
-        '<material id="8" name="orennayar" type="diffuse"><bsdf type="oren-nayar" /><roughness val="0.7" /><reflectance val="0.3 0.6 0.3" /></material>',
+        f'<material id="8" name="orennayar" type="diffuse"><bsdf type="oren-nayar" /><roughness val="0.7" /><reflectance val="0.3 0.6 0.3" />{BUMP_INV}</material>',
         f'<material id="9" name="diffuse_point" type="diffuse"><bsdf type="lambert" /><reflectance val="1 1 1"><texture id="2" type="texref" matrix="{ident}" filter="point" input_gamma="1" /></reflectance></material>',
         '<material id="10" name="glass" type="dielectric"><int_ior val="1.5" /><ext_ior val="1.0" /><reflectance val="1 1 1" /><transmittance val="0.95 1 0.95" /></material>',
         f'<material id="11" name="masked" type="blend"><bsdf_1 id="5" /><bsdf_2 id="8" /><weight val="1.0"><texture id="2" type="texref" matrix="2 0 0 0 0 2 0 0 0 0 1 0 0 0 0 1" input_gamma="1" /></weight></material>',
@@ -80,6 +90,7 @@ def main():
   <texture id="1" name="noise" loc="data/chunk_00001.image4ub" offset="8" bytesize="256" width="8" height="8" />
   <texture id="2" name="checker" loc="data/chunk_00002.image4ub" offset="8" bytesize="256" width="8" height="8" />
   <texture id="3" name="params" loc="data/chunk_00003.image4f" offset="8" bytesize="256" width="4" height="4" />
+  <texture id="4" name="normals" loc="data/chunk_00018.image4ub" offset="8" bytesize="1024" width="16" height="16" />
 </textures_lib>
 <materials_lib>
   {chr(10).join("  " + m for m in mats)}

@@ -748,7 +748,7 @@ HPT_DEV float lightEvalPDF(const LightRec& L, V3 illuminationPoint, V3 ray_dir, 
   return pdfAtoW(L.pdfA, hitDist, cosVal);
 }
 
-HPT_DEV V3 lightIntensity(const DevScene& S, const LightRec& L, V3 a_rayPos, V3 a_rayDir)   // :109-173 (RGB; env / projective out of scope)
+HPT_DEV V3 lightIntensity(const DevScene& S, const LightRec& L, V3 a_rayPos, V3 a_rayDir)   // :109-173 (RGB; projective lights out of scope)
 {
   V3 lightColor = ld3(L.intensity);
   lightColor = lightColor * L.mult;
@@ -765,7 +765,103 @@ HPT_DEV V3 lightIntensity(const DevScene& S, const LightRec& L, V3 a_rayPos, V3 
     const float t = smin(smax(tVal, 0.0f), 1.0f);
     lightColor = lightColor * (t * t * (3.0f - 2.0f * t));
   }
+  else if (L.texId != 0xFFFFFFFFu) {                                    // :163-170: the environment map seen along the shadow ray
+    const V2 tc = mulRows2x4(L.samplerRow0, L.samplerRow1, sphereMapTo2DTexCoord(a_rayDir));
+    const V4 texColor = texSample(S.textures, L.texId, tc);
+    lightColor = lightColor * v3(texColor.x, texColor.y, texColor.z);
+  }
   return lightColor;
+}
+
+// ---- sampled environment map: include/clight.h:128-218, integrator_pt_lgt.cpp:30-55, 175-236, cglobals.h:360-373 -----------------------------
+HPT_DEV int selectIndexPropToOpt(float a_r, const float* a_accum, int N, float& pdf)
+{
+  int leftBound = 0, rightBound = N - 2, counter = 0, currPos = -1;
+  const float x = a_r * a_accum[N - 1];
+  while (rightBound - leftBound > 1 && counter < 50) {
+    const int currSize = rightBound + leftBound;
+    const int currPos1 = (currSize % 2 == 0) ? (currSize + 1) / 2 : (currSize + 0) / 2;
+    const float a = a_accum[currPos1 + 0], b = a_accum[currPos1 + 1];
+    if (a < x && x <= b) { currPos = currPos1; break; }
+    else if (x <= a) rightBound = currPos1;
+    else if (x > b) leftBound = currPos1;
+    counter++;
+  }
+  if (currPos < 0) {
+    const float a1 = a_accum[leftBound + 0], b1 = a_accum[leftBound + 1], a2 = a_accum[rightBound + 0], b2 = a_accum[rightBound + 1];
+    if (a1 < x && x <= b1) currPos = leftBound;
+    if (a2 < x && x <= b2) currPos = rightBound;
+  }
+  if (x == 0.0f) currPos = 0;
+  else if (currPos < 0) currPos = (rightBound + leftBound + 1) / 2;
+  pdf = (a_accum[currPos + 1] - a_accum[currPos]) / a_accum[N - 1];
+  return currPos;
+}
+HPT_DEV float evalMap2DPdf(V2 tc, const float* intervals, int sizeX, int sizeY)
+{
+  const float fw = (float)sizeX, fh = (float)sizeY;
+  if (tc.x < 0.0f || tc.x > 1.0f) tc.x -= (float)((int)(tc.x));
+  if (tc.y < 0.0f || tc.x > 1.0f) tc.y -= (float)((int)(tc.y));                 // (sic: .x in the second test, clight.h:199)
+  int pixelX = (int)(fw * tc.x - 0.5f), pixelY = (int)(fh * tc.y - 0.5f);
+  if (pixelX >= sizeX) pixelX = sizeX - 1;
+  if (pixelY >= sizeY) pixelY = sizeY - 1;
+  if (pixelX < 0) pixelX += sizeX;
+  if (pixelY < 0) pixelY += sizeY;
+  const int pixelOffset = pixelY * sizeX + pixelX, maxSize = sizeX * sizeY;
+  const int offset0 = (pixelOffset + 0 < maxSize + 0) ? pixelOffset + 0 : maxSize - 1;
+  const int offset1 = (pixelOffset + 1 < maxSize + 1) ? pixelOffset + 1 : maxSize;
+  return (intervals[offset1] - intervals[offset0]) * (fw * fh) / intervals[sizeX * sizeY];
+}
+// LightSampleRev, LIGHT_GEOM_ENV: SampleMap2D over the pdf table, inverse sampler transform, lat-long to direction
+HPT_DEV LightSam envLightSampleRev(const DevScene& S, const LightRec& L, V3 rands, V3 illuminationPoint)
+{
+  const int sizeX = (int)L.pdfTableSizeX, sizeY = (int)L.pdfTableSizeY;
+  const float fw = (float)sizeX, fh = (float)sizeY, fN = fw * fh;
+  float pdf = 1.0f;
+  int pixelOffset = selectIndexPropToOpt(rands.z, S.arrays1f + L.pdfTableOffset, sizeX * sizeY + 1, pdf);
+  if (pixelOffset >= sizeX * sizeY) pixelOffset = sizeX * sizeY - 1;
+  const int yPos = pixelOffset / sizeX, xPos = pixelOffset - yPos * sizeX;
+  const float texX = (1.0f / fw) * (((float)(xPos) + 0.5f) + (rands.x * 2.0f - 1.0f) * 0.5f);
+  const float texY = (1.0f / fh) * (((float)(yPos) + 0.5f) + (rands.y * 2.0f - 1.0f) * 0.5f);
+  const float mapPdf = pdf * fN;
+  const V2 tcT = mulRows2x4(L.samplerRow0Inv, L.samplerRow1Inv, v2(texX, texY));
+  const float phi = tcT.x * 2.f * HPT_PI, theta = tcT.y * HPT_PI;                // texCoord2DToSphereMap
+  const float sinTheta = sinf(theta);
+  const float x = sinTheta * cosf(phi), y = sinTheta * sinf(phi), z = cosf(theta);
+  const V3 sampleDir = v3(y, -z, x);
+  LightSam r;
+  r.hasIES = false; r.isOmni = true; r.norm = sampleDir;
+  r.pos = illuminationPoint + sampleDir * 1000.0f;
+  r.pdf = (mapPdf * 1.0f) / (2.f * HPT_PI * HPT_PI * smax(absf(sinTheta), 1e-20f));
+  return r;
+}
+// kernel_HitEnvironment (integrator_pt.cpp:550-595) + EnvironmentColor (integrator_pt_lgt.cpp:175-210): what a ray that left the scene sees
+HPT_DEV V3 environmentRadiance(const DevScene& S, V3 rdir, float misPdf, uint flags, uint XY)
+{
+  V3 color = ld3(S.envColor);
+  if (S.envTexId == 0xFFFFFFFFu && S.envCamBackId == 0xFFFFFFFFu) return color;   // (the plain-colour case: nothing else can apply)
+  float envPdf = 1.0f;
+  if (S.envTexId != 0xFFFFFFFFu) {
+    const float sinTheta = sqrtf_(1.0f - rdir.y * rdir.y);
+    const V2 tcT = mulRows2x4(S.envSamRow0, S.envSamRow1, sphereMapTo2DTexCoord(rdir));
+    if (sinTheta != 0.f && S.envEnableSam != 0 && S.integratorType == INTEGRATOR_MIS_PT && S.envLightId != 0xFFFFFFFFu) {
+      const LightRec& L = S.lights[S.envLightId];
+      const float mapPdf = evalMap2DPdf(tcT, S.arrays1f + L.pdfTableOffset, (int)L.pdfTableSizeX, (int)L.pdfTableSizeY);
+      envPdf = (mapPdf * 1.0f) / (2.f * HPT_PI * HPT_PI * smax(absf(sinTheta), 1e-20f));
+    }
+    const V4 t = texSample(S.textures, S.envTexId, tcT);
+    color = color * v3(t.x, t.y, t.z);
+  }
+  const bool isSpec = misPdf < 0.0f, exitZero = (flags & RAY_FLAG_PRIME_RAY_MISS) != 0;
+  if (S.integratorType == INTEGRATOR_MIS_PT && S.envEnableSam != 0 && !isSpec && !exitZero)
+    color = color * misWeightHeuristic(misPdf, (1.0f / float(S.numLights)) * envPdf);
+  else if (S.integratorType == INTEGRATOR_SHADOW_PT && S.envEnableSam != 0) color = v3(0, 0, 0);
+  if (exitZero && S.envCamBackId != 0xFFFFFFFFu) {                               // the camera back plate
+    const uint x = XY & 0x0000FFFFu, y = (XY & 0xFFFF0000u) >> 16;
+    const V4 t = texSample(S.textures, S.envCamBackId, v2((float(x) + 0.5f) / float(S.winWidth), (float(y) + 0.5f) / float(S.winHeight)));
+    color = v3(t.x, t.y, t.z);
+  }
+  return color;
 }
 
 // RemapMaterialId (integrator_pt_mat.cpp:530-573)

@@ -76,6 +76,9 @@ struct hpt_ctx
   DevBuf<int> dRemapInst, dRemapLists;
   DevBuf<MaterialRec> dMaterials; DevBuf<LightRec> dLights; DevBuf<TexRec> dTextures;
   std::vector<void*> texData; std::vector<TexRec> hTextures;
+  DevBuf<float> dArrays1f; size_t numArrays1f = 0;       // m_arrays1f (pdf table of a sampled environment map)
+  std::vector<uint> hLightGeom;                          // geomType of every light, to validate m_envLightId
+  bool envLightOk(uint id) const { return id < hLightGeom.size() && hLightGeom[id] == LIGHT_GEOM_ENV; }
   DevBuf<Rng> dGens;
   DevBuf<uint> dQueue, dStackOvf; DevBuf<Counters> dCounters;
   DevBuf<float> dFrame, dRecord, dRef, dData, dGrad, dLoss; DevBuf<double> dLossAcc;
@@ -156,7 +159,7 @@ extern "C" void hpt_destroy(hpt_ctx* c)
   (void)hpt_comm_destroy(c);
   c->dNodes.release(); c->dTris.release(); c->dInsts.release(); c->dTriIndices.release(); c->dMatIdByPrim.release();
   c->dMatVertOffset.release(); c->dPackedXY.release(); c->dVData.release(); c->dNormMat.release(); c->dRemapInst.release();
-  c->dRemapLists.release(); c->dMaterials.release(); c->dLights.release(); c->dTextures.release(); c->dGens.release();
+  c->dRemapLists.release(); c->dMaterials.release(); c->dLights.release(); c->dTextures.release(); c->dArrays1f.release(); c->dGens.release();
   c->dQueue.release(); c->dStackOvf.release(); c->dCounters.release(); c->dFrame.release(); c->dRecord.release(); c->dRef.release(); c->dData.release();
   c->dGrad.release(); c->dLoss.release(); c->dLossAcc.release();
   for (hpt_ctx::WfGroup* g : c->wfGroups) {
@@ -493,10 +496,15 @@ static int check_materials(hpt_ctx* c, const MaterialRec* m, size_t n, size_t nu
   }
   return HPT_OK;
 }
-static int check_lights(hpt_ctx* c, const LightRec* l, size_t n, size_t numTex)
+static int check_lights(hpt_ctx* c, const LightRec* l, size_t n, size_t numTex, size_t numArrays1f)
 {
   for (size_t i = 0; i < n; i++) {
-    if (l[i].geomType == LIGHT_GEOM_ENV) return c->fail(HPT_ERR_UNSUPPORTED, "sampled environment-map lights are outside the hot path's scope");
+    if (l[i].geomType == LIGHT_GEOM_ENV) {                                // a sampled environment map: its pdf table must lie inside m_arrays1f
+      const uint64_t need = (uint64_t)l[i].pdfTableSizeX * l[i].pdfTableSizeY + 1u;
+      if (l[i].pdfTableSizeX == 0 || l[i].pdfTableSizeY == 0 || (uint64_t)l[i].pdfTableOffset + need > numArrays1f || l[i].pdfTableSize < need)
+        return c->fail(HPT_ERR_ARG, "environment light: pdf table outside m_arrays1f");
+      if (l[i].texId != 0xFFFFFFFFu && l[i].texId >= numTex) return c->fail(HPT_ERR_ARG, "environment light refers to a texture that does not exist");
+    }
     if (l[i].geomType < LIGHT_GEOM_RECT || l[i].geomType > LIGHT_GEOM_ENV) return c->fail(HPT_ERR_ARG, "bad light geomType");
     if (l[i].iesId != 0xFFFFFFFFu && l[i].iesId >= numTex) return c->fail(HPT_ERR_ARG, "light refers to an IES texture that does not exist");
   }
@@ -511,7 +519,8 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
   if (d->numTextures == 0 || !d->textures) return c->fail(HPT_ERR_ARG, "m_textures must at least hold the white dummy texture");
   int rc = check_materials(c, (const MaterialRec*)d->materials, d->numMaterials, d->numTextures, d->numMaterials); if (rc) return rc;
   c->leanMaterials = lean_materials((const MaterialRec*)d->materials, d->numMaterials);
-  rc = check_lights(c, (const LightRec*)d->lights, d->numLights, d->numTextures); if (rc) return rc;
+  if (d->numArrays1f && !d->arrays1f) return c->fail(HPT_ERR_ARG, "m_arrays1f: count without data");
+  rc = check_lights(c, (const LightRec*)d->lights, d->numLights, d->numTextures, d->numArrays1f); if (rc) return rc;
 
   if (d->vPos4f) {                                                     // LoadSceneGeometry + LoadSceneInstances order
     hpt_clear_geom(c);
@@ -575,6 +584,14 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
   S.triIndices = c->dTriIndices.p; S.vData8f = c->dVData.p; S.matIdByPrimId = c->dMatIdByPrim.p; S.matVertOffset = c->dMatVertOffset.p;
   S.normMat = c->dNormMat.p; S.remapInst = c->dRemapInst.p; S.allRemapLists = c->dRemapLists.p; S.allRemapListsSize = d->allRemapListsSize;
   S.numLights = d->numLights; S.materials = c->dMaterials.p; S.lights = c->dLights.p; S.textures = c->dTextures.p;
+  c->numArrays1f = d->numArrays1f;
+  { std::vector<float> a(d->numArrays1f ? d->arrays1f : nullptr, d->numArrays1f ? d->arrays1f + d->numArrays1f : nullptr); if (a.empty()) a.push_back(0.0f);
+    HIPCHK(c, c->dArrays1f.upload(a.data(), a.size())); }
+  S.arrays1f = c->dArrays1f.p;
+  c->hLightGeom.resize(d->numLights);
+  for (uint i = 0; i < d->numLights; i++) c->hLightGeom[i] = ((const LightRec*)d->lights)[i].geomType;
+  // a new scene invalidates the environment ids of the previous UpdateMembersPlainData until the next one
+  S.envTexId = S.envLightId = S.envCamBackId = 0xFFFFFFFFu; S.envEnableSam = 0;
   c->sceneUploaded = true;
   c->tPathTrace[1] = c->tNaive[1] = c->tDR[1] = float(now_ms() - t0);   // host -> device time of the scene commit
   return HPT_OK;
@@ -592,6 +609,15 @@ extern "C" int hpt_update_params(hpt_ctx* c, const hpt_params* p)
   S.traceDepth = p->traceDepth; S.integratorType = p->integratorType; S.renderLayer = p->renderLayer; S.tileSize = p->tileSize;
   S.exposureMult = p->exposureMult; S.camLensRadius = p->camLensRadius; S.camTargetDist = p->camTargetDist;
   std::memcpy(S.camRespoceRGB, p->camRespoceRGB, 16); std::memcpy(S.envColor, p->envColor, 16);
+  // the environment map (integrator_pt_scene.cpp:441-478): ids are checked against what CommitDeviceData uploaded
+  if ((p->envTexId != 0xFFFFFFFFu || p->envCamBackId != 0xFFFFFFFFu || p->envLightId != 0xFFFFFFFFu) && !c->sceneUploaded)
+    return c->fail(HPT_ERR_STATE, "UpdateMembersPlainData with an environment map before CommitDeviceData");
+  if (p->envTexId != 0xFFFFFFFFu && p->envTexId >= c->hTextures.size()) return c->fail(HPT_ERR_ARG, "m_envTexId refers to a texture that does not exist");
+  if (p->envCamBackId != 0xFFFFFFFFu && p->envCamBackId >= c->hTextures.size()) return c->fail(HPT_ERR_ARG, "m_envCamBackId refers to a texture that does not exist");
+  if (p->envLightId != 0xFFFFFFFFu && (p->envLightId >= c->S.numLights || !c->envLightOk(p->envLightId))) return c->fail(HPT_ERR_ARG, "m_envLightId is not a LIGHT_GEOM_ENV light with a pdf table");
+  if (p->envEnableSam != 0 && p->envLightId == 0xFFFFFFFFu) return c->fail(HPT_ERR_ARG, "m_envEnableSam without m_envLightId");
+  S.envTexId = p->envTexId; S.envLightId = p->envLightId; S.envCamBackId = p->envCamBackId; S.envEnableSam = p->envEnableSam;
+  std::memcpy(S.envSamRow0, p->envSamRow0, 16); std::memcpy(S.envSamRow1, p->envSamRow1, 16);
   c->paramsSet = true;
   return HPT_OK;
 }
@@ -610,7 +636,8 @@ extern "C" int hpt_update_lights(hpt_ctx* c, size_t first, size_t count, const v
 {
   if (!c || !lights) return HPT_ERR_ARG;
   if (first + count > c->S.numLights) return c->fail(HPT_ERR_ARG, "Update_m_lights: range out of bounds");
-  int rc = check_lights(c, (const LightRec*)lights, count, c->hTextures.size()); if (rc) return rc;
+  int rc = check_lights(c, (const LightRec*)lights, count, c->hTextures.size(), c->numArrays1f); if (rc) return rc;
+  for (size_t i = 0; i < count; i++) c->hLightGeom[first + i] = ((const LightRec*)lights)[i].geomType;
   (void)hipSetDevice(c->device);
   HIPCHK(c, hipMemcpy(c->dLights.p + first, lights, count * sizeof(LightRec), hipMemcpyHostToDevice));
   return HPT_OK;
@@ -707,7 +734,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   HIPCHK(c, c->dQueue.alloc(1));
   HIPCHK(c, hipMemsetAsync(c->dQueue.p, 0, 4, st));
   job.queue = c->dQueue.p;
-  job.gens = c->dGens.p; job.packedXY = c->dPackedXY.p;
+  job.gens = c->dGens.p; job.packedXY = c->dPackedXY.p; job.packedCount = c->packedCount;
   job.counters = nullptr;
   const bool stats = c->instrument && !dr;
   c->lastSchedule = 1;

@@ -29,6 +29,7 @@ struct Job
   float* outColor;                // full W*H*channels framebuffer (device)
   Rng*   gens;                    // m_randomGens (device, persistent)
   const uint* packedXY;           // m_packedXY
+  uint  packedCount;              // entries in packedXY (the input-ray mode reads it only for the camera back plate)
   uint*  queue;                   // work-queue head (zeroed before launch)
   Counters* counters;             // instrumentation (STATS builds)
   // differentiable rendering
@@ -182,7 +183,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevS
       if ((flags & RAY_FLAG_IS_DEAD) != 0 || bounce >= maxBounce) {
         // kernel_HitEnvironment (integrator_pt.cpp:550-595), constant environment colour.
         // The DR replay adds the environment term unconditionally (diff_render/integrator_dr.cpp:1077-1098).
-        const V3 env = ld3(S.envColor);
+        const V3 env = DR ? ld3(S.envColor) : environmentRadiance(S, rdir, misPdf, flags, INRAYS ? (PIX_TID < job.packedCount ? job.packedXY[PIX_TID] : 0u) : PIX_XY);
         if (DR) accum = accum + thr * env;
         else if ((flags & RAY_FLAG_OUT_OF_SCENE) != 0) {
           if (S.integratorType == INTEGRATOR_STUPID_PT) accum = thr * env; else accum = accum + thr * env;

@@ -201,7 +201,7 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
       const int lightId = min((int)floorf(rndId * float(nLights)), nLights - 1);
       if (lightId >= 0 && mtype != MAT_TYPE_LIGHT_SOURCE) {
         const LightRec& L = S.lights[lightId];
-        const LightSam ls = lightSampleRev(L, v3(r4.x, r4.y, r4.z), hitPos);
+        const LightSam ls = (L.geomType == LIGHT_GEOM_ENV) ? envLightSampleRev(S, L, v3(r4.x, r4.y, r4.z), hitPos) : lightSampleRev(L, v3(r4.x, r4.y, r4.z), hitPos);
         const V3 dlt = hitPos - ls.pos;
         const float hitDist = sqrtf_(dot(dlt, dlt));
         const V3 shadowRayDir = normalize(ls.pos - hitPos);

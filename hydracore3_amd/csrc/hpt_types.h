@@ -88,6 +88,7 @@ struct DevScene
   const MaterialRec* materials;
   const LightRec*    lights;
   const TexRec*      textures;
+  const float*       arrays1f;    // m_arrays1f: pdf table of the sampled environment map
 
   // plain-data members (UpdateMembersPlainData)
   float projInv[16], worldViewInv[16];
@@ -95,6 +96,8 @@ struct DevScene
   uint  traceDepth, integratorType, renderLayer, tileSize;
   float exposureMult, camLensRadius, camTargetDist;
   float camRespoceRGB[4], envColor[4];
+  uint  envTexId, envLightId, envCamBackId, envEnableSam;   // m_envTexId, m_envLightId, m_envCamBackId, m_envEnableSam (0xFFFFFFFF: none)
+  float envSamRow0[4], envSamRow1[4];
 };
 
 struct Counters { unsigned long long v[16]; };  // rays, nodes, tris, surfaceHits, shadowRays, paths, instEnter, texFetch,

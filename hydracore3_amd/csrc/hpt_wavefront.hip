@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256, HPT_WF_SHADE_WAVES) wfShadeKernel(const D
       if (didBounce) bounce++;
       if ((flags & RAY_FLAG_IS_DEAD) != 0 || bounce >= S.traceDepth) {
         if (!DR && (flags & RAY_FLAG_OUT_OF_SCENE) != 0) {                  // kernel_HitEnvironment (integrator_pt.cpp:550-595)
-          const V3 env = ld3(S.envColor);
+          const V3 env = environmentRadiance(S, rdir, misPdf, flags, XY);
           if (S.integratorType == INTEGRATOR_STUPID_PT) accum = thr * env; else accum = accum + thr * env;
         }
         alive = false;

@@ -139,6 +139,8 @@ public:
     p.traceDepth = m_traceDepth; p.integratorType = m_intergatorType; p.renderLayer = m_renderLayer; p.tileSize = m_tileSize; p.spectralMode = uint32_t(m_spectral_mode);
     p.exposureMult = m_exposureMult; p.camLensRadius = m_camLensRadius; p.camTargetDist = m_camTargetDist;
     std::memcpy(p.camRespoceRGB, m_camRespoceRGB, 16); std::memcpy(p.envColor, m_envColor, 16);
+    p.envTexId = m_envTexId; p.envLightId = m_envLightId; p.envCamBackId = m_envCamBackId; p.envEnableSam = m_envEnableSam;
+    std::memcpy(p.envSamRow0, m_envSamRow0, 16); std::memcpy(p.envSamRow1, m_envSamRow1, 16);
     report(hpt_update_params(m_ctx, &p), "UpdateMembersPlainData");
   }
   virtual void PackXYBlock(uint32_t tidX, uint32_t tidY, uint32_t /*a_passNum*/)
@@ -179,6 +181,8 @@ public:
   int      m_spectral_mode = 0;
   float    m_exposureMult = 1.0f, m_camLensRadius = 0.0f, m_camTargetDist = 0.0f;
   float    m_camRespoceRGB[4] = {1, 1, 1, 1}, m_envColor[4] = {0, 0, 0, 0};
+  uint32_t m_envTexId = 0xFFFFFFFFu, m_envLightId = 0xFFFFFFFFu, m_envCamBackId = 0xFFFFFFFFu, m_envEnableSam = 0;   // integrator_pt.h (environment map)
+  float    m_envSamRow0[4] = {1, 0, 0, 0}, m_envSamRow1[4] = {0, 1, 0, 0};
 
   hpt_ctx* context() const { return m_ctx; }
 

@@ -155,6 +155,10 @@ struct LoadedScene
   double fov = 45.0, nearClip = 0.01, farClip = 100.0, camPos[3] = {0, 0, 15}, camLookAt[3] = {0, 0, 0}, camUp[3] = {0, 1, 0};
   uint32_t traceDepth = 6, spp = 1;
   float envColor[4] = {0, 0, 0, 0};
+  // the environment map of LoadSceneLights (integrator_pt_scene.cpp:441-478) and m_arrays1f (its pdf table)
+  uint32_t envTexId = 0xFFFFFFFFu, envLightId = 0xFFFFFFFFu, envCamBackId = 0xFFFFFFFFu, envEnableSam = 0;
+  float envSamRow0[4] = {1, 0, 0, 0}, envSamRow1[4] = {0, 1, 0, 0};
+  std::vector<float> arrays1f;
   std::vector<hpt_texture_desc> texDescs;                 // filled by desc(): points into `textures`
 
   hpt_scene_desc desc()
@@ -176,6 +180,7 @@ struct LoadedScene
       o.data = t.bytes.data();
     }
     d.textures = texDescs.data(); d.numTextures = (uint32_t)texDescs.size();
+    d.arrays1f = arrays1f.empty() ? nullptr : arrays1f.data(); d.numArrays1f = (uint32_t)arrays1f.size();
     return d;
   }
 
@@ -208,7 +213,8 @@ struct LoadedScene
     p.winStartX = p.winStartY = 0; p.winWidth = p.fbWidth = width; p.winHeight = p.fbHeight = height;
     p.traceDepth = traceDepth; p.integratorType = integratorType; p.renderLayer = renderLayer; p.tileSize = tileSize(); p.spectralMode = 0;
     p.exposureMult = 1.0f; p.camLensRadius = 0.0f; p.camTargetDist = (float)fl;
-    for (int k = 0; k < 4; k++) { p.camRespoceRGB[k] = 1.0f; p.envColor[k] = envColor[k]; }
+    for (int k = 0; k < 4; k++) { p.camRespoceRGB[k] = 1.0f; p.envColor[k] = envColor[k]; p.envSamRow0[k] = envSamRow0[k]; p.envSamRow1[k] = envSamRow1[k]; }
+    p.envTexId = envTexId; p.envLightId = envLightId; p.envCamBackId = envCamBackId; p.envEnableSam = envEnableSam;
     return p;
   }
 
@@ -400,7 +406,51 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
     const auto color = parseFloats(inten->child("color")->get("val"));
     const double power = inten->child("multiplier") ? std::atof(inten->child("multiplier")->get("val").c_str()) : 1.0;
     if (color.size() < 3) { err = "xml: light colour"; return false; }
-    if (ltype == "sky") { for (int k = 0; k < 3; k++) sc.envColor[k] = (float)color[k]; sc.envColor[3] = 0.0f; oldToNew.push_back(-1); continue; }   // plain-colour environment (:439-486)
+    if (ltype == "sky") {                                                     // LIGHT_GEOM_ENV (integrator_pt_scene_lgt.cpp:36-59, integrator_pt_scene.cpp:441-486)
+      for (int k = 0; k < 3; k++) sc.envColor[k] = (float)color[k];
+      sc.envColor[3] = color.size() >= 4 ? (float)color[3] : 0.0f;
+      const XmlNode* cn = inten->child("color");
+      float row0[4] = {1, 0, 0, 0}, row1[4] = {0, 1, 0, 0};
+      uint32_t envTex = 0xFFFFFFFFu, backTex = 0xFFFFFFFFu;
+      bool sample = false;
+      if (cn->child("texture")) {
+        if (!loadTextureFromNode(cn, row0, row1, envTex)) return false;
+        // "m_textureLoadInfo[lightSource.texId]": the reference indexes the XML table with the loaded-texture index (:460-461)
+        sample = envTex < texInfo.size() && (texInfo[envTex].path.find(".exr") != std::string::npos || texInfo[envTex].bpp > 4);
+      }
+      if (const XmlNode* back = ln->child("back")) { float r0[4], r1[4]; if (!loadTextureFromNode(back, r0, r1, backTex)) return false; }
+      for (int k = 0; k < 4; k++) { sc.envSamRow0[k] = row0[k]; sc.envSamRow1[k] = row1[k]; }
+      sc.envTexId = envTex; sc.envCamBackId = backTex; sc.envLightId = 0xFFFFFFFFu; sc.envEnableSam = (envTex != 0xFFFFFFFFu && sample) ? 1u : 0u;
+      if (!sc.envEnableSam) { oldToNew.push_back(-1); continue; }            // a plain-colour or LDR environment is not a light to sample
+      const LoadedTexture& tex = sc.textures[envTex];
+      if (tex.format != 1) { err = "xml: a sampled environment map must be a float4 image"; return false; }
+      LightSource lt = blankLight();
+      for (int k = 0; k < 4; k++) { lt.intensity[k] = sc.envColor[k]; lt.samplerRow0[k] = row0[k]; lt.samplerRow1[k] = row1[k]; }
+      lt.mult = (float)power; lt.geomType = 6; lt.distType = 1; lt.texId = envTex; lt.camBackTexId = backTex;     // LIGHT_GEOM_ENV, LIGHT_DIST_OMNI
+      M4 tr = m4Identity();
+      for (int k = 0; k < 4; k++) { tr.m[0][k] = row0[k]; tr.m[1][k] = row1[k]; }
+      const M4 ti = m4Inverse(tr);
+      for (int k = 0; k < 4; k++) { lt.samplerRow0Inv[k] = (float)ti.m[0][k]; lt.samplerRow1Inv[k] = (float)ti.m[1][k]; }
+      // PdfTableFromImage + PrefixSumm (integrator_pt_scene_lgt.cpp:219-270): max(r, g, b) at the texel centres, floored at a tenth of the mean
+      const int tw = (int)tex.width, th = (int)tex.height;
+      const float* texels = (const float*)tex.bytes.data();
+      std::vector<float> lum((size_t)tw * th);
+      float avg = 0.0f;
+      for (int y = 0; y < th; y++) {
+        float avgInRow = 0.0f;
+        for (int x = 0; x < tw; x++) { const float* c4 = texels + 4 * ((size_t)y * tw + x); const float l = std::max(c4[0], std::max(c4[1], c4[2])); lum[(size_t)y * tw + x] = l; avgInRow += l; }
+        avg += avgInRow;
+      }
+      avg /= float(tw * th);
+      lt.pdfTableOffset = (uint32_t)sc.arrays1f.size(); lt.pdfTableSize = (uint32_t)lum.size() + 1u; lt.pdfTableSizeX = (uint32_t)tw; lt.pdfTableSizeY = (uint32_t)th;
+      double accum = 0.0;
+      for (size_t i = 0; i < lum.size(); i++) { sc.arrays1f.push_back((float)accum); accum += (double)std::max(lum[i], 0.1f * avg); }
+      sc.arrays1f.push_back((float)accum);
+      sc.envLightId = (uint32_t)sc.lights.size();
+      oldToNew.push_back((int)sc.lights.size());
+      sc.lights.push_back(lt);
+      continue;
+    }
     LightSource lt = blankLight();
     lightFrame(m, lt);
     for (int k = 0; k < 3; k++) lt.intensity[k] = (float)color[k];

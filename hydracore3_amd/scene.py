@@ -86,7 +86,7 @@ class SceneDesc(C.Structure):
                 ("allRemapListsLen", C.c_uint32), ("allRemapListsSize", C.c_uint32),
                 ("materials", C.c_void_p), ("numMaterials", C.c_uint32), ("numLights", C.c_uint32),
                 ("lights", C.c_void_p), ("textures", C.POINTER(TextureDesc)),
-                ("numTextures", C.c_uint32), ("reserved", C.c_uint32)]
+                ("numTextures", C.c_uint32), ("numArrays1f", C.c_uint32), ("arrays1f", C.c_void_p)]
 
 
 class Params(C.Structure):
@@ -96,7 +96,9 @@ class Params(C.Structure):
                 ("traceDepth", C.c_uint32), ("integratorType", C.c_uint32), ("renderLayer", C.c_uint32),
                 ("tileSize", C.c_uint32), ("spectralMode", C.c_uint32), ("reserved0", C.c_uint32),
                 ("exposureMult", C.c_float), ("camLensRadius", C.c_float), ("camTargetDist", C.c_float), ("reserved1", C.c_float),
-                ("camRespoceRGB", C.c_float * 4), ("envColor", C.c_float * 4)]
+                ("camRespoceRGB", C.c_float * 4), ("envColor", C.c_float * 4),
+                ("envTexId", C.c_uint32), ("envLightId", C.c_uint32), ("envCamBackId", C.c_uint32), ("envEnableSam", C.c_uint32),
+                ("envSamRow0", C.c_float * 4), ("envSamRow1", C.c_float * 4)]
 
 
 class Hit(C.Structure):     # CRT_Hit, external/CrossRT/CrossRT.h:23-30
@@ -372,6 +374,23 @@ def light_point(matrix, color, mult, dist="omni", cos1=0.0, cos2=0.0) -> np.ndar
     return lt
 
 
+def pdf_table_from_image(tex):
+    """PdfTableFromImage + PrefixSumm (integrator_pt_scene_lgt.cpp:219-270): luminance max(r, g, b) at the texel centres, floored at a tenth
+    of the mean, prefix-summed in double; w*h + 1 floats."""
+    assert tex.fmt == TEX_RGBA32F, "only HDR maps are sampled explicitly (integrator_pt_scene.cpp:461-463)"
+    lum = tex.data[..., :3].max(axis=-1).astype(np.float32)
+    row_sums = np.zeros(tex.height, np.float32)
+    for x in range(tex.width):                                    # avgInRow += lum, in float, left to right
+        row_sums = (row_sums + lum[:, x]).astype(np.float32)
+    avg = np.float32(0.0)
+    for y in range(tex.height):
+        avg = np.float32(avg + row_sums[y])
+    avg = np.float32(avg / np.float32(tex.width * tex.height))
+    lum = np.maximum(lum, np.float32(0.1) * avg).reshape(-1)
+    acc = np.concatenate([[0.0], np.cumsum(lum.astype(np.float64))])
+    return acc.astype(np.float32), tex.width, tex.height
+
+
 def light_directional(matrix, color, mult) -> np.ndarray:
     m = np.asarray(matrix, dtype=np.float64)
     lt = _blank_light()
@@ -425,6 +444,10 @@ class SceneData:
         self.cam_pos, self.cam_look_at, self.cam_up = (0, 0, 15), (0, 0, 0), (0, 1, 0)
         self.trace_depth, self.spp = 6, 1
         self.env_color = (0.0, 0.0, 0.0, 0.0)
+        # the environment map of LoadSceneLights (integrator_pt_scene.cpp:441-478): texture, light entry when sampled explicitly, camera back
+        self.env_tex_id, self.env_light_id, self.env_cam_back_id, self.env_enable_sam = UINT_MAX, UINT_MAX, UINT_MAX, 0
+        self.env_sam_row0, self.env_sam_row1 = (1.0, 0.0, 0.0, 0.0), (0.0, 1.0, 0.0, 0.0)
+        self.arrays1f = np.zeros(0, np.float32)               # m_arrays1f: pdf tables
         self.exposure_mult = 1.0
         self.cam_lens_radius = 0.0
         self._keep = []
@@ -501,6 +524,38 @@ class SceneData:
         self.textures.append(tex)
         return len(self.textures) - 1
 
+    def set_environment(self, color, tex_id=UINT_MAX, mult=1.0, row0=(1, 0, 0, 0), row1=(0, 1, 0, 0), cam_back=UINT_MAX, sample=None):
+        """The LIGHT_GEOM_ENV branch of LoadLightSourceFromNode + LoadSceneLights (integrator_pt_scene_lgt.cpp:36-59,
+        integrator_pt_scene.cpp:441-486): a plain colour, or a lat-long map that is sampled explicitly when it is HDR (`sample` overrides
+        the reference's rule 'EXR file or more than 4 bytes per pixel'). Returns the light id of the sampled map, or -1."""
+        self.env_color = (*[float(v) for v in color[:3]], float(color[3]) if len(color) > 3 else 0.0)
+        self.env_sam_row0, self.env_sam_row1 = tuple(float(v) for v in row0), tuple(float(v) for v in row1)
+        self.env_tex_id, self.env_light_id, self.env_cam_back_id, self.env_enable_sam = tex_id, UINT_MAX, cam_back, 0
+        if tex_id == UINT_MAX:
+            return -1
+        tex = self.textures[tex_id]
+        if sample is None:
+            sample = tex.fmt == TEX_RGBA32F
+        self.env_enable_sam = 1 if sample else 0
+        if not sample:
+            return -1
+        lt = _blank_light()
+        lt["intensity"] = self.env_color
+        lt["mult"] = mult
+        lt["geomType"], lt["distType"] = LIGHT_GEOM_ENV, LIGHT_DIST_OMNI
+        lt["texId"], lt["camBackTexId"] = tex_id, cam_back
+        lt["samplerRow0"], lt["samplerRow1"] = row0, row1
+        t = np.eye(4)
+        t[0, :], t[1, :] = row0, row1
+        ti = np.linalg.inv(t)
+        lt["samplerRow0Inv"], lt["samplerRow1Inv"] = ti[0, :].astype(np.float32), ti[1, :].astype(np.float32)
+        table, w, h = pdf_table_from_image(tex)
+        lt["pdfTableOffset"], lt["pdfTableSize"], lt["pdfTableSizeX"], lt["pdfTableSizeY"] = self.arrays1f.size, table.size, w, h
+        self.arrays1f = np.concatenate([self.arrays1f, table]).astype(np.float32)
+        self.env_light_id = len(self.lights)
+        self.lights.append(lt)
+        return self.env_light_id
+
     # -- C structures ------------------------------------------------------------------------------------------------
     def tile_size(self) -> int:
         """SetViewport (integrator_pt.h:379-389)."""
@@ -529,6 +584,9 @@ class SceneData:
         p.camTargetDist = float(np.linalg.norm(np.asarray(self.cam_look_at, float) - np.asarray(self.cam_pos, float)))
         p.camRespoceRGB[:] = [1.0, 1.0, 1.0, 1.0]
         p.envColor[:] = list(self.env_color)
+        p.envTexId, p.envLightId, p.envCamBackId, p.envEnableSam = self.env_tex_id, self.env_light_id, self.env_cam_back_id, self.env_enable_sam
+        p.envSamRow0[:] = list(self.env_sam_row0)
+        p.envSamRow1[:] = list(self.env_sam_row1)
         return p
 
     def desc(self) -> SceneDesc:
@@ -568,6 +626,7 @@ class SceneData:
             tarr[i].data = ptr(t.data)
         k.append(tarr)
         d.textures, d.numTextures = tarr, len(self.textures)
+        d.arrays1f, d.numArrays1f = (ptr(self.arrays1f.astype(np.float32)), int(self.arrays1f.size)) if self.arrays1f.size else (None, 0)
         return d
 
 
@@ -710,6 +769,25 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
             tex_cache[key] = sc.add_texture(tex)
         return tuple(row0), tuple(row1), tex_cache[key]
 
+    def color4(node):
+        """GetColorFromNode (integrator_pt_scene_mat.cpp:124-143): one value splats, three get w = 0, four are taken as they are."""
+        v = _f(node.get("val")) if node is not None and node.get("val") is not None else []
+        if len(v) == 1:
+            return np.array([v[0]] * 4, np.float32)
+        if len(v) == 3:
+            return np.array([*v, 0.0], np.float32)
+        if len(v) == 4:
+            return np.array(v, np.float32)
+        return np.zeros(4, np.float32)
+
+    def val1f(node, default=0.0):
+        """hydra_xml::readval1f (hydraxml.cpp:390-402)."""
+        return default if node is None else np.float32(float(node.get("val")) if node.get("val") is not None else float(node.text or 0.0))
+
+    def length(v):          # LiteMath length in float
+        v = np.asarray(v, np.float32)
+        return np.sqrt(np.float32(np.dot(v, v)), dtype=np.float32)
+
     # lights first: materials with light_id copy intensity from them (integrator_pt_scene.cpp:973-996, 575-599)
     scene_node = root.find("scenes/scene")
     light_nodes = {int(l.get("id")): l for l in root.findall("lights_lib/light")}
@@ -722,9 +800,20 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
         color = _f(inten.find("color").get("val"))
         mult_node = inten.find("multiplier")
         power = float(mult_node.get("val")) if mult_node is not None else 1.0
-        if ltype == "sky":
-            sc.env_color = (*color[:3], 0.0)
-            old_to_new.append(-1)           # plain-colour environment: not sampled (:439-486)
+        if ltype == "sky":                  # LIGHT_GEOM_ENV (integrator_pt_scene_lgt.cpp:36-59, integrator_pt_scene.cpp:441-486)
+            cnode = inten.find("color")
+            env_rows, env_tex, back_tex = ((1, 0, 0, 0), (0, 1, 0, 0)), UINT_MAX, UINT_MAX
+            env_sample = None
+            if cnode.find("texture") is not None:
+                r0, r1, env_tex = load_texture_from_node(cnode)
+                env_rows = (r0, r1)
+                # "m_textureLoadInfo[lightSource.texId]": the reference indexes the XML table with the loaded-texture index (:460-461)
+                info = tex_info[env_tex] if env_tex < len(tex_info) else None
+                env_sample = info is not None and (".exr" in info[0] or info[3] > 4)
+            if lnode.find("back") is not None:
+                back_tex = load_texture_from_node(lnode.find("back"))[2]
+            lid = sc.set_environment(color4(cnode), env_tex, power, env_rows[0], env_rows[1], back_tex, env_sample)
+            old_to_new.append(lid)          # a plain-colour or LDR environment is not a light to sample
             continue
         size = lnode.find("size")
         if ltype == "directional":
@@ -748,25 +837,6 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
                 lt["iesMatrix"] = colmajor(im)
         old_to_new.append(len(sc.lights))
         sc.lights.append(lt)
-
-    def color4(node):
-        """GetColorFromNode (integrator_pt_scene_mat.cpp:124-143): one value splats, three get w = 0, four are taken as they are."""
-        v = _f(node.get("val")) if node is not None and node.get("val") is not None else []
-        if len(v) == 1:
-            return np.array([v[0]] * 4, np.float32)
-        if len(v) == 3:
-            return np.array([*v, 0.0], np.float32)
-        if len(v) == 4:
-            return np.array(v, np.float32)
-        return np.zeros(4, np.float32)
-
-    def val1f(node, default=0.0):
-        """hydra_xml::readval1f (hydraxml.cpp:390-402)."""
-        return default if node is None else np.float32(float(node.get("val")) if node.get("val") is not None else float(node.text or 0.0))
-
-    def length(v):          # LiteMath length in float
-        v = np.asarray(v, np.float32)
-        return np.sqrt(np.float32(np.dot(v, v)), dtype=np.float32)
 
     def zero_material():
         """Material mat = {} of the typed loaders; spectra ids stay 'none' (RGB mode)."""

@@ -62,7 +62,8 @@ typedef struct hpt_scene_desc {
   const void*     lights;         /* m_lights: 320-byte LightSource records (include/clight.h:19-56) */
   const hpt_texture_desc* textures; /* m_textures */
   uint32_t        numTextures;
-  uint32_t        reserved;
+  uint32_t        numArrays1f;
+  const float*    arrays1f;       /* m_arrays1f: the environment light's pdf table (integrator_pt_scene.cpp:464-475); may be NULL */
 } hpt_scene_desc;
 
 /* The plain-data members UpdateMembersPlainData() refreshes before every *Block call (integrator_pt.h:268, main.cpp:398). */
@@ -79,6 +80,13 @@ typedef struct hpt_params {
   float    exposureMult, camLensRadius, camTargetDist, reserved1;
   float    camRespoceRGB[4];  /* m_camRespoceRGB */
   float    envColor[4];       /* m_envColor */
+  /* the environment of LoadSceneLights (integrator_pt_scene.cpp:441-478), read by EnvironmentColor / kernel_HitEnvironment
+   * (integrator_pt_lgt.cpp:175-210, integrator_pt.cpp:550-595): 0xFFFFFFFF = none */
+  uint32_t envTexId;          /* m_envTexId: index into the texture table */
+  uint32_t envLightId;        /* m_envLightId: the LIGHT_GEOM_ENV entry of m_lights when the map is sampled explicitly */
+  uint32_t envCamBackId;      /* m_envCamBackId: texture shown to primary rays that miss */
+  uint32_t envEnableSam;      /* m_envEnableSam */
+  float    envSamRow0[4], envSamRow1[4]; /* m_envSamRow0 / m_envSamRow1 */
 } hpt_params;
 
 /* CRT_Hit (external/CrossRT/CrossRT.h:23-30) */

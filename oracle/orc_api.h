@@ -46,7 +46,8 @@ typedef struct orc_scene_desc {
   const void*     lights;         // 320-byte LightSource records (include/clight.h:19-56)
   const orc_texture_desc* textures;
   uint32_t        numTextures;
-  uint32_t        reserved;
+  uint32_t        numArrays1f;
+  const float*    arrays1f;       // m_arrays1f: pdf table of the sampled environment map (may be NULL)
 } orc_scene_desc;
 
 typedef struct orc_params {
@@ -62,6 +63,8 @@ typedef struct orc_params {
   float    exposureMult, camLensRadius, camTargetDist, reserved1;
   float    camRespoceRGB[4];
   float    envColor[4];
+  uint32_t envTexId, envLightId, envCamBackId, envEnableSam;   // m_envTexId, m_envLightId, m_envCamBackId, m_envEnableSam (0xFFFFFFFF: none)
+  float    envSamRow0[4], envSamRow1[4];                       // m_envSamRow0, m_envSamRow1
 } orc_params;
 
 // CRT_Hit (external/CrossRT/CrossRT.h:23-30)

@@ -27,6 +27,8 @@ struct Params
   uint traceDepth, integratorType, renderLayer, tileSize, spectralMode;
   float exposureMult, camLensRadius, camTargetDist;
   f4 camRespoceRGB, envColor;
+  uint envTexId, envLightId, envCamBackId, envEnableSam;
+  f4 envSamRow0, envSamRow1;
 };
 
 // IntegratorDR::TexInfo (diff_render/integrator_dr.h:56-64)
@@ -120,7 +122,26 @@ struct Ctx
       case LIGHT_GEOM_DIRECT: return directLightSampleRev(L, rands2, illiminationPoint);
       case LIGHT_GEOM_SPHERE: return sphereLightSampleRev(L, rands2);
       case LIGHT_GEOM_POINT:  return pointLightSampleRev(L);
-      default:                return areaLightSampleRev(L, rands2);   // env-map lights: out of scope
+      case LIGHT_GEOM_ENV: {                                          // :30-55: SampleMap2D (:212-236) over the pdf table in m_arrays1f
+        const int sizeX = (int)L.pdfTableSizeX, sizeY = (int)L.pdfTableSizeY;
+        const float fw = (float)sizeX, fh = (float)sizeY, fN = fw * fh;
+        float pdf = 1.0f;
+        int pixelOffset = SelectIndexPropToOpt(rands.z, sc.arrays1f.data(), (int)L.pdfTableOffset, sizeX * sizeY + 1, &pdf);
+        if (pixelOffset >= sizeX * sizeY) pixelOffset = sizeX * sizeY - 1;
+        const int yPos = pixelOffset / sizeX, xPos = pixelOffset - yPos * sizeX;
+        const float texX = (1.0f / fw) * (((float)(xPos) + 0.5f) + (rands.x * 2.0f - 1.0f) * 0.5f);
+        const float texY = (1.0f / fh) * (((float)(yPos) + 0.5f) + (rands.y * 2.0f - 1.0f) * 0.5f);
+        const float mapPdf = pdf * fN;
+        const f2 texCoordT = mulRows2x4(L.samplerRow0Inv, L.samplerRow1Inv, mk2(texX, texY));
+        float sintheta = 0.0f;
+        const f3 sampleDir = texCoord2DToSphereMap(texCoordT, &sintheta);
+        LightSample res;
+        res.hasIES = false; res.isOmni = true; res.norm = sampleDir;
+        res.pos = illiminationPoint + sampleDir * 1000.0f;
+        res.pdf = (mapPdf * 1.0f) / (2.f * kPI * kPI * std::max(std::abs(sintheta), 1e-20f));
+        return res;
+      }
+      default:                return areaLightSampleRev(L, rands2);
     }
   }
   float LightPdfSelectRev(int) const { return 1.0f / float(sc.lights.size()); }   // :60-63
@@ -161,7 +182,31 @@ struct Ctx
       const float cos_theta = std::max(-dot(a_rayDir, norm), 0.0f);
       lightColor = lightColor * mylocalsmoothstep(cos2, cos1, cos_theta);
     }
+    else if (L.texId != uint(-1)) {                                   // :163-170: the environment map seen along the shadow ray
+      float sintheta = 0.0f;
+      const f2 texCoord = sphereMapTo2DTexCoord(a_rayDir, &sintheta);
+      const f2 texCoordT = mulRows2x4(L.samplerRow0, L.samplerRow1, texCoord);
+      lightColor = lightColor * sc.tex_sample(L.texId, texCoordT);
+    }
     return lightColor;
+  }
+
+  f4 EnvironmentColor(f3 a_dir, float& outPdf) const   // :175-210 (RGB mode)
+  {
+    f4 color = p.envColor;
+    const uint envTexId = p.envTexId;
+    if (envTexId != uint(-1)) {
+      float sinTheta = 1.0f;
+      const f2 tc = sphereMapTo2DTexCoord(a_dir, &sinTheta);
+      const f2 texCoordT = mulRows2x4(p.envSamRow0, p.envSamRow1, tc);
+      if (sinTheta != 0.f && p.envEnableSam != 0 && p.integratorType == INTEGRATOR_MIS_PT && p.envLightId != uint(-1)) {
+        const LightSource& L = sc.lights[p.envLightId];
+        const float mapPdf = evalMap2DPdf(texCoordT, sc.arrays1f.data(), (int)L.pdfTableOffset, (int)L.pdfTableSizeX, (int)L.pdfTableSizeY);
+        outPdf = (mapPdf * 1.0f) / (2.f * kPI * kPI * std::max(std::abs(sinTheta), 1e-20f));
+      }
+      color = color * sc.tex_sample(envTexId, texCoordT);
+    }
+    return color;
   }
 
   // ---- materials (integrator_pt_mat.cpp) -----------------------------------------------------------------------------
@@ -511,10 +556,24 @@ struct Ctx
     s->rayFlags = nextFlags;
   }
 
-  void HitEnvironment(Path* s) const   // :550-595 (constant environment colour; env texture / camera back plate out of scope)
+  void HitEnvironment(uint tid, Path* s) const   // :550-595
   {
     if ((s->rayFlags & RAY_FLAG_OUT_OF_SCENE) == 0) return;
-    const f4 envColor = p.envColor;
+    float envPdf = 1.0f;
+    f4 envColor = EnvironmentColor(xyz(s->rayDirAndFar), envPdf);
+    const bool isSpec = s->mis.matSamplePdf < 0.0f;                    // isSpecular (cglobals.h:300)
+    const bool exitZero = (s->rayFlags & RAY_FLAG_PRIME_RAY_MISS) != 0;
+    if (p.integratorType == INTEGRATOR_MIS_PT && p.envEnableSam != 0 && !isSpec && !exitZero) {
+      const float lgtPdf = LightPdfSelectRev((int)p.envLightId) * envPdf;
+      const float bsdfPdf = s->mis.matSamplePdf;
+      envColor = envColor * misWeightHeuristic(bsdfPdf, lgtPdf);
+    }
+    else if (p.integratorType == INTEGRATOR_SHADOW_PT && p.envEnableSam != 0) envColor = mk4(0, 0, 0, 0);
+    if (exitZero && p.envCamBackId != uint(-1)) {                      // the camera back plate for primary rays that miss
+      const uint XY = tid < packedXY.size() ? packedXY[tid] : 0u;
+      const uint x = (XY & 0x0000FFFF), y = (XY & 0xFFFF0000) >> 16;
+      envColor = sc.tex_sample(p.envCamBackId, mk2((float(x) + 0.5f) / float(p.winWidth), (float(y) + 0.5f) / float(p.winHeight)));
+    }
     if (p.integratorType == INTEGRATOR_STUPID_PT) s->accumColor = s->accumThroughput * envColor;
     else                                          s->accumColor = s->accumColor + s->accumThroughput * envColor;
   }
@@ -546,7 +605,7 @@ struct Ctx
       NextBounce(depth, shadeColor, &s, rec);
       if (isDeadRay(s.rayFlags)) break;
     }
-    HitEnvironment(&s);
+    HitEnvironment(tid, &s);
     ContributeToImage(tid, channels, &s, out_color, disableImageContrib);
     return s.accumColor;
   }
@@ -573,7 +632,7 @@ struct Ctx
       NextBounce(depth, shadeColor, &s, nullptr);
       if (isDeadRay(s.rayFlags)) break;
     }
-    HitEnvironment(&s);
+    HitEnvironment(tid, &s);
     if (channels == 1) out_color[tid] += s.accumColor.x;
     else { out_color[tid * channels + 0] += s.accumColor.x; out_color[tid * channels + 1] += s.accumColor.y; out_color[tid * channels + 2] += s.accumColor.z; }
     randomGens[tid] = s.gen;
@@ -589,7 +648,7 @@ struct Ctx
       NextBounce(depth, mk4(0, 0, 0, 0), &s, nullptr);
       if (isDeadRay(s.rayFlags)) break;
     }
-    HitEnvironment(&s);
+    HitEnvironment(tid, &s);
     ContributeToImage(tid, channels, &s, out_color, false);
   }
 
@@ -770,6 +829,8 @@ static void copy_params(Params& p, const orc_params* s)
   p.exposureMult = s->exposureMult; p.camLensRadius = s->camLensRadius; p.camTargetDist = s->camTargetDist;
   std::memcpy(&p.camRespoceRGB, s->camRespoceRGB, 16);
   std::memcpy(&p.envColor, s->envColor, 16);
+  p.envTexId = s->envTexId; p.envLightId = s->envLightId; p.envCamBackId = s->envCamBackId; p.envEnableSam = s->envEnableSam;
+  std::memcpy(&p.envSamRow0, s->envSamRow0, 16); std::memcpy(&p.envSamRow1, s->envSamRow1, 16);
 }
 
 extern "C" {

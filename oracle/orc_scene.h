@@ -175,6 +175,7 @@ struct Scene
   std::vector<Material> materials;
   std::vector<LightSource> lights;
   std::vector<Texture>  textures;
+  std::vector<float>    arrays1f;        // m_arrays1f
 
   std::vector<SimpleBvh> blas;            // per geom
   SimpleBvh              tlas;
@@ -207,6 +208,8 @@ struct Scene
       else if (d.format == 1) t.hdr.assign((const float*)d.data, (const float*)d.data + 4 * n);
       else t.hdr.assign((const float*)d.data, (const float*)d.data + n);
     }
+    arrays1f.clear();
+    if (s->arrays1f && s->numArrays1f) arrays1f.assign(s->arrays1f, s->arrays1f + s->numArrays1f);
     instMatricesInv.resize(instMatrices.size());
     for (size_t i = 0; i < instMatrices.size(); i++) instMatricesInv[i] = affine_inverse(instMatrices[i]);
     build_accel();

@@ -173,6 +173,57 @@ static inline f2 sphereMapTo2DTexCoord(f3 ray_dir, float* pSinTheta) // cglobals
   return mk2(texX, texY);
 }
 
+static inline f3 texCoord2DToSphereMap(f2 a_texCoord, float* pSinTheta) // cglobals.h:360-373, the reverse of sphereMapTo2DTexCoord
+{
+  const float phi = a_texCoord.x * 2.f * kPI, theta = a_texCoord.y * kPI;
+  const float sinTheta = std::sin(theta);
+  const float x = sinTheta * std::cos(phi), y = sinTheta * std::sin(phi), z = std::cos(theta);
+  *pSinTheta = sinTheta;
+  return mk3(y, -z, x);
+}
+// ---- include/clight.h:128-218: the piecewise-constant 2-D distribution of a sampled environment map -----------------
+static inline int SelectIndexPropToOpt(float a_r, const float* a_accum, int a_offset, int N, float* pPDF)
+{
+  int leftBound = 0, rightBound = N - 2, counter = 0, currPos = -1;
+  const int maxStep = 50;
+  const float x = a_r * a_accum[a_offset + N - 1];
+  while (rightBound - leftBound > 1 && counter < maxStep) {
+    const int currSize = rightBound + leftBound;
+    const int currPos1 = (currSize % 2 == 0) ? (currSize + 1) / 2 : (currSize + 0) / 2;
+    const float a = a_accum[a_offset + currPos1 + 0], b = a_accum[a_offset + currPos1 + 1];
+    if (a < x && x <= b) { currPos = currPos1; break; }
+    else if (x <= a) rightBound = currPos1;
+    else if (x > b) leftBound = currPos1;
+    counter++;
+  }
+  if (currPos < 0) {
+    const float a1 = a_accum[a_offset + leftBound + 0], b1 = a_accum[a_offset + leftBound + 1];
+    const float a2 = a_accum[a_offset + rightBound + 0], b2 = a_accum[a_offset + rightBound + 1];
+    if (a1 < x && x <= b1) currPos = leftBound;
+    if (a2 < x && x <= b2) currPos = rightBound;
+  }
+  if (x == 0.0f) currPos = 0;
+  else if (currPos < 0) currPos = (rightBound + leftBound + 1) / 2;
+  *pPDF = (a_accum[a_offset + currPos + 1] - a_accum[a_offset + currPos]) / a_accum[a_offset + N - 1];
+  return currPos;
+}
+static inline float evalMap2DPdf(f2 texCoordT, const float* intervals, int a_inOffs, int sizeX, int sizeY)
+{
+  const float fw = (float)sizeX, fh = (float)sizeY;
+  if (texCoordT.x < 0.0f || texCoordT.x > 1.0f) texCoordT.x -= (float)((int)(texCoordT.x));
+  if (texCoordT.y < 0.0f || texCoordT.x > 1.0f) texCoordT.y -= (float)((int)(texCoordT.y));     // (sic: .x in the second test, clight.h:199)
+  int pixelX = (int)(fw * texCoordT.x - 0.5f), pixelY = (int)(fh * texCoordT.y - 0.5f);
+  if (pixelX >= sizeX) pixelX = sizeX - 1;
+  if (pixelY >= sizeY) pixelY = sizeY - 1;
+  if (pixelX < 0) pixelX += sizeX;
+  if (pixelY < 0) pixelY += sizeY;
+  const int pixelOffset = pixelY * sizeX + pixelX, maxSize = sizeX * sizeY;
+  const int offset0 = (pixelOffset + 0 < maxSize + 0) ? pixelOffset + 0 : maxSize - 1;
+  const int offset1 = (pixelOffset + 1 < maxSize + 1) ? pixelOffset + 1 : maxSize;
+  const float i0 = intervals[a_inOffs + offset0], i1 = intervals[a_inOffs + offset1];
+  return (i1 - i0) * (fw * fh) / intervals[a_inOffs + sizeX * sizeY];
+}
+
 // ---- include/cmaterial.h --------------------------------------------------------------------------------------
 struct BsdfSample { f4 val; f3 dir; float pdf; uint flags; float ior; };   // cmaterial.h:9-16
 struct BsdfEval { f4 val; float pdf; };                                    // cmaterial.h:18-22

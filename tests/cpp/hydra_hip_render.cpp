@@ -27,6 +27,7 @@ int main(int argc, char** argv)
     blob(f, "remapInst", sc.remapInst); blob(f, "allRemapLists", sc.allRemapLists);
     blob(f, "materials", sc.materials); blob(f, "lights", sc.lights);
     blob(f, "params", std::vector<hpt_params>(1, p));
+    blob(f, "arrays1f", sc.arrays1f);
     for (size_t i = 0; i < sc.textures.size(); i++) {
       const hydra_hip::LoadedTexture& t = sc.textures[i];
       blob(f, "texHeader", std::vector<uint32_t>{ t.width, t.height, t.format, t.flags, t.addressU, t.addressV, t.filter });

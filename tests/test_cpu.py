@@ -383,7 +383,7 @@ def _read_blobs(path):
     return out
 
 
-@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials"])
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map"])
 def test_cpp_scene_loader_produces_the_same_tables(scene_name, tmp_path):
     """hydracore3_amd/csrc/scene_loader.h (Hydra XML + VSGF + image4ub + IES in C++) == the Python fixture loader:
     every table byte for byte, matrices and light frames to float rounding (both invert in double)."""
@@ -435,7 +435,11 @@ def test_cpp_scene_loader_produces_the_same_tables(scene_name, tmp_path):
     pr, pg = np.frombuffer(p_ref[:128], np.float32), np.frombuffer(p_got[:128], np.float32)       # projInv, worldViewInv
     assert np.allclose(pg, pr, rtol=1e-5, atol=1e-6)
     assert p_got[128:176] == p_ref[128:176]                                                          # window, depth, integrator, tile ...
-    assert np.allclose(np.frombuffer(p_got[176:], np.float32), np.frombuffer(p_ref[176:], np.float32), rtol=1e-6)
+    assert len(p_got) == len(p_ref) == 272
+    assert np.allclose(np.frombuffer(p_got[176:224], np.float32), np.frombuffer(p_ref[176:224], np.float32), rtol=1e-6)   # exposure .. envColor
+    assert p_got[224:240] == p_ref[224:240]                                                          # environment map ids
+    assert np.allclose(np.frombuffer(p_got[240:], np.float32), np.frombuffer(p_ref[240:], np.float32), rtol=1e-6)         # its sampler rows
+    assert named.get("arrays1f", b"") == np.ascontiguousarray(sc.arrays1f, np.float32).tobytes()
     # textures, in the order the reference's lazy loading creates them
     tex = [(np.frombuffer(h, np.uint32), b) for (kh, h), (kb, b) in zip(blobs, blobs[1:]) if kh == "texHeader" and kb == "texBytes"]
     assert len(tex) == len(sc.textures)
@@ -445,3 +449,25 @@ def test_cpp_scene_loader_produces_the_same_tables(scene_name, tmp_path):
             assert b == t.data.tobytes()
         else:
             assert np.allclose(np.frombuffer(b, np.float32), t.data.reshape(-1), rtol=1e-6, atol=1e-7)
+
+
+def test_environment_map_estimators_agree():
+    """A scene lit only by a sampled HDR environment map (tests/golden/scenes/env_map): the MIS estimator (explicit SampleMap2D samples
+    weighted against the implicit hits through evalMap2DPdf, integrator_pt_lgt.cpp:30-55, 175-236, integrator_pt.cpp:550-595) and the
+    naive one (implicit hits only) converge to the same image - which holds only if the table pdf, the inverse sampler transform and
+    the lat-long mapping are consistent. The reference's own acceptance practice (testing/run_tests.py:59-64)."""
+    from hydracore3_amd import scene as S
+    from oracle.orc import OracleIntegrator
+    sc = S.load_hydra_xml(scene_path("env_map"), 48, 32)
+    assert sc.env_enable_sam == 1 and sc.env_light_id == 0 and sc.lights[0]["geomType"] == S.LIGHT_GEOM_ENV
+    t = sc.arrays1f
+    assert t.size == 32 * 16 + 1 and t[0] == 0.0 and np.all(np.diff(t) > 0)
+    spp = 192
+    mis = OracleIntegrator(sc, sc.params(S.INTEGRATOR_MIS_PT)).render(spp) / spp
+    naive = OracleIntegrator(sc, sc.params(S.INTEGRATOR_STUPID_PT)).render(spp, naive=True) / spp
+    assert np.isfinite(mis).all() and np.isfinite(naive).all()
+    m, n = mis[..., :3].mean(axis=(0, 1)), naive[..., :3].mean(axis=(0, 1))
+    assert np.allclose(m, n, rtol=0.03), (m, n)
+    # the camera back plate replaces the map for primary rays that miss: those pixels carry no Monte-Carlo noise at all
+    same = np.all(np.abs(mis[..., :3] - naive[..., :3]) < 1e-6, axis=-1)
+    assert same.sum() > 200 and same.sum() < 48 * 32

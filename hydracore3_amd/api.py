@@ -25,6 +25,7 @@ ABI = {
     "hpt_destroy": (None, [_vp]),
     "hpt_last_error": (C.c_char_p, [_vp]),
     "hpt_device_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.c_char_p, _sz]),
+    "hpt_plastic_precompute": (_i, [_f, _f, _f, _vp, _vp, _vp, C.POINTER(_f), C.POINTER(_f)]),
     "hpt_device_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "hpt_device_free": (_i, [_vp, _vp]),
     "hpt_device_copy": (_i, [_vp, _vp, _vp, _sz, _i]),

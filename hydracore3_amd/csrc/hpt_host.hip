@@ -1,5 +1,6 @@
 // Host side of the C ABI (include/hydra_hip.h): context, BVH2 build + upload, scene tables, launches, timing.
 // Compiled by hipcc together with the kernels; exports only the extern "C" hpt_* symbols.
+#include "plastic_precompute.h"
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -187,6 +188,18 @@ extern "C" int hpt_device_info(hpt_ctx* c, int* numCUs, int* wavefront, char* na
   if (numCUs) *numCUs = c->numCUs;
   if (wavefront) *wavefront = 64;
   if (name && nameLen) { std::strncpy(name, c->devName.c_str(), nameLen - 1); name[nameLen - 1] = 0; }
+  return HPT_OK;
+}
+
+// ---- mi::fresnel_coat_precompute for the scene loaders (host only, no device needed) --------------------------------------------------------
+extern "C" int hpt_plastic_precompute(float alpha, float intIor, float extIor, const float* diffuse4, const float* specular4,
+                                      float* outTransmittance64, float* outInternalReflectance, float* outSpecularSamplingWeight)
+{
+  if (!diffuse4 || !specular4 || !outTransmittance64 || !outInternalReflectance || !outSpecularSamplingWeight) return HPT_ERR_ARG;
+  if (!(alpha > 0.0f) || !(intIor > 0.0f) || !(extIor > 0.0f)) return HPT_ERR_ARG;
+  const hydra_hip::plastic::CoatPrecomputed p = hydra_hip::plastic::fresnelCoatPrecompute(alpha, intIor, extIor, diffuse4, specular4);
+  std::memcpy(outTransmittance64, p.transmittance, sizeof(p.transmittance));
+  *outInternalReflectance = p.internalReflectance; *outSpecularSamplingWeight = p.specularSamplingWeight;
   return HPT_OK;
 }
 
@@ -479,7 +492,7 @@ static bool lean_materials(const MaterialRec* m, size_t n)
   for (size_t i = 0; i < n; i++) if ((m[i].mtype != MAT_TYPE_GLTF && m[i].mtype != MAT_TYPE_LIGHT_SOURCE) || m[i].texid[1] != 0xFFFFFFFFu) return false;
   return true;
 }
-static int check_materials(hpt_ctx* c, const MaterialRec* m, size_t n, size_t numTex, size_t numMats)
+static int check_materials(hpt_ctx* c, const MaterialRec* m, size_t n, size_t numTex, size_t numMats, size_t numArrays1f)
 {
   for (size_t i = 0; i < n; i++) {
     const uint t = m[i].mtype;
@@ -488,8 +501,10 @@ static int check_materials(hpt_ctx* c, const MaterialRec* m, size_t n, size_t nu
       if (m[i].texid[0] >= numTex) return c->fail(HPT_ERR_ARG, "material refers to a texture that does not exist");
       continue;
     }
-    if (t != MAT_TYPE_GLTF && t != MAT_TYPE_GLASS && t != MAT_TYPE_CONDUCTOR && t != MAT_TYPE_DIFFUSE && t != MAT_TYPE_DIELECTRIC && t != MAT_TYPE_LIGHT_SOURCE)
-      return c->fail(HPT_ERR_UNSUPPORTED, "material type " + std::to_string(t) + " (plastic / thin film) is outside the hot path's scope");
+    if (t != MAT_TYPE_GLTF && t != MAT_TYPE_GLASS && t != MAT_TYPE_CONDUCTOR && t != MAT_TYPE_DIFFUSE && t != MAT_TYPE_DIELECTRIC && t != MAT_TYPE_PLASTIC && t != MAT_TYPE_LIGHT_SOURCE)
+      return c->fail(HPT_ERR_UNSUPPORTED, "material type " + std::to_string(t) + " (thin film) is outside the hot path's scope");
+    if (t == MAT_TYPE_PLASTIC && (uint64_t)m[i].datai[0] + (uint64_t)MI_ROUGH_TRANSMITTANCE_RES > numArrays1f)
+      return c->fail(HPT_ERR_ARG, "plastic material: transmittance table outside m_arrays1f");
     if (m[i].texid[1] != 0xFFFFFFFFu && m[i].texid[1] >= numTex) return c->fail(HPT_ERR_ARG, "material refers to a normal map that does not exist");
     if (m[i].texid[0] >= numTex) return c->fail(HPT_ERR_ARG, "material refers to a texture that does not exist");
     if ((m[i].cflags & FLAG_FOUR_TEXTURES) && (m[i].texid[2] >= numTex || m[i].texid[3] >= numTex)) return c->fail(HPT_ERR_ARG, "material refers to a texture that does not exist");
@@ -517,7 +532,7 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
   (void)hipSetDevice(c->device);
   const double t0 = now_ms();
   if (d->numTextures == 0 || !d->textures) return c->fail(HPT_ERR_ARG, "m_textures must at least hold the white dummy texture");
-  int rc = check_materials(c, (const MaterialRec*)d->materials, d->numMaterials, d->numTextures, d->numMaterials); if (rc) return rc;
+  int rc = check_materials(c, (const MaterialRec*)d->materials, d->numMaterials, d->numTextures, d->numMaterials, d->numArrays1f); if (rc) return rc;
   c->leanMaterials = lean_materials((const MaterialRec*)d->materials, d->numMaterials);
   if (d->numArrays1f && !d->arrays1f) return c->fail(HPT_ERR_ARG, "m_arrays1f: count without data");
   rc = check_lights(c, (const LightRec*)d->lights, d->numLights, d->numTextures, d->numArrays1f); if (rc) return rc;
@@ -626,7 +641,7 @@ extern "C" int hpt_update_materials(hpt_ctx* c, size_t first, size_t count, cons
 {
   if (!c || !mats) return HPT_ERR_ARG;
   if (first + count > c->dMaterials.n) return c->fail(HPT_ERR_ARG, "Update_m_materials: range out of bounds");
-  int rc = check_materials(c, (const MaterialRec*)mats, count, c->hTextures.size(), c->dMaterials.n); if (rc) return rc;
+  int rc = check_materials(c, (const MaterialRec*)mats, count, c->hTextures.size(), c->dMaterials.n, c->numArrays1f); if (rc) return rc;
   if (!lean_materials((const MaterialRec*)mats, count)) c->leanMaterials = false;      // (an update can only widen the set of BSDFs in use)
   (void)hipSetDevice(c->device);
   HIPCHK(c, hipMemcpy(c->dMaterials.p + first, mats, count * sizeof(MaterialRec), hipMemcpyHostToDevice));

@@ -123,6 +123,7 @@ HPT_DEV void blendTreeEval(const DevScene& S, uint rootId, V2 uv, V3 l, V3 v, V3
       res.val = res.val + cv.val * curW * bm; res.pdf += cv.pdf * curW;
     }
     else if (t == MAT_TYPE_DIFFUSE) { diffuseEval(m, ld3(m.colors[0]) * tex3, l, v, n, cv); res.val = res.val + cv.val * curW * bm; res.pdf += cv.pdf * curW; }
+    else if (t == MAT_TYPE_PLASTIC) { plasticEval(m, ld3(m.colors[0]) * tex3, l, v, n, cv, S.arrays1f, m.datai[0]); res.val = res.val + cv.val * curW * bm; res.pdf += cv.pdf * curW; }
     else if (t == MAT_TYPE_BLEND) {                          // BlendEval: first child next (no pop), second child waits on the stack
       const float w = m.data[0] * tex3.x;
       const uint id1 = m.datai[0], id2 = m.datai[1];
@@ -220,6 +221,7 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
             if (!(smax(m.data[1], m.data[0]) < 1e-3f)) conductorRoughEval(m, m.data[2], m.data[3], shadowRayDir, vdir, evalNorm, tex3, bv);
           }
           else if (!(DR || LEAN) && mtype == MAT_TYPE_DIFFUSE) diffuseEval(m, ld3(m.colors[0]) * tex3, shadowRayDir, vdir, evalNorm, bv);
+          else if (!(DR || LEAN) && mtype == MAT_TYPE_PLASTIC) plasticEval(m, ld3(m.colors[0]) * tex3, shadowRayDir, vdir, evalNorm, bv, S.arrays1f, m.datai[0]);
           else if (!(DR || LEAN) && mtype == MAT_TYPE_BLEND) blendTreeEval(S, matId, uv, shadowRayDir, vdir, hitNorm, hitTang, bv);
           if (!(DR || LEAN) && mtype != MAT_TYPE_BLEND) bv.val = bv.val * bumpMult;     // res.val += currVal.val * weight * bumpCosMult, weight 1
           const float cosThetaOut = smax(dot(shadowRayDir, hitNorm), 0.0f);
@@ -294,6 +296,7 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
         else                                      conductorRoughSampleAndEval(ml, ml.data[2], ml.data[3], rands, vdir, sNorm, ltex3, ms);
       }
       else if (!(DR || LEAN) && lt == MAT_TYPE_DIFFUSE) diffuseSampleAndEval(ml, ld3(ml.colors[0]) * ltex3, rands, vdir, sNorm, ms);
+      else if (!(DR || LEAN) && lt == MAT_TYPE_PLASTIC) plasticSampleAndEval(ml, ld3(ml.colors[0]) * ltex3, rands, vdir, sNorm, ms, S.arrays1f, ml.datai[0]);
       else if (!(DR || LEAN) && lt == MAT_TYPE_GLASS) glassSampleAndEval(ml, rands, vdir, hitNorm, ms, misIor);      // the geometric normal (:182)
       else if (!(DR || LEAN) && lt == MAT_TYPE_DIELECTRIC) {
         dielectricSmoothSampleAndEval(ml, ml.data[1], misIor, rands, vdir, sNorm, ms);

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "integrator_hip.h"
+#include "plastic_precompute.h"
 
 namespace hydra_hip {
 
@@ -591,6 +592,18 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
       if (const XmlNode* n = mn->child("ext_ior")) mat.data[0] = attrFloat(n);
       if (const XmlNode* n = mn->child("reflectance")) color4(n, mat.colors[0]);
       if (const XmlNode* n = mn->child("transmittance")) color4(n, mat.colors[1]);
+    } else if (type == "plastic") {                                           // LoadPlasticMaterial (:675-757), RGB mode
+      mat.mtype = 5; mat.lightId = 0xFFFFFFFFu;
+      if (const XmlNode* rc = mn->child("reflectance")) { color4(rc, mat.colors[0]); if (!loadTextureFromNode(rc, mat.row0[0], mat.row1[0], mat.texid[0])) return false; }
+      const float intIor = val1f(mn->child("int_ior"), 1.49f), extIor = val1f(mn->child("ext_ior"), 1.000277f);
+      mat.data[1] = intIor / extIor;
+      mat.data[0] = val1f(mn->child("alpha"), 0.1f);
+      if (mat.data[0] == 0.0f) mat.data[0] = 1e-6f;                          // "dirty hack" (:723-727)
+      if (const XmlNode* nl = mn->child("nonlinear")) mat.nonlinear = (uint32_t)std::atof((nl->has("val") ? nl->get("val") : nl->text).c_str());
+      const plastic::CoatPrecomputed pre = plastic::fresnelCoatPrecompute(mat.data[0], intIor, extIor, mat.colors[0], one4);
+      mat.data[3] = pre.internalReflectance; mat.data[2] = pre.specularSamplingWeight;
+      mat.datai[0] = (uint32_t)sc.arrays1f.size();
+      sc.arrays1f.insert(sc.arrays1f.end(), pre.transmittance, pre.transmittance + plastic::TRANSMITTANCE_RES);
     } else if (type == "blend") {                                             // LoadBlendMaterial (:619-647)
       mat.mtype = 6; mat.data[0] = 1.0f;
       if (const XmlNode* n = mn->child("bsdf_1")) mat.datai[0] = (uint32_t)std::atoll(n->get("id", "0").c_str());
@@ -605,7 +618,7 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
     if (mtypeAttr != "hydra_material") {
       bool known = false;
       if (!loadTypedMaterial(mn, mtypeAttr, mat, known)) return false;
-      if (!known) { err = "xml: material type '" + mtypeAttr + "' is outside the path (plastic, thin_film: SURVEY.md 2a)"; return false; }
+      if (!known) { err = "xml: material type '" + mtypeAttr + "' is outside the path (thin_film: SURVEY.md 2a)"; return false; }
       for (int k = 0; k < 4; k++) {
         bool zero = true; for (int j = 0; j < 4; j++) zero = zero && mat.row0[k][j] == 0.0f && mat.row1[k][j] == 0.0f;
         if (zero) { mat.row0[k][0] = 1.0f; mat.row1[k][1] = 1.0f; }

@@ -53,6 +53,7 @@ FLAG_NMAP_INVERT_X, FLAG_NMAP_INVERT_Y, FLAG_NMAP_SWAP_XY = 32, 64, 128
 MAT_TYPE_GLTF, MAT_TYPE_CONDUCTOR, MAT_TYPE_DIFFUSE, MAT_TYPE_DIELECTRIC = 1, 3, 4, 7
 MAT_TYPE_GLASS = 2
 MAT_TYPE_BLEND = 6
+MAT_TYPE_PLASTIC = 5
 MAT_TYPE_LIGHT_SOURCE = 0xEFFFFFFF
 # include/cmaterial.h:67-147 (slots in Material::colors / Material::data)
 GLTF_COLOR_BASE, GLTF_COLOR_COAT, GLTF_COLOR_METAL = 0, 1, 2
@@ -524,6 +525,35 @@ class SceneData:
         self.textures.append(tex)
         return len(self.textures) - 1
 
+    def material_plastic(self, color, alpha=0.1, int_ior=1.49, ext_ior=1.000277, nonlinear=0, tex_id=0, row0=(1, 0, 0, 0), row1=(0, 1, 0, 0)):
+        """LoadPlasticMaterial (integrator_pt_scene_mat.cpp:675-757): MAT_TYPE_PLASTIC (include/cmat_plastic.h), a rough dielectric coat over a
+        diffuse base; its 64-entry transmittance table goes to m_arrays1f (offset in datai[0]). The table and the two scalars come from
+        hpt_plastic_precompute = mi::fresnel_coat_precompute (mi_materials.cpp:377-451), the one implementation both loaders share."""
+        from .api import load_library
+        m = np.zeros((), dtype=MATERIAL_DTYPE)
+        m["mtype"], m["lightId"], m["nonlinear"] = MAT_TYPE_PLASTIC, UINT_MAX, nonlinear
+        m["spdid"] = UINT_MAX
+        m["texid"] = (tex_id, UINT_MAX, 0, 0)
+        for k in range(4):
+            m["row0"][k] = (1, 0, 0, 0); m["row1"][k] = (0, 1, 0, 0)
+        m["row0"][0], m["row1"][0] = row0, row1
+        c4 = np.array([*color[:3], color[3] if len(color) > 3 else 0.0], np.float32)
+        m["colors"][0] = c4
+        m["data"][1] = np.float32(int_ior) / np.float32(ext_ior)              # PLASTIC_IOR_RATIO
+        a = np.float32(alpha) if alpha != 0.0 else np.float32(1e-6)           # "dirty hack" (:723-727)
+        m["data"][0] = a                                                      # PLASTIC_ROUGHNESS
+        table = np.zeros(64, np.float32)
+        refl, weight = C.c_float(0), C.c_float(0)
+        spec = np.ones(4, np.float32)
+        rc = load_library().hpt_plastic_precompute(float(a), float(np.float32(int_ior)), float(np.float32(ext_ior)), c4.ctypes.data, spec.ctypes.data,
+                                                   table.ctypes.data, C.byref(refl), C.byref(weight))
+        if rc != 0:
+            raise ValueError("hpt_plastic_precompute rejected the parameters")
+        m["data"][3], m["data"][2] = refl.value, weight.value                 # PLASTIC_PRECOMP_REFLECTANCE, PLASTIC_SPEC_SAMPLE_WEIGHT
+        m["datai"][0] = self.arrays1f.size
+        self.arrays1f = np.concatenate([self.arrays1f, table]).astype(np.float32)
+        return m
+
     def set_environment(self, color, tex_id=UINT_MAX, mult=1.0, row0=(1, 0, 0, 0), row1=(0, 1, 0, 0), cam_back=UINT_MAX, sample=None):
         """The LIGHT_GEOM_ENV branch of LoadLightSourceFromNode + LoadSceneLights (integrator_pt_scene_lgt.cpp:36-59,
         integrator_pt_scene.cpp:441-486): a plain colour, or a lat-long map that is sampled explicitly when it is HDR (`sample` overrides
@@ -983,7 +1013,17 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
             bind_texture(mat, 0, wn)
         return mat
 
-    typed_loaders = {"gltf": convert_gltf, "rough_conductor": load_rough_conductor, "diffuse": load_diffuse,
+    def load_plastic(mnode):
+        """LoadPlasticMaterial (integrator_pt_scene_mat.cpp:675-757), RGB mode."""
+        rn = mnode.find("reflectance")
+        color = color4(rn) if rn is not None else np.zeros(4, np.float32)
+        r0, r1, tid = load_texture_from_node(rn) if rn is not None else ((0, 0, 0, 0), (0, 0, 0, 0), 0)
+        nl = mnode.find("nonlinear")
+        nonlinear = int(float(nl.get("val") if nl.get("val") is not None else (nl.text or 0))) if nl is not None else 0
+        return sc.material_plastic(color, float(val1f(mnode.find("alpha"), 0.1)), float(val1f(mnode.find("int_ior"), 1.49)),
+                                   float(val1f(mnode.find("ext_ior"), 1.000277)), nonlinear, tid, r0, r1)
+
+    typed_loaders = {"plastic": load_plastic, "gltf": convert_gltf, "rough_conductor": load_rough_conductor, "diffuse": load_diffuse,
                      "dielectric": load_dielectric, "blend": load_blend}
 
     # ConvertOldHydraMaterial (integrator_pt_scene_mat.cpp:280-450), every branch: emission, diffuse (+ Oren-Nayar), reflectivity with and
@@ -1004,7 +1044,7 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
             sc.materials.append(mat)
             continue
         if mtype_attr != "hydra_material":
-            raise NotImplementedError(f"material type '{mtype_attr}' is outside the path (plastic, thin_film: SURVEY.md 2a)")
+            raise NotImplementedError(f"material type '{mtype_attr}' is outside the path (thin_film: SURVEY.md 2a)")
         mat = _blank_material()
         mat["texid"] = (0, 0, 0, 0)                                           # Material mat = {}: no 0xFFFFFFFF sentinels in this converter
         mat["spdid"] = (0, 0, 0, 0)

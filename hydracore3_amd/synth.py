@@ -258,7 +258,7 @@ def dr_scene(xml_path, width=512, height=512, tex_size=256, target=False) -> S.S
 def random_scene(seed: int, width=48, height=32) -> S.SceneData:
     """Seeded random small scene for fuzz parity: a floor + back wall, 3..7 transformed spheres with materials drawn from every
     constructor of the hot path with parameters that include the corners (metalness 0 / 1, glossiness 0 / 1, coat 0 / 1, smooth and
-    rough conductors, Oren-Nayar), an optional textured material, 1..3 lights of random types, random environment, random depth."""
+    rough conductors, Oren-Nayar, glass, plastic, blends, normal maps), an optional textured material, 1..3 lights of random types, random environment, random depth."""
     r = np.random.RandomState(seed)
     sc = S.SceneData()
     sc.width, sc.height = width, height
@@ -273,7 +273,10 @@ def random_scene(seed: int, width=48, height=32) -> S.SceneData:
     col = lambda: tuple(float(v) for v in r.uniform(0.1, 0.95, 3))
 
     def rand_material():
-        k = r.randint(7)
+        k = r.randint(8)
+        if k == 7:
+            return sc.material_plastic(col(), float(r.choice([0.0, 0.05, r.uniform(0.05, 0.5)])), float(r.uniform(1.3, 1.8)), 1.0, int(r.randint(2)),
+                                       tex if r.uniform() < 0.3 else 0)
         if k == 6:
             return S.material_glass(col(), col(), float(r.uniform(1.2, 2.2)))
         if k == 0:

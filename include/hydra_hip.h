@@ -103,6 +103,11 @@ int  hpt_device_info(hpt_ctx* ctx, int* numCUs, int* wavefront, char* name, size
  * diff_render/drmain.cpp:174-261 keeping its texture, gradient and Adam moments resident). No reference counterpart: the reference's
  * generated GPU class owns its buffers (main.cpp:221-224). kind: 1 host->device, 2 device->host, 3 device->device; copies are
  * synchronous, memset is asynchronous on the null stream. */
+/* mi::fresnel_coat_precompute (mi_materials.cpp:377-451), what LoadPlasticMaterial (integrator_pt_scene_mat.cpp:675-757) stores for a
+ * MAT_TYPE_PLASTIC: the 64-entry rough-transmittance table (appended to m_arrays1f, its offset in Material::datai[0]) and the two scalars
+ * Material::data[PLASTIC_PRECOMP_REFLECTANCE = 3], data[PLASTIC_SPEC_SAMPLE_WEIGHT = 2]. Host code; no context, no device. RGB mode. */
+int  hpt_plastic_precompute(float alpha, float intIor, float extIor, const float* diffuseReflectance4, const float* specularReflectance4,
+                            float* outTransmittance64, float* outInternalReflectance, float* outSpecularSamplingWeight);
 int  hpt_device_malloc(hpt_ctx* ctx, size_t bytes, void** outDev);
 int  hpt_device_free(hpt_ctx* ctx, void* dev);
 int  hpt_device_copy(hpt_ctx* ctx, void* dst, const void* src, size_t bytes, int kind);

@@ -181,9 +181,9 @@ def image2d4f_regularizer(data, grad):
 
 
 def probe(name, *args):
-    a = np.zeros(8, np.float32)
+    a = np.zeros(max(8, len(args)), np.float32)
     a[:len(args)] = args
-    out = np.zeros(4, np.float32)
+    out = np.zeros(8, np.float32)
     rc = lib().orc_probe(name.encode(), a.ctypes.data, out.ctypes.data)
     if rc != 0:
         raise KeyError(name)

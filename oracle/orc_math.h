@@ -44,6 +44,7 @@ static inline f4 operator*(f4 a, f4 b) { return mk4(a.x * b.x, a.y * b.y, a.z * 
 static inline f4 operator*(f4 a, float s) { return mk4(a.x * s, a.y * s, a.z * s, a.w * s); }
 static inline f4 operator*(float s, f4 a) { return mk4(s * a.x, s * a.y, s * a.z, s * a.w); }
 static inline f4 operator/(f4 a, float s) { return mk4(a.x / s, a.y / s, a.z / s, a.w / s); }
+static inline f4 operator/(f4 a, f4 b) { return mk4(a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w); }
 
 static inline f2 operator+(f2 a, f2 b) { return mk2(a.x + b.x, a.y + b.y); }
 static inline f2 operator*(f2 a, f2 b) { return mk2(a.x * b.x, a.y * b.y); }

@@ -282,6 +282,10 @@ struct Ctx
         diffuseSampleAndEval(m, reflSpec, rands, v, shadeNormal, tc, &res);
       } break;
       case MAT_TYPE_GLASS: glassSampleAndEval(m, rands, v, geomNormal, &res, &a_misPrev->ior); break;    // integrator_pt_mat.cpp:178-183: the geometric normal
+      case MAT_TYPE_PLASTIC: {                                                                     // :270-282 (RGB mode)
+        const f4 reflSpec = m.colors[0] * texColor;                                                  // PLASTIC_COLOR x texture (integrator_spectrum.cpp:128-133 RGB early-out)
+        plasticSampleAndEval(m, reflSpec, rands, v, shadeNormal, &res, sc.arrays1f.data(), m.datai[0]);
+      } break;
       case MAT_TYPE_DIELECTRIC: {
         const f4 intIORSpec = splat4(m.data[DIELECTRIC_ETA_INT]);
         const uint specId = m.spdid[0];
@@ -345,6 +349,12 @@ struct Ctx
           f4 reflSpec = m.colors[DIFFUSE_COLOR];
           reflSpec = reflSpec * texColor;
           diffuseEval(m, reflSpec, l, v, shadeNormal, tc, &currVal);
+          res.val = res.val + currVal.val * weight * bumpCosMult;
+          res.pdf += currVal.pdf * weight;
+        } break;
+        case MAT_TYPE_PLASTIC: {                                                      // :484-499
+          const f4 reflSpec = m.colors[0] * texColor;
+          plasticEval(m, reflSpec, l, v, shadeNormal, &currVal, sc.arrays1f.data(), m.datai[0]);
           res.val = res.val + currVal.val * weight * bumpCosMult;
           res.pdf += currVal.pdf * weight;
         } break;
@@ -1062,6 +1072,25 @@ int orc_probe(const char* name, const float* a, float* out)
   if (n == "trD") { out[0] = trD(mk3(a[0], a[1], a[2]), mk2(a[3], a[4])); return 0; }
   if (n == "lambertSample") { const f3 r = lambertSample(mk2(a[0], a[1]), mk3(0, 0, 1), mk3(a[2], a[3], a[4])); out[0] = r.x; out[1] = r.y; out[2] = r.z; return 0; }
   if (n == "MapSamplesToDisc") { const f2 r = MapSamplesToDisc(mk2(a[0], a[1])); out[0] = r.x; out[1] = r.y; return 0; }
+  if (n == "plasticEval" || n == "plasticSample") {
+    // a[0..3] roughness, ior ratio, spec weight, internal reflectance; a[4] nonlinear; a[5..7] reflectance; a[8..10] v; a[11..13] l or rands.xyz;
+    // a[14..77] the transmittance table; n = +z
+    Material m; std::memset(&m, 0, sizeof(m));
+    for (int k = 0; k < 4; k++) m.data[k] = a[k];
+    m.nonlinear = (uint)a[4];
+    const f4 refl = mk4(a[5], a[6], a[7], 0.0f);
+    const f3 v = mk3(a[8], a[9], a[10]);
+    if (n == "plasticEval") {
+      BsdfEval r; r.val = mk4(0, 0, 0, 0); r.pdf = 0.0f;
+      plasticEval(m, refl, mk3(a[11], a[12], a[13]), v, mk3(0, 0, 1), &r, a + 14, 0);
+      out[0] = r.val.x; out[1] = r.val.y; out[2] = r.val.z; out[3] = r.pdf;
+    } else {
+      BsdfSample r; r.val = mk4(0, 0, 0, 0); r.pdf = 1.0f; r.dir = mk3(0, 1, 0); r.flags = 0; r.ior = 1.0f;
+      plasticSampleAndEval(m, refl, mk4(a[11], a[12], a[13], 0.0f), v, mk3(0, 0, 1), &r, a + 14, 0);
+      out[0] = r.dir.x; out[1] = r.dir.y; out[2] = r.dir.z; out[3] = r.val.x; out[4] = r.val.y; out[5] = r.val.z; out[6] = r.pdf;
+    }
+    return 0;
+  }
   if (n == "orennayarFunc") { out[0] = orennayarFunc(mk3(a[0], a[1], a[2]), mk3(a[3], a[4], a[5]), mk3(0, 0, 1), a[6]); return 0; }
   return 1;
 }

@@ -672,6 +672,147 @@ static inline void glassSampleAndEval(const Material& m, f4 rands, f3 viewDir, f
   pRes->pdf = 1.0f;
 }
 
+// ---- Mitsuba-style GGX helpers (include/cmaterial.h:563-583, 746-905) and MAT_TYPE_PLASTIC (include/cmat_plastic.h) ---------------------
+static const uint MAT_TYPE_PLASTIC = 5;                              // include/cmaterial.h:42; data: roughness, ior ratio, spec weight, reflectance (:133-136)
+static const int  MI_ROUGH_TRANSMITTANCE_RES = 64;                   // include/cglobals.h:18
+static const float EPSILON_32 = 5.960464477539063E-8f;               // include/cglobals.h:24
+static inline float FrDielectric(float cosTheta_i, float eta)        // :563-583
+{
+  cosTheta_i = clampf(cosTheta_i, -1.0f, 1.0f);
+  if (cosTheta_i < 0.0f) { eta = 1.0f / eta; cosTheta_i = -cosTheta_i; }
+  const float sin2Theta_i = 1.0f - cosTheta_i * cosTheta_i;
+  const float sin2Theta_t = sin2Theta_i / (eta * eta);
+  if (sin2Theta_t >= 1.0f) return 1.f;
+  const float cosTheta_t = safe_sqrt(1.0f - sin2Theta_t);
+  const float r_parl = (eta * cosTheta_i - cosTheta_t) / (eta * cosTheta_i + cosTheta_t);
+  const float r_perp = (cosTheta_i - eta * cosTheta_t) / (cosTheta_i + eta * cosTheta_t);
+  return (r_parl * r_parl + r_perp * r_perp) / 2.0f;
+}
+static inline f2 square_to_uniform_disk_concentric(f2 s)             // :770-791
+{
+  const float x = 2.f * s.x - 1.f, y = 2.f * s.y - 1.f;
+  float phi, r;
+  if (x == 0 && y == 0) { r = phi = 0; }
+  else if (x * x > y * y) { r = x; phi = (kPI / 4.f) * (y / x); }
+  else { r = y; phi = (kPI / 2.f) - (x / y) * (kPI / 4.f); }
+  return mk2(r * std::cos(phi), r * std::sin(phi));
+}
+static inline f3 square_to_cosine_hemisphere(f2 s)                   // :793-803
+{
+  const f2 p = square_to_uniform_disk_concentric(s);
+  return mk3(p.x, p.y, safe_sqrt(1.f - (p.x * p.x + p.y * p.y)));
+}
+static inline float smith_g1(f3 v, f3 m, f2 alpha)                   // :813-833
+{
+  const float xy_alpha_2 = alpha.x * v.x * alpha.x * v.x + alpha.y * v.y * alpha.y * v.y, tan_theta_alpha_2 = xy_alpha_2 / (v.z * v.z);
+  float result = 2.f / (1.f + safe_sqrt(1.f + tan_theta_alpha_2));
+  if (xy_alpha_2 == 0.f) result = 1.f;
+  if (v.z * dot(v, m) <= 0.f) result = 0.f;
+  return result;
+}
+static inline float eval_microfacet_ggx(f3 m, f2 alpha)              // :840-857, type 1
+{
+  const float alpha_uv = alpha.x * alpha.y, cos_theta = m.z;
+  const float ax = m.x / alpha.x, ay = m.y / alpha.y;
+  const float q = ax * ax + ay * ay + m.z * m.z;
+  const float result = 1.f / (kPI * alpha_uv * (q * q));
+  return result * cos_theta > 1e-20f ? result : 0.f;
+}
+static inline f3 sample_visible_normal(f3 wi, f2 rands, f2 alpha)    // :859-900 (the pdf in .w is not used by the plastic)
+{
+  const f3 wi_p = normalize(mk3(alpha.x * wi.x, alpha.y * wi.y, wi.z));
+  const float sin_theta2 = wi_p.x * wi_p.x + wi_p.y * wi_p.y;       // sincos_phi (:751-762)
+  const float inv_sin_theta = 1.f / safe_sqrt(sin_theta2);
+  float rx = wi_p.x * inv_sin_theta, ry = wi_p.y * inv_sin_theta;
+  if (std::abs(sin_theta2) <= 4.f * EPSILON_32) { rx = 1.f; ry = 0.f; } else { rx = clampf(rx, -1.f, 1.f); ry = clampf(ry, -1.f, 1.f); }
+  const float sin_phi = ry, cos_phi = rx, cos_theta = wi_p.z;
+  f2 p = square_to_uniform_disk_concentric(rands);                   // sample_visible_11 (:859-874)
+  const float s = 0.5f * (1.f + cos_theta);
+  p.y = lerpf(safe_sqrt(1.f - p.x * p.x), p.y, s);
+  const float x = p.x, y = p.y, z = safe_sqrt(1.f - (p.x * p.x + p.y * p.y));
+  const float sin_theta_i = safe_sqrt(1.f - cos_theta * cos_theta);
+  const float norm = 1.f / (sin_theta_i * y + cos_theta * z);
+  const float slx = (cos_theta * y - sin_theta_i * z) * norm, sly = x * norm;
+  const float sx = (cos_phi * slx - sin_phi * sly) * alpha.x, sy = (sin_phi * slx + cos_phi * sly) * alpha.y;
+  return normalize(mk3(-sx, -sy, 1.0f));
+}
+static inline float plasticTransmittance(const float* transmittance, uint trOffset, float cos_theta)   // the lerp_gather written out at cmat_plastic.h:27-38
+{
+  float x = cos_theta;
+  x *= float(MI_ROUGH_TRANSMITTANCE_RES - 1);
+  const uint index = std::min(uint(x), uint(MI_ROUGH_TRANSMITTANCE_RES - 2));
+  const float v0 = transmittance[trOffset + index], v1 = transmittance[trOffset + index + 1];
+  return lerpf(v0, v1, x - float(index));
+}
+static inline void plasticSampleAndEval(const Material& m, f4 a_reflSpec, f4 rands, f3 v, f3 n, BsdfSample* pRes, const float* transmittance, uint trOffset)   // cmat_plastic.h:7-99
+{
+  const float alpha = m.data[0], eta = m.data[1], spec_weight = m.data[2], internal_refl = m.data[3];
+  const uint nonlinear = m.nonlinear;
+  const f2 alpha2 = mk2(alpha, alpha);
+  f3 s = n, t = n;
+  CoordinateSystemV2(n, &s, &t);
+  const f3 wi = mk3(dot(v, s), dot(v, t), dot(v, n));
+  if (wi.z <= 0) return;
+  const float cos_theta_i = std::max(wi.z, EPSILON_32);
+  const float t_i = plasticTransmittance(transmittance, trOffset, cos_theta_i);
+  float prob_specular = (1.f - t_i) * spec_weight, prob_diffuse = t_i * (1.f - spec_weight);
+  if (prob_diffuse != 0.0f && prob_specular != 0.0f) { prob_specular = prob_specular / (prob_specular + prob_diffuse); prob_diffuse = 1.f - prob_specular; }
+  else { prob_diffuse = 1.0f; prob_specular = 0.0f; }
+  const bool sample_specular = rands.z < prob_specular;
+  f3 wo = mk3(0, 0, 0);
+  if (sample_specular) {
+    const f3 wm = sample_visible_normal(wi, mk2(rands.x, rands.y), alpha2);
+    const f3 d = (-1.0f) * wi;
+    wo = d - 2.0f * dot(d, wm) * wm;                                  // reflect((-1)*wi, wm)
+  } else wo = square_to_cosine_hemisphere(mk2(rands.x, rands.y));
+  if (cos_theta_i * wo.z <= 0) return;
+  const float cos_theta_o = std::max(wo.z, EPSILON_32);
+  const f3 H = normalize(wo + wi);
+  const float D = eval_microfacet_ggx(H, alpha2);
+  float pdf = D * smith_g1(wi, H, alpha2) / (4.f * cos_theta_i);
+  pdf *= prob_specular;
+  pdf += prob_diffuse * kINV_PI * cos_theta_o;
+  const float F = FrDielectric(dot(wi, H), eta);
+  const float G = smith_g1(wi, H, alpha2) * smith_g1(wo, H, alpha2);
+  const float val = F * D * G / (4.f * cos_theta_i * cos_theta_o);
+  const float t_o = plasticTransmittance(transmittance, trOffset, cos_theta_o);
+  const f4 diffuse = a_reflSpec / (splat4(1.f) - (nonlinear > 0 ? (a_reflSpec * internal_refl) : splat4(internal_refl)));
+  const float inv_eta_2 = 1.f / (eta * eta);
+  pRes->dir = normalize(wo.x * s + wo.y * t + wo.z * n);
+  pRes->val = splat4(val) + diffuse * (kINV_PI * inv_eta_2 * t_i * t_o);
+  pRes->pdf = pdf;
+  pRes->flags = RAY_FLAG_HAS_NON_SPEC;
+}
+static inline void plasticEval(const Material& m, f4 a_reflSpec, f3 l, f3 v, f3 n, BsdfEval* pRes, const float* transmittance, uint trOffset)   // cmat_plastic.h:102-191
+{
+  const float alpha = m.data[0], eta = m.data[1], spec_weight = m.data[2], internal_refl = m.data[3];
+  const uint nonlinear = m.nonlinear;
+  const f2 alpha2 = mk2(alpha, alpha);
+  f3 s = n, t = n;
+  CoordinateSystemV2(n, &s, &t);
+  const f3 wo = mk3(dot(l, s), dot(l, t), dot(l, n)), wi = mk3(dot(v, s), dot(v, t), dot(v, n));
+  if (wi.z * wo.z <= 0) return;
+  const float cos_theta_i = std::max(wi.z, EPSILON_32), cos_theta_o = std::max(wo.z, EPSILON_32);
+  const float t_i = plasticTransmittance(transmittance, trOffset, cos_theta_i);
+  float prob_specular = (1.f - t_i) * spec_weight, prob_diffuse = t_i * (1.f - spec_weight);
+  if (prob_diffuse != 0.0f && prob_specular != 0.0f) { prob_specular = prob_specular / (prob_specular + prob_diffuse); prob_diffuse = 1.f - prob_specular; }
+  else { prob_diffuse = 1.0f; prob_specular = 0.0f; }
+  const f3 H = normalize(wo + wi);
+  const float D = eval_microfacet_ggx(H, alpha2);
+  const float smith_g1_wi = smith_g1(wi, H, alpha2);
+  float pdf = D * smith_g1_wi / (4.f * cos_theta_i);
+  pdf *= prob_specular;
+  pdf += prob_diffuse * kINV_PI * cos_theta_o;
+  const float F = FrDielectric(dot(wi, H), eta);
+  const float G = smith_g1(wo, H, alpha2) * smith_g1_wi;
+  const float val = F * D * G / (4.f * cos_theta_i * cos_theta_o);
+  const float t_o = plasticTransmittance(transmittance, trOffset, cos_theta_o);
+  const f4 diffuse = a_reflSpec / (splat4(1.f) - (nonlinear > 0 ? (a_reflSpec * internal_refl) : splat4(internal_refl)));
+  const float inv_eta_2 = 1.f / (eta * eta);
+  pRes->val = splat4(val) + diffuse * (kINV_PI * inv_eta_2 * t_i * t_o);
+  pRes->pdf = pdf;
+}
+
 // ---- include/clight.h -----------------------------------------------------------------------------------------
 struct LightSample { f3 pos, norm; float pdf; bool isOmni, hasIES; };   // :58-65
 

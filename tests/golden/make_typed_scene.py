@@ -2,7 +2,7 @@
 """Writes tests/golden/scenes/typed_materials: a small Hydra scene (XML + VSGF + image4ub / image4f) whose materials use the typed nodes of
 LoadSceneMaterials (integrator_pt_scene.cpp:500-570) - gltf (ConvertGLTFMaterial, with colour / glossiness / metalness textures and the
 packed glossiness_metalness_coat form), rough_conductor (alpha and alpha_u / alpha_v), diffuse (Lambert, Oren-Nayar, textured),
-dielectric, blend (constant and texture-masked weight, nested) - the sampler attributes of ReadSamplerFromColorNode (addressing modes,
+dielectric, plastic (LoadPlasticMaterial: its transmittance table in m_arrays1f), blend (constant and texture-masked weight, nested) - the sampler attributes of ReadSamplerFromColorNode (addressing modes,
 point filter, texture matrix, input_gamma) a remap list, and normal-map bump (<displacement type="normal_bump">, with and without the invert / swap flags, also on a blend leaf). Own data, not the reference's: the two loaders (Python, C++) are checked
 against each other on it and the GPU against the oracle."""
 import os
@@ -48,13 +48,13 @@ def main():
     sp = synth._sphere_mesh(2)
     pad4 = lambda a: np.concatenate([np.asarray(a, np.float32).reshape(-1, 3), np.zeros((len(a), 1), np.float32)], 1) if np.asarray(a).shape[-1] == 3 else np.asarray(a, np.float32)
     ntri = sp[4].size // 3
-    nsph = 12
+    nsph = 14
     for i in range(nsph):                                             # one sphere mesh per material 1..12
         write_vsgf(os.path.join(OUT, "data", f"chunk_{i + 4:05d}.vsgf"), pad4(sp[0]), pad4(sp[1]), pad4(sp[2]), np.asarray(sp[3], np.float32), np.asarray(sp[4], np.uint32), np.full(ntri, i + 1, np.uint32))
     q = synth._quad((-8, 0, 6), (16, 0, 0), (0, 0, -14), 2, 2, 3.0)
-    write_vsgf(os.path.join(OUT, "data", "chunk_00016.vsgf"), pad4(q[0]), pad4(q[1]), pad4(q[2]), np.asarray(q[3], np.float32), np.asarray(q[4], np.uint32), np.zeros(q[4].size // 3, np.uint32))
+    write_vsgf(os.path.join(OUT, "data", "chunk_00026.vsgf"), pad4(q[0]), pad4(q[1]), pad4(q[2]), np.asarray(q[3], np.float32), np.asarray(q[4], np.uint32), np.zeros(q[4].size // 3, np.uint32))
     lq = synth._quad((-1, 0, -1), (2, 0, 0), (0, 0, 2))
-    write_vsgf(os.path.join(OUT, "data", "chunk_00017.vsgf"), pad4(lq[0]), pad4(lq[1]), pad4(lq[2]), np.asarray(lq[3], np.float32), np.asarray(lq[4], np.uint32), np.full(lq[4].size // 3, 13, np.uint32))
+    write_vsgf(os.path.join(OUT, "data", "chunk_00027.vsgf"), pad4(lq[0]), pad4(lq[1]), pad4(lq[2]), np.asarray(lq[3], np.float32), np.asarray(lq[4], np.uint32), np.full(lq[4].size // 3, 15, np.uint32))
     ident = "1 0 0 0 0 1 0 0 0 0 1 0 0 0 0 1"
     BUMP = '<displacement type="normal_bump"><normal_map><invert x="0" y="0" swap_xy="0" /><texture id="4" type="texref" matrix="2 0 0 0 0 2 0 0 0 0 1 0 0 0 0 1" input_gamma="1" /></normal_map></displacement>'
     BUMP_INV = BUMP.replace('x="0" y="0" swap_xy="0"', 'x="1" y="1" swap_xy="1"').replace('matrix="2 0 0 0 0 2', 'filter="point" matrix="3 0 0 0 0 3')
@@ -72,13 +72,15 @@ def main():
         '<material id="10" name="glass" type="dielectric"><int_ior val="1.5" /><ext_ior val="1.0" /><reflectance val="1 1 1" /><transmittance val="0.95 1 0.95" /></material>',
         f'<material id="11" name="masked" type="blend"><bsdf_1 id="5" /><bsdf_2 id="8" /><weight val="1.0"><texture id="2" type="texref" matrix="2 0 0 0 0 2 0 0 0 0 1 0 0 0 0 1" input_gamma="1" /></weight></material>',
         '<material id="12" name="nested" type="blend"><bsdf_1 id="11" /><bsdf_2 id="1" /><weight val="0.35" /></material>',
-        '<material id="13" name="light_material" type="hydra_material" light_id="0" visible="1"><emission><color val="20 20 20" /></emission></material>',
+        '<material id="13" name="plastic" type="plastic"><reflectance val="0.2 0.45 0.7" /><alpha val="0.12" /><int_ior val="1.49" /><ext_ior val="1.000277" /></material>',
+        f'<material id="14" name="plastic_nl" type="plastic"><reflectance val="0.9 0.9 0.9"><texture id="1" type="texref" matrix="{ident}" input_gamma="2.2" /></reflectance><alpha val="0.3" /><int_ior val="1.6" /><ext_ior val="1.0" /><nonlinear val="1" />{BUMP}</material>',
+        '<material id="15" name="light_material" type="hydra_material" light_id="0" visible="1"><emission><color val="20 20 20" /></emission></material>',
     ]
     geo = [f'<mesh id="{i}" name="s{i}" type="vsgf" loc="data/chunk_{i + 4:05d}.vsgf" />' for i in range(nsph)]
-    geo += [f'<mesh id="{nsph}" name="floor" type="vsgf" loc="data/chunk_00016.vsgf" />', f'<mesh id="{nsph + 1}" name="lightmesh" type="vsgf" loc="data/chunk_00017.vsgf" light_id="0" />']
+    geo += [f'<mesh id="{nsph}" name="floor" type="vsgf" loc="data/chunk_00026.vsgf" />', f'<mesh id="{nsph + 1}" name="lightmesh" type="vsgf" loc="data/chunk_00027.vsgf" light_id="0" />']
     inst = []
     for i in range(nsph):
-        x, z = -3.6 + 0.65 * i, -0.7 * (i % 3)
+        x, z = -3.9 + 0.6 * i, -0.7 * (i % 3)
         s = 0.3 + 0.02 * (i % 2)
         rm = 0 if i == 0 else -1                                      # the first sphere is recoloured through remap list 0 (1 -> 6)
         inst.append(f'<instance id="{i}" mesh_id="{i}" rmap_id="{rm}" matrix="{s} 0 0 {x} 0 {s} 0 {0.33 + 0.25 * (i % 2)} 0 0 {s} {z} 0 0 0 1" />')
@@ -99,7 +101,7 @@ def main():
   {chr(10).join("  " + g for g in geo)}
 </geometry_lib>
 <lights_lib>
-  <light id="0" name="area" type="area" shape="rect" distribution="diffuse" visible="1" mat_id="13" mesh_id="{nsph + 1}">
+  <light id="0" name="area" type="area" shape="rect" distribution="diffuse" visible="1" mat_id="15" mesh_id="{nsph + 1}">
     <size half_length="1" half_width="1" />
     <intensity><color val="1 1 1" /><multiplier val="20" /></intensity>
   </light>

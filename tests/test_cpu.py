@@ -471,3 +471,40 @@ def test_environment_map_estimators_agree():
     # the camera back plate replaces the map for primary rays that miss: those pixels carry no Monte-Carlo noise at all
     same = np.all(np.abs(mis[..., :3] - naive[..., :3]) < 1e-6, axis=-1)
     assert same.sum() > 200 and same.sum() < 48 * 32
+
+
+def test_plastic_bsdf_pdf_normalises_and_sampling_matches_eval():
+    """MAT_TYPE_PLASTIC (include/cmat_plastic.h) over the table of hpt_plastic_precompute (mi_materials.cpp:377-451): the pdf plasticEval
+    reports integrates to one over the hemisphere; plasticSampleAndEval's direction, value and pdf equal plasticEval at that direction;
+    the table is a transmittance (0..1, rising towards normal incidence) and the internal reflectance lies in (0, 1)."""
+    from hydracore3_amd import scene as S
+    from oracle import orc
+    sc = S.SceneData()
+    for alpha, nonlinear in ((0.1, 0), (0.3, 1)):
+        m = sc.material_plastic((0.6, 0.4, 0.2), alpha, 1.49, 1.000277, nonlinear)
+        off = int(m["datai"][0])
+        table = sc.arrays1f[off:off + 64]
+        assert np.all(table > 0.0) and np.all(table < 1.0) and table[-1] > table[0] and 0.0 < float(m["data"][3]) < 1.0
+        assert abs(table[-1] - (1.0 - ((1.49 / 1.000277 - 1.0) / (1.49 / 1.000277 + 1.0)) ** 2)) < 0.02          # ~ 1 - F(0) for a nearly smooth coat
+        head = [*m["data"][:4], float(nonlinear), 0.6, 0.4, 0.2]
+        for v in ((0.0, 0.0, 1.0), (0.6, 0.0, 0.8), (0.95, 0.1, np.sqrt(1 - 0.95 ** 2 - 0.01))):
+            # midpoint quadrature of the pdf over the hemisphere in (cos theta, phi)
+            n_mu, n_phi = 240, 512
+            mu = (np.arange(n_mu) + 0.5) / n_mu
+            phi = (np.arange(n_phi) + 0.5) / n_phi * 2 * np.pi
+            total = 0.0
+            for c in mu:
+                sn = np.sqrt(1 - c * c)
+                for ph in phi:
+                    r = orc.probe("plasticEval", *head, *v, sn * np.cos(ph), sn * np.sin(ph), c, *table)
+                    total += r[3]
+            total *= (1.0 / n_mu) * (2 * np.pi / n_phi)
+            assert 0.97 < total < 1.02, (alpha, v, total)       # (a little of the specular lobe falls below the horizon at grazing views)
+            rng = np.random.default_rng(1)
+            for _ in range(50):
+                u = rng.uniform(0, 1, 3)
+                smp = orc.probe("plasticSample", *head, *v, *u, *table)
+                if np.all(smp[3:6] == 0.0) and np.all(smp[:3] == (0.0, 1.0, 0.0)):
+                    continue                                       # the sampler's early-out: the reflected direction fell below the horizon
+                ev = orc.probe("plasticEval", *head, *v, *smp[:3], *table)
+                assert np.allclose(smp[3:6], ev[:3], rtol=2e-4, atol=1e-6) and np.isclose(smp[6], ev[3], rtol=2e-4), (u, smp, ev)

@@ -537,13 +537,13 @@ def test_legacy_material_converter_scene_matches_oracle():
 def test_typed_material_scene_matches_oracle():
     """tests/golden/scenes/typed_materials (own fixture, make_typed_scene.py): the typed material nodes of LoadSceneMaterials
     (integrator_pt_scene.cpp:500-570) - gltf with colour / glossiness / metalness textures and the packed form, rough_conductor,
-    diffuse, dielectric, blend - per-use samplers (clamp, point filter, texture matrix, linear-space and float textures) and a remap
+    diffuse, dielectric, plastic, blend - per-use samplers (clamp, point filter, texture matrix, linear-space and float textures) and a remap
     list; HIP == oracle, both schedules agree."""
     from hydracore3_amd.api import HipIntegrator
     from oracle.orc import OracleIntegrator
     from hydracore3_amd import scene as S
     sc = load_hydra_xml(scene_path("typed_materials"))
-    assert sorted({int(m["mtype"]) for m in sc.materials}) == [1, 3, 4, 6, 7, 0xEFFFFFFF]
+    assert sorted({int(m["mtype"]) for m in sc.materials}) == [1, 3, 4, 5, 6, 7, 0xEFFFFFFF] and sc.arrays1f.size == 128
     assert sc.all_remap_lists.tolist() == [1, 6, 0, 2] and sc.remap_inst[0][0] == 0
     assert {(t.fmt, t.filter, t.addr_u) for t in sc.textures} >= {(S.TEX_RGBA8, S.FILTER_LINEAR, S.ADDR_WRAP), (S.TEX_RGBA8, S.FILTER_LINEAR, S.ADDR_CLAMP),
                                                                        (S.TEX_RGBA32F, S.FILTER_NEAREST, S.ADDR_WRAP), (S.TEX_RGBA8, S.FILTER_NEAREST, S.ADDR_WRAP)}
@@ -586,6 +586,66 @@ def test_environment_map_scene_matches_oracle():
     g2, c2 = HipIntegrator(sc), OracleIntegrator(sc)
     a2, b2 = g2.render(4), c2.render(4)
     assert per_pixel_l2(a2, b2, 4) < 1e-3 and not np.allclose(a2[0], a[0] * 0.5)
+
+
+def test_plastic_material_matches_oracle():
+    """MAT_TYPE_PLASTIC (include/cmat_plastic.h, integrator_pt_mat.cpp:258-275, 484-499): rough dielectric coat over a diffuse base, the
+    transmittance table read from m_arrays1f at Material::datai[0]; linear and nonlinear variants, textured, bumped, and as the leaf of a
+    blend; HIP == oracle sample for sample, schedules agree."""
+    from hydracore3_amd.api import HipIntegrator
+    from oracle.orc import OracleIntegrator
+    from hydracore3_amd import scene as S, synth
+    sc = S.SceneData()
+    sc.width, sc.height = 72, 48
+    sc.cam_pos, sc.cam_look_at, sc.cam_up = (0.0, 1.8, 6.5), (0.0, 0.8, 0.0), (0.0, 1.0, 0.0)
+    sc.fov, sc.trace_depth = 42.0, 5
+    sc.env_color = (0.1, 0.12, 0.15, 0.0)
+    rng = np.random.RandomState(5)
+    img = rng.randint(0, 2 ** 32, (4, 4), dtype=np.uint64).astype(np.uint32) | np.uint32(0xFF000000)
+    tex = sc.add_texture(S.Texture(img, S.TEX_RGBA8, True, S.ADDR_WRAP, S.ADDR_WRAP, S.FILTER_LINEAR))
+    M = sc.materials
+    M.append(S.material_lambert((0.6, 0.6, 0.6)))                                                 # 0 floor
+    M.append(sc.material_plastic((0.7, 0.2, 0.2), 0.1))                                           # 1 the defaults of the reference's loader
+    M.append(sc.material_plastic((0.2, 0.6, 0.3), 0.35, 1.6, 1.0, nonlinear=1))                   # 2 rough, nonlinear
+    M.append(sc.material_plastic((0.9, 0.9, 0.9), 0.0, tex_id=tex, row0=(2, 0, 0, 0), row1=(0, 2, 0, 0)))   # 3 alpha 0 -> 1e-6, textured
+    M.append(S.material_conductor(0.2, 3.9, 0.15, 0.15))                                          # 4
+    M.append(S.material_blend(1, 4, 0.5))                                                         # 5 plastic / metal
+    M.append(sc.material_plastic((0.3, 0.3, 0.8), 0.2))                                           # 6 gets a normal map below
+    ny, nx = np.mgrid[0:8, 0:8]
+    dx, dy = 0.4 * np.sin(nx * np.pi / 2.0), 0.4 * np.cos(ny * np.pi / 2.0)
+    enc = lambda v: np.clip(np.rint((v * 0.5 + 0.5) * 255.0), 0, 255).astype(np.uint32)
+    nz = np.clip(np.rint(np.sqrt(1.0 - dx * dx - dy * dy) * 255.0), 0, 255).astype(np.uint32)
+    nmap = sc.add_texture(S.Texture(enc(dx) | (enc(dy) << 8) | (nz << 16) | np.uint32(0xFF000000), S.TEX_RGBA8, False))
+    S.set_normal_map(M[6], nmap, row0=(3, 0, 0, 0), row1=(0, 3, 0, 0))
+    assert sc.arrays1f.size == 4 * 64 and [int(M[i]["datai"][0]) for i in (1, 2, 3, 6)] == [0, 64, 128, 192]
+    p, n, t, uv, idx = synth._quad((-8, 0, 6), (16, 0, 0), (0, 0, -14), 2, 2, 4.0)
+    sc.add_instance(sc.add_mesh(p, n, t, uv, idx, [0]), np.eye(4))
+    sp = synth._sphere_mesh(2)
+    ntri = sp[4].size // 3
+    for i, mat in enumerate((1, 2, 3, 5, 6)):
+        gid = sc.add_mesh(sp[0], sp[1], sp[2], sp[3], sp[4], np.full(ntri, mat, np.uint32))
+        sc.add_instance(gid, S.translate(-2.6 + 1.3 * i, 0.6, -0.4 * (i % 2)) @ S.rotate_y(40.0 * i) @ S.scale(0.55, 0.55, 0.55))
+    sc.lights.append(S.light_rect(S.translate(0.0, 4.0, 1.5), 1.0, 1.0, (1, 1, 1), 14.0))
+    sc.lights.append(S.light_sphere(S.translate(-3.0, 2.5, 2.0), 0.3, (1.0, 0.8, 0.6), 25.0))
+    for integ in (INTEGRATOR_MIS_PT, INTEGRATOR_SHADOW_PT):
+        prm = sc.params(integ)
+        gpu, cpu = HipIntegrator(sc, prm), OracleIntegrator(sc, prm)
+        a, b = gpu.render(8), cpu.render(8)
+        l2 = per_pixel_l2(a, b, 8)
+        print(f"plastic ({integ}): L2 {l2:.2e}, mean {a[..., :3].mean() / 8:.4f}")
+        assert l2 < 1e-4 and np.isfinite(a).all() and a[..., :3].mean() > 0.05
+        assert np.array_equal(gpu.random_gens(), cpu.random_gens())
+        wf = HipIntegrator(sc, prm); wf.set_schedule(2)
+        assert np.array_equal(wf.render(8), a)
+    gn, cn = HipIntegrator(sc), OracleIntegrator(sc)
+    nv, nc = gn.render(4, naive=True), cn.render(4, naive=True)
+    assert per_pixel_l2(nv, nc, 4) < 1e-4 and np.array_equal(gn.random_gens(), cn.random_gens())
+    # a table that does not fit m_arrays1f is refused, not read out of bounds
+    from hydracore3_amd.api import HydraHipError
+    bad = M[6].copy(); bad["datai"][0] = sc.arrays1f.size - 10
+    sc.materials = M[:6] + [bad]
+    with pytest.raises(HydraHipError, match="m_arrays1f"):
+        HipIntegrator(sc)
 
 
 def test_dynamic_updates_equal_a_fresh_build(cornell):

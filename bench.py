@@ -246,6 +246,8 @@ def main():
         integ.set_launch_config(args.blocks_per_cu)
     if args.schedule or args.refill_below or args.trace_blocks_per_cu or args.groups:
         integ.set_schedule(args.schedule, args.refill_below, args.trace_blocks_per_cu, args.groups)
+    if os.environ.get("HYDRA_BENCH_FORCE_FULL") == "1":          # kernel study: run the kernels with every BSDF branch on a gltf-only scene
+        integ.set_option("force_full_materials", 1)
     N = W * H
     from hydracore3_amd.sharding import tid_interleave
     weak = args.scaling == "weak"

@@ -99,6 +99,7 @@ struct hpt_ctx
   uint wfGrace = 16;                     // trips a trace wave keeps going after the queue ran dry before it suspends its rays (0 = never)
   // multi-GPU collectives (RCCL, loaded on first use: single-GPU users never touch it)
   void* rcclLib = nullptr; void* comm = nullptr; int commRanks = 0, commRank = 0;
+  bool forceFull = false;                // diagnostic (hpt_set_option "force_full_materials")
   bool leanMaterials = false;            // every material is gltf or emissive: the kernels without the other BSDF branches are used
   int  schedule = 0;                     // 0 automatic, 1 megakernel, 2 wavefront (hpt_set_schedule)
   int  nodeMinOverride = -1;             // env HPT_NODE_MIN (tuning): overrides the per-scene choice of DevScene::nodeMin
@@ -705,10 +706,10 @@ extern "C" int hpt_set_random_gens(hpt_ctx* c, const uint32_t* in, uint32_t coun
 }
 
 // ---- the hot path -------------------------------------------------------------------------------------------------------------------
-static int gridBlocks(hpt_ctx* c, bool dr)
+static int gridBlocks(hpt_ctx* c, bool dr, bool fullMaterials = false)
 {
   int bpc = c->blocksPerCU;
-  if (bpc <= 0) bpc = 4;                  // = __launch_bounds__(256, 4); measured for DR: 2 -> 185, 3 -> 206, 4 -> 259 Mpaths/s
+  if (bpc <= 0) bpc = fullMaterials ? HPT_FULL_WAVES : 4;   // = the kernel's __launch_bounds__; measured for DR: 2 -> 185, 3 -> 206, 4 -> 259 Mpaths/s
   return c->numCUs * bpc;
 }
 
@@ -745,7 +746,8 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   if (dr && !c->leanMaterials) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceDR: gltf and emissive materials without normal maps only (what the reference's replay differentiates, integrator_dr.cpp:461-612)");
   // never more lanes than pixels: with fewer, the hardware's round-robin block placement spreads them evenly over the CUs, whereas a
   // full grid would let whichever waves ask first take all the work (a small multi-GPU share of a frame)
-  const int blocks = (int)std::min<size_t>((size_t)gridBlocks(c, dr), ((size_t)job.tidCount + 255) / 256);
+  const bool fullMaterials = !dr && !(c->leanMaterials && !c->forceFull && !naive && !inRays && !(c->instrument && !dr));   // MODE 0 / 1 / 2 / STATS kernels
+  const int blocks = (int)std::min<size_t>((size_t)gridBlocks(c, dr, fullMaterials), ((size_t)job.tidCount + 255) / 256);
   HIPCHK(c, c->dQueue.alloc(1));
   HIPCHK(c, hipMemsetAsync(c->dQueue.p, 0, 4, st));
   job.queue = c->dQueue.p;
@@ -768,7 +770,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   else if (inRays) launchPT<false, false, 2>(c->S, job, blocks, st, deep);
   else if (naive)  launchPT<false, false, 1>(c->S, job, blocks, st, deep);
   else if (stats)  launchPT<true, false, 0>(c->S, job, blocks, st, deep);
-  else if (c->leanMaterials) launchPT<false, false, 3>(c->S, job, blocks, st, deep);
+  else if (c->leanMaterials && !c->forceFull) launchPT<false, false, 3>(c->S, job, blocks, st, deep);
   else             launchPT<false, false, 0>(c->S, job, blocks, st, deep);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev1, st));
@@ -884,7 +886,7 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr)
       wj.itemBase = g.itemBase; wj.itemCount = g.itemCount; wj.iter = (uint)g.it; wj.record = g.rec.p;
       const dim3 sg((g.itemCount + 255u) / 256u);
       if (dr)                    wfShadeKernel<true, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
-      else if (c->leanMaterials) wfShadeKernel<false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
+      else if (c->leanMaterials && !c->forceFull) wfShadeKernel<false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
       else                       wfShadeKernel<false, false><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
       if ((g.it % WF_CHECK) == WF_CHECK - 1) {
         const uint slot = g.checkpoints % WF_RING;
@@ -1223,6 +1225,7 @@ extern "C" int hpt_set_option(hpt_ctx* c, const char* name, int value)
   const std::string k(name);
   if (k == "wf_grace") c->wfGrace = (uint)value;                                      // trips after the queue ran dry before a trace wave suspends its rays (0: never)
   else if (k == "node_min") { c->nodeMinOverride = value & 63; c->accelCommitted = false; }   // voted exit of the inner-node loop; takes effect at the next CommitScene
+  else if (k == "force_full_materials") c->forceFull = value != 0;                     // diagnostic: never pick the lean (gltf + emissive) kernels
   else return c->fail(HPT_ERR_ARG, "hpt_set_option: unknown option " + k);
   return HPT_OK;
 }

@@ -52,8 +52,15 @@ struct Job
 // MODE: 0 = PathTrace (MIS / shadow / stupid by m_intergatorType), 1 = NaivePathTrace, 2 = PathTraceFromInputRays (the caller's rays
 // instead of camera rays, linear tid -> output index, raw accumColor: integrator_pt.cpp:159-199, 659-676, 761-798),
 // 3 = PathTrace for scenes with gltf + emissive materials only (shadeVertex<LEAN>)
+// waves per SIMD the kernels with every BSDF branch (MODE 0 / 1 / 2) are compiled for; the lean and DR kernels keep HPT_MIN_WAVES.
+// Measured (profiles/ab_full.sh, 1024^2 x 64 spp, Mpaths/s at 4 / 3 / 2 waves): Cornell forced onto this kernel 1410 / 1531 / 1264,
+// legacy_materials 1585 / 1714 / 1528, env_map 1425 / 1507 / 1369, typed_materials 1123 / 1125 / 1105 - 168 VGPRs instead of 128 take
+// the spills from 160 to 44 registers and that outweighs the lost wave.
+#ifndef HPT_FULL_WAVES
+#define HPT_FULL_WAVES 3
+#endif
 template <bool STATS, bool DR, int MODE, bool DEEP, bool FLAT>
-__global__ void __launch_bounds__(256, HPT_MIN_WAVES) pathTraceKernel(const DevScene S, const Job job)
+__global__ void __launch_bounds__(256, (DR || MODE == 3) ? HPT_MIN_WAVES : HPT_FULL_WAVES) pathTraceKernel(const DevScene S, const Job job)
 {
   constexpr bool NAIVE = (MODE == 1), INRAYS = (MODE == 2), LEAN = (MODE == 3);
   __shared__ uint stackMem[LDS_STACK * 256];

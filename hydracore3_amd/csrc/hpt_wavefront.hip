@@ -98,11 +98,14 @@ HPT_DEV void blockAppend(uint* counter, bool qNear, bool qShad, uint& posNear, u
   posShad = base + cn + mbcnt64(ms);
 }
 
+#ifndef HPT_WF_SHADE_FULL_WAVES
+#define HPT_WF_SHADE_FULL_WAVES 3      // the shade kernel with every BSDF branch: 1 M-triangle interior forced onto it 209 (4 waves) -> 214 Mpaths/s (profiles/ab_wfs.sh)
+#endif
 #ifndef HPT_WF_SHADE_WAVES
 #define HPT_WF_SHADE_WAVES 4
 #endif
 template <bool DR, bool LEAN>
-__global__ void __launch_bounds__(256, HPT_WF_SHADE_WAVES) wfShadeKernel(const DevScene S, const WfPool P, const WfJob job)
+__global__ void __launch_bounds__(256, (DR || LEAN) ? HPT_WF_SHADE_WAVES : HPT_WF_SHADE_FULL_WAVES) wfShadeKernel(const DevScene S, const WfPool P, const WfJob job)
 {
   const uint s = blockIdx.x * 256u + threadIdx.x;
   uint* ctr = P.ctr + WF_CTR_WORDS * (job.iter & 1u);

@@ -27,7 +27,7 @@ enum : uint { MAT_TYPE_GLASS = 2 };    // include/cmaterial.h:39; colours: 0 ref
 enum : uint { MAT_TYPE_GLTF = 1, MAT_TYPE_CONDUCTOR = 3, MAT_TYPE_DIFFUSE = 4, MAT_TYPE_DIELECTRIC = 7, MAT_TYPE_LIGHT_SOURCE = 0xEFFFFFFFu };
 enum : uint { RAY_EVENT_S = 1, RAY_EVENT_T = 8 };
 enum : uint { LIGHT_GEOM_RECT = 1, LIGHT_GEOM_DISC = 2, LIGHT_GEOM_SPHERE = 3, LIGHT_GEOM_DIRECT = 4, LIGHT_GEOM_POINT = 5, LIGHT_GEOM_ENV = 6 };
-enum : uint { LIGHT_DIST_LAMBERT = 0, LIGHT_DIST_OMNI = 1, LIGHT_DIST_SPOT = 2, LIGHT_FLAG_POINT_AREA = 1 };
+enum : uint { LIGHT_DIST_LAMBERT = 0, LIGHT_DIST_OMNI = 1, LIGHT_DIST_SPOT = 2, LIGHT_FLAG_POINT_AREA = 1, LIGHT_FLAG_PROJECTIVE = 2 };
 enum : uint { INTEGRATOR_STUPID_PT = 0, INTEGRATOR_SHADOW_PT = 1, INTEGRATOR_MIS_PT = 2, FB_COLOR = 0, FB_DIRECT = 1, FB_INDIRECT = 2 };
 // Material::colors / Material::data slots (include/cmaterial.h:67-147)
 enum { GLTF_COLOR_BASE = 0, GLTF_COLOR_COAT = 1, GLTF_COLOR_METAL = 2 };
@@ -890,7 +890,7 @@ HPT_DEV float lightEvalPDF(const LightRec& L, V3 illuminationPoint, V3 ray_dir, 
   return pdfAtoW(L.pdfA, hitDist, cosVal);
 }
 
-HPT_DEV V3 lightIntensity(const DevScene& S, const LightRec& L, V3 a_rayPos, V3 a_rayDir)   // :109-173 (RGB; projective lights out of scope)
+HPT_DEV V3 lightIntensity(const DevScene& S, const LightRec& L, V3 a_rayPos, V3 a_rayDir)   // :109-173 (RGB mode)
 {
   V3 lightColor = ld3(L.intensity);
   lightColor = lightColor * L.mult;
@@ -906,6 +906,12 @@ HPT_DEV V3 lightIntensity(const DevScene& S, const LightRec& L, V3 a_rayPos, V3 
     const float tVal = (cos_theta - L.lightCos2) / (L.lightCos1 - L.lightCos2);    // mylocalsmoothstep (clight.h:220-225)
     const float t = smin(smax(tVal, 0.0f), 1.0f);
     lightColor = lightColor * (t * t * (3.0f - 2.0f * t));
+    if ((L.flags & LIGHT_FLAG_PROJECTIVE) != 0 && L.texId != 0xFFFFFFFFu) {       // :153-161: a slide projector - the texture through the light's view-projection
+      const V4 clip = mul4x4(L.iesMatrix, v4(a_rayPos.x, a_rayPos.y, a_rayPos.z, 1.0f));
+      const V3 ndc = v3(clip.x, clip.y, clip.z) / clip.w;
+      const V4 texColor = texSample(S.textures, L.texId, v2(ndc.x * 0.5f + 0.5f, ndc.y * 0.5f + 0.5f));
+      lightColor = lightColor * v3(texColor.x, texColor.y, texColor.z);
+    }
   }
   else if (L.texId != 0xFFFFFFFFu) {                                    // :163-170: the environment map seen along the shadow ray
     const V2 tc = mulRows2x4(L.samplerRow0, L.samplerRow1, sphereMapTo2DTexCoord(a_rayDir));

@@ -522,6 +522,7 @@ static int check_lights(hpt_ctx* c, const LightRec* l, size_t n, size_t numTex, 
       if (l[i].texId != 0xFFFFFFFFu && l[i].texId >= numTex) return c->fail(HPT_ERR_ARG, "environment light refers to a texture that does not exist");
     }
     if (l[i].geomType < LIGHT_GEOM_RECT || l[i].geomType > LIGHT_GEOM_ENV) return c->fail(HPT_ERR_ARG, "bad light geomType");
+    if (l[i].geomType != LIGHT_GEOM_ENV && l[i].texId != 0xFFFFFFFFu && l[i].texId >= numTex) return c->fail(HPT_ERR_ARG, "light refers to a projected texture that does not exist");
     if (l[i].iesId != 0xFFFFFFFFu && l[i].iesId >= numTex) return c->fail(HPT_ERR_ARG, "light refers to an IES texture that does not exist");
   }
   return HPT_OK;

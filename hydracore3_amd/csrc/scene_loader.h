@@ -138,6 +138,33 @@ inline M4 m4Inverse(const M4& A)                             // Gauss-Jordan wit
 }
 inline void m4ToColMajor(const M4& A, float out[16]) { for (int c = 0; c < 4; c++) for (int r = 0; r < 4; r++) out[c * 4 + r] = (float)A.m[r][c]; }
 inline std::vector<double> parseFloats(const std::string& s) { std::vector<double> v; std::istringstream is(s); double x; while (is >> x) v.push_back(x); return v; }
+// LiteMath::perspectiveMatrix / lookAt (OpenGL conventions), in double
+inline M4 m4Perspective(double fovDeg, double aspect, double zNear, double zFar)
+{
+  const double ymax = zNear * std::tan(fovDeg * M_PI / 360.0), xmax = ymax * aspect;
+  const double left = -xmax, right = xmax, bottom = -ymax, top = ymax;
+  const double t = 2.0 * zNear, t2 = right - left, t3 = top - bottom, t4 = zFar - zNear;
+  M4 proj; std::memset(&proj, 0, sizeof(proj));
+  proj.m[0][0] = t / t2; proj.m[1][1] = t / t3; proj.m[0][2] = (right + left) / t2; proj.m[1][2] = (top + bottom) / t3;
+  proj.m[2][2] = (-zFar - zNear) / t4; proj.m[3][2] = -1.0; proj.m[2][3] = (-t * zFar) / t4;
+  return proj;
+}
+inline M4 m4LookAt(const double* eye, const double* center, const double* up)
+{
+  double f[3] = { center[0] - eye[0], center[1] - eye[1], center[2] - eye[2] };
+  const double fl = std::sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]); for (double& x : f) x /= fl;
+  const double ul = std::sqrt(up[0] * up[0] + up[1] * up[1] + up[2] * up[2]);
+  const double un[3] = { up[0] / ul, up[1] / ul, up[2] / ul };
+  double s[3] = { f[1] * un[2] - f[2] * un[1], f[2] * un[0] - f[0] * un[2], f[0] * un[1] - f[1] * un[0] };
+  const double sl = std::sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]); for (double& x : s) x /= sl;
+  const double u[3] = { s[1] * f[2] - s[2] * f[1], s[2] * f[0] - s[0] * f[2], s[0] * f[1] - s[1] * f[0] };
+  M4 wv = m4Identity();
+  for (int k = 0; k < 3; k++) { wv.m[0][k] = s[k]; wv.m[1][k] = u[k]; wv.m[2][k] = -f[k]; }
+  wv.m[0][3] = -(s[0] * eye[0] + s[1] * eye[1] + s[2] * eye[2]);
+  wv.m[1][3] = -(u[0] * eye[0] + u[1] * eye[1] + u[2] * eye[2]);
+  wv.m[2][3] = (f[0] * eye[0] + f[1] * eye[1] + f[2] * eye[2]);
+  return wv;
+}
 inline M4 m4FromText(const std::string& s) { M4 r = m4Identity(); const std::vector<double> v = parseFloats(s); for (int k = 0; k < 16 && k < (int)v.size(); k++) r.m[k / 4][k % 4] = v[k]; return r; }
 
 // ---- the loaded scene --------------------------------------------------------------------------------------------------------------
@@ -473,6 +500,25 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
     } else {
       lt.geomType = 5; lt.pdfA = 1.0f;
       lt.distType = (dist == "omni" || dist == "uniform" || dist == "ies") ? 1u : (dist == "spot" ? 2u : 0u);
+      if (dist == "spot") {                                                   // integrator_pt_scene_lgt.cpp:125-160
+        auto val = [](const XmlNode* n) -> float { return n ? (float)std::atof((n->has("val") ? n->get("val") : n->text).c_str()) : 0.0f; };
+        const float halfRad = 0.5f * 0.017453292519943295769f;
+        lt.lightCos2 = std::cos(halfRad * val(ln->child("falloff_angle")));
+        lt.lightCos1 = std::cos(halfRad * val(ln->child("falloff_angle2")));
+        if (const XmlNode* proj = ln->child("projective")) {                  // a slide projector: view-projection of the light in iesMatrix
+          M4 rot = m; rot.m[0][3] = rot.m[1][3] = rot.m[2][3] = 0.0; rot.m[3][3] = 1.0;
+          const double eye[3] = { m.m[0][3], m.m[1][3], m.m[2][3] };
+          const double look[3] = { -m.m[0][1] + m.m[0][3], -m.m[1][1] + m.m[1][3], -m.m[2][1] + m.m[2][3] };     // M * (0, -1, 0, 1)
+          const double up[3] = { rot.m[0][2], rot.m[1][2], rot.m[2][2] };                                         // rot * (0, 0, 1)
+          const M4 vp = m4Mul(m4Perspective(val(proj->child("fov")), 1.0, val(proj->child("nearClipPlane")), val(proj->child("farClipPlane"))), m4LookAt(eye, look, up));
+          m4ToColMajor(vp, lt.iesMatrix);
+          if (proj->child("texture")) {
+            float r0[4], r1[4]; uint32_t tid = 0;
+            if (!loadTextureFromNode(proj, r0, r1, tid)) return false;
+            lt.flags |= 2u; lt.texId = tid;                                   // LIGHT_FLAG_PROJECTIVE
+          }
+        }
+      }
     }
     if (const XmlNode* ies = ln->child("ies")) {
       LoadedTexture t; if (!iesSphericalTexture(folder + "/" + ies->get("loc"), t, err)) return false;

@@ -63,6 +63,7 @@ EMISSION_COLOR, EMISSION_MULT = 0, 0
 # include/clight.h:5-17
 LIGHT_GEOM_RECT, LIGHT_GEOM_DISC, LIGHT_GEOM_SPHERE, LIGHT_GEOM_DIRECT, LIGHT_GEOM_POINT, LIGHT_GEOM_ENV = 1, 2, 3, 4, 5, 6
 LIGHT_DIST_LAMBERT, LIGHT_DIST_OMNI, LIGHT_DIST_SPOT = 0, 1, 2
+LIGHT_FLAG_POINT_AREA, LIGHT_FLAG_PROJECTIVE = 1, 2
 # LiteImage::Sampler numbering
 ADDR_WRAP, ADDR_CLAMP = 0, 2
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
@@ -390,6 +391,21 @@ def pdf_table_from_image(tex):
     lum = np.maximum(lum, np.float32(0.1) * avg).reshape(-1)
     acc = np.concatenate([[0.0], np.cumsum(lum.astype(np.float64))])
     return acc.astype(np.float32), tex.width, tex.height
+
+
+def set_projective(lt, matrix, fov, z_near, z_far, tex_id=UINT_MAX):
+    """The <projective> node of a spot light (integrator_pt_scene_lgt.cpp:136-159): iesMatrix = perspective(fov, 1, near, far) * lookAt(pos,
+    M * (0, -1, 0), rot(M) * (0, 0, 1)); with a texture the light becomes a slide projector (LIGHT_FLAG_PROJECTIVE)."""
+    m = np.asarray(matrix, dtype=np.float64)
+    rot = m.copy(); rot[:, 3] = (0, 0, 0, 1)
+    pos = (m @ np.array([0, 0, 0, 1.0]))[:3]
+    look_at_t = (m @ np.array([0, -1.0, 0, 1.0]))[:3]
+    up_t = (rot @ np.array([0, 0, 1.0, 1.0]))[:3]
+    lt["iesMatrix"] = colmajor(perspective_matrix(fov, 1.0, z_near, z_far) @ look_at(pos, look_at_t, up_t))
+    if tex_id != UINT_MAX:
+        lt["flags"] = int(lt["flags"]) | LIGHT_FLAG_PROJECTIVE
+        lt["texId"] = tex_id
+    return lt
 
 
 def light_directional(matrix, color, mult) -> np.ndarray:
@@ -855,6 +871,14 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
             lt = light_sphere(m, float(size.get("radius")), color, power)
         else:
             lt = light_point(m, color, power, dist)
+            if dist == "spot":                                        # integrator_pt_scene_lgt.cpp:125-160
+                half_rad = np.float32(0.5) * np.float32(0.017453292519943295769)
+                lt["lightCos2"] = np.cos(half_rad * val1f(lnode.find("falloff_angle")), dtype=np.float32)
+                lt["lightCos1"] = np.cos(half_rad * val1f(lnode.find("falloff_angle2")), dtype=np.float32)
+                proj = lnode.find("projective")
+                if proj is not None:
+                    set_projective(lt, m, float(val1f(proj.find("fov"))), float(val1f(proj.find("nearClipPlane"))), float(val1f(proj.find("farClipPlane"))),
+                                   load_texture_from_node(proj)[2] if proj.find("texture") is not None else UINT_MAX)
         ies = lnode.find("ies")
         if ies is not None:
             img = ies_spherical_texture(os.path.join(folder, ies.get("loc")))

@@ -181,6 +181,12 @@ struct Ctx
       const f3 norm = xyz(L.norm);
       const float cos_theta = std::max(-dot(a_rayDir, norm), 0.0f);
       lightColor = lightColor * mylocalsmoothstep(cos2, cos1, cos_theta);
+      if ((L.flags & LIGHT_FLAG_PROJECTIVE) != 0 && L.texId != uint(-1)) {          // :153-161: a slide projector - the texture through the light's view-projection
+        const f4 posLightClipSpace = mul(L.iesMatrix, xyzw(a_rayPos, 1.0f));
+        const f3 posLightSpaceNDC = xyz(posLightClipSpace) / posLightClipSpace.w;
+        const f2 shadowTexCoord = mk2(posLightSpaceNDC.x * 0.5f + 0.5f, posLightSpaceNDC.y * 0.5f + 0.5f);
+        lightColor = lightColor * sc.tex_sample(L.texId, shadowTexCoord);
+      }
     }
     else if (L.texId != uint(-1)) {                                   // :163-170: the environment map seen along the shadow ray
       float sintheta = 0.0f;

@@ -36,7 +36,7 @@ static const int DIFFUSE_COLOR = 0, DIFFUSE_ROUGHNESS = 0;
 // include/clight.h:5-17
 static const uint LIGHT_GEOM_RECT = 1, LIGHT_GEOM_DISC = 2, LIGHT_GEOM_SPHERE = 3, LIGHT_GEOM_DIRECT = 4, LIGHT_GEOM_POINT = 5, LIGHT_GEOM_ENV = 6;
 static const uint LIGHT_DIST_LAMBERT = 0, LIGHT_DIST_OMNI = 1, LIGHT_DIST_SPOT = 2;
-static const uint LIGHT_FLAG_POINT_AREA = 1;
+static const uint LIGHT_FLAG_POINT_AREA = 1, LIGHT_FLAG_PROJECTIVE = 2;
 // integrator_pt.h:330-332, 406-408
 static const uint INTEGRATOR_STUPID_PT = 0, INTEGRATOR_SHADOW_PT = 1, INTEGRATOR_MIS_PT = 2;
 static const uint FB_COLOR = 0, FB_DIRECT = 1, FB_INDIRECT = 2;

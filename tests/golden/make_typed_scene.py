@@ -3,7 +3,7 @@
 LoadSceneMaterials (integrator_pt_scene.cpp:500-570) - gltf (ConvertGLTFMaterial, with colour / glossiness / metalness textures and the
 packed glossiness_metalness_coat form), rough_conductor (alpha and alpha_u / alpha_v), diffuse (Lambert, Oren-Nayar, textured),
 dielectric, plastic (LoadPlasticMaterial: its transmittance table in m_arrays1f), blend (constant and texture-masked weight, nested) - the sampler attributes of ReadSamplerFromColorNode (addressing modes,
-point filter, texture matrix, input_gamma) a remap list, and normal-map bump (<displacement type="normal_bump">, with and without the invert / swap flags, also on a blend leaf). Own data, not the reference's: the two loaders (Python, C++) are checked
+point filter, texture matrix, input_gamma) a remap list, a spot light with falloff angles and a projected texture (<projective>), and normal-map bump (<displacement type="normal_bump">, with and without the invert / swap flags, also on a blend leaf). Own data, not the reference's: the two loaders (Python, C++) are checked
 against each other on it and the GPU against the oracle."""
 import os
 import struct
@@ -106,6 +106,11 @@ def main():
     <intensity><color val="1 1 1" /><multiplier val="20" /></intensity>
   </light>
   <light id="1" name="sky" type="sky" shape="point" distribution="uniform"><intensity><color val="0.1 0.12 0.16" /><multiplier val="1" /></intensity></light>
+  <light id="2" name="projector" type="point" shape="point" distribution="spot" visible="0">
+    <size radius="0" /><falloff_angle val="70" /><falloff_angle2 val="50" />
+    <intensity><color val="1 0.9 0.8" /><multiplier val="60" /></intensity>
+    <projective><fov val="70" /><nearClipPlane val="0.1" /><farClipPlane val="100" /><texture id="2" type="texref" matrix="1 0 0 0 0 1 0 0 0 0 1 0 0 0 0 1" input_gamma="1" /></projective>
+  </light>
 </lights_lib>
 <cam_lib>
   <camera id="0" name="cam" type="uvn"><fov>42</fov><nearClipPlane>0.01</nearClipPlane><farClipPlane>100.0</farClipPlane><up>0 1 0</up><position>0 2.2 7.5</position><look_at>0 0.6 0</look_at></camera>
@@ -120,6 +125,7 @@ def main():
     </remap_lists>
     <instance_light id="0" light_id="0" matrix="1 0 0 0 0 1 0 3.5 0 0 1 0.5 0 0 0 1" lgroup_id="-1" />
     <instance_light id="1" light_id="1" matrix="1 0 0 0 0 1 0 0 0 0 1 0 0 0 0 1" lgroup_id="-1" />
+    <instance_light id="2" light_id="2" matrix="1 0 0 -2.5 0 0.8 -0.6 3.0 0 0.6 0.8 2.5 0 0 0 1" lgroup_id="-1" />
     {chr(10).join("    " + i for i in inst)}
   </scene>
 </scenes>

@@ -537,14 +537,17 @@ def test_legacy_material_converter_scene_matches_oracle():
 def test_typed_material_scene_matches_oracle():
     """tests/golden/scenes/typed_materials (own fixture, make_typed_scene.py): the typed material nodes of LoadSceneMaterials
     (integrator_pt_scene.cpp:500-570) - gltf with colour / glossiness / metalness textures and the packed form, rough_conductor,
-    diffuse, dielectric, plastic, blend - per-use samplers (clamp, point filter, texture matrix, linear-space and float textures) and a remap
-    list; HIP == oracle, both schedules agree."""
+    diffuse, dielectric, plastic, blend - per-use samplers (clamp, point filter, texture matrix, linear-space and float textures), a remap
+    list and a spot light that projects a texture (integrator_pt_lgt.cpp:145-161); HIP == oracle, both schedules agree."""
     from hydracore3_amd.api import HipIntegrator
     from oracle.orc import OracleIntegrator
     from hydracore3_amd import scene as S
     sc = load_hydra_xml(scene_path("typed_materials"))
     assert sorted({int(m["mtype"]) for m in sc.materials}) == [1, 3, 4, 5, 6, 7, 0xEFFFFFFF] and sc.arrays1f.size == 128
     assert sc.all_remap_lists.tolist() == [1, 6, 0, 2] and sc.remap_inst[0][0] == 0
+    spot = sc.lights[1]                                                   # the slide projector: falloff angles 70 / 50 degrees, LIGHT_FLAG_PROJECTIVE
+    assert int(spot["distType"]) == S.LIGHT_DIST_SPOT and int(spot["flags"]) & S.LIGHT_FLAG_PROJECTIVE and int(spot["texId"]) != 0xFFFFFFFF
+    assert abs(float(spot["lightCos2"]) - np.cos(np.radians(35.0))) < 1e-6 and abs(float(spot["lightCos1"]) - np.cos(np.radians(25.0))) < 1e-6
     assert {(t.fmt, t.filter, t.addr_u) for t in sc.textures} >= {(S.TEX_RGBA8, S.FILTER_LINEAR, S.ADDR_WRAP), (S.TEX_RGBA8, S.FILTER_LINEAR, S.ADDR_CLAMP),
                                                                        (S.TEX_RGBA32F, S.FILTER_NEAREST, S.ADDR_WRAP), (S.TEX_RGBA8, S.FILTER_NEAREST, S.ADDR_WRAP)}
     for integ in (INTEGRATOR_MIS_PT, INTEGRATOR_SHADOW_PT):

@@ -24,6 +24,7 @@ using namespace hpt;
 
 // Scenes with at least this many instanced triangles count as "heavy": wavefront schedule, single-level BVH, voted exit of the node loop.
 static const size_t HEAVY_SCENE_TRIS = size_t(1) << 13;    // measured (profiles/crossover.sh): wavefront wins from 16 K triangles up, loses 2x on the 36-triangle Cornell box
+static const size_t MANY_INSTANCES = 6;                      // instances from which the single-level layout is chosen for light scenes too (see hpt_commit_scene)
 
 namespace {
 
@@ -352,7 +353,11 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   // Automatic choice, measured: heavy static scenes (wavefront schedule) gain 8 % from the single-level layout (1M triangles: 191 -> 207
   // Mpaths/s; no instance enter / leave trips, triangle-loop lane utilisation 0.21 -> 0.38); the Cornell-box class on the megakernel loses
   // 8 % to it (looser world-space boxes around rotated instances, per-triangle ray transform) and keeps the two-level TLAS/BLAS layout.
-  const bool flat = instTris <= FLAT_TRI_BUDGET && (c->accelLayout == 2 || (c->accelLayout == 0 && instTris >= HEAVY_SCENE_TRIS));
+  // Scenes of many small instances (the own fixtures: 6 ... 16 transformed spheres on a floor) also gain from it on the megakernel:
+  // typed_materials 1031 -> 1127, legacy_materials 1574 -> 1752, env_map 1526 -> 1670 Mpaths/s (profiles/ab_layout.sh), the instance
+  // enter / leave trips outweigh the looser boxes once a ray meets several overlapping BLAS boxes.
+  const bool autoFlat = instTris >= HEAVY_SCENE_TRIS || c->insts.size() >= MANY_INSTANCES;
+  const bool flat = instTris <= FLAT_TRI_BUDGET && (c->accelLayout == 2 || (c->accelLayout == 0 && autoFlat));
   if (flat) {
     const size_t ni = c->insts.size();
     std::vector<Aabb> boxes; boxes.reserve(instTris);

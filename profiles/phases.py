@@ -4,7 +4,7 @@ import numpy as np
 from hydracore3_amd.api import HipIntegrator
 from hydracore3_amd.scene import load_hydra_xml
 from hydracore3_amd.synth import interior_scene
-for name in ('cornell','interior'):
+for name in (sys.argv[1:] or ('cornell','interior')):
     sc = load_hydra_xml('tests/golden/scenes/test_035/statex_00001.xml',1024,1024) if name=='cornell' else interior_scene(1920,1080)
     for layout in (1, 2):
       g = HipIntegrator(sc, accel_layout=layout); g.set_instrumentation(True); print('layout', layout)

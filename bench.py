@@ -361,7 +361,7 @@ def main():
                     "nodes_per_ray": round(ab["nodes_per_ray"], 2), "tris_per_ray": round(ab["tris_per_ray"], 2),
                     "rays_per_path": round(ab["rays_per_path"], 2)}
         if args.workload == "cornell":
-            roofline["note"] = ("36-triangle scene: the algorithmic bytes are served by L1/L2 (HBM traffic per launch is three orders below), so frac > 1 is "
+            roofline["note"] = ("36-triangle scene: the algorithmic bytes are served by L1/L2 (HBM traffic per launch is almost four orders below), so frac > 1 is "
                                 "not an HBM claim; the kernel is VALU-bound: 97 % busy at 37 % lane utilisation (profiles/r1_measurements.md, pmc_mega.sh)")
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.workload, W, H)

@@ -383,8 +383,6 @@ def main():
                           "mean_radiance": round(mean_lum, 5), "sharded_frame_verified": verified},
                "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

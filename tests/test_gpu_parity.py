@@ -858,3 +858,22 @@ def test_normal_map_bump_matches_oracle():
     with pytest.raises(HydraHipError, match="normal maps"):
         dr.PathTraceDR(dr.N, 4, np.zeros((sc.height, sc.width, 4), np.float32), 1, np.zeros((sc.height, sc.width, 4), np.float32),
                        np.ones(size, np.float32), np.zeros(size, np.float32))
+
+
+def test_bench_under_torch_distributed_run_exits_cleanly():
+    """The driver launches bench.py through torch.distributed.run for N > 1: with one rank and the process group forced on (RCCL on the
+    one GPU of the box) the run must print its JSON line and exit 0 - the teardown of the process group included."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HYDRA_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--spp", "16", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{\"metric\"")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0 and out["unit"] == "Mpaths/s"

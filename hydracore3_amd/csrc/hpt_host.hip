@@ -79,6 +79,7 @@ struct hpt_ctx
   DevBuf<MaterialRec> dMaterials; DevBuf<LightRec> dLights; DevBuf<TexRec> dTextures;
   std::vector<void*> texData; std::vector<TexRec> hTextures;
   DevBuf<float> dArrays1f; size_t numArrays1f = 0;       // m_arrays1f (pdf table of a sampled environment map)
+  std::vector<MaterialRec> hMaterials;                   // host mirror of m_materials: the blend graph is validated as a whole
   std::vector<uint> hLightGeom;                          // geomType of every light, to validate m_envLightId
   bool envLightOk(uint id) const { return id < hLightGeom.size() && hLightGeom[id] == LIGHT_GEOM_ENV; }
   DevBuf<Rng> dGens;
@@ -517,6 +518,27 @@ static int check_materials(hpt_ctx* c, const MaterialRec* m, size_t n, size_t nu
   }
   return HPT_OK;
 }
+// A blend refers to two other materials, possibly blends: the sampling loop of shadeVertex follows such references until it meets a
+// leaf, so a reference cycle would never end on the device. Three-colour depth-first search over the blend nodes.
+static int check_blend_graph(hpt_ctx* c, const std::vector<MaterialRec>& m)
+{
+  std::vector<unsigned char> state(m.size(), 0);           // 0 not seen, 1 on the current path, 2 done
+  std::vector<std::pair<uint, int>> path;
+  for (uint root = 0; root < (uint)m.size(); root++) {
+    if (m[root].mtype != MAT_TYPE_BLEND || state[root] != 0) continue;
+    path.clear(); path.push_back({ root, 0 }); state[root] = 1;
+    while (!path.empty()) {
+      auto& top = path.back();
+      if (top.second == 2) { state[top.first] = 2; path.pop_back(); continue; }
+      const uint child = m[top.first].datai[top.second++];
+      if (child >= m.size()) return c->fail(HPT_ERR_ARG, "blend material refers to a material that does not exist");
+      if (m[child].mtype != MAT_TYPE_BLEND) continue;
+      if (state[child] == 1) return c->fail(HPT_ERR_ARG, "blend materials refer to each other in a cycle (material " + std::to_string(child) + ")");
+      if (state[child] == 0) { state[child] = 1; path.push_back({ child, 0 }); }
+    }
+  }
+  return HPT_OK;
+}
 static int check_lights(hpt_ctx* c, const LightRec* l, size_t n, size_t numTex, size_t numArrays1f)
 {
   for (size_t i = 0; i < n; i++) {
@@ -541,6 +563,9 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
   if (d->numTextures == 0 || !d->textures) return c->fail(HPT_ERR_ARG, "m_textures must at least hold the white dummy texture");
   int rc = check_materials(c, (const MaterialRec*)d->materials, d->numMaterials, d->numTextures, d->numMaterials, d->numArrays1f); if (rc) return rc;
   c->leanMaterials = lean_materials((const MaterialRec*)d->materials, d->numMaterials);
+  { std::vector<MaterialRec> hm((const MaterialRec*)d->materials, (const MaterialRec*)d->materials + d->numMaterials);
+    rc = check_blend_graph(c, hm); if (rc) return rc;
+    c->hMaterials.swap(hm); }
   if (d->numArrays1f && !d->arrays1f) return c->fail(HPT_ERR_ARG, "m_arrays1f: count without data");
   rc = check_lights(c, (const LightRec*)d->lights, d->numLights, d->numTextures, d->numArrays1f); if (rc) return rc;
 
@@ -649,6 +674,12 @@ extern "C" int hpt_update_materials(hpt_ctx* c, size_t first, size_t count, cons
   if (!c || !mats) return HPT_ERR_ARG;
   if (first + count > c->dMaterials.n) return c->fail(HPT_ERR_ARG, "Update_m_materials: range out of bounds");
   int rc = check_materials(c, (const MaterialRec*)mats, count, c->hTextures.size(), c->dMaterials.n, c->numArrays1f); if (rc) return rc;
+  if (c->hMaterials.size() == c->dMaterials.n) {                                        // the blend graph of the table as it will be after the update
+    std::vector<MaterialRec> hm(c->hMaterials);
+    std::memcpy(hm.data() + first, mats, count * sizeof(MaterialRec));
+    rc = check_blend_graph(c, hm); if (rc) return rc;
+    c->hMaterials.swap(hm);
+  }
   if (!lean_materials((const MaterialRec*)mats, count)) c->leanMaterials = false;      // (an update can only widen the set of BSDFs in use)
   (void)hipSetDevice(c->device);
   HIPCHK(c, hipMemcpy(c->dMaterials.p + first, mats, count * sizeof(MaterialRec), hipMemcpyHostToDevice));

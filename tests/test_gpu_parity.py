@@ -759,6 +759,17 @@ def test_blend_materials_match_oracle():
     gn, cn = HipIntegrator(sc), OracleIntegrator(sc)
     nv, nc = gn.render(4, naive=True), cn.render(4, naive=True)
     assert per_pixel_l2(nv, nc, 4) < 1e-5 and np.array_equal(gn.random_gens(), cn.random_gens())
+    # a reference cycle among blends would never end on the device: refused at upload and at Update_m_materials
+    from hydracore3_amd.api import HydraHipError
+    import ctypes as C
+    live = HipIntegrator(sc)
+    loop = np.array([S.material_blend(7, 5, 0.5)], dtype=S.MATERIAL_DTYPE)        # 5 := blend(7, 5): refers to itself and, through 7, back again
+    with pytest.raises(HydraHipError, match="cycle"):
+        live._chk(live.L.hpt_update_materials(live.h, 5, 1, loop.ctypes.data))
+    assert np.array_equal(live.render(2), HipIntegrator(sc).render(2))            # the refused update left the context intact
+    sc.materials[5] = loop[0]
+    with pytest.raises(HydraHipError, match="cycle"):
+        HipIntegrator(sc)
 
 
 def test_event_bits_inherit_material_id_bits():

@@ -555,6 +555,47 @@ static int check_lights(hpt_ctx* c, const LightRec* l, size_t n, size_t numTex, 
   return HPT_OK;
 }
 
+// Every index the kernels follow without a bounds check of their own (an out-of-range one would fault on the device, which on this class of
+// machine can take the whole node down): material ids per primitive and per remap target, vertex indices, remap-list and light ids.
+static int check_tables(hpt_ctx* c, const hpt_scene_desc* d)
+{
+  if (d->numInsts && (!d->remapInst || !d->normMatrices)) return c->fail(HPT_ERR_ARG, "m_remapInst / m_normMatrices missing");
+  if (d->numTris && (!d->triIndices || !d->matIdByPrimId)) return c->fail(HPT_ERR_ARG, "m_triIndices / m_matIdByPrimId missing");
+  if (d->numVerts && !d->vData8f) return c->fail(HPT_ERR_ARG, "m_vData8f missing");
+  if (d->numGeoms && !d->matVertOffset) return c->fail(HPT_ERR_ARG, "m_matVertOffset missing");
+  for (uint g = 0; g < d->numGeoms; g++) {
+    // per-mesh counts: given (geometry handed over with the tables), or the distance to the next mesh's offsets (geometry went through
+    // AddGeom_Triangles3f: the Integrator keeps only m_matVertOffset)
+    const uint64_t triOff = d->matVertOffset[2 * g + 0], vertOff = d->matVertOffset[2 * g + 1];
+    const uint64_t triEnd = d->geomTriCount ? triOff + d->geomTriCount[g] : (g + 1 < d->numGeoms ? d->matVertOffset[2 * (g + 1) + 0] : d->numTris);
+    const uint64_t vertEnd = d->geomVertCount ? vertOff + d->geomVertCount[g] : (g + 1 < d->numGeoms ? d->matVertOffset[2 * (g + 1) + 1] : d->numVerts);
+    if (triEnd < triOff || vertEnd < vertOff || triEnd > d->numTris || vertEnd > d->numVerts) return c->fail(HPT_ERR_ARG, "m_matVertOffset: geometry " + std::to_string(g) + " reaches past the tables");
+    for (uint64_t t = 3 * triOff; t < 3 * triEnd; t++)
+      if (d->triIndices[t] >= vertEnd - vertOff) return c->fail(HPT_ERR_ARG, "m_triIndices: vertex index out of the mesh's range (geometry " + std::to_string(g) + ")");
+  }
+  for (uint t = 0; t < d->numTris; t++)
+    if ((d->matIdByPrimId[t] & 0x00FFFFFFu) >= d->numMaterials) return c->fail(HPT_ERR_ARG, "m_matIdByPrimId: material id " + std::to_string(d->matIdByPrimId[t]) + " does not exist");
+  // m_allRemapLists = the lists back to back, then one offset per list and the total (integrator_pt_scene.cpp:909-924)
+  const uint size = d->allRemapListsSize, len = d->allRemapListsLen;
+  int numLists = 0;
+  if (len) {
+    if (!d->allRemapLists || size >= len) return c->fail(HPT_ERR_ARG, "m_allRemapLists: size does not leave room for the offsets");
+    numLists = (int)(len - size) - 1;
+    for (int l = 0; l <= numLists; l++) {
+      const int off = d->allRemapLists[size + (uint)l];
+      if (off < 0 || (uint)off > size || (off & 1) || (l > 0 && off < d->allRemapLists[size + (uint)l - 1])) return c->fail(HPT_ERR_ARG, "m_allRemapLists: bad offset table");
+    }
+    for (uint i = 1; i < size; i += 2)
+      if (d->allRemapLists[i] < 0 || (uint)d->allRemapLists[i] >= d->numMaterials) return c->fail(HPT_ERR_ARG, "m_allRemapLists: remap target " + std::to_string(d->allRemapLists[i]) + " does not exist");
+  }
+  for (uint i = 0; i < d->numInsts; i++) {
+    const int list = d->remapInst[2 * i + 0], light = d->remapInst[2 * i + 1];
+    if (list < -1 || list >= numLists) return c->fail(HPT_ERR_ARG, "m_remapInst: remap list " + std::to_string(list) + " does not exist");
+    if (light < -1 || light >= (int)d->numLights) return c->fail(HPT_ERR_ARG, "m_remapInst: light " + std::to_string(light) + " does not exist");
+  }
+  return HPT_OK;
+}
+
 extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
 {
   if (!c || !d) return HPT_ERR_ARG;
@@ -568,6 +609,7 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
     c->hMaterials.swap(hm); }
   if (d->numArrays1f && !d->arrays1f) return c->fail(HPT_ERR_ARG, "m_arrays1f: count without data");
   rc = check_lights(c, (const LightRec*)d->lights, d->numLights, d->numTextures, d->numArrays1f); if (rc) return rc;
+  rc = check_tables(c, d); if (rc) return rc;
 
   if (d->vPos4f) {                                                     // LoadSceneGeometry + LoadSceneInstances order
     hpt_clear_geom(c);
@@ -602,6 +644,10 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
   {
     std::vector<int> rl(d->allRemapLists ? std::vector<int>(d->allRemapLists, d->allRemapLists + d->allRemapListsLen) : std::vector<int>());
     if (rl.empty()) rl.push_back(0);
+    // RemapMaterialId (integrator_pt_mat.cpp:530-573) bisects over the list's INT count while indexing PAIRS, so its probes reach up to one
+    // list length past the list's end (for the last list: past the array, in the reference too). Zero padding keeps those probes in bounds
+    // and makes what they read the same here and in the checker.
+    rl.resize(rl.size() + (size_t)d->allRemapListsSize + 2, 0);
     HIPCHK(c, c->dRemapLists.upload(rl.data(), rl.size()));
   }
   HIPCHK(c, c->dMaterials.upload((const MaterialRec*)d->materials, d->numMaterials));

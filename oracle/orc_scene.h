@@ -194,6 +194,9 @@ struct Scene
     normMatrices.assign((const m4*)s->normMatrices, (const m4*)s->normMatrices + s->numInsts);
     remapInst.assign(s->remapInst, s->remapInst + 2 * (size_t)s->numInsts);
     if (s->allRemapLists) allRemapLists.assign(s->allRemapLists, s->allRemapLists + s->allRemapListsLen);
+    // RemapMaterialId's bisection probes up to one list length past a list's end (see orc_pathtrace.cpp): zero padding keeps the probes of the
+    // last list inside the vector
+    allRemapLists.resize(allRemapLists.size() + (size_t)s->allRemapListsSize + 2, 0);
     allRemapListsSize = s->allRemapListsSize;
     materials.assign((const Material*)s->materials, (const Material*)s->materials + s->numMaterials);
     lights.assign((const LightSource*)s->lights, (const LightSource*)s->lights + s->numLights);

@@ -888,3 +888,41 @@ def test_bench_under_torch_distributed_run_exits_cleanly():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0 and out["unit"] == "Mpaths/s"
+
+
+def test_upload_refuses_tables_with_out_of_range_indices(cornell):
+    """hpt_upload_scene checks every index the kernels follow without a bounds check of their own - material ids per primitive and per
+    remap target, vertex indices, remap-list and light ids, the remap offset table - and returns an error instead of faulting on the device."""
+    from hydracore3_amd.api import HipIntegrator, HydraHipError
+    from hydracore3_amd import scene as S
+
+    def fresh():
+        sc = load_hydra_xml(scene_path("typed_materials"))
+        return sc
+
+    def refused(mutate, pattern):
+        sc = fresh()
+        mutate(sc)
+        with pytest.raises(HydraHipError, match=pattern):
+            HipIntegrator(sc)
+
+    def bad_mat(sc):
+        sc.mat_id_by_prim = sc.mat_id_by_prim.copy(); sc.mat_id_by_prim[7] = len(sc.materials)
+    def bad_index(sc):
+        sc.tri_indices = sc.tri_indices.copy(); sc.tri_indices[5] = 10 ** 6
+    def bad_list(sc):
+        sc.remap_inst[3] = (5, -1)
+    def bad_light(sc):
+        sc.remap_inst[2] = (-1, 17)
+    def bad_target(sc):
+        sc.set_remap_lists([[1, 6, 2, 400]])
+    def bad_offsets(sc):
+        sc.all_remap_lists = np.array([1, 6, 4, 2], np.int32); sc.all_remap_lists_size = 2
+    refused(bad_mat, "m_matIdByPrimId")
+    refused(bad_index, "m_triIndices")
+    refused(bad_list, "remap list")
+    refused(bad_light, "light 17")
+    refused(bad_target, "remap target")
+    refused(bad_offsets, "offset table")
+    a = HipIntegrator(fresh()).render(2)                                  # and the untouched scene still loads and renders
+    assert np.isfinite(a).all() and a[..., :3].mean() > 0

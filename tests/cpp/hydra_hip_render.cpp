@@ -1,7 +1,9 @@
-// Renders a Hydra XML scene through the C ABI without Python:  hydra_hip_render <scene.xml> <width> <height> <spp> <out.bin> [--tables]
+// Renders a Hydra XML scene through the C ABI without Python:  hydra_hip_render <scene.xml> <width> <height> <spp> <out.bin> [--tables | --ppm preview.ppm]
 //   default   : scene_loader.h -> LoadedScene::upload -> hpt_path_trace_block; writes the raw float4 frame (un-normalised, as the callee
 //               accumulates it) to <out.bin> and prints the mean radiance per sample
 //   --tables  : no GPU needed - dumps the loaded tables as [name '\0'][u64 byte count][bytes] records for the loader test
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -12,7 +14,7 @@ template <class T> static void blob(FILE* f, const char* name, const std::vector
 
 int main(int argc, char** argv)
 {
-  if (argc < 6) { std::fprintf(stderr, "usage: %s <scene.xml> <width> <height> <spp> <out.bin> [--tables]\n", argv[0]); return 2; }
+  if (argc < 6) { std::fprintf(stderr, "usage: %s <scene.xml> <width> <height> <spp> <out.bin> [--tables | --ppm preview.ppm]\n", argv[0]); return 2; }
   const int W = std::atoi(argv[2]), H = std::atoi(argv[3]), spp = std::atoi(argv[4]);
   const bool tables = argc > 6 && std::string(argv[6]) == "--tables";
   hydra_hip::LoadedScene sc; std::string err;
@@ -45,6 +47,16 @@ int main(int argc, char** argv)
   if (rc != HPT_OK) { std::fprintf(stderr, "[hydra_hip_render]: %s\n", hpt_last_error(ctx)); return 1; }
   float t[4]; hpt_get_execution_time(ctx, "PathTraceBlock", t);
   std::fwrite(frame.data(), sizeof(float), frame.size(), f); std::fclose(f);
+  if (argc > 6 && std::string(argv[6]) == "--ppm" && argc > 7) {                       // 8-bit preview: radiance / spp, gamma 2.2, top row first
+    if (FILE* pf = std::fopen(argv[7], "wb")) {
+      std::fprintf(pf, "P6\n%d %d\n255\n", W, H);
+      for (int y = H - 1; y >= 0; y--) for (int x = 0; x < W; x++) for (int k = 0; k < 3; k++) {
+        const float v = std::pow(std::min(std::max(frame[((size_t)y * W + x) * 4 + k] / float(spp), 0.0f), 1.0f), 1.0f / 2.2f);
+        std::fputc((int)(v * 255.0f + 0.5f), pf);
+      }
+      std::fclose(pf);
+    }
+  }
   double s = 0.0; for (size_t i = 0; i < frame.size(); i += 4) s += frame[i] + frame[i + 1] + frame[i + 2];
   std::printf("[hydra_hip_render]: %dx%d @ %d spp, mean radiance %.5f, kernel %.3f ms\n", W, H, spp, s / (3.0 * W * H * spp), t[0]);
   hpt_destroy(ctx);

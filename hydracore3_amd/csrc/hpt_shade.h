@@ -374,6 +374,9 @@ HPT_DEV void drReverseSweep(const DevScene& S, const float* record, size_t s, si
       for (int k = 0; k < 4; k++) {
         const int off = __float_as_int(r[(13 + k) * s]);
         const float w = r[(17 + k) * s];
+#ifdef HPT_DR_SKIP_FIRST_BOUNCE   // diagnostic build only: the share of the scatter that the camera-visible vertex (same texels for every sample of a pixel) accounts for
+        if (b == 0) { if (off < -1) gbase[0] = g.x * w; continue; }
+#endif
 #ifdef HPT_DR_NO_ATOMICS    // diagnostic build only: how much of PathTraceDR is the gradient scatter?
         if (off < -1) gbase[0] = g.x * w;
         continue;

@@ -508,3 +508,79 @@ def test_plastic_bsdf_pdf_normalises_and_sampling_matches_eval():
                     continue                                       # the sampler's early-out: the reflected direction fell below the horizon
                 ev = orc.probe("plasticEval", *head, *v, *smp[:3], *table)
                 assert np.allclose(smp[3:6], ev[:3], rtol=2e-4, atol=1e-6) and np.isclose(smp[6], ev[3], rtol=2e-4), (u, smp, ev)
+
+
+def _identity_scene(width=40, height=28):
+    """A floor and three spheres under a constant environment (no lights): the stage of the identity checks below."""
+    from hydracore3_amd import scene as S
+    sc = S.SceneData()
+    sc.width, sc.height = width, height
+    sc.cam_pos, sc.cam_look_at, sc.cam_up = (0.0, 1.6, 6.0), (0.0, 0.6, 0.0), (0.0, 1.0, 0.0)
+    sc.fov, sc.trace_depth = 40.0, 4
+    sc.env_color = (0.8, 0.9, 1.0, 0.0)
+    p, n, t, uv, idx = synth._quad((-8, 0, 6), (16, 0, 0), (0, 0, -14), 2, 2, 4.0)
+    sc.materials.append(S.material_lambert((0.5, 0.5, 0.5)))
+    sc.add_instance(sc.add_mesh(p, n, t, uv, idx, [0]), np.eye(4))
+    sp = synth._sphere_mesh(2)
+    ntri = sp[4].size // 3
+    for i in range(3):
+        gid = sc.add_mesh(sp[0], sp[1], sp[2], sp[3], sp[4], np.full(ntri, 1 + i, np.uint32))
+        sc.add_instance(gid, S.translate(-1.6 + 1.6 * i, 0.7, 0.0) @ S.rotate_y(30.0 * i) @ S.scale(0.7, 0.7, 0.7))
+    return sc
+
+
+def test_identities_of_the_widened_branches():
+    """Closed-form relations the restated branches must satisfy whatever the scene, checked on the oracle (which the GPU is held to):
+    a neutral normal map changes nothing; a constant environment map equals the plain environment colour to rounding under the naive
+    estimator; blend(A, A, w) has A's expectation; a clear legacy glass in a white furnace returns exactly one per path that leaves
+    the scene; plastic does not create energy."""
+    from hydracore3_amd import scene as S
+    from oracle.orc import OracleIntegrator
+    spp = 24
+    base = _identity_scene()
+    base.materials += [S.material_gltf((0.8, 0.3, 0.2, 1.0), 0.0, 0.7, 1.0, 1.5), S.material_conductor(0.2, 3.9, 0.2, 0.2), S.material_diffuse((0.3, 0.4, 0.8), 0.4)]
+    ref = OracleIntegrator(base).render(spp)
+
+    # 1. a normal map that says "straight up" in tangent space (float texels 0.5, 0.5, 1) on the floor, whose tangent frame is exactly
+    #    orthonormal, leaves the frame unchanged (on the spheres the interpolated tangent is not exactly perpendicular to the interpolated
+    #    normal, and the reference's inverse of (tan, bitan, n) then tilts even a neutral map)
+    sc = _identity_scene()
+    flat = sc.add_texture(S.Texture(np.tile(np.array([0.5, 0.5, 1.0, 1.0], np.float32), (2, 2, 1)), S.TEX_RGBA32F, False))
+    S.set_normal_map(sc.materials[0], flat, row0=(3, 0, 0, 0), row1=(0, 3, 0, 0))
+    sc.materials += base.materials[1:]
+    bumped = OracleIntegrator(sc).render(spp)
+    assert np.sqrt(np.mean(np.sum(((bumped - ref)[..., :3] / spp) ** 2, -1))) < 1e-6
+
+    # 2. a constant HDR environment map: the naive estimator (implicit hits only) draws the same numbers and multiplies by the same colour
+    sc = _identity_scene(); sc.materials += base.materials[1:]
+    const = sc.add_texture(S.Texture(np.ones((4, 8, 4), np.float32), S.TEX_RGBA32F, False))
+    sc.set_environment(base.env_color, const, sample=True)
+    a = OracleIntegrator(sc, sc.params(S.INTEGRATOR_STUPID_PT)).render(spp, naive=True)
+    b = OracleIntegrator(base, base.params(S.INTEGRATOR_STUPID_PT)).render(spp, naive=True)
+    assert np.allclose(a, b, rtol=2e-6, atol=0)                           # (the bilinear weights of a constant map sum to one within an ulp)
+    # ... and with the map sampled explicitly the MIS estimator agrees with it in the mean (uniform table pdf against the cosine lobe)
+    m = OracleIntegrator(sc, sc.params(S.INTEGRATOR_MIS_PT)).render(4 * spp) / (4 * spp)
+    assert np.allclose(m[..., :3].mean(axis=(0, 1)), (b / spp)[..., :3].mean(axis=(0, 1)), rtol=0.03)
+
+    # 3. blend(A, A, w): one more generator step per hit, the same expectation
+    sc = _identity_scene()
+    sc.materials += [S.material_blend(4, 4, 0.3), S.material_blend(5, 5, 0.8), S.material_blend(6, 6, 0.5)] + base.materials[1:]
+    blended = OracleIntegrator(sc).render(4 * spp) / (4 * spp)
+    many = OracleIntegrator(base).render(4 * spp) / (4 * spp)
+    assert np.allclose(blended[..., :3].mean(axis=(0, 1)), many[..., :3].mean(axis=(0, 1)), rtol=0.02)
+
+    # 4. white furnace: clear glass (both colours one) neither absorbs nor creates light - cos * val / pdf is exactly one per event, so a path
+    #    that leaves the scene carries throughput one and the pixel mean is the fraction of such paths; plastic stays at or below the furnace
+    for name, mats in (("glass", [S.material_glass((1, 1, 1), (1, 1, 1), 1.5)] * 3),):
+        sc = _identity_scene(); sc.env_color = (1.0, 1.0, 1.0, 0.0); sc.trace_depth = 12
+        sc.materials[0] = S.material_glass((1, 1, 1), (1, 1, 1), 1.5)
+        sc.materials += mats
+        img = OracleIntegrator(sc, sc.params(S.INTEGRATOR_STUPID_PT)).render(spp, naive=True) / spp
+        vals = np.unique(np.round(img[..., :3] * spp).astype(int))
+        assert np.allclose(img[..., :3] * spp, np.round(img[..., :3] * spp), atol=2e-4), name      # every sample contributed exactly 0 or 1
+        assert img[..., :3].mean() > 0.9 and img[..., :3].max() <= 1.0 + 1e-5 and vals.max() == spp
+    sc = _identity_scene(); sc.env_color = (1.0, 1.0, 1.0, 0.0); sc.trace_depth = 8
+    sc.materials[0] = sc.material_plastic((0.9, 0.9, 0.9), 0.15)
+    sc.materials += [sc.material_plastic((1.0, 1.0, 1.0), 0.05), sc.material_plastic((0.7, 0.7, 0.7), 0.4, nonlinear=1), sc.material_plastic((0.95, 0.95, 0.95), 0.25, 1.8, 1.0)]
+    img = OracleIntegrator(sc, sc.params(S.INTEGRATOR_STUPID_PT)).render(8 * spp, naive=True) / (8 * spp)
+    assert img[..., :3].mean() < 1.0 and np.percentile(img[..., :3], 99) < 1.08

@@ -39,6 +39,9 @@ ABI = {
     "hpt_commit_scene": (_i, [_vp, _u32]),
     "hpt_ray_query_nearest": (_i, [_vp, _vp, _vp, _u32, _vp]),
     "hpt_ray_query_any": (_i, [_vp, _vp, _vp, _u32, _vp]),
+    "hpt_ray_query_nearest_motion": (_i, [_vp, _vp, _vp, _u32, _f, _vp]),
+    "hpt_ray_query_any_motion": (_i, [_vp, _vp, _vp, _u32, _f, _vp]),
+    "hpt_add_instance_motion": (_u32, [_vp, _u32, _vp, _u32]),
     "hpt_upload_scene": (_i, [_vp, C.POINTER(SceneDesc)]),
     "hpt_update_params": (_i, [_vp, C.POINTER(Params)]),
     "hpt_update_materials": (_i, [_vp, _sz, _sz, _vp]),
@@ -217,6 +220,20 @@ class HipIntegrator:
         return ms.value
 
     # ---- ISceneObject queries -----------------------------------------------------------------------------------------
+    def RayQuery_NearestHitMotion(self, pos_near, dir_far, time):
+        pos_near = np.ascontiguousarray(pos_near, np.float32)
+        dir_far = np.ascontiguousarray(dir_far, np.float32)
+        out = np.zeros(pos_near.shape[0], HIT_DTYPE)
+        self._chk(self.L.hpt_ray_query_nearest_motion(self.h, pos_near.ctypes.data, dir_far.ctypes.data, pos_near.shape[0], float(time), out.ctypes.data))
+        return out
+
+    def RayQuery_AnyHitMotion(self, pos_near, dir_far, time):
+        pos_near = np.ascontiguousarray(pos_near, np.float32)
+        dir_far = np.ascontiguousarray(dir_far, np.float32)
+        out = np.zeros(pos_near.shape[0], np.uint32)
+        self._chk(self.L.hpt_ray_query_any_motion(self.h, pos_near.ctypes.data, dir_far.ctypes.data, pos_near.shape[0], float(time), out.ctypes.data))
+        return out
+
     def RayQuery_NearestHit(self, pos_near, dir_far):
         pos_near = np.ascontiguousarray(pos_near, np.float32)
         dir_far = np.ascontiguousarray(dir_far, np.float32)

@@ -1128,8 +1128,25 @@ HPT_DEV void toObjectSpace(const BvhInst* insts, const uint inst, const V3 wo, c
   d = v3(r0.x * wd.x + r0.y * wd.y + r0.z * wd.z, r1.x * wd.x + r1.y * wd.y + r1.z * wd.z, r2.x * wd.x + r2.y * wd.y + r2.z * wd.z);
 }
 
-template <bool ANY, bool STATS, bool DEEP>
-HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, float tfar, HitRec& hit, const TravStack& stk, TravStats& st)
+// A moving instance (AddInstanceMotion, EmbreeRT.cpp:264-292): the object->world matrix is interpolated linearly between its two keys at the
+// ray's time and inverted for this ray (Embree's motion-blurred instances do the same: lerp of local2world, then its inverse).
+// m = 24 floats: rows of the 3x4 matrix at time 0, then at time 1. Cofactor inverse in float, the translation subtracted first.
+HPT_DEV void toObjectSpaceMotion(const float* m, const float time, const V3 wo, const V3 wd, V3& o, V3& d)
+{
+  float a[12];
+  for (int k = 0; k < 12; k++) a[k] = m[k] + time * (m[12 + k] - m[k]);
+  const float c00 = a[5] * a[10] - a[6] * a[9], c01 = a[2] * a[9] - a[1] * a[10], c02 = a[1] * a[6] - a[2] * a[5];
+  const float c10 = a[6] * a[8] - a[4] * a[10], c11 = a[0] * a[10] - a[2] * a[8], c12 = a[2] * a[4] - a[0] * a[6];
+  const float c20 = a[4] * a[9] - a[5] * a[8],  c21 = a[1] * a[8] - a[0] * a[9],  c22 = a[0] * a[5] - a[1] * a[4];
+  const float det = a[0] * c00 + a[1] * c10 + a[2] * c20;
+  const float id = 1.0f / det;
+  const V3 p = v3(wo.x - a[3], wo.y - a[7], wo.z - a[11]);
+  o = v3((c00 * p.x + c01 * p.y + c02 * p.z) * id, (c10 * p.x + c11 * p.y + c12 * p.z) * id, (c20 * p.x + c21 * p.y + c22 * p.z) * id);
+  d = v3((c00 * wd.x + c01 * wd.y + c02 * wd.z) * id, (c10 * wd.x + c11 * wd.y + c12 * wd.z) * id, (c20 * wd.x + c21 * wd.y + c22 * wd.z) * id);
+}
+
+template <bool ANY, bool STATS, bool DEEP, bool MOTION = false>
+HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, float tfar, HitRec& hit, const TravStack& stk, TravStats& st, const float time = 0.0f)
 {
   hit.t = tfar; hit.prim = 0xFFFFFFFFu; hit.inst = 0xFFFFFFFFu; hit.u = 0.0f; hit.v = 0.0f;
   bool found = false;
@@ -1192,7 +1209,8 @@ HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, 
       const uint inst = cur & 0x0FFFFFFFu;
       const uint root = S.insts[inst].root;
       if (STATS) st.insts++;
-      toObjectSpace(S.insts, inst, wo, wd, o, d);
+      if (MOTION && S.insts[inst].pad0 != 0u) toObjectSpaceMotion(S.instMotion + 24u * inst, time, wo, wd, o, d);
+      else toObjectSpace(S.insts, inst, wo, wd, o, d);
       id = rcp3(d);
       curInst = inst;
       HPT_PUSH(REF_RESTORE);
@@ -1263,11 +1281,11 @@ HPT_DEV bool traceRayFlat(const DevScene& S, const V3 wo, const V3 wd, float tne
 }
 
 // dispatch on the scene's acceleration-structure layout (compile-time: each kernel variant is built for one layout)
-template <bool ANY, bool STATS, bool DEEP, bool FLAT>
-HPT_DEV bool traceAny(const DevScene& S, const V3 wo, const V3 wd, float tnear, float tfar, HitRec& hit, const TravStack& stk, TravStats& st)
+template <bool ANY, bool STATS, bool DEEP, bool FLAT, bool MOTION = false>
+HPT_DEV bool traceAny(const DevScene& S, const V3 wo, const V3 wd, float tnear, float tfar, HitRec& hit, const TravStack& stk, TravStats& st, const float time = 0.0f)
 {
-  if (FLAT) return traceRayFlat<ANY, STATS, DEEP>(S, wo, wd, tnear, tfar, hit, stk, st);
-  return traceRay<ANY, STATS, DEEP>(S, wo, wd, tnear, tfar, hit, stk, st);
+  if (FLAT) return traceRayFlat<ANY, STATS, DEEP>(S, wo, wd, tnear, tfar, hit, stk, st);      // (moving instances force the two-level layout)
+  return traceRay<ANY, STATS, DEEP, MOTION>(S, wo, wd, tnear, tfar, hit, stk, st, time);
 }
 
 } // namespace hpt

@@ -37,7 +37,7 @@ struct Geom
   bool               dirty = true;
 };
 
-struct Inst { uint geomId; float m[16]; };
+struct Inst { uint geomId; float m[16]; bool motion = false; float m1[16] = {0}; };   // m1: the matrix at time 1 of a moving instance (AddInstanceMotion)
 
 template <class T>
 struct DevBuf                      // owning device array; freed on scope exit (locals on error paths) or by hpt_destroy (context members)
@@ -79,6 +79,8 @@ struct hpt_ctx
   DevBuf<MaterialRec> dMaterials; DevBuf<LightRec> dLights; DevBuf<TexRec> dTextures;
   std::vector<void*> texData; std::vector<TexRec> hTextures;
   DevBuf<float> dArrays1f; size_t numArrays1f = 0;       // m_arrays1f (pdf table of a sampled environment map)
+  DevBuf<float> dInstMotion, dNormMat2;                  // motion blur: key matrices of the moving instances, end-of-motion normal matrices
+  bool anyMotion = false;                                // some instance moves: two-level layout, megakernel schedule, MOTION kernels
   std::vector<MaterialRec> hMaterials;                   // host mirror of m_materials: the blend graph is validated as a whole
   std::vector<uint> hLightGeom;                          // geomType of every light, to validate m_envLightId
   bool envLightOk(uint id) const { return id < hLightGeom.size() && hLightGeom[id] == LIGHT_GEOM_ENV; }
@@ -291,6 +293,17 @@ extern "C" uint32_t hpt_add_instance(hpt_ctx* c, uint32_t geomId, const float m[
   return (uint32_t)(c->insts.size() - 1);
 }
 
+extern "C" uint32_t hpt_add_instance_motion(hpt_ctx* c, uint32_t geomId, const float* matrices, uint32_t matrixNumber)
+{
+  if (!c || !matrices || geomId >= c->geoms.size() || matrixNumber == 0) return 0xFFFFFFFFu;
+  if (matrixNumber == 1) return hpt_add_instance(c, geomId, matrices);
+  if (matrixNumber != 2) { c->fail(HPT_ERR_UNSUPPORTED, "AddInstanceMotion: two key matrices are supported (what LoadSceneInstances passes)"); return 0xFFFFFFFFu; }
+  Inst in; in.geomId = geomId; std::memcpy(in.m, matrices, 64); std::memcpy(in.m1, matrices + 16, 64); in.motion = true;
+  c->insts.push_back(in);
+  c->accelCommitted = false;
+  return (uint32_t)(c->insts.size() - 1);
+}
+
 extern "C" int hpt_update_instance(hpt_ctx* c, uint32_t instId, const float m[16])
 {
   if (!c || !m) return HPT_ERR_ARG;
@@ -358,7 +371,10 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   // typed_materials 1031 -> 1127, legacy_materials 1574 -> 1752, env_map 1526 -> 1670 Mpaths/s (profiles/ab_layout.sh), the instance
   // enter / leave trips outweigh the looser boxes once a ray meets several overlapping BLAS boxes.
   const bool autoFlat = instTris >= HEAVY_SCENE_TRIS || c->insts.size() >= MANY_INSTANCES;
-  const bool flat = instTris <= FLAT_TRI_BUDGET && (c->accelLayout == 2 || (c->accelLayout == 0 && autoFlat));
+  c->anyMotion = false;
+  for (const Inst& in : c->insts) c->anyMotion = c->anyMotion || in.motion;
+  if (c->anyMotion && c->accelLayout == 2) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: moving instances need the two-level layout");
+  const bool flat = !c->anyMotion && instTris <= FLAT_TRI_BUDGET && (c->accelLayout == 2 || (c->accelLayout == 0 && autoFlat));
   if (flat) {
     const size_t ni = c->insts.size();
     std::vector<Aabb> boxes; boxes.reserve(instTris);
@@ -415,11 +431,14 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
     const Geom& g = c->geoms[c->insts[i].geomId];
     if (g.bvh.rootRef == REF_NONE) continue;               // empty mesh: never enters the TLAS
     Aabb w; w.reset();
-    const float* m = c->insts[i].m;
-    for (int k = 0; k < 8; k++) {
-      const float p[3] = { (k & 1) ? g.bvh.bounds.hi[0] : g.bvh.bounds.lo[0], (k & 2) ? g.bvh.bounds.hi[1] : g.bvh.bounds.lo[1], (k & 4) ? g.bvh.bounds.hi[2] : g.bvh.bounds.lo[2] };
-      const float q[3] = { m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12], m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13], m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14] };
-      w.grow(q);
+    // a moving instance: every point travels on a segment between its two key positions, so the union of the two key boxes bounds it
+    for (int key = 0; key < (c->insts[i].motion ? 2 : 1); key++) {
+      const float* m = key ? c->insts[i].m1 : c->insts[i].m;
+      for (int k = 0; k < 8; k++) {
+        const float p[3] = { (k & 1) ? g.bvh.bounds.hi[0] : g.bvh.bounds.lo[0], (k & 2) ? g.bvh.bounds.hi[1] : g.bvh.bounds.lo[1], (k & 4) ? g.bvh.bounds.hi[2] : g.bvh.bounds.lo[2] };
+        const float q[3] = { m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12], m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13], m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14] };
+        w.grow(q);
+      }
     }
     w.pad();
     ib.push_back(w); liveInst.push_back((uint)i);
@@ -447,7 +466,17 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   std::vector<BvhInst> dinst(std::max<size_t>(ni, 1));    // (never empty: an empty scene still hands valid pointers to the kernels)
   for (size_t i = 0; i < ni; i++) {
     inverse_rows(c->insts[i].m, dinst[i].row0, dinst[i].row1, dinst[i].row2);
-    dinst[i].root = geomRoot[c->insts[i].geomId]; dinst[i].geomId = c->insts[i].geomId; dinst[i].pad0 = dinst[i].pad1 = 0;
+    dinst[i].root = geomRoot[c->insts[i].geomId]; dinst[i].geomId = c->insts[i].geomId; dinst[i].pad0 = c->insts[i].motion ? 1u : 0u; dinst[i].pad1 = 0;
+  }
+  {                                                          // object->world rows (3x4) at both keys for the moving instances
+    std::vector<float> mo(24 * std::max<size_t>(ni, 1), 0.0f);
+    for (size_t i = 0; i < ni; i++) for (int key = 0; key < 2; key++) {
+      const float* m = (key && c->insts[i].motion) ? c->insts[i].m1 : c->insts[i].m;
+      float* o = &mo[24 * i + 12 * (size_t)key];
+      for (int r = 0; r < 3; r++) { o[4 * r + 0] = m[r]; o[4 * r + 1] = m[4 + r]; o[4 * r + 2] = m[8 + r]; o[4 * r + 3] = m[12 + r]; }
+    }
+    HIPCHK(c, c->dInstMotion.upload(mo.data(), mo.size()));
+    c->S.instMotion = c->dInstMotion.p;
   }
   if (nodes.empty()) nodes.push_back(BvhNode());           // keep the pointers valid
   if (tris.empty()) tris.push_back(BvhTri());
@@ -469,7 +498,7 @@ static hipError_t ensureStackOverflow(hpt_ctx* c, size_t lanes)
   return c->dStackOvf.alloc(extra * lanes);
 }
 
-static int ray_query(hpt_ctx* c, const float* posNear, const float* dirFar, uint32_t n, void* out, int any)
+static int ray_query(hpt_ctx* c, const float* posNear, const float* dirFar, uint32_t n, void* out, int any, float time = 0.0f)
 {
   if (!c || !posNear || !dirFar || !out) return HPT_ERR_ARG;
   if (!c->accelCommitted) return c->fail(HPT_ERR_STATE, "RayQuery before CommitScene");
@@ -482,8 +511,9 @@ static int ray_query(hpt_ctx* c, const float* posNear, const float* dirFar, uint
   HIPCHK(c, dout.alloc(outWords));
   const uint blocks = (n + 255) / 256;
   HIPCHK(c, ensureStackOverflow(c, (size_t)blocks * 256));
-  if (c->S.flatMode) rayQueryKernel<true><<<dim3(blocks), dim3(256), 0, 0>>>(c->S, dp.p, dd.p, n, dout.p, any, c->dStackOvf.p);
-  else               rayQueryKernel<false><<<dim3(blocks), dim3(256), 0, 0>>>(c->S, dp.p, dd.p, n, dout.p, any, c->dStackOvf.p);
+  if (c->S.flatMode)     rayQueryKernel<true><<<dim3(blocks), dim3(256), 0, 0>>>(c->S, dp.p, dd.p, n, dout.p, any, c->dStackOvf.p);
+  else if (c->anyMotion) rayQueryKernel<false, true><<<dim3(blocks), dim3(256), 0, 0>>>(c->S, dp.p, dd.p, n, dout.p, any, c->dStackOvf.p, time);
+  else                   rayQueryKernel<false><<<dim3(blocks), dim3(256), 0, 0>>>(c->S, dp.p, dd.p, n, dout.p, any, c->dStackOvf.p);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpy(out, dout.p, outWords * 4, hipMemcpyDeviceToHost));
   dp.release(); dd.release(); dout.release();
@@ -492,6 +522,8 @@ static int ray_query(hpt_ctx* c, const float* posNear, const float* dirFar, uint
 
 extern "C" int hpt_ray_query_nearest(hpt_ctx* c, const float* p, const float* d, uint32_t n, hpt_hit* out) { return ray_query(c, p, d, n, out, 0); }
 extern "C" int hpt_ray_query_any(hpt_ctx* c, const float* p, const float* d, uint32_t n, uint32_t* out) { return ray_query(c, p, d, n, out, 1); }
+extern "C" int hpt_ray_query_nearest_motion(hpt_ctx* c, const float* p, const float* d, uint32_t n, float time, hpt_hit* out) { return ray_query(c, p, d, n, out, 0, time); }
+extern "C" int hpt_ray_query_any_motion(hpt_ctx* c, const float* p, const float* d, uint32_t n, float time, uint32_t* out) { return ray_query(c, p, d, n, out, 1, time); }
 
 // ---- scene tables -----------------------------------------------------------------------------------------------------------------
 static bool lean_materials(const MaterialRec* m, size_t n)
@@ -620,8 +652,13 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
       if (id == 0xFFFFFFFFu) return HPT_ERR_ARG;
     }
     hpt_clear_scene(c);
-    for (uint i = 0; i < d->numInsts; i++)
-      if (hpt_add_instance(c, d->instGeomId[i], d->instMatrices + 16 * (size_t)i) == 0xFFFFFFFFu) return c->fail(HPT_ERR_ARG, "AddInstance: bad geomId");
+    for (uint i = 0; i < d->numInsts; i++) {
+      const bool moving = d->instHasMotion && d->instMatricesMotion && d->instHasMotion[i] != 0;
+      float two[32];
+      if (moving) { std::memcpy(two, d->instMatrices + 16 * (size_t)i, 64); std::memcpy(two + 16, d->instMatricesMotion + 16 * (size_t)i, 64); }
+      const uint32_t id = moving ? hpt_add_instance_motion(c, d->instGeomId[i], two, 2) : hpt_add_instance(c, d->instGeomId[i], d->instMatrices + 16 * (size_t)i);
+      if (id == 0xFFFFFFFFu) return c->fail(HPT_ERR_ARG, "AddInstance: bad geomId");
+    }
     rc = hpt_commit_scene(c, 0); if (rc) return rc;
   }
   if (!c->accelCommitted) return c->fail(HPT_ERR_STATE, "CommitDeviceData before CommitScene");
@@ -640,6 +677,19 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
     o[8] = m[2]; o[9] = m[6]; o[10] = m[10]; o[11] = 0.0f;
   }
   HIPCHK(c, c->dNormMat.upload(nm.data(), nm.size()));
+  // motion blur: m_normMatrices[m_normMatrices2Offs + i] = transpose(inverse(matrix at the end of the motion)) (integrator_pt_scene.cpp:864-897)
+  if (d->normMatrices2Offs != 0 && d->normMatrices2Offs != d->numInsts) return c->fail(HPT_ERR_ARG, "m_normMatrices2Offs must be 0 or the instance count");
+  if ((d->normMatrices2Offs != 0) != c->anyMotion) return c->fail(HPT_ERR_ARG, "m_normMatrices2Offs and the instances added with AddInstanceMotion disagree");
+  {
+    std::vector<float> nm2(12 * (size_t)std::max(1u, d->numInsts), 0.0f);
+    if (d->normMatrices2Offs) for (uint i = 0; i < d->numInsts; i++) {
+      const float* m = d->normMatrices + 16 * ((size_t)d->normMatrices2Offs + i);
+      float* o = &nm2[12 * (size_t)i];
+      o[0] = m[0]; o[1] = m[4]; o[2] = m[8];  o[4] = m[1]; o[5] = m[5]; o[6] = m[9];  o[8] = m[2]; o[9] = m[6]; o[10] = m[10];
+    }
+    HIPCHK(c, c->dNormMat2.upload(nm2.data(), nm2.size()));
+  }
+  c->S.normMat2 = c->dNormMat2.p; c->S.motion = d->normMatrices2Offs ? 1u : 0u; c->S.padMotion = 0;
   HIPCHK(c, c->dRemapInst.upload(d->remapInst, 2 * (size_t)d->numInsts));
   {
     std::vector<int> rl(d->allRemapLists ? std::vector<int>(d->allRemapLists, d->allRemapLists + d->allRemapListsLen) : std::vector<int>());
@@ -813,6 +863,14 @@ static void launchPT(const DevScene& S, const Job& job, int blocks, hipStream_t 
   }
 }
 
+// the MOTION variants: moving instances (two-level layout only), every BSDF branch
+template <int MODE>
+static void launchPTMotion(const DevScene& S, const Job& job, int blocks, hipStream_t st, bool deep)
+{
+  if (deep) pathTraceKernel<false, false, MODE, true, false, true><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
+  else      pathTraceKernel<false, false, MODE, false, false, true><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
+}
+
 static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStream_t st)
 {
   const bool inRays = job.inRayPos != nullptr;
@@ -826,10 +884,13 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   if (c->dGens.n < (inRays ? (size_t)job.tidEnd : (size_t)c->packedCount)) return c->fail(HPT_ERR_STATE, "PathTraceBlock: m_randomGens smaller than the thread range (InitRandomGens)");
   if (job.channels < 1 || job.channels > 4) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceBlock: channels must be 1..4 (spectral layers are out of scope)");
   if (dr && (c->S.traceDepth == 0 || c->S.traceDepth > 16)) return c->fail(HPT_ERR_ARG, "PathTraceDR: trace depth must be 1..16");
+  if (dr && c->S.motion) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceDR: motion blur is not differentiated");
+  if (c->S.motion && c->schedule == 2) return c->fail(HPT_ERR_UNSUPPORTED, "motion blur runs on the megakernel schedule");
   if (dr && !c->leanMaterials) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceDR: gltf and emissive materials without normal maps only (what the reference's replay differentiates, integrator_dr.cpp:461-612)");
   // never more lanes than pixels: with fewer, the hardware's round-robin block placement spreads them evenly over the CUs, whereas a
   // full grid would let whichever waves ask first take all the work (a small multi-GPU share of a frame)
-  const bool fullMaterials = !dr && !(c->leanMaterials && !c->forceFull && !naive && !inRays && !(c->instrument && !dr));   // MODE 0 / 1 / 2 / STATS kernels
+  const bool motion = c->S.motion != 0;
+  const bool fullMaterials = motion || !dr && !(c->leanMaterials && !c->forceFull && !naive && !inRays && !(c->instrument && !dr));   // MODE 0 / 1 / 2 / STATS kernels
   const int blocks = (int)std::min<size_t>((size_t)gridBlocks(c, dr, fullMaterials), ((size_t)job.tidCount + 255) / 256);
   HIPCHK(c, c->dQueue.alloc(1));
   HIPCHK(c, hipMemsetAsync(c->dQueue.p, 0, 4, st));
@@ -838,7 +899,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   job.counters = nullptr;
   const bool stats = c->instrument && !dr;
   c->lastSchedule = 1;
-  if (!inRays && useWavefront(c, naive, dr, stats && c->schedule != 2, job.tidCount)) { c->lastSchedule = 2; return launch_wavefront(c, job, st, dr); }
+  if (!inRays && !motion && useWavefront(c, naive, dr, stats && c->schedule != 2, job.tidCount)) { c->lastSchedule = 2; return launch_wavefront(c, job, st, dr); }
   if (stats) { HIPCHK(c, c->dCounters.alloc(1)); HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(Counters), st)); job.counters = c->dCounters.p; }
   if (dr) {
     job.recordLanes = (uint)blocks * 256u;
@@ -849,7 +910,10 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   job.stackOverflow = c->dStackOvf.p; job.gridLanes = (uint)blocks * 256u;
   HIPCHK(c, hipEventRecord(c->ev0, st));
   const bool deep = c->stackNeeded > (uint)LDS_STACK;
-  if (dr)          launchPT<false, true, 0>(c->S, job, blocks, st, deep);
+  if (motion) {
+    if (inRays) launchPTMotion<2>(c->S, job, blocks, st, deep); else if (naive) launchPTMotion<1>(c->S, job, blocks, st, deep); else launchPTMotion<0>(c->S, job, blocks, st, deep);
+  }
+  else if (dr)     launchPT<false, true, 0>(c->S, job, blocks, st, deep);
   else if (inRays) launchPT<false, false, 2>(c->S, job, blocks, st, deep);
   else if (naive)  launchPT<false, false, 1>(c->S, job, blocks, st, deep);
   else if (stats)  launchPT<true, false, 0>(c->S, job, blocks, st, deep);

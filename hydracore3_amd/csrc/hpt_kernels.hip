@@ -59,7 +59,7 @@ struct Job
 #ifndef HPT_FULL_WAVES
 #define HPT_FULL_WAVES 3
 #endif
-template <bool STATS, bool DR, int MODE, bool DEEP, bool FLAT>
+template <bool STATS, bool DR, int MODE, bool DEEP, bool FLAT, bool MOTION = false>
 __global__ void __launch_bounds__(256, (DR || MODE == 3) ? HPT_MIN_WAVES : HPT_FULL_WAVES) pathTraceKernel(const DevScene S, const Job job)
 {
   constexpr bool NAIVE = (MODE == 1), INRAYS = (MODE == 2), LEAN = (MODE == 3);
@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(256, (DR || MODE == 3) ? HPT_MIN_WAVES : HPT_F
   V3   rpos = v3(0, 0, 0), rdir = v3(0, 0, 1);
   V3   accum = v3(0, 0, 0), thr = v3(1, 1, 1);
   float misPdf = 1.0f, misIor = 1.0f;
+  float pathTime = 0.0f;                 // motion blur: the path's time in [0, 1] (only the MOTION variants ever change or read it)
   TravStats st; st.nodes = st.tris = st.insts = st.waveNodeIters = st.waveTriIters = 0;
   uint nRays = 0, nShadow = 0, nHits = 0, nPaths = 0;
   float lossLocal = 0.0f;
@@ -135,10 +136,12 @@ __global__ void __launch_bounds__(256, (DR || MODE == 3) ? HPT_MIN_WAVES : HPT_F
         const V3 p1 = mul4x3(S.worldViewInv, org);                         // transform_ray3f (cglobals.h:254-263)
         const V3 p2 = mul4x3(S.worldViewInv, org + 100.0f * dir);
         rpos = p1; rdir = normalize(p2 - p1);
+        if (MOTION) pathTime = id4.w;                                      // *time = rayDirData.time (integrator_pt.cpp:197)
       } else {
         const V4 lens = rng_float4(gen);                                   // GetRandomNumbersLens
         const uint XY = PIX_XY;
         cameraRay(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
+        if (MOTION) pathTime = rng_float1(gen);                            // GetRandomNumbersTime (integrator_pt.cpp:114-115): one step per path, after the lens
       }
       alive = true;
       if (STATS) nPaths++;
@@ -149,7 +152,7 @@ __global__ void __launch_bounds__(256, (DR || MODE == 3) ? HPT_MIN_WAVES : HPT_F
     // ---- (4) closest hit: kernel_RayTrace2 -> RayQuery_NearestHit ----------------------------------------------------------
     HitRec hit; hit.inst = 0xFFFFFFFFu; hit.prim = 0; hit.t = 0; hit.u = hit.v = 0;
     if (alive) {
-      traceAny<false, STATS, DEEP, FLAT>(S, rpos, rdir, 0.0f, HPT_FLT_MAX, hit, stk, st);
+      traceAny<false, STATS, DEEP, FLAT, MOTION>(S, rpos, rdir, 0.0f, HPT_FLT_MAX, hit, stk, st, pathTime);
       if (STATS) nRays++;
     }
 
@@ -167,15 +170,15 @@ __global__ void __launch_bounds__(256, (DR || MODE == 3) ? HPT_MIN_WAVES : HPT_F
 
     if (alive) {
       if (STATS && hit.inst != 0xFFFFFFFFu) nHits++;
-      didBounce = shadeVertex<DR, NAIVE, LEAN>(S, job.data, hit, rpos, rdir, accum, thr, misPdf, misIor, flags, bounce, gen,
-                                         wantShadow, shPos, shDir, shFar, contrib, recA, recS, recdA, recdS, recTaps, recTex, tailR);
+      didBounce = shadeVertex<DR, NAIVE, LEAN, MOTION>(S, job.data, hit, rpos, rdir, accum, thr, misPdf, misIor, flags, bounce, gen,
+                                                 wantShadow, shPos, shDir, shFar, contrib, recA, recS, recdA, recdS, recTaps, recTex, tailR, pathTime);
     }
 
     STAMP(2);
     // ---- (6) shadow rays: RayQuery_AnyHit ---------------------------------------------------------------------------------------
     if (wantShadow) {
       HitRec sh;
-      const bool occluded = traceAny<true, STATS, DEEP, FLAT>(S, shPos, shDir, 0.0f, shFar, sh, stk, st);
+      const bool occluded = traceAny<true, STATS, DEEP, FLAT, MOTION>(S, shPos, shDir, 0.0f, shFar, sh, stk, st, pathTime);
       if (STATS) { nRays++; nShadow++; }
       if (!occluded) accum = accum + contrib; else if (DR) { recS = v3(0, 0, 0); recdS = v3(0, 0, 0); }
     } else if (DR) { recS = v3(0, 0, 0); recdS = v3(0, 0, 0); }
@@ -274,8 +277,8 @@ __global__ void initRandomGensKernel(Rng* gens, uint n, uint firstSeed)
 }
 
 // batched RayQuery_NearestHit / RayQuery_AnyHit for the ISceneObject entry points
-template <bool FLAT>
-__global__ void __launch_bounds__(256) rayQueryKernel(const DevScene S, const float4* posNear, const float4* dirFar, uint n, void* out, int anyHit, uint* stackOverflow)
+template <bool FLAT, bool MOTION = false>
+__global__ void __launch_bounds__(256) rayQueryKernel(const DevScene S, const float4* posNear, const float4* dirFar, uint n, void* out, int anyHit, uint* stackOverflow, float time = 0.0f)
 {
   __shared__ uint stackMem[LDS_STACK * 256];
   const uint i = blockIdx.x * 256u + threadIdx.x;
@@ -284,10 +287,10 @@ __global__ void __launch_bounds__(256) rayQueryKernel(const DevScene S, const fl
   const float4 p = posNear[i], d = dirFar[i];
   HitRec h; TravStats st; st.nodes = st.tris = st.insts = st.waveNodeIters = st.waveTriIters = 0;
   if (anyHit) {
-    const bool occ = traceAny<true, false, true, FLAT>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, st);
+    const bool occ = traceAny<true, false, true, FLAT, MOTION>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, st, time);
     ((uint*)out)[i] = occ ? 1u : 0u;
   } else {
-    const bool found = traceAny<false, false, true, FLAT>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, st);
+    const bool found = traceAny<false, false, true, FLAT, MOTION>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, st, time);
     // CRT_Hit (CrossRT.h:23-30) as the Embree backend fills it (EmbreeRT.cpp:343-360)
     float4* o = (float4*)out + 2 * (size_t)i;
     if (found) {

@@ -63,11 +63,16 @@ HPT_DEV void cameraRay(const DevScene& S, uint x, uint y, V4 pixelOffsets, V3& r
 // ---- blend materials (integrator_pt_mat.cpp:23-77, 123-130, 316-333, 511-527); only in the non-LEAN kernels ---------------------------------
 // ---- normal-map bump (integrator_pt_mat.cpp:94-107, 131-139, 298-303, 336-355; NormalMapTransform in include/cmaterial.h) -------------------
 // world-space tangent of the hit (integrator_pt.cpp:270-302: interpolated, through the normal matrix, normalised, flipped with the normal)
-HPT_DEV V3 hitTangent(const DevScene& S, uint A, uint B, uint C, uint vertOffset, float wA, float uvx, float uvy, const float* nm, float flipNorm)
+HPT_DEV V3 hitTangent(const DevScene& S, uint A, uint B, uint C, uint vertOffset, float wA, float uvx, float uvy, const float* nm, float flipNorm,
+                      const float* nm2 = nullptr, float time = 0.0f)
 {
   const float4 tA = ((const float4*)S.vData8f)[2 * (A + vertOffset) + 1], tB = ((const float4*)S.vData8f)[2 * (B + vertOffset) + 1], tC = ((const float4*)S.vData8f)[2 * (C + vertOffset) + 1];
   const V3 tO = v3(wA * tA.x + uvy * tB.x + uvx * tC.x, wA * tA.y + uvy * tB.y + uvx * tC.y, wA * tA.z + uvy * tB.z + uvx * tC.z);
-  const V3 t = v3(nm[0] * tO.x + nm[1] * tO.y + nm[2] * tO.z, nm[4] * tO.x + nm[5] * tO.y + nm[6] * tO.z, nm[8] * tO.x + nm[9] * tO.y + nm[10] * tO.z);
+  V3 t = v3(nm[0] * tO.x + nm[1] * tO.y + nm[2] * tO.z, nm[4] * tO.x + nm[5] * tO.y + nm[6] * tO.z, nm[8] * tO.x + nm[9] * tO.y + nm[10] * tO.z);
+  if (nm2) {                                                             // motion blur: lerp towards the end-of-motion matrix applied to the result (integrator_pt.cpp:285-292)
+    const V3 t2 = v3(nm2[0] * t.x + nm2[1] * t.y + nm2[2] * t.z, nm2[4] * t.x + nm2[5] * t.y + nm2[6] * t.z, nm2[8] * t.x + nm2[9] * t.y + nm2[10] * t.z);
+    t = t + time * (t2 - t);
+  }
   return flipNorm * normalize(t);
 }
 // BumpMapping: the tangent-space normal of the map through the inverse of the matrix with rows (tan, bitan, n) - by cofactors,
@@ -136,11 +141,11 @@ HPT_DEV void blendTreeEval(const DevScene& S, uint rootId, V2 uv, V3 l, V3 v, V3
 
 // LEAN: the scene holds gltf and emissive materials only (the host checked): the conductor / diffuse / glass / dielectric branches are
 // compiled out - fewer live registers and spills in the kernels every benchmark scene runs (the DR variant is lean by definition).
-template <bool DR, bool NAIVE, bool LEAN = false>
+template <bool DR, bool NAIVE, bool LEAN = false, bool MOTION = false>
 HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec& hit,
                          V3& rpos, V3& rdir, V3& accum, V3& thr, float& misPdf, float& misIor, uint& flags, const uint bounce, Rng& gen,
                          bool& wantShadow, V3& shPos, V3& shDir, float& shFar, V3& contrib,
-                         V3& recA, V3& recS, V3& recdA, V3& recdS, Taps& recTaps, uint& recTex, V3& tailR)
+                         V3& recA, V3& recS, V3& recdA, V3& recdS, Taps& recTaps, uint& recTex, V3& tailR, const float time = 0.0f)
 {
   bool didBounce = false;
   if (hit.inst == 0xFFFFFFFFu) {
@@ -166,6 +171,13 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
     V3 hitNorm = v3(nm[0] * nrmO.x + nm[1] * nrmO.y + nm[2] * nrmO.z,
                     nm[4] * nrmO.x + nm[5] * nrmO.y + nm[6] * nrmO.z,
                     nm[8] * nrmO.x + nm[9] * nrmO.y + nm[10] * nrmO.z);
+    if (MOTION) {                                                        // integrator_pt.cpp:285-292: m_normMatrices[m_normMatrices2Offs + inst] applied to the
+      const float* nm2 = S.normMat2 + 12 * instId;                       // already transformed normal, then lerp(hitNorm, hitNorm2, time)
+      const V3 n2 = v3(nm2[0] * hitNorm.x + nm2[1] * hitNorm.y + nm2[2] * hitNorm.z,
+                       nm2[4] * hitNorm.x + nm2[5] * hitNorm.y + nm2[6] * hitNorm.z,
+                       nm2[8] * hitNorm.x + nm2[9] * hitNorm.y + nm2[10] * hitNorm.z);
+      hitNorm = hitNorm + time * (n2 - hitNorm);
+    }
     hitNorm = normalize(hitNorm);
     const float flipNorm = dot(rdir, hitNorm) > 0.001f ? -1.0f : 1.0f;
     hitNorm = flipNorm * hitNorm;
@@ -176,7 +188,7 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
     const V3 vdir = (-1.0f) * rdir;
     V3 hitTang = v3(0, 0, 0);                                          // only materials with a normal map (or a blend that may hold one) read it
     if (!(DR || LEAN) && (mtype == MAT_TYPE_BLEND || (mtype != MAT_TYPE_LIGHT_SOURCE && m.texid[1] != 0xFFFFFFFFu)))
-      hitTang = hitTangent(S, A, B, C, vertOffset, wA, uvx, uvy, nm, flipNorm);
+      hitTang = hitTangent(S, A, B, C, vertOffset, wA, uvx, uvy, nm, flipNorm, MOTION ? S.normMat2 + 12 * instId : nullptr, time);
 
     // -- kernel_SampleLightSource (integrator_pt.cpp:350-424): the randoms are drawn for every surface hit --
     V3 shade = v3(0, 0, 0), dshade = v3(0, 0, 0);

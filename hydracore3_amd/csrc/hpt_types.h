@@ -54,7 +54,7 @@ struct BvhTri { float v0[3]; uint primId; float e1[3]; uint instId; float e2[3];
 static_assert(sizeof(BvhTri) == 48, "triangle record must be 48 bytes");
 
 // 64-byte instance record: world->object rows (3x4), BLAS root reference, mesh id
-struct BvhInst { float row0[4], row1[4], row2[4]; uint root, geomId, pad0, pad1; };
+struct BvhInst { float row0[4], row1[4], row2[4]; uint root, geomId, pad0, pad1; };   // pad0 = 1: a moving instance (DevScene::instMotion)
 static_assert(sizeof(BvhInst) == 64, "instance record must be 64 bytes");
 
 struct TexRec
@@ -89,6 +89,11 @@ struct DevScene
   const LightRec*    lights;
   const TexRec*      textures;
   const float*       arrays1f;    // m_arrays1f: pdf table of the sampled environment map
+  // motion blur (integrator_pt_scene.cpp:848-897, EmbreeRT.cpp:264-292): instances with two key transforms, interpolated per ray at its time
+  const float*       instMotion;  // 24 floats per instance: object->world rows (3x4) at time 0, then at time 1 (only read for BvhInst::pad0 != 0)
+  const float*       normMat2;    // 12 floats per instance: rows of the upper 3x3 of m_normMatrices[m_normMatrices2Offs + i]
+  uint               motion;      // m_normMatrices2Offs != 0: a time is drawn per path and normals are interpolated
+  uint               padMotion;
 
   // plain-data members (UpdateMembersPlainData)
   float projInv[16], worldViewInv[16];

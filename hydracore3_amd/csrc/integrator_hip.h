@@ -57,6 +57,7 @@ public:
   { hpt_update_geom_triangles3f(m_ctx, a_geomId, a_vpos3f, a_vertNumber, a_triIndices, a_indNumber, a_flags, vByteStride); }
   void     ClearScene() { hpt_clear_scene(m_ctx); }
   uint32_t AddInstance(uint32_t a_geomId, const float4x4& a_matrix) { return hpt_add_instance(m_ctx, a_geomId, a_matrix.m); }
+  uint32_t AddInstanceMotion(uint32_t a_geomId, const float4x4* a_matrices, uint32_t a_matrixNumber) { return hpt_add_instance_motion(m_ctx, a_geomId, a_matrices[0].m, a_matrixNumber); }
   void     UpdateInstance(uint32_t a_instanceId, const float4x4& a_matrix) { hpt_update_instance(m_ctx, a_instanceId, a_matrix.m); }
   void     CommitScene(uint32_t options = 4) { hpt_commit_scene(m_ctx, options); }
   // single-ray forms of the reference interface; the batched C entry points are what a throughput caller should use

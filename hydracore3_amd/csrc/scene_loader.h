@@ -173,6 +173,8 @@ struct LoadedTexture { uint32_t width = 1, height = 1, format = 0, flags = 0, ad
 struct LoadedScene
 {
   std::vector<float> vPos4f, vData8f, instMatrices, normMatrices;
+  // motion blur (integrator_pt_scene.cpp:848-897): <motion matrix=..> of an instance; once one moves, normMatrices gets a second half
+  std::vector<float> instMatricesMotion; std::vector<uint32_t> instHasMotion; uint32_t normMatrices2Offs = 0;
   std::vector<uint32_t> triIndices, matIdByPrimId, matVertOffset, geomTriCount, geomVertCount, instGeomId;
   std::vector<int32_t> remapInst, allRemapLists{0};
   uint32_t allRemapListsSize = 0;
@@ -209,6 +211,7 @@ struct LoadedScene
     }
     d.textures = texDescs.data(); d.numTextures = (uint32_t)texDescs.size();
     d.arrays1f = arrays1f.empty() ? nullptr : arrays1f.data(); d.numArrays1f = (uint32_t)arrays1f.size();
+    if (normMatrices2Offs) { d.instMatricesMotion = instMatricesMotion.data(); d.instHasMotion = instHasMotion.data(); d.normMatrices2Offs = normMatrices2Offs; }
     return d;
   }
 
@@ -255,7 +258,14 @@ struct LoadedScene
       if (hpt_add_geom_triangles3f(ctx, vPos4f.data() + 4 * (size_t)vertOff, geomVertCount[g], triIndices.data() + 3 * (size_t)triOff, 3 * (size_t)geomTriCount[g], 0, 16) == 0xFFFFFFFFu) return HPT_ERR_ARG;
     }
     rc = hpt_clear_scene(ctx); if (rc) return rc;
-    for (size_t i = 0; i < instGeomId.size(); i++) if (hpt_add_instance(ctx, instGeomId[i], instMatrices.data() + 16 * i) == 0xFFFFFFFFu) return HPT_ERR_ARG;
+    for (size_t i = 0; i < instGeomId.size(); i++) {
+      uint32_t id;
+      if (normMatrices2Offs && instHasMotion[i]) {                            // AddInstanceMotion(geomId, {matrix, matrix_motion}, 2) (:864-868)
+        float two[32]; std::memcpy(two, instMatrices.data() + 16 * i, 64); std::memcpy(two + 16, instMatricesMotion.data() + 16 * i, 64);
+        id = hpt_add_instance_motion(ctx, instGeomId[i], two, 2);
+      } else id = hpt_add_instance(ctx, instGeomId[i], instMatrices.data() + 16 * i);
+      if (id == 0xFFFFFFFFu) return HPT_ERR_ARG;
+    }
     rc = hpt_commit_scene(ctx, 4); if (rc) return rc;
     hpt_scene_desc d = desc();
     rc = hpt_upload_scene(ctx, &d); if (rc) return rc;
@@ -800,15 +810,29 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
   }
 
   // instances: matrix, m_normMatrices = transpose(inverse4x4(M)) (integrator_pt_scene.cpp:852-885), remap list and light ids
+  std::vector<M4> endMatrices;                                                // the matrix at the end of the motion, per instance
   for (const XmlNode* inst : sceneNode->all("instance")) {
     const M4 m = m4FromText(inst->get("matrix"));
     float cm[16]; m4ToColMajor(m, cm); sc.instMatrices.insert(sc.instMatrices.end(), cm, cm + 16);
     m4ToColMajor(m4Transpose(m4Inverse(m)), cm); sc.normMatrices.insert(sc.normMatrices.end(), cm, cm + 16);
+    const XmlNode* mot = inst->child("motion");                              // hydraxml.h:170-176
+    const M4 m1 = mot ? m4FromText(mot->get("matrix")) : m;
+    endMatrices.push_back(m1);
+    m4ToColMajor(m1, cm); sc.instMatricesMotion.insert(sc.instMatricesMotion.end(), cm, cm + 16);
+    sc.instHasMotion.push_back(mot ? 1u : 0u);
     sc.instGeomId.push_back((uint32_t)std::atoi(inst->get("mesh_id").c_str()));
     int lightId = -1;
     if (inst->has("linst_id")) { const int li = std::atoi(inst->get("linst_id").c_str()); if (li >= 0 && li < (int)oldToNew.size()) lightId = oldToNew[(size_t)li]; }
     sc.remapInst.push_back(inst->has("rmap_id") ? std::atoi(inst->get("rmap_id").c_str()) : -1);
     sc.remapInst.push_back(lightId);
+  }
+  bool anyMotion = false; for (uint32_t f : sc.instHasMotion) anyMotion = anyMotion || f != 0;
+  if (anyMotion) {                                                           // m_normMatrices2 appended, m_normMatrices2Offs = the instance count (:888-897)
+    const size_t ni = sc.instGeomId.size();
+    sc.normMatrices2Offs = (uint32_t)ni;
+    for (size_t i = 0; i < ni; i++) {
+      float cm[16]; m4ToColMajor(m4Transpose(m4Inverse(endMatrices[i])), cm); sc.normMatrices.insert(sc.normMatrices.end(), cm, cm + 16);
+    }
   }
   return true;
 }

@@ -88,7 +88,8 @@ class SceneDesc(C.Structure):
                 ("allRemapListsLen", C.c_uint32), ("allRemapListsSize", C.c_uint32),
                 ("materials", C.c_void_p), ("numMaterials", C.c_uint32), ("numLights", C.c_uint32),
                 ("lights", C.c_void_p), ("textures", C.POINTER(TextureDesc)),
-                ("numTextures", C.c_uint32), ("numArrays1f", C.c_uint32), ("arrays1f", C.c_void_p)]
+                ("numTextures", C.c_uint32), ("numArrays1f", C.c_uint32), ("arrays1f", C.c_void_p),
+                ("instMatricesMotion", C.c_void_p), ("instHasMotion", C.c_void_p), ("normMatrices2Offs", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Params(C.Structure):
@@ -451,6 +452,7 @@ class SceneData:
         self.mat_vert_offset = []       # (triOffset, vertOffset) per geom
         self.geom_tri_count, self.geom_vert_count = [], []
         self.inst_geom, self.inst_matrices, self.remap_inst = [], [], []
+        self.inst_motion = {}                                 # instance id -> matrix at the end of the motion (hydraxml.h:170-176 <motion matrix=..>)
         self.all_remap_lists = np.zeros((1,), np.int32)     # no lists: just the trailing offset 0
         self.all_remap_lists_size = 0
         self.materials, self.lights = [], []
@@ -521,10 +523,13 @@ class SceneData:
         self.tri_indices, self.mat_id_by_prim = np.concatenate(ti), np.concatenate(mi)
         return first
 
-    def add_instance(self, geom_id, matrix_rowmajor, remap_list=-1, light_id=-1) -> int:
+    def add_instance(self, geom_id, matrix_rowmajor, remap_list=-1, light_id=-1, motion_matrix=None) -> int:
+        """AddInstance, or AddInstanceMotion(geomId, {matrix, matrix_motion}, 2) when motion_matrix is given (integrator_pt_scene.cpp:852-885)."""
         self.inst_geom.append(geom_id)
         self.inst_matrices.append(np.asarray(matrix_rowmajor, np.float64).reshape(4, 4))
         self.remap_inst.append((remap_list, light_id))
+        if motion_matrix is not None:
+            self.inst_motion[len(self.inst_geom) - 1] = np.asarray(motion_matrix, np.float64).reshape(4, 4)
         return len(self.inst_geom) - 1
 
     def set_remap_lists(self, lists):
@@ -656,6 +661,15 @@ class SceneData:
         mats = np.stack([colmajor(m) for m in self.inst_matrices]) if ni else np.zeros((0, 16), np.float32)
         # m_normMatrices[i] = transpose(inverse4x4(M_i))  (integrator_pt_scene.cpp:877)
         nm = np.stack([colmajor(np.linalg.inv(m).T) for m in self.inst_matrices]) if ni else np.zeros((0, 16), np.float32)
+        # motion blur (integrator_pt_scene.cpp:848-897): once one instance moves, m_normMatrices carries a second half for the end of the motion
+        # (the same matrix again for the instances that stay put) and m_normMatrices2Offs = the instance count
+        d.instMatricesMotion, d.instHasMotion, d.normMatrices2Offs = None, None, 0
+        if self.inst_motion and ni:
+            end = [self.inst_motion.get(i, self.inst_matrices[i]) for i in range(ni)]
+            nm = np.concatenate([nm, np.stack([colmajor(np.linalg.inv(m).T) for m in end])])
+            d.instMatricesMotion = ptr(np.stack([colmajor(m) for m in end]))
+            d.instHasMotion = ptr(np.asarray([1 if i in self.inst_motion else 0 for i in range(ni)], np.uint32))
+            d.normMatrices2Offs = ni
         d.instMatrices, d.normMatrices = ptr(mats), ptr(nm)
         d.remapInst = ptr(np.asarray(self.remap_inst, np.int32).reshape(-1, 2))
         d.allRemapLists = ptr(self.all_remap_lists)
@@ -1191,6 +1205,8 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
     for inst in scene_node.findall("instance"):
         linst = inst.get("linst_id")
         light_id = old_to_new[int(linst)] if linst is not None and int(linst) >= 0 else -1
+        mot = inst.find("motion")
         sc.add_instance(int(inst.get("mesh_id")), np.asarray(_f(inst.get("matrix"))).reshape(4, 4),
-                        int(inst.get("rmap_id", -1)), light_id)
+                        int(inst.get("rmap_id", -1)), light_id,
+                        np.asarray(_f(mot.get("matrix"))).reshape(4, 4) if mot is not None else None)
     return sc

@@ -64,6 +64,13 @@ typedef struct hpt_scene_desc {
   uint32_t        numTextures;
   uint32_t        numArrays1f;
   const float*    arrays1f;       /* m_arrays1f: the environment light's pdf table (integrator_pt_scene.cpp:464-475); may be NULL */
+  /* motion blur (integrator_pt_scene.cpp:848-897): with normMatrices2Offs != 0 (= numInsts) normMatrices holds 2 x numInsts matrices, the
+   * second half for the end of the motion; instMatricesMotion / instHasMotion are read only when the geometry comes with the tables
+   * (vPos4f != NULL) and stand for AddInstanceMotion(geomId, {matrix, matrix_motion}, 2) (:864-868). All may be NULL / 0. */
+  const float*    instMatricesMotion; /* numInsts column-major float4x4: the instance matrix at time 1 */
+  const uint32_t* instHasMotion;      /* numInsts flags */
+  uint32_t        normMatrices2Offs;  /* m_normMatrices2Offs */
+  uint32_t        reserved;
 } hpt_scene_desc;
 
 /* The plain-data members UpdateMembersPlainData() refreshes before every *Block call (integrator_pt.h:268, main.cpp:398). */
@@ -121,11 +128,17 @@ int      hpt_update_geom_triangles3f(hpt_ctx* ctx, uint32_t geomId, const float*
                                      const uint32_t* triIndices, size_t indNumber, uint32_t flags, size_t vByteStride); /* UpdateGeom_Triangles3f :85-86 */
 int      hpt_clear_scene(hpt_ctx* ctx);                                                  /* ClearScene           :105 */
 uint32_t hpt_add_instance(hpt_ctx* ctx, uint32_t geomId, const float matrix16[16]);      /* AddInstance          :118; returns instId or 0xFFFFFFFF */
+/* AddInstanceMotion :127 (EmbreeRT.cpp:264-292): matrixNumber key transforms, linearly interpolated at the ray's time; 2 are supported
+ * (what LoadSceneInstances passes). Forces the two-level layout and the megakernel schedule. */
+uint32_t hpt_add_instance_motion(hpt_ctx* ctx, uint32_t geomId, const float* matrices /* matrixNumber x 16, column-major */, uint32_t matrixNumber);
 int      hpt_update_instance(hpt_ctx* ctx, uint32_t instId, const float matrix16[16]);   /* UpdateInstance       :134 */
 int      hpt_commit_scene(hpt_ctx* ctx, uint32_t options);                               /* CommitScene          :110: builds + uploads the two-level BVH2 */
 /* RayQuery_NearestHit / RayQuery_AnyHit (:148,:165), batched: n rays from host memory, results to host memory. */
 int      hpt_ray_query_nearest(hpt_ctx* ctx, const float* posAndNear4, const float* dirAndFar4, uint32_t n, hpt_hit* out);
 int      hpt_ray_query_any(hpt_ctx* ctx, const float* posAndNear4, const float* dirAndFar4, uint32_t n, uint32_t* out);
+/* RayQuery_NearestHitMotion / RayQuery_AnyHitMotion (:157,:174): the same at a time in [0, 1] of the moving instances (one time per batch). */
+int      hpt_ray_query_nearest_motion(hpt_ctx* ctx, const float* posAndNear4, const float* dirAndFar4, uint32_t n, float time, hpt_hit* out);
+int      hpt_ray_query_any_motion(hpt_ctx* ctx, const float* posAndNear4, const float* dirAndFar4, uint32_t n, float time, uint32_t* out);
 
 /* ---- scene tables --------------------------------------------------------------------------------------------- */
 /* CommitDeviceData() (integrator_pt.h:265): uploads every scene vector. If desc->vPos4f is non-NULL the geometry

@@ -40,6 +40,8 @@ def lib():
             f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
         L.orc_ray_nearest.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
         L.orc_ray_any.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
+        L.orc_ray_nearest_motion.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_int]
+        L.orc_ray_any_motion.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_int]
         L.orc_put_diff_tex2d.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.orc_put_diff_tex2d.restype = C.c_int
@@ -127,6 +129,20 @@ class OracleIntegrator:
         dir_far = np.ascontiguousarray(dir_far, np.float32)
         out = np.zeros(pos_near.shape[0], np.uint32)
         self.L.orc_ray_any(self.h, pos_near.ctypes.data, dir_far.ctypes.data, pos_near.shape[0], out.ctypes.data, int(brute))
+        return out
+
+    def ray_nearest_motion(self, pos_near, dir_far, time, brute=False):
+        pos_near = np.ascontiguousarray(pos_near, np.float32)
+        dir_far = np.ascontiguousarray(dir_far, np.float32)
+        out = np.zeros(pos_near.shape[0], HIT_DTYPE)
+        self.L.orc_ray_nearest_motion(self.h, pos_near.ctypes.data, dir_far.ctypes.data, pos_near.shape[0], C.c_float(time), out.ctypes.data, int(brute))
+        return out
+
+    def ray_any_motion(self, pos_near, dir_far, time, brute=False):
+        pos_near = np.ascontiguousarray(pos_near, np.float32)
+        dir_far = np.ascontiguousarray(dir_far, np.float32)
+        out = np.zeros(pos_near.shape[0], np.uint32)
+        self.L.orc_ray_any_motion(self.h, pos_near.ctypes.data, dir_far.ctypes.data, pos_near.shape[0], C.c_float(time), out.ctypes.data, int(brute))
         return out
 
     def put_diff_tex2d(self, tex_id, w, h, channels):

@@ -48,6 +48,11 @@ typedef struct orc_scene_desc {
   uint32_t        numTextures;
   uint32_t        numArrays1f;
   const float*    arrays1f;       // m_arrays1f: pdf table of the sampled environment map (may be NULL)
+  // motion blur (integrator_pt_scene.cpp:848-897): normMatrices holds 2 x numInsts matrices when normMatrices2Offs != 0 (= numInsts)
+  const float*    instMatricesMotion; // numInsts column-major float4x4: the instance matrix at time 1 (may be NULL)
+  const uint32_t* instHasMotion;      // numInsts flags (may be NULL)
+  uint32_t        normMatrices2Offs;  // m_normMatrices2Offs
+  uint32_t        reserved;
 } orc_scene_desc;
 
 typedef struct orc_params {
@@ -95,6 +100,9 @@ void     orc_path_trace_from_input_rays_block(orc_ctx*, uint32_t tid, uint32_t c
 // bruteForce != 0 tests every triangle of every instance (no BVH).
 void     orc_ray_nearest(orc_ctx*, const float* posNear4, const float* dirFar4, uint32_t n, orc_hit* out, int bruteForce);
 void     orc_ray_any(orc_ctx*, const float* posNear4, const float* dirFar4, uint32_t n, uint32_t* out, int bruteForce);
+// RayQuery_NearestHitMotion / RayQuery_AnyHitMotion (CrossRT.h:157,174): the same at a time in [0, 1] of the moving instances
+void     orc_ray_nearest_motion(orc_ctx*, const float* posNear4, const float* dirFar4, uint32_t n, float time, orc_hit* out, int bruteForce);
+void     orc_ray_any_motion(orc_ctx*, const float* posNear4, const float* dirFar4, uint32_t n, float time, uint32_t* out, int bruteForce);
 
 // IntegratorDR::PutDiffTex2D / PathTraceDR (diff_render/integrator_dr.cpp:33-53, 1135-1218)
 int      orc_put_diff_tex2d(orc_ctx*, uint32_t texId, uint32_t width, uint32_t height, uint32_t channels, uint64_t* outOffset, uint64_t* outSize);

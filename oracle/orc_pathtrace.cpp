@@ -385,6 +385,7 @@ struct Ctx
     f4 accumColor, accumThroughput, rayPosAndNear, rayDirAndFar;
     RandomGen gen; MisData mis; uint rayFlags;
     f4 hit1, hit2, hit3; uint instId;
+    float time;                                   // motion blur: the path's time in [0, 1] (integrator_pt.cpp:112-115)
   };
 
   static inline bool isDeadRay(uint f) { return (f & RAY_FLAG_IS_DEAD) != 0; }
@@ -424,6 +425,7 @@ struct Ctx
     const f4 pixelOffsets = rndFloat4(&genLocal);      // GetRandomNumbersLens; no time / wavelength draws in RGB, static scenes
     if (rec && rec->enabled) rec->lens = pixelOffsets;
     CameraRay(tid, pixelOffsets, &s->rayPosAndNear, &s->rayDirAndFar);
+    s->time = sc.motion ? rndFloat1(&genLocal) : 0.0f;  // GetRandomNumbersTime: only when m_normMatrices2Offs != 0 (:114-115)
     s->gen = genLocal;
   }
 
@@ -443,6 +445,11 @@ struct Ctx
     const f2 hitTexCoord = mk2(data1.w, data2.w);
     f3 hitNorm = mul3x3(sc.normMatrices[hit.instId], xyz(data1));
     f3 hitTang = mul3x3(sc.normMatrices[hit.instId], xyz(data2));
+    if (sc.motion) {                                    // :285-292: the end-of-motion matrix applied to the already transformed vectors, then lerp
+      const f3 hitNorm2 = mul3x3(sc.normMatrices2[hit.instId], hitNorm), hitTang2 = mul3x3(sc.normMatrices2[hit.instId], hitTang);
+      hitNorm = hitNorm + s->time * (hitNorm2 - hitNorm);
+      hitTang = hitTang + s->time * (hitTang2 - hitTang);
+    }
     hitNorm = normalize(hitNorm);
     hitTang = normalize(hitTang);
     const float flipNorm = dot(xyz(rayDir), hitNorm) > 0.001f ? -1.0f : 1.0f;
@@ -461,7 +468,7 @@ struct Ctx
   void RayTrace2(uint bounce, Path* s, Record* rec) const   // :214-348
   {
     if (isDeadRay(s->rayFlags)) return;
-    const orc_hit hit = sc.nearest_hit(s->rayPosAndNear, s->rayDirAndFar);
+    const orc_hit hit = sc.nearest_hit(s->rayPosAndNear, s->rayDirAndFar, false, s->time);
     if (rec && rec->enabled) rec->hit[bounce] = hit;
     if (hit.geomId != uint(-1)) SurfaceFromHit(hit, s->rayPosAndNear, s->rayDirAndFar, s);
     else {
@@ -493,7 +500,7 @@ struct Ctx
     const f3 shadowRayDir = normalize(lSam.pos - hpos);
     const f3 shadowRayPos = hpos + hnorm * std::max(maxcomp(hpos), 1.0f) * 5e-6f;
     const bool inIllumArea = (dot(shadowRayDir, lSam.norm) < 0.0f) || lSam.isOmni || lSam.hasIES;
-    const bool needShade = inIllumArea && !sc.any_hit(xyzw(shadowRayPos, 0.0f), xyzw(shadowRayDir, hitDist * 0.9995f));
+    const bool needShade = inIllumArea && !sc.any_hit(xyzw(shadowRayPos, 0.0f), xyzw(shadowRayDir, hitDist * 0.9995f), false, s->time);
     if (rec && rec->enabled) rec->inShadow[bounce] = needShade ? 0 : 1;
     if (needShade) {
       const BsdfEval bsdfV = MaterialEval(matId, shadowRayDir, (-1.0f) * ray_dir, hnorm, htang, huv);
@@ -640,6 +647,7 @@ struct Ctx
     transform_ray3f(p.worldViewInv, &rayPos, &rayDir);
     s.rayPosAndNear = xyzw(rayPos, 0.0f);
     s.rayDirAndFar = xyzw(rayDir, FLT_MAX);
+    s.time = sc.motion ? rayDirAndT[4 * tid + 3] : 0.0f;  // *time = rayDirData.time (:197)
     s.gen = randomGens[tid];
     for (uint depth = 0; depth < p.traceDepth; depth++) {
       RayTrace2(depth, &s, nullptr);
@@ -919,6 +927,17 @@ void orc_ray_any(orc_ctx* h, const float* posNear4, const float* dirFar4, uint32
   #pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads())
   for (long i = 0; i < (long)n; i++)
     out[i] = sc.any_hit(((const f4*)posNear4)[i], ((const f4*)dirFar4)[i], bruteForce != 0) ? 1u : 0u;
+}
+
+void orc_ray_nearest_motion(orc_ctx* h, const float* posNear4, const float* dirFar4, uint32_t n, float time, orc_hit* out, int bruteForce)
+{
+  const Scene& sc = h->c.sc;
+  for (uint32_t i = 0; i < n; i++) out[i] = sc.nearest_hit(((const f4*)posNear4)[i], ((const f4*)dirFar4)[i], bruteForce != 0, time);
+}
+void orc_ray_any_motion(orc_ctx* h, const float* posNear4, const float* dirFar4, uint32_t n, float time, uint32_t* out, int bruteForce)
+{
+  const Scene& sc = h->c.sc;
+  for (uint32_t i = 0; i < n; i++) out[i] = sc.any_hit(((const f4*)posNear4)[i], ((const f4*)dirFar4)[i], bruteForce != 0, time) ? 1u : 0u;
 }
 
 // IntegratorDR::PutDiffTex2D (integrator_dr.cpp:33-53)

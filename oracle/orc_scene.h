@@ -169,6 +169,9 @@ struct Scene
   std::vector<uint>     geomTriCount, geomVertCount;
   std::vector<uint>     instGeomId;
   std::vector<m4>       instMatrices, instMatricesInv, normMatrices;
+  std::vector<m4>       instMatricesMotion, normMatrices2;   // motion blur: the key at time 1, m_normMatrices[m_normMatrices2Offs + i]
+  std::vector<uint>     instHasMotion;
+  bool                  motion = false;                       // m_normMatrices2Offs != 0
   std::vector<int>      remapInst;        // 2 per instance
   std::vector<int>      allRemapLists;
   uint                  allRemapListsSize = 0;
@@ -192,6 +195,13 @@ struct Scene
     instGeomId.assign(s->instGeomId, s->instGeomId + s->numInsts);
     instMatrices.assign((const m4*)s->instMatrices, (const m4*)s->instMatrices + s->numInsts);
     normMatrices.assign((const m4*)s->normMatrices, (const m4*)s->normMatrices + s->numInsts);
+    motion = s->normMatrices2Offs != 0;
+    normMatrices2.clear(); instMatricesMotion.clear(); instHasMotion.assign(s->numInsts, 0u);
+    if (motion) normMatrices2.assign((const m4*)s->normMatrices + s->normMatrices2Offs, (const m4*)s->normMatrices + s->normMatrices2Offs + s->numInsts);
+    if (s->instMatricesMotion && s->instHasMotion) {
+      instMatricesMotion.assign((const m4*)s->instMatricesMotion, (const m4*)s->instMatricesMotion + s->numInsts);
+      instHasMotion.assign(s->instHasMotion, s->instHasMotion + s->numInsts);
+    }
     remapInst.assign(s->remapInst, s->remapInst + 2 * (size_t)s->numInsts);
     if (s->allRemapLists) allRemapLists.assign(s->allRemapLists, s->allRemapLists + s->allRemapListsLen);
     // RemapMaterialId's bisection probes up to one list length past a list's end (see orc_pathtrace.cpp): zero padding keeps the probes of the
@@ -245,7 +255,9 @@ struct Scene
         for (int c = 0; c < 8; c++) {
           const f3 p = mk3((c & 1) ? r.hi.x : r.lo.x, (c & 2) ? r.hi.y : r.lo.y, (c & 4) ? r.hi.z : r.lo.z);
           box_grow(w, mul4x3(instMatrices[i], p));
+          if (instHasMotion[i]) box_grow(w, mul4x3(instMatricesMotion[i], p));       // points move on segments: the two key boxes bound the sweep
         }
+        if (instHasMotion[i]) { const f3 e = (w.hi - w.lo) * 1e-5f + mk3(1e-6f, 1e-6f, 1e-6f); w.lo = w.lo - e; w.hi = w.hi + e; }
       } else { w.lo = w.hi = mk3(0, 0, 0); }
       ib[i] = w;
     }
@@ -264,11 +276,29 @@ struct Scene
     return prim < b.prim;
   }
 
-  void intersect_instance(uint inst, f3 o, f3 d, float tnear, float tfar, Best& best, bool anyHit, bool brute) const
+  // A moving instance (AddInstanceMotion, EmbreeRT.cpp:264-292): object->world interpolated linearly between the two keys at the ray's time,
+  // then inverted for this ray - cofactors in float, the translation subtracted first (the same arithmetic as the device's)
+  void to_object_space_motion(uint inst, float time, f3 wo, f3 wd, f3* o, f3* d) const
+  {
+    const m4& m0 = instMatrices[inst]; const m4& m1 = instMatricesMotion[inst];
+    float a[12];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) { const float k0 = m0.c[c][r], k1 = m1.c[c][r]; a[4 * r + c] = k0 + time * (k1 - k0); }
+    const float c00 = a[5] * a[10] - a[6] * a[9], c01 = a[2] * a[9] - a[1] * a[10], c02 = a[1] * a[6] - a[2] * a[5];
+    const float c10 = a[6] * a[8] - a[4] * a[10], c11 = a[0] * a[10] - a[2] * a[8], c12 = a[2] * a[4] - a[0] * a[6];
+    const float c20 = a[4] * a[9] - a[5] * a[8],  c21 = a[1] * a[8] - a[0] * a[9],  c22 = a[0] * a[5] - a[1] * a[4];
+    const float det = a[0] * c00 + a[1] * c10 + a[2] * c20;
+    const float id = 1.0f / det;
+    const f3 p = mk3(wo.x - a[3], wo.y - a[7], wo.z - a[11]);
+    *o = mk3((c00 * p.x + c01 * p.y + c02 * p.z) * id, (c10 * p.x + c11 * p.y + c12 * p.z) * id, (c20 * p.x + c21 * p.y + c22 * p.z) * id);
+    *d = mk3((c00 * wd.x + c01 * wd.y + c02 * wd.z) * id, (c10 * wd.x + c11 * wd.y + c12 * wd.z) * id, (c20 * wd.x + c21 * wd.y + c22 * wd.z) * id);
+  }
+
+  void intersect_instance(uint inst, f3 o, f3 d, float tnear, float tfar, Best& best, bool anyHit, bool brute, float time = 0.0f) const
   {
     const uint g = instGeomId[inst];
     const m4& inv = instMatricesInv[inst];
-    const f3 lo = mul4x3(inv, o), ld = mul3x3(inv, d);
+    f3 lo = mul4x3(inv, o), ld = mul3x3(inv, d);
+    if (instHasMotion[inst]) to_object_space_motion(inst, time, o, d, &lo, &ld);
     const SimpleBvh& b = blas[g];
     if (brute) {
       for (uint p = 0; p < geomTriCount[g]; p++) {
@@ -301,11 +331,11 @@ struct Scene
     }
   }
 
-  Best trace(f3 o, f3 d, float tnear, float tfar, bool anyHit, bool brute) const
+  Best trace(f3 o, f3 d, float tnear, float tfar, bool anyHit, bool brute, float time = 0.0f) const
   {
     Best best; best.hit = false; best.t = tfar; best.prim = best.inst = 0xFFFFFFFFu; best.u = best.v = 0.0f;
     if (brute) {
-      for (uint i = 0; i < instGeomId.size(); i++) { intersect_instance(i, o, d, tnear, tfar, best, anyHit, true); if (anyHit && best.hit) break; }
+      for (uint i = 0; i < instGeomId.size(); i++) { intersect_instance(i, o, d, tnear, tfar, best, anyHit, true, time); if (anyHit && best.hit) break; }
       return best;
     }
     if (tlas.nodes.empty()) return best;
@@ -316,7 +346,7 @@ struct Scene
       if (!ray_box(n.box, o, d, tnear, far_)) continue;
       if (n.count > 0) {
         for (int i = n.first; i < n.first + n.count; i++) {
-          intersect_instance(tlas.items[i], o, d, tnear, tfar, best, anyHit, false);
+          intersect_instance(tlas.items[i], o, d, tnear, tfar, best, anyHit, false, time);
           if (anyHit && best.hit) return best;
         }
       } else { stack[sp++] = n.left; stack[sp++] = n.right; }
@@ -325,9 +355,9 @@ struct Scene
   }
 
   // RayQuery_NearestHit (EmbreeRT.cpp:310-362): coords[0] = v (weight of C), coords[1] = u (weight of B)
-  orc_hit nearest_hit(f4 posNear, f4 dirFar, bool brute = false) const
+  orc_hit nearest_hit(f4 posNear, f4 dirFar, bool brute = false, float time = 0.0f) const
   {
-    const Best b = trace(xyz(posNear), xyz(dirFar), posNear.w, dirFar.w, false, brute);
+    const Best b = trace(xyz(posNear), xyz(dirFar), posNear.w, dirFar.w, false, brute, time);
     orc_hit h;
     if (b.hit) {
       h.t = b.t; h.primId = b.prim; h.instId = b.inst; h.geomId = instGeomId[b.inst];
@@ -339,9 +369,9 @@ struct Scene
     return h;
   }
   // RayQuery_AnyHit (EmbreeRT.cpp:364-392)
-  bool any_hit(f4 posNear, f4 dirFar, bool brute = false) const
+  bool any_hit(f4 posNear, f4 dirFar, bool brute = false, float time = 0.0f) const
   {
-    return trace(xyz(posNear), xyz(dirFar), posNear.w, dirFar.w, true, brute).hit;
+    return trace(xyz(posNear), xyz(dirFar), posNear.w, dirFar.w, true, brute, time).hit;
   }
 
   // ---- textures ---------------------------------------------------------------------------------------------

@@ -30,6 +30,8 @@ int main(int argc, char** argv)
     blob(f, "materials", sc.materials); blob(f, "lights", sc.lights);
     blob(f, "params", std::vector<hpt_params>(1, p));
     blob(f, "arrays1f", sc.arrays1f);
+    blob(f, "instMatricesMotion", sc.instMatricesMotion); blob(f, "instHasMotion", sc.instHasMotion);
+    blob(f, "normMatrices2Offs", std::vector<uint32_t>(1, sc.normMatrices2Offs));
     for (size_t i = 0; i < sc.textures.size(); i++) {
       const hydra_hip::LoadedTexture& t = sc.textures[i];
       blob(f, "texHeader", std::vector<uint32_t>{ t.width, t.height, t.format, t.flags, t.addressU, t.addressV, t.filter });

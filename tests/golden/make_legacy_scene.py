@@ -2,7 +2,8 @@
 """Writes tests/golden/scenes/legacy_materials: a small Hydra scene (XML + VSGF + image4ub, the formats of the shipped fixtures) whose
 materials walk every branch of ConvertOldHydraMaterial (integrator_pt_scene_mat.cpp:280-450): diffuse, diffuse + Oren-Nayar roughness,
 textured diffuse, reflectivity + diffuse without Fresnel (Lambert/metal mix), reflectivity with Fresnel (coated plastic), reflectivity only
-(metal), transparency (legacy glass), emission with a multiplier and no light, and the light-bound emissive material.
+(metal), transparency (legacy glass), emission with a multiplier and no light, and the light-bound emissive material; one sphere moves
+during the exposure (motion blur).
 Own data, not the reference's: the two loaders (Python, C++) are checked against each other on it and the GPU against the oracle."""
 import os
 import struct
@@ -61,7 +62,9 @@ def main():
     for i in range(8):
         x, z = -3.3 + 0.95 * i, -0.6 * (i % 3)
         s = 0.42 + 0.03 * (i % 2)
-        inst.append(f'<instance id="{i}" mesh_id="{i}" rmap_id="-1" matrix="{s} 0 0 {x} 0 {s} 0 {0.45 + 0.2 * (i % 2)} 0 0 {s} {z} 0 0 0 1" />')
+        # the third sphere slides and rises during the exposure (<motion matrix=..>, hydraxml.h:170-176: motion blur)
+        motion = f'<motion matrix="{s} 0 0 {x + 0.45} 0 {s} 0 {0.85 + 0.2 * (i % 2)} 0 0 {s} {z} 0 0 0 1" />' if i == 2 else ""
+        inst.append(f'<instance id="{i}" mesh_id="{i}" rmap_id="-1" matrix="{s} 0 0 {x} 0 {s} 0 {0.45 + 0.2 * (i % 2)} 0 0 {s} {z} 0 0 0 1">{motion}</instance>')
     inst.append('<instance id="8" mesh_id="8" rmap_id="-1" matrix="1 0 0 0 0 1 0 0 0 0 1 0 0 0 0 1" />')
     inst.append('<instance id="9" mesh_id="9" rmap_id="-1" matrix="1 0 0 0 0 1 0 3.5 0 0 1 0.5 0 0 0 1" light_id="0" linst_id="0" />')
     xml = f'''<?xml version="1.0"?>

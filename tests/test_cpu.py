@@ -412,7 +412,7 @@ def test_cpp_scene_loader_produces_the_same_tables(scene_name, tmp_path):
         assert named[k] == np.ascontiguousarray(ref).tobytes(), k
     ni = d.numInsts
     for k, ptr in (("instMatrices", d.instMatrices), ("normMatrices", d.normMatrices)):
-        got, ref = np.frombuffer(named[k], np.float32), arr(ptr, np.float32, 16 * ni)
+        got, ref = np.frombuffer(named[k], np.float32), arr(ptr, np.float32, 16 * ni * (2 if k == "normMatrices" and sc.inst_motion else 1))
         assert np.allclose(got, ref, rtol=1e-6, atol=1e-7), k
     mats = np.frombuffer(named["materials"], S.MATERIAL_DTYPE)
     ref_m = np.array(sc.materials, dtype=S.MATERIAL_DTYPE)
@@ -440,6 +440,10 @@ def test_cpp_scene_loader_produces_the_same_tables(scene_name, tmp_path):
     assert p_got[224:240] == p_ref[224:240]                                                          # environment map ids
     assert np.allclose(np.frombuffer(p_got[240:], np.float32), np.frombuffer(p_ref[240:], np.float32), rtol=1e-6)         # its sampler rows
     assert named.get("arrays1f", b"") == np.ascontiguousarray(sc.arrays1f, np.float32).tobytes()
+    assert np.frombuffer(named["normMatrices2Offs"], np.uint32)[0] == d.normMatrices2Offs == (ni if sc.inst_motion else 0)
+    if sc.inst_motion:
+        assert np.array_equal(np.frombuffer(named["instHasMotion"], np.uint32), [1 if i in sc.inst_motion else 0 for i in range(ni)])
+        assert np.allclose(np.frombuffer(named["instMatricesMotion"], np.float32), arr(d.instMatricesMotion, np.float32, 16 * ni), rtol=1e-6, atol=1e-7)
     # textures, in the order the reference's lazy loading creates them
     tex = [(np.frombuffer(h, np.uint32), b) for (kh, h), (kb, b) in zip(blobs, blobs[1:]) if kh == "texHeader" and kb == "texBytes"]
     assert len(tex) == len(sc.textures)

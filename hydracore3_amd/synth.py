@@ -345,4 +345,19 @@ def random_scene(seed: int, width=48, height=32) -> S.SceneData:
         if int(m["mtype"]) not in (S.MAT_TYPE_BLEND, S.MAT_TYPE_LIGHT_SOURCE) and r.uniform() < 0.25:
             k = float(r.choice([1.0, 2.0, 5.0]))
             S.set_normal_map(m, nmap, bool(r.randint(2)), bool(r.randint(2)), bool(r.randint(2)), (k, 0, 0, 0), (0, k, 0, 0))
+    # a third of the scenes sit under a small HDR environment map (sampled explicitly, with a shifted sampler), a quarter have a moving sphere,
+    # spot lights sometimes project the colour texture (all drawn last, see above)
+    if r.uniform() < 0.33:
+        sky = r.uniform(0.05, 0.6, (4, 8, 4)).astype(np.float32)
+        sky[int(r.randint(0, 2)), int(r.randint(0, 8)), :3] = r.uniform(5.0, 40.0, 3)
+        env = sc.add_texture(S.Texture(sky, S.TEX_RGBA32F, False, S.ADDR_WRAP, S.ADDR_CLAMP, S.FILTER_LINEAR))
+        sc.set_environment((1.0, 1.0, 1.0), env, 1.0, (1, 0, 0, float(r.uniform(0, 1))), (0, 1, 0, 0), cam_back=tex if r.uniform() < 0.3 else S.UINT_MAX)
+    if r.uniform() < 0.25 and len(sc.inst_geom) > 2:
+        i = int(r.randint(1, min(len(sc.inst_geom), 1 + nobj)))
+        m0 = sc.inst_matrices[i]
+        sc.inst_motion[i] = S.translate(float(r.uniform(-0.6, 0.6)), float(r.uniform(0.0, 0.5)), float(r.uniform(-0.4, 0.4))) @ m0 @ S.rotate_y(float(r.uniform(-40, 40)))
+    for lt in L:
+        if int(lt["distType"]) == S.LIGHT_DIST_SPOT and r.uniform() < 0.5:
+            mrow = np.eye(4); mrow[:3, 3] = lt["pos"][:3]
+            S.set_projective(lt, mrow, float(r.uniform(40, 80)), 0.1, 100.0, tex)
     return sc

@@ -465,10 +465,15 @@ struct Ctx
     s->instId = hit.instId;
   }
 
+  mutable long dbgCur = -1;                                  // debugging aid: ORC_DBG_TID=<tid> prints the rays of that thread (single-threaded runs)
+  long dbgTid = std::getenv("ORC_DBG_TID") ? std::atol(std::getenv("ORC_DBG_TID")) : -1;
   void RayTrace2(uint bounce, Path* s, Record* rec) const   // :214-348
   {
     if (isDeadRay(s->rayFlags)) return;
     const orc_hit hit = sc.nearest_hit(s->rayPosAndNear, s->rayDirAndFar, false, s->time);
+    if (dbgTid >= 0 && dbgCur == dbgTid)
+      std::fprintf(stderr, "[orc dbg] bounce %u o %.9g %.9g %.9g d %.9g %.9g %.9g time %.9g -> inst %u prim %u t %.9g\n", bounce, s->rayPosAndNear.x, s->rayPosAndNear.y, s->rayPosAndNear.z,
+                   s->rayDirAndFar.x, s->rayDirAndFar.y, s->rayDirAndFar.z, s->time, hit.instId, hit.primId, hit.t);
     if (rec && rec->enabled) rec->hit[bounce] = hit;
     if (hit.geomId != uint(-1)) SurfaceFromHit(hit, s->rayPosAndNear, s->rayDirAndFar, s);
     else {
@@ -621,6 +626,7 @@ struct Ctx
   {
     Path s;
     InitEyeRay2(tid, &s, rec);
+    dbgCur = (long)tid;
     for (uint depth = 0; depth < p.traceDepth; depth++) {
       RayTrace2(depth, &s, rec);
       if (isDeadRay(s.rayFlags)) break;

@@ -428,8 +428,8 @@ def test_full_size_interior_properties():
 
 @pytest.mark.parametrize("seed", list(range(12)))
 def test_fuzzed_scenes_match_oracle(seed):
-    """Seeded random scenes (synth.random_scene): material parameters at their corners, every light type, random depth, sampler modes
-    and integrators - HIP == oracle on images, generators and ray queries; the two schedules agree bit for bit."""
+    """Seeded random scenes (synth.random_scene): material parameters at their corners, blends, normal maps, plastic, every light type,
+    projected textures, HDR environment maps, moving instances, random depth, sampler modes and integrators - HIP == oracle on images, generators and ray queries; the two schedules agree bit for bit."""
     from hydracore3_amd.api import HipIntegrator
     from oracle.orc import OracleIntegrator
     from hydracore3_amd import synth
@@ -449,6 +449,11 @@ def test_fuzzed_scenes_match_oracle(seed):
     for f in ("primId", "instId", "geomId"):
         assert np.array_equal(hg[f], hc[f]), f
     assert np.array_equal(hg["t"].view(np.uint32), hc["t"].view(np.uint32))
+    if sc.inst_motion:                                                    # moving instances: the static query sees time 0, and the keys in between
+        for time in (0.0, 0.6):
+            hm, cm = gpu.RayQuery_NearestHitMotion(pos, dr, time), cpu.ray_nearest_motion(pos, dr, time, brute=True)
+            assert np.array_equal(hm["instId"], cm["instId"]) and np.array_equal(hm["t"].view(np.uint32), cm["t"].view(np.uint32))
+        return                                                            # (megakernel schedule only)
     wf = HipIntegrator(sc, p); wf.set_schedule(2)
     assert np.array_equal(wf.render(spp), a)
 

@@ -23,7 +23,9 @@ static const size_t FLAT_TRI_BUDGET = size_t(32) << 20;
 using namespace hpt;
 
 // Scenes with at least this many instanced triangles count as "heavy": wavefront schedule, single-level BVH, voted exit of the node loop.
-static const size_t HEAVY_SCENE_TRIS = size_t(1) << 13;    // measured (profiles/crossover.sh): wavefront wins from 16 K triangles up, loses 2x on the 36-triangle Cornell box
+static const size_t HEAVY_SCENE_TRIS = size_t(1) << 14;    // measured (profiles/crossover.sh): wavefront + voted node loop win from 16 K triangles up, lose 2x on the 36-triangle
+                                                           // Cornell box and 20 % on the 8 202-triangle test_228 (megakernel without the vote 667, wavefront + vote 531 Mpaths/s)
+static const size_t FLAT_AUTO_TRIS = size_t(1) << 12;      // instanced triangles from which the single-level layout is chosen whatever the instance count
 static const size_t MANY_INSTANCES = 6;                      // instances from which the single-level layout is chosen for light scenes too (see hpt_commit_scene)
 
 namespace {
@@ -370,7 +372,8 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   // Scenes of many small instances (the own fixtures: 6 ... 16 transformed spheres on a floor) also gain from it on the megakernel:
   // typed_materials 1031 -> 1127, legacy_materials 1574 -> 1752, env_map 1526 -> 1670 Mpaths/s (profiles/ab_layout.sh), the instance
   // enter / leave trips outweigh the looser boxes once a ray meets several overlapping BLAS boxes.
-  const bool autoFlat = instTris >= HEAVY_SCENE_TRIS || c->insts.size() >= MANY_INSTANCES;
+  // ... and so does the 8 202-triangle test_228 with its 3 instances (megakernel: two-level 617, single-level 667 Mpaths/s).
+  const bool autoFlat = instTris >= FLAT_AUTO_TRIS || c->insts.size() >= MANY_INSTANCES;
   c->anyMotion = false;
   for (const Inst& in : c->insts) c->anyMotion = c->anyMotion || in.motion;
   if (c->anyMotion && c->accelLayout == 2) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: moving instances need the two-level layout");

@@ -8,10 +8,12 @@ from hydracore3_amd.api import HipIntegrator
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for name in ("typed_materials", "legacy_materials", "env_map", "test_035"):
+for name in (os.environ.get("SCENES", "typed_materials,legacy_materials,env_map,test_035").split(",")):
     sc = load_hydra_xml(os.path.join(root, "tests", "golden", "scenes", name, "statex_00001.xml"), size, size)
     for sched in ((1,) if sc.inst_motion else (1, 2)):      # moving instances: megakernel only
         g = HipIntegrator(sc, accel_layout=int(os.environ.get("LAYOUT", "0"))); g.set_schedule(sched)
+        if os.environ.get("NODE_MIN"):
+            g.set_option("node_min", int(os.environ["NODE_MIN"])); g.LoadScene(sc)
         if os.environ.get("BPC"):
             g.set_launch_config(int(os.environ["BPC"]))
         if os.environ.get("FORCE_FULL"):

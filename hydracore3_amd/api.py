@@ -77,6 +77,7 @@ ABI = {
     "hpt_reduce_framebuffer": (_i, [_vp, _vp, _sz, _i, _vp]),
     "hpt_allreduce_grad": (_i, [_vp, _vp, _sz, _vp]),
     "hpt_get_schedule": (_i, [_vp, C.POINTER(_i), C.POINTER(_u32)]),
+    "hpt_get_accel_info": (_i, [_vp, C.POINTER(_f)]),
     "hpt_set_option": (_i, [_vp, C.c_char_p, _i]),
     "hpt_last_kernel_ms": (_i, [_vp, C.POINTER(_f)]),
 }
@@ -289,6 +290,11 @@ class HipIntegrator:
 
     def set_option(self, name: str, value: int):
         self._chk(self.L.hpt_set_option(self.h, name.encode(), value))
+
+    def accel_info(self):
+        out = (C.c_float * 4)()
+        self._chk(self.L.hpt_get_accel_info(self.h, out))
+        return {"sah_node_visits": out[0], "inst_tris": int(out[1]), "instances": int(out[2]), "flat": bool(out[3])}
 
     def last_schedule(self):
         s, it = C.c_int(0), C.c_uint32(0)

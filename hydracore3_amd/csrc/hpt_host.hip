@@ -23,8 +23,13 @@ static const size_t FLAT_TRI_BUDGET = size_t(32) << 20;
 using namespace hpt;
 
 // Scenes with at least this many instanced triangles count as "heavy": wavefront schedule, single-level BVH, voted exit of the node loop.
-static const size_t HEAVY_SCENE_TRIS = size_t(1) << 14;    // measured (profiles/crossover.sh): wavefront + voted node loop win from 16 K triangles up, lose 2x on the 36-triangle
-                                                           // Cornell box and 20 % on the 8 202-triangle test_228 (megakernel without the vote 667, wavefront + vote 531 Mpaths/s)
+// A "heavy" scene is one whose committed BVH is expected to cost a ray at least this many inner-node visits (sah_node_visits, the
+// surface-area estimate): it gets the wavefront schedule (when the call has enough pixels) and the voted node-loop exit. Measured
+// (profiles/sah_info.py, crossover.sh, crossover_small.sh, full_kernel.py): Cornell box 8.5, test_228 (8 202 triangles) 10.3, the own fixtures
+// 3.7 ... 4.8 - all fastest on the megakernel without the vote (test_228: 667 vs 531 Mpaths/s); the interior generator from 4 850 to 1 M
+// triangles 30 ... 60 - all fastest on the wavefront schedule with the vote (4 850 triangles: 340 vs 254). The triangle count does not
+// separate the two families (test_228 has more triangles than the smallest interior).
+static const float  HEAVY_SAH_VISITS = 20.0f;
 static const size_t FLAT_AUTO_TRIS = size_t(1) << 12;      // instanced triangles from which the single-level layout is chosen whatever the instance count
 static const size_t MANY_INSTANCES = 6;                      // instances from which the single-level layout is chosen for light scenes too (see hpt_commit_scene)
 
@@ -82,6 +87,7 @@ struct hpt_ctx
   std::vector<void*> texData; std::vector<TexRec> hTextures;
   DevBuf<float> dArrays1f; size_t numArrays1f = 0;       // m_arrays1f (pdf table of a sampled environment map)
   DevBuf<float> dInstMotion, dNormMat2;                  // motion blur: key matrices of the moving instances, end-of-motion normal matrices
+  float sahVisits = 0.0f;                                // expected inner-node visits per ray of the committed structure (sah_node_visits)
   bool anyMotion = false;                                // some instance moves: two-level layout, megakernel schedule, MOTION kernels
   std::vector<MaterialRec> hMaterials;                   // host mirror of m_materials: the blend graph is validated as a whole
   std::vector<uint> hLightGeom;                          // geomType of every light, to validate m_envLightId
@@ -315,6 +321,24 @@ extern "C" int hpt_update_instance(hpt_ctx* c, uint32_t instId, const float m[16
   return HPT_OK;
 }
 
+// Expected inner-node visits of a random ray through the root box (the surface-area heuristic the builder minimises): 1 for the root plus
+// area(child) / area(root) for every child that is an inner node. The number that tells a light scene from a heavy one better than the
+// triangle count does (see useWavefront).
+static float sah_node_visits(const Bvh2& t)
+{
+  const float a0 = t.bounds.halfArea();
+  if (t.nodes.empty() || !(a0 > 0.0f)) return 0.0f;
+  double v = 1.0;
+  for (const BvhNode& n : t.nodes) for (int k = 0; k < 2; k++) {
+    const uint ref = k ? n.ref1 : n.ref0;
+    if (ref == REF_NONE || (ref & REF_LEAF)) continue;
+    const float* q = n.q + 6 * k;
+    const float dx = q[1] - q[0], dy = q[3] - q[2], dz = q[5] - q[4];
+    if (dx >= 0.0f) v += double(dx * dy + dy * dz + dz * dx) / a0;
+  }
+  return (float)v;
+}
+
 // world -> object rows of an instance matrix (column-major 4x4, affine): cofactor inverse in double, rounded once
 static void inverse_rows(const float* m, float row0[4], float row1[4], float row2[4])
 {
@@ -365,7 +389,6 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   size_t instTris = 0;
   for (const Inst& in : c->insts) instTris += c->geoms[in.geomId].idx.size() / 3;
   c->instTris = instTris;
-  c->S.nodeMin = c->nodeMinOverride >= 0 ? (uint)c->nodeMinOverride : (instTris >= HEAVY_SCENE_TRIS ? 16u : 0u);
   // Automatic choice, measured: heavy static scenes (wavefront schedule) gain 8 % from the single-level layout (1M triangles: 191 -> 207
   // Mpaths/s; no instance enter / leave trips, triangle-loop lane utilisation 0.21 -> 0.38); the Cornell-box class on the megakernel loses
   // 8 % to it (looser world-space boxes around rotated instances, per-triangle ray transform) and keeps the two-level TLAS/BLAS layout.
@@ -422,6 +445,8 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
     HIPCHK(c, c->dInsts.upload(dinst.data(), dinst.size()));
     c->S.nodes = c->dNodes.p; c->S.tris = c->dTris.p; c->S.insts = c->dInsts.p;
     c->S.rootRef = tree.rootRef; c->S.numInsts = (uint)ni; c->S.flatMode = 1;
+    c->sahVisits = sah_node_visits(tree);
+    c->S.nodeMin = c->nodeMinOverride >= 0 ? (uint)c->nodeMinOverride : (c->sahVisits >= HEAVY_SAH_VISITS ? 16u : 0u);
     c->stackNeeded = tree.depth + 1u;
     if (c->stackNeeded > MAX_STACK) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: BVH deeper than the 64-entry traversal stack");
     c->accelCommitted = true;
@@ -447,6 +472,18 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
     ib.push_back(w); liveInst.push_back((uint)i);
   }
   Bvh2 tlas = Bvh2Builder::build(ib, 1, std::max(16, ceil_log2(ib.size() + 1) + 2), true);
+  {                                                          // TLAS visits + the chance of entering each instance x its BLAS visits
+    double v = sah_node_visits(tlas);
+    const float a0 = tlas.bounds.halfArea();
+    std::vector<float> blasVisits(c->geoms.size(), -1.0f);
+    for (size_t k = 0; k < ib.size() && a0 > 0.0f; k++) {
+      const uint g = c->insts[liveInst[k]].geomId;
+      if (blasVisits[g] < 0.0f) blasVisits[g] = sah_node_visits(c->geoms[g].bvh);
+      v += double(ib[k].halfArea()) / a0 * blasVisits[g];
+    }
+    c->sahVisits = (float)v;
+    c->S.nodeMin = c->nodeMinOverride >= 0 ? (uint)c->nodeMinOverride : (c->sahVisits >= HEAVY_SAH_VISITS ? 16u : 0u);
+  }
   // instance leaves refer to positions in `ib`; map them back to real instance ids
   auto fixInst = [&](uint ref) -> uint {
     if (ref != REF_NONE && (ref & REF_LEAF) && ((ref >> 28) & 7u) == 0u) return REF_LEAF | liveInst[ref & 0x0FFFFFFFu];
@@ -929,9 +966,8 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
 
 
 // ---- wavefront schedule ---------------------------------------------------------------------------------------------------------------
-// Scenes at or above this many instanced triangles are rendered by the shade / trace kernel pair; below it the path state's trip
-// through HBM costs more than the ray replacement gains (measured crossover: see DESIGN.md, "two schedules").
-static const size_t WF_AUTO_TRIS = HEAVY_SCENE_TRIS;
+// Heavy scenes (HEAVY_SAH_VISITS) are rendered by the shade / trace kernel pair; on light ones the path state's trip through HBM costs more
+// than the ray replacement gains (measured crossover: see DESIGN.md, "two schedules").
 static const uint   WF_AUTO_PIXELS = 1u << 19;
 static const uint   WF_POOL_MAX = 1u << 22;        // pool slots (pixels in flight) per batch: 4M x 148 B = 620 MB
 static const uint   WF_CHECK = 8;                  // progress word copied back every WF_CHECK shade passes
@@ -945,7 +981,7 @@ static bool useWavefront(hpt_ctx* c, bool naive, bool dr, bool stats, uint tidCo
   if (c->schedule == 2) return true;
   // ... and only for calls with enough pixels to keep the trace kernel's lanes supplied with replacement rays: measured on the 1M-triangle
   // scene (profiles/share.sh, 2.07 M / 1.04 M / 518 K / 259 K pixels per call): wavefront 226 / 199 / 162 / 108 vs megakernel 171 / 161 / 159 / 146 Mpaths/s
-  return c->instTris >= WF_AUTO_TRIS && tidCount >= WF_AUTO_PIXELS;
+  return c->sahVisits >= HEAVY_SAH_VISITS && tidCount >= WF_AUTO_PIXELS;
 }
 
 template <bool STATS>
@@ -1377,6 +1413,12 @@ extern "C" int hpt_set_option(hpt_ctx* c, const char* name, int value)
   else if (k == "node_min") { c->nodeMinOverride = value & 63; c->accelCommitted = false; }   // voted exit of the inner-node loop; takes effect at the next CommitScene
   else if (k == "force_full_materials") c->forceFull = value != 0;                     // diagnostic: never pick the lean (gltf + emissive) kernels
   else return c->fail(HPT_ERR_ARG, "hpt_set_option: unknown option " + k);
+  return HPT_OK;
+}
+extern "C" int hpt_get_accel_info(hpt_ctx* c, float out[4])
+{
+  if (!c || !out) return HPT_ERR_ARG;
+  out[0] = c->sahVisits; out[1] = (float)c->instTris; out[2] = (float)c->insts.size(); out[3] = c->S.flatMode ? 1.0f : 0.0f;
   return HPT_OK;
 }
 extern "C" int hpt_get_schedule(hpt_ctx* c, int* lastSchedule, uint32_t* lastIterations)

@@ -243,6 +243,9 @@ int  hpt_comm_destroy(hpt_ctx* ctx);
 int  hpt_reduce_framebuffer(hpt_ctx* ctx, float* frameDev, size_t count, int root, void* stream);
 int  hpt_allreduce_grad(hpt_ctx* ctx, float* gradDev, size_t count, void* stream);
 /* Schedule the last hpt_path_trace_block(_dev) call used (1 / 2) and, for the wavefront one, its number of shade+trace rounds. */
+/* What CommitScene built: out[0] = expected inner-node visits per ray (surface-area estimate over the committed BVH; the quantity the automatic
+ * schedule / layout choice is measured against), out[1] = instanced triangles, out[2] = instances, out[3] = 1 for the single-level layout. */
+int  hpt_get_accel_info(hpt_ctx* ctx, float out[4]);
 int  hpt_get_schedule(hpt_ctx* ctx, int* lastSchedule, uint32_t* lastIterations);
 /* Duration of the last path-tracing kernel, measured with HIP events on the stream it ran on (ms). */
 int  hpt_last_kernel_ms(hpt_ctx* ctx, float* ms);

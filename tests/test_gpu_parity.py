@@ -1004,3 +1004,24 @@ def test_motion_blur_matches_oracle():
         wf.render(1)
     with pytest.raises(HydraHipError, match="two-level"):
         HipIntegrator(sc, accel_layout=2)
+
+
+def test_automatic_schedule_follows_the_sah_estimate():
+    """The automatic schedule is decided from the committed BVH (hpt_get_accel_info: the surface-area estimate of inner-node visits per ray),
+    not from the triangle count: the reference's 8 202-triangle test_228 (estimate ~10) stays on the megakernel, the 4 850-triangle
+    interior (estimate ~30) goes to the wavefront schedule once the call has 2^19 pixels; either way the frame is the same."""
+    from hydracore3_amd.api import HipIntegrator
+    from hydracore3_amd import synth
+    cases = [(load_hydra_xml(scene_path("test_035"), 1024, 512), 1, (4.0, 15.0)), (load_hydra_xml(scene_path("test_228"), 1024, 512), 1, (6.0, 16.0)),
+             (synth.interior_scene(1024, 512, subdiv=0, tex_size=64), 2, (24.0, 45.0))]
+    for sc, want, (lo, hi) in cases:
+        g = HipIntegrator(sc)
+        info = g.accel_info()
+        assert lo < info["sah_node_visits"] < hi, info
+        a = g.render(1)
+        assert g.last_schedule()[0] == want, (info, g.last_schedule())
+        other = HipIntegrator(sc); other.set_schedule(3 - want)
+        assert np.array_equal(other.render(1), a)
+    small = HipIntegrator(synth.interior_scene(640, 360, subdiv=0, tex_size=64))          # fewer than 2^19 pixels: megakernel even when heavy
+    small.render(1)
+    assert small.last_schedule()[0] == 1

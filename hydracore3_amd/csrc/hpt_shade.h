@@ -57,10 +57,6 @@ HPT_DEV void cameraRay(const DevScene& S, uint x, uint y, V4 pixelOffsets, V3& r
   rayDir = normalize(p2 - p1);
 }
 
-// Shades the vertex a closest-hit query returned for one path.  All path registers are passed by reference and the
-// function is always inlined, so both callers keep them in VGPRs.  Returns true when the path continues (didBounce).
-// A miss only sets the OUT_OF_SCENE flags.  The caller traces the shadow ray (if wantShadow) and adds `contrib`.
-// ---- blend materials (integrator_pt_mat.cpp:23-77, 123-130, 316-333, 511-527); only in the non-LEAN kernels ---------------------------------
 // ---- normal-map bump (integrator_pt_mat.cpp:94-107, 131-139, 298-303, 336-355; NormalMapTransform in include/cmaterial.h) -------------------
 // world-space tangent of the hit (integrator_pt.cpp:270-302: interpolated, through the normal matrix, normalised, flipped with the normal)
 HPT_DEV V3 hitTangent(const DevScene& S, uint A, uint B, uint C, uint vertOffset, float wA, float uvx, float uvy, const float* nm, float flipNorm,
@@ -96,6 +92,7 @@ HPT_DEV float bumpCosMult(V3 l, V3 geomNormal, V3 shadeNormal)
   const float c1 = smax(dot(l, geomNormal), 0.0f), c2 = smax(dot(l, shadeNormal), 0.0f);
   return (c1 <= 0.0f) ? 0.0f : c2 / smax(c1, 1e-6f);
 }
+// ---- blend materials (integrator_pt_mat.cpp:23-77, 123-130, 316-333, 511-527); only in the non-LEAN kernels ---------------------------------
 // texture colour and the "four scalar parameters" of a leaf material (:139-167)
 HPT_DEV void leafTextures(const DevScene& S, const MaterialRec& m, V2 uv, V3& tex3, V3& four)
 {
@@ -139,6 +136,10 @@ HPT_DEV void blendTreeEval(const DevScene& S, uint rootId, V2 uv, V3 l, V3 v, V3
   } while (top > 0);
 }
 
+// Shades the vertex a closest-hit query returned for one path.  All path registers are passed by reference and the
+// function is always inlined, so both callers keep them in VGPRs.  Returns true when the path continues (didBounce).
+// A miss only sets the OUT_OF_SCENE flags.  The caller traces the shadow ray (if wantShadow) and adds `contrib`.
+// MOTION: moving instances - the normal (and tangent) are interpolated at the path's `time` (see hitTangent).
 // LEAN: the scene holds gltf and emissive materials only (the host checked): the conductor / diffuse / glass / dielectric branches are
 // compiled out - fewer live registers and spills in the kernels every benchmark scene runs (the DR variant is lean by definition).
 template <bool DR, bool NAIVE, bool LEAN = false, bool MOTION = false>

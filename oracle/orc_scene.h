@@ -277,20 +277,22 @@ struct Scene
   }
 
   // A moving instance (AddInstanceMotion, EmbreeRT.cpp:264-292): object->world interpolated linearly between the two keys at the ray's time,
-  // then inverted for this ray - cofactors in float, the translation subtracted first (the same arithmetic as the device's)
+  // then inverted for this ray - cofactors in double, the translation subtracted first (the same arithmetic as the device's)
   void to_object_space_motion(uint inst, float time, f3 wo, f3 wd, f3* o, f3* d) const
   {
     const m4& m0 = instMatrices[inst]; const m4& m1 = instMatricesMotion[inst];
-    float a[12];
-    for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) { const float k0 = m0.c[c][r], k1 = m1.c[c][r]; a[4 * r + c] = k0 + time * (k1 - k0); }
-    const float c00 = a[5] * a[10] - a[6] * a[9], c01 = a[2] * a[9] - a[1] * a[10], c02 = a[1] * a[6] - a[2] * a[5];
-    const float c10 = a[6] * a[8] - a[4] * a[10], c11 = a[0] * a[10] - a[2] * a[8], c12 = a[2] * a[4] - a[0] * a[6];
-    const float c20 = a[4] * a[9] - a[5] * a[8],  c21 = a[1] * a[8] - a[0] * a[9],  c22 = a[0] * a[5] - a[1] * a[4];
-    const float det = a[0] * c00 + a[1] * c10 + a[2] * c20;
-    const float id = 1.0f / det;
-    const f3 p = mk3(wo.x - a[3], wo.y - a[7], wo.z - a[11]);
-    *o = mk3((c00 * p.x + c01 * p.y + c02 * p.z) * id, (c10 * p.x + c11 * p.y + c12 * p.z) * id, (c20 * p.x + c21 * p.y + c22 * p.z) * id);
-    *d = mk3((c00 * wd.x + c01 * wd.y + c02 * wd.z) * id, (c10 * wd.x + c11 * wd.y + c12 * wd.z) * id, (c20 * wd.x + c21 * wd.y + c22 * wd.z) * id);
+    double a[12];
+    const double t = (double)time;
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) { const double k0 = (double)m0.c[c][r], k1 = (double)m1.c[c][r]; a[4 * r + c] = k0 + t * (k1 - k0); }
+    const double c00 = a[5] * a[10] - a[6] * a[9], c01 = a[2] * a[9] - a[1] * a[10], c02 = a[1] * a[6] - a[2] * a[5];
+    const double c10 = a[6] * a[8] - a[4] * a[10], c11 = a[0] * a[10] - a[2] * a[8], c12 = a[2] * a[4] - a[0] * a[6];
+    const double c20 = a[4] * a[9] - a[5] * a[8],  c21 = a[1] * a[8] - a[0] * a[9],  c22 = a[0] * a[5] - a[1] * a[4];
+    const double det = a[0] * c00 + a[1] * c10 + a[2] * c20;
+    const double id = 1.0 / det;
+    const double px = (double)wo.x - a[3], py = (double)wo.y - a[7], pz = (double)wo.z - a[11];
+    const double dx = (double)wd.x, dy = (double)wd.y, dz = (double)wd.z;
+    *o = mk3((float)((c00 * px + c01 * py + c02 * pz) * id), (float)((c10 * px + c11 * py + c12 * pz) * id), (float)((c20 * px + c21 * py + c22 * pz) * id));
+    *d = mk3((float)((c00 * dx + c01 * dy + c02 * dz) * id), (float)((c10 * dx + c11 * dy + c12 * dz) * id), (float)((c20 * dx + c21 * dy + c22 * dz) * id));
   }
 
   void intersect_instance(uint inst, f3 o, f3 d, float tnear, float tfar, Best& best, bool anyHit, bool brute, float time = 0.0f) const

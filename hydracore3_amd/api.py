@@ -25,6 +25,7 @@ ABI = {
     "hpt_destroy": (None, [_vp]),
     "hpt_last_error": (C.c_char_p, [_vp]),
     "hpt_device_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.c_char_p, _sz]),
+    "hpt_set_optics": (_i, [_vp, _vp, _u32, _f, _f]),
     "hpt_plastic_precompute": (_i, [_f, _f, _f, _vp, _vp, _vp, C.POINTER(_f), C.POINTER(_f)]),
     "hpt_device_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "hpt_device_free": (_i, [_vp, _vp]),
@@ -144,6 +145,8 @@ class HipIntegrator:
         self._desc = scene.desc()
         self.CommitDeviceData()
         self.UpdateMembersPlainData(params if params is not None else scene.params())
+        lines = np.ascontiguousarray(scene.lens_lines, np.float32).reshape(-1, 4)       # m_lines / m_physSize (lens simulation; none: off)
+        self._chk(self.L.hpt_set_optics(self.h, lines.ctypes.data if lines.size else None, lines.shape[0], float(scene.phys_size[0]), float(scene.phys_size[1])))
         self.PackXYBlock(self.W, self.H, 1)
         self.InitRandomGens(self.N)
 

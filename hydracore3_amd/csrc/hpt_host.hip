@@ -86,6 +86,7 @@ struct hpt_ctx
   DevBuf<MaterialRec> dMaterials; DevBuf<LightRec> dLights; DevBuf<TexRec> dTextures;
   std::vector<void*> texData; std::vector<TexRec> hTextures;
   DevBuf<float> dArrays1f; size_t numArrays1f = 0;       // m_arrays1f (pdf table of a sampled environment map)
+  DevBuf<float4> dLensLines;                             // m_lines of the lens simulation (hpt_set_optics)
   DevBuf<float> dInstMotion, dNormMat2;                  // motion blur: key matrices of the moving instances, end-of-motion normal matrices
   float sahVisits = 0.0f;                                // expected inner-node visits per ray of the committed structure (sah_node_visits)
   bool anyMotion = false;                                // some instance moves: two-level layout, megakernel schedule, MOTION kernels
@@ -805,6 +806,20 @@ extern "C" int hpt_update_params(hpt_ctx* c, const hpt_params* p)
   return HPT_OK;
 }
 
+// SetLines / SetPhysSize + m_enableOpticSim (integrator_pt.h:353-362, integrator_pt_scene.cpp:714-720, 1078-1141): n = 0 switches it off
+extern "C" int hpt_set_optics(hpt_ctx* c, const float* lines4, uint32_t n, float physSizeX, float physSizeY)
+{
+  if (!c || (n && !lines4)) return HPT_ERR_ARG;
+  if (n > 64) return c->fail(HPT_ERR_ARG, "SetLines: more than 64 lens interfaces");
+  for (uint32_t i = 0; i < n; i++) if (!(lines4[4 * i + 3] >= 0.0f)) return c->fail(HPT_ERR_ARG, "SetLines: negative aperture radius");
+  (void)hipSetDevice(c->device);
+  std::vector<float4> l(std::max<uint32_t>(n, 1u), make_float4(0, 0, 0, 0));
+  for (uint32_t i = 0; i < n; i++) l[i] = make_float4(lines4[4 * i], lines4[4 * i + 1], lines4[4 * i + 2], lines4[4 * i + 3]);
+  HIPCHK(c, c->dLensLines.upload(l.data(), l.size()));
+  c->S.lensLines = c->dLensLines.p; c->S.lensCount = n; c->S.physSize[0] = physSizeX; c->S.physSize[1] = physSizeY; c->S.padLens = 0;
+  return HPT_OK;
+}
+
 extern "C" int hpt_update_materials(hpt_ctx* c, size_t first, size_t count, const void* mats)
 {
   if (!c || !mats) return HPT_ERR_ARG;
@@ -924,13 +939,14 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   if (c->dGens.n < (inRays ? (size_t)job.tidEnd : (size_t)c->packedCount)) return c->fail(HPT_ERR_STATE, "PathTraceBlock: m_randomGens smaller than the thread range (InitRandomGens)");
   if (job.channels < 1 || job.channels > 4) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceBlock: channels must be 1..4 (spectral layers are out of scope)");
   if (dr && (c->S.traceDepth == 0 || c->S.traceDepth > 16)) return c->fail(HPT_ERR_ARG, "PathTraceDR: trace depth must be 1..16");
+  if (dr && c->S.lensCount) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceDR: the lens simulation is not differentiated");
   if (dr && c->S.motion) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceDR: motion blur is not differentiated");
   if (c->S.motion && c->schedule == 2) return c->fail(HPT_ERR_UNSUPPORTED, "motion blur runs on the megakernel schedule");
   if (dr && !c->leanMaterials) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceDR: gltf and emissive materials without normal maps only (what the reference's replay differentiates, integrator_dr.cpp:461-612)");
   // never more lanes than pixels: with fewer, the hardware's round-robin block placement spreads them evenly over the CUs, whereas a
   // full grid would let whichever waves ask first take all the work (a small multi-GPU share of a frame)
   const bool motion = c->S.motion != 0;
-  const bool fullMaterials = motion || !dr && !(c->leanMaterials && !c->forceFull && !naive && !inRays && !(c->instrument && !dr));   // MODE 0 / 1 / 2 / STATS kernels
+  const bool fullMaterials = motion || !dr && !(c->leanMaterials && !c->forceFull && c->S.lensCount == 0u && !naive && !inRays && !(c->instrument && !dr));   // MODE 0 / 1 / 2 / STATS kernels
   const int blocks = (int)std::min<size_t>((size_t)gridBlocks(c, dr, fullMaterials), ((size_t)job.tidCount + 255) / 256);
   HIPCHK(c, c->dQueue.alloc(1));
   HIPCHK(c, hipMemsetAsync(c->dQueue.p, 0, 4, st));
@@ -957,7 +973,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   else if (inRays) launchPT<false, false, 2>(c->S, job, blocks, st, deep);
   else if (naive)  launchPT<false, false, 1>(c->S, job, blocks, st, deep);
   else if (stats)  launchPT<true, false, 0>(c->S, job, blocks, st, deep);
-  else if (c->leanMaterials && !c->forceFull) launchPT<false, false, 3>(c->S, job, blocks, st, deep);
+  else if (c->leanMaterials && !c->forceFull && c->S.lensCount == 0u) launchPT<false, false, 3>(c->S, job, blocks, st, deep);
   else             launchPT<false, false, 0>(c->S, job, blocks, st, deep);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev1, st));
@@ -1072,7 +1088,7 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr)
       wj.itemBase = g.itemBase; wj.itemCount = g.itemCount; wj.iter = (uint)g.it; wj.record = g.rec.p;
       const dim3 sg((g.itemCount + 255u) / 256u);
       if (dr)                    wfShadeKernel<true, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
-      else if (c->leanMaterials && !c->forceFull) wfShadeKernel<false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
+      else if (c->leanMaterials && !c->forceFull && c->S.lensCount == 0u) wfShadeKernel<false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
       else                       wfShadeKernel<false, false><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
       if ((g.it % WF_CHECK) == WF_CHECK - 1) {
         const uint slot = g.checkpoints % WF_RING;

@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256, (DR || MODE == 3) ? HPT_MIN_WAVES : HPT_F
       } else {
         const V4 lens = rng_float4(gen);                                   // GetRandomNumbersLens
         const uint XY = PIX_XY;
-        cameraRay(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
+        cameraRay<!(DR || LEAN)>(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
         if (MOTION) pathTime = rng_float1(gen);                            // GetRandomNumbersTime (integrator_pt.cpp:114-115): one step per path, after the lens
       }
       alive = true;

@@ -33,7 +33,77 @@ HPT_DEV V4 texFetchAD(const DevScene& S, const float* data, uint texId, V2 uv, T
   return texSample(S.textures, texId, uv);
 }
 
-// SampleCameraRay + kernel_InitEyeRay2 (integrator_pt.cpp:44-157), RGB / static-scene subset
+// ---- lens simulation: TraceLensesFromFilm and its helpers (integrator_pt.cpp:806-938, after pbrt's RealisticCamera) --------------------------
+HPT_DEV bool lensQuadratic(float A, float B, float C, float& t0, float& t1)
+{
+  const float discrim = B * B - 4.0f * A * C;
+  if (discrim < 0.f) return false;
+  const float rootDiscrim = sqrtf_(discrim);
+  const float q = (B < 0.0f) ? -.5f * (B - rootDiscrim) : -.5f * (B + rootDiscrim);
+  t0 = q / A; t1 = C / q;
+  if (t0 > t1) { const float t = t0; t0 = t1; t1 = t; }
+  return true;
+}
+HPT_DEV bool lensRefract(V3 wi, V3 n, float eta, V3& wt)
+{
+  const float cosThetaI = dot(n, wi);
+  const float sin2ThetaI = smax(0.0f, 1.0f - cosThetaI * cosThetaI);
+  const float sin2ThetaT = eta * eta * sin2ThetaI;
+  if (sin2ThetaT >= 1) return false;
+  const float cosThetaT = sqrtf_(1 - sin2ThetaT);
+  wt = eta * (-1.0f) * wi + (eta * cosThetaI - cosThetaT) * n;
+  return true;
+}
+HPT_DEV bool intersectSphericalElement(float radius, float zCenter, V3 rayPos, V3 rayDir, float& t, V3& n)
+{
+  const V3 o = rayPos - v3(0, 0, zCenter);
+  const float A = rayDir.x * rayDir.x + rayDir.y * rayDir.y + rayDir.z * rayDir.z;
+  const float B = 2 * (rayDir.x * o.x + rayDir.y * o.y + rayDir.z * o.z);
+  const float C = o.x * o.x + o.y * o.y + o.z * o.z - radius * radius;
+  float t0, t1;
+  if (!lensQuadratic(A, B, C, t0, t1)) return false;
+  const bool useCloserT = (rayDir.z > 0.0f) != (radius < 0.0f);
+  t = useCloserT ? smin(t0, t1) : smax(t0, t1);
+  if (t < 0.0f) return false;
+  n = normalize(o + t * rayDir);
+  n = (dot(n, -1.0f * rayDir) < 0.f) ? (-1.0f) * n : n;               // faceforward
+  return true;
+}
+HPT_DEV bool traceLensesFromFilm(const DevScene& S, V3& rayPos, V3& rayDir)
+{
+  float elementZ = 0;
+  V3 p = v3(rayPos.x, rayPos.y, -rayPos.z), d = v3(rayDir.x, rayDir.y, -rayDir.z);     // camera -> lens-system space
+  for (uint i = 0; i < S.lensCount; i++) {
+    const float4 e = S.lensLines[i];                                   // {curvatureRadius, thickness, eta, apertureRadius}
+    elementZ -= e.y;
+    float t; V3 n = v3(0, 0, 0);
+    const bool isStop = (e.x == 0.0f);
+    if (isStop) {
+      if (d.z >= 0.0f) return false;
+      t = (elementZ - p.z) / d.z;
+    } else {
+      if (!intersectSphericalElement(e.x, elementZ + e.x, p, d, t, n)) return false;
+    }
+    const V3 pHit = p + t * d;
+    if (pHit.x * pHit.x + pHit.y * pHit.y > e.w * e.w) return false;
+    p = pHit;
+    if (!isStop) {
+      const float etaI = e.z;
+      float etaT = (i == S.lensCount - 1u) ? 1.0f : S.lensLines[i + 1u].z;
+      if (etaT == 0.0f) etaT = 1.0f;
+      V3 wt;
+      if (!lensRefract(normalize((-1.0f) * d), n, etaI / etaT, wt)) return false;
+      d = wt;
+    }
+  }
+  rayPos = v3(p.x, p.y, -p.z); rayDir = v3(d.x, d.y, -d.z);
+  return true;
+}
+
+// SampleCameraRay + kernel_InitEyeRay2 (integrator_pt.cpp:44-157), RGB subset
+// LENS: the lens-simulation branch exists only in the kernels with every BSDF branch (the host routes scenes with m_enableOpticSim to them):
+// compiled into the lean kernels it cost the Cornell benchmark 0.6 % without ever running (profiles/ab.sh, base vs -DHPT_NO_LENS)
+template <bool LENS>
 HPT_DEV void cameraRay(const DevScene& S, uint x, uint y, V4 pixelOffsets, V3& rayPos, V3& rayDir)
 {
   const float fx = float(x) + pixelOffsets.x, fy = float(y) + pixelOffsets.y;
@@ -50,6 +120,15 @@ HPT_DEV void cameraRay(const DevScene& S, uint x, uint y, V4 pixelOffsets, V3& r
     const float k = S.camLensRadius * 2.0f;
     org.x += k * d2.x; org.y += k * d2.y;
     dir = normalize(focusPosition - org);
+  }
+  else if (LENS && S.lensCount != 0u) {                                  // m_enableOpticSim (:79-103): a film point, a point on the rear element, the lens stack
+    org = v3(0.25f * S.physSize[0] * (2.0f * xn - 1.0f), 0.25f * S.physSize[1] * (2.0f * yn - 1.0f), 0.0f);
+    const float4 rear = S.lensLines[0];                                  // LensRearZ() = thickness, LensRearRadius() = apertureRadius of the first line
+    const V2 rs = mapSamplesToDisc(v2(pixelOffsets.z - 0.5f, pixelOffsets.w - 0.5f));
+    const float k = rear.w * 2.0f;
+    dir = normalize(v3(k * rs.x, k * rs.y, rear.y) - org);
+    if (!traceLensesFromFilm(S, org, dir)) { org = v3(0, -10000000.0f, 0.0f); dir = v3(0, -1, 0); }   // "shoot ray under the floor"
+    else { dir = (-1.0f) * normalize(dir); org = (-1.0f) * org; }
   }
   const V3 p1 = mul4x3(S.worldViewInv, org);                             // transform_ray3f (cglobals.h:254-263)
   const V3 p2 = mul4x3(S.worldViewInv, org + 100.0f * dir);

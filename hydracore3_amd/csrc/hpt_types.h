@@ -94,6 +94,11 @@ struct DevScene
   const float*       normMat2;    // 12 floats per instance: rows of the upper 3x3 of m_normMatrices[m_normMatrices2Offs + i]
   uint               motion;      // m_normMatrices2Offs != 0: a time is drawn per path and normals are interpolated
   uint               padMotion;
+  // lens simulation (integrator_pt.cpp:78-104, 806-938): m_lines as {curvatureRadius, thickness, eta, apertureRadius}, film side first
+  const float4*      lensLines;   // lensCount entries; lensCount = 0: m_enableOpticSim off
+  uint               lensCount;
+  float              physSize[2]; // m_physSize
+  uint               padLens;
 
   // plain-data members (UpdateMembersPlainData)
   float projInv[16], worldViewInv[16];

@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(256, (DR || LEAN) ? HPT_WF_SHADE_WAVES : HPT_W
       passes--;
       accum = v3(0, 0, 0); thr = v3(1, 1, 1); flags = 0; bounce = 0; misPdf = 1.0f; misIor = 1.0f;
       const V4 lens = rng_float4(gen);
-      cameraRay(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
+      cameraRay<!(DR || LEAN)>(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
       alive = true;
     }
     job.gens[tid] = gen;

@@ -12,6 +12,7 @@
 // to float rounding). Header-only host C++17, no dependencies: the XML subset Hydra writes (elements, attributes, text, comments)
 // is parsed by the ~80 lines below instead of pugixml.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -189,6 +190,7 @@ struct LoadedScene
   uint32_t envTexId = 0xFFFFFFFFu, envLightId = 0xFFFFFFFFu, envCamBackId = 0xFFFFFFFFu, envEnableSam = 0;
   float envSamRow0[4] = {1, 0, 0, 0}, envSamRow1[4] = {0, 1, 0, 0};
   std::vector<float> arrays1f;
+  std::vector<float> lensLines; float physSize[2] = {0, 0};   // lens simulation: m_lines as {curvatureRadius, thickness, eta, apertureRadius}, m_physSize
   std::vector<hpt_texture_desc> texDescs;                 // filled by desc(): points into `textures`
 
   hpt_scene_desc desc()
@@ -271,6 +273,7 @@ struct LoadedScene
     rc = hpt_upload_scene(ctx, &d); if (rc) return rc;
     hpt_params p = params(integratorType);
     rc = hpt_update_params(ctx, &p); if (rc) return rc;
+    rc = hpt_set_optics(ctx, lensLines.empty() ? nullptr : lensLines.data(), (uint32_t)(lensLines.size() / 4), physSize[0], physSize[1]); if (rc) return rc;
     rc = hpt_pack_xy(ctx, (uint32_t)width, (uint32_t)height); if (rc) return rc;
     return hpt_init_random_gens(ctx, (uint32_t)(width * height));
   }
@@ -370,6 +373,28 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
   { const auto p = parseFloats(cam->childText("position")), l = parseFloats(cam->childText("look_at")), u = parseFloats(cam->childText("up"));
     if (p.size() < 3 || l.size() < 3 || u.size() < 3) { err = "xml: camera vectors"; return false; }
     for (int k = 0; k < 3; k++) { sc.camPos[k] = p[k]; sc.camLookAt[k] = l[k]; sc.camUp[k] = u[k]; } }
+
+  // lens simulation: LoadOpticsFromNode (integrator_pt_scene.cpp:1078-1141). The reference reads m_aspect there before anything has set it;
+  // height / width of the frame is taken (the film's aspect in pbrt's RealisticCamera, which the code follows). Its fallback to an <optics>
+  // node never triggers (opticNode != opticNode).
+  if (const XmlNode* optics = cam->child("optical_system")) {
+    const float scale = optics->has("scale") ? (float)std::atof(optics->get("scale").c_str()) : 1.0f;
+    const float diagonal = optics->has("sensor_diagonal") ? (float)std::atof(optics->get("sensor_diagonal").c_str()) : 0.035f;
+    struct Line { int id; float r, t, ior, ap; };
+    std::vector<Line> lines; int k = 0;
+    for (const XmlNode* ln : optics->all("line")) {
+      Line l; l.id = ln->has("id") ? std::atoi(ln->get("id").c_str()) : k;
+      l.r = scale * (float)std::atof(ln->get("curvature_radius", "0").c_str()); l.t = scale * (float)std::atof(ln->get("thickness", "0").c_str());
+      l.ior = (float)std::atof(ln->get("ior", "0").c_str());
+      l.ap = scale * (float)std::atof((ln->has("semi_diameter") ? ln->get("semi_diameter") : ln->get("aperture_radius", "0")).c_str());
+      lines.push_back(l); k++;
+    }
+    const bool desc = optics->get("order") == "scene_to_sensor";
+    std::stable_sort(lines.begin(), lines.end(), [desc](const Line& a, const Line& b) { return desc ? a.id > b.id : a.id < b.id; });
+    for (const Line& l : lines) { sc.lensLines.push_back(l.r); sc.lensLines.push_back(l.t); sc.lensLines.push_back(l.ior); sc.lensLines.push_back(l.ap); }
+    const float aspect = float(sc.height) / float(sc.width);
+    sc.physSize[0] = 2.0f * std::sqrt(diagonal * diagonal / (1.0f + aspect * aspect)); sc.physSize[1] = aspect * sc.physSize[0];
+  }
 
   // textures: LoadSceneTexturesInfo (integrator_pt_scene.cpp:330-355) keeps the nodes with a size, indexed by position; a <texture id=..> is
   // loaded on first use, one table entry per distinct (id, address modes, filter) - the HydraSampler equality of integrator_pt.h:75-83

@@ -452,6 +452,7 @@ class SceneData:
         self.mat_vert_offset = []       # (triOffset, vertOffset) per geom
         self.geom_tri_count, self.geom_vert_count = [], []
         self.inst_geom, self.inst_matrices, self.remap_inst = [], [], []
+        self.lens_lines, self.phys_size = np.zeros((0, 4), np.float32), (0.0, 0.0)   # lens simulation: m_lines {radius, thickness, ior, aperture}, m_physSize
         self.inst_motion = {}                                 # instance id -> matrix at the end of the motion (hydraxml.h:170-176 <motion matrix=..>)
         self.all_remap_lists = np.zeros((1,), np.int32)     # no lists: just the trailing offset 0
         self.all_remap_lists_size = 0
@@ -574,6 +575,17 @@ class SceneData:
         m["datai"][0] = self.arrays1f.size
         self.arrays1f = np.concatenate([self.arrays1f, table]).astype(np.float32)
         return m
+
+    def set_optics(self, lines, sensor_diagonal=0.035, scale=1.0, order="sensor_to_scene"):
+        """LoadOpticsFromNode (integrator_pt_scene.cpp:1078-1141): `lines` = (id, curvature_radius, thickness, ior, semi_diameter) tuples, sorted by id
+        (descending for order == "scene_to_sensor"); m_physSize from the sensor diagonal. The reference reads m_aspect there before anything
+        has set it; height / width of the frame is taken here (the film's aspect in pbrt's RealisticCamera, which this code follows)."""
+        ids = sorted(lines, key=lambda l: l[0], reverse=(order == "scene_to_sensor"))
+        self.lens_lines = np.array([[scale * l[1], scale * l[2], l[3], scale * l[4]] for l in ids], np.float32).reshape(-1, 4)
+        aspect = np.float32(self.height) / np.float32(self.width)
+        d = np.float32(sensor_diagonal)
+        px = np.float32(2.0) * np.sqrt(d * d / (np.float32(1.0) + aspect * aspect), dtype=np.float32)
+        self.phys_size = (float(px), float(aspect * px))
 
     def set_environment(self, color, tex_id=UINT_MAX, mult=1.0, row0=(1, 0, 0, 0), row1=(0, 1, 0, 0), cam_back=UINT_MAX, sample=None):
         """The LIGHT_GEOM_ENV branch of LoadLightSourceFromNode + LoadSceneLights (integrator_pt_scene_lgt.cpp:36-59,
@@ -768,6 +780,13 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
     sc.fov = float(cam.findtext("fov"))
     sc.near, sc.far = float(cam.findtext("nearClipPlane")), float(cam.findtext("farClipPlane"))
     sc.cam_pos, sc.cam_look_at, sc.cam_up = _f(cam.findtext("position")), _f(cam.findtext("look_at")), _f(cam.findtext("up"))
+    optics = cam.find("optical_system")                                       # (the reference's fallback to <optics> never triggers: opticNode != opticNode)
+    if optics is not None:
+        lines = []
+        for k, ln in enumerate(optics.findall("line")):
+            ap = ln.get("semi_diameter") if ln.get("semi_diameter") is not None else ln.get("aperture_radius", "0")
+            lines.append((int(ln.get("id", k)), float(ln.get("curvature_radius", 0)), float(ln.get("thickness", 0)), float(ln.get("ior", 0)), float(ap)))
+        sc.set_optics(lines, float(optics.get("sensor_diagonal", 0.035)), float(optics.get("scale", 1.0)), optics.get("order", ""))
 
     # textures: LoadSceneTexturesInfo (integrator_pt_scene.cpp:330-355) keeps the nodes with a size, indexed by position; a material's
     # <texture id=..> is loaded on first use, one m_textures entry per distinct (id, address modes, filter) - the HydraSampler

@@ -110,6 +110,10 @@ int  hpt_device_info(hpt_ctx* ctx, int* numCUs, int* wavefront, char* name, size
  * diff_render/drmain.cpp:174-261 keeping its texture, gradient and Adam moments resident). No reference counterpart: the reference's
  * generated GPU class owns its buffers (main.cpp:221-224). kind: 1 host->device, 2 device->host, 3 device->device; copies are
  * synchronous, memset is asynchronous on the null stream. */
+/* Integrator::SetLines + SetPhysSize with m_enableOpticSim (integrator_pt.h:353-362; LoadOpticsFromNode integrator_pt_scene.cpp:1078-1141): the
+ * lens stack traced from the film by SampleCameraRay (integrator_pt.cpp:79-103, 806-938). lines4 = n x {curvatureRadius, thickness, eta,
+ * apertureRadius}, film side first (radius 0 = the aperture stop); n = 0 switches the simulation off. Takes effect at the next call. */
+int  hpt_set_optics(hpt_ctx* ctx, const float* lines4, uint32_t n, float physSizeX, float physSizeY);
 /* mi::fresnel_coat_precompute (mi_materials.cpp:377-451), what LoadPlasticMaterial (integrator_pt_scene_mat.cpp:675-757) stores for a
  * MAT_TYPE_PLASTIC: the 64-entry rough-transmittance table (appended to m_arrays1f, its offset in Material::datai[0]) and the two scalars
  * Material::data[PLASTIC_PRECOMP_REFLECTANCE = 3], data[PLASTIC_SPEC_SAMPLE_WEIGHT = 2]. Host code; no context, no device. RGB mode. */

@@ -40,6 +40,7 @@ def lib():
             f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
         L.orc_ray_nearest.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
         L.orc_ray_any.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
+        L.orc_set_optics.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float]
         L.orc_ray_nearest_motion.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_int]
         L.orc_ray_any_motion.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_int]
         L.orc_put_diff_tex2d.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -75,6 +76,8 @@ class OracleIntegrator:
         self.W, self.H = self.params.winWidth, self.params.winHeight
         self.N = self.W * self.H
         self.L.orc_set_threads(threads)
+        lines = np.ascontiguousarray(scene.lens_lines, np.float32).reshape(-1, 4)
+        self.L.orc_set_optics(self.h, lines.ctypes.data if lines.size else None, lines.shape[0], C.c_float(scene.phys_size[0]), C.c_float(scene.phys_size[1]))
         self.L.orc_pack_xy(self.h, None)
         self.L.orc_init_random_gens(self.h, self.N)
 

@@ -100,6 +100,8 @@ void     orc_path_trace_from_input_rays_block(orc_ctx*, uint32_t tid, uint32_t c
 // bruteForce != 0 tests every triangle of every instance (no BVH).
 void     orc_ray_nearest(orc_ctx*, const float* posNear4, const float* dirFar4, uint32_t n, orc_hit* out, int bruteForce);
 void     orc_ray_any(orc_ctx*, const float* posNear4, const float* dirFar4, uint32_t n, uint32_t* out, int bruteForce);
+// SetLines / SetPhysSize with m_enableOpticSim: n x {curvatureRadius, thickness, eta, apertureRadius}, film side first; n = 0 turns it off
+void     orc_set_optics(orc_ctx*, const float* lines4, uint32_t n, float physSizeX, float physSizeY);
 // RayQuery_NearestHitMotion / RayQuery_AnyHitMotion (CrossRT.h:157,174): the same at a time in [0, 1] of the moving instances
 void     orc_ray_nearest_motion(orc_ctx*, const float* posNear4, const float* dirFar4, uint32_t n, float time, orc_hit* out, int bruteForce);
 void     orc_ray_any_motion(orc_ctx*, const float* posNear4, const float* dirFar4, uint32_t n, float time, uint32_t* out, int bruteForce);

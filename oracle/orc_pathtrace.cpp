@@ -393,6 +393,72 @@ struct Ctx
   static inline uint extractMatId(uint f) { return f & 0x00FFFFFFu; }
   static inline uint packMatId(uint f, uint m) { return (f & 0xFF000000u) | (m & 0x00FFFFFFu); }
 
+  // ---- lens simulation (integrator_pt.cpp:806-938, after pbrt's RealisticCamera); m_lines as {curvatureRadius, thickness, eta, apertureRadius} ----
+  std::vector<f4> lensLines; f2 physSize = mk2(0, 0);
+  static bool Quadratic(float A, float B, float C, float* t0, float* t1)
+  {
+    const float discrim = B * B - 4.0f * A * C;
+    if (discrim < 0.f) return false;
+    const float rootDiscrim = std::sqrt(discrim);
+    const float q = (B < 0.0f) ? -.5f * (B - rootDiscrim) : -.5f * (B + rootDiscrim);
+    *t0 = q / A; *t1 = C / q;
+    if (*t0 > *t1) { const float t = *t0; *t0 = *t1; *t1 = t; }
+    return true;
+  }
+  static bool Refract(f3 wi, f3 n, float eta, f3* wt)
+  {
+    const float cosThetaI = dot(n, wi);
+    const float sin2ThetaI = std::max(0.0f, 1.0f - cosThetaI * cosThetaI);
+    const float sin2ThetaT = eta * eta * sin2ThetaI;
+    if (sin2ThetaT >= 1) return false;
+    const float cosThetaT = std::sqrt(1 - sin2ThetaT);
+    *wt = eta * (-1.0f) * wi + (eta * cosThetaI - cosThetaT) * n;
+    return true;
+  }
+  static bool IntersectSphericalElement(float radius, float zCenter, f3 rayPos, f3 rayDir, float* t, f3* n)
+  {
+    const f3 o = rayPos - mk3(0, 0, zCenter);
+    const float A = rayDir.x * rayDir.x + rayDir.y * rayDir.y + rayDir.z * rayDir.z;
+    const float B = 2 * (rayDir.x * o.x + rayDir.y * o.y + rayDir.z * o.z);
+    const float C = o.x * o.x + o.y * o.y + o.z * o.z - radius * radius;
+    float t0, t1;
+    if (!Quadratic(A, B, C, &t0, &t1)) return false;
+    const bool useCloserT = (rayDir.z > 0.0f) != (radius < 0.0f);
+    *t = useCloserT ? std::min(t0, t1) : std::max(t0, t1);
+    if (*t < 0.0f) return false;
+    *n = normalize(o + (*t) * rayDir);
+    *n = (dot(*n, -1.0f * rayDir) < 0.f) ? (-1.0f) * (*n) : *n;       // faceforward
+    return true;
+  }
+  bool TraceLensesFromFilm(f3& inoutRayPos, f3& inoutRayDir) const
+  {
+    float elementZ = 0;
+    f3 p = mk3(inoutRayPos.x, inoutRayPos.y, -inoutRayPos.z), d = mk3(inoutRayDir.x, inoutRayDir.y, -inoutRayDir.z);
+    for (size_t i = 0; i < lensLines.size(); i++) {
+      const f4 e = lensLines[i];
+      elementZ -= e.y;
+      float t; f3 n = mk3(0, 0, 0);
+      const bool isStop = (e.x == 0.0f);
+      if (isStop) {
+        if (d.z >= 0.0f) return false;
+        t = (elementZ - p.z) / d.z;
+      } else if (!IntersectSphericalElement(e.x, elementZ + e.x, p, d, &t, &n)) return false;
+      const f3 pHit = p + t * d;
+      if (pHit.x * pHit.x + pHit.y * pHit.y > e.w * e.w) return false;
+      p = pHit;
+      if (!isStop) {
+        const float etaI = e.z;
+        float etaT = (i == lensLines.size() - 1) ? 1.0f : lensLines[i + 1].z;
+        if (etaT == 0.0f) etaT = 1.0f;
+        f3 wt;
+        if (!Refract(normalize((-1.0f) * d), n, etaI / etaT, &wt)) return false;
+        d = wt;
+      }
+    }
+    inoutRayPos = mk3(p.x, p.y, -p.z); inoutRayDir = mk3(d.x, d.y, -d.z);
+    return true;
+  }
+
   // SampleCameraRay + kernel_InitEyeRay2 (:44-157); the camera part is shared with the DR replay
   void CameraRay(uint tid, f4 pixelOffsets, f4* rayPosAndNear, f4* rayDirAndFar) const
   {
@@ -409,6 +475,13 @@ struct Ctx
       const f2 xy = p.camLensRadius * 2.0f * MapSamplesToDisc(mk2(pixelOffsets.z - 0.5f, pixelOffsets.w - 0.5f));
       rayPos.x += xy.x; rayPos.y += xy.y;
       rayDir = normalize(focusPosition - rayPos);
+    }
+    else if (!lensLines.empty()) {                      // m_enableOpticSim (:79-103)
+      rayPos = mk3(0.25f * physSize.x * (2.0f * xCoordNormalized - 1.0f), 0.25f * physSize.y * (2.0f * yCoordNormalized - 1.0f), 0.0f);
+      const f2 rareSam = (lensLines[0].w * 2.0f) * MapSamplesToDisc(mk2(pixelOffsets.z - 0.5f, pixelOffsets.w - 0.5f));
+      rayDir = normalize(mk3(rareSam.x, rareSam.y, lensLines[0].y) - rayPos);
+      if (!TraceLensesFromFilm(rayPos, rayDir)) { rayPos = mk3(0, -10000000.0f, 0.0f); rayDir = mk3(0, -1, 0); }
+      else { rayDir = (-1.0f) * normalize(rayDir); rayPos = (-1.0f) * rayPos; }
     }
     transform_ray3f(p.worldViewInv, &rayPos, &rayDir);
     *rayPosAndNear = xyzw(rayPos, 0.0f);
@@ -933,6 +1006,13 @@ void orc_ray_any(orc_ctx* h, const float* posNear4, const float* dirFar4, uint32
   #pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads())
   for (long i = 0; i < (long)n; i++)
     out[i] = sc.any_hit(((const f4*)posNear4)[i], ((const f4*)dirFar4)[i], bruteForce != 0) ? 1u : 0u;
+}
+
+void orc_set_optics(orc_ctx* h, const float* lines4, uint32_t n, float physSizeX, float physSizeY)
+{
+  h->c.lensLines.clear();
+  for (uint32_t i = 0; i < n; i++) h->c.lensLines.push_back(mk4(lines4[4 * i], lines4[4 * i + 1], lines4[4 * i + 2], lines4[4 * i + 3]));
+  h->c.physSize = mk2(physSizeX, physSizeY);
 }
 
 void orc_ray_nearest_motion(orc_ctx* h, const float* posNear4, const float* dirFar4, uint32_t n, float time, orc_hit* out, int bruteForce)

@@ -30,6 +30,7 @@ int main(int argc, char** argv)
     blob(f, "materials", sc.materials); blob(f, "lights", sc.lights);
     blob(f, "params", std::vector<hpt_params>(1, p));
     blob(f, "arrays1f", sc.arrays1f);
+    blob(f, "lensLines", sc.lensLines); blob(f, "physSize", std::vector<float>(sc.physSize, sc.physSize + 2));
     blob(f, "instMatricesMotion", sc.instMatricesMotion); blob(f, "instHasMotion", sc.instHasMotion);
     blob(f, "normMatrices2Offs", std::vector<uint32_t>(1, sc.normMatrices2Offs));
     for (size_t i = 0; i < sc.textures.size(); i++) {

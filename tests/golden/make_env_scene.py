@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Writes tests/golden/scenes/env_map: a small Hydra scene lit only by a lat-long HDR environment map (image4f, so LoadSceneLights adds
 it to the lights with a pdf table - integrator_pt_scene.cpp:441-478), with a texture matrix on the map, a camera back plate
-(<back>, integrator_pt_scene_lgt.cpp:51-58) and diffuse / glossy / mirror / glass spheres on a floor. Own data, not the reference's: the
+(<back>, integrator_pt_scene_lgt.cpp:51-58), diffuse / glossy / mirror / glass spheres on a floor, seen through a simulated lens
+(<optical_system>, integrator_pt_scene.cpp:1078-1141). Own data, not the reference's: the
 two loaders (Python, C++) are checked against each other on it and the GPU against the oracle."""
 import os
 import struct
@@ -63,6 +64,13 @@ def main():
         x, z = -2.6 + 1.3 * i, -0.6 * (i % 2)
         inst.append(f'<instance id="{i}" mesh_id="{i}" rmap_id="-1" matrix="0.5 0 0 {x} 0 0.5 0 0.5 0 0 0.5 {z} 0 0 0 1" />')
     inst.append(f'<instance id="{nsph}" mesh_id="{nsph}" rmap_id="-1" matrix="{ident}" />')
+    # a double-Gauss 50 mm f/2 prescription (the widely circulated six-element design; millimetres, front element first) behind scale = 0.001:
+    # exercises LoadOpticsFromNode's scale, semi_diameter, the stop (radius 0) and order="scene_to_sensor" (integrator_pt_scene.cpp:1078-1141)
+    dgauss = [(29.475, 3.76, 1.67, 12.6), (84.83, 0.12, 1.0, 12.6), (19.275, 4.025, 1.67, 11.5), (40.77, 3.275, 1.699, 11.5), (12.75, 5.705, 1.0, 9.0),
+              (0.0, 4.5, 0.0, 8.55), (-14.495, 1.18, 1.603, 8.5), (40.77, 6.065, 1.658, 10.0), (-20.385, 0.19, 1.0, 10.0), (437.065, 3.22, 1.717, 10.0),
+              (-39.73, 36.9, 1.0, 10.0)]
+    LENS = '<optical_system order="scene_to_sensor" scale="0.001" sensor_diagonal="0.035">' + "".join(
+        f'<line id="{i}" curvature_radius="{r}" thickness="{t}" ior="{n}" semi_diameter="{a}" />' for i, (r, t, n, a) in enumerate(dgauss)) + '</optical_system>'
     xml = f'''<?xml version="1.0"?>
 <textures_lib>
   <texture id="0" name="Map#0" loc="data/chunk_00000.image4ub" offset="8" bytesize="4" width="1" height="1" />
@@ -86,7 +94,9 @@ def main():
   </light>
 </lights_lib>
 <cam_lib>
-  <camera id="0" name="cam" type="uvn"><fov>45</fov><nearClipPlane>0.01</nearClipPlane><farClipPlane>100.0</farClipPlane><up>0 1 0</up><position>0 1.6 6.5</position><look_at>0 0.5 0</look_at></camera>
+  <camera id="0" name="cam" type="uvn"><fov>45</fov><nearClipPlane>0.01</nearClipPlane><farClipPlane>100.0</farClipPlane><up>0 1 0</up><position>0 1.6 6.5</position><look_at>0 0.5 0</look_at>
+    {LENS}
+  </camera>
 </cam_lib>
 <render_lib>
   <render_settings type="HydraModern" id="0"><width>96</width><height>64</height><trace_depth>5</trace_depth><maxRaysPerPixel>4</maxRaysPerPixel></render_settings>

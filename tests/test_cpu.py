@@ -440,6 +440,8 @@ def test_cpp_scene_loader_produces_the_same_tables(scene_name, tmp_path):
     assert p_got[224:240] == p_ref[224:240]                                                          # environment map ids
     assert np.allclose(np.frombuffer(p_got[240:], np.float32), np.frombuffer(p_ref[240:], np.float32), rtol=1e-6)         # its sampler rows
     assert named.get("arrays1f", b"") == np.ascontiguousarray(sc.arrays1f, np.float32).tobytes()
+    assert np.allclose(np.frombuffer(named.get("lensLines", b""), np.float32), sc.lens_lines.reshape(-1), rtol=1e-6)
+    assert np.allclose(np.frombuffer(named["physSize"], np.float32), sc.phys_size, rtol=1e-6)
     assert np.frombuffer(named["normMatrices2Offs"], np.uint32)[0] == d.normMatrices2Offs == (ni if sc.inst_motion else 0)
     if sc.inst_motion:
         assert np.array_equal(np.frombuffer(named["instHasMotion"], np.uint32), [1 if i in sc.inst_motion else 0 for i in range(ni)])

@@ -143,7 +143,16 @@ public:
     p.envTexId = m_envTexId; p.envLightId = m_envLightId; p.envCamBackId = m_envCamBackId; p.envEnableSam = m_envEnableSam;
     std::memcpy(p.envSamRow0, m_envSamRow0, 16); std::memcpy(p.envSamRow1, m_envSamRow1, 16);
     report(hpt_update_params(m_ctx, &p), "UpdateMembersPlainData");
+    // m_lines / m_physSize / m_enableOpticSim (integrator_pt.h:206-228, 353-362): the lens simulation of SampleCameraRay
+    report(hpt_set_optics(m_ctx, m_enableOpticSim && !m_lines.empty() ? &m_lines[0].curvatureRadius : nullptr,
+                          m_enableOpticSim ? uint32_t(m_lines.size()) : 0u, m_physSize[0], m_physSize[1]), "UpdateMembersPlainData (optics)");
   }
+  struct LensElementInterface { float curvatureRadius, thickness, eta, apertureRadius; };     // integrator_pt.h:206-212
+  void SetLines(const std::vector<LensElementInterface>& a_lines) { m_lines = a_lines; }      // :356-362
+  void SetPhysSize(float x, float y) { m_physSize[0] = x; m_physSize[1] = y; }               // :354
+  uint32_t m_enableOpticSim = 0;
+  std::vector<LensElementInterface> m_lines;
+  float m_physSize[2] = {0, 0};
   virtual void PackXYBlock(uint32_t tidX, uint32_t tidY, uint32_t /*a_passNum*/)
   { if (m_ctx) { UpdateMembersPlainData(); report(hpt_pack_xy(m_ctx, tidX, tidY), "PackXYBlock"); } }
   virtual void PathTraceBlock(uint32_t tid, uint32_t channels, float* out_color, uint32_t a_passNum)

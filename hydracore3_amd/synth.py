@@ -360,4 +360,11 @@ def random_scene(seed: int, width=48, height=32) -> S.SceneData:
         if int(lt["distType"]) == S.LIGHT_DIST_SPOT and r.uniform() < 0.5:
             mrow = np.eye(4); mrow[:3, 3] = lt["pos"][:3]
             S.set_projective(lt, mrow, float(r.uniform(40, 80)), 0.1, 100.0, tex)
+    # ... and one scene in seven is seen through a lens stack: a symmetric triplet around a stop, randomly scaled (drawn last, see above)
+    if r.uniform() < 0.15:
+        k = float(r.uniform(0.8, 1.2))
+        rad, ap = 60.0 * k, float(r.uniform(9.0, 14.0))
+        lines = [(0, rad, 4.0, 1.6, ap), (1, -rad * 2.5, 2.0, 1.0, ap), (2, 0.0, 2.0, 0.0, float(r.uniform(4.0, 8.0))), (3, rad * 2.5, 4.0, 1.6, ap),
+                 (4, -rad, float(r.uniform(38.0, 46.0)), 1.0, ap)]
+        sc.set_optics(lines, 0.035, 0.001, "scene_to_sensor")
     return sc

@@ -1427,6 +1427,7 @@ extern "C" int hpt_set_option(hpt_ctx* c, const char* name, int value)
   const std::string k(name);
   if (k == "wf_grace") c->wfGrace = (uint)value;                                      // trips after the queue ran dry before a trace wave suspends its rays (0: never)
   else if (k == "node_min") { c->nodeMinOverride = value & 63; c->accelCommitted = false; }   // voted exit of the inner-node loop; takes effect at the next CommitScene
+  else if (k == "dbg_no_normal_lerp") { if (c->S.motion) c->S.motion = value ? 3u : 1u; }   // diagnostic: moving instances without the reference's normal interpolation (bit 1 of DevScene::motion)
   else if (k == "force_full_materials") c->forceFull = value != 0;                     // diagnostic: never pick the lean (gltf + emissive) kernels
   else return c->fail(HPT_ERR_ARG, "hpt_set_option: unknown option " + k);
   return HPT_OK;

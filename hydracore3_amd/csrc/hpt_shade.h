@@ -251,7 +251,7 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
     V3 hitNorm = v3(nm[0] * nrmO.x + nm[1] * nrmO.y + nm[2] * nrmO.z,
                     nm[4] * nrmO.x + nm[5] * nrmO.y + nm[6] * nrmO.z,
                     nm[8] * nrmO.x + nm[9] * nrmO.y + nm[10] * nrmO.z);
-    if (MOTION) {                                                        // integrator_pt.cpp:285-292: m_normMatrices[m_normMatrices2Offs + inst] applied to the
+    if (MOTION && (S.motion & 2u) == 0u) {                               // integrator_pt.cpp:285-292: m_normMatrices[m_normMatrices2Offs + inst] applied to the
       const float* nm2 = S.normMat2 + 12 * instId;                       // already transformed normal, then lerp(hitNorm, hitNorm2, time)
       const V3 n2 = v3(nm2[0] * hitNorm.x + nm2[1] * hitNorm.y + nm2[2] * hitNorm.z,
                        nm2[4] * hitNorm.x + nm2[5] * hitNorm.y + nm2[6] * hitNorm.z,
@@ -268,7 +268,7 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
     const V3 vdir = (-1.0f) * rdir;
     V3 hitTang = v3(0, 0, 0);                                          // only materials with a normal map (or a blend that may hold one) read it
     if (!(DR || LEAN) && (mtype == MAT_TYPE_BLEND || (mtype != MAT_TYPE_LIGHT_SOURCE && m.texid[1] != 0xFFFFFFFFu)))
-      hitTang = hitTangent(S, A, B, C, vertOffset, wA, uvx, uvy, nm, flipNorm, MOTION ? S.normMat2 + 12 * instId : nullptr, time);
+      hitTang = hitTangent(S, A, B, C, vertOffset, wA, uvx, uvy, nm, flipNorm, (MOTION && (S.motion & 2u) == 0u) ? S.normMat2 + 12 * instId : nullptr, time);
 
     // -- kernel_SampleLightSource (integrator_pt.cpp:350-424): the randoms are drawn for every surface hit --
     V3 shade = v3(0, 0, 0), dshade = v3(0, 0, 0);

@@ -518,7 +518,7 @@ struct Ctx
     const f2 hitTexCoord = mk2(data1.w, data2.w);
     f3 hitNorm = mul3x3(sc.normMatrices[hit.instId], xyz(data1));
     f3 hitTang = mul3x3(sc.normMatrices[hit.instId], xyz(data2));
-    if (sc.motion) {                                    // :285-292: the end-of-motion matrix applied to the already transformed vectors, then lerp
+    if (sc.motion && !std::getenv("ORC_DBG_NO_NORMAL_LERP")) {   // :285-292: the end-of-motion matrix applied to the already transformed vectors, then lerp
       const f3 hitNorm2 = mul3x3(sc.normMatrices2[hit.instId], hitNorm), hitTang2 = mul3x3(sc.normMatrices2[hit.instId], hitTang);
       hitNorm = hitNorm + s->time * (hitNorm2 - hitNorm);
       hitTang = hitTang + s->time * (hitTang2 - hitTang);

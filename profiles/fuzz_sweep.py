@@ -11,8 +11,12 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 bad = []
 for seed in range(first, first + count):
     sc = synth.random_scene(seed)
+    if os.environ.get("ONLY_MOTION") and not sc.inst_motion:
+        continue
     for naive in (False, True):
         g, c = HipIntegrator(sc), OracleIntegrator(sc)
+        if os.environ.get("ORC_DBG_NO_NORMAL_LERP") and sc.inst_motion:
+            g.set_option("dbg_no_normal_lerp", 1)       # the same diagnostic switch on the device side
         a, b = g.render(4, naive=naive), c.render(4, naive=naive)
         d = (a[..., :3].astype(np.float64) - b[..., :3]) / 4
         l2 = float(np.sqrt(np.mean(np.sum(d * d, -1))))

@@ -131,7 +131,7 @@ struct hpt_ctx
   uint64_t gradSize = 0;
 
   // GetExecutionTime slots
-  float tPathTrace[4] = {0, 0, 0, 0}, tNaive[4] = {0, 0, 0, 0}, tDR[4] = {0, 0, 0, 0};
+  float tPathTrace[4] = {0, 0, 0, 0}, tNaive[4] = {0, 0, 0, 0}, tDR[4] = {0, 0, 0, 0}, tFromRays[4] = {0, 0, 0, 0};
   float lastKernelMs = 0.0f;
 
   int fail(int code, const std::string& m) { err = m; std::fprintf(stderr, "[hydra_hip] %s\n", m.c_str()); return code; }
@@ -1179,9 +1179,19 @@ extern "C" int hpt_path_trace_from_input_rays_block(hpt_ctx* c, uint32_t tid, ui
   if (tid == 0 || passNum == 0) return HPT_OK;
   DevBuf<float> dp, dd, dout;
   const size_t n = (size_t)tid * channels;
+  const double t0 = now_ms();
   HIPCHK(c, dp.upload(rayPos, (size_t)tid * 4)); HIPCHK(c, dd.upload(rayDir, (size_t)tid * 4)); HIPCHK(c, dout.upload(out, n));
+  const double t1 = now_ms();
   int rc = hpt_path_trace_from_input_rays_block_dev(c, tid, channels, dp.p, dd.p, dout.p, passNum, nullptr);
+  if (rc == HPT_OK) { hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) rc = c->hipFail(e, "hipDeviceSynchronize"); }
+  const double t2 = now_ms();
   if (rc == HPT_OK) { hipError_t e = hipMemcpy(out, dout.p, n * sizeof(float), hipMemcpyDeviceToHost); if (e != hipSuccess) rc = c->hipFail(e, "hipMemcpy"); }
+  const double t3 = now_ms();
+  if (rc == HPT_OK) {                                                      // fromRaysPtTime (integrator_pt_host.cpp:92-103) in GetExecutionTime's four slots
+    float kms = 0.0f; (void)hipEventElapsedTime(&kms, c->ev0, c->ev1);
+    c->lastKernelMs = kms;
+    c->tFromRays[0] = kms; c->tFromRays[1] = float(t1 - t0); c->tFromRays[2] = float(t3 - t2); c->tFromRays[3] = float((t2 - t1) - kms);
+  }
   dp.release(); dd.release(); dout.release();
   return rc;
 }
@@ -1390,6 +1400,7 @@ extern "C" int hpt_get_execution_time(hpt_ctx* c, const char* name, float out[4]
   const float* src = nullptr;
   if (n == "PathTrace" || n == "PathTraceBlock") src = c->tPathTrace;                       // integrator_pt_lgt.cpp:241-251
   else if (n == "NaivePathTrace" || n == "NaivePathTraceBlock") src = c->tNaive;
+  else if (n == "PathTraceFromInputRays" || n == "PathTraceFromInputRaysBlock") src = c->tFromRays;
   else if (n == "PathTraceDR" || n == "PathTraceDRBlock") src = c->tDR;                     // integrator_dr2.cpp:82-88
   if (!src) return HPT_OK;                                                                 // unknown names leave `out` untouched, as the reference does
   for (int i = 0; i < 4; i++) out[i] = src[i];

@@ -1025,3 +1025,24 @@ def test_automatic_schedule_follows_the_sah_estimate():
     small = HipIntegrator(synth.interior_scene(640, 360, subdiv=0, tex_size=64))          # fewer than 2^19 pixels: megakernel even when heavy
     small.render(1)
     assert small.last_schedule()[0] == 1
+
+
+def test_cam_plugin_driver_loop_matches_the_camera_path(tmp_path):
+    """tests/cpp/hydra_hip_camrays.cpp: the loop of cam_plugin/main_with_cam.cpp:96-166 (MakeRaysBlock -> PathTraceFromInputRaysBlock ->
+    AddSamplesContributionBlock in tiles) with a pinhole camera standing in for the plugin. Its frame is another Monte-Carlo estimate of
+    what PathTraceBlock renders: same mean, same picture."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    from hydracore3_amd.api import HipIntegrator
+    tool = os.path.join(ROOT, "hydracore3_amd", "hydra_hip_camrays")
+    out = str(tmp_path / "cam.bin")
+    W, H, spp = 96, 64, 48
+    r = subprocess.run([tool, scene_path("test_035"), str(W), str(H), str(spp), out, "2048"], capture_output=True, text=True)
+    print(r.stdout.strip())
+    assert r.returncode == 0, r.stdout + r.stderr
+    cam = np.fromfile(out, np.float32).reshape(H, W, 4)[..., :3] / spp
+    ref = HipIntegrator(load_hydra_xml(scene_path("test_035"), W, H)).render(spp)[..., :3] / spp
+    assert np.isfinite(cam).all() and abs(cam.mean() - ref.mean()) < 0.03 * ref.mean()
+    blur = lambda a: a.reshape(H // 8, 8, W // 8, 8, 3).mean(axis=(1, 3))
+    assert np.corrcoef(blur(cam).ravel(), blur(ref).ravel())[0, 1] > 0.98

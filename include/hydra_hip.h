@@ -233,7 +233,11 @@ int  hpt_set_schedule(hpt_ctx* ctx, int schedule, int refillBelow, int traceBloc
  *   "wf_grace"  trips a wavefront trace wave keeps going after the ray queue ran dry before it parks its unfinished rays (traversal
  *               state + stack to HBM) for the next round's trace pass, which resumes them first; 0 = run every ray to the end.
  *               Only applied in rounds with at least 2 rays per lane of the trace grid.
- *   "node_min"  voted exit of the inner-node loop (0..63, applied at the next hpt_commit_scene; default chosen per scene). */
+ *   "node_min"  voted exit of the inner-node loop (0..63, applied at the next hpt_commit_scene; default chosen per scene).
+ * Diagnostic switches (these DO change which kernels run or what they compute; never set in production):
+ *   "force_full_materials"  1: never pick the kernels specialised for gltf + emissive scenes (kernel studies)
+ *   "dbg_no_normal_lerp"    1: moving instances without the reference's normal interpolation (integrator_pt.cpp:285-292); the checker has the
+ *                           same switch (ORC_DBG_NO_NORMAL_LERP) - used to show where the rare path divergences under motion blur come from */
 int  hpt_set_option(hpt_ctx* ctx, const char* name, int value);
 /* ---- multi-GPU: one context = one GPU = one rank -----------------------------------------------------
  * The path shards without a data-path exchange; these three calls are the only traffic over xGMI. RCCL is loaded on first use.

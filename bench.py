@@ -1,40 +1,71 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mpaths/s of Integrator::PathTraceBlock on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cornell|interior] [--spp S]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cornell|interior|dr|dr_interior] [--spp S]
 
-A *step* is one PathTraceBlock call over the whole frame (W*H pixels x spp passes, MIS path tracing) with the
-framebuffer, RNG states and scene resident in HBM. N = 1 runs BASELINE.json configs[1] (scenes/test_035 Cornell box,
-1024 x 1024, 1024 spp). For N > 1 (launched through torch.distributed.run, one rank per GPU, scene replicated):
+A *step* is one PathTraceBlock call over the whole frame (W*H pixels x spp passes, MIS path tracing) with the framebuffer,
+RNG states and scene resident in HBM. N = 1 runs BASELINE.json configs[1] (scenes/test_035 Cornell box, 1024 x 1024, 1024 spp)
+and appends ("also") short runs of configs[2] (1M-triangle interior, wavefront schedule) and configs[3] (PathTraceDR + Adam).
 
-  --scaling weak (default)  sample sharding: every rank renders the WHOLE frame at --spp with its own RNG sub-streams
-                            (generators seeded as threads r*W*H.. of one big InitRandomGens call) and ONE RCCL reduce(SUM)
-                            per step adds the N frames on rank 0: N x the samples per pixel in (almost) the same time.
-                            Per-GPU work is fixed, value = paths of all ranks / time.
-  --scaling strong          pixel sharding of ONE frame at --spp: rank r renders every N-th 1024-tid chunk of the swizzled
-                            pixel order into a zeroed full-size framebuffer, one RCCL reduce(SUM) assembles the frame,
-                            bit-identical to the single-GPU frame (--verify). A pixel's passes are sequential (its RNG stream
-                            continues from pass to pass), so this mode runs out of independent paths per GPU on small frames
-                            ("multi-GPU").
+N > 1: one rank per GPU (the scene is replicated, no data-path collective but ONE RCCL reduce(SUM) of the framebuffer per step).
+Started plainly (`python bench.py --gpus N`, WORLD_SIZE unset) the script spawns its N ranks itself through
+`python -m torch.distributed.run` BEFORE touching the GPU; started by torch.distributed.run it reads RANK / WORLD_SIZE.
 
-Prints ONE JSON line on rank 0 (see the contract in the task description); `roofline` prices the persistent
-path-tracing kernel against HBM bandwidth using ALGORITHMIC bytes measured by the library's
-instrumented build on the same scene, `cpu_baseline` times the CPU oracle (a restated port, not the original binary)
-on a bounded sample.
+  --scaling strong (default)  FIXED TOTAL WORK: one frame at --spp.
+        --shard samples (default)  every rank renders ALL pixels with spp / N passes from its own RNG sub-streams (generators seeded as
+                                   threads r*W*H.. of one big InitRandomGens call); the reduce adds the N partial frames. Per-GPU
+                                   parallelism stays at W*H pixels, so the per-GPU rate does not fall with N.
+        --shard pixels             the north-star split: rank r renders every N-th 1024-tid chunk of the swizzled pixel order at the full
+                                   --spp, bit-identical to the single-GPU frame. A pixel's passes are sequential (its RNG stream continues
+                                   from pass to pass), so small frames run out of independent paths per GPU ("multi-GPU").
+        The JSON line's `value` is the samples split; the pixels split is timed as well and reported under "also".
+  --scaling weak              every rank renders the whole frame at the full --spp (N x the samples in the same time): per-GPU work fixed.
+
+Sharded frames are verified on rank 0 after the timed region (at 8 spp; --no-verify skips it).
+
+Prints ONE JSON line on rank 0 (contract in the task description). `roofline` names the ceiling that binds the dominant kernel: the
+Cornell megakernel is VALU-issue bound (profiles/pmc_cornell.json), the wavefront trace kernel of the 1M-triangle scene is priced
+against HBM both by ALGORITHMIC bytes and by the rocprofv3 counters. `cpu_baseline` times the CPU oracle (a restated
+port, not the original binary) in a child process on the box's usable cores.
 """
 import argparse
 import json
+import math
 import os
+import subprocess
 import sys
 import time
-
-import torch   # imported first: the HIP runtime torch bundles must be the one libhydra_hip.so binds to
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+SIMDS = 1024               # 256 CUs x 4 SIMDs
+F_CLK_GHZ = 2.4            # max shader clock; a wave64 VALU instruction occupies its SIMD for 4 cycles
+VALU_PEAK_GINST = SIMDS * F_CLK_GHZ / 4.0     # wave-instructions per ns the chip can issue = 614.4 G/s
+
+
+# ---- host CPU ---------------------------------------------------------------------------------------------------------------------------
+def usable_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota (os.cpu_count() is the whole machine)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(math.ceil(float(q) / float(p)))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown CPU"
 
 
 def build_scene(workload, width, height):
@@ -46,17 +77,269 @@ def build_scene(workload, width, height):
     return interior_scene(width, height, subdiv=subdiv)
 
 
-def run_dr(args, rank, world, dev, stream, dist=None, backend="nccl"):
-    """IntegratorDR fwd+bwd + Adam.  --workload dr: BASELINE.json configs[3] (test_228-class scene, 256 x 256 x 4 albedo, 512^2 @ 256 spp);
-    --workload dr_interior: configs[4] (1M-triangle interior, tex_size^2 x 4 fp32 albedo bound to its 32 gltf materials, 1920x1080).
+def cpu_baseline_child(workload, width, height, target_s):
+    """Runs in a child process (bench.py --cpu-baseline-only): the CPU oracle - a restated port of PathTraceBlock, OpenMP over pixels,
+    schedule(dynamic, 64) - on a bounded sample of the same frame, twice, on the usable cores."""
+    import numpy as np
+    from oracle.orc import OracleIntegrator
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or usable_cores()
+    sc = build_scene(workload, width, height)
+    o = OracleIntegrator(sc, threads=cores)
+    img = np.zeros((height, width, 4), np.float32)
+    t0 = time.time(); o.path_trace_block(img, 1); t1 = time.time() - t0
+    spp = int(max(1, min(64, 0.5 * target_s / max(t1, 1e-3))))
+    runs = []
+    for _ in range(2):
+        t0 = time.time(); o.path_trace_block(img, spp); runs.append(time.time() - t0)
+    rates = [width * height * spp / dt / 1e6 for dt in runs]
+    out = {"value": min(rates), "unit": "Mpaths/s", "cores": cores, "kind": "port",
+           "sample": f"{workload} {width}x{height} @ {spp} spp, twice ({runs[0]:.1f} s, {runs[1]:.1f} s: {rates[0]:.2f} / {rates[1]:.2f} Mpaths/s, "
+                     f"{min(rates) / cores * 1e3:.1f} Kpaths/s per thread); oracle/liboracle.so = restated port of PathTraceBlock, OpenMP "
+                     f"schedule(dynamic,64), OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND', 'unset')}, {cores} threads "
+                     f"(affinity {len(os.sched_getaffinity(0))}, machine {os.cpu_count()}) on {cpu_model()}"}
+    print("CPU_BASELINE " + json.dumps(out), flush=True)
+
+
+def cpu_baseline(workload, width, height, target_s=20.0):
+    cores = usable_cores()
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="spread", OMP_PLACES="cores")
+    for k in list(env):
+        if k == "LD_PRELOAD" or k.startswith("ROCP") or k.startswith("HSA_TOOLS"):
+            env.pop(k)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", workload, "--width", str(width), "--height", str(height),
+                        "--cpu-seconds", str(target_s)], env=env, capture_output=True, text=True)
+    for line in r.stdout.splitlines():
+        if line.startswith("CPU_BASELINE "):
+            return json.loads(line[len("CPU_BASELINE "):])
+    sys.stderr.write("[bench] cpu_baseline child failed:\n" + r.stdout[-2000:] + r.stderr[-2000:])
+    return None
+
+
+# ---- roofline pieces -------------------------------------------------------------------------------------------------------------------
+def algorithmic_bytes(counters, paths, spp):
+    """SURVEY.md 8d: bytes a path has to touch, from the traversal / shading counters of an instrumented launch."""
+    c = counters
+    trav = c["nodes"] * 64 + c["tris"] * 48 + c["instances_entered"] * 64
+    surf = c["surface_hits"] * (3 * 4 + 3 * 32 + 4 + 8 + 64 + 320 + 4 * 4)
+    nee = c["surface_hits"] * 320
+    per_pixel = (8 + 8 + 4 + 16) * (paths / spp)
+    total = trav + surf + nee + per_pixel
+    return {"total": total / paths, "traversal": trav / paths, "nodes_per_ray": c["nodes"] / max(c["rays"], 1),
+            "tris_per_ray": c["tris"] / max(c["rays"], 1), "rays_per_path": c["rays"] / paths}
+
+
+def load_profile(name):
+    f = os.path.join(ROOT, "profiles", name)
+    try:
+        return json.load(open(f))
+    except Exception:
+        return None
+
+
+def make_roofline(workload, integ, torch, dev, stream, N, W, H, spp, t_count, kernel_ms):
+    """Counts rays / nodes / triangles with the instrumented megakernel on the same frame (fewer passes: the statistics are stationary) and
+    prices the timed launch. Returns the `roofline` object."""
+    import numpy as np
+    sched_used, wf_rounds = integ.last_schedule()
+    probe_spp = min(spp, 8)
+    integ.set_schedule(1)                                     # the instrumented build is the megakernel: same rays, same node / triangle visits
+    integ.set_instrumentation(True)
+    integ.InitRandomGens(N)
+    integ.set_tid_interleave(0, 1)
+    probe = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    integ.path_trace_block_dev(probe.data_ptr(), probe_spp, 0, N, 4, False, stream)
+    torch.cuda.synchronize()
+    cnt = integ.counters()
+    integ.set_instrumentation(False)
+    ab = algorithmic_bytes(cnt, float(N) * probe_spp, probe_spp)
+    k_ms = float(np.mean(kernel_ms))
+    paths = float(t_count) * spp
+    hbm_alg = ab["total"] * paths / (k_ms * 1e-3) / 1e9
+    extra = {"kernel": "pathTraceKernel" if sched_used == 1 else f"wavefront: {wf_rounds} x (wfShadeKernel + wfTraceKernel)",
+             "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_path": round(ab["total"], 1), "traversal_bytes_per_path": round(ab["traversal"], 1),
+             "nodes_per_ray": round(ab["nodes_per_ray"], 2), "tris_per_ray": round(ab["tris_per_ray"], 2), "rays_per_path": round(ab["rays_per_path"], 2)}
+    tj = load_profile(f"traffic_{workload}.json")
+    traffic, traffic_src = None, None
+    if tj:
+        traffic = tj["hbm_bytes_per_launch"] * paths / float(tj["paths_per_launch"])     # counter bytes per path x this launch's paths
+        traffic_src = f"{tj.get('from')}, collected at commit {tj.get('commit', 'unrecorded (round 1)')}: per-path counter bytes rescaled to this launch, not measured in this run"
+    pmc = load_profile(f"pmc_{workload}.json")
+    if sched_used == 1 and pmc and pmc.get("valu_insts_per_path"):
+        # VALU-issue roofline: wave-instructions the kernel issues (profiled count per path, a property of binary + scene) over the
+        # LIVE kernel time, against 1024 SIMDs x f_clk / 4 cycles per wave64 instruction
+        ginst = pmc["valu_insts_per_path"] * paths / (k_ms * 1e-3) / 1e9
+        return dict({"bound": "valu", "achieved": round(ginst, 2), "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwaveinst/s",
+                     "frac": round(ginst / VALU_PEAK_GINST, 4), "traffic": traffic, "traffic_source": traffic_src,
+                     "lane_utilisation": pmc.get("lane_utilisation"), "useful_lane_frac": round(ginst / VALU_PEAK_GINST * pmc.get("lane_utilisation", 0.0), 4),
+                     "pmc_source": f"profiles/pmc_{workload}.json, collected at commit {pmc.get('commit')}: SQ_INSTS_VALU per path and SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU); the kernel time is measured in this run",
+                     "hbm_algorithmic": {"achieved": round(hbm_alg, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_alg / HBM_PEAK_GBS, 4),
+                                         "note": "SURVEY 8d algorithmic bytes; served by L1/L2 on this scene, NOT an HBM claim"},
+                     "hbm_counter_frac": round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if traffic else None}, **extra)
+    r = dict({"bound": "hbm", "achieved": round(hbm_alg, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_alg / HBM_PEAK_GBS, 4),
+              "traffic": traffic, "traffic_source": traffic_src,
+              "traversal_only_frac": round(ab["traversal"] * paths / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+              "hbm_counter_frac": round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+              "note": "achieved / frac = ALGORITHMIC bytes (SURVEY 8d) over the live launch time: the top of the BVH is served by L2 / Infinity Cache, "
+                      "so the counter fraction (FETCH_SIZE doubled per the gfx950 rule + WRITE_SIZE) is the HBM-side figure"}, **extra)
+    if pmc:
+        r["lane_utilisation"] = pmc.get("lane_utilisation"); r["pmc_source"] = f"profiles/pmc_{workload}.json, commit {pmc.get('commit')}"
+    return r
+
+
+# ---- forward workloads ------------------------------------------------------------------------------------------------------------------
+def run_forward(args, workload, rank, world, dev, dist, backend, steps, warmup, spp, shard, with_roofline=True):
+    """Times `steps` PathTraceBlock calls; returns the result dict (rank 0) or None."""
+    import numpy as np
+    import torch
+    from hydracore3_amd.api import HipIntegrator
+    from hydracore3_amd.sharding import tid_interleave
+    W, H = (args.width or (1024 if workload == "cornell" else 1920)), (args.height or (1024 if workload == "cornell" else 1080))
+    sc = build_scene(workload, W, H)
+    integ = HipIntegrator(sc, device=dev.index, accel_layout=args.accel_layout)
+    if args.blocks_per_cu:
+        integ.set_launch_config(args.blocks_per_cu)
+    if args.schedule or args.refill_below or args.trace_blocks_per_cu or args.groups:
+        integ.set_schedule(args.schedule, args.refill_below, args.trace_blocks_per_cu, args.groups)
+    if os.environ.get("HYDRA_BENCH_FORCE_FULL") == "1":          # kernel study: run the kernels with every BSDF branch on a gltf-only scene
+        integ.set_option("force_full_materials", 1)
+    N = W * H
+    weak = args.scaling == "weak"
+    share = world * args.emulate_share
+    my_spp = spp
+    if weak or shard == "samples":
+        # sample sharding: rank r renders ALL pixels, its generators seeded as threads r*N .. (r+1)*N-1 of one big InitRandomGens call
+        t_begin, t_count = 0, N
+        if share > 1:
+            integ.InitRandomGens(N, first_seed=rank * N)
+        if not weak:
+            my_spp = spp // share + (1 if rank < spp % share else 0)      # fixed total work: the frame's spp passes are dealt out over the ranks
+    else:
+        t_begin, t_count, chunk, stride = tid_interleave(rank, share, N)   # rank r renders every world-th 1024-tid chunk
+        integ.set_tid_interleave(chunk, stride)
+
+    frame = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def reduce_frame(f):
+        if dist is None:
+            return
+        if backend == "nccl":
+            dist.reduce(f, dst=0, op=dist.ReduceOp.SUM)       # final RCCL reduce of the framebuffer over xGMI
+        else:
+            host = f.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                f.copy_(host)
+
+    def step():
+        frame.zero_()
+        if my_spp > 0:
+            integ.path_trace_block_dev(frame.data_ptr(), my_spp, t_begin, t_count, 4, False, stream)
+        reduce_frame(frame)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    sync()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+        if world == 1:
+            kernel_ms.append(integ.last_kernel_ms())               # HIP events on the launch stream (syncs on the 2nd event)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        kernel_ms = [integ.last_kernel_ms()]
+    paths_per_step = float(N) * spp * (world if weak else 1) * (args.emulate_share if (not weak and args.emulate_share > 1) else 1) / (args.emulate_share if not weak else 1)
+    paths_per_step = float(N) * spp * (world if weak else 1)      # (with --emulate-share K: the K ranks together would have finished the frame in this time)
+    value = paths_per_step * steps / elapsed / 1e6
+    mean_lum = float(frame[..., :3].mean().item()) / (spp * (world if weak else 1)) if rank == 0 else 0.0
+
+    # ---- verification of the sharded frame (rank 0 re-renders the ranks' shares alone, at a few passes) ----
+    verified = None
+    if world > 1 and not args.no_verify and args.emulate_share == 1:
+        vspp = min(8 * world, spp)
+        vint = HipIntegrator(sc, device=dev.index, accel_layout=args.accel_layout)
+        vf = torch.zeros_like(frame)
+        mine = vspp
+        if weak or shard == "samples":
+            vint.InitRandomGens(N, first_seed=rank * N)
+            if not weak:
+                mine = vspp // world + (1 if rank < vspp % world else 0)
+            if mine:
+                vint.path_trace_block_dev(vf.data_ptr(), mine, 0, N, 4, False, stream)
+        else:
+            vint.set_tid_interleave(chunk, stride)
+            vint.path_trace_block_dev(vf.data_ptr(), vspp, t_begin, t_count, 4, False, stream)
+        reduce_frame(vf)
+        torch.cuda.synchronize()
+        if rank == 0:
+            ref = torch.zeros_like(frame)
+            if weak or shard == "samples":
+                part = torch.zeros_like(frame)
+                for r in range(world):
+                    solo = HipIntegrator(sc, device=dev.index, accel_layout=args.accel_layout)
+                    solo.InitRandomGens(N, first_seed=r * N)
+                    n_r = vspp if weak else vspp // world + (1 if r < vspp % world else 0)
+                    part.zero_()
+                    if n_r:
+                        solo.path_trace_block_dev(part.data_ptr(), n_r, 0, N, 4, False, stream)
+                    torch.cuda.synchronize()
+                    ref += part
+                verified = bool(torch.allclose(ref, vf, rtol=1e-5, atol=1e-5))      # equal up to the reduce's summation order
+            else:
+                solo = HipIntegrator(sc, device=dev.index, accel_layout=args.accel_layout)
+                solo.path_trace_block_dev(ref.data_ptr(), vspp, 0, N, 4, False, stream)
+                torch.cuda.synchronize()
+                verified = bool(torch.equal(ref, vf))                                 # disjoint pixels: bit-identical to the single-GPU frame
+            if not verified:
+                raise SystemExit(f"sharded frame ({shard}) differs from the single-GPU rendering of the same shares")
+    roofline = None
+    if rank == 0 and with_roofline:
+        roofline = make_roofline(workload, integ, torch, dev, stream, N, W, H, my_spp if not weak else spp, t_count, kernel_ms)
+    if rank != 0:
+        return None
+    if world == 1:
+        sharding = "single GPU"
+    elif weak:
+        sharding = f"weak: {world} ranks x whole frame x {spp} spp each (decorrelated RNG sub-streams) + RCCL reduce(SUM)"
+    elif shard == "samples":
+        sharding = f"fixed work, sample sharding: {world} ranks x all pixels x {spp}/{world} spp (RNG sub-streams) + RCCL reduce(SUM)"
+    else:
+        sharding = f"fixed work, pixel sharding: {world} ranks x interleaved 1024-tid chunks of one frame at {spp} spp + RCCL reduce(SUM)"
+    name = (f"scenes/test_035 Cornell box {W}x{H} @ {spp} spp, forward PathTraceBlock" if workload == "cornell"
+            else f"synthetic 1M-triangle interior {W}x{H} @ {spp} spp, forward PathTraceBlock")
+    return {"metric": "Mpaths/s (fwd PathTraceBlock, MIS path tracing)", "value": round(value, 2), "unit": "Mpaths/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": name, "paths_per_step": int(paths_per_step), "trace_depth": sc.trace_depth, "integrator": "mispt", "sharding": sharding,
+                       "mean_radiance": round(mean_lum, 5), "sharded_frame_verified": verified},
+            "roofline": roofline}
+
+
+# ---- differentiable rendering -----------------------------------------------------------------------------------------------------------
+def run_dr(args, workload, rank, world, dev, dist, backend, steps, warmup, spp_arg):
+    """IntegratorDR fwd+bwd + Adam.  dr: BASELINE.json configs[3] (test_228-class scene, 256 x 256 x 4 albedo, 512^2 @ 256 spp);
+    dr_interior: configs[4] (1M-triangle interior, tex_size^2 x 4 fp32 albedo bound to its 32 gltf materials, 1920x1080).
     One step = memset(grad) + PathTraceDR (record, replay and adjoint fused, gradient atomics into HBM) [+ all_reduce(SUM) of the
     gradient and the loss over the ranks] + AdamOptimizer::step (every rank applies the identical step to its replica of a_data)."""
+    import numpy as np
+    import torch
     from hydracore3_amd.api import HipIntegrator
     from hydracore3_amd.synth import dr_scene, interior_scene
-    big = args.workload == "dr_interior"
+    stream = torch.cuda.current_stream().cuda_stream
+    big = workload == "dr_interior"
     if big:
         W, H = args.width or 1920, args.height or 1080
-        spp = args.spp if args.spp != 1024 else 16
+        spp = spp_arg if spp_arg != 1024 else 16
         ts = int(os.environ.get("HYDRA_BENCH_TEX", "4096"))
         sc = interior_scene(W, H, tex_size=ts)                      # the generated texture is the checker the optimisation should recover
         tex_id, tw = 1, ts                                          # (texture 0 is the white dummy)
@@ -64,12 +347,13 @@ def run_dr(args, rank, world, dev, stream, dist=None, backend="nccl"):
     else:
         xml = os.path.join(ROOT, "tests", "golden", "scenes", "test_228", "statex_00001.xml")
         W, H = args.width or 512, args.height or 512
-        spp = args.spp if args.spp != 1024 else 256
+        spp = spp_arg if spp_arg != 1024 else 256
         sc, tex_id = dr_scene(xml, W, H)
         tw = 256
         tgt, _ = dr_scene(xml, W, H, target=True)
     N = W * H
     weak = args.scaling == "weak"
+    samples = weak or args.shard == "samples"
     # reference image: the same scene with the target (checker) albedo, a few passes on the GPU (identical on every rank)
     tgt_int = HipIntegrator(tgt, device=dev.index)
     ref = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
@@ -78,11 +362,15 @@ def run_dr(args, rank, world, dev, stream, dist=None, backend="nccl"):
     ref = torch.flip(ref / 64.0, dims=[0]).contiguous()            # PixelLossPT reads the reference y-flipped (integrator_dr.cpp:1119)
     del tgt_int
     integ = HipIntegrator(sc, device=dev.index)
+    integ.set_option("dr_skip_nonfinite", 1)                       # an optimisation loop: one NaN sample must not poison Adam's moments
     off, size = integ.PutDiffTex2D(tex_id, tw, tw, 4)
-    if weak:
+    my_spp = spp
+    if samples:
         t_begin, t_count = 0, N
         if world > 1:
             integ.InitRandomGens(N, first_seed=rank * N)
+        if not weak:
+            my_spp = spp // world + (1 if rank < spp % world else 0)
     else:
         from hydracore3_amd.sharding import tid_interleave
         t_begin, t_count, chunk, stride = tid_interleave(rank, world, N)
@@ -96,7 +384,10 @@ def run_dr(args, rank, world, dev, stream, dist=None, backend="nccl"):
 
     def step(it):
         grad.zero_(); loss.zero_(); frame.zero_()
-        integ._chk(L.hpt_path_trace_dr_dev(integ.h, t_begin, t_count, 4, frame.data_ptr(), spp, ref.data_ptr(), data.data_ptr(), grad.data_ptr(), size, loss.data_ptr(), stream))
+        if my_spp:
+            integ._chk(L.hpt_path_trace_dr_dev(integ.h, t_begin, t_count, 4, frame.data_ptr(), my_spp, ref.data_ptr(), data.data_ptr(), grad.data_ptr(), size, loss.data_ptr(), stream))
+            if samples and not weak and world > 1:
+                loss.mul_(float(my_spp) / float(spp))              # PathTraceDR's loss is the sample mean over ITS passes: weight by the share
         if dist is not None:                                       # a_dataGrad: ncclAllReduce(sum), once per optimisation iteration
             if backend == "nccl":
                 dist.all_reduce(grad, op=dist.ReduceOp.SUM); dist.all_reduce(loss, op=dist.ReduceOp.SUM)
@@ -113,13 +404,13 @@ def run_dr(args, rank, world, dev, stream, dist=None, backend="nccl"):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     sync()
     kms = []
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    for i in range(steps):
+        step(warmup + i)
         if world == 1:
             kms.append(integ.last_kernel_ms())
         losses.append(float(loss.item()) / N)
@@ -130,52 +421,32 @@ def run_dr(args, rank, world, dev, stream, dist=None, backend="nccl"):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         kms = [integ.last_kernel_ms()]
-    value = float(N) * spp * args.steps * (world if weak else 1) / elapsed / 1e6
+    paths_per_step = N * spp * (world if weak else 1)
+    value = float(paths_per_step) * steps / elapsed / 1e6
     if rank != 0:
-        return
+        return None
     what = (f"synthetic 1M-triangle interior + {tw}x{tw}x4 differentiable albedo, {W}x{H} @ {spp} spp" if big
             else f"scenes/test_228 + 256x256x4 differentiable albedo, {W}x{H} @ {spp} spp")
-    out = {"metric": "Mpaths/s (fwd+bwd grad, IntegratorDR::PathTraceDR + Adam)", "value": round(value, 2), "unit": "Mpaths/s", "n_gpus": world,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-           "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": what + ", PathTraceDR fwd+bwd + Adam",
-                      "paths_per_step": N * spp * (world if weak else 1), "trace_depth": sc.trace_depth, "grad_floats": int(size),
-                      "sharding": "single GPU" if world == 1 else (("sample" if weak else "pixel") + f" sharding over {world} ranks + all_reduce(SUM) of a_dataGrad and the loss"),
-                      "loss_per_step": [round(v, 6) for v in losses]},
-           "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                        "kernel": "pathTraceKernel<DR>", "kernel_ms": round(float(np.mean(kms)), 3)},
-           "cpu_baseline": None}
-    print(json.dumps(out), flush=True)
+    k_ms = float(np.mean(kms))
+    # gradient scatter priced as the guide prices float atomics: one dword per lane per atomic instruction against ~1.3 TB/s chip-wide
+    return {"metric": "Mpaths/s (fwd+bwd grad, IntegratorDR::PathTraceDR + Adam)", "value": round(value, 2), "unit": "Mpaths/s", "n_gpus": world,
+            "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": what + ", PathTraceDR fwd+bwd + Adam", "paths_per_step": int(paths_per_step), "trace_depth": sc.trace_depth, "grad_floats": int(size),
+                       "sharding": "single GPU" if world == 1 else (("sample" if samples else "pixel") + f" sharding over {world} ranks ({args.scaling}) + all_reduce(SUM) of a_dataGrad and the loss"),
+                       "loss_per_step": [round(v, 6) for v in losses]},
+            "roofline": {"bound": "valu", "achieved": None, "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwaveinst/s", "frac": None, "traffic": None,
+                         "kernel": "pathTraceKernel<DR>" if integ.last_schedule()[0] == 1 else "wavefront DR", "kernel_ms": round(k_ms, 3),
+                         "note": "no PMC profile of the DR kernels is committed: unpriced"}}
 
 
-def algorithmic_bytes(counters, paths, spp):
-    """SURVEY.md 8d: bytes a path has to touch, from the traversal / shading counters of an instrumented launch."""
-    c = counters
-    trav = c["nodes"] * 64 + c["tris"] * 48 + c["instances_entered"] * 64
-    surf = c["surface_hits"] * (3 * 4 + 3 * 32 + 4 + 8 + 64 + 320 + 4 * 4)
-    nee = c["surface_hits"] * 320
-    per_pixel = (8 + 8 + 4 + 16) * (paths / spp)
-    total = trav + surf + nee + per_pixel
-    return {"total": total / paths, "traversal": trav / paths, "nodes_per_ray": c["nodes"] / max(c["rays"], 1),
-            "tris_per_ray": c["tris"] / max(c["rays"], 1), "rays_per_path": c["rays"] / paths}
-
-
-def cpu_baseline(workload, width, height, target_s=12.0):
-    """Time the CPU oracle (restated port of PathTraceBlock, OpenMP over pixels) on a bounded sample of the same frame."""
-    from oracle.orc import OracleIntegrator
-    sc = build_scene(workload, width, height)
-    cores = os.cpu_count() or 1
-    o = OracleIntegrator(sc, threads=cores)
-    img = np.zeros((height, width, 4), np.float32)
-    t0 = time.time()
-    o.path_trace_block(img, 1)
-    t1 = time.time() - t0
-    spp = int(max(1, min(64, target_s / max(t1, 1e-3))))
-    t0 = time.time()
-    o.path_trace_block(img, spp)
-    dt = time.time() - t0
-    return {"value": width * height * spp / dt / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
-            "sample": f"{workload} {width}x{height} @ {spp} spp (oracle/liboracle.so, OpenMP, {cores} threads, {dt:.1f} s)"}
+def compact(r):
+    """An `also` entry: the numbers of a secondary workload without the contract's boilerplate."""
+    if r is None:
+        return None
+    return {"workload": r["config"]["workload"], "metric": r["metric"], "value": r["value"], "unit": r["unit"], "steps": r["steps"],
+            "ms_per_step": r["ms_per_step"], "paths_per_step": r["config"]["paths_per_step"], "sharding": r["config"]["sharding"],
+            "sharded_frame_verified": r["config"].get("sharded_frame_verified"), "roofline": r.get("roofline")}
 
 
 def main():
@@ -188,27 +459,60 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="N = 1: skip the secondary workloads (configs[2], configs[3]) appended under \"also\"")
+    ap.add_argument("--no-build", action="store_true", help="never compile (profiler runs: build first, `python __graft_entry__.py`); fail if the library is missing")
+    ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the check of the sharded frame against single-GPU renderings of the same shares")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--schedule", type=int, default=0, help="0 automatic, 1 persistent megakernel, 2 wavefront (shade + trace kernels)")
     ap.add_argument("--refill-below", type=int, default=0, help="wavefront: refill a trace wave when fewer lanes than this hold a ray")
     ap.add_argument("--trace-blocks-per-cu", type=int, default=0)
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = sample sharding (every rank renders the whole frame at --spp with its own RNG sub-streams, the frames are "
-                         "summed by one RCCL reduce: N x the samples in the same time); strong = pixel sharding of ONE frame at --spp "
-                         "(interleaved 1024-tid chunks, bit-identical to the single-GPU frame)")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N > 1: strong = fixed total work (one frame at --spp, split by --shard); weak = every rank renders the whole frame at --spp")
+    ap.add_argument("--shard", default="samples", choices=["samples", "pixels"],
+                    help="how --scaling strong splits the frame: samples = all pixels x spp/N passes per rank (RNG sub-streams); pixels = interleaved "
+                         "1024-tid chunks at the full spp (the north-star split, bit-identical to the single-GPU frame)")
     ap.add_argument("--emulate-share", type=int, default=1, help="study only: render rank 0's share of a K-rank job on one GPU (value = K x its rate: the K-GPU rate without the reduce)")
     ap.add_argument("--accel-layout", type=int, default=0, help="0 automatic, 1 two-level TLAS/BLAS, 2 single-level world-space BVH")
     ap.add_argument("--groups", type=int, default=0, help="wavefront: concurrent pixel groups (streams) per call, 0 = automatic")
-    ap.add_argument("--verify", action="store_true", help="rank 0 re-renders the whole frame alone and checks the sharded frame is bit-identical")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.cpu_baseline_only:                                    # child process of cpu_baseline(): never touches the GPU
+        W, H = (args.width or 1024), (args.height or 1024)
+        cpu_baseline_child(args.workload if args.workload in ("cornell", "interior") else "cornell", W, H, args.cpu_seconds)
+        return
+
+    no_build = args.no_build or os.environ.get("HYDRA_BENCH_NO_BUILD") == "1"
+    # ---- plain `python bench.py --gpus N`: spawn the N ranks BEFORE anything touches the GPU (never re-exec a GPU-initialised process) ----
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if not no_build:
+            import __graft_entry__ as g
+            g.build()
+        port = 29500 + (os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + ["--no-build"]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+    args.gpus = world
+
+    # ---- build and CPU baseline: before the GPU is initialised in this process --------------------------------------------------------
+    import __graft_entry__ as g
+    if rank == 0 and not no_build:
+        g.build()
+    if no_build and not os.path.exists(g.LIB):
+        raise SystemExit(f"{g.LIB} is missing and --no-build was given: run `python __graft_entry__.py` first")
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("cornell", "interior"):
+        W0 = args.width or (1024 if args.workload == "cornell" else 1920)
+        H0 = args.height or (1024 if args.workload == "cornell" else 1080)
+        cpu = cpu_baseline(args.workload, W0, H0)
+
+    import torch   # imported before the library is loaded: the HIP runtime torch bundles must be the one libhydra_hip.so binds to
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     # HYDRA_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices, the reduce is staged
@@ -225,163 +529,34 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
-
-    import __graft_entry__ as g
-    if rank == 0:
-        g.build()
-    if dist is not None:
         dist.barrier()
-    from hydracore3_amd.api import HipIntegrator
+
     if args.workload in ("dr", "dr_interior"):
-        run_dr(args, rank, world, dev, torch.cuda.current_stream().cuda_stream, dist, backend)
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-
-    W, H = (args.width or (1024 if args.workload == "cornell" else 1920)), (args.height or (1024 if args.workload == "cornell" else 1080))
-    spp = args.spp
-    sc = build_scene(args.workload, W, H)
-    integ = HipIntegrator(sc, device=dev_index, accel_layout=args.accel_layout)
-    if args.blocks_per_cu:
-        integ.set_launch_config(args.blocks_per_cu)
-    if args.schedule or args.refill_below or args.trace_blocks_per_cu or args.groups:
-        integ.set_schedule(args.schedule, args.refill_below, args.trace_blocks_per_cu, args.groups)
-    if os.environ.get("HYDRA_BENCH_FORCE_FULL") == "1":          # kernel study: run the kernels with every BSDF branch on a gltf-only scene
-        integ.set_option("force_full_materials", 1)
-    N = W * H
-    from hydracore3_amd.sharding import tid_interleave
-    weak = args.scaling == "weak"
-    if weak:
-        # sample sharding: rank r renders ALL pixels, its generators seeded as threads r*N .. (r+1)*N-1 of one big InitRandomGens call
-        t_begin, t_count = 0, N
-        if world > 1:
-            integ.InitRandomGens(N, first_seed=rank * N)
+        out = run_dr(args, args.workload, rank, world, dev, dist, backend, args.steps, args.warmup, args.spp)
+        if out is not None:
+            out["cpu_baseline"] = None
     else:
-        t_begin, t_count, chunk, stride = tid_interleave(rank, world * args.emulate_share, N)   # rank r renders every world-th 1024-tid chunk
-        integ.set_tid_interleave(chunk, stride)
-
-    frame = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        frame.zero_()
-        integ.path_trace_block_dev(frame.data_ptr(), spp, t_begin, t_count, 4, False, stream)
-        if dist is not None:
-            if backend == "nccl":
-                dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)   # final RCCL reduce of the framebuffer over xGMI
-            else:
-                host = frame.cpu()
-                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-                if rank == 0:
-                    frame.copy_(host)
-
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    sync()
-    kernel_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        if world == 1:
-            kernel_ms.append(integ.last_kernel_ms())               # HIP events on the launch stream (syncs on the 2nd event)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        kernel_ms = [integ.last_kernel_ms()]
-    total_paths = float(N) * spp * args.steps * (world if weak else 1)     # (with --emulate-share K: the K ranks together would have finished the frame in this time)
-    value = total_paths / elapsed / 1e6
-
-    mean_lum = float(frame[..., :3].mean().item()) / (spp * (world if weak else 1)) if rank == 0 else 0.0
-
-    verified = None
-    if args.verify and rank == 0:
-        integ.set_tid_interleave(0, 1)
-        ref = torch.zeros_like(frame)
-        if weak:
-            # re-render every rank's contribution alone (same seeds, same number of calls) and sum: equal up to the reduce's summation order
-            total = torch.zeros_like(frame)
-            for r in range(world):
-                solo = HipIntegrator(sc, device=dev_index, accel_layout=args.accel_layout)
-                solo.InitRandomGens(N, first_seed=r * N)
-                for _ in range(args.warmup + args.steps):
-                    ref.zero_()
-                    solo.path_trace_block_dev(ref.data_ptr(), spp, 0, N, 4, False, stream)
-                torch.cuda.synchronize()
-                total += ref
-            verified = bool(torch.allclose(total, frame, rtol=1e-5, atol=1e-5))
-        else:
-            solo = HipIntegrator(sc, device=dev_index, accel_layout=args.accel_layout)
-            for _ in range(args.warmup + args.steps):                 # the RNG streams continue from step to step
-                ref.zero_()
-                solo.path_trace_block_dev(ref.data_ptr(), spp, 0, N, 4, False, stream)
-            torch.cuda.synchronize()
-            verified = bool(torch.equal(ref, frame))
-        if not verified:
-            raise SystemExit("sharded frame differs from the single-GPU frame")
-
-    roofline, cpu = None, None
-    if rank == 0:
-        # algorithmic bytes per path from the instrumented kernel on the same frame (fewer passes: the statistics are stationary)
-        sched_used, wf_rounds = integ.last_schedule()
-        probe_spp = min(spp, 8)
-        integ.set_schedule(1)                                     # the instrumented build is the megakernel: same rays, same node / triangle visits
-        integ.set_instrumentation(True)
-        integ.InitRandomGens(N)
-        integ.set_tid_interleave(0, 1)
-        probe = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
-        integ.path_trace_block_dev(probe.data_ptr(), probe_spp, 0, N, 4, False, stream)
-        torch.cuda.synchronize()
-        cnt = integ.counters()
-        integ.set_instrumentation(False)
-        ab = algorithmic_bytes(cnt, float(N) * probe_spp, probe_spp)
-        k_ms = float(np.mean(kernel_ms))
-        paths_per_launch = float(t_count) * spp
-        achieved = ab["total"] * paths_per_launch / (k_ms * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
-        if os.path.exists(tfile):
-            try:
-                tj = json.load(open(tfile))
-                traffic = tj["hbm_bytes_per_launch"] * paths_per_launch / float(tj["paths_per_launch"])   # scaled to this launch's path count
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "kernel": "pathTraceKernel" if sched_used == 1 else f"wavefront: {wf_rounds} x (wfShadeKernel + wfTraceKernel)",
-                    "kernel_ms": round(k_ms, 3),
-                    "algorithmic_bytes_per_path": round(ab["total"], 1), "traversal_bytes_per_path": round(ab["traversal"], 1),
-                    "nodes_per_ray": round(ab["nodes_per_ray"], 2), "tris_per_ray": round(ab["tris_per_ray"], 2),
-                    "rays_per_path": round(ab["rays_per_path"], 2)}
-        if args.workload == "cornell":
-            roofline["note"] = ("36-triangle scene: the algorithmic bytes are served by L1/L2 (HBM traffic per launch is almost four orders below), so frac > 1 is "
-                                "not an HBM claim; the kernel is VALU-bound: 97 % busy at 37 % lane utilisation (profiles/r1_measurements.md, pmc_mega.sh)")
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.workload, W, H)
+        out = run_forward(args, args.workload, rank, world, dev, dist, backend, args.steps, args.warmup, args.spp, args.shard)
+        if out is not None:
+            out["cpu_baseline"] = cpu
+        also = []
+        if world > 1 and args.scaling == "strong" and args.shard == "samples" and not args.no_also:
+            # the north-star split of the same fixed work, timed beside it
+            r = run_forward(args, args.workload, rank, world, dev, dist, backend, args.steps, args.warmup, args.spp, "pixels", with_roofline=False)
+            also.append(compact(r))
+        if world == 1 and args.workload == "cornell" and not args.no_also and not (args.width or args.height):
+            # configs[2] and configs[3], short: the numbers DESIGN.md quotes, timed by whoever runs this line
+            r = run_forward(args, "interior", rank, world, dev, dist, backend, 2, 1, 64, args.shard)
+            also.append(compact(r))
+            r = run_dr(args, "dr", rank, world, dev, dist, backend, 3, 1, 1024)
+            also.append(compact(r))
+        if out is not None and also:
+            out["also"] = [a for a in also if a is not None]
 
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-
-    if rank == 0:
-        out = {"metric": "Mpaths/s (fwd PathTraceBlock, MIS path tracing)", "value": round(value, 2), "unit": "Mpaths/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"scenes/test_035 Cornell box {W}x{H} @ {spp} spp, forward PathTraceBlock" if args.workload == "cornell"
-                          else f"synthetic 1M-triangle interior {W}x{H} @ {spp} spp, forward PathTraceBlock",
-                          "paths_per_step": N * spp * (world if weak else 1), "trace_depth": sc.trace_depth, "integrator": "mispt",
-                          "sharding": "single GPU" if world == 1 else
-                                      (f"sample sharding: {world} ranks x whole frame x {spp} spp each (decorrelated RNG sub-streams) + RCCL reduce(SUM)" if weak
-                                       else f"pixel sharding: {world} ranks x interleaved 1024-tid chunks of one frame + RCCL reduce(SUM)"),
-                          "mean_radiance": round(mean_lum, 5), "sharded_frame_verified": verified},
-               "roofline": roofline, "cpu_baseline": cpu}
+    if rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
 
 

@@ -109,6 +109,30 @@ COUNTER_NAMES = ("rays", "nodes", "tris", "surface_hits", "shadow_rays", "paths"
                  "cyc_queue_regen", "cyc_trace_nearest", "cyc_shade", "cyc_trace_shadow", "cyc_path_end", "loop_trips", "wave_node_iters", "wave_tri_iters")
 
 
+class DevArray:
+    """A float32 array in HBM owned through the C ABI's hpt_device_* helpers (tests and tools that do not link the HIP runtime)."""
+
+    def __init__(self, integ, ptr, shape):
+        self.integ, self.ptr, self.shape = integ, ptr, tuple(shape)
+        self.size = int(np.prod(self.shape)) if self.shape else 1
+        self.nbytes = self.size * 4
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, np.float32)
+        assert host.size == self.size
+        self.integ._chk(self.integ.L.hpt_device_copy(self.integ.h, self.ptr, host.ctypes.data, self.nbytes, 1))
+
+    def download(self):
+        out = np.zeros(self.shape, np.float32)
+        self.integ._chk(self.integ.L.hpt_device_copy(self.integ.h, out.ctypes.data, self.ptr, self.nbytes, 2))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.integ._chk(self.integ.L.hpt_device_free(self.integ.h, self.ptr))
+            self.ptr = None
+
+
 class HipIntegrator:
     """Integrator-shaped front end of the HIP core. One instance = one hpt_ctx = one GPU."""
 
@@ -269,6 +293,28 @@ class HipIntegrator:
         self._chk(self.L.hpt_path_trace_dr(self.h, tid_begin, tid, channels, out_color.ctypes.data, a_passNum, a_refImg.ctypes.data,
                                            a_data.ctypes.data, a_dataGrad.ctypes.data, a_data.size, C.byref(loss)))
         return loss.value
+
+    # ---- device-resident arrays for the *_dev entry points (hpt_device_malloc / copy / free) ---------------------------------
+    def dev_array(self, host: np.ndarray):
+        """Upload a float32 array; returns a DevArray (free()d with the integrator or explicitly)."""
+        host = np.ascontiguousarray(host, np.float32)
+        p = _vp()
+        self._chk(self.L.hpt_device_malloc(self.h, host.nbytes, C.byref(p)))
+        a = DevArray(self, p.value, host.shape)
+        a.upload(host)
+        return a
+
+    def PathTraceDR_dev(self, out: "DevArray", a_passNum, ref: "DevArray", data: "DevArray", grad: "DevArray", loss: "DevArray", tid_begin=0, tid=None, channels=4):
+        """PathTraceDR with every array resident in HBM (drmain's loop): memset(grad), memset(loss), launch. The loss word holds the
+        sum over pixels of the per-sample losses / a_passNum (divide by W*H for PathTraceDR's return value)."""
+        tid = self.N - tid_begin if tid is None else tid
+        self._chk(self.L.hpt_device_memset(self.h, grad.ptr, 0, grad.nbytes))
+        self._chk(self.L.hpt_device_memset(self.h, loss.ptr, 0, 4))
+        self._chk(self.L.hpt_path_trace_dr_dev(self.h, tid_begin, tid, channels, out.ptr, a_passNum, ref.ptr, data.ptr, grad.ptr, data.size, loss.ptr, None))
+
+    def AdamStep_dev(self, state: "DevArray", grad: "DevArray", momentum: "DevArray", gsq: "DevArray", it: int):
+        """AdamOptimizer<float>::step(state, grad, iter) (diff_render/adam.h:43-62) on device arrays."""
+        self._chk(self.L.hpt_adam_step_dev(self.h, state.ptr, grad.ptr, momentum.ptr, gsq.ptr, state.size, int(it), None))
 
     # ---- instrumentation ----------------------------------------------------------------------------------------------------
     def set_instrumentation(self, enabled: bool):

@@ -1,0 +1,114 @@
+// Small helper kernels of the C ABI (compiled into the host translation unit): PackXY, InitRandomGens, batched ray queries,
+// the texture regulariser's gradient and AdamOptimizer::step. The path-tracing kernels themselves live in hpt_kernels.hip /
+// hpt_wavefront.hip and are compiled as separate translation units (hpt_decl.h declares them).
+#include <hip/hip_runtime.h>
+#include "hpt_decl.h"
+
+namespace hpt {
+
+// ---- helper kernels --------------------------------------------------------------------------------------------------------------
+// kernel_PackXY over the window (integrator_rt.cpp:13-31)
+__global__ void packXYKernel(uint* out, int W, int H, uint ts)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= W || y >= H) return;
+  uint offset = (uint)y * (uint)W + (uint)x;
+  if (ts != 1u) {
+    const uint inX = (uint)x % ts, inY = (uint)y % ts;
+    const uint wBlocks = (uint)W / ts;
+    offset = (((uint)x / ts) + ((uint)y / ts) * wBlocks) * ts * ts + inY * ts + inX;
+  }
+  if (offset < (uint)W * (uint)H) out[offset] = (((uint)y << 16) & 0xFFFF0000u) | ((uint)x & 0x0000FFFFu);
+}
+
+// InitRandomGens (integrator_pt.cpp:13-21)
+__global__ void initRandomGensKernel(Rng* gens, uint n, uint firstSeed)
+{
+  const uint i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) gens[i] = rng_init(firstSeed + i);
+}
+
+// batched RayQuery_NearestHit / RayQuery_AnyHit for the ISceneObject entry points
+template <bool FLAT, bool MOTION = false>
+__global__ void __launch_bounds__(256) rayQueryKernel(const DevScene S, const float4* posNear, const float4* dirFar, uint n, void* out, int anyHit, uint* stackOverflow, float time = 0.0f)
+{
+  __shared__ uint stackMem[LDS_STACK * 256];
+  const uint i = blockIdx.x * 256u + threadIdx.x;
+  TravStack stk; stk.lds = &stackMem[threadIdx.x]; stk.ovf = stackOverflow + i; stk.ovfStride = gridDim.x * 256u;
+  if (i >= n) return;
+  const float4 p = posNear[i], d = dirFar[i];
+  HitRec h; TravStats st; st.nodes = st.tris = st.insts = st.waveNodeIters = st.waveTriIters = 0;
+  if (anyHit) {
+    const bool occ = traceAny<true, false, true, FLAT, MOTION>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, st, time);
+    ((uint*)out)[i] = occ ? 1u : 0u;
+  } else {
+    const bool found = traceAny<false, false, true, FLAT, MOTION>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, st, time);
+    // CRT_Hit (CrossRT.h:23-30) as the Embree backend fills it (EmbreeRT.cpp:343-360)
+    float4* o = (float4*)out + 2 * (size_t)i;
+    if (found) {
+      o[0] = make_float4(h.t, __uint_as_float(h.prim), __uint_as_float(h.inst), __uint_as_float(S.insts[h.inst].geomId));
+      o[1] = make_float4(h.v, h.u, 1.0f - h.v - h.u, 0.0f);
+    } else {
+      o[0] = make_float4(d.w, __uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu));
+      o[1] = make_float4(0, 0, 0, 0);
+    }
+  }
+}
+
+// Image2D4fRegularizer (diff_render/integrator_dr.cpp:317-367): grad += d/d data of  sum_{interior pixels} sqrt(sum_{4 neighbours} |p0 - p_k|^2_rgb).
+// Hand-derived instead of Enzyme, gather form (no atomics): texel q receives its own term (4 q - sum nb)/sqrt(S_q) when it is interior,
+// and -(n - q)/sqrt(S_n) from each interior neighbour n; terms with S == 0 contribute nothing.
+HPT_DEV float regS(const float4* d, int w, int x, int y)
+{
+  const float4 p0 = d[y * w + x], a = d[(y + 1) * w + x], b = d[(y - 1) * w + x], c = d[y * w + x - 1], e = d[y * w + x + 1];
+  float S = 0.0f;
+  const float4 nb[4] = { a, b, c, e };
+  for (int k = 0; k < 4; k++) { const float dx = p0.x - nb[k].x, dy = p0.y - nb[k].y, dz = p0.z - nb[k].z; S += dx * dx + dy * dy + dz * dz; }
+  return S;
+}
+__global__ void image2D4fRegularizerKernel(int w, int h, const float4* data, float4* grad)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  const float4 q = data[y * w + x];
+  float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+  const bool interior = x >= 1 && x < w - 1 && y >= 1 && y < h - 1;
+  if (interior) {
+    const float S = regS(data, w, x, y);
+    if (S > 0.0f) {
+      const float inv = 1.0f / __builtin_sqrtf(S);
+      const float4 a = data[(y + 1) * w + x], b = data[(y - 1) * w + x], c = data[y * w + x - 1], e = data[y * w + x + 1];
+      gx += (4.0f * q.x - (a.x + b.x + c.x + e.x)) * inv; gy += (4.0f * q.y - (a.y + b.y + c.y + e.y)) * inv; gz += (4.0f * q.z - (a.z + b.z + c.z + e.z)) * inv;
+    }
+  }
+  const int nx[4] = { x, x, x - 1, x + 1 }, ny[4] = { y + 1, y - 1, y, y };
+  for (int k = 0; k < 4; k++) {
+    const int X = nx[k], Y = ny[k];
+    if (X >= 1 && X < w - 1 && Y >= 1 && Y < h - 1) {              // neighbour n is an interior pixel: q is one of ITS four neighbours
+      const float S = regS(data, w, X, Y);
+      if (S > 0.0f) {
+        const float inv = 1.0f / __builtin_sqrtf(S);
+        const float4 n = data[Y * w + X];
+        gx -= (n.x - q.x) * inv; gy -= (n.y - q.y) * inv; gz -= (n.z - q.z) * inv;
+      }
+    }
+  }
+  float4 g = grad[y * w + x];
+  g.x += gx; g.y += gy; g.z += gz;
+  grad[y * w + x] = g;
+}
+
+// AdamOptimizer<float>::step (diff_render/adam.h:43-62): HBM-bound, 16 bytes per lane per array
+__global__ void adamStepKernel(float* state, const float* grad, float* momentum, float* gsq, size_t n, float gamma)
+{
+  const float alpha = 0.5f, beta = 0.25f, epsilon = 1e-8f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float g = grad[i];
+    const float mo = momentum[i] * beta + g * (1.0f - beta);
+    const float gs = 2.0f * (gsq[i] * alpha + (g * g) * (1.0f - alpha));
+    momentum[i] = mo; gsq[i] = gs;
+    state[i] -= (gamma * mo / (__builtin_sqrtf(gs + epsilon)));
+  }
+}
+
+} // namespace hpt

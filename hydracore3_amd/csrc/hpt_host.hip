@@ -11,8 +11,8 @@
 #include <dlfcn.h>
 
 #include "../../include/hydra_hip.h"
-#include "hpt_kernels.hip"
-#include "hpt_wavefront.hip"
+#include "hpt_decl.h"
+#include "hpt_helpers.hip"
 #include "bvh_build.h"
 
 static const uint MAX_STACK = 64;                           // traversal stack entries per lane: LDS_STACK in LDS + the rest in an HBM overflow buffer
@@ -109,10 +109,12 @@ struct hpt_ctx
   std::vector<WfGroup*> wfGroups;
   hipEvent_t wfFork = nullptr;
   int  wfGroupCount = 0;                 // 0 = automatic
+  uint wfIterCap = 0;                    // diagnostic (hpt_set_option "dbg_wf_iter_cap"): rounds after which the wavefront loop gives up
   uint wfGrace = 16;                     // trips a trace wave keeps going after the queue ran dry before it suspends its rays (0 = never)
   // multi-GPU collectives (RCCL, loaded on first use: single-GPU users never touch it)
   void* rcclLib = nullptr; void* comm = nullptr; int commRanks = 0, commRank = 0;
   bool forceFull = false;                // diagnostic (hpt_set_option "force_full_materials")
+  bool drSkipNonFinite = false;          // hpt_set_option "dr_skip_nonfinite": off = PixelLossPT as the reference has it
   bool leanMaterials = false;            // every material is gltf or emissive: the kernels without the other BSDF branches are used
   int  schedule = 0;                     // 0 automatic, 1 megakernel, 2 wavefront (hpt_set_schedule)
   int  nodeMinOverride = -1;             // env HPT_NODE_MIN (tuning): overrides the per-scene choice of DevScene::nodeMin
@@ -787,6 +789,10 @@ extern "C" int hpt_update_params(hpt_ctx* c, const hpt_params* p)
   if (p->spectralMode != 0) return c->fail(HPT_ERR_UNSUPPORTED, "spectral rendering is outside the hot path's scope");
   if (p->winWidth <= 0 || p->winHeight <= 0 || p->fbWidth <= 0 || p->fbHeight <= 0 || p->winWidth > 65535 || p->winHeight > 65535) return c->fail(HPT_ERR_ARG, "bad viewport");
   if (p->tileSize != 1 && p->tileSize != 2 && p->tileSize != 4 && p->tileSize != 8) return c->fail(HPT_ERR_ARG, "bad tile size");
+  // kernel_PackXY tiles the window without a remainder (integrator_rt.cpp:13-31); SetViewport only ever picks a tile size that divides both
+  // sides (integrator_pt.h:379-389). Anything else would index past W*H in PackXY and in every kernel that reads m_packedXY.
+  if (p->winWidth % (int)p->tileSize != 0 || p->winHeight % (int)p->tileSize != 0)
+    return c->fail(HPT_ERR_ARG, "tile size must divide the viewport's width and height (SetViewport falls back to 4 / 2 / 1, integrator_pt.h:379-389)");
   DevScene& S = c->S;
   std::memcpy(S.projInv, p->projInv, 64); std::memcpy(S.worldViewInv, p->worldViewInv, 64);
   S.winStartX = p->winStartX; S.winStartY = p->winStartY; S.winWidth = p->winWidth; S.winHeight = p->winHeight; S.fbWidth = p->fbWidth; S.fbHeight = p->fbHeight;
@@ -854,7 +860,9 @@ extern "C" int hpt_pack_xy(hpt_ctx* c, uint32_t tidX, uint32_t tidY)
   if ((int)tidX != c->S.winWidth || (int)tidY != c->S.winHeight) return c->fail(HPT_ERR_ARG, "PackXYBlock: size differs from the viewport");
   (void)hipSetDevice(c->device);
   const size_t n = (size_t)tidX * tidY;
+  if (c->S.tileSize == 0u || tidX % c->S.tileSize != 0u || tidY % c->S.tileSize != 0u) return c->fail(HPT_ERR_ARG, "PackXYBlock: tile size does not divide the viewport");
   HIPCHK(c, c->dPackedXY.alloc(n));
+  HIPCHK(c, hipMemsetAsync(c->dPackedXY.p, 0, n * sizeof(uint), nullptr));
   packXYKernel<<<dim3((tidX + 15) / 16, (tidY + 15) / 16), dim3(16, 16), 0, 0>>>(c->dPackedXY.p, (int)tidX, (int)tidY, c->S.tileSize);
   HIPCHK(c, hipGetLastError());
   c->packedCount = (uint)n;
@@ -942,6 +950,10 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   if (dr && c->S.lensCount) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceDR: the lens simulation is not differentiated");
   if (dr && c->S.motion) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceDR: motion blur is not differentiated");
   if (c->S.motion && c->schedule == 2) return c->fail(HPT_ERR_UNSUPPORTED, "motion blur runs on the megakernel schedule");
+  // the DR kernels add the constant m_envColor unweighted; the reference's replay evaluates EnvironmentColor() with the map and the
+  // env-sampling MIS weight (integrator_dr.cpp:1077-1098): such scenes are refused rather than differentiated differently
+  if (dr && (c->S.envTexId != 0xFFFFFFFFu || c->S.envEnableSam != 0u || c->S.envCamBackId != 0xFFFFFFFFu))
+    return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceDR: environment maps, their sampling and camera back plates are not differentiated (constant m_envColor only)");
   if (dr && !c->leanMaterials) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceDR: gltf and emissive materials without normal maps only (what the reference's replay differentiates, integrator_dr.cpp:461-612)");
   // never more lanes than pixels: with fewer, the hardware's round-robin block placement spreads them evenly over the CUs, whereas a
   // full grid would let whichever waves ask first take all the work (a small multi-GPU share of a frame)
@@ -953,6 +965,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   job.queue = c->dQueue.p;
   job.gens = c->dGens.p; job.packedXY = c->dPackedXY.p; job.packedCount = c->packedCount;
   job.counters = nullptr;
+  job.drSkipNonFinite = c->drSkipNonFinite ? 1u : 0u;
   const bool stats = c->instrument && !dr;
   c->lastSchedule = 1;
   if (!inRays && !motion && useWavefront(c, naive, dr, stats && c->schedule != 2, job.tidCount)) { c->lastSchedule = 2; return launch_wavefront(c, job, st, dr); }
@@ -1044,12 +1057,14 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr)
   WfJob wj;
   wj.tidBegin = job.tidBegin; wj.tidChunk = job.tidChunk; wj.tidStride = job.tidStride; wj.tidEnd = job.tidEnd;
   wj.passNum = job.passNum; wj.channels = job.channels; wj.outColor = job.outColor; wj.gens = job.gens; wj.packedXY = job.packedXY;
+  wj.drSkipNonFinite = job.drSkipNonFinite;
   wj.refImg = job.refImg; wj.data = job.data; wj.grad = job.grad; wj.lossAccum = job.lossAccum; wj.record = nullptr;
   // every path takes at most traceDepth shade passes after the one that generated it; the pass that ends it (or the next one, when a
   // shadow ray was outstanding) also generates the pixel's next path
   // safety net only (the loop ends when a round queues no ray): pixels whose rays were suspended sit rounds out, so there is no tight bound
-  const unsigned long long iterCap = 64ull * ((unsigned long long)job.passNum * (c->S.traceDepth + 2ull) + 4ull);
+  const unsigned long long iterCap = c->wfIterCap ? c->wfIterCap : 64ull * ((unsigned long long)job.passNum * (c->S.traceDepth + 2ull) + 4ull);
   c->lastWfIters = 0;
+  unsigned long long capLeft = 0;                  // rays still queued when a group ran into iterCap
   if (dr) { HIPCHK(c, c->dLossAcc.alloc(1)); HIPCHK(c, hipMemsetAsync(c->dLossAcc.p, 0, sizeof(double), st)); }
   HIPCHK(c, hipEventRecord(c->ev0, st));
   HIPCHK(c, hipEventRecord(c->wfFork, st));
@@ -1111,7 +1126,19 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr)
         if (stats) launchWfTrace<true>(c, P, wj.iter, traceBlocks, g.stream, deep, ovf); else launchWfTrace<false>(c, P, wj.iter, traceBlocks, g.stream, deep, ovf);
         g.it++;
         if (gi == 0) c->lastWfIters++;
-        if (g.it >= iterCap) g.finished = true;
+        if (g.it >= iterCap) {
+          // The safety net tripped. One more shade pass tells whether anything is left: it queues a ray for every path still alive and the
+          // rays the last trace pass suspended are already counted in the same word. Work left = an incomplete frame: say so.
+          wj.iter = (uint)g.it;
+          if (dr)                    wfShadeKernel<true, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
+          else if (c->leanMaterials && !c->forceFull && c->S.lensCount == 0u) wfShadeKernel<false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
+          else                       wfShadeKernel<false, false><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
+          uint left = 0;
+          HIPCHK(c, hipMemcpyAsync(&left, P.ctr + WF_CTR_WORDS * (wj.iter & 1u), sizeof(uint), hipMemcpyDeviceToHost, g.stream));
+          HIPCHK(c, hipStreamSynchronize(g.stream));
+          if (left != 0u) capLeft += left;
+          g.finished = true;
+        }
       }
       if (g.finished) {
         live--;
@@ -1124,6 +1151,9 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr)
   }
   if (dr) wfLossFinishKernel<<<dim3(1), dim3(1), 0, st>>>(c->dLossAcc.p, job.lossAccum);
   HIPCHK(c, hipEventRecord(c->ev1, st));
+  if (capLeft != 0ull)
+    return c->fail(HPT_ERR_STATE, "wavefront schedule: stopped after " + std::to_string(iterCap) + " rounds with " + std::to_string(capLeft) +
+                   " rays still queued - the frame is incomplete (render it with hpt_set_schedule(ctx, 1, ...) or hpt_set_option(\"wf_grace\", 0))");
   return HPT_OK;
 }
 
@@ -1439,6 +1469,8 @@ extern "C" int hpt_set_option(hpt_ctx* c, const char* name, int value)
   if (k == "wf_grace") c->wfGrace = (uint)value;                                      // trips after the queue ran dry before a trace wave suspends its rays (0: never)
   else if (k == "node_min") { c->nodeMinOverride = value & 63; c->accelCommitted = false; }   // voted exit of the inner-node loop; takes effect at the next CommitScene
   else if (k == "dbg_no_normal_lerp") { if (c->S.motion) c->S.motion = value ? 3u : 1u; }   // diagnostic: moving instances without the reference's normal interpolation (bit 1 of DevScene::motion)
+  else if (k == "dbg_wf_iter_cap") c->wfIterCap = (uint)value;                         // diagnostic: make the wavefront loop's safety net reachable in a test
+  else if (k == "dr_skip_nonfinite") c->drSkipNonFinite = value != 0;                  // PathTraceDR: drop samples whose radiance is not finite (default 0: PixelLossPT as in the reference)
   else if (k == "force_full_materials") c->forceFull = value != 0;                     // diagnostic: never pick the lean (gltf + emissive) kernels
   else return c->fail(HPT_ERR_ARG, "hpt_set_option: unknown option " + k);
   return HPT_OK;

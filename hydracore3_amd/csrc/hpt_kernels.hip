@@ -16,51 +16,12 @@
 // Exit condition every wave reaches: the queue counter only grows, a lane that draws an index past the end never asks
 // again, and a wave leaves the loop when none of its lanes holds a live path or a pixel.
 #include <hip/hip_runtime.h>
-#include "hpt_shade.h"
+#include "hpt_decl.h"
 
 namespace hpt {
 
-struct Job
-{
-  uint   tidBegin, tidCount;      // work items of this launch: item k renders tid = tidBegin + (k / chunk) * chunk * stride + k % chunk
-  uint   tidChunk, tidStride;     // (stride 1 = one contiguous window; stride W = every W-th chunk: the interleaved multi-GPU split)
-  uint   tidEnd;                  // number of threads of the whole frame (items mapping past it are dropped)
-  uint   passNum, channels;
-  float* outColor;                // full W*H*channels framebuffer (device)
-  Rng*   gens;                    // m_randomGens (device, persistent)
-  const uint* packedXY;           // m_packedXY
-  uint  packedCount;              // entries in packedXY (the input-ray mode reads it only for the camera back plate)
-  uint*  queue;                   // work-queue head (zeroed before launch)
-  Counters* counters;             // instrumentation (STATS builds)
-  // differentiable rendering
-  const float* refImg;            // a_refImg
-  const float* data;              // a_data
-  float* grad;                    // a_dataGrad (atomically accumulated)
-  float* lossAccum;               // sum over samples of loss / passNum
-  float* record;                  // per-lane, per-bounce adjoint records: [bounce][field][lane]
-  uint   recordLanes;             // total lanes of the grid (stride of the record buffer)
-  uint*  stackOverflow;           // HBM part of the traversal stacks: [depth - LDS_STACK][global lane]
-  uint   gridLanes;
-  const float4* inRayPos;         // PathTraceFromInputRays: RayPosAndW[tid] / RayDirAndT[tid] in camera space (MODE 2)
-  const float4* inRayDir;
-};
-
-
-#ifndef HPT_MIN_WAVES
-#define HPT_MIN_WAVES 4   // waves per SIMD the register allocator must fit (measured: 2 -> 725, 3 -> 913..1262, 4 -> 1005..1365 Mpaths/s on the Cornell box)
-#endif
-// MODE: 0 = PathTrace (MIS / shadow / stupid by m_intergatorType), 1 = NaivePathTrace, 2 = PathTraceFromInputRays (the caller's rays
-// instead of camera rays, linear tid -> output index, raw accumColor: integrator_pt.cpp:159-199, 659-676, 761-798),
-// 3 = PathTrace for scenes with gltf + emissive materials only (shadeVertex<LEAN>)
-// waves per SIMD the kernels with every BSDF branch (MODE 0 / 1 / 2) are compiled for; the lean and DR kernels keep HPT_MIN_WAVES.
-// Measured (profiles/ab_full.sh, 1024^2 x 64 spp, Mpaths/s at 4 / 3 / 2 waves): Cornell forced onto this kernel 1410 / 1531 / 1264,
-// legacy_materials 1585 / 1714 / 1528, env_map 1425 / 1507 / 1369, typed_materials 1123 / 1125 / 1105 - 168 VGPRs instead of 128 take
-// the spills from 160 to 44 registers and that outweighs the lost wave.
-#ifndef HPT_FULL_WAVES
-#define HPT_FULL_WAVES 3
-#endif
-template <bool STATS, bool DR, int MODE, bool DEEP, bool FLAT, bool MOTION = false>
-__global__ void __launch_bounds__(256, (DR || MODE == 3) ? HPT_MIN_WAVES : HPT_FULL_WAVES) pathTraceKernel(const DevScene S, const Job job)
+template <bool STATS, bool DR, int MODE, bool DEEP, bool FLAT, bool MOTION>
+__global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const Job job)
 {
   constexpr bool NAIVE = (MODE == 1), INRAYS = (MODE == 2), LEAN = (MODE == 3);
   __shared__ uint stackMem[LDS_STACK * 256];
@@ -207,15 +168,16 @@ __global__ void __launch_bounds__(256, (DR || MODE == 3) ? HPT_MIN_WAVES : HPT_F
           const uint yRef = (uint)S.winHeight - ((XY & 0xFFFF0000u) >> 16) - 1u;
           const float* rp = job.refImg + ((size_t)yRef * pitch + (XY & 0x0000FFFFu)) * job.channels;
           const V3 diff = v3(accum.x - rp[0], accum.y - rp[1], accum.z - rp[2]);
-          // One sample in ~1e8 on the 1M-triangle scene comes out non-finite (a 0/0 in a grazing GGX term; the reference's formulas,
-          // unguarded there too). In the optimisation loop a single NaN gradient poisons Adam's moments for good, so such a sample
-          // contributes neither loss, colour nor gradient here - the one deliberate deviation from PixelLossPT.
-          const bool sane = __builtin_isfinite(diff.x + diff.y + diff.z);
+          // PixelLossPT adds every sample, finite or not (integrator_dr.cpp:1124-1131): that is the default here too. One sample in ~1e8 on
+          // the 1M-triangle scene comes out non-finite (a 0/0 in a grazing GGX term of the reference's formulas, unguarded there too) and in
+          // an optimisation loop a single NaN gradient poisons Adam's moments for good, so hpt_set_option("dr_skip_nonfinite", 1) lets such
+          // a sample contribute neither loss, colour nor gradient.
+          const bool sane = job.drSkipNonFinite == 0u || __builtin_isfinite(diff.x + diff.y + diff.z);
           if (sane) {
             lossLocal += (diff.x * diff.x + diff.y * diff.y + diff.z * diff.z) / float(job.passNum);
             PIX(0) += accum.x; PIX(1) += accum.y; PIX(2) += accum.z;           // out_color += colorRend (:1124-1126)
+            drReverseSweep(S, job.record, job.recordLanes, glane, bounce, tailR + env, diff, job.grad, job.drSkipNonFinite != 0u);
           }
-          if (sane) drReverseSweep(S, job.record, job.recordLanes, glane, bounce, tailR + env, diff, job.grad);
         } else {
           // kernel_ContributeToImage (integrator_pt.cpp:598-657)
           const V3 c = accum * ld3(S.camRespoceRGB);
@@ -254,109 +216,35 @@ __global__ void __launch_bounds__(256, (DR || MODE == 3) ? HPT_MIN_WAVES : HPT_F
   }
 }
 
-// ---- helper kernels --------------------------------------------------------------------------------------------------------------
-// kernel_PackXY over the window (integrator_rt.cpp:13-31)
-__global__ void packXYKernel(uint* out, int W, int H, uint ts)
-{
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= W || y >= H) return;
-  uint offset = (uint)y * (uint)W + (uint)x;
-  if (ts != 1u) {
-    const uint inX = (uint)x % ts, inY = (uint)y % ts;
-    const uint wBlocks = (uint)W / ts;
-    offset = (((uint)x / ts) + ((uint)y / ts) * wBlocks) * ts * ts + inY * ts + inX;
-  }
-  out[offset] = (((uint)y << 16) & 0xFFFF0000u) | ((uint)x & 0x0000FFFFu);
-}
-
-// InitRandomGens (integrator_pt.cpp:13-21)
-__global__ void initRandomGensKernel(Rng* gens, uint n, uint firstSeed)
-{
-  const uint i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) gens[i] = rng_init(firstSeed + i);
-}
-
-// batched RayQuery_NearestHit / RayQuery_AnyHit for the ISceneObject entry points
-template <bool FLAT, bool MOTION = false>
-__global__ void __launch_bounds__(256) rayQueryKernel(const DevScene S, const float4* posNear, const float4* dirFar, uint n, void* out, int anyHit, uint* stackOverflow, float time = 0.0f)
-{
-  __shared__ uint stackMem[LDS_STACK * 256];
-  const uint i = blockIdx.x * 256u + threadIdx.x;
-  TravStack stk; stk.lds = &stackMem[threadIdx.x]; stk.ovf = stackOverflow + i; stk.ovfStride = gridDim.x * 256u;
-  if (i >= n) return;
-  const float4 p = posNear[i], d = dirFar[i];
-  HitRec h; TravStats st; st.nodes = st.tris = st.insts = st.waveNodeIters = st.waveTriIters = 0;
-  if (anyHit) {
-    const bool occ = traceAny<true, false, true, FLAT, MOTION>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, st, time);
-    ((uint*)out)[i] = occ ? 1u : 0u;
-  } else {
-    const bool found = traceAny<false, false, true, FLAT, MOTION>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, st, time);
-    // CRT_Hit (CrossRT.h:23-30) as the Embree backend fills it (EmbreeRT.cpp:343-360)
-    float4* o = (float4*)out + 2 * (size_t)i;
-    if (found) {
-      o[0] = make_float4(h.t, __uint_as_float(h.prim), __uint_as_float(h.inst), __uint_as_float(S.insts[h.inst].geomId));
-      o[1] = make_float4(h.v, h.u, 1.0f - h.v - h.u, 0.0f);
-    } else {
-      o[0] = make_float4(d.w, __uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu), __uint_as_float(0xFFFFFFFFu));
-      o[1] = make_float4(0, 0, 0, 0);
-    }
-  }
-}
-
-// Image2D4fRegularizer (diff_render/integrator_dr.cpp:317-367): grad += d/d data of  sum_{interior pixels} sqrt(sum_{4 neighbours} |p0 - p_k|^2_rgb).
-// Hand-derived instead of Enzyme, gather form (no atomics): texel q receives its own term (4 q - sum nb)/sqrt(S_q) when it is interior,
-// and -(n - q)/sqrt(S_n) from each interior neighbour n; terms with S == 0 contribute nothing.
-HPT_DEV float regS(const float4* d, int w, int x, int y)
-{
-  const float4 p0 = d[y * w + x], a = d[(y + 1) * w + x], b = d[(y - 1) * w + x], c = d[y * w + x - 1], e = d[y * w + x + 1];
-  float S = 0.0f;
-  const float4 nb[4] = { a, b, c, e };
-  for (int k = 0; k < 4; k++) { const float dx = p0.x - nb[k].x, dy = p0.y - nb[k].y, dz = p0.z - nb[k].z; S += dx * dx + dy * dy + dz * dz; }
-  return S;
-}
-__global__ void image2D4fRegularizerKernel(int w, int h, const float4* data, float4* grad)
-{
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= w || y >= h) return;
-  const float4 q = data[y * w + x];
-  float gx = 0.0f, gy = 0.0f, gz = 0.0f;
-  const bool interior = x >= 1 && x < w - 1 && y >= 1 && y < h - 1;
-  if (interior) {
-    const float S = regS(data, w, x, y);
-    if (S > 0.0f) {
-      const float inv = 1.0f / __builtin_sqrtf(S);
-      const float4 a = data[(y + 1) * w + x], b = data[(y - 1) * w + x], c = data[y * w + x - 1], e = data[y * w + x + 1];
-      gx += (4.0f * q.x - (a.x + b.x + c.x + e.x)) * inv; gy += (4.0f * q.y - (a.y + b.y + c.y + e.y)) * inv; gz += (4.0f * q.z - (a.z + b.z + c.z + e.z)) * inv;
-    }
-  }
-  const int nx[4] = { x, x, x - 1, x + 1 }, ny[4] = { y + 1, y - 1, y, y };
-  for (int k = 0; k < 4; k++) {
-    const int X = nx[k], Y = ny[k];
-    if (X >= 1 && X < w - 1 && Y >= 1 && Y < h - 1) {              // neighbour n is an interior pixel: q is one of ITS four neighbours
-      const float S = regS(data, w, X, Y);
-      if (S > 0.0f) {
-        const float inv = 1.0f / __builtin_sqrtf(S);
-        const float4 n = data[Y * w + X];
-        gx -= (n.x - q.x) * inv; gy -= (n.y - q.y) * inv; gz -= (n.z - q.z) * inv;
-      }
-    }
-  }
-  float4 g = grad[y * w + x];
-  g.x += gx; g.y += gy; g.z += gz;
-  grad[y * w + x] = g;
-}
-
-// AdamOptimizer<float>::step (diff_render/adam.h:43-62): HBM-bound, 16 bytes per lane per array
-__global__ void adamStepKernel(float* state, const float* grad, float* momentum, float* gsq, size_t n, float gamma)
-{
-  const float alpha = 0.5f, beta = 0.25f, epsilon = 1e-8f;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float g = grad[i];
-    const float mo = momentum[i] * beta + g * (1.0f - beta);
-    const float gs = 2.0f * (gsq[i] * alpha + (g * g) * (1.0f - alpha));
-    momentum[i] = mo; gsq[i] = gs;
-    state[i] -= (gamma * mo / (__builtin_sqrtf(gs + epsilon)));
-  }
-}
+// ---- explicit instantiations: one group per translation unit (-DHPT_INST_GROUP=n, see __graft_entry__.build) ----------------------------
+// DEEP: the scene's BVH can need more than LDS_STACK stack entries; FLAT: single-level world-space BVH vs two-level TLAS/BLAS
+#define HPT_INST4(STATS, DR, MODE) \
+  template __global__ void pathTraceKernel<STATS, DR, MODE, false, false, false>(const DevScene, const Job); \
+  template __global__ void pathTraceKernel<STATS, DR, MODE, true,  false, false>(const DevScene, const Job); \
+  template __global__ void pathTraceKernel<STATS, DR, MODE, false, true,  false>(const DevScene, const Job); \
+  template __global__ void pathTraceKernel<STATS, DR, MODE, true,  true,  false>(const DevScene, const Job);
+#ifndef HPT_INST_GROUP
+#error "compile hpt_kernels.hip with -DHPT_INST_GROUP=1..7"
+#endif
+#if HPT_INST_GROUP == 1      // gltf + emissive scenes (every benchmark workload)
+HPT_INST4(false, false, 3)
+#elif HPT_INST_GROUP == 2    // every BSDF branch
+HPT_INST4(false, false, 0)
+#elif HPT_INST_GROUP == 3    // NaivePathTrace
+HPT_INST4(false, false, 1)
+#elif HPT_INST_GROUP == 4    // PathTraceFromInputRays
+HPT_INST4(false, false, 2)
+#elif HPT_INST_GROUP == 5    // instrumented
+HPT_INST4(true, false, 0)
+#elif HPT_INST_GROUP == 6    // PathTraceDR
+HPT_INST4(false, true, 0)
+#elif HPT_INST_GROUP == 7    // moving instances (two-level layout only)
+template __global__ void pathTraceKernel<false, false, 0, false, false, true>(const DevScene, const Job);
+template __global__ void pathTraceKernel<false, false, 0, true,  false, true>(const DevScene, const Job);
+template __global__ void pathTraceKernel<false, false, 1, false, false, true>(const DevScene, const Job);
+template __global__ void pathTraceKernel<false, false, 1, true,  false, true>(const DevScene, const Job);
+template __global__ void pathTraceKernel<false, false, 2, false, false, true>(const DevScene, const Job);
+template __global__ void pathTraceKernel<false, false, 2, true,  false, true>(const DevScene, const Job);
+#endif
 
 } // namespace hpt

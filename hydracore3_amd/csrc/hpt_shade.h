@@ -450,7 +450,7 @@ HPT_DEV void drClearShadowTerm(float* record, size_t s, size_t idx, uint bounce)
 // Hand-derived reverse sweep replacing __enzyme_autodiff (integrator_dr.cpp:1172-1183). With T_0 = 1, T_{b+1} = T_b A_b and
 // C = sum_b T_b S_b + T_n tail:  dC/dtex_b = T_b dS_b + T_b dA_b R_{b+1},  R_b = S_b + A_b R_{b+1},  R_n = tail;  the loss gradient
 // 2 (C - ref) dC/dtex_b is scattered to the four bilinear taps with float atomics.
-HPT_DEV void drReverseSweep(const DevScene& S, const float* record, size_t s, size_t idx, uint bounce, V3 Rn, V3 diff, float* grad)
+HPT_DEV void drReverseSweep(const DevScene& S, const float* record, size_t s, size_t idx, uint bounce, V3 Rn, V3 diff, float* grad, const bool skipNonFinite)
 {
   for (int b = (int)bounce - 1; b >= 0; b--) {
     const float* r = record + ((size_t)b * REC_FIELDS) * s + idx;
@@ -460,7 +460,7 @@ HPT_DEV void drReverseSweep(const DevScene& S, const float* record, size_t s, si
       const V3 TdA = v3(r[6 * s], r[7 * s], r[8 * s]), TdS = v3(r[9 * s], r[10 * s], r[11 * s]);
       const V3 dC = TdS + TdA * Rn;
       V3 g = v3(2.0f * diff.x * dC.x, 2.0f * diff.y * dC.y, 2.0f * diff.z * dC.z);
-      if (!__builtin_isfinite(g.x + g.y + g.z)) g = v3(0, 0, 0);
+      if (skipNonFinite && !__builtin_isfinite(g.x + g.y + g.z)) g = v3(0, 0, 0);   // (only with dr_skip_nonfinite: the reference scatters whatever comes out)
       const TexRec t = S.textures[texId];
       float* gbase = grad + t.diffOffset;
       for (int k = 0; k < 4; k++) {

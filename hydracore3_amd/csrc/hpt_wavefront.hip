@@ -22,58 +22,17 @@
 // schedules (same functions, same order, IEEE flags), so the two produce bit-identical frames; tests/test_gpu_parity.py holds
 // them to that. wfShadeKernel<DR = true> carries the differentiable integrator (adjoint records per slot, reverse sweep at path end).
 #include <hip/hip_runtime.h>
-#include "hpt_shade.h"
+#include "hpt_decl.h"
 
 namespace hpt {
 
-static const uint WF_RANGES = 64u;                   // the trace kernel pulls rays from this many ranges of the queue (work stealing)
-static const uint WF_CTR_WORDS = 32u * (1u + WF_RANGES);
-static const uint WF_SUSP_WORDS = 10u;               // cur, sp, curInst, hitT, hitU, hitV, hitPrim, hitInst, found, (spare)
-static const uint WF_ALIVE = 1u, WF_PEND = 2u, WF_ENDING = 4u;   // status bits; passes left in bits 8..31
-
-struct WfPool
-{
-  float4* rayO;      // rpos.xyz, misPdf
-  float4* rayD;      // rdir.xyz, misIor
-  float4* thr;       // throughput.xyz, flags
-  float4* acc;       // accumulated radiance.xyz, bounce
-  float4* shO;       // shadow ray origin.xyz, far
-  float4* shD;       // shadow ray direction.xyz
-  float4* contrib;   // thr * shade of the pending light sample
-  float4* hit;       // t, u, v, primId
-  uint*   hitInst;   // instId or 0xFFFFFFFF
-  uint*   occl;      // shadow ray result
-  uint*   status;
-  float*  lossSlot;  // DR: per-slot sum of the pixel's sample losses (reduced in double at the end: one float accumulator for 10^7..10^8
-                     // samples loses the small increments - measured 1.5 % low on the 1M-triangle scene)
-  uint*   inflight;  // bit 0 / 1: the slot's closest-hit / shadow ray was suspended by a trace pass and has not finished yet
-  uint*   rayQ[2];   // compacted ray queue of round (iteration & 1): slot id | (shadow ray ? 1 << 31 : 0) | (resumed ray ? 1 << 30 : 0)
-  uint*   susp[2];   // traversal state of the rays a trace pass suspended, written for the NEXT round: [WF_SUSP_WORDS + stack][maxSusp],
-                     // record k belongs to queue entry k of that round (suspended rays are queued first)
-  uint    maxSusp;   // records per buffer (= lanes of the trace grid: a lane suspends at most one ray per pass)
-  uint    suspStack; // stack entries per record
-  uint*   ctr;       // two sets of WF_CTR_WORDS (set iteration & 1 is live): [0] rays queued by the shade pass;
-                     // [32 * (1 + r)] head of queue range r for the trace pass (one 128-byte line each: the atomics of different
-                     // ranges go to different L2 channels instead of serialising on one address)
-};
-
-struct WfJob
-{
-  uint   itemBase, itemCount;     // pool slot s renders work item itemBase + s (item -> tid as in Job)
-  uint   tidBegin, tidChunk, tidStride, tidEnd;
-  uint   passNum, channels, iter;
-  float* outColor;
-  Rng*   gens;
-  const uint* packedXY;
-  // differentiable rendering (wfShadeKernel<DR = true>): a_refImg, a_data, a_dataGrad, loss accumulator, adjoint records [bounce][field][slot]
-  const float* refImg; const float* data; float* grad; float* lossAccum; float* record;
-};
-
+#if !defined(HPT_WF_INST) || HPT_WF_INST != 2      // (small kernels: emitted once, with the shade kernels)
 __global__ void wfInitKernel(WfPool P, uint n, uint passNum)
 {
   const uint i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { P.status[i] = passNum << 8; P.inflight[i] = 0u; if (P.lossSlot) P.lossSlot[i] = 0.0f; }       // (the counters are zeroed by the host: the grid may be smaller than the counter block)
 }
+#endif
 
 // Ray compaction. Every wave ballots its two kinds of rays and prefix-sums the lanes (mbcnt); the four waves of the block add
 // their counts in LDS and ONE atomicAdd per block reserves the block's run of the queue. (One atomic per wave was measured at
@@ -98,14 +57,8 @@ HPT_DEV void blockAppend(uint* counter, bool qNear, bool qShad, uint& posNear, u
   posShad = base + cn + mbcnt64(ms);
 }
 
-#ifndef HPT_WF_SHADE_FULL_WAVES
-#define HPT_WF_SHADE_FULL_WAVES 3      // the shade kernel with every BSDF branch: 1 M-triangle interior forced onto it 209 (4 waves) -> 214 Mpaths/s (profiles/ab_wfs.sh)
-#endif
-#ifndef HPT_WF_SHADE_WAVES
-#define HPT_WF_SHADE_WAVES 4
-#endif
 template <bool DR, bool LEAN>
-__global__ void __launch_bounds__(256, (DR || LEAN) ? HPT_WF_SHADE_WAVES : HPT_WF_SHADE_FULL_WAVES) wfShadeKernel(const DevScene S, const WfPool P, const WfJob job)
+__global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const WfPool P, const WfJob job)
 {
   const uint s = blockIdx.x * 256u + threadIdx.x;
   uint* ctr = P.ctr + WF_CTR_WORDS * (job.iter & 1u);
@@ -175,11 +128,11 @@ __global__ void __launch_bounds__(256, (DR || LEAN) ? HPT_WF_SHADE_WAVES : HPT_W
       const uint x = XY & 0x0000FFFFu, y = (XY & 0xFFFF0000u) >> 16;
       const float* rp = job.refImg + ((size_t)((uint)S.winHeight - y - 1u) * (uint)S.winWidth + x) * job.channels;
       const V3 diff = v3(accum.x - rp[0], accum.y - rp[1], accum.z - rp[2]);
-      if (__builtin_isfinite(diff.x + diff.y + diff.z)) {                   // (non-finite samples: see the megakernel)
+      if (job.drSkipNonFinite == 0u || __builtin_isfinite(diff.x + diff.y + diff.z)) {   // (non-finite samples: see the megakernel)
         P.lossSlot[s] += (diff.x * diff.x + diff.y * diff.y + diff.z * diff.z) / float(job.passNum);
         float* o = job.outColor + ((size_t)y * (uint)S.winWidth + x) * job.channels;
         o[0] += accum.x; o[1] += accum.y; o[2] += accum.z;
-        drReverseSweep(S, job.record, job.itemCount, s, bounce, tailR + env, diff, job.grad);
+        drReverseSweep(S, job.record, job.itemCount, s, bounce, tailR + env, diff, job.grad, job.drSkipNonFinite != 0u);
       }
     } else if (finalize) {                                                   // kernel_ContributeToImage (integrator_pt.cpp:598-657)
       const uint pixel = ((XY & 0xFFFF0000u) >> 16) * (uint)S.winWidth + (XY & 0x0000FFFFu);
@@ -217,6 +170,7 @@ __global__ void __launch_bounds__(256, (DR || LEAN) ? HPT_WF_SHADE_WAVES : HPT_W
   if (qShad) rayQ[ks] = s | 0x80000000u;
 }
 
+#if !defined(HPT_WF_INST) || HPT_WF_INST != 2
 // DR: sum of the per-slot losses in double, one atomic per block; wfLossFinishKernel adds the total to the caller's float
 __global__ void __launch_bounds__(256) wfLossReduceKernel(const float* lossSlot, uint n, double* acc)
 {
@@ -229,13 +183,11 @@ __global__ void __launch_bounds__(256) wfLossReduceKernel(const float* lossSlot,
   if (threadIdx.x == 0u) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
 }
 __global__ void wfLossFinishKernel(const double* acc, float* loss) { *loss += (float)*acc; }
+#endif
 
 // ---- persistent traversal with ray replacement -------------------------------------------------------------------------------
 #ifndef HPT_WF_XCD_RANGES
 #define HPT_WF_XCD_RANGES 1
-#endif
-#ifndef HPT_WF_WAVES
-#define HPT_WF_WAVES 5   // measured on the 1M-triangle scene: 4 -> 213, 5 -> 224, 6 -> 217 Mpaths/s (96 VGPRs: no spills; 24 KB of LDS per block)
 #endif
 template <bool DEEP, bool FLAT, bool STATS>
 __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScene S, const WfPool P, uint iter, uint refillBelow, uint grace,
@@ -474,5 +426,20 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
     }
   }
 }
+
+// ---- explicit instantiations (the host launches them through the declarations in hpt_decl.h) -----------------------------------------------
+#ifndef HPT_WF_INST
+#define HPT_WF_INST 0          // 0: everything in one translation unit; 1: shade kernels only; 2: trace kernels only
+#endif
+#if HPT_WF_INST == 0 || HPT_WF_INST == 1
+template __global__ void wfShadeKernel<true, true>(const DevScene, const WfPool, const WfJob);
+template __global__ void wfShadeKernel<false, true>(const DevScene, const WfPool, const WfJob);
+template __global__ void wfShadeKernel<false, false>(const DevScene, const WfPool, const WfJob);
+#endif
+#if HPT_WF_INST == 0 || HPT_WF_INST == 2
+#define HPT_WFT(DEEP, FLAT, STATS) template __global__ void wfTraceKernel<DEEP, FLAT, STATS>(const DevScene, const WfPool, uint, uint, uint, uint*, uint, Counters*);
+HPT_WFT(false, false, false) HPT_WFT(true, false, false) HPT_WFT(false, true, false) HPT_WFT(true, true, false)
+HPT_WFT(false, false, true)  HPT_WFT(true, false, true)  HPT_WFT(false, true, true)  HPT_WFT(true, true, true)
+#endif
 
 } // namespace hpt

@@ -52,6 +52,7 @@ def lib():
         L.orc_path_trace_dr_fd.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
                                            C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p]
         L.orc_path_trace_from_input_rays_block.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.orc_rng_kat.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_tex_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_probe.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p]
@@ -147,6 +148,10 @@ class OracleIntegrator:
         out = np.zeros(pos_near.shape[0], np.uint32)
         self.L.orc_ray_any_motion(self.h, pos_near.ctypes.data, dir_far.ctypes.data, pos_near.shape[0], C.c_float(time), out.ctypes.data, int(brute))
         return out
+
+    def set_option(self, name, value):
+        if self.L.orc_set_option(self.h, name.encode(), int(value)) != 0:
+            raise KeyError(name)
 
     def put_diff_tex2d(self, tex_id, w, h, channels):
         off, size = C.c_uint64(0), C.c_uint64(0)

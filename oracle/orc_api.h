@@ -110,6 +110,8 @@ void     orc_ray_any_motion(orc_ctx*, const float* posNear4, const float* dirFar
 int      orc_put_diff_tex2d(orc_ctx*, uint32_t texId, uint32_t width, uint32_t height, uint32_t channels, uint64_t* outOffset, uint64_t* outSize);
 float    orc_path_trace_dr(orc_ctx*, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out_color, uint32_t passNum,
                            const float* refImg, const float* data, float* dataGrad, uint64_t gradSize);
+// options that mirror the product's hpt_set_option where a parity test needs both sides switched: "dr_skip_nonfinite"
+int      orc_set_option(orc_ctx*, const char* name, int value);
 // Finite-difference companion: replays exactly the samples orc_path_trace_dr would draw (same RNG state
 // on entry) and returns d(sum over samples of |c - ref|^2)/d data[idx[i]] by central differences with step h.
 void     orc_path_trace_dr_fd(orc_ctx*, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, uint32_t passNum,

@@ -69,6 +69,7 @@ struct Ctx
   std::vector<RandomGen> randomGens;
   std::vector<TexInfo>   texAddressTable;   // DR
   size_t                 gradSize = 0;
+  bool                   drSkipNonFinite = false;   // orc_set_option("dr_skip_nonfinite"): mirror of the product's option, not reference behaviour
 
   // ------------------------------------------------------------------------------------------------------------
   // integrator_rt.cpp:13-31
@@ -1058,17 +1059,21 @@ static float dr_sample(Ctx& c, uint tid, uint channels, float* out_color, const 
   const uint yRef = (uint)c.p.winHeight - y - 1;
   const f4 colorRend = ro.color.v;
   const f4 colorRef = mk4(refImg[(yRef * pitch + x) * channels + 0], refImg[(yRef * pitch + x) * channels + 1], refImg[(yRef * pitch + x) * channels + 2], 0.0f);
+  const f4 diff = colorRend - colorRef;
+  // Mirror of the product's hpt_set_option("dr_skip_nonfinite", 1) - NOT reference behaviour (PixelLossPT adds every sample,
+  // integrator_dr.cpp:1124-1131): a sample whose radiance is not finite gives neither colour, loss nor gradient.
+  if (c.drSkipNonFinite && !std::isfinite(diff.x + diff.y + diff.z)) return 0.0f;
   out_color[(y * pitch + x) * channels + 0] += colorRend.x;
   out_color[(y * pitch + x) * channels + 1] += colorRend.y;
   out_color[(y * pitch + x) * channels + 2] += colorRend.z;
-  const f4 diff = colorRend - colorRef;
   const float loss = diff.x * diff.x + diff.y * diff.y + diff.z * diff.z;
   if (grad) {
     for (uint b = 0; b < c.p.traceDepth && b < (uint)MAXB; b++) {
       if (!ro.isParam[b]) continue;
       const TexInfo& info = c.texAddressTable[ro.texId[b]];
       const f4 dC = ro.color.d[b];                       // dC_ch / d texColor_ch at bounce b
-      const float g[3] = { 2.0f * diff.x * dC.x, 2.0f * diff.y * dC.y, 2.0f * diff.z * dC.z };
+      float g[3] = { 2.0f * diff.x * dC.x, 2.0f * diff.y * dC.y, 2.0f * diff.z * dC.z };
+      if (c.drSkipNonFinite && !std::isfinite(g[0] + g[1] + g[2])) g[0] = g[1] = g[2] = 0.0f;
       for (int k = 0; k < 4; k++) {
         const float w = ro.taps[b].w[k];
         if (info.channels == 4) {
@@ -1082,6 +1087,12 @@ static float dr_sample(Ctx& c, uint tid, uint channels, float* out_color, const 
     }
   }
   return loss;
+}
+
+int orc_set_option(orc_ctx* h, const char* name, int value)
+{
+  if (std::strcmp(name, "dr_skip_nonfinite") == 0) { h->c.drSkipNonFinite = value != 0; return 0; }
+  return 1;
 }
 
 float orc_path_trace_dr(orc_ctx* h, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out_color, uint32_t passNum,

@@ -96,13 +96,13 @@ def cpu_baseline_child(workload, width, height, target_s):
            "sample": f"{workload} {width}x{height} @ {spp} spp, twice ({runs[0]:.1f} s, {runs[1]:.1f} s: {rates[0]:.2f} / {rates[1]:.2f} Mpaths/s, "
                      f"{min(rates) / cores * 1e3:.1f} Kpaths/s per thread); oracle/liboracle.so = restated port of PathTraceBlock, OpenMP "
                      f"schedule(dynamic,64), OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND', 'unset')}, {cores} threads "
-                     f"(affinity {len(os.sched_getaffinity(0))}, machine {os.cpu_count()}) on {cpu_model()}"}
+                     f"(affinity mask {os.environ.get('HYDRA_BENCH_AFFINITY', '?')} CPUs, cgroup quota applied, machine {os.cpu_count()}) on {cpu_model()}"}
     print("CPU_BASELINE " + json.dumps(out), flush=True)
 
 
 def cpu_baseline(workload, width, height, target_s=20.0):
     cores = usable_cores()
-    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="spread", OMP_PLACES="cores")
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="spread", OMP_PLACES="cores", HYDRA_BENCH_AFFINITY=str(len(os.sched_getaffinity(0))))
     for k in list(env):
         if k == "LD_PRELOAD" or k.startswith("ROCP") or k.startswith("HSA_TOOLS"):
             env.pop(k)
@@ -501,6 +501,8 @@ def main():
     args.gpus = world
 
     # ---- build and CPU baseline: before the GPU is initialised in this process --------------------------------------------------------
+    import torch   # imported BEFORE libhydra_hip.so is loaded (build() loads it): the HIP runtime torch bundles must be the one the library binds to;
+    #                importing torch does not initialise the GPU
     import __graft_entry__ as g
     if rank == 0 and not no_build:
         g.build()
@@ -512,7 +514,6 @@ def main():
         H0 = args.height or (1024 if args.workload == "cornell" else 1080)
         cpu = cpu_baseline(args.workload, W0, H0)
 
-    import torch   # imported before the library is loaded: the HIP runtime torch bundles must be the one libhydra_hip.so binds to
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     # HYDRA_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices, the reduce is staged

@@ -50,7 +50,25 @@ out = {"tag": tag, "workload": workload, "bench": bench, "rocprof_kernel_ms_per_
        "hbm_bytes_per_launch": fetch_kb * 2 * 1024 + write_kb * 1024,
        "hbm_bytes_per_launch_raw_fetch": fetch_kb * 1024 + write_kb * 1024,
        "TCC_HIT_sum": w.get("TCC_HIT_sum"), "TCC_MISS_sum": w.get("TCC_MISS_sum")}
-json.dump(out, open(os.path.join(root, "profiles", f"{tag}_summary.json"), "w"), indent=1)
-json.dump({"hbm_bytes_per_launch": out["hbm_bytes_per_launch"], "from": f"profiles/{tag}_summary.json",
+import subprocess
+commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "unknown"
+json.dump({"hbm_bytes_per_launch": out["hbm_bytes_per_launch"], "from": f"profiles/{tag}_summary.json", "commit": commit,
            "paths_per_launch": bench["config"]["paths_per_step"]}, open(os.path.join(root, "profiles", f"traffic_{workload}.json"), "w"))
+# SQ passes (profiles/collect.sh step 4): one PathTraceBlock call at fewer passes; summed over the product kernels of that call
+if glob.glob(os.path.join(src, "pmc_sq1", "*", "*counter_collection.csv")):
+    CALLS = 1
+    sq = dict(pmc("pmc_sq1")); sq.update(pmc("pmc_sq2"))
+    bsq = json.loads(open(os.path.join(src, "bench_line_sq.json")).read())
+    paths = float(bsq["config"]["paths_per_step"])
+    k_ms = float(bsq["roofline"]["kernel_ms"])
+    lane = sq["SQ_THREAD_CYCLES_VALU"] / (64.0 * sq["SQ_ACTIVE_INST_VALU"])
+    clk_ghz = sq.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / (k_ms * 1e6)       # effective shader clock (MI355X_MICROARCH.md, DVFS): sum over 8 XCDs
+    pj = {"workload": workload, "commit": commit, "from": f"gpurun_out/{tag}/pmc_sq1, pmc_sq2 (profiles/collect.sh)", "paths": paths, "kernel_ms": k_ms,
+          "counters": sq, "valu_insts_per_path": sq["SQ_INSTS_VALU"] / paths, "lane_utilisation": round(lane, 4),
+          "valu_busy_at_2p4GHz": round(4.0 * sq["SQ_INSTS_VALU"] / (1024 * 2.4e9 * k_ms * 1e-3), 4),
+          "effective_clock_GHz": round(clk_ghz, 3) if clk_ghz else None,
+          "wait_any_frac": round(sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], 4), "active_inst_frac": round(sq["SQ_ACTIVE_INST_ANY"] / sq["SQ_WAVE_CYCLES"], 4)}
+    json.dump(pj, open(os.path.join(root, "profiles", f"pmc_{workload}.json"), "w"), indent=1)
+    out["pmc"] = pj
+json.dump(out, open(os.path.join(root, "profiles", f"{tag}_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -147,7 +147,7 @@ class HipIntegrator:
         self.params = None
         self.W = self.H = self.N = 0
         if accel_layout:
-            self._chk(self.L.hpt_set_accel_layout(self.h, accel_layout))   # 1 = two-level TLAS/BLAS, 2 = single-level
+            self._chk(self.L.hpt_set_accel_layout(self.h, accel_layout))   # 1 = two-level TLAS/BLAS, 2 = single-level, 3 = triangle sweep (tiny scenes)
         if scene is not None:
             self.LoadScene(scene, params)
 
@@ -343,7 +343,8 @@ class HipIntegrator:
     def accel_info(self):
         out = (C.c_float * 4)()
         self._chk(self.L.hpt_get_accel_info(self.h, out))
-        return {"sah_node_visits": out[0], "inst_tris": int(out[1]), "instances": int(out[2]), "flat": bool(out[3])}
+        return {"sah_node_visits": out[0], "inst_tris": int(out[1]), "instances": int(out[2]), "flat": int(out[3]) == 1,
+                "layout": ("two-level", "flat", "sweep")[int(out[3])]}
 
     def last_schedule(self):
         s, it = C.c_int(0), C.c_uint32(0)

@@ -1286,10 +1286,75 @@ HPT_DEV bool traceRayFlat(const DevScene& S, const V3 wo, const V3 wd, float tne
   return found;
 }
 
+// ---- sweep: no tree at all ----------------------------------------------------------------------------------------------------------------
+// Scenes of a few dozen triangles (the Cornell-box class, hpt_host.hip: SWEEP_MAX_TRIS). A BVH walk keeps a third of a wave's lanes busy
+// there (per-ray trip counts differ, measured 0.31 in the node loop and 0.33 in the triangle loop) and waits on a dependent load every step.
+// Here the WAVE walks the scene instead: instance by instance, triangle by triangle, the same for all 64 lanes, the records fetched with
+// scalar loads through the constant address space (s_load_dwordx4: SGPR operands, no vector memory instruction, no stack, no LDS) and
+// every lane tests its own ray against the wave's triangle - 100 % of the lanes on every instruction. The ray is taken to each
+// instance's object space with the rows the two-level path uses and the triangle test is the shared one, so every hit (t, u, v, ids) is
+// bit-identical to the other layouts: the closest hit does not depend on the order of the tests (ties go to the lower (instId, primId)).
+// DevScene::sweepInsts: per instance {world->object rows, first triangle record, geomId, 0, triangle count}; DevScene::sweepTris: the triangle
+// records per MESH in primitive order (+ one spare record at the end for the read-ahead). The two-level structure stays valid beside them (the wavefront schedule and forced layouts use it).
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+typedef uint  u32x4n __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(4))) const f32x4n cfloat4;          // uniform address + constant address space = scalar load
+typedef __attribute__((address_space(4))) const u32x4n cuint4;
+HPT_DEV float4 ldc4(const cfloat4* p) { const f32x4n v = *p; return make_float4(v.x, v.y, v.z, v.w); }
+// The sweep visits (instance, primitive) pairs in increasing order (DevScene::sweepTris holds each instance's records sorted by primitive
+// id), so the tie rule of triangleTest - at equal distance the lower (instId, primId) wins - reduces to "the first one found stays".
+HPT_DEV void triangleTestInOrder(const float4 a, const float4 b, const float4 c, const V3 o, const V3 d, const float tnear, const uint inst,
+                                 float& bestT, uint& bestPrim, uint& bestInst, float& bestU, float& bestV, bool& found)
+{
+  const V3 e1 = v3(b.x, b.y, b.z), e2 = v3(c.x, c.y, c.z);
+  const V3 pvec = cross(d, e2);
+  const float det = dot(e1, pvec);
+  const float inv = 1.0f / det;
+  const V3 tvec = o - v3(a.x, a.y, a.z);
+  const float uu = dot(tvec, pvec) * inv;
+  const V3 qvec = cross(tvec, e1);
+  const float vv = dot(d, qvec) * inv;
+  const float tt = dot(e2, qvec) * inv;
+  const bool closer = found ? (tt < bestT) : (tt <= bestT);
+  const bool ok = (det != 0.0f) && (uu >= 0.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f) && (tt >= tnear) && closer;
+  if (ok) { bestT = tt; bestPrim = __float_as_uint(a.w); bestInst = inst; bestU = uu; bestV = vv; found = true; }
+}
+
+template <bool ANY, bool STATS>
+HPT_DEV bool traceSweep(const DevScene& S, const V3 wo, const V3 wd, const float tnear, const float tfar, HitRec& hit, TravStats& st)
+{
+  hit.t = tfar; hit.prim = 0xFFFFFFFFu; hit.inst = 0xFFFFFFFFu; hit.u = 0.0f; hit.v = 0.0f;
+  bool found = false;
+  const cfloat4* insts = (const cfloat4*)S.sweepInsts;
+  const cfloat4* tris = (const cfloat4*)S.sweepTris;
+  const uint ni = S.numInsts;
+  for (uint i = 0; i < ni; i++) {
+    const float4 r0 = ldc4(insts + 4u * i + 0u), r1 = ldc4(insts + 4u * i + 1u), r2 = ldc4(insts + 4u * i + 2u);
+    const u32x4n r3 = ((const cuint4*)insts)[4u * i + 3u];                 // {first triangle record, geomId, 0, triangle count}
+    // toObjectSpace (same expressions, same order)
+    const V3 o = v3(r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w, r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w, r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w);
+    const V3 d = v3(r0.x * wd.x + r0.y * wd.y + r0.z * wd.z, r1.x * wd.x + r1.y * wd.y + r1.z * wd.z, r2.x * wd.x + r2.y * wd.y + r2.z * wd.z);
+    if (STATS) st.insts++;
+    const uint first = r3.x, cnt = r3.w;
+    const cfloat4* tp = tris + 3u * first;
+    float4 a = ldc4(tp), b = ldc4(tp + 1), c = ldc4(tp + 2);               // (the array ends with one spare record: the read-ahead below never leaves it)
+    for (uint k = 0; k < cnt; k++) {
+      tp += 3;
+      const float4 na = ldc4(tp), nb = ldc4(tp + 1), nc = ldc4(tp + 2);     // the next record's scalar loads are in flight during this test
+      if (STATS) { st.tris++; if (firstActiveLane()) st.waveTriIters++; }
+      triangleTestInOrder(a, b, c, o, d, tnear, i, hit.t, hit.prim, hit.inst, hit.u, hit.v, found);
+      if (ANY && __ballot(!found) == 0ull) return true;                    // every lane of the wave that traces a ray has its occluder
+      a = na; b = nb; c = nc;
+    }
+  }
+  return found;
+}
+
 // dispatch on the scene's acceleration-structure layout (compile-time: each kernel variant is built for one layout)
-template <bool ANY, bool STATS, bool DEEP, bool FLAT, bool MOTION = false>
+template <bool ANY, bool STATS, bool DEEP, bool FLAT, bool MOTION = false, bool SWEEP = false>
 HPT_DEV bool traceAny(const DevScene& S, const V3 wo, const V3 wd, float tnear, float tfar, HitRec& hit, const TravStack& stk, TravStats& st, const float time = 0.0f)
 {
+  if (SWEEP) return traceSweep<ANY, STATS>(S, wo, wd, tnear, tfar, hit, st);
   if (FLAT) return traceRayFlat<ANY, STATS, DEEP>(S, wo, wd, tnear, tfar, hit, stk, st);      // (moving instances force the two-level layout)
   return traceRay<ANY, STATS, DEEP, MOTION>(S, wo, wd, tnear, tfar, hit, stk, st, time);
 }

@@ -29,7 +29,7 @@ __global__ void initRandomGensKernel(Rng* gens, uint n, uint firstSeed)
 }
 
 // batched RayQuery_NearestHit / RayQuery_AnyHit for the ISceneObject entry points
-template <bool FLAT, bool MOTION = false>
+template <bool FLAT, bool MOTION = false, bool SWEEP = false>
 __global__ void __launch_bounds__(256) rayQueryKernel(const DevScene S, const float4* posNear, const float4* dirFar, uint n, void* out, int anyHit, uint* stackOverflow, float time = 0.0f)
 {
   __shared__ uint stackMem[LDS_STACK * 256];
@@ -39,10 +39,10 @@ __global__ void __launch_bounds__(256) rayQueryKernel(const DevScene S, const fl
   const float4 p = posNear[i], d = dirFar[i];
   HitRec h; TravStats st; st.nodes = st.tris = st.insts = st.waveNodeIters = st.waveTriIters = 0;
   if (anyHit) {
-    const bool occ = traceAny<true, false, true, FLAT, MOTION>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, st, time);
+    const bool occ = traceAny<true, false, true, FLAT, MOTION, SWEEP>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, st, time);
     ((uint*)out)[i] = occ ? 1u : 0u;
   } else {
-    const bool found = traceAny<false, false, true, FLAT, MOTION>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, st, time);
+    const bool found = traceAny<false, false, true, FLAT, MOTION, SWEEP>(S, v3(p.x, p.y, p.z), v3(d.x, d.y, d.z), p.w, d.w, h, stk, st, time);
     // CRT_Hit (CrossRT.h:23-30) as the Embree backend fills it (EmbreeRT.cpp:343-360)
     float4* o = (float4*)out + 2 * (size_t)i;
     if (found) {

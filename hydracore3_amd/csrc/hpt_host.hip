@@ -31,6 +31,10 @@ using namespace hpt;
 // separate the two families (test_228 has more triangles than the smallest interior).
 static const float  HEAVY_SAH_VISITS = 20.0f;
 static const size_t FLAT_AUTO_TRIS = size_t(1) << 12;      // instanced triangles from which the single-level layout is chosen whatever the instance count
+// Tiny scenes (the Cornell-box class): no tree walk at all, the wave sweeps the instances' triangles with scalar loads (hpt_device.h: traceSweep).
+// Cost is linear in the triangle count (one exact triangle test per lane and triangle, ~72 VALU instructions at 100 % lane utilisation) against
+// ~2 450 issue slots per ray of the BVH walk on the Cornell box at 31 % utilisation: the crossover sits around 32 instanced triangles.
+static const size_t SWEEP_MAX_TRIS = 32, SWEEP_MAX_INSTS = 8;
 static const size_t MANY_INSTANCES = 6;                      // instances from which the single-level layout is chosen for light scenes too (see hpt_commit_scene)
 
 namespace {
@@ -79,7 +83,7 @@ struct hpt_ctx
   uint stackNeeded = 0;
 
   // device buffers
-  DevBuf<BvhNode> dNodes; DevBuf<BvhTri> dTris; DevBuf<BvhInst> dInsts;
+  DevBuf<BvhNode> dNodes; DevBuf<BvhTri> dTris; DevBuf<BvhInst> dInsts, dSweepInsts; DevBuf<BvhTri> dSweepTris;
   DevBuf<uint> dTriIndices, dMatIdByPrim, dMatVertOffset, dPackedXY;
   DevBuf<float> dVData, dNormMat;
   DevBuf<int> dRemapInst, dRemapLists;
@@ -174,7 +178,7 @@ extern "C" void hpt_destroy(hpt_ctx* c)
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   (void)hpt_comm_destroy(c);
-  c->dNodes.release(); c->dTris.release(); c->dInsts.release(); c->dTriIndices.release(); c->dMatIdByPrim.release();
+  c->dNodes.release(); c->dTris.release(); c->dInsts.release(); c->dSweepInsts.release(); c->dSweepTris.release(); c->dTriIndices.release(); c->dMatIdByPrim.release();
   c->dMatVertOffset.release(); c->dPackedXY.release(); c->dVData.release(); c->dNormMat.release(); c->dRemapInst.release();
   c->dRemapLists.release(); c->dMaterials.release(); c->dLights.release(); c->dTextures.release(); c->dArrays1f.release(); c->dGens.release();
   c->dQueue.release(); c->dStackOvf.release(); c->dCounters.release(); c->dFrame.release(); c->dRecord.release(); c->dRef.release(); c->dData.release();
@@ -447,7 +451,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
     HIPCHK(c, c->dTris.upload(tris.data(), tris.size()));
     HIPCHK(c, c->dInsts.upload(dinst.data(), dinst.size()));
     c->S.nodes = c->dNodes.p; c->S.tris = c->dTris.p; c->S.insts = c->dInsts.p;
-    c->S.rootRef = tree.rootRef; c->S.numInsts = (uint)ni; c->S.flatMode = 1;
+    c->S.rootRef = tree.rootRef; c->S.numInsts = (uint)ni; c->S.flatMode = 1; c->S.sweep = 0; c->S.sweepInsts = nullptr; c->S.sweepTris = nullptr;
     c->sahVisits = sah_node_visits(tree);
     c->S.nodeMin = c->nodeMinOverride >= 0 ? (uint)c->nodeMinOverride : (c->sahVisits >= HEAVY_SAH_VISITS ? 16u : 0u);
     c->stackNeeded = tree.depth + 1u;
@@ -511,6 +515,26 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
     inverse_rows(c->insts[i].m, dinst[i].row0, dinst[i].row1, dinst[i].row2);
     dinst[i].root = geomRoot[c->insts[i].geomId]; dinst[i].geomId = c->insts[i].geomId; dinst[i].pad0 = c->insts[i].motion ? 1u : 0u; dinst[i].pad1 = 0;
   }
+  // the triangle sweep keeps its own copy of the instance records: {rows, first triangle record, geomId, 0, triangle count}
+  const bool sweep = !c->anyMotion && ni >= 1 && (c->accelLayout == 3 || (c->accelLayout == 0 && instTris <= SWEEP_MAX_TRIS && ni <= SWEEP_MAX_INSTS));
+  if (c->accelLayout == 3 && c->anyMotion) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: moving instances need the two-level layout");
+  if (sweep) {
+    std::vector<uint> geomTriBase(c->geoms.size(), 0u);
+    std::vector<BvhTri> st;                                     // every mesh's records in primitive order
+    for (size_t gi = 0; gi < c->geoms.size(); gi++) {
+      const Geom& g = c->geoms[gi];
+      geomTriBase[gi] = (uint)st.size();
+      const size_t base = st.size();
+      st.resize(base + g.tris.size());
+      for (const BvhTri& t : g.tris) st[base + t.primId] = t;   // g.tris is a permutation of the mesh's primitives (BVH leaf order)
+    }
+    st.push_back(BvhTri());                                     // the spare record traceSweep's read-ahead lands on
+    HIPCHK(c, c->dSweepTris.upload(st.data(), st.size()));
+    std::vector<BvhInst> sw(dinst);
+    for (size_t i = 0; i < ni; i++) { const uint g = c->insts[i].geomId; sw[i].root = geomTriBase[g]; sw[i].pad0 = 0; sw[i].pad1 = (uint)c->geoms[g].tris.size(); }
+    HIPCHK(c, c->dSweepInsts.upload(sw.data(), sw.size()));
+  }
+  c->S.sweep = sweep ? 1u : 0u; c->S.sweepInsts = sweep ? c->dSweepInsts.p : nullptr; c->S.sweepTris = sweep ? c->dSweepTris.p : nullptr;
   {                                                          // object->world rows (3x4) at both keys for the moving instances
     std::vector<float> mo(24 * std::max<size_t>(ni, 1), 0.0f);
     for (size_t i = 0; i < ni; i++) for (int key = 0; key < 2; key++) {
@@ -554,7 +578,8 @@ static int ray_query(hpt_ctx* c, const float* posNear, const float* dirFar, uint
   HIPCHK(c, dout.alloc(outWords));
   const uint blocks = (n + 255) / 256;
   HIPCHK(c, ensureStackOverflow(c, (size_t)blocks * 256));
-  if (c->S.flatMode)     rayQueryKernel<true><<<dim3(blocks), dim3(256), 0, 0>>>(c->S, dp.p, dd.p, n, dout.p, any, c->dStackOvf.p);
+  if (c->S.sweep)        rayQueryKernel<false, false, true><<<dim3(blocks), dim3(256), 0, 0>>>(c->S, dp.p, dd.p, n, dout.p, any, c->dStackOvf.p);
+  else if (c->S.flatMode) rayQueryKernel<true><<<dim3(blocks), dim3(256), 0, 0>>>(c->S, dp.p, dd.p, n, dout.p, any, c->dStackOvf.p);
   else if (c->anyMotion) rayQueryKernel<false, true><<<dim3(blocks), dim3(256), 0, 0>>>(c->S, dp.p, dd.p, n, dout.p, any, c->dStackOvf.p, time);
   else                   rayQueryKernel<false><<<dim3(blocks), dim3(256), 0, 0>>>(c->S, dp.p, dd.p, n, dout.p, any, c->dStackOvf.p);
   HIPCHK(c, hipGetLastError());
@@ -732,7 +757,7 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
     }
     HIPCHK(c, c->dNormMat2.upload(nm2.data(), nm2.size()));
   }
-  c->S.normMat2 = c->dNormMat2.p; c->S.motion = d->normMatrices2Offs ? 1u : 0u; c->S.padMotion = 0;
+  c->S.normMat2 = c->dNormMat2.p; c->S.motion = d->normMatrices2Offs ? 1u : 0u; 
   HIPCHK(c, c->dRemapInst.upload(d->remapInst, 2 * (size_t)d->numInsts));
   {
     std::vector<int> rl(d->allRemapLists ? std::vector<int>(d->allRemapLists, d->allRemapLists + d->allRemapListsLen) : std::vector<int>());
@@ -917,7 +942,8 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr)
 template <bool STATS, bool DR, int NAIVE>
 static void launchPT(const DevScene& S, const Job& job, int blocks, hipStream_t st, bool deep)
 {
-  if (S.flatMode) {
+  if (S.sweep) pathTraceKernel<STATS, DR, NAIVE, false, false, false, true><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
+  else if (S.flatMode) {
     if (deep) pathTraceKernel<STATS, DR, NAIVE, true, true><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
     else      pathTraceKernel<STATS, DR, NAIVE, false, true><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
   } else {
@@ -1478,7 +1504,7 @@ extern "C" int hpt_set_option(hpt_ctx* c, const char* name, int value)
 extern "C" int hpt_get_accel_info(hpt_ctx* c, float out[4])
 {
   if (!c || !out) return HPT_ERR_ARG;
-  out[0] = c->sahVisits; out[1] = (float)c->instTris; out[2] = (float)c->insts.size(); out[3] = c->S.flatMode ? 1.0f : 0.0f;
+  out[0] = c->sahVisits; out[1] = (float)c->instTris; out[2] = (float)c->insts.size(); out[3] = c->S.sweep ? 2.0f : (c->S.flatMode ? 1.0f : 0.0f);
   return HPT_OK;
 }
 extern "C" int hpt_get_schedule(hpt_ctx* c, int* lastSchedule, uint32_t* lastIterations)
@@ -1490,7 +1516,7 @@ extern "C" int hpt_get_schedule(hpt_ctx* c, int* lastSchedule, uint32_t* lastIte
 }
 extern "C" int hpt_set_accel_layout(hpt_ctx* c, int layout)
 {
-  if (!c || layout < 0 || layout > 2) return HPT_ERR_ARG;
+  if (!c || layout < 0 || layout > 3) return HPT_ERR_ARG;
   c->accelLayout = layout; c->accelCommitted = false;
   return HPT_OK;
 }

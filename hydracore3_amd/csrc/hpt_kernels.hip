@@ -20,7 +20,7 @@
 
 namespace hpt {
 
-template <bool STATS, bool DR, int MODE, bool DEEP, bool FLAT, bool MOTION>
+template <bool STATS, bool DR, int MODE, bool DEEP, bool FLAT, bool MOTION, bool SWEEP>
 __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const Job job)
 {
   constexpr bool NAIVE = (MODE == 1), INRAYS = (MODE == 2), LEAN = (MODE == 3);
@@ -113,7 +113,7 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
     // ---- (4) closest hit: kernel_RayTrace2 -> RayQuery_NearestHit ----------------------------------------------------------
     HitRec hit; hit.inst = 0xFFFFFFFFu; hit.prim = 0; hit.t = 0; hit.u = hit.v = 0;
     if (alive) {
-      traceAny<false, STATS, DEEP, FLAT, MOTION>(S, rpos, rdir, 0.0f, HPT_FLT_MAX, hit, stk, st, pathTime);
+      traceAny<false, STATS, DEEP, FLAT, MOTION, SWEEP>(S, rpos, rdir, 0.0f, HPT_FLT_MAX, hit, stk, st, pathTime);
       if (STATS) nRays++;
     }
 
@@ -139,7 +139,7 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
     // ---- (6) shadow rays: RayQuery_AnyHit ---------------------------------------------------------------------------------------
     if (wantShadow) {
       HitRec sh;
-      const bool occluded = traceAny<true, STATS, DEEP, FLAT, MOTION>(S, shPos, shDir, 0.0f, shFar, sh, stk, st, pathTime);
+      const bool occluded = traceAny<true, STATS, DEEP, FLAT, MOTION, SWEEP>(S, shPos, shDir, 0.0f, shFar, sh, stk, st, pathTime);
       if (STATS) { nRays++; nShadow++; }
       if (!occluded) accum = accum + contrib; else if (DR) { recS = v3(0, 0, 0); recdS = v3(0, 0, 0); }
     } else if (DR) { recS = v3(0, 0, 0); recdS = v3(0, 0, 0); }
@@ -222,7 +222,8 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
   template __global__ void pathTraceKernel<STATS, DR, MODE, false, false, false>(const DevScene, const Job); \
   template __global__ void pathTraceKernel<STATS, DR, MODE, true,  false, false>(const DevScene, const Job); \
   template __global__ void pathTraceKernel<STATS, DR, MODE, false, true,  false>(const DevScene, const Job); \
-  template __global__ void pathTraceKernel<STATS, DR, MODE, true,  true,  false>(const DevScene, const Job);
+  template __global__ void pathTraceKernel<STATS, DR, MODE, true,  true,  false>(const DevScene, const Job); \
+  template __global__ void pathTraceKernel<STATS, DR, MODE, false, false, false, true>(const DevScene, const Job);   /* the triangle sweep of tiny scenes */
 #ifndef HPT_INST_GROUP
 #error "compile hpt_kernels.hip with -DHPT_INST_GROUP=1..7"
 #endif

@@ -71,6 +71,8 @@ struct DevScene
   const BvhNode* nodes;
   const BvhTri*  tris;
   const BvhInst* insts;
+  const BvhTri*  sweepTris;       // sweep scenes: triangle records per mesh in PRIMITIVE order (traceSweep's tie rule relies on it), one spare record at the end
+  const BvhInst* sweepInsts;      // sweep scenes: the instance records with root = first triangle record, pad1 = triangle count
   uint           rootRef;
   uint           numInsts;
   uint           nodeMin;         // traversal leaves its inner-node loop when fewer lanes than this still hold an inner node (0: never)
@@ -93,7 +95,7 @@ struct DevScene
   const float*       instMotion;  // 24 floats per instance: object->world rows (3x4) at time 0, then at time 1 (only read for BvhInst::pad0 != 0)
   const float*       normMat2;    // 12 floats per instance: rows of the upper 3x3 of m_normMatrices[m_normMatrices2Offs + i]
   uint               motion;      // m_normMatrices2Offs != 0: a time is drawn per path and normals are interpolated
-  uint               padMotion;
+  uint               sweep;       // 1: the scene is small enough for the wave-uniform triangle sweep (traceSweep); BvhInst::root / pad1 = the instance's triangle range
   // lens simulation (integrator_pt.cpp:78-104, 806-938): m_lines as {curvatureRadius, thickness, eta, apertureRadius}, film side first
   const float4*      lensLines;   // lensCount entries; lensCount = 0: m_enableOpticSim off
   uint               lensCount;

@@ -236,6 +236,23 @@ def test_both_accel_layouts_give_identical_hits_and_images(scene_name):
     assert np.array_equal(two.RayQuery_AnyHit(pos, dr), flat.RayQuery_AnyHit(pos, dr))
     assert np.array_equal(two.render(4), flat.render(4))
     assert np.array_equal(two.random_gens(), flat.random_gens())
+    # the third layout: no tree, the wave sweeps every instance's triangles (scalar loads, 100 % of the lanes); automatic for scenes of
+    # <= 32 instanced triangles such as test_035, forced here on the 8 202 triangles of test_228 as well
+    sweep = HipIntegrator(sc, accel_layout=3)
+    auto = HipIntegrator(sc)
+    assert sweep.accel_info()["layout"] == "sweep" and two.accel_info()["layout"] == "two-level" and flat.accel_info()["layout"] == "flat"
+    assert auto.accel_info()["layout"] == ("sweep" if scene_name == "test_035" else "flat")
+    n = 8000 if scene_name == "test_035" else 1500
+    hs = sweep.RayQuery_NearestHit(pos[:n], dr[:n])
+    assert np.array_equal(ha[:n].view(np.uint8), hs.view(np.uint8))
+    assert np.array_equal(two.RayQuery_AnyHit(pos[:n], dr[:n]), sweep.RayQuery_AnyHit(pos[:n], dr[:n]))
+    dr2 = dr[:n].copy(); dr2[:, 3] = np.random.default_rng(4).uniform(0.5, 12.0, n).astype(np.float32)       # finite tfar: shadow-ray style
+    assert np.array_equal(two.RayQuery_AnyHit(pos[:n], dr2), sweep.RayQuery_AnyHit(pos[:n], dr2))
+    spp = 4 if scene_name == "test_035" else 1
+    t2, s2 = HipIntegrator(sc, accel_layout=1), HipIntegrator(sc, accel_layout=3)
+    assert np.array_equal(t2.render(spp), s2.render(spp))
+    assert np.array_equal(t2.random_gens(), s2.random_gens())
+    assert np.array_equal(t2.render(spp, naive=True), s2.render(spp, naive=True))
 
 
 @pytest.mark.parametrize("scene_name", ["test_035", "test_228", "zoo", "interior"])

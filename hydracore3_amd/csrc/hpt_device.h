@@ -143,7 +143,10 @@ HPT_DEV V3 mapSampleToCosineDistribution(float r1, float r2, V3 direction, V3 hi
   if (power >= 1e6f) return direction;
   const float sin_phi = sinf(HPT_TWOPI * r1);
   const float cos_phi = cosf(HPT_TWOPI * r1);
-  const float cos_theta = powf(1.0f - r2, 1.0f / (power + 1.0f));
+  // pow(x, 1 / (power + 1)): every caller on the path passes power = 1 (Lambert), where the exponent is exactly 0.5 and the correctly rounded
+  // square root is the same function to the last bit or one off it - the distance device powf and glibc powf keep from each other anyway -
+  // at a tenth of the instructions
+  const float cos_theta = (power == 1.0f) ? sqrtf_(1.0f - r2) : powf(1.0f - r2, 1.0f / (power + 1.0f));
   const float sin_theta = sqrtf_(1.0f - cos_theta * cos_theta);
   const V3 dev = v3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
   V3 nx, nz;
@@ -212,8 +215,10 @@ HPT_DEV Taps bilinearTaps(uint w, uint h, uint addrU, uint addrV, V2 uv)
   const float fx = absf(ffx - (float)px), fy = absf(ffy - (float)py);
   const float fx1 = 1.0f - fx, fy1 = 1.0f - fy;
   const int sx = (ffx > 0.0f) ? 1 : -1, sy = (ffy > 0.0f) ? 1 : -1;
-  const int x0 = wrapi(px, (int)w), x1 = wrapi(px + sx, (int)w);
-  const int y0 = wrapi(py, (int)h), y1 = wrapi(py + sy, (int)h);
+  const bool pw = (w & (w - 1u)) == 0u, ph = (h & (h - 1u)) == 0u;
+  int x0, x1, y0, y1;
+  if (pw && ph) { x0 = px & ((int)w - 1); x1 = (px + sx) & ((int)w - 1); y0 = py & ((int)h - 1); y1 = (py + sy) & ((int)h - 1); }   // == wrapi for a power of two (two's complement)
+  else { x0 = wrapi(px, (int)w); x1 = wrapi(px + sx, (int)w); y0 = wrapi(py, (int)h); y1 = wrapi(py + sy, (int)h); }
   Taps r;
   r.off[0] = y0 * (int)w + x0; r.off[1] = y0 * (int)w + x1; r.off[2] = y1 * (int)w + x0; r.off[3] = y1 * (int)w + x1;
   r.w[0] = fx1 * fy1; r.w[1] = fx * fy1; r.w[2] = fx1 * fy; r.w[3] = fx * fy;
@@ -1295,7 +1300,7 @@ HPT_DEV bool traceRayFlat(const DevScene& S, const V3 wo, const V3 wd, float tne
 // instance's object space with the rows the two-level path uses and the triangle test is the shared one, so every hit (t, u, v, ids) is
 // bit-identical to the other layouts: the closest hit does not depend on the order of the tests (ties go to the lower (instId, primId)).
 // DevScene::sweepInsts: per instance {world->object rows, first triangle record, geomId, 0, triangle count}; DevScene::sweepTris: the triangle
-// records per MESH in primitive order (+ one spare record at the end for the read-ahead). The two-level structure stays valid beside them (the wavefront schedule and forced layouts use it).
+// records per MESH in primitive order, padded to an even count with a degenerate record (det = 0: never hit). The two-level structure stays valid beside them (the wavefront schedule and forced layouts use it).
 typedef float f32x4n __attribute__((ext_vector_type(4)));
 typedef uint  u32x4n __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(4))) const f32x4n cfloat4;          // uniform address + constant address space = scalar load
@@ -1330,21 +1335,20 @@ HPT_DEV bool traceSweep(const DevScene& S, const V3 wo, const V3 wd, const float
   const uint ni = S.numInsts;
   for (uint i = 0; i < ni; i++) {
     const float4 r0 = ldc4(insts + 4u * i + 0u), r1 = ldc4(insts + 4u * i + 1u), r2 = ldc4(insts + 4u * i + 2u);
-    const u32x4n r3 = ((const cuint4*)insts)[4u * i + 3u];                 // {first triangle record, geomId, 0, triangle count}
+    const u32x4n r3 = ((const cuint4*)insts)[4u * i + 3u];                 // {first triangle record, geomId, 0, number of record PAIRS}
     // toObjectSpace (same expressions, same order)
     const V3 o = v3(r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w, r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w, r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w);
     const V3 d = v3(r0.x * wd.x + r0.y * wd.y + r0.z * wd.z, r1.x * wd.x + r1.y * wd.y + r1.z * wd.z, r2.x * wd.x + r2.y * wd.y + r2.z * wd.z);
     if (STATS) st.insts++;
-    const uint first = r3.x, cnt = r3.w;
+    const uint first = r3.x, pairs = r3.w;                                 // records come in pairs (the host pads an odd mesh with a record that cannot be hit)
     const cfloat4* tp = tris + 3u * first;
-    float4 a = ldc4(tp), b = ldc4(tp + 1), c = ldc4(tp + 2);               // (the array ends with one spare record: the read-ahead below never leaves it)
-    for (uint k = 0; k < cnt; k++) {
-      tp += 3;
-      const float4 na = ldc4(tp), nb = ldc4(tp + 1), nc = ldc4(tp + 2);     // the next record's scalar loads are in flight during this test
-      if (STATS) { st.tris++; if (firstActiveLane()) st.waveTriIters++; }
-      triangleTestInOrder(a, b, c, o, d, tnear, i, hit.t, hit.prim, hit.inst, hit.u, hit.v, found);
+    for (uint k = 0; k < pairs; k++, tp += 6) {
+      // six scalar loads, one wait: two triangles per trip
+      const float4 a0 = ldc4(tp), b0 = ldc4(tp + 1), c0 = ldc4(tp + 2), a1 = ldc4(tp + 3), b1 = ldc4(tp + 4), c1 = ldc4(tp + 5);
+      if (STATS) { st.tris += 2; if (firstActiveLane()) st.waveTriIters += 2; }
+      triangleTestInOrder(a0, b0, c0, o, d, tnear, i, hit.t, hit.prim, hit.inst, hit.u, hit.v, found);
+      triangleTestInOrder(a1, b1, c1, o, d, tnear, i, hit.t, hit.prim, hit.inst, hit.u, hit.v, found);
       if (ANY && __ballot(!found) == 0ull) return true;                    // every lane of the wave that traces a ray has its occluder
-      a = na; b = nb; c = nc;
     }
   }
   return found;

@@ -515,7 +515,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
     inverse_rows(c->insts[i].m, dinst[i].row0, dinst[i].row1, dinst[i].row2);
     dinst[i].root = geomRoot[c->insts[i].geomId]; dinst[i].geomId = c->insts[i].geomId; dinst[i].pad0 = c->insts[i].motion ? 1u : 0u; dinst[i].pad1 = 0;
   }
-  // the triangle sweep keeps its own copy of the instance records: {rows, first triangle record, geomId, 0, triangle count}
+  // the triangle sweep keeps its own copy of the instance records: {rows, first triangle record, geomId, 0, number of record pairs}
   const bool sweep = !c->anyMotion && ni >= 1 && (c->accelLayout == 3 || (c->accelLayout == 0 && instTris <= SWEEP_MAX_TRIS && ni <= SWEEP_MAX_INSTS));
   if (c->accelLayout == 3 && c->anyMotion) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: moving instances need the two-level layout");
   if (sweep) {
@@ -527,11 +527,12 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
       const size_t base = st.size();
       st.resize(base + g.tris.size());
       for (const BvhTri& t : g.tris) st[base + t.primId] = t;   // g.tris is a permutation of the mesh's primitives (BVH leaf order)
+      if (st.size() & 1u) { BvhTri z; std::memset(&z, 0, sizeof(z)); z.primId = 0xFFFFFFFFu; st.push_back(z); }   // pairs: an all-zero triangle has det == 0 and is never hit
     }
-    st.push_back(BvhTri());                                     // the spare record traceSweep's read-ahead lands on
+    if (st.empty()) st.push_back(BvhTri());
     HIPCHK(c, c->dSweepTris.upload(st.data(), st.size()));
     std::vector<BvhInst> sw(dinst);
-    for (size_t i = 0; i < ni; i++) { const uint g = c->insts[i].geomId; sw[i].root = geomTriBase[g]; sw[i].pad0 = 0; sw[i].pad1 = (uint)c->geoms[g].tris.size(); }
+    for (size_t i = 0; i < ni; i++) { const uint g = c->insts[i].geomId; sw[i].root = geomTriBase[g]; sw[i].pad0 = 0; sw[i].pad1 = (uint)(c->geoms[g].tris.size() + 1) / 2u; }
     HIPCHK(c, c->dSweepInsts.upload(sw.data(), sw.size()));
   }
   c->S.sweep = sweep ? 1u : 0u; c->S.sweepInsts = sweep ? c->dSweepInsts.p : nullptr; c->S.sweepTris = sweep ? c->dSweepTris.p : nullptr;
@@ -1281,6 +1282,7 @@ extern "C" int hpt_put_diff_tex2d(hpt_ctx* c, uint32_t texId, uint32_t w, uint32
   TexRec& t = c->hTextures[texId];
   t.diffOffset = c->gradSize; t.diffW = w; t.diffH = h; t.diffChannels = channels;
   const uint64_t sz = (uint64_t)w * h * channels;
+  if (c->gradSize + sz > (uint64_t(1) << 31)) return c->fail(HPT_ERR_UNSUPPORTED, "PutDiffTex2D: more than 2^31 parameters (the gradient scatter indexes a_dataGrad with 31 bits)");
   *outOffset = c->gradSize; *outSize = sz;
   c->gradSize += sz;
   HIPCHK(c, c->dTextures.upload(c->hTextures.data(), c->hTextures.size()));

@@ -33,6 +33,7 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
   // across the two traversals and the shading code: running framebuffer value, packed (x,y), tid, passes left.
   __shared__ float coldPix[3 * 256];
   __shared__ uint  coldU[3 * 256];
+  __shared__ uint  drStage[DR ? 4 * DR_STAGE_DWORDS : 1];               // PathTraceDR: the waves' staging areas of the cooperative gradient scatter
 #define PIX(k)      coldPix[(k) * 256 + threadIdx.x]
 #define PIX_XY      coldU[0 * 256 + threadIdx.x]
 #define PIX_TID     coldU[1 * 256 + threadIdx.x]
@@ -176,7 +177,7 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
           if (sane) {
             lossLocal += (diff.x * diff.x + diff.y * diff.y + diff.z * diff.z) / float(job.passNum);
             PIX(0) += accum.x; PIX(1) += accum.y; PIX(2) += accum.z;           // out_color += colorRend (:1124-1126)
-            drReverseSweep(S, job.record, job.recordLanes, glane, bounce, tailR + env, diff, job.grad, job.drSkipNonFinite != 0u);
+            drReverseSweep(S, job.record, job.recordLanes, glane, bounce, tailR + env, diff, job.grad, job.drSkipNonFinite != 0u, drStage + (threadIdx.x >> 6) * DR_STAGE_DWORDS);
           }
         } else {
           // kernel_ContributeToImage (integrator_pt.cpp:598-657)

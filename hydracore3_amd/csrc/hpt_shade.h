@@ -450,37 +450,65 @@ HPT_DEV void drClearShadowTerm(float* record, size_t s, size_t idx, uint bounce)
 // Hand-derived reverse sweep replacing __enzyme_autodiff (integrator_dr.cpp:1172-1183). With T_0 = 1, T_{b+1} = T_b A_b and
 // C = sum_b T_b S_b + T_n tail:  dC/dtex_b = T_b dS_b + T_b dA_b R_{b+1},  R_b = S_b + A_b R_{b+1},  R_n = tail;  the loss gradient
 // 2 (C - ref) dC/dtex_b is scattered to the four bilinear taps with float atomics.
-HPT_DEV void drReverseSweep(const DevScene& S, const float* record, size_t s, size_t idx, uint bounce, V3 Rn, V3 diff, float* grad, const bool skipNonFinite)
+//
+// The scatter is wave-cooperative. Float atomics execute at the memory side, one request per 64-byte line an instruction touches
+// (MI355X_MICROARCH.md, "Global float atomics": 64 lanes in 64 different rows run 17x below the contiguous rate), and a lane's own 12
+// adds - 4 taps x rgb - sit in two or three lines (rgb of a texel are adjacent, the taps of one row of the footprint usually are). Issued
+// lane by lane they were 12 instructions of up to 64 lines each. Here the lanes that have a gradient at this bounce stage their 12 values
+// and 4 element indices in LDS ([16][64] dwords per wave) and ALL lanes of the wave that are in the sweep then walk the staged pairs in
+// order - consecutive lanes take consecutive (tap, channel) elements of one source lane - so an instruction touches ~5x fewer lines, and
+// lanes without a gradient of their own help those that have one. `stage`: the wave's 1024-dword LDS area. Same sums, another order.
+static const uint DR_STAGE_DWORDS = 16u * 64u;
+HPT_DEV void drReverseSweep(const DevScene& S, const float* record, size_t s, size_t idx, uint bounce, V3 Rn, V3 diff, float* grad, const bool skipNonFinite, uint* stage)
 {
-  for (int b = (int)bounce - 1; b >= 0; b--) {
+  const unsigned long long am = __ballot(true);                           // the lanes in this sweep (their paths ended in this trip)
+  const uint ne = (uint)__popcll(am), ra = mbcnt64(am);
+  for (int b = (int)S.traceDepth - 1; b >= 0; b--) {                      // wave-uniform trip count; a lane joins at its own last bounce
+    const bool mine = (uint)b < bounce;
+    V3 A = v3(0, 0, 0), Sb = v3(0, 0, 0);
+    uint texId = 0xFFFFFFFFu;
     const float* r = record + ((size_t)b * REC_FIELDS) * s + idx;
-    const V3 A = v3(r[0 * s], r[1 * s], r[2 * s]), Sb = v3(r[3 * s], r[4 * s], r[5 * s]);
-    const uint texId = __float_as_uint(r[12 * s]);
-    if (texId != 0xFFFFFFFFu) {
-      const V3 TdA = v3(r[6 * s], r[7 * s], r[8 * s]), TdS = v3(r[9 * s], r[10 * s], r[11 * s]);
-      const V3 dC = TdS + TdA * Rn;
-      V3 g = v3(2.0f * diff.x * dC.x, 2.0f * diff.y * dC.y, 2.0f * diff.z * dC.z);
-      if (skipNonFinite && !__builtin_isfinite(g.x + g.y + g.z)) g = v3(0, 0, 0);   // (only with dr_skip_nonfinite: the reference scatters whatever comes out)
-      const TexRec t = S.textures[texId];
-      float* gbase = grad + t.diffOffset;
-      for (int k = 0; k < 4; k++) {
-        const int off = __float_as_int(r[(13 + k) * s]);
-        const float w = r[(17 + k) * s];
-#ifdef HPT_DR_SKIP_FIRST_BOUNCE   // diagnostic build only: the share of the scatter that the camera-visible vertex (same texels for every sample of a pixel) accounts for
-        if (b == 0) { if (off < -1) gbase[0] = g.x * w; continue; }
-#endif
-#ifdef HPT_DR_NO_ATOMICS    // diagnostic build only: how much of PathTraceDR is the gradient scatter?
-        if (off < -1) gbase[0] = g.x * w;
-        continue;
-#endif
-        if (t.diffChannels == 4) {
-          atomicAdd(gbase + (size_t)off * 4 + 0, g.x * w);
-          atomicAdd(gbase + (size_t)off * 4 + 1, g.y * w);
-          atomicAdd(gbase + (size_t)off * 4 + 2, g.z * w);
-        } else atomicAdd(gbase + off, (g.x + g.y + g.z) * w);
+    if (mine) { A = v3(r[0 * s], r[1 * s], r[2 * s]); Sb = v3(r[3 * s], r[4 * s], r[5 * s]); texId = __float_as_uint(r[12 * s]); }
+    const bool has = mine && texId != 0xFFFFFFFFu;
+    const unsigned long long hm = __ballot(has);
+    if (hm != 0ull) {
+      const uint n = (uint)__popcll(hm), rk = mbcnt64(hm);
+      if (has) {
+        const V3 TdA = v3(r[6 * s], r[7 * s], r[8 * s]), TdS = v3(r[9 * s], r[10 * s], r[11 * s]);
+        const V3 dC = TdS + TdA * Rn;
+        V3 g = v3(2.0f * diff.x * dC.x, 2.0f * diff.y * dC.y, 2.0f * diff.z * dC.z);
+        if (skipNonFinite && !__builtin_isfinite(g.x + g.y + g.z)) g = v3(0, 0, 0);   // (only with dr_skip_nonfinite: the reference scatters whatever comes out)
+        const TexRec t = S.textures[texId];
+        const bool four = t.diffChannels == 4;
+        for (int k = 0; k < 4; k++) {
+          const uint off = (uint)__float_as_int(r[(13 + k) * s]);
+          const float w = r[(17 + k) * s];
+          // element index of the tap's first float in a_dataGrad (bit 31: a one-channel texture, its sum goes to that single float)
+          stage[(12 + k) * 64 + rk] = four ? (uint)t.diffOffset + off * 4u : (((uint)t.diffOffset + off) | 0x80000000u);
+          float* sv = (float*)stage;
+          sv[(3 * k + 0) * 64 + rk] = four ? g.x * w : (g.x + g.y + g.z) * w;
+          sv[(3 * k + 1) * 64 + rk] = g.y * w;
+          sv[(3 * k + 2) * 64 + rk] = g.z * w;
+        }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (uint p = ra; p < 12u * n; p += ne) {
+        const uint src = (p * 0xAAABu) >> 19;                             // p / 12 (p < 768)
+        const uint e = p - 12u * src, tap = (e * 11u) >> 5, ch = e - 3u * tap;   // e / 3, e % 3 (e < 12)
+        const uint ix = stage[(12 + tap) * 64 + src];
+        const float val = ((const float*)stage)[e * 64 + src];
+#ifndef HPT_DR_NO_ATOMICS    // diagnostic build only: how much of PathTraceDR is the gradient scatter?
+        if ((ix & 0x80000000u) == 0u) atomicAdd(grad + (size_t)ix + ch, val);
+        else if (ch == 0u) atomicAdd(grad + (size_t)(ix & 0x7FFFFFFFu), val);
+#else
+        if (ix == 0x7FFFFFFFu) grad[0] = val;
+#endif
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    Rn = Sb + A * Rn;
+    if (mine) Rn = Sb + A * Rn;
   }
 }
 

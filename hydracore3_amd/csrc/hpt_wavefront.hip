@@ -60,6 +60,7 @@ HPT_DEV void blockAppend(uint* counter, bool qNear, bool qShad, uint& posNear, u
 template <bool DR, bool LEAN>
 __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const WfPool P, const WfJob job)
 {
+  __shared__ uint drStage[DR ? 4 * DR_STAGE_DWORDS : 1];                   // the waves' staging areas of the cooperative gradient scatter (drReverseSweep)
   const uint s = blockIdx.x * 256u + threadIdx.x;
   uint* ctr = P.ctr + WF_CTR_WORDS * (job.iter & 1u);
   if (s <= WF_RANGES) P.ctr[WF_CTR_WORDS * ((job.iter + 1u) & 1u) + 32u * s] = 0u;   // counters of the NEXT round (its trace pass is long done)
@@ -132,7 +133,7 @@ __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const W
         P.lossSlot[s] += (diff.x * diff.x + diff.y * diff.y + diff.z * diff.z) / float(job.passNum);
         float* o = job.outColor + ((size_t)y * (uint)S.winWidth + x) * job.channels;
         o[0] += accum.x; o[1] += accum.y; o[2] += accum.z;
-        drReverseSweep(S, job.record, job.itemCount, s, bounce, tailR + env, diff, job.grad, job.drSkipNonFinite != 0u);
+        drReverseSweep(S, job.record, job.itemCount, s, bounce, tailR + env, diff, job.grad, job.drSkipNonFinite != 0u, drStage + (threadIdx.x >> 6) * DR_STAGE_DWORDS);
       }
     } else if (finalize) {                                                   // kernel_ContributeToImage (integrator_pt.cpp:598-657)
       const uint pixel = ((XY & 0xFFFF0000u) >> 16) * (uint)S.winWidth + (XY & 0x0000FFFFu);

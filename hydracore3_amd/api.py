@@ -47,6 +47,7 @@ ABI = {
     "hpt_update_params": (_i, [_vp, C.POINTER(Params)]),
     "hpt_update_materials": (_i, [_vp, _sz, _sz, _vp]),
     "hpt_update_lights": (_i, [_vp, _sz, _sz, _vp]),
+    "hpt_update_mat_id_offsets": (_i, [_vp, _vp, _sz]),
     "hpt_pack_xy": (_i, [_vp, _u32, _u32]),
     "hpt_get_packed_xy": (_i, [_vp, _vp, _u32]),
     "hpt_init_random_gens": (_i, [_vp, _u32]),
@@ -211,6 +212,11 @@ class HipIntegrator:
     def Update_m_lights(self, first, lights):
         lights = np.ascontiguousarray(lights)
         self._chk(self.L.hpt_update_lights(self.h, first, lights.size, lights.ctypes.data))
+
+    def Update_m_matIdOffsets(self, mat_vert_offset):
+        """Integrator::Update_m_matIdOffsets (integrator_pt.h:470): re-upload m_matVertOffset (uint32 [numGeoms, 2])."""
+        mvo = np.ascontiguousarray(mat_vert_offset, np.uint32)
+        self._chk(self.L.hpt_update_mat_id_offsets(self.h, mvo.ctypes.data, mvo.size // 2))
 
     # ---- the hot path -----------------------------------------------------------------------------------------------
     def PathTraceBlock(self, tid, channels, out_color, a_passNum, tid_begin=0):

@@ -96,6 +96,7 @@ struct hpt_ctx
   bool anyMotion = false;                                // some instance moves: two-level layout, megakernel schedule, MOTION kernels
   std::vector<MaterialRec> hMaterials;                   // host mirror of m_materials: the blend graph is validated as a whole
   std::vector<uint> hLightGeom;                          // geomType of every light, to validate m_envLightId
+  std::vector<uint> hTriIndices;                         // host mirror of m_triIndices: Update_m_matIdOffsets re-validates the vertex indices a mesh will read
   bool envLightOk(uint id) const { return id < hLightGeom.size() && hLightGeom[id] == LIGHT_GEOM_ENV; }
   DevBuf<Rng> dGens;
   DevBuf<uint> dQueue, dStackOvf; DevBuf<Counters> dCounters;
@@ -734,6 +735,7 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
   if (d->numInsts != c->insts.size()) return c->fail(HPT_ERR_ARG, "scene tables and acceleration structure disagree on the instance count");
 
   HIPCHK(c, c->dTriIndices.upload(d->triIndices, 3 * (size_t)d->numTris));
+  c->hTriIndices.assign(d->triIndices, d->triIndices + 3 * (size_t)d->numTris);
   HIPCHK(c, c->dVData.upload(d->vData8f, 8 * (size_t)d->numVerts));
   HIPCHK(c, c->dMatIdByPrim.upload(d->matIdByPrimId, d->numTris));
   HIPCHK(c, c->dMatVertOffset.upload(d->matVertOffset, 2 * (size_t)d->numGeoms));
@@ -876,6 +878,26 @@ extern "C" int hpt_update_lights(hpt_ctx* c, size_t first, size_t count, const v
   for (size_t i = 0; i < count; i++) c->hLightGeom[first + i] = ((const LightRec*)lights)[i].geomType;
   (void)hipSetDevice(c->device);
   HIPCHK(c, hipMemcpy(c->dLights.p + first, lights, count * sizeof(LightRec), hipMemcpyHostToDevice));
+  return HPT_OK;
+}
+
+// Update_m_matIdOffsets (integrator_pt.h:470): m_matVertOffset changed on the host
+extern "C" int hpt_update_mat_id_offsets(hpt_ctx* c, const uint32_t* mvo, size_t numGeoms)
+{
+  if (!c || !mvo) return HPT_ERR_ARG;
+  if (!c->sceneUploaded) return c->fail(HPT_ERR_STATE, "Update_m_matIdOffsets before CommitDeviceData");
+  if (2 * numGeoms != c->dMatVertOffset.n) return c->fail(HPT_ERR_ARG, "Update_m_matIdOffsets: geometry count differs from the committed scene");
+  const size_t numTris = c->dMatIdByPrim.n, numVerts = c->dVData.n / 8;
+  for (size_t g = 0; g < numGeoms; g++) {                     // every mesh's range must stay inside the uploaded tables (the kernels index them unchecked)
+    const size_t nt = g < c->geoms.size() ? c->geoms[g].idx.size() / 3 : 0;
+    if (mvo[2 * g] > numTris || mvo[2 * g + 1] > numVerts || (size_t)mvo[2 * g] + nt > numTris)
+      return c->fail(HPT_ERR_ARG, "Update_m_matIdOffsets: geometry " + std::to_string(g) + " reaches past the tables");
+    for (size_t t = 3 * (size_t)mvo[2 * g]; t < 3 * ((size_t)mvo[2 * g] + nt) && t < c->hTriIndices.size(); t++)
+      if ((size_t)c->hTriIndices[t] + mvo[2 * g + 1] >= numVerts)
+        return c->fail(HPT_ERR_ARG, "Update_m_matIdOffsets: geometry " + std::to_string(g) + " reaches past the tables (vertex index)");
+  }
+  (void)hipSetDevice(c->device);
+  HIPCHK(c, hipMemcpy(c->dMatVertOffset.p, mvo, 2 * numGeoms * sizeof(uint32_t), hipMemcpyHostToDevice));
   return HPT_OK;
 }
 

@@ -65,8 +65,11 @@ public:
   { CRT_Hit h; std::memset(&h, 0xFF, sizeof(h)); hpt_ray_query_nearest(m_ctx, posAndNear, dirAndFar, 1, reinterpret_cast<hpt_hit*>(&h)); return h; }
   bool     RayQuery_AnyHit(const float posAndNear[4], const float dirAndFar[4])
   { uint32_t r = 0; hpt_ray_query_any(m_ctx, posAndNear, dirAndFar, 1, &r); return r != 0; }
-  CRT_Hit  RayQuery_NearestHitMotion(const float p[4], const float d[4], float /*time*/) { return RayQuery_NearestHit(p, d); }   // static scenes
-  bool     RayQuery_AnyHitMotion(const float p[4], const float d[4], float /*time*/ = 0.0f) { return RayQuery_AnyHit(p, d); }
+  // the *Motion forms (CrossRT.h:157,174): moving instances are evaluated at `time` in [0, 1]
+  CRT_Hit  RayQuery_NearestHitMotion(const float p[4], const float d[4], float time)
+  { CRT_Hit h; std::memset(&h, 0xFF, sizeof(h)); hpt_ray_query_nearest_motion(m_ctx, p, d, 1, time, reinterpret_cast<hpt_hit*>(&h)); return h; }
+  bool     RayQuery_AnyHitMotion(const float p[4], const float d[4], float time = 0.0f)
+  { uint32_t r = 0; hpt_ray_query_any_motion(m_ctx, p, d, 1, time, &r); return r != 0; }
 private:
   hpt_ctx* m_ctx;
 };
@@ -117,7 +120,8 @@ public:
     }
     std::vector<uint32_t> instGeom(m_instGeomId);
     hpt_scene_desc d; std::memset(&d, 0, sizeof(d));
-    d.numGeoms = uint32_t(m_matVertOffset.size() / 2); d.numInsts = uint32_t(m_normMatrices.size());
+    // with motion blur m_normMatrices holds a second half for the end of the motion, starting at m_normMatrices2Offs (= the instance count)
+    d.numGeoms = uint32_t(m_matVertOffset.size() / 2); d.numInsts = m_normMatrices2Offs ? m_normMatrices2Offs : uint32_t(m_normMatrices.size());
     d.numVerts = uint32_t(m_vData8f.size() / 8); d.numTris = uint32_t(m_matIdByPrimId.size());
     d.vPos4f = nullptr;                                                    // geometry went in through m_pAccelStruct (LoadSceneGeometry)
     d.vData8f = m_vData8f.data(); d.triIndices = m_triIndices.data(); d.matIdByPrimId = m_matIdByPrimId.data();
@@ -128,6 +132,8 @@ public:
     d.materials = m_materials.data(); d.numMaterials = uint32_t(m_materials.size());
     d.lights = m_lights.data(); d.numLights = uint32_t(m_lights.size());
     d.textures = td.data(); d.numTextures = uint32_t(td.size());
+    d.arrays1f = m_arrays1f.empty() ? nullptr : m_arrays1f.data(); d.numArrays1f = uint32_t(m_arrays1f.size());   // pdf table of a sampled environment map, plastic tables
+    d.normMatrices2Offs = m_normMatrices2Offs;                              // the moving instances themselves went in through AddInstanceMotion
     report(hpt_upload_scene(m_ctx, &d), "CommitDeviceData");
     if (m_randomGensInit != m_maxThreadId) { hpt_init_random_gens(m_ctx, m_maxThreadId); m_randomGensInit = m_maxThreadId; }   // InitRandomGens
   }
@@ -168,6 +174,7 @@ public:
   virtual void GetExecutionTime(const char* a_funcName, float a_out[4]) { if (m_ctx) hpt_get_execution_time(m_ctx, a_funcName, a_out); }
   virtual void Update_m_materials(size_t a_first, size_t a_count) { if (m_ctx) report(hpt_update_materials(m_ctx, a_first, a_count, m_materials.data() + a_first), "Update_m_materials"); }
   virtual void Update_m_lights(size_t a_first, size_t a_count) { if (m_ctx) report(hpt_update_lights(m_ctx, a_first, a_count, m_lights.data() + a_first), "Update_m_lights"); }
+  virtual void Update_m_matIdOffsets() { if (m_ctx) report(hpt_update_mat_id_offsets(m_ctx, m_matVertOffset.data(), m_matVertOffset.size() / 2), "Update_m_matIdOffsets"); }   // integrator_pt.h:470
   virtual void SceneRestrictions(uint32_t a_restrictions[4]) const
   { a_restrictions[0] = 1u << 20; a_restrictions[1] = 1u << 27; a_restrictions[2] = (1u << 28) - 1u; a_restrictions[3] = (1u << 28) - 1u; }   // 28-bit triangle references
 
@@ -180,6 +187,8 @@ public:
   std::vector<int>         m_allRemapLists, m_remapInst;   // m_remapInst: int2 per instance
   uint32_t                 m_allRemapListsSize = 0;
   std::vector<float4x4>    m_normMatrices;
+  uint32_t                 m_normMatrices2Offs = 0;   // integrator_pt.h:498: where the end-of-motion normal matrices start (0: no motion blur)
+  std::vector<float>       m_arrays1f;                // integrator_pt.h:485
   std::vector<uint32_t>    m_instGeomId;
   std::vector<TextureData> m_textures;
   BVH2SceneHIP*            m_pAccelStruct = nullptr;

@@ -152,6 +152,9 @@ int  hpt_upload_scene(hpt_ctx* ctx, const hpt_scene_desc* desc);
 int  hpt_update_params(hpt_ctx* ctx, const hpt_params* params);                          /* UpdateMembersPlainData :268 */
 int  hpt_update_materials(hpt_ctx* ctx, size_t first, size_t count, const void* mats);   /* Update_m_materials     :468 */
 int  hpt_update_lights(hpt_ctx* ctx, size_t first, size_t count, const void* lights);    /* Update_m_lights        :469 */
+/* Update_m_matIdOffsets() (integrator_pt.h:470): re-upload m_matVertOffset (uint2 x numGeoms: first triangle / first vertex of every mesh in
+ * m_matIdByPrimId / m_triIndices and m_vData8f) after the host changed it; the ranges are checked against the uploaded tables. */
+int  hpt_update_mat_id_offsets(hpt_ctx* ctx, const uint32_t* matVertOffset, size_t numGeoms);
 int  hpt_pack_xy(hpt_ctx* ctx, uint32_t tidX, uint32_t tidY);                            /* PackXYBlock (integrator_pt_host.cpp:19-27) */
 int  hpt_get_packed_xy(hpt_ctx* ctx, uint32_t* out, uint32_t count);
 int  hpt_init_random_gens(hpt_ctx* ctx, uint32_t maxThreads);                            /* InitRandomGens (integrator_pt.cpp:13-21) */
@@ -216,17 +219,21 @@ int  hpt_set_instrumentation(hpt_ctx* ctx, int enabled);
 int  hpt_get_counters(hpt_ctx* ctx, uint64_t out[16]);
 /* Launch geometry of the persistent kernel: blocks per CU (0 = automatic). */
 int  hpt_set_launch_config(hpt_ctx* ctx, int blocksPerCU);
-/* Acceleration-structure layout chosen at the next hpt_commit_scene: 0 = automatic (one world-space BVH2 over all instanced triangles
- * when the scene is static and small enough, else two-level), 1 = force the two-level TLAS/BLAS layout, 2 = force the single-level one.
- * Both layouts intersect triangles in object space and return bit-identical hits. */
+/* Acceleration-structure layout chosen at the next hpt_commit_scene: 0 = automatic (the triangle sweep for scenes of <= 32 instanced
+ * triangles, one world-space BVH2 over all instanced triangles for heavy static scenes, scenes from 4 096 instanced triangles and scenes of
+ * six or more instances, else two-level), 1 = force the two-level TLAS/BLAS layout, 2 = force the single-level one, 3 = force the sweep
+ * (no tree: every wave tests every triangle, fetched with scalar loads; cost linear in the triangle count).
+ * All layouts intersect triangles in object space with the same arithmetic and return bit-identical hits. */
 int  hpt_set_accel_layout(hpt_ctx* ctx, int layout);
 /* How hpt_path_trace_block(_dev) schedules the work: 1 = one persistent megakernel (a lane keeps its path from camera to end),
  * 2 = wavefront (a shade kernel and a persistent trace kernel with ballot/prefix-sum ray compaction and ray replacement, path state
- * in HBM), 0 = automatic (wavefront for scenes of >= 2^17 instanced triangles). Both give bit-identical frames. refillBelow (1..64,
+ * in HBM), 0 = automatic: wavefront when the committed BVH is expected to cost a ray >= 20 inner-node visits (hpt_get_accel_info's
+ * surface-area estimate) and the call has >= 2^19 pixels, else the megakernel. Both give bit-identical frames. refillBelow (1..64,
  * 0 = keep): a trace wave refills from the ray queue when fewer lanes than this still hold a ray; traceBlocksPerCU 0 = automatic.
  * groups (0 = automatic): the pixels of a call are cut into this many groups with their own path pool, ray queue and HIP stream, so
  * that the tail of one group's trace pass (a few long rays) overlaps the other groups' shade and trace passes.
- * The naive and differentiable integrators always use the megakernel. The wavefront call returns once the frame is nearly done
+ * The naive integrator, input-ray batches and scenes with moving instances always use the megakernel; PathTraceDR follows the same
+ * automatic choice as PathTraceBlock (its wavefront form keeps the adjoint records per pool slot). The wavefront call returns once the frame is nearly done
  * (it polls a device progress word); results are complete after the stream is synchronised, as for the megakernel. */
 int  hpt_set_schedule(hpt_ctx* ctx, int schedule, int refillBelow, int traceBlocksPerCU, int groups);
 /* Tuning knobs without a place in the reference's interface (results never depend on them):
@@ -235,6 +242,9 @@ int  hpt_set_schedule(hpt_ctx* ctx, int schedule, int refillBelow, int traceBloc
  *               Only applied in rounds with at least 2 rays per lane of the trace grid.
  *   "node_min"  voted exit of the inner-node loop (0..63, applied at the next hpt_commit_scene; default chosen per scene).
  * Diagnostic switches (these DO change which kernels run or what they compute; never set in production):
+ *   "dr_skip_nonfinite"     PathTraceDR: 1 = a sample whose radiance is not finite contributes neither colour, loss nor gradient (what an
+ *                           optimisation loop wants: one NaN poisons Adam's moments for good); 0 (default) = PixelLossPT as the reference
+ *                           has it, which adds every sample (diff_render/integrator_dr.cpp:1124-1131)
  *   "force_full_materials"  1: never pick the kernels specialised for gltf + emissive scenes (kernel studies)
  *   "dbg_no_normal_lerp"    1: moving instances without the reference's normal interpolation (integrator_pt.cpp:285-292); the checker has the
  *                           same switch (ORC_DBG_NO_NORMAL_LERP) - used to show where the rare path divergences under motion blur come from */
@@ -252,7 +262,7 @@ int  hpt_reduce_framebuffer(hpt_ctx* ctx, float* frameDev, size_t count, int roo
 int  hpt_allreduce_grad(hpt_ctx* ctx, float* gradDev, size_t count, void* stream);
 /* Schedule the last hpt_path_trace_block(_dev) call used (1 / 2) and, for the wavefront one, its number of shade+trace rounds. */
 /* What CommitScene built: out[0] = expected inner-node visits per ray (surface-area estimate over the committed BVH; the quantity the automatic
- * schedule / layout choice is measured against), out[1] = instanced triangles, out[2] = instances, out[3] = 1 for the single-level layout. */
+ * schedule / layout choice is measured against), out[1] = instanced triangles, out[2] = instances, out[3] = layout (0 two-level, 1 single-level, 2 triangle sweep). */
 int  hpt_get_accel_info(hpt_ctx* ctx, float out[4]);
 int  hpt_get_schedule(hpt_ctx* ctx, int* lastSchedule, uint32_t* lastIterations);
 /* Duration of the last path-tracing kernel, measured with HIP events on the stream it ran on (ms). */

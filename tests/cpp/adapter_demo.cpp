@@ -6,14 +6,76 @@
 #include <cmath>
 #include <cstdio>
 #include <vector>
-#include "../../hydracore3_amd/csrc/integrator_hip.h"
+#include <cstdlib>
+#include <string>
+#include "../../hydracore3_amd/csrc/scene_loader.h"        // (brings integrator_hip.h): only to READ a Hydra XML scene into plain tables
 
 using namespace hydra_hip;
 
+// adapter_demo <scene.xml> <width> <height> <spp> <out.bin>: a whole Hydra scene through the ADAPTER CLASSES only - geometry and (moving)
+// instances through BVH2SceneHIP (AddGeom_Triangles3f / AddInstance / AddInstanceMotion / CommitScene), the scene vectors through the
+// Integrator-named members (m_materials ... m_arrays1f, m_normMatrices + m_normMatrices2Offs, the m_env* ids), then CommitDeviceData,
+// PackXYBlock, UpdateMembersPlainData, PathTraceBlock - the calls main.cpp makes. The test compares the frame with the ctypes front end.
+static int renderScene(const char* xml, int W, int H, int spp, const char* out)
+{
+  LoadedScene sc; std::string err;
+  if (!LoadHydraXml(xml, W, H, sc, err)) { std::printf("adapter_demo: %s\n", err.c_str()); return 1; }
+  IntegratorHIP integ(W * H, 0);
+  if (!integ.valid()) { std::printf("adapter_demo: no GPU\n"); return 2; }
+  BVH2SceneHIP* acc = integ.m_pAccelStruct;
+  acc->ClearGeom();
+  for (size_t g = 0; g < sc.geomTriCount.size(); g++) {                    // LoadSceneGeometry (integrator_pt_scene.cpp:790-846)
+    const uint32_t triOff = sc.matVertOffset[2 * g], vertOff = sc.matVertOffset[2 * g + 1];
+    acc->AddGeom_Triangles3f(sc.vPos4f.data() + 4 * size_t(vertOff), sc.geomVertCount[g], sc.triIndices.data() + 3 * size_t(triOff), 3 * size_t(sc.geomTriCount[g]), 4, 16);
+  }
+  acc->ClearScene();
+  for (size_t i = 0; i < sc.instGeomId.size(); i++) {                       // LoadSceneInstances (:848-897)
+    float4x4 two[2]; std::memcpy(two[0].m, sc.instMatrices.data() + 16 * i, 64);
+    if (sc.normMatrices2Offs && sc.instHasMotion[i]) { std::memcpy(two[1].m, sc.instMatricesMotion.data() + 16 * i, 64); acc->AddInstanceMotion(sc.instGeomId[i], two, 2); }
+    else acc->AddInstance(sc.instGeomId[i], two[0]);
+  }
+  acc->CommitScene();
+  integ.m_matVertOffset = sc.matVertOffset; integ.m_matIdByPrimId = sc.matIdByPrimId; integ.m_triIndices = sc.triIndices; integ.m_vData8f = sc.vData8f;
+  integ.m_normMatrices.resize(sc.normMatrices.size() / 16); std::memcpy(integ.m_normMatrices.data(), sc.normMatrices.data(), sc.normMatrices.size() * 4);
+  integ.m_normMatrices2Offs = sc.normMatrices2Offs;
+  integ.m_instGeomId = sc.instGeomId; integ.m_remapInst.assign(sc.remapInst.begin(), sc.remapInst.end());
+  integ.m_allRemapLists.assign(sc.allRemapLists.begin(), sc.allRemapLists.end()); integ.m_allRemapListsSize = sc.allRemapListsSize;
+  integ.m_materials = sc.materials; integ.m_lights = sc.lights; integ.m_arrays1f = sc.arrays1f;
+  integ.m_textures.clear();
+  for (const LoadedTexture& t : sc.textures) { TextureData d; d.width = t.width; d.height = t.height; d.format = t.format; d.flags = t.flags; d.addressU = t.addressU; d.addressV = t.addressV; d.filter = t.filter; d.texels = t.bytes; integ.m_textures.push_back(d); }
+  const hpt_params p = sc.params();
+  float4x4 pi, wv; std::memcpy(pi.m, p.projInv, 64); std::memcpy(wv.m, p.worldViewInv, 64);
+  integ.SetProjInv(pi); integ.SetWorldViewInv(wv);
+  integ.m_traceDepth = p.traceDepth; integ.SetIntegratorType(p.integratorType); integ.m_camTargetDist = p.camTargetDist;
+  std::memcpy(integ.m_envColor, p.envColor, 16);
+  integ.m_envTexId = p.envTexId; integ.m_envLightId = p.envLightId; integ.m_envCamBackId = p.envCamBackId; integ.m_envEnableSam = p.envEnableSam;
+  std::memcpy(integ.m_envSamRow0, p.envSamRow0, 16); std::memcpy(integ.m_envSamRow1, p.envSamRow1, 16);
+  if (!sc.lensLines.empty()) {
+    std::vector<IntegratorHIP::LensElementInterface> lines(sc.lensLines.size() / 4);
+    std::memcpy(lines.data(), sc.lensLines.data(), sc.lensLines.size() * 4);
+    integ.SetLines(lines); integ.SetPhysSize(sc.physSize[0], sc.physSize[1]); integ.m_enableOpticSim = 1;
+  }
+  integ.SetFrameBufferSize(W, H); integ.SetViewport(0, 0, W, H);
+  integ.CommitDeviceData();
+  integ.PackXYBlock(W, H, 1);
+  integ.UpdateMembersPlainData();
+  std::vector<float> frame(size_t(W) * H * 4, 0.0f);
+  integ.PathTraceBlock(W * H, 4, frame.data(), spp);
+  // the ISceneObject queries answer through the same object, *Motion forms at the ray's time
+  const float o[4] = { float(sc.camPos[0]), float(sc.camPos[1]), float(sc.camPos[2]), 0.0f };
+  const float d[4] = { float(sc.camLookAt[0] - sc.camPos[0]), float(sc.camLookAt[1] - sc.camPos[1]), float(sc.camLookAt[2] - sc.camPos[2]), 1e30f };
+  const CRT_Hit h0 = acc->RayQuery_NearestHitMotion(o, d, 0.0f), h1 = acc->RayQuery_NearestHitMotion(o, d, 1.0f);
+  std::printf("adapter_demo: %s %dx%d @ %d spp; central ray (unnormalised direction) hits instance %d at t = %.5f (time 0) / instance %d at t = %.5f (time 1)\n",
+              xml, W, H, spp, int(h0.instId), h0.t, int(h1.instId), h1.t);
+  if (FILE* f = std::fopen(out, "wb")) { std::fwrite(frame.data(), 4, frame.size(), f); std::fclose(f); } else return 1;
+  return 0;
+}
+
 static float4x4 identity() { float4x4 r{}; r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0f; return r; }
 
-int main()
+int main(int argc, char** argv)
 {
+  if (argc >= 6) return renderScene(argv[1], std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]), argv[5]);
   const int W = 64, H = 64, SPP = 4;
   IntegratorHIP integ(W * H, 0);
   if (!integ.valid()) { std::printf("adapter_demo: no GPU\n"); return 2; }

@@ -1157,3 +1157,46 @@ def test_wavefront_round_cap_reports_an_incomplete_frame():
     gpu2 = HipIntegrator(sc); gpu2.set_schedule(2, 56, 0, 1)
     ref = HipIntegrator(sc); ref.set_schedule(1)
     assert np.array_equal(gpu2.render(4), ref.render(4))
+
+
+# ---- the C++ adapter with everything the ctypes path can do -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("xml", [scene_path("env_map"), MOTION_XML, scene_path("typed_materials")])
+def test_cpp_adapter_renders_whole_scenes_like_the_ctypes_path(xml, tmp_path):
+    """tests/cpp/adapter_demo.cpp in scene mode: IntegratorHIP / BVH2SceneHIP only (AddGeom / AddInstance / AddInstanceMotion, the
+    Integrator-named vectors incl. m_arrays1f and m_normMatrices2Offs, CommitDeviceData, UpdateMembersPlainData, PackXYBlock, PathTraceBlock)
+    on the sampled environment map (pdf table in m_arrays1f), the reference's moving-instance fixture and the plastic / blend scene; the frame
+    equals the one the ctypes front end renders from the same file."""
+    import subprocess
+    from conftest import ROOT
+    from hydracore3_amd.api import HipIntegrator
+    tool = os.path.join(ROOT, "hydracore3_amd", "adapter_demo")
+    out = str(tmp_path / "frame.bin")
+    r = subprocess.run([tool, xml, "96", "64", "6", out], capture_output=True, text=True)
+    print(r.stdout.strip())
+    assert r.returncode == 0 and "IntegratorHIP::" not in r.stdout, r.stdout + r.stderr
+    frame = np.fromfile(out, np.float32).reshape(64, 96, 4)
+    ref = HipIntegrator(load_hydra_xml(xml, 96, 64)).render(6)
+    assert per_pixel_l2(frame, ref, 6) < 1e-3
+    assert float(frame[..., :3].mean()) > 0.0
+
+
+def test_update_mat_id_offsets_hook(cornell):
+    """Update_m_matIdOffsets (integrator_pt.h:470): m_matVertOffset re-uploaded through hpt_update_mat_id_offsets. Pointing mesh 1's triangle
+    offset at mesh 0's material ids changes the colours of that instance exactly as a scene built with those offsets does; ranges that leave
+    the tables are refused."""
+    from hydracore3_amd.api import HipIntegrator, HydraHipError
+    sc, _, _ = cornell
+    a = HipIntegrator(sc)
+    base = a.render(2)
+    mvo = np.asarray(sc.mat_vert_offset, np.uint32).reshape(-1, 2).copy()
+    same = HipIntegrator(sc); same.Update_m_matIdOffsets(mvo)
+    assert np.array_equal(same.render(2), base)                                  # the identity update changes nothing
+    swapped = mvo.copy(); swapped[1, 0] = mvo[0, 0]                              # mesh 1 reads mesh 0's material ids (and indices)
+    b = HipIntegrator(sc); b.Update_m_matIdOffsets(swapped)
+    img = b.render(2)
+    assert np.isfinite(img).all() and not np.array_equal(img, base)
+    bad = mvo.copy(); bad[-1, 0] = 10 ** 6
+    with pytest.raises(HydraHipError, match="reaches past"):
+        a.Update_m_matIdOffsets(bad)
+    with pytest.raises(HydraHipError, match="geometry count"):
+        a.Update_m_matIdOffsets(mvo[:1])

@@ -81,6 +81,7 @@ ABI = {
     "hpt_get_schedule": (_i, [_vp, C.POINTER(_i), C.POINTER(_u32)]),
     "hpt_get_accel_info": (_i, [_vp, C.POINTER(_f)]),
     "hpt_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "hpt_get_commit_time": (_i, [_vp, C.POINTER(_f)]),
     "hpt_last_kernel_ms": (_i, [_vp, C.POINTER(_f)]),
 }
 
@@ -351,6 +352,21 @@ class HipIntegrator:
         self._chk(self.L.hpt_get_accel_info(self.h, out))
         return {"sah_node_visits": out[0], "inst_tris": int(out[1]), "instances": int(out[2]), "flat": int(out[3]) == 1,
                 "layout": ("two-level", "flat", "sweep")[int(out[3])]}
+
+    def commit_time(self):
+        """The last CommitScene: host ms, upload ms, device refit ms, refitted (bool)."""
+        out = (C.c_float * 4)()
+        self._chk(self.L.hpt_get_commit_time(self.h, out))
+        return {"host_ms": out[0], "upload_ms": out[1], "refit_ms": out[2], "refitted": bool(out[3])}
+
+    def UpdateInstance(self, inst_id, matrix_rowmajor):
+        """ISceneObject::UpdateInstance (CrossRT.h:134); takes effect at the next CommitScene."""
+        from .scene import colmajor
+        cm = colmajor(np.asarray(matrix_rowmajor))
+        self._chk(self.L.hpt_update_instance(self.h, inst_id, cm.ctypes.data))
+
+    def CommitScene(self):
+        self._chk(self.L.hpt_commit_scene(self.h, 4))
 
     def last_schedule(self):
         s, it = C.c_int(0), C.c_uint32(0)

@@ -111,4 +111,63 @@ __global__ void adamStepKernel(float* state, const float* grad, float* momentum,
   }
 }
 
+// ---- device refit of the single-level BVH (UpdateInstance / UpdateGeom_Triangles3f + CommitScene on a committed scene) --------------------
+// The topology the host built stays; only the boxes are recomputed, bottom-up, on the GPU: (1) one lane per triangle record takes the
+// record's object-space vertices to world space with the instance's CURRENT matrix and writes the padded box the builder would have
+// given it; (2) level by level from the deepest, one lane per node: a child's box is the padded union of the primitive boxes below it
+// (kept unpadded per node in `bounds`, so the padding does not compound with the depth). Hits do not depend on the boxes as long as
+// they contain their triangles, so the refitted tree returns bit for bit what a fresh build returns.
+HPT_DEV void padBox(float* lo, float* hi)              // Aabb::pad (bvh_build.h)
+{
+  const float ex = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+  float mag = 0.0f;
+  for (int a = 0; a < 3; a++) mag = fmaxf(mag, fmaxf(absf(lo[a]), absf(hi[a])));
+  const float p = 1e-5f * fmaxf(ex, mag) + 1e-30f;
+  for (int a = 0; a < 3; a++) { lo[a] -= p; hi[a] += p; }
+}
+__global__ void refitTriBoxesKernel(const BvhTri* tris, const float* instMat, uint n, float* triBox)
+{
+  const uint k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const BvhTri t = tris[k];
+  const float* m = instMat + 12u * t.instId;            // object -> world rows (3 x 4)
+  float lo[3] = { HPT_FLT_MAX, HPT_FLT_MAX, HPT_FLT_MAX }, hi[3] = { -HPT_FLT_MAX, -HPT_FLT_MAX, -HPT_FLT_MAX };
+  for (int v = 0; v < 3; v++) {
+    const float p[3] = { t.v0[0] + (v == 1 ? t.e1[0] : v == 2 ? t.e2[0] : 0.0f), t.v0[1] + (v == 1 ? t.e1[1] : v == 2 ? t.e2[1] : 0.0f), t.v0[2] + (v == 1 ? t.e1[2] : v == 2 ? t.e2[2] : 0.0f) };
+    for (int a = 0; a < 3; a++) {
+      const float q = m[4 * a + 0] * p[0] + m[4 * a + 1] * p[1] + m[4 * a + 2] * p[2] + m[4 * a + 3];
+      lo[a] = fminf(lo[a], q); hi[a] = fmaxf(hi[a], q);
+    }
+  }
+  padBox(lo, hi);                                        // covers the rounding of v0 + e and of the transform, as the builder's per-triangle pad does
+  float* o = triBox + 6u * (size_t)k;
+  o[0] = lo[0]; o[1] = hi[0]; o[2] = lo[1]; o[3] = hi[1]; o[4] = lo[2]; o[5] = hi[2];
+}
+__global__ void refitLevelKernel(BvhNode* nodes, const uint* ids, uint count, const float* triBox, float* bounds)
+{
+  const uint i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint id = ids[i];
+  BvhNode nd = nodes[id];
+  float nlo[3] = { HPT_FLT_MAX, HPT_FLT_MAX, HPT_FLT_MAX }, nhi[3] = { -HPT_FLT_MAX, -HPT_FLT_MAX, -HPT_FLT_MAX };
+  for (int c = 0; c < 2; c++) {
+    const uint ref = c ? nd.ref1 : nd.ref0;
+    if (ref == REF_NONE) continue;
+    float lo[3] = { HPT_FLT_MAX, HPT_FLT_MAX, HPT_FLT_MAX }, hi[3] = { -HPT_FLT_MAX, -HPT_FLT_MAX, -HPT_FLT_MAX };
+    if (ref & REF_LEAF) {
+      const uint cnt = (ref >> 28) & 7u, first = ref & 0x0FFFFFFFu;
+      for (uint k = 0; k < cnt; k++) { const float* b = triBox + 6u * (size_t)(first + k); for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], b[2 * a]); hi[a] = fmaxf(hi[a], b[2 * a + 1]); } }
+    } else {
+      const float* b = bounds + 6u * (size_t)ref;       // the child's level is deeper: already refitted
+      for (int a = 0; a < 3; a++) { lo[a] = b[2 * a]; hi[a] = b[2 * a + 1]; }
+    }
+    for (int a = 0; a < 3; a++) { nlo[a] = fminf(nlo[a], lo[a]); nhi[a] = fmaxf(nhi[a], hi[a]); }
+    padBox(lo, hi);
+    for (int a = 0; a < 3; a++) { nd.q[6 * c + 2 * a] = lo[a]; nd.q[6 * c + 2 * a + 1] = hi[a]; }
+  }
+  float* o = bounds + 6u * (size_t)id;
+  for (int a = 0; a < 3; a++) { o[2 * a] = nlo[a]; o[2 * a + 1] = nhi[a]; }
+  nodes[id] = nd;
+}
+
 } // namespace hpt

@@ -92,6 +92,14 @@ struct hpt_ctx
   DevBuf<float> dArrays1f; size_t numArrays1f = 0;       // m_arrays1f (pdf table of a sampled environment map)
   DevBuf<float4> dLensLines;                             // m_lines of the lens simulation (hpt_set_optics)
   DevBuf<float> dInstMotion, dNormMat2;                  // motion blur: key matrices of the moving instances, end-of-motion normal matrices
+  // device refit of the single-level layout (refit_flat): the committed tree's nodes grouped by level, scratch boxes, what the tree was built for
+  DevBuf<uint> dLevelNodes; DevBuf<float> dTriBox, dNodeBounds, dInstO2W;
+  std::vector<uint> levelOffsets;                        // nodes of level l = dLevelNodes[levelOffsets[l] .. levelOffsets[l + 1])
+  std::vector<BvhTri> flatTris;                         // host copy of the single-level layout's triangle records (BVH order)
+  bool flatRefittable = false;                           // a single-level tree is committed and nothing but instance matrices / vertex positions changed since
+  std::vector<uint> dirtyGeoms;                          // meshes whose vertices changed since the last commit (UpdateGeom_Triangles3f)
+  bool refitEnabled = true;                              // hpt_set_option("refit", 0): always rebuild
+  float tCommit[4] = {0, 0, 0, 0};                       // last CommitScene: host build ms, upload ms, device refit ms, 1 = refit / 0 = build
   float sahVisits = 0.0f;                                // expected inner-node visits per ray of the committed structure (sah_node_visits)
   bool anyMotion = false;                                // some instance moves: two-level layout, megakernel schedule, MOTION kernels
   std::vector<MaterialRec> hMaterials;                   // host mirror of m_materials: the blend graph is validated as a whole
@@ -179,7 +187,7 @@ extern "C" void hpt_destroy(hpt_ctx* c)
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   (void)hpt_comm_destroy(c);
-  c->dNodes.release(); c->dTris.release(); c->dInsts.release(); c->dSweepInsts.release(); c->dSweepTris.release(); c->dTriIndices.release(); c->dMatIdByPrim.release();
+  c->dNodes.release(); c->dTris.release(); c->dInsts.release(); c->dSweepInsts.release(); c->dSweepTris.release(); c->dLevelNodes.release(); c->dTriBox.release(); c->dNodeBounds.release(); c->dInstO2W.release(); c->dTriIndices.release(); c->dMatIdByPrim.release();
   c->dMatVertOffset.release(); c->dPackedXY.release(); c->dVData.release(); c->dNormMat.release(); c->dRemapInst.release();
   c->dRemapLists.release(); c->dMaterials.release(); c->dLights.release(); c->dTextures.release(); c->dArrays1f.release(); c->dGens.release();
   c->dQueue.release(); c->dStackOvf.release(); c->dCounters.release(); c->dFrame.release(); c->dRecord.release(); c->dRef.release(); c->dData.release();
@@ -260,7 +268,7 @@ extern "C" int hpt_device_memset(hpt_ctx* c, void* dev, int value, size_t bytes)
 extern "C" int hpt_clear_geom(hpt_ctx* c)
 {
   if (!c) return HPT_ERR_ARG;
-  c->geoms.clear(); c->insts.clear(); c->accelCommitted = false;
+  c->geoms.clear(); c->insts.clear(); c->accelCommitted = false; c->flatRefittable = false;
   return HPT_OK;
 }
 
@@ -284,7 +292,7 @@ extern "C" uint32_t hpt_add_geom_triangles3f(hpt_ctx* c, const float* vpos, size
   Geom g;
   if (fill_geom(c, g, vpos, nVert, idx, nIdx, stride) != HPT_OK) return 0xFFFFFFFFu;
   c->geoms.push_back(std::move(g));
-  c->accelCommitted = false;
+  c->accelCommitted = false; c->flatRefittable = false;
   return (uint32_t)(c->geoms.size() - 1);
 }
 
@@ -295,17 +303,20 @@ extern "C" int hpt_update_geom_triangles3f(hpt_ctx* c, uint32_t geomId, const fl
   Geom& g = c->geoms[geomId];
   if (nIdx > g.idx.size() || nVert * 3 > g.pos.size()) return c->fail(HPT_ERR_ARG, "UpdateGeom_Triangles3f: growing a geometry is not supported");
   c->accelCommitted = false;
+  // the committed single-level tree survives a change of vertex POSITIONS (same triangles): its boxes are refitted on the device
+  if ((nIdx / 3) * 3 != g.idx.size() || std::memcmp(idx, g.idx.data(), g.idx.size() * sizeof(uint32_t)) != 0) c->flatRefittable = false;
+  else c->dirtyGeoms.push_back(geomId);
   return fill_geom(c, g, vpos, nVert, idx, nIdx, stride);
 }
 
-extern "C" int hpt_clear_scene(hpt_ctx* c) { if (!c) return HPT_ERR_ARG; c->insts.clear(); c->accelCommitted = false; return HPT_OK; }
+extern "C" int hpt_clear_scene(hpt_ctx* c) { if (!c) return HPT_ERR_ARG; c->insts.clear(); c->accelCommitted = false; c->flatRefittable = false; return HPT_OK; }
 
 extern "C" uint32_t hpt_add_instance(hpt_ctx* c, uint32_t geomId, const float m[16])
 {
   if (!c || !m || geomId >= c->geoms.size()) return 0xFFFFFFFFu;
   Inst in; in.geomId = geomId; std::memcpy(in.m, m, 64);
   c->insts.push_back(in);
-  c->accelCommitted = false;
+  c->accelCommitted = false; c->flatRefittable = false;
   return (uint32_t)(c->insts.size() - 1);
 }
 
@@ -316,7 +327,7 @@ extern "C" uint32_t hpt_add_instance_motion(hpt_ctx* c, uint32_t geomId, const f
   if (matrixNumber != 2) { c->fail(HPT_ERR_UNSUPPORTED, "AddInstanceMotion: two key matrices are supported (what LoadSceneInstances passes)"); return 0xFFFFFFFFu; }
   Inst in; in.geomId = geomId; std::memcpy(in.m, matrices, 64); std::memcpy(in.m1, matrices + 16, 64); in.motion = true;
   c->insts.push_back(in);
-  c->accelCommitted = false;
+  c->accelCommitted = false; c->flatRefittable = false;
   return (uint32_t)(c->insts.size() - 1);
 }
 
@@ -366,10 +377,68 @@ static void inverse_rows(const float* m, float row0[4], float row1[4], float row
 
 static int ceil_log2(size_t v) { int l = 0; while ((size_t(1) << l) < v) l++; return l; }
 
+// object -> world rows (3 x 4) of every instance, as refitTriBoxesKernel reads them
+static void inst_o2w_rows(const std::vector<Inst>& insts, std::vector<float>& out)
+{
+  out.assign(12 * std::max<size_t>(insts.size(), 1), 0.0f);
+  for (size_t i = 0; i < insts.size(); i++) {
+    const float* m = insts[i].m; float* o = &out[12 * i];
+    for (int r = 0; r < 3; r++) { o[4 * r + 0] = m[r]; o[4 * r + 1] = m[4 + r]; o[4 * r + 2] = m[8 + r]; o[4 * r + 3] = m[12 + r]; }
+  }
+}
+
+// UpdateInstance / UpdateGeom_Triangles3f + CommitScene on a committed single-level scene (CrossRT.h:85-86, 134, 110): the tree's topology stays,
+// its boxes are recomputed on the device (refitTriBoxesKernel + one refitLevelKernel per level, deepest first). The host only inverts the
+// instance matrices again and, for meshes whose vertices moved, rewrites their triangle records.
+static int refit_flat(hpt_ctx* c)
+{
+  const double t0 = now_ms();
+  const size_t ni = c->insts.size();
+  std::vector<BvhInst> dinst(std::max<size_t>(ni, 1));
+  for (size_t i = 0; i < ni; i++) {
+    inverse_rows(c->insts[i].m, dinst[i].row0, dinst[i].row1, dinst[i].row2);
+    dinst[i].root = REF_NONE; dinst[i].geomId = c->insts[i].geomId; dinst[i].pad0 = dinst[i].pad1 = 0;
+  }
+  std::vector<float> o2w; inst_o2w_rows(c->insts, o2w);
+  if (!c->dirtyGeoms.empty()) {                                 // moved vertices: the object-space records (v0, e1, e2) of those meshes' triangles
+    std::vector<char> dirty(c->geoms.size(), 0);
+    for (uint g : c->dirtyGeoms) if (g < dirty.size()) dirty[g] = 1;
+    for (BvhTri& t : c->flatTris) {
+      const uint gi = c->insts[t.instId].geomId;
+      if (!dirty[gi]) continue;
+      const Geom& g = c->geoms[gi];
+      const float* A = &g.pos[3 * g.idx[3 * t.primId + 0]]; const float* B = &g.pos[3 * g.idx[3 * t.primId + 1]]; const float* C = &g.pos[3 * g.idx[3 * t.primId + 2]];
+      for (int a = 0; a < 3; a++) { t.v0[a] = A[a]; t.e1[a] = B[a] - A[a]; t.e2[a] = C[a] - A[a]; }
+    }
+    for (uint g : c->dirtyGeoms) if (g < c->geoms.size()) c->geoms[g].dirty = true;   // a later two-level build must redo these BLAS
+  }
+  const double t1 = now_ms();
+  HIPCHK(c, c->dInsts.upload(dinst.data(), dinst.size()));
+  HIPCHK(c, c->dInstO2W.upload(o2w.data(), o2w.size()));
+  if (!c->dirtyGeoms.empty()) HIPCHK(c, c->dTris.upload(c->flatTris.data(), c->flatTris.size()));
+  c->dirtyGeoms.clear();
+  const double t2 = now_ms();
+  const uint nt = (uint)c->instTris;
+  if (nt) refitTriBoxesKernel<<<dim3((nt + 255u) / 256u), dim3(256), 0, 0>>>(c->dTris.p, c->dInstO2W.p, nt, c->dTriBox.p);
+  for (size_t l = c->levelOffsets.size() - 1; l-- > 0;) {
+    const uint cnt = c->levelOffsets[l + 1] - c->levelOffsets[l];
+    if (cnt) refitLevelKernel<<<dim3((cnt + 255u) / 256u), dim3(256), 0, 0>>>(c->dNodes.p, c->dLevelNodes.p + c->levelOffsets[l], cnt, c->dTriBox.p, c->dNodeBounds.p);
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipDeviceSynchronize());
+  c->S.insts = c->dInsts.p;
+  c->tCommit[0] = float(t1 - t0); c->tCommit[1] = float(t2 - t1); c->tCommit[2] = float(now_ms() - t2); c->tCommit[3] = 1.0f;
+  c->accelCommitted = true;
+  return HPT_OK;
+}
+
 extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
 {
   if (!c) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
+  if (c->flatRefittable && c->refitEnabled && c->S.flatMode == 1u) return refit_flat(c);
+  const double tBuild0 = now_ms();
+  c->dirtyGeoms.clear();
   // ---- bottom level: one BVH2 per mesh over object-space triangles ----
   uint maxBlasDepth = 0;
   for (Geom& g : c->geoms) {
@@ -448,9 +517,33 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
       inverse_rows(c->insts[i].m, dinst[i].row0, dinst[i].row1, dinst[i].row2);
       dinst[i].root = REF_NONE; dinst[i].geomId = c->insts[i].geomId; dinst[i].pad0 = dinst[i].pad1 = 0;
     }
+    const double tUp0 = now_ms();
     HIPCHK(c, c->dNodes.upload(nodes.data(), nodes.size()));
     HIPCHK(c, c->dTris.upload(tris.data(), tris.size()));
     HIPCHK(c, c->dInsts.upload(dinst.data(), dinst.size()));
+    {                                                          // what refit_flat needs: the nodes grouped by level, scratch for the boxes
+      std::vector<uint> level(tree.nodes.size(), 0u), order; order.reserve(tree.nodes.size());
+      uint maxLevel = 0;
+      if (tree.rootRef != REF_NONE && !(tree.rootRef & REF_LEAF)) {
+        std::vector<uint> stack(1, tree.rootRef);
+        while (!stack.empty()) {
+          const uint id = stack.back(); stack.pop_back();
+          for (uint ref : { tree.nodes[id].ref0, tree.nodes[id].ref1 })
+            if (ref != REF_NONE && !(ref & REF_LEAF)) { level[ref] = level[id] + 1u; maxLevel = std::max(maxLevel, level[ref]); stack.push_back(ref); }
+        }
+      }
+      c->levelOffsets.assign(tree.nodes.empty() ? 1 : maxLevel + 2, 0u);
+      for (size_t i = 0; i < tree.nodes.size(); i++) c->levelOffsets[level[i] + 1]++;
+      for (size_t l = 1; l < c->levelOffsets.size(); l++) c->levelOffsets[l] += c->levelOffsets[l - 1];
+      std::vector<uint> fill(c->levelOffsets.begin(), c->levelOffsets.end() - 1), ids(std::max<size_t>(tree.nodes.size(), 1), 0u);
+      for (size_t i = 0; i < tree.nodes.size(); i++) ids[fill[level[i]]++] = (uint)i;
+      HIPCHK(c, c->dLevelNodes.upload(ids.data(), ids.size()));
+      HIPCHK(c, c->dTriBox.alloc(6 * std::max<size_t>(instTris, 1)));
+      HIPCHK(c, c->dNodeBounds.alloc(6 * std::max<size_t>(tree.nodes.size(), 1)));
+      c->flatTris.swap(tris);
+      c->flatRefittable = tree.rootRef != REF_NONE && !(tree.rootRef & REF_LEAF) && instTris > 0;
+    }
+    c->tCommit[0] = float(tUp0 - tBuild0); c->tCommit[1] = float(now_ms() - tUp0); c->tCommit[2] = 0.0f; c->tCommit[3] = 0.0f;
     c->S.nodes = c->dNodes.p; c->S.tris = c->dTris.p; c->S.insts = c->dInsts.p;
     c->S.rootRef = tree.rootRef; c->S.numInsts = (uint)ni; c->S.flatMode = 1; c->S.sweep = 0; c->S.sweepInsts = nullptr; c->S.sweepTris = nullptr;
     c->sahVisits = sah_node_visits(tree);
@@ -554,6 +647,8 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   HIPCHK(c, c->dInsts.upload(dinst.data(), dinst.size()));
   c->S.nodes = c->dNodes.p; c->S.tris = c->dTris.p; c->S.insts = c->dInsts.p;
   c->S.rootRef = rootRef; c->S.numInsts = (uint)ni; c->S.flatMode = 0;
+  c->flatRefittable = false;
+  c->tCommit[0] = float(now_ms() - tBuild0); c->tCommit[1] = 0.0f; c->tCommit[2] = 0.0f; c->tCommit[3] = 0.0f;
   c->stackNeeded = tlas.depth + 1u + maxBlasDepth + 1u;
   if (c->stackNeeded > MAX_STACK) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: BVH deeper than the 64-entry traversal stack");
   c->accelCommitted = true;
@@ -1517,7 +1612,8 @@ extern "C" int hpt_set_option(hpt_ctx* c, const char* name, int value)
   if (!c || !name || value < 0) return HPT_ERR_ARG;
   const std::string k(name);
   if (k == "wf_grace") c->wfGrace = (uint)value;                                      // trips after the queue ran dry before a trace wave suspends its rays (0: never)
-  else if (k == "node_min") { c->nodeMinOverride = value & 63; c->accelCommitted = false; }   // voted exit of the inner-node loop; takes effect at the next CommitScene
+  else if (k == "node_min") { c->nodeMinOverride = value & 63; c->accelCommitted = false; c->flatRefittable = false; }
+  else if (k == "refit") c->refitEnabled = value != 0;                                  // 0: UpdateInstance / UpdateGeom + CommitScene always rebuild the tree on the host   // voted exit of the inner-node loop; takes effect at the next CommitScene
   else if (k == "dbg_no_normal_lerp") { if (c->S.motion) c->S.motion = value ? 3u : 1u; }   // diagnostic: moving instances without the reference's normal interpolation (bit 1 of DevScene::motion)
   else if (k == "dbg_wf_iter_cap") c->wfIterCap = (uint)value;                         // diagnostic: make the wavefront loop's safety net reachable in a test
   else if (k == "dr_skip_nonfinite") c->drSkipNonFinite = value != 0;                  // PathTraceDR: drop samples whose radiance is not finite (default 0: PixelLossPT as in the reference)
@@ -1531,6 +1627,12 @@ extern "C" int hpt_get_accel_info(hpt_ctx* c, float out[4])
   out[0] = c->sahVisits; out[1] = (float)c->instTris; out[2] = (float)c->insts.size(); out[3] = c->S.sweep ? 2.0f : (c->S.flatMode ? 1.0f : 0.0f);
   return HPT_OK;
 }
+extern "C" int hpt_get_commit_time(hpt_ctx* c, float out[4])
+{
+  if (!c || !out) return HPT_ERR_ARG;
+  for (int i = 0; i < 4; i++) out[i] = c->tCommit[i];
+  return HPT_OK;
+}
 extern "C" int hpt_get_schedule(hpt_ctx* c, int* lastSchedule, uint32_t* lastIterations)
 {
   if (!c) return HPT_ERR_ARG;
@@ -1541,7 +1643,7 @@ extern "C" int hpt_get_schedule(hpt_ctx* c, int* lastSchedule, uint32_t* lastIte
 extern "C" int hpt_set_accel_layout(hpt_ctx* c, int layout)
 {
   if (!c || layout < 0 || layout > 3) return HPT_ERR_ARG;
-  c->accelLayout = layout; c->accelCommitted = false;
+  c->accelLayout = layout; c->accelCommitted = false; c->flatRefittable = false;
   return HPT_OK;
 }
 extern "C" int hpt_last_kernel_ms(hpt_ctx* c, float* ms)

@@ -240,6 +240,7 @@ int  hpt_set_schedule(hpt_ctx* ctx, int schedule, int refillBelow, int traceBloc
  *   "wf_grace"  trips a wavefront trace wave keeps going after the ray queue ran dry before it parks its unfinished rays (traversal
  *               state + stack to HBM) for the next round's trace pass, which resumes them first; 0 = run every ray to the end.
  *               Only applied in rounds with at least 2 rays per lane of the trace grid.
+ *   "refit"     1 (default): CommitScene after UpdateInstance / UpdateGeom_Triangles3f refits the single-level tree on the device; 0: rebuild.
  *   "node_min"  voted exit of the inner-node loop (0..63, applied at the next hpt_commit_scene; default chosen per scene).
  * Diagnostic switches (these DO change which kernels run or what they compute; never set in production):
  *   "dr_skip_nonfinite"     PathTraceDR: 1 = a sample whose radiance is not finite contributes neither colour, loss nor gradient (what an
@@ -264,6 +265,11 @@ int  hpt_allreduce_grad(hpt_ctx* ctx, float* gradDev, size_t count, void* stream
 /* What CommitScene built: out[0] = expected inner-node visits per ray (surface-area estimate over the committed BVH; the quantity the automatic
  * schedule / layout choice is measured against), out[1] = instanced triangles, out[2] = instances, out[3] = layout (0 two-level, 1 single-level, 2 triangle sweep). */
 int  hpt_get_accel_info(hpt_ctx* ctx, float out[4]);
+/* The last hpt_commit_scene: out[0] = host milliseconds (BVH build, or for a refit the matrix inversions and record updates), out[1] = upload ms,
+ * out[2] = device refit ms, out[3] = 1 when the committed single-level tree was REFITTED on the device (UpdateInstance / UpdateGeom_Triangles3f
+ * with unchanged topology: boxes recomputed bottom-up by two small kernels, CrossRT.h:85-86, 134) and 0 when it was built on the host.
+ * hpt_set_option("refit", 0) forces the build. */
+int  hpt_get_commit_time(hpt_ctx* ctx, float out[4]);
 int  hpt_get_schedule(hpt_ctx* ctx, int* lastSchedule, uint32_t* lastIterations);
 /* Duration of the last path-tracing kernel, measured with HIP events on the stream it ran on (ms). */
 int  hpt_last_kernel_ms(hpt_ctx* ctx, float* ms);

@@ -1200,3 +1200,47 @@ def test_update_mat_id_offsets_hook(cornell):
         a.Update_m_matIdOffsets(bad)
     with pytest.raises(HydraHipError, match="geometry count"):
         a.Update_m_matIdOffsets(mvo[:1])
+
+
+def test_update_instance_refits_the_single_level_tree_on_the_device():
+    """ISceneObject::UpdateInstance + CommitScene (CrossRT.h:134, 110) on a committed single-level scene: the tree is not rebuilt - its boxes are
+    refitted bottom-up on the GPU (hpt_get_commit_time says so) - and the scene then renders and answers ray queries bit for bit like a context
+    built from scratch for the moved instances, and like the same update with the refit switched off (host rebuild)."""
+    from hydracore3_amd.api import HipIntegrator
+    from hydracore3_amd import scene as S, synth
+    sc = synth.interior_scene(96, 64, objects=14, subdiv=2, tex_size=16)
+    live, rebuilt = HipIntegrator(sc), HipIntegrator(sc)
+    assert live.accel_info()["layout"] == "flat" and not live.commit_time()["refitted"]
+    rebuilt.set_option("refit", 0)
+    live.render(1); rebuilt.render(1)
+    moved = synth.interior_scene(96, 64, objects=14, subdiv=2, tex_size=16)
+    rng = np.random.default_rng(3)
+    for i in (2, 5, 9, 15):                                               # four of the sixteen instances move, turn and stretch
+        m = S.translate(*rng.uniform(-0.6, 0.6, 3)) @ np.asarray(moved.inst_matrices[i]) @ S.rotate_y(float(rng.uniform(0, 90))) @ S.scale(1.0, float(rng.uniform(0.7, 1.5)), 1.0)
+        moved.inst_matrices[i] = m
+        for g in (live, rebuilt):
+            g.UpdateInstance(i, m)
+    for g in (live, rebuilt):
+        g.CommitScene()
+        d = moved.desc(); d.vPos4f = None                                 # tables only: the normal matrices follow the instance matrices
+        g._desc = d; g.scene = moved
+        g.CommitDeviceData()
+        g.InitRandomGens(g.N)
+    assert live.commit_time()["refitted"] and not rebuilt.commit_time()["refitted"]
+    print("refit:", live.commit_time(), " rebuild:", rebuilt.commit_time())
+    fresh = HipIntegrator(moved)
+    pos, dr = random_rays(20000, 17, -5.0, 5.0)
+    hf = fresh.RayQuery_NearestHit(pos, dr)
+    assert np.array_equal(live.RayQuery_NearestHit(pos, dr).view(np.uint8), hf.view(np.uint8))
+    assert np.array_equal(rebuilt.RayQuery_NearestHit(pos, dr).view(np.uint8), hf.view(np.uint8))
+    assert np.array_equal(live.RayQuery_AnyHit(pos, dr), fresh.RayQuery_AnyHit(pos, dr))
+    a, b, c = live.render(4), fresh.render(4), rebuilt.render(4)
+    assert np.array_equal(a, b) and np.array_equal(c, b)
+    assert not np.array_equal(a, HipIntegrator(sc).render(4))
+    # a second round of updates refits the refitted tree again
+    m = S.translate(0.2, 0.1, -0.3) @ np.asarray(moved.inst_matrices[7])
+    moved.inst_matrices[7] = m
+    live.UpdateInstance(7, m); live.CommitScene()
+    d = moved.desc(); d.vPos4f = None; live._desc = d; live.CommitDeviceData(); live.InitRandomGens(live.N)
+    assert live.commit_time()["refitted"]
+    assert np.array_equal(live.render(3), HipIntegrator(moved).render(3))

@@ -905,13 +905,62 @@ def test_bench_under_torch_distributed_run_exits_cleanly():
     from conftest import ROOT
     env = dict(os.environ, HYDRA_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29533",
-           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--spp", "16", "--no-cpu-baseline"]
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--spp", "16", "--no-cpu-baseline", "--no-also", "--no-build"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{\"metric\"")]
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0 and out["unit"] == "Mpaths/s"
+
+
+def _bench_two_ranks(extra, timeout=900):
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HYDRA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # started PLAINLY, the way the driver starts --gpus 1: bench.py spawns its two ranks itself before anything touches the GPU
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-build"] + extra,
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{\"metric\"")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_of_the_hip_path_reassemble_the_single_gpu_frame():
+    """The multi-rank path of bench.py with the HIP kernels (two ranks sharing the box's one GPU, collectives staged over gloo - the rehearsal of
+    the RCCL run): plain `python bench.py --gpus 2` spawns the ranks itself; fixed total work split by SAMPLES (all pixels x spp / 2 per rank,
+    RNG sub-streams, frames summed) and by PIXELS (interleaved tid chunks, bit-identical to the single-GPU frame) - both verified by rank 0
+    against single-rank renderings of the same shares inside the run; weak scaling likewise."""
+    out = _bench_two_ranks(["--spp", "32"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["config"]["sharded_frame_verified"] is True and "sample sharding" in out["config"]["sharding"]
+    assert out["config"]["paths_per_step"] == 1024 * 1024 * 32                      # fixed total work: not N x the samples
+    also = out["also"][0]
+    assert also["sharded_frame_verified"] is True and "pixel sharding" in also["sharding"] and also["paths_per_step"] == 1024 * 1024 * 32
+    weak = _bench_two_ranks(["--spp", "16", "--scaling", "weak", "--no-also"])
+    assert weak["scaling"] == "weak" and weak["config"]["sharded_frame_verified"] is True and weak["config"]["paths_per_step"] == 2 * 1024 * 1024 * 16
+
+
+def test_two_ranks_all_reduce_the_gradient():
+    """PathTraceDR over two ranks: the gradient and the loss are all_reduce(SUM)-ed once per iteration and every rank applies the same Adam step;
+    the loss sequence of the sharded run follows the single-rank run of the same total work (different RNG sub-streams: statistically, 3 %)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    two = _bench_two_ranks(["--workload", "dr", "--spp", "64", "--width", "128", "--height", "128"])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "dr", "--spp", "64", "--width", "128", "--height", "128", "--steps", "2", "--warmup", "1", "--no-build"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    one = json.loads([l for l in r.stdout.splitlines() if l.startswith("{\"metric\"")][0])
+    l2, l1 = two["config"]["loss_per_step"], one["config"]["loss_per_step"]
+    print("loss per step: two ranks", l2, " one rank", l1)
+    assert two["n_gpus"] == 2 and "all_reduce" in two["config"]["sharding"]
+    assert len(l2) == len(l1) == 2 and all(abs(a - b) <= 0.03 * abs(b) for a, b in zip(l2, l1))
+    assert l2[1] < l2[0]                                                              # and the optimisation makes progress
 
 
 def test_upload_refuses_tables_with_out_of_range_indices(cornell):

@@ -73,6 +73,7 @@ struct WfPool
   uint*   status;
   float*  lossSlot;  // DR: per-slot sum of the pixel's sample losses (reduced in double at the end: one float accumulator for 10^7..10^8
                      // samples loses the small increments - measured 1.5 % low on the 1M-triangle scene)
+  float*  time;      // motion blur: the path's time in [0, 1] (drawn at regeneration, read by the trace pass and by the shading of every vertex)
   uint*   inflight;  // bit 0 / 1: the slot's closest-hit / shadow ray was suspended by a trace pass and has not finished yet
   uint*   rayQ[2];   // compacted ray queue of round (iteration & 1): slot id | (shadow ray ? 1 << 31 : 0) | (resumed ray ? 1 << 30 : 0)
   uint*   susp[2];   // traversal state of the rays a trace pass suspended, written for the NEXT round: [WF_SUSP_WORDS + stack][maxSusp],
@@ -109,9 +110,9 @@ struct WfJob
 #define HPT_WFS_BOUNDS(DR, LEAN) __launch_bounds__(256, ((DR) || (LEAN)) ? HPT_WF_SHADE_WAVES : HPT_WF_SHADE_FULL_WAVES)
 
 __global__ void wfInitKernel(WfPool P, uint n, uint passNum);
-template <bool DR, bool LEAN>
+template <bool DR, bool LEAN, bool MOTION = false>
 __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const WfPool P, const WfJob job);
-template <bool DEEP, bool FLAT, bool STATS>
+template <bool DEEP, bool FLAT, bool STATS, bool MOTION = false>
 __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScene S, const WfPool P, uint iter, uint refillBelow, uint grace,
                                                                    uint* stackOverflow, uint gridLanes, Counters* counters);
 __global__ void __launch_bounds__(256) wfLossReduceKernel(const float* lossSlot, uint n, double* acc);

@@ -1243,8 +1243,8 @@ HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, 
 // The triangle test itself still runs in the instance's OBJECT space - the ray is taken there with the same world->object rows the
 // two-level path uses, cached while consecutive triangles belong to the same instance - so every hit (t, u, v, ids) is bit-identical
 // to the two-level / Embree semantics. Boxes only cull.
-template <bool ANY, bool STATS, bool DEEP>
-HPT_DEV bool traceRayFlat(const DevScene& S, const V3 wo, const V3 wd, float tnear, float tfar, HitRec& hit, const TravStack& stk, TravStats& st)
+template <bool ANY, bool STATS, bool DEEP, bool MOTION = false>
+HPT_DEV bool traceRayFlat(const DevScene& S, const V3 wo, const V3 wd, float tnear, float tfar, HitRec& hit, const TravStack& stk, TravStats& st, const float time = 0.0f)
 {
   hit.t = tfar; hit.prim = 0xFFFFFFFFu; hit.inst = 0xFFFFFFFFu; hit.u = 0.0f; hit.v = 0.0f;
   bool found = false;
@@ -1277,7 +1277,9 @@ HPT_DEV bool traceRayFlat(const DevScene& S, const V3 wo, const V3 wd, float tne
         const uint inst = __float_as_uint(b.w);
         if (inst != curInst) {                                // world -> object space of this triangle's instance
           if (STATS) st.insts++;
-          toObjectSpace(S.insts, inst, wo, wd, o, d);
+          // a moving instance: its world boxes span both keys (host), its triangles are met in the object space of the ray's own time
+          if (MOTION && S.insts[inst].pad0 != 0u) toObjectSpaceMotion(S.instMotion + 24u * inst, time, wo, wd, o, d);
+          else toObjectSpace(S.insts, inst, wo, wd, o, d);
           curInst = inst;
         }
         if (triangleTest(a, b, c, o, d, tnear, inst, hit.t, hit.prim, hit.inst, hit.u, hit.v, found) && ANY) return true;
@@ -1359,7 +1361,7 @@ template <bool ANY, bool STATS, bool DEEP, bool FLAT, bool MOTION = false, bool 
 HPT_DEV bool traceAny(const DevScene& S, const V3 wo, const V3 wd, float tnear, float tfar, HitRec& hit, const TravStack& stk, TravStats& st, const float time = 0.0f)
 {
   if (SWEEP) return traceSweep<ANY, STATS>(S, wo, wd, tnear, tfar, hit, st);
-  if (FLAT) return traceRayFlat<ANY, STATS, DEEP>(S, wo, wd, tnear, tfar, hit, stk, st);      // (moving instances force the two-level layout)
+  if (FLAT) return traceRayFlat<ANY, STATS, DEEP, MOTION>(S, wo, wd, tnear, tfar, hit, stk, st, time);
   return traceRay<ANY, STATS, DEEP, MOTION>(S, wo, wd, tnear, tfar, hit, stk, st, time);
 }
 

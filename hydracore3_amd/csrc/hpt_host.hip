@@ -101,7 +101,7 @@ struct hpt_ctx
   bool refitEnabled = true;                              // hpt_set_option("refit", 0): always rebuild
   float tCommit[4] = {0, 0, 0, 0};                       // last CommitScene: host build ms, upload ms, device refit ms, 1 = refit / 0 = build
   float sahVisits = 0.0f;                                // expected inner-node visits per ray of the committed structure (sah_node_visits)
-  bool anyMotion = false;                                // some instance moves: two-level layout, megakernel schedule, MOTION kernels
+  bool anyMotion = false;                                // some instance moves: the MOTION kernel variants (either BVH layout, either schedule; no sweep, no refit)
   std::vector<MaterialRec> hMaterials;                   // host mirror of m_materials: the blend graph is validated as a whole
   std::vector<uint> hLightGeom;                          // geomType of every light, to validate m_envLightId
   std::vector<uint> hTriIndices;                         // host mirror of m_triIndices: Update_m_matIdOffsets re-validates the vertex indices a mesh will read
@@ -114,7 +114,7 @@ struct hpt_ctx
   // stream, so that the tail of one group's trace pass overlaps the other groups' work
   struct WfGroup
   {
-    DevBuf<float4> f4[8]; DevBuf<uint> u[9]; DevBuf<float> rec, lossSlot;
+    DevBuf<float4> f4[8]; DevBuf<uint> u[9]; DevBuf<float> rec, lossSlot, time;
     hipStream_t stream = nullptr; hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t done = nullptr;
     uint* progress = nullptr;            // pinned: rays queued after every WF_CHECK-th shade pass (0 = group finished)
     uint checkpoints = 0, itemBase = 0, itemCount = 0; unsigned long long it = 0; bool finished = false;
@@ -195,7 +195,7 @@ extern "C" void hpt_destroy(hpt_ctx* c)
   for (hpt_ctx::WfGroup* g : c->wfGroups) {
     for (auto& b : g->f4) b.release();
     for (auto& b : g->u) b.release();
-    g->rec.release(); g->lossSlot.release();
+    g->rec.release(); g->lossSlot.release(); g->time.release();
     if (g->progress) (void)hipHostFree(g->progress);
     for (auto& e : g->ev) if (e) (void)hipEventDestroy(e);
     if (g->done) (void)hipEventDestroy(g->done);
@@ -476,22 +476,35 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   const bool autoFlat = instTris >= FLAT_AUTO_TRIS || c->insts.size() >= MANY_INSTANCES;
   c->anyMotion = false;
   for (const Inst& in : c->insts) c->anyMotion = c->anyMotion || in.motion;
-  if (c->anyMotion && c->accelLayout == 2) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: moving instances need the two-level layout");
-  const bool flat = !c->anyMotion && instTris <= FLAT_TRI_BUDGET && (c->accelLayout == 2 || (c->accelLayout == 0 && autoFlat));
+  const bool flat = instTris <= FLAT_TRI_BUDGET && (c->accelLayout == 2 || (c->accelLayout == 0 && autoFlat));
+  {                                                          // object->world rows (3x4) at both keys for the moving instances (both layouts read them)
+    const size_t nim = c->insts.size();
+    std::vector<float> mo(24 * std::max<size_t>(nim, 1), 0.0f);
+    for (size_t i = 0; i < nim; i++) for (int key = 0; key < 2; key++) {
+      const float* m = (key && c->insts[i].motion) ? c->insts[i].m1 : c->insts[i].m;
+      float* o = &mo[24 * i + 12 * (size_t)key];
+      for (int r = 0; r < 3; r++) { o[4 * r + 0] = m[r]; o[4 * r + 1] = m[4 + r]; o[4 * r + 2] = m[8 + r]; o[4 * r + 3] = m[12 + r]; }
+    }
+    HIPCHK(c, c->dInstMotion.upload(mo.data(), mo.size()));
+    c->S.instMotion = c->dInstMotion.p;
+  }
   if (flat) {
     const size_t ni = c->insts.size();
     std::vector<Aabb> boxes; boxes.reserve(instTris);
     std::vector<uint> triInst, triPrim; triInst.reserve(instTris); triPrim.reserve(instTris);
     for (size_t i = 0; i < ni; i++) {
       const Geom& g = c->geoms[c->insts[i].geomId];
-      const float* m = c->insts[i].m;
       const size_t nt = g.idx.size() / 3;
       for (size_t t = 0; t < nt; t++) {
         Aabb b; b.reset();
-        for (int k = 0; k < 3; k++) {
-          const float* p = &g.pos[3 * g.idx[3 * t + k]];
-          const float q[3] = { m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12], m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13], m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14] };
-          b.grow(q);
+        // a moving instance: every point travels on the segment between its two key positions, so the box over both keys bounds the triangle at any time
+        for (int key = 0; key < (c->insts[i].motion ? 2 : 1); key++) {
+          const float* m = key ? c->insts[i].m1 : c->insts[i].m;
+          for (int k = 0; k < 3; k++) {
+            const float* p = &g.pos[3 * g.idx[3 * t + k]];
+            const float q[3] = { m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12], m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13], m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14] };
+            b.grow(q);
+          }
         }
         b.pad();                                            // covers the rounding of the world-space vertex positions too
         boxes.push_back(b); triInst.push_back((uint)i); triPrim.push_back((uint)t);
@@ -515,7 +528,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
     std::vector<BvhInst> dinst(std::max<size_t>(ni, 1));
     for (size_t i = 0; i < ni; i++) {
       inverse_rows(c->insts[i].m, dinst[i].row0, dinst[i].row1, dinst[i].row2);
-      dinst[i].root = REF_NONE; dinst[i].geomId = c->insts[i].geomId; dinst[i].pad0 = dinst[i].pad1 = 0;
+      dinst[i].root = REF_NONE; dinst[i].geomId = c->insts[i].geomId; dinst[i].pad0 = c->insts[i].motion ? 1u : 0u; dinst[i].pad1 = 0;
     }
     const double tUp0 = now_ms();
     HIPCHK(c, c->dNodes.upload(nodes.data(), nodes.size()));
@@ -541,7 +554,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
       HIPCHK(c, c->dTriBox.alloc(6 * std::max<size_t>(instTris, 1)));
       HIPCHK(c, c->dNodeBounds.alloc(6 * std::max<size_t>(tree.nodes.size(), 1)));
       c->flatTris.swap(tris);
-      c->flatRefittable = tree.rootRef != REF_NONE && !(tree.rootRef & REF_LEAF) && instTris > 0;
+      c->flatRefittable = tree.rootRef != REF_NONE && !(tree.rootRef & REF_LEAF) && instTris > 0 && !c->anyMotion;   // (the refit kernels know one key only)
     }
     c->tCommit[0] = float(tUp0 - tBuild0); c->tCommit[1] = float(now_ms() - tUp0); c->tCommit[2] = 0.0f; c->tCommit[3] = 0.0f;
     c->S.nodes = c->dNodes.p; c->S.tris = c->dTris.p; c->S.insts = c->dInsts.p;
@@ -611,7 +624,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   }
   // the triangle sweep keeps its own copy of the instance records: {rows, first triangle record, geomId, 0, number of record pairs}
   const bool sweep = !c->anyMotion && ni >= 1 && (c->accelLayout == 3 || (c->accelLayout == 0 && instTris <= SWEEP_MAX_TRIS && ni <= SWEEP_MAX_INSTS));
-  if (c->accelLayout == 3 && c->anyMotion) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: moving instances need the two-level layout");
+  if (c->accelLayout == 3 && c->anyMotion) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: the triangle sweep does not hold moving instances (two-level or single-level layout)");
   if (sweep) {
     std::vector<uint> geomTriBase(c->geoms.size(), 0u);
     std::vector<BvhTri> st;                                     // every mesh's records in primitive order
@@ -630,16 +643,6 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
     HIPCHK(c, c->dSweepInsts.upload(sw.data(), sw.size()));
   }
   c->S.sweep = sweep ? 1u : 0u; c->S.sweepInsts = sweep ? c->dSweepInsts.p : nullptr; c->S.sweepTris = sweep ? c->dSweepTris.p : nullptr;
-  {                                                          // object->world rows (3x4) at both keys for the moving instances
-    std::vector<float> mo(24 * std::max<size_t>(ni, 1), 0.0f);
-    for (size_t i = 0; i < ni; i++) for (int key = 0; key < 2; key++) {
-      const float* m = (key && c->insts[i].motion) ? c->insts[i].m1 : c->insts[i].m;
-      float* o = &mo[24 * i + 12 * (size_t)key];
-      for (int r = 0; r < 3; r++) { o[4 * r + 0] = m[r]; o[4 * r + 1] = m[4 + r]; o[4 * r + 2] = m[8 + r]; o[4 * r + 3] = m[12 + r]; }
-    }
-    HIPCHK(c, c->dInstMotion.upload(mo.data(), mo.size()));
-    c->S.instMotion = c->dInstMotion.p;
-  }
   if (nodes.empty()) nodes.push_back(BvhNode());           // keep the pointers valid
   if (tris.empty()) tris.push_back(BvhTri());
   HIPCHK(c, c->dNodes.upload(nodes.data(), nodes.size()));
@@ -676,6 +679,7 @@ static int ray_query(hpt_ctx* c, const float* posNear, const float* dirFar, uint
   const uint blocks = (n + 255) / 256;
   HIPCHK(c, ensureStackOverflow(c, (size_t)blocks * 256));
   if (c->S.sweep)        rayQueryKernel<false, false, true><<<dim3(blocks), dim3(256), 0, 0>>>(c->S, dp.p, dd.p, n, dout.p, any, c->dStackOvf.p);
+  else if (c->S.flatMode && c->anyMotion) rayQueryKernel<true, true><<<dim3(blocks), dim3(256), 0, 0>>>(c->S, dp.p, dd.p, n, dout.p, any, c->dStackOvf.p, time);
   else if (c->S.flatMode) rayQueryKernel<true><<<dim3(blocks), dim3(256), 0, 0>>>(c->S, dp.p, dd.p, n, dout.p, any, c->dStackOvf.p);
   else if (c->anyMotion) rayQueryKernel<false, true><<<dim3(blocks), dim3(256), 0, 0>>>(c->S, dp.p, dd.p, n, dout.p, any, c->dStackOvf.p, time);
   else                   rayQueryKernel<false><<<dim3(blocks), dim3(256), 0, 0>>>(c->S, dp.p, dd.p, n, dout.p, any, c->dStackOvf.p);
@@ -1074,8 +1078,13 @@ static void launchPT(const DevScene& S, const Job& job, int blocks, hipStream_t 
 template <int MODE>
 static void launchPTMotion(const DevScene& S, const Job& job, int blocks, hipStream_t st, bool deep)
 {
-  if (deep) pathTraceKernel<false, false, MODE, true, false, true><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
-  else      pathTraceKernel<false, false, MODE, false, false, true><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
+  if (S.flatMode) {
+    if (deep) pathTraceKernel<false, false, MODE, true, true, true><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
+    else      pathTraceKernel<false, false, MODE, false, true, true><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
+  } else {
+    if (deep) pathTraceKernel<false, false, MODE, true, false, true><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
+    else      pathTraceKernel<false, false, MODE, false, false, true><<<dim3(blocks), dim3(256), 0, st>>>(S, job);
+  }
 }
 
 static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStream_t st)
@@ -1093,7 +1102,6 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   if (dr && (c->S.traceDepth == 0 || c->S.traceDepth > 16)) return c->fail(HPT_ERR_ARG, "PathTraceDR: trace depth must be 1..16");
   if (dr && c->S.lensCount) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceDR: the lens simulation is not differentiated");
   if (dr && c->S.motion) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceDR: motion blur is not differentiated");
-  if (c->S.motion && c->schedule == 2) return c->fail(HPT_ERR_UNSUPPORTED, "motion blur runs on the megakernel schedule");
   // the DR kernels add the constant m_envColor unweighted; the reference's replay evaluates EnvironmentColor() with the map and the
   // env-sampling MIS weight (integrator_dr.cpp:1077-1098): such scenes are refused rather than differentiated differently
   if (dr && (c->S.envTexId != 0xFFFFFFFFu || c->S.envEnableSam != 0u || c->S.envCamBackId != 0xFFFFFFFFu))
@@ -1112,7 +1120,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   job.drSkipNonFinite = c->drSkipNonFinite ? 1u : 0u;
   const bool stats = c->instrument && !dr;
   c->lastSchedule = 1;
-  if (!inRays && !motion && useWavefront(c, naive, dr, stats && c->schedule != 2, job.tidCount)) { c->lastSchedule = 2; return launch_wavefront(c, job, st, dr); }
+  if (!inRays && useWavefront(c, naive, dr, stats && c->schedule != 2, job.tidCount)) { c->lastSchedule = 2; return launch_wavefront(c, job, st, dr); }
   if (stats) { HIPCHK(c, c->dCounters.alloc(1)); HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(Counters), st)); job.counters = c->dCounters.p; }
   if (dr) {
     job.recordLanes = (uint)blocks * 256u;
@@ -1162,6 +1170,16 @@ static void launchWfTrace(hpt_ctx* c, const WfPool& P, uint iter, int blocks, hi
 {
   const uint lanes = (uint)blocks * 256u; Counters* cn = c->dCounters.p;
   const uint grace = c->wfGrace;
+  if (c->S.motion != 0u && !STATS) {                           // moving instances: the rays carry their path's time
+    if (c->S.flatMode) {
+      if (deep) wfTraceKernel<true, true, false, true><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
+      else      wfTraceKernel<false, true, false, true><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
+    } else {
+      if (deep) wfTraceKernel<true, false, false, true><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
+      else      wfTraceKernel<false, false, false, true><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
+    }
+    return;
+  }
   if (c->S.flatMode) {
     if (deep) wfTraceKernel<true, true, STATS><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
     else      wfTraceKernel<false, true, STATS><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
@@ -1229,10 +1247,11 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr)
     HIPCHK(c, g.u[6].alloc(g.itemCount));
     HIPCHK(c, g.u[7].alloc(suspWords)); HIPCHK(c, g.u[8].alloc(suspWords));
     if (dr) { HIPCHK(c, g.rec.alloc((size_t)g.itemCount * REC_FIELDS * (c->S.traceDepth + 1))); HIPCHK(c, g.lossSlot.alloc(g.itemCount)); }
+    if (c->S.motion) HIPCHK(c, g.time.alloc(g.itemCount));
     WfPool& P = pools[gi];
     P.rayO = g.f4[0].p; P.rayD = g.f4[1].p; P.thr = g.f4[2].p; P.acc = g.f4[3].p;
     P.shO = g.f4[4].p; P.shD = g.f4[5].p; P.contrib = g.f4[6].p; P.hit = g.f4[7].p;
-    P.hitInst = g.u[0].p; P.occl = g.u[1].p; P.lossSlot = dr ? g.lossSlot.p : nullptr; P.status = g.u[2].p; P.rayQ[0] = g.u[3].p; P.rayQ[1] = g.u[5].p; P.ctr = g.u[4].p; P.inflight = g.u[6].p;
+    P.hitInst = g.u[0].p; P.occl = g.u[1].p; P.lossSlot = dr ? g.lossSlot.p : nullptr; P.time = c->S.motion ? g.time.p : nullptr; P.status = g.u[2].p; P.rayQ[0] = g.u[3].p; P.rayQ[1] = g.u[5].p; P.ctr = g.u[4].p; P.inflight = g.u[6].p;
     P.susp[0] = g.u[7].p; P.susp[1] = g.u[8].p; P.maxSusp = (uint)maxSusp; P.suspStack = std::max(c->stackNeeded, 1u);
     HIPCHK(c, hipStreamWaitEvent(g.stream, c->wfFork, 0));
     HIPCHK(c, hipMemsetAsync(P.ctr, 0, 2 * WF_CTR_WORDS * sizeof(uint), g.stream));
@@ -1247,6 +1266,7 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr)
       wj.itemBase = g.itemBase; wj.itemCount = g.itemCount; wj.iter = (uint)g.it; wj.record = g.rec.p;
       const dim3 sg((g.itemCount + 255u) / 256u);
       if (dr)                    wfShadeKernel<true, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
+      else if (c->S.motion)      wfShadeKernel<false, false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
       else if (c->leanMaterials && !c->forceFull && c->S.lensCount == 0u) wfShadeKernel<false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
       else                       wfShadeKernel<false, false><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
       if ((g.it % WF_CHECK) == WF_CHECK - 1) {
@@ -1275,6 +1295,7 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr)
           // rays the last trace pass suspended are already counted in the same word. Work left = an incomplete frame: say so.
           wj.iter = (uint)g.it;
           if (dr)                    wfShadeKernel<true, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
+          else if (c->S.motion)      wfShadeKernel<false, false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
           else if (c->leanMaterials && !c->forceFull && c->S.lensCount == 0u) wfShadeKernel<false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
           else                       wfShadeKernel<false, false><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
           uint left = 0;

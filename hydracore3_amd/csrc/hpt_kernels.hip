@@ -226,7 +226,7 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
   template __global__ void pathTraceKernel<STATS, DR, MODE, true,  true,  false>(const DevScene, const Job); \
   template __global__ void pathTraceKernel<STATS, DR, MODE, false, false, false, true>(const DevScene, const Job);   /* the triangle sweep of tiny scenes */
 #ifndef HPT_INST_GROUP
-#error "compile hpt_kernels.hip with -DHPT_INST_GROUP=1..7"
+#error "compile hpt_kernels.hip with -DHPT_INST_GROUP=1..8"
 #endif
 #if HPT_INST_GROUP == 1      // gltf + emissive scenes (every benchmark workload)
 HPT_INST4(false, false, 3)
@@ -240,13 +240,20 @@ HPT_INST4(false, false, 2)
 HPT_INST4(true, false, 0)
 #elif HPT_INST_GROUP == 6    // PathTraceDR
 HPT_INST4(false, true, 0)
-#elif HPT_INST_GROUP == 7    // moving instances (two-level layout only)
+#elif HPT_INST_GROUP == 7    // moving instances
 template __global__ void pathTraceKernel<false, false, 0, false, false, true>(const DevScene, const Job);
 template __global__ void pathTraceKernel<false, false, 0, true,  false, true>(const DevScene, const Job);
 template __global__ void pathTraceKernel<false, false, 1, false, false, true>(const DevScene, const Job);
 template __global__ void pathTraceKernel<false, false, 1, true,  false, true>(const DevScene, const Job);
 template __global__ void pathTraceKernel<false, false, 2, false, false, true>(const DevScene, const Job);
 template __global__ void pathTraceKernel<false, false, 2, true,  false, true>(const DevScene, const Job);
+#elif HPT_INST_GROUP == 8    // moving instances, single-level layout
+template __global__ void pathTraceKernel<false, false, 0, false, true, true>(const DevScene, const Job);
+template __global__ void pathTraceKernel<false, false, 0, true,  true, true>(const DevScene, const Job);
+template __global__ void pathTraceKernel<false, false, 1, false, true, true>(const DevScene, const Job);
+template __global__ void pathTraceKernel<false, false, 1, true,  true, true>(const DevScene, const Job);
+template __global__ void pathTraceKernel<false, false, 2, false, true, true>(const DevScene, const Job);
+template __global__ void pathTraceKernel<false, false, 2, true,  true, true>(const DevScene, const Job);
 #endif
 
 } // namespace hpt

@@ -57,7 +57,7 @@ HPT_DEV void blockAppend(uint* counter, bool qNear, bool qShad, uint& posNear, u
   posShad = base + cn + mbcnt64(ms);
 }
 
-template <bool DR, bool LEAN>
+template <bool DR, bool LEAN, bool MOTION>
 __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const WfPool P, const WfJob job)
 {
   __shared__ uint drStage[DR ? 4 * DR_STAGE_DWORDS : 1];                   // the waves' staging areas of the cooperative gradient scatter (drReverseSweep)
@@ -84,6 +84,8 @@ __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const W
     const uint XY = job.packedXY[tid];
     V3 accum = v3(0, 0, 0), thr = v3(1, 1, 1), rpos = v3(0, 0, 0), rdir = v3(0, 0, 1);
     float misPdf = 1.0f, misIor = 1.0f; uint flags = 0, bounce = 0;
+    float pathTime = 0.0f;
+    if (MOTION && alive) pathTime = P.time[s];
     if (alive || ending) { const float4 a = P.acc[s]; accum = v3(a.x, a.y, a.z); bounce = __float_as_uint(a.w); }
     if (DR && ending) { const float4 t4 = P.thr[s]; thr = v3(t4.x, t4.y, t4.z); }     // the environment term of the finished path needs its throughput
     // (6') the shadow ray traced since the last visit: add the candidate contribution in the megakernel's order
@@ -105,8 +107,8 @@ __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const W
       V3 rA = v3(0, 0, 0), rS = v3(0, 0, 0), rdA = v3(0, 0, 0), rdS = v3(0, 0, 0); Taps taps; uint recTex = 0xFFFFFFFFu;   // adjoint record of this vertex (DR)
       for (int k = 0; k < 4; k++) { taps.off[k] = 0; taps.w[k] = 0.0f; }
       const V3 thrBefore = thr;
-      const bool didBounce = shadeVertex<DR, false, LEAN>(S, DR ? job.data : nullptr, hit, rpos, rdir, accum, thr, misPdf, misIor, flags, bounce, gen,
-                                                    wantShadow, shPos, shDir, shFar, contrib, rA, rS, rdA, rdS, taps, recTex, tailR);
+      const bool didBounce = shadeVertex<DR, false, LEAN, MOTION>(S, DR ? job.data : nullptr, hit, rpos, rdir, accum, thr, misPdf, misIor, flags, bounce, gen,
+                                                    wantShadow, shPos, shDir, shFar, contrib, rA, rS, rdA, rdS, taps, recTex, tailR, pathTime);
       if (DR && didBounce) {
         if (!wantShadow) { rS = v3(0, 0, 0); rdS = v3(0, 0, 0); }           // (an occluded sample is cleared when its shadow ray comes back)
         drStoreRecord(job.record, job.itemCount, s, bounce, rA, rS, rdA, rdS, thrBefore, recTex, taps);
@@ -146,6 +148,7 @@ __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const W
       accum = v3(0, 0, 0); thr = v3(1, 1, 1); flags = 0; bounce = 0; misPdf = 1.0f; misIor = 1.0f;
       const V4 lens = rng_float4(gen);
       cameraRay<!(DR || LEAN)>(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
+      if (MOTION) { pathTime = rng_float1(gen); P.time[s] = pathTime; }    // GetRandomNumbersTime (integrator_pt.cpp:114-115): one step per path, after the lens
       alive = true;
     }
     job.gens[tid] = gen;
@@ -190,7 +193,7 @@ __global__ void wfLossFinishKernel(const double* acc, float* loss) { *loss += (f
 #ifndef HPT_WF_XCD_RANGES
 #define HPT_WF_XCD_RANGES 1
 #endif
-template <bool DEEP, bool FLAT, bool STATS>
+template <bool DEEP, bool FLAT, bool STATS, bool MOTION>
 __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScene S, const WfPool P, uint iter, uint refillBelow, uint grace,
                                                                    uint* stackOverflow, uint gridLanes, Counters* counters)
 {
@@ -214,8 +217,10 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
     return;
   }
 
-  __shared__ uint stashMem[4 * 8 * 64];
-  uint* stash = stashMem + (threadIdx.x >> 6) * (8 * 64);
+  constexpr uint STASH = MOTION ? 9u : 8u;                                 // dwords per stashed ray (motion blur: + the ray's time)
+  __shared__ uint stashMem[4 * STASH * 64];
+  uint* stash = stashMem + (threadIdx.x >> 6) * (STASH * 64);
+  float rayTime = 0.0f;
   const uint lane = threadIdx.x & 63u;
   bool has = false, isAny = false, found = false, resumed = false;
   uint dryTrips = 0;
@@ -274,6 +279,7 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
                 uint* e = stash + (stashCount + lane);
                 e[0 * 64] = __float_as_uint(a.x); e[1 * 64] = __float_as_uint(a.y); e[2 * 64] = __float_as_uint(a.z); e[3 * 64] = __float_as_uint(a.w);
                 e[4 * 64] = __float_as_uint(b.x); e[5 * 64] = __float_as_uint(b.y); e[6 * 64] = __float_as_uint(b.z); e[7 * 64] = q;
+                if (MOTION) e[8 * 64] = __float_as_uint(P.time[sl]);       // both rays of a path carry the path's time
               }
               stashCount += granted;
             }
@@ -288,6 +294,7 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
           wo = v3(__uint_as_float(e[0 * 64]), __uint_as_float(e[1 * 64]), __uint_as_float(e[2 * 64])); hitT = __uint_as_float(e[3 * 64]);
           wd = v3(__uint_as_float(e[4 * 64]), __uint_as_float(e[5 * 64]), __uint_as_float(e[6 * 64]));
           const uint q = e[7 * 64];
+          if (MOTION) rayTime = __uint_as_float(e[8 * 64]);
           slot = q & 0x3FFFFFFFu; isAny = (q >> 31) != 0u; resumed = (q & 0x40000000u) != 0u;
           o = wo; d = wd; id = rcp3(wd);
           cur = S.rootRef; curInst = 0xFFFFFFFFu; sp = 0; found = false;
@@ -300,7 +307,8 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
             for (int k = 0; k < sp; k++) { const uint v = r[(WF_SUSP_WORDS + k) * SM]; if (DEEP) stkPush(stk, k, v); else stk.lds[k * 256] = v; }
             if (FLAT) curInst = 0xFFFFFFFFu;                                 // the object-space ray is rebuilt at the next triangle
             else if (curInst != 0xFFFFFFFFu) {
-              toObjectSpace(S.insts, curInst, wo, wd, o, d);
+              if (MOTION && S.insts[curInst].pad0 != 0u) toObjectSpaceMotion(S.instMotion + 24u * curInst, rayTime, wo, wd, o, d);
+              else toObjectSpace(S.insts, curInst, wo, wd, o, d);
               id = rcp3(d);
             }
           }
@@ -351,8 +359,9 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
               uint inst = curInst;
               if (FLAT) {
                 inst = __float_as_uint(b.w);
-                if (inst != curInst) {                                          // world -> object space of this triangle's instance
-                  toObjectSpace(S.insts, inst, wo, wd, o, d);
+                if (inst != curInst) {                                          // world -> object space of this triangle's instance (at the ray's time, if it moves)
+                  if (MOTION && S.insts[inst].pad0 != 0u) toObjectSpaceMotion(S.instMotion + 24u * inst, rayTime, wo, wd, o, d);
+                  else toObjectSpace(S.insts, inst, wo, wd, o, d);
                   curInst = inst;
                 }
               }
@@ -362,7 +371,8 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
             else if (sp > 0) HPT_POP(); else done = true;
           } else if (cnt == 0u) {
             const uint inst = cur & 0x0FFFFFFFu;
-            toObjectSpace(S.insts, inst, wo, wd, o, d);
+            if (MOTION && S.insts[inst].pad0 != 0u) toObjectSpaceMotion(S.instMotion + 24u * inst, rayTime, wo, wd, o, d);
+            else toObjectSpace(S.insts, inst, wo, wd, o, d);
             id = rcp3(d);
             curInst = inst;
             HPT_PUSH(REF_RESTORE);
@@ -436,11 +446,14 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
 template __global__ void wfShadeKernel<true, true>(const DevScene, const WfPool, const WfJob);
 template __global__ void wfShadeKernel<false, true>(const DevScene, const WfPool, const WfJob);
 template __global__ void wfShadeKernel<false, false>(const DevScene, const WfPool, const WfJob);
+template __global__ void wfShadeKernel<false, false, true>(const DevScene, const WfPool, const WfJob);     // moving instances (every BSDF branch)
 #endif
 #if HPT_WF_INST == 0 || HPT_WF_INST == 2
 #define HPT_WFT(DEEP, FLAT, STATS) template __global__ void wfTraceKernel<DEEP, FLAT, STATS>(const DevScene, const WfPool, uint, uint, uint, uint*, uint, Counters*);
 HPT_WFT(false, false, false) HPT_WFT(true, false, false) HPT_WFT(false, true, false) HPT_WFT(true, true, false)
 HPT_WFT(false, false, true)  HPT_WFT(true, false, true)  HPT_WFT(false, true, true)  HPT_WFT(true, true, true)
+#define HPT_WFTM(DEEP, FLAT) template __global__ void wfTraceKernel<DEEP, FLAT, false, true>(const DevScene, const WfPool, uint, uint, uint, uint*, uint, Counters*);
+HPT_WFTM(false, false) HPT_WFTM(true, false) HPT_WFTM(false, true) HPT_WFTM(true, true)
 #endif
 
 } // namespace hpt

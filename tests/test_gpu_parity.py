@@ -1066,12 +1066,20 @@ def test_motion_blur_matches_oracle():
     still = _motion_scene(); still.inst_motion = {}
     s = HipIntegrator(still).render(8)
     assert per_pixel_l2(s, a, 8) > 1e-2
-    # schedules / layouts that cannot hold moving instances say so
-    wf = HipIntegrator(sc); wf.set_schedule(2)
-    with pytest.raises(HydraHipError, match="megakernel"):
-        wf.render(1)
-    with pytest.raises(HydraHipError, match="two-level"):
-        HipIntegrator(sc, accel_layout=2)
+    # either BVH layout and either schedule hold moving instances: same hits, same frames, same generators bit for bit
+    two, flat = HipIntegrator(sc, accel_layout=1), HipIntegrator(sc, accel_layout=2)
+    assert two.accel_info()["layout"] == "two-level" and flat.accel_info()["layout"] == "flat"
+    for time in (0.0, 0.37, 1.0):
+        assert np.array_equal(flat.RayQuery_NearestHitMotion(org, dirs, time).view(np.uint8), two.RayQuery_NearestHitMotion(org, dirs, time).view(np.uint8)), time
+        assert np.array_equal(flat.RayQuery_AnyHitMotion(org, dirs, time), two.RayQuery_AnyHitMotion(org, dirs, time))
+    ref = two.render(6)
+    assert np.array_equal(flat.render(6), ref) and np.array_equal(flat.random_gens(), two.random_gens())
+    for layout in (1, 2):
+        wf = HipIntegrator(sc, accel_layout=layout); wf.set_schedule(2, 56, 0, 1)
+        assert np.array_equal(wf.render(6), ref), layout
+        assert wf.last_schedule()[0] == 2 and np.array_equal(wf.random_gens(), two.random_gens())
+    with pytest.raises(HydraHipError, match="sweep"):
+        HipIntegrator(sc, accel_layout=3)
 
 
 def test_automatic_schedule_follows_the_sah_estimate():

@@ -24,6 +24,7 @@
 #include <string>
 #include <vector>
 
+#include <zlib.h>                       // inflate for PNG textures (link the tools with -lz)
 #include "integrator_hip.h"
 #include "plastic_precompute.h"
 
@@ -314,6 +315,85 @@ inline void lightFrame(const M4& m, LightSource& l)          // pos = M (0,0,0,1
 inline double colLen(const M4& m, int c) { return std::sqrt(m.m[0][c] * m.m[0][c] + m.m[1][c] * m.m[1][c] + m.m[2][c] * m.m[2][c]); }
 
 // CreateSphericalTextureFromIES, axially symmetric photometry, normalised to max 1 (integrator_pt_scene_lgt.cpp:171-186)
+// ---- LDR image files of LoadTextureAndMakeCombined (integrator_pt_scene_tex.cpp:24-33: .png / .ppm / .bmp through LiteImage::LoadImage<uint32_t>) ----
+// RGBA8 texels, r in the low byte, rows in FILE order (PNG / PPM: top row first; BMP: as stored, bottom row first unless its height is negative).
+// LiteImage is absent from the tree, so the row order it hands out is unpinned; .jpg / .exr need decoders this image does not carry.
+inline uint32_t be32(const uint8_t* p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | uint32_t(p[3]); }
+inline bool decodePng(const std::vector<uint8_t>& f, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba, std::string& err)
+{
+  static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
+  if (f.size() < 33 || std::memcmp(f.data(), sig, 8) != 0) { err = "not a PNG file"; return false; }
+  std::vector<uint8_t> idat, plte, trns; uint8_t depth = 0, ctype = 0, interlace = 0; w = h = 0;
+  for (size_t p = 8; p + 12 <= f.size();) {
+    const uint32_t len = be32(&f[p]); const std::string type((const char*)&f[p + 4], 4);
+    if (p + 12 + (size_t)len > f.size()) { err = "PNG truncated"; return false; }
+    const uint8_t* d = &f[p + 8];
+    if (type == "IHDR" && len >= 13) { w = be32(d); h = be32(d + 4); depth = d[8]; ctype = d[9]; interlace = d[12]; }
+    else if (type == "PLTE") plte.assign(d, d + len);
+    else if (type == "tRNS") trns.assign(d, d + len);
+    else if (type == "IDAT") idat.insert(idat.end(), d, d + len);
+    else if (type == "IEND") break;
+    p += 12 + (size_t)len;
+  }
+  if (w == 0 || h == 0 || depth != 8 || interlace != 0 || (ctype != 0 && ctype != 2 && ctype != 3 && ctype != 4 && ctype != 6)) { err = "PNG: only 8-bit non-interlaced images are read"; return false; }
+  const uint32_t ch = ctype == 0 ? 1u : ctype == 2 ? 3u : ctype == 3 ? 1u : ctype == 4 ? 2u : 4u;
+  const size_t stride = (size_t)w * ch;
+  std::vector<uint8_t> raw((stride + 1) * h);
+  uLongf outLen = (uLongf)raw.size();
+  if (uncompress(raw.data(), &outLen, idat.data(), (uLong)idat.size()) != Z_OK || outLen != raw.size()) { err = "PNG: inflate failed"; return false; }
+  std::vector<uint8_t> img(stride * h);
+  for (uint32_t y = 0; y < h; y++) {                                          // undo the scanline filters (PNG spec 9)
+    const uint8_t ft = raw[(stride + 1) * y]; const uint8_t* in = &raw[(stride + 1) * y + 1];
+    uint8_t* out = &img[stride * y]; const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
+    for (size_t x = 0; x < stride; x++) {
+      const int a = x >= ch ? out[x - ch] : 0, b = up ? up[x] : 0, c = (up && x >= ch) ? up[x - ch] : 0;
+      int pred = 0;
+      if (ft == 1) pred = a; else if (ft == 2) pred = b; else if (ft == 3) pred = (a + b) >> 1;
+      else if (ft == 4) { const int pp = a + b - c, pa = std::abs(pp - a), pb = std::abs(pp - b), pc = std::abs(pp - c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+      else if (ft != 0) { err = "PNG: bad filter type"; return false; }
+      out[x] = (uint8_t)(in[x] + pred);
+    }
+  }
+  rgba.resize((size_t)w * h * 4);
+  for (size_t i = 0; i < (size_t)w * h; i++) {
+    const uint8_t* s = &img[i * ch]; uint8_t* o = &rgba[4 * i];
+    if (ctype == 0) { o[0] = o[1] = o[2] = s[0]; o[3] = 255; }
+    else if (ctype == 2) { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = 255; }
+    else if (ctype == 3) { const size_t k = s[0]; if (3 * k + 2 >= plte.size()) { err = "PNG: palette index out of range"; return false; } o[0] = plte[3 * k]; o[1] = plte[3 * k + 1]; o[2] = plte[3 * k + 2]; o[3] = k < trns.size() ? trns[k] : 255; }
+    else if (ctype == 4) { o[0] = o[1] = o[2] = s[0]; o[3] = s[1]; }
+    else { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3]; }
+  }
+  return true;
+}
+inline bool decodePpm(const std::vector<uint8_t>& f, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba, std::string& err)
+{
+  size_t p = 0; auto token = [&]() { std::string t; while (p < f.size()) { if (f[p] == '#') { while (p < f.size() && f[p] != '\n') p++; } else if (std::isspace(f[p])) { if (!t.empty()) break; p++; } else t.push_back((char)f[p++]); } return t; };
+  if (token() != "P6") { err = "PPM: only binary P6 is read"; return false; }
+  w = (uint32_t)std::atoll(token().c_str()); h = (uint32_t)std::atoll(token().c_str()); const int maxv = std::atoi(token().c_str());
+  p++;                                                                        // the single whitespace byte after the header
+  if (w == 0 || h == 0 || maxv != 255 || p + (size_t)w * h * 3 > f.size()) { err = "PPM: bad header or truncated"; return false; }
+  rgba.resize((size_t)w * h * 4);
+  for (size_t i = 0; i < (size_t)w * h; i++) { rgba[4 * i] = f[p + 3 * i]; rgba[4 * i + 1] = f[p + 3 * i + 1]; rgba[4 * i + 2] = f[p + 3 * i + 2]; rgba[4 * i + 3] = 255; }
+  return true;
+}
+inline bool decodeBmp(const std::vector<uint8_t>& f, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba, std::string& err)
+{
+  if (f.size() < 54 || f[0] != 'B' || f[1] != 'M') { err = "not a BMP file"; return false; }
+  uint32_t off; int32_t sw, sh; uint16_t bpp; uint32_t comp;
+  std::memcpy(&off, &f[10], 4); std::memcpy(&sw, &f[18], 4); std::memcpy(&sh, &f[22], 4); std::memcpy(&bpp, &f[28], 2); std::memcpy(&comp, &f[30], 4);
+  if (sw <= 0 || sh == 0 || (bpp != 24 && bpp != 32) || (comp != 0 && comp != 3)) { err = "BMP: only uncompressed 24 / 32-bit images are read"; return false; }
+  w = (uint32_t)sw; h = (uint32_t)std::abs(sh);
+  const size_t stride = (((size_t)w * (bpp / 8)) + 3) & ~size_t(3);
+  if (off + stride * h > f.size()) { err = "BMP truncated"; return false; }
+  rgba.resize((size_t)w * h * 4);
+  for (uint32_t y = 0; y < h; y++) for (uint32_t x = 0; x < w; x++) {         // rows as stored (bottom-up for a positive height)
+    const uint8_t* s = &f[off + stride * y + (size_t)x * (bpp / 8)]; uint8_t* o = &rgba[4 * ((size_t)y * w + x)];
+    o[0] = s[2]; o[1] = s[1]; o[2] = s[0]; o[3] = bpp == 32 ? s[3] : 255;
+  }
+  return true;
+}
+inline bool endsWithNoCase(const std::string& s, const char* ext) { const size_t n = std::strlen(ext); if (s.size() < n) return false; for (size_t i = 0; i < n; i++) if (std::tolower((unsigned char)s[s.size() - n + i]) != ext[i]) return false; return true; }
+
 inline bool iesSphericalTexture(const std::string& path, LoadedTexture& tex, std::string& err)
 {
   std::vector<uint8_t> raw; if (!readFile(path, raw)) { err = "cannot read " + path; return false; }
@@ -436,11 +516,17 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
     auto it = texCache.find(key); if (it != texCache.end()) { outId = it->second; return true; }
     if (xid >= texInfo.size()) { err = "xml: texture id not in textures_lib"; return false; }
     const TexInfo& ti = texInfo[xid];
-    if (ti.path.find(".image") == std::string::npos) { err = "texture file '" + ti.path + "': only the Hydra .image4ub / .image4f containers are read here"; return false; }
     std::vector<uint8_t> img;
     if (!readFile(ti.path, img) || img.size() < 8) { err = "cannot read " + ti.path; return false; }
-    uint32_t w, h; std::memcpy(&w, img.data(), 4); std::memcpy(&h, img.data() + 4, 4);          // {w, h} then the texels (integrator_pt_scene_tex.cpp:53-93)
     LoadedTexture t; t.addressU = au; t.addressV = av; t.filter = filt;
+    if (ti.path.find(".image") == std::string::npos) {                        // LDR files through LiteImage::LoadImage<uint32_t> (:24-33)
+      uint32_t w = 0, h = 0; std::vector<uint8_t> rgba; std::string derr;
+      const bool ok = endsWithNoCase(ti.path, ".png") ? decodePng(img, w, h, rgba, derr) : endsWithNoCase(ti.path, ".ppm") ? decodePpm(img, w, h, rgba, derr)
+                    : endsWithNoCase(ti.path, ".bmp") ? decodeBmp(img, w, h, rgba, derr) : (derr = "only .image4ub / .image4f / .png / .ppm / .bmp are read here (no JPEG / EXR decoder in this image)", false);
+      if (!ok) { err = "texture file '" + ti.path + "': " + derr; return false; }
+      t.width = w; t.height = h; t.format = 0u; t.flags = disableGamma ? 0u : 1u; t.bytes.swap(rgba);
+    } else {
+    uint32_t w, h; std::memcpy(&w, img.data(), 4); std::memcpy(&h, img.data() + 4, 4);          // {w, h} then the texels (integrator_pt_scene_tex.cpp:53-93)
     if (w == 0 || h == 0) {                                                  // white float dummy (:67-73)
       t.width = t.height = 1; t.format = 1; t.flags = 0; const float one[4] = {1, 1, 1, 1}; t.bytes.assign((const uint8_t*)one, (const uint8_t*)one + 16);
     } else {
@@ -448,6 +534,7 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
       if (img.size() < 8 + (size_t)w * h * texel) { err = "image truncated: " + ti.path; return false; }
       t.width = w; t.height = h; t.format = ti.bpp == 16 ? 1u : 0u; t.flags = (ti.bpp != 16 && !disableGamma) ? 1u : 0u;
       t.bytes.assign(img.begin() + 8, img.begin() + 8 + (size_t)w * h * texel);
+    }
     }
     sc.textures.push_back(std::move(t));
     outId = texCache[key] = (uint32_t)sc.textures.size() - 1;

@@ -732,6 +732,108 @@ def load_image4ub(path):
     return np.frombuffer(raw, "<u4", w * h, 8).reshape(h, w)
 
 
+def decode_ldr_image(path, raw):
+    """.png / .ppm / .bmp -> uint32 [h, w] RGBA8 (r in the low byte), rows in file order - the same decoders as csrc/scene_loader.h
+    (8-bit non-interlaced PNG through zlib, binary PPM, uncompressed 24 / 32-bit BMP); no JPEG / EXR decoder in this image."""
+    import zlib
+    low = path.lower()
+    if low.endswith(".png"):
+        if raw[:8] != b"\x89PNG\r\n\x1a\n":
+            raise ValueError(f"{path}: not a PNG file")
+        p, idat, plte, trns, hdr = 8, b"", b"", b"", None
+        while p + 12 <= len(raw):
+            ln, typ = struct.unpack_from(">I4s", raw, p)
+            d = raw[p + 8:p + 8 + ln]
+            if typ == b"IHDR":
+                hdr = struct.unpack_from(">IIBBBBB", d)
+            elif typ == b"PLTE":
+                plte = d
+            elif typ == b"tRNS":
+                trns = d
+            elif typ == b"IDAT":
+                idat += d
+            elif typ == b"IEND":
+                break
+            p += 12 + ln
+        w, h, depth, ctype, _, _, interlace = hdr
+        if depth != 8 or interlace != 0 or ctype not in (0, 2, 3, 4, 6):
+            raise NotImplementedError(f"{path}: only 8-bit non-interlaced PNG images are read")
+        ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+        stride = w * ch
+        data = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, stride + 1)
+        img = np.zeros((h, stride), np.uint8)
+        for y in range(h):                                                   # undo the scanline filters (PNG spec 9)
+            ft, line = int(data[y, 0]), data[y, 1:].astype(np.int32)
+            up = img[y - 1].astype(np.int32) if y else np.zeros(stride, np.int32)
+            if ft == 0:
+                out = line
+            elif ft == 2:
+                out = line + up
+            else:
+                out = np.zeros(stride, np.int32)
+                for x in range(stride):
+                    a = out[x - ch] if x >= ch else 0
+                    b = up[x]
+                    c = up[x - ch] if x >= ch else 0
+                    if ft == 1:
+                        pred = a
+                    elif ft == 3:
+                        pred = (a + b) >> 1
+                    elif ft == 4:
+                        pp = a + b - c
+                        pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - c)
+                        pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                    else:
+                        raise ValueError(f"{path}: bad PNG filter type {ft}")
+                    out[x] = (line[x] + pred) & 255
+            img[y] = (out & 255).astype(np.uint8)
+        px = img.reshape(h, w, ch).astype(np.uint32)
+        if ctype == 0:
+            r = g = b = px[..., 0]; a = np.full((h, w), 255, np.uint32)
+        elif ctype == 2:
+            r, g, b = px[..., 0], px[..., 1], px[..., 2]; a = np.full((h, w), 255, np.uint32)
+        elif ctype == 3:
+            pal = np.frombuffer(plte, np.uint8).reshape(-1, 3).astype(np.uint32)
+            al = np.full(pal.shape[0], 255, np.uint32); al[:len(trns)] = np.frombuffer(trns, np.uint8)[:pal.shape[0]]
+            k = px[..., 0]
+            r, g, b, a = pal[k, 0], pal[k, 1], pal[k, 2], al[k]
+        elif ctype == 4:
+            r = g = b = px[..., 0]; a = px[..., 1]
+        else:
+            r, g, b, a = px[..., 0], px[..., 1], px[..., 2], px[..., 3]
+        return (r | (g << 8) | (b << 16) | (a << 24)).astype(np.uint32)
+    if low.endswith(".ppm"):
+        toks, p = [], 0
+        while len(toks) < 4:
+            while raw[p:p + 1].isspace():
+                p += 1
+            if raw[p:p + 1] == b"#":
+                p = raw.index(b"\n", p)
+                continue
+            q = p
+            while not raw[q:q + 1].isspace():
+                q += 1
+            toks.append(raw[p:q]); p = q
+        if toks[0] != b"P6" or int(toks[3]) != 255:
+            raise NotImplementedError(f"{path}: only binary P6 PPM with 8-bit samples is read")
+        w, h = int(toks[1]), int(toks[2])
+        px = np.frombuffer(raw, np.uint8, w * h * 3, p + 1).reshape(h, w, 3).astype(np.uint32)
+        return (px[..., 0] | (px[..., 1] << 8) | (px[..., 2] << 16) | np.uint32(0xFF000000)).astype(np.uint32)
+    if low.endswith(".bmp"):
+        off, = struct.unpack_from("<I", raw, 10)
+        sw, sh = struct.unpack_from("<ii", raw, 18)
+        bpp, = struct.unpack_from("<H", raw, 28)
+        comp, = struct.unpack_from("<I", raw, 30)
+        if sw <= 0 or sh == 0 or bpp not in (24, 32) or comp not in (0, 3):
+            raise NotImplementedError(f"{path}: only uncompressed 24 / 32-bit BMP images are read")
+        w, h, bs = sw, abs(sh), bpp // 8
+        stride = (w * bs + 3) & ~3
+        rows = np.frombuffer(raw, np.uint8, stride * h, off).reshape(h, stride)[:, :w * bs].reshape(h, w, bs).astype(np.uint32)
+        a = rows[..., 3] if bs == 4 else np.full((h, w), 255, np.uint32)
+        return (rows[..., 2] | (rows[..., 1] << 8) | (rows[..., 0] << 16) | (a << 24)).astype(np.uint32)
+    raise NotImplementedError(f"texture file '{path}': only .image4ub / .image4f / .png / .ppm / .bmp are read here (no JPEG / EXR decoder in this image)")
+
+
 def ies_spherical_texture(path):
     """CreateSphericalTextureFromIES (ies_parser/ies_render.cpp:29-120), axially symmetric photometry only
     (one horizontal angle), which is what scenes/test_228 uses; normalised to max 1
@@ -835,9 +937,11 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
         key, row0, row1, disable_gamma = sam
         if key not in tex_cache:
             path, w, h, bpp = tex_info[key[0]]
-            if ".image" not in path:
-                raise NotImplementedError(f"texture file '{path}': only the Hydra .image4ub / .image4f containers are read here")
             raw = open(path, "rb").read()
+            if ".image" not in path:                                           # LDR files through LiteImage::LoadImage<uint32_t> (:24-33)
+                tex = Texture(decode_ldr_image(path, raw), TEX_RGBA8, not disable_gamma, key[1], key[2], key[4])
+                tex_cache[key] = sc.add_texture(tex)
+                return tuple(row0), tuple(row1), tex_cache[key]
             fw, fh = struct.unpack_from("<II", raw, 0)
             if fw == 0 or fh == 0:                                             # white float dummy (:67-73)
                 tex = Texture(np.ones((1, 1, 4), np.float32), TEX_RGBA32F, False, key[1], key[2], key[4])

@@ -383,7 +383,7 @@ def _read_blobs(path):
     return out
 
 
-@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map"])
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures"])
 def test_cpp_scene_loader_produces_the_same_tables(scene_name, tmp_path):
     """hydracore3_amd/csrc/scene_loader.h (Hydra XML + VSGF + image4ub + IES in C++) == the Python fixture loader:
     every table byte for byte, matrices and light frames to float rounding (both invert in double)."""
@@ -590,3 +590,32 @@ def test_identities_of_the_widened_branches():
     sc.materials += [sc.material_plastic((1.0, 1.0, 1.0), 0.05), sc.material_plastic((0.7, 0.7, 0.7), 0.4, nonlinear=1), sc.material_plastic((0.95, 0.95, 0.95), 0.25, 1.8, 1.0)]
     img = OracleIntegrator(sc, sc.params(S.INTEGRATOR_STUPID_PT)).render(8 * spp, naive=True) / (8 * spp)
     assert img[..., :3].mean() < 1.0 and np.percentile(img[..., :3], 99) < 1.08
+
+
+def test_ldr_image_files_decode_to_the_containers_texels(tmp_path):
+    """.png / .bmp / .ppm textures (LoadTextureAndMakeCombined's LiteImage::LoadImage<uint32_t> branch, integrator_pt_scene_tex.cpp:24-33): the
+    png_textures fixture stores test_035's 256 x 256 texture as an RGBA PNG whose rows cycle through all five filter types and the 2 x 2 one
+    as a top-down 24-bit BMP; the loader returns the very texels of the .image4ub containers. A binary PPM and a bottom-up BMP round-trip too."""
+    import struct
+    from hydracore3_amd.scene import decode_ldr_image, load_hydra_xml
+    a = load_hydra_xml(scene_path("test_035"), 32, 32)
+    b = load_hydra_xml(scene_path("png_textures"), 32, 32)
+    big_a = [t for t in a.textures if t.width == 256][0]
+    big_b = [t for t in b.textures if t.width == 256][0]
+    assert np.array_equal(big_a.data, big_b.data) and big_b.srgb and big_b.fmt == big_a.fmt
+    small = [t for t in b.textures if t.width == 2 and t.height == 2]
+    assert len(small) == 1 and np.all((small[0].data >> 24) == 255)
+    raw0 = open(os.path.join(os.path.dirname(scene_path("test_035")), "data", "chunk_00000.image4ub"), "rb").read()
+    assert np.array_equal(small[0].data & 0xFFFFFF, np.frombuffer(raw0, "<u4", 4, 8).reshape(2, 2) & 0xFFFFFF)
+    rng = np.random.default_rng(1)
+    px = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)
+    ppm = tmp_path / "t.ppm"
+    ppm.write_bytes(b"P6\n# a comment\n7 5\n255\n" + px.tobytes())
+    want = px[..., 0].astype(np.uint32) | (px[..., 1].astype(np.uint32) << 8) | (px[..., 2].astype(np.uint32) << 16) | np.uint32(0xFF000000)
+    assert np.array_equal(decode_ldr_image(str(ppm), ppm.read_bytes()), want)
+    stride = (7 * 3 + 3) & ~3                                             # a bottom-up BMP: rows come out as stored
+    rows = b"".join(px[y, :, ::-1].tobytes() + b"\0" * (stride - 21) for y in range(5))
+    bmp = b"BM" + struct.pack("<IHHI", 54 + len(rows), 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 7, 5, 1, 24, 0, len(rows), 2835, 2835, 0, 0) + rows
+    assert np.array_equal(decode_ldr_image("x.bmp", bmp), want)
+    with pytest.raises(NotImplementedError):
+        decode_ldr_image("x.jpg", b"")

@@ -57,7 +57,7 @@ HPT_DEV V3 operator/(V3 a, V3 b) { return v3(a.x / b.x, a.y / b.y, a.z / b.z); }
 HPT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 HPT_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 HPT_DEV float length(V3 a) { return __builtin_sqrtf(dot(a, a)); }
-HPT_DEV V3 normalize(V3 a) { return a / length(a); }
+HPT_DEV V3 normalize(V3 a) { const float lenInv = 1.0f / length(a); return a * lenInv; }
 HPT_DEV V3 reflect(V3 i, V3 n) { return i - 2.0f * dot(n, i) * n; }
 // std::min / std::max semantics (NaN behaviour included), as the reference's host build evaluates them
 HPT_DEV float smax(float a, float b) { return (a < b) ? b : a; }

@@ -5,7 +5,8 @@
 // conventions below are inferred from the reference's call sites:
 //   * float4x4 is column-major (m_col[4]); M*v is matrix x column vector          (integrator_pt_scene.cpp:443-448)
 //   * mul4x3(M,p) = affine point transform, mul3x3(M,v) = upper-left 3x3 times v  (include/cglobals.h:254-263)
-//   * normalize(v) = v / sqrt(dot(v,v)); dot sums x,y,z left to right
+//   * normalize(v) = v * (1 / sqrt(dot(v,v))) - one reciprocal, three products, the form of LiteMath's generated header (`float lenInv = float(1)/length(a);
+//     return a*lenInv;`); LiteMath is absent from the tree, so this is from memory of the library, unpinned like the rest. dot sums x,y,z left to right
 //   * reflect(i,n) = i - 2*dot(n,i)*n (GLSL semantics)                            (include/cmat_gltf.h:26)
 //   * complex{re,im}, complex_norm = re^2 + im^2                                  (include/cmaterial.h:685-694)
 // PARITY UNPINNED: LiteMath itself cannot be consulted, these are textbook definitions.
@@ -55,7 +56,7 @@ static inline float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; 
 static inline float dot2(f2 a, f2 b) { return a.x * b.x + a.y * b.y; }
 static inline f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 static inline float length(f3 a) { return std::sqrt(dot(a, a)); }
-static inline f3 normalize(f3 a) { return a / length(a); }
+static inline f3 normalize(f3 a) { const float lenInv = 1.0f / length(a); return a * lenInv; }
 static inline f3 reflect(f3 i, f3 n) { return i - 2.0f * dot(n, i) * n; }
 static inline float clampf(float x, float lo, float hi) { return std::min(std::max(x, lo), hi); }
 static inline float lerpf(float a, float b, float t) { return a + t * (b - a); }

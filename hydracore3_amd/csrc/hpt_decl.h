@@ -52,6 +52,10 @@ struct Job
 template <bool STATS, bool DR, int MODE, bool DEEP, bool FLAT, bool MOTION = false, bool SWEEP = false>
 __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const Job job);
 
+// spectral rendering (hpt_spectral.hip): one thread per pixel, four wavelengths per path
+template <bool DEEP, bool FLAT, bool SWEEP>
+__global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene S, const Job job);
+
 // ---- wavefront schedule (hpt_wavefront.hip) --------------------------------------------------------------------------------------------
 static const uint WF_RANGES = 64u;                   // the trace kernel pulls rays from this many ranges of the queue (work stealing)
 static const uint WF_CTR_WORDS = 32u * (1u + WF_RANGES);

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <set>
 #include <chrono>
 #include <dlfcn.h>
 
@@ -89,6 +90,8 @@ struct hpt_ctx
   DevBuf<int> dRemapInst, dRemapLists;
   DevBuf<MaterialRec> dMaterials; DevBuf<LightRec> dLights; DevBuf<TexRec> dTextures;
   std::vector<void*> texData; std::vector<TexRec> hTextures;
+  DevBuf<float> dSpecValues; DevBuf<uint> dSpecOffsetSz; DevBuf<float4> dCieXYZ;   // spectral tables (m_spec_values, m_spec_offset_sz, m_cie_xyz)
+  bool spectralOk = false; std::string spectralWhyNot;   // whether the uploaded scene is within the spectral kernel's scope
   DevBuf<float> dArrays1f; size_t numArrays1f = 0;       // m_arrays1f (pdf table of a sampled environment map)
   DevBuf<float4> dLensLines;                             // m_lines of the lens simulation (hpt_set_optics)
   DevBuf<float> dInstMotion, dNormMat2;                  // motion blur: key matrices of the moving instances, end-of-motion normal matrices
@@ -189,7 +192,7 @@ extern "C" void hpt_destroy(hpt_ctx* c)
   (void)hpt_comm_destroy(c);
   c->dNodes.release(); c->dTris.release(); c->dInsts.release(); c->dSweepInsts.release(); c->dSweepTris.release(); c->dLevelNodes.release(); c->dTriBox.release(); c->dNodeBounds.release(); c->dInstO2W.release(); c->dTriIndices.release(); c->dMatIdByPrim.release();
   c->dMatVertOffset.release(); c->dPackedXY.release(); c->dVData.release(); c->dNormMat.release(); c->dRemapInst.release();
-  c->dRemapLists.release(); c->dMaterials.release(); c->dLights.release(); c->dTextures.release(); c->dArrays1f.release(); c->dGens.release();
+  c->dRemapLists.release(); c->dMaterials.release(); c->dLights.release(); c->dTextures.release(); c->dArrays1f.release(); c->dSpecValues.release(); c->dSpecOffsetSz.release(); c->dCieXYZ.release(); c->dGens.release();
   c->dQueue.release(); c->dStackOvf.release(); c->dCounters.release(); c->dFrame.release(); c->dRecord.release(); c->dRef.release(); c->dData.release();
   c->dGrad.release(); c->dLoss.release(); c->dLossAcc.release();
   for (hpt_ctx::WfGroup* g : c->wfGroups) {
@@ -901,6 +904,67 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
   { std::vector<float> a(d->numArrays1f ? d->arrays1f : nullptr, d->numArrays1f ? d->arrays1f + d->numArrays1f : nullptr); if (a.empty()) a.push_back(0.0f);
     HIPCHK(c, c->dArrays1f.upload(a.data(), a.size())); }
   S.arrays1f = c->dArrays1f.p;
+  // ---- spectral tables (all optional: RGB rendering does not read them) ----
+  {
+    const uint WAVES = 471u;                                   // LAMBDA_MAX - LAMBDA_MIN + 1 samples per spectrum (Spectrum::ResampleUniform)
+    c->spectralOk = d->specValues && d->specOffsetSz && d->numSpectra > 0 && d->cieXYZ && d->numCieXYZ >= WAVES;
+    c->spectralWhyNot = c->spectralOk ? "" : "the scene came without m_spec_values / m_spec_offset_sz / m_cie_xyz";
+    std::vector<uint> so(2 * std::max(1u, d->numSpectra), 0u);
+    for (uint i = 0; i < d->numSpectra && d->specOffsetSz; i++) {
+      so[2 * i] = d->specOffsetSz[2 * i]; so[2 * i + 1] = d->specOffsetSz[2 * i + 1];
+      if (so[2 * i] == 0xFFFFFFFFu) { if (c->spectralOk) { c->spectralOk = false; c->spectralWhyNot = "spectra given by textures (lambda_ref_ids) are outside the path's scope"; } so[2 * i] = 0; continue; }
+      if ((uint64_t)so[2 * i] + std::max(so[2 * i + 1], WAVES - 1u) > d->numSpecValues) return c->fail(HPT_ERR_ARG, "m_spec_offset_sz: spectrum " + std::to_string(i) + " reaches past m_spec_values");
+    }
+    auto specIdOk = [&](uint id) { return id == 0xFFFFFFFFu || id < d->numSpectra; };
+    const MaterialRec* mm = (const MaterialRec*)d->materials;
+    // the materials a hit can reach: m_matIdByPrimId through the remap list of every instance of the mesh (RemapMaterialId); an entry of
+    // the library nothing resolves to - the fixture's own material 0, remapped to the conductor on its only instance - does not take
+    // the scene out of scope
+    std::vector<char> reached(d->numMaterials, 0);
+    if (c->spectralOk) {
+      std::set<std::pair<uint, int>> seen;
+      for (uint inst = 0; inst < d->numInsts; inst++) {
+        const uint g = d->instGeomId[inst];
+        const int list = d->remapInst[2 * inst + 0];
+        if (g >= d->numGeoms || !seen.insert(std::make_pair(g, list)).second) continue;
+        int rOff = 0, rSize = 0;
+        if (list >= 0 && d->allRemapLists && (uint)list + 1 + d->allRemapListsSize < d->allRemapListsLen) {
+          rOff = d->allRemapLists[d->allRemapListsSize + list]; rSize = (d->allRemapLists[d->allRemapListsSize + list + 1] - rOff) / 2;
+        }
+        const uint t0 = d->matVertOffset[2 * g], t1 = std::min(t0 + d->geomTriCount[g], d->numTris);
+        for (uint t = t0; t < t1; t++) {
+          uint id = d->matIdByPrimId[t];
+          for (int k2 = 0; k2 < rSize; k2++) if ((uint)d->allRemapLists[rOff + 2 * k2] == id) { id = (uint)d->allRemapLists[rOff + 2 * k2 + 1]; break; }
+          id &= 0x00FFFFFFu;
+          if (id < d->numMaterials) reached[id] = 1;
+        }
+      }
+    }
+    for (uint i = 0; i < d->numMaterials; i++) {
+      for (int k2 = 0; k2 < 4; k2++) if (d->specValues && !specIdOk(mm[i].spdid[k2])) return c->fail(HPT_ERR_ARG, "material " + std::to_string(i) + " refers to a spectrum that does not exist");
+      if (!reached[i]) continue;
+      const uint t = mm[i].mtype;
+      if (c->spectralOk && t != MAT_TYPE_DIFFUSE && t != MAT_TYPE_CONDUCTOR && t != MAT_TYPE_LIGHT_SOURCE) { c->spectralOk = false; c->spectralWhyNot = "material " + std::to_string(i) + " (type " + std::to_string(t) + ") is not diffuse, conductor or emissive"; }
+      if (c->spectralOk && t != MAT_TYPE_LIGHT_SOURCE && mm[i].texid[1] != 0xFFFFFFFFu) { c->spectralOk = false; c->spectralWhyNot = "normal maps are not in the spectral kernel"; }
+    }
+    const LightRec* ll2 = (const LightRec*)d->lights;
+    for (uint i = 0; i < d->numLights; i++) {
+      if (d->specValues && !specIdOk(ll2[i].specId)) return c->fail(HPT_ERR_ARG, "light " + std::to_string(i) + " refers to a spectrum that does not exist");
+      if (c->spectralOk && ll2[i].geomType == LIGHT_GEOM_ENV) { c->spectralOk = false; c->spectralWhyNot = "sampled environment maps are not in the spectral kernel"; }
+    }
+    for (int k2 = 0; k2 < 3; k2++) if (d->camResponseSpectrumId[k2] >= (int)d->numSpectra) return c->fail(HPT_ERR_ARG, "m_camResponseSpectrumId refers to a spectrum that does not exist");
+    std::vector<float> sv(d->specValues ? std::vector<float>(d->specValues, d->specValues + d->numSpecValues) : std::vector<float>());
+    if (sv.empty()) sv.push_back(0.0f);
+    std::vector<float4> cie(std::max(d->numCieXYZ, 1u), make_float4(0, 0, 0, 0));
+    for (uint i = 0; i < d->numCieXYZ && d->cieXYZ; i++) cie[i] = make_float4(d->cieXYZ[4 * i], d->cieXYZ[4 * i + 1], d->cieXYZ[4 * i + 2], d->cieXYZ[4 * i + 3]);
+    HIPCHK(c, c->dSpecValues.upload(sv.data(), sv.size()));
+    HIPCHK(c, c->dSpecOffsetSz.upload(so.data(), so.size()));
+    HIPCHK(c, c->dCieXYZ.upload(cie.data(), cie.size()));
+    S.specValues = c->dSpecValues.p; S.specOffsetSz = c->dSpecOffsetSz.p; S.cieXYZ = c->dCieXYZ.p;
+    S.numCieXYZ = d->cieXYZ ? d->numCieXYZ : 0u; S.numSpectra = d->numSpectra;
+    for (int k2 = 0; k2 < 3; k2++) S.camResponseSpectrumId[k2] = d->specValues ? d->camResponseSpectrumId[k2] : -1;
+    S.camResponseType = d->camResponseType;
+  }
   c->hLightGeom.resize(d->numLights);
   for (uint i = 0; i < d->numLights; i++) c->hLightGeom[i] = ((const LightRec*)d->lights)[i].geomType;
   // a new scene invalidates the environment ids of the previous UpdateMembersPlainData until the next one
@@ -913,7 +977,9 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
 extern "C" int hpt_update_params(hpt_ctx* c, const hpt_params* p)
 {
   if (!c || !p) return HPT_ERR_ARG;
-  if (p->spectralMode != 0) return c->fail(HPT_ERR_UNSUPPORTED, "spectral rendering is outside the hot path's scope");
+  if (p->spectralMode > 1) return c->fail(HPT_ERR_ARG, "bad spectral mode");
+  if (p->spectralMode == 1 && !c->sceneUploaded) return c->fail(HPT_ERR_STATE, "UpdateMembersPlainData with m_spectral_mode before CommitDeviceData");
+  if (p->spectralMode == 1 && !c->spectralOk) return c->fail(HPT_ERR_UNSUPPORTED, "spectral rendering: " + c->spectralWhyNot);
   if (p->winWidth <= 0 || p->winHeight <= 0 || p->fbWidth <= 0 || p->fbHeight <= 0 || p->winWidth > 65535 || p->winHeight > 65535) return c->fail(HPT_ERR_ARG, "bad viewport");
   if (p->tileSize != 1 && p->tileSize != 2 && p->tileSize != 4 && p->tileSize != 8) return c->fail(HPT_ERR_ARG, "bad tile size");
   // kernel_PackXY tiles the window without a remainder (integrator_rt.cpp:13-31); SetViewport only ever picks a tile size that divides both
@@ -925,6 +991,7 @@ extern "C" int hpt_update_params(hpt_ctx* c, const hpt_params* p)
   S.winStartX = p->winStartX; S.winStartY = p->winStartY; S.winWidth = p->winWidth; S.winHeight = p->winHeight; S.fbWidth = p->fbWidth; S.fbHeight = p->fbHeight;
   S.traceDepth = p->traceDepth; S.integratorType = p->integratorType; S.renderLayer = p->renderLayer; S.tileSize = p->tileSize;
   S.exposureMult = p->exposureMult; S.camLensRadius = p->camLensRadius; S.camTargetDist = p->camTargetDist;
+  S.spectralMode = p->spectralMode;
   std::memcpy(S.camRespoceRGB, p->camRespoceRGB, 16); std::memcpy(S.envColor, p->envColor, 16);
   // the environment map (integrator_pt_scene.cpp:441-478): ids are checked against what CommitDeviceData uploaded
   if ((p->envTexId != 0xFFFFFFFFu || p->envCamBackId != 0xFFFFFFFFu || p->envLightId != 0xFFFFFFFFu) && !c->sceneUploaded)
@@ -1098,7 +1165,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   if (inRays) { job.tidStride = 1; job.tidChunk = 0x40000000u; }
   if (!inRays && job.tidStride == 1 && (size_t)job.tidBegin + job.tidCount > c->packedCount) return c->fail(HPT_ERR_ARG, "PathTraceBlock: tid range exceeds the viewport");
   if (c->dGens.n < (inRays ? (size_t)job.tidEnd : (size_t)c->packedCount)) return c->fail(HPT_ERR_STATE, "PathTraceBlock: m_randomGens smaller than the thread range (InitRandomGens)");
-  if (job.channels < 1 || job.channels > 4) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceBlock: channels must be 1..4 (spectral layers are out of scope)");
+  if (job.channels < 1 || (job.channels > 4 && c->S.spectralMode == 0u)) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceBlock: channels must be 1..4 (more are the wavelength layers of spectral rendering)");
   if (dr && (c->S.traceDepth == 0 || c->S.traceDepth > 16)) return c->fail(HPT_ERR_ARG, "PathTraceDR: trace depth must be 1..16");
   if (dr && c->S.lensCount) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceDR: the lens simulation is not differentiated");
   if (dr && c->S.motion) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceDR: motion blur is not differentiated");
@@ -1109,6 +1176,24 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   if (dr && !c->leanMaterials) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceDR: gltf and emissive materials without normal maps only (what the reference's replay differentiates, integrator_dr.cpp:461-612)");
   // never more lanes than pixels: with fewer, the hardware's round-robin block placement spreads them evenly over the CUs, whereas a
   // full grid would let whichever waves ask first take all the work (a small multi-GPU share of a frame)
+  if (c->S.spectralMode != 0u) {                               // four wavelengths per path: its own (plain) kernel
+    if (dr || naive || inRays) return c->fail(HPT_ERR_UNSUPPORTED, "spectral rendering: PathTraceBlock only (not the naive, input-ray or differentiable integrators)");
+    if (c->S.motion) return c->fail(HPT_ERR_UNSUPPORTED, "spectral rendering: moving instances are not in the spectral kernel");
+    if (c->S.lensCount || c->S.envTexId != 0xFFFFFFFFu || c->S.envCamBackId != 0xFFFFFFFFu) return c->fail(HPT_ERR_UNSUPPORTED, "spectral rendering: lens simulation / environment maps are not in the spectral kernel");
+    const int sblocks = (int)(((size_t)job.tidCount + 255) / 256);
+    job.gens = c->dGens.p; job.packedXY = c->dPackedXY.p; job.packedCount = c->packedCount;
+    HIPCHK(c, ensureStackOverflow(c, (size_t)sblocks * 256));
+    job.stackOverflow = c->dStackOvf.p; job.gridLanes = (uint)sblocks * 256u;
+    const bool sdeep = c->stackNeeded > (uint)LDS_STACK;
+    c->lastSchedule = 1;
+    HIPCHK(c, hipEventRecord(c->ev0, st));
+    if (c->S.sweep)          pathTraceSpectralKernel<false, false, true><<<dim3(sblocks), dim3(256), 0, st>>>(c->S, job);
+    else if (c->S.flatMode)  { if (sdeep) pathTraceSpectralKernel<true, true, false><<<dim3(sblocks), dim3(256), 0, st>>>(c->S, job); else pathTraceSpectralKernel<false, true, false><<<dim3(sblocks), dim3(256), 0, st>>>(c->S, job); }
+    else                     { if (sdeep) pathTraceSpectralKernel<true, false, false><<<dim3(sblocks), dim3(256), 0, st>>>(c->S, job); else pathTraceSpectralKernel<false, false, false><<<dim3(sblocks), dim3(256), 0, st>>>(c->S, job); }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev1, st));
+    return HPT_OK;
+  }
   const bool motion = c->S.motion != 0;
   const bool fullMaterials = motion || !dr && !(c->leanMaterials && !c->forceFull && c->S.lensCount == 0u && !naive && !inRays && !(c->instrument && !dr));   // MODE 0 / 1 / 2 / STATS kernels
   const int blocks = (int)std::min<size_t>((size_t)gridBlocks(c, dr, fullMaterials), ((size_t)job.tidCount + 255) / 256);

@@ -1,0 +1,385 @@
+// Spectral rendering (m_spectral_mode != 0, KSPEC_SPECTRAL_RENDERING): the same path tracer carrying four wavelengths per path.
+//
+// What changes against the RGB path (integrator_pt.cpp:117-118, 145-146, 618-622; integrator_spectrum.cpp; spectrum.h):
+//   * kernel_InitEyeRay2 draws one more generator step per path (GetRandomNumbersSpec, after the lens numbers) and places four
+//     wavelengths in [LAMBDA_MIN, LAMBDA_MAX] with SampleWavelengths (one uniform offset, three rotations by a quarter of the range);
+//   * radiance and throughput are float4 - one value per wavelength - and every colour-valued quantity is looked up per wavelength:
+//     SampleMatColorSpectrumTexture / SampleMatParamSpectrum / LightIntensity read m_spec_values (every spectrum resampled at 1 nm,
+//     spectrum.cpp: ResampleUniform) through m_spec_offset_sz[spdid] with SampleUniformSpectrum's linear interpolation;
+//   * kernel_ContributeToImage turns the four samples into RGB with the CIE 1931 observer (SpectrumToXYZ over m_cie_xyz, XYZToRGB),
+//     or adds the first sample (channels == 1).
+// The tables (m_spec_values, m_spec_offset_sz, m_cie_xyz) come in through the C ABI with the other scene vectors: the host owns them.
+//
+// Scope of this kernel: the BSDFs of the reference's own spectral fixture (scenes/test_spectral/spectral_cornell_conductor.xml) -
+// diffuse (Lambert / Oren-Nayar) with a reflectance spectrum, smooth and rough conductors with eta / k spectra, emissive surfaces and
+// every analytic light with an intensity spectrum - in a plain one-thread-per-pixel kernel (no path regeneration, no work queue): a first
+// correct path, not yet a tuned one. hpt_update_params refuses spectral mode for scenes with other materials, spectral textures
+// (lambda_ref_ids) or dispersion. With more than four channels the output is the reference's stack of wavelength layers.
+#include <hip/hip_runtime.h>
+#include "hpt_decl.h"
+
+namespace hpt {
+
+static constexpr float LAMBDA_MIN = 360.0f, LAMBDA_MAX = 830.0f;          // include/cglobals.h:22-23
+HPT_DEV V4 operator+(V4 a, V4 b) { return v4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+HPT_DEV V4 operator*(V4 a, V4 b) { return v4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+HPT_DEV V4 operator*(V4 a, float s) { return v4(a.x * s, a.y * s, a.z * s, a.w * s); }
+HPT_DEV V4 operator*(float s, V4 a) { return v4(s * a.x, s * a.y, s * a.z, s * a.w); }
+HPT_DEV V4 operator/(V4 a, float s) { return v4(a.x / s, a.y / s, a.z / s, a.w / s); }
+HPT_DEV V4 v4s(float a) { return v4(a, a, a, a); }
+HPT_DEV V4 ld4(const float* p) { return v4(p[0], p[1], p[2], p[3]); }
+HPT_DEV float comp(const V4& a, int i) { return i == 0 ? a.x : i == 1 ? a.y : i == 2 ? a.z : a.w; }
+
+// SampleWavelengths (spectrum.h:58-75)
+HPT_DEV V4 sampleWavelengths(float u, float a, float b)
+{
+  float r[4];
+  r[0] = lerpf(a, b, u);
+  const float delta = (b - a) / 4.0f;
+  for (int i = 1; i < 4; i++) { r[i] = r[i - 1] + delta; if (r[i] > b) r[i] = a + (r[i] - b); }
+  return v4(r[0], r[1], r[2], r[3]);
+}
+// SampleUniformSpectrum (spectrum.h:106-126): 1 nm table starting at LAMBDA_MIN, linear between neighbours
+HPT_DEV float sampleUniformSpectrum1(const float* vals, uint offset, float w)
+{
+  const int WAVESN = int(LAMBDA_MAX - LAMBDA_MIN);
+  const int i1 = (int)smin(smax(w - LAMBDA_MIN, 0.0f), float(WAVESN - 1));
+  const int i2 = min(i1 + 1, WAVESN - 1);
+  const float x1 = LAMBDA_MIN + float(i1);
+  const float y1 = vals[offset + (uint)i1], y2 = vals[offset + (uint)i2];
+  return y1 + (w - x1) * (y2 - y1);
+}
+HPT_DEV V4 sampleUniformSpectrum(const float* vals, uint offset, V4 w)
+{ return v4(sampleUniformSpectrum1(vals, offset, w.x), sampleUniformSpectrum1(vals, offset, w.y), sampleUniformSpectrum1(vals, offset, w.z), sampleUniformSpectrum1(vals, offset, w.w)); }
+
+// SampleMatColorSpectrumTexture / SampleMatColorParamSpectrum without spectral textures (integrator_spectrum.cpp:4-22, 128-145)
+HPT_DEV V4 matColorSpectrum(const DevScene& S, const MaterialRec& m, V4 waves, int paramId, int specSlot)
+{
+  const uint specId = m.spdid[specSlot];
+  if (specId < 0xFFFFFFFFu) return sampleUniformSpectrum(S.specValues, S.specOffsetSz[2u * specId], waves);
+  return ld4(m.colors[paramId]);
+}
+// SampleMatParamSpectrum (:25-44)
+HPT_DEV V4 matParamSpectrum(const DevScene& S, const MaterialRec& m, V4 waves, int paramId, int specSlot)
+{
+  const uint specId = m.spdid[specSlot];
+  if (specId < 0xFFFFFFFFu) return sampleUniformSpectrum(S.specValues, S.specOffsetSz[2u * specId], waves);
+  return v4s(m.data[paramId]);
+}
+// LightIntensity with the light's spectrum (integrator_pt_lgt.cpp:109-173): the scalar factors are those of the RGB path
+HPT_DEV V4 lightIntensitySpec(const DevScene& S, const LightRec& L, V4 waves, V3 a_rayPos, V3 a_rayDir)
+{
+  V4 lightColor = ld4(L.intensity);
+  if (L.specId < 0xFFFFFFFFu) lightColor = sampleUniformSpectrum(S.specValues, S.specOffsetSz[2u * L.specId], waves);
+  lightColor = lightColor * L.mult;
+  if (L.iesId != 0xFFFFFFFFu) {
+    if ((L.flags & LIGHT_FLAG_POINT_AREA) != 0) a_rayDir = normalize(ld3(L.pos) - a_rayPos);
+    const V4 dt = mul4x4(L.iesMatrix, v4(a_rayDir.x, a_rayDir.y, a_rayDir.z, 0.0f));
+    const V2 tc = sphereMapTo2DTexCoord((-1.0f) * v3(dt.x, dt.y, dt.z));
+    lightColor = lightColor * texSample(S.textures, L.iesId, tc);
+  }
+  if (L.distType == LIGHT_DIST_SPOT) {
+    const float cos_theta = smax(-dot(a_rayDir, ld3(L.norm)), 0.0f);
+    const float tVal = (cos_theta - L.lightCos2) / (L.lightCos1 - L.lightCos2);
+    const float t = smin(smax(tVal, 0.0f), 1.0f);
+    lightColor = lightColor * (t * t * (3.0f - 2.0f * t));
+    if ((L.flags & LIGHT_FLAG_PROJECTIVE) != 0 && L.texId != 0xFFFFFFFFu) {
+      const V4 clip = mul4x4(L.iesMatrix, v4(a_rayPos.x, a_rayPos.y, a_rayPos.z, 1.0f));
+      const V3 ndc = v3(clip.x, clip.y, clip.z) / clip.w;
+      lightColor = lightColor * texSample(S.textures, L.texId, v2(ndc.x * 0.5f + 0.5f, ndc.y * 0.5f + 0.5f));
+    }
+  }
+  return lightColor;
+}
+
+// SpectrumToXYZ + XYZToRGB (spectrum.h:151-214), all four wavelengths alive (no dispersion in scope)
+HPT_DEV V3 spectrumToRGB(const DevScene& S, V4 spec, V4 lambda)
+{
+  const float pdf = 1.0f / (LAMBDA_MAX - LAMBDA_MIN);
+  const float CIE_Y_integral = 106.856895f;
+  float X = 0.0f, Y = 0.0f, Z = 0.0f;
+  float xs[4], ys[4], zs[4];
+  for (int i = 0; i < 4; i++) {
+    const float s = comp(spec, i) / pdf;
+    const uint offset = (uint)(floorf(comp(lambda, i) + 0.5f) - LAMBDA_MIN);
+    float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+    if (offset < 471u && offset < S.numCieXYZ) { const float4 c = S.cieXYZ[offset]; cx = c.x; cy = c.y; cz = c.z; }
+    xs[i] = cx * s; ys[i] = cy * s; zs[i] = cz * s;
+  }
+  X = (((xs[0] + xs[1]) + xs[2]) + xs[3]) / 4.0f;                           // SpectrumAverage: left-to-right sum / SPECTRUM_SAMPLE_SZ
+  Y = (((ys[0] + ys[1]) + ys[2]) + ys[3]) / 4.0f;
+  Z = (((zs[0] + zs[1]) + zs[2]) + zs[3]) / 4.0f;
+  const float x = X / CIE_Y_integral, y = Y / CIE_Y_integral, z = Z / CIE_Y_integral;
+  return v3(+3.240479f * x - 1.537150f * y - 0.498535f * z, -0.969256f * x + 1.875991f * y + 0.041556f * z, +0.055648f * x - 0.204043f * y + 1.057311f * z);
+}
+// SpectralCamRespoceToRGB (integrator_spectrum.cpp:68-124)
+HPT_DEV V3 spectralCamResponseToRGB(const DevScene& S, V4 spec, V4 waves)
+{
+  if (S.camResponseSpectrumId[0] < 0) return spectrumToRGB(S, spec, waves);
+  V4 rX = v4s(1.0f), rY, rZ;
+  rX = sampleUniformSpectrum(S.specValues, S.specOffsetSz[2 * S.camResponseSpectrumId[0]], waves);
+  rY = S.camResponseSpectrumId[1] >= 0 ? sampleUniformSpectrum(S.specValues, S.specOffsetSz[2 * S.camResponseSpectrumId[1]], waves) : rX;
+  rZ = S.camResponseSpectrumId[2] >= 0 ? sampleUniformSpectrum(S.specValues, S.specOffsetSz[2 * S.camResponseSpectrumId[2]], waves) : rY;
+  V3 xyz = v3(0, 0, 0);
+  for (int i = 0; i < 4; i++) { xyz.x += comp(spec, i) * comp(rX, i); xyz.y += comp(spec, i) * comp(rY, i); xyz.z += comp(spec, i) * comp(rZ, i); }
+  if (S.camResponseType == 1u)                                              // CAM_RESPONCE_XYZ
+    return v3(+3.240479f * xyz.x - 1.537150f * xyz.y - 0.498535f * xyz.z, -0.969256f * xyz.x + 1.875991f * xyz.y + 0.041556f * xyz.z, +0.055648f * xyz.x - 0.204043f * xyz.y + 1.057311f * xyz.z);
+  return xyz;
+}
+
+struct SpecEval { V4 val; float pdf; };
+struct SpecSample { V4 val; V3 dir; float pdf; uint flags; };
+
+// MaterialEval, spectral (integrator_pt_mat.cpp:405-420, 471-482 with cmat_conductor.h:103-137, cmat_diffuse.h:27-39)
+HPT_DEV SpecEval materialEvalSpec(const DevScene& S, const MaterialRec& m, V4 waves, V3 l, V3 v, V3 n, V3 texColor3)
+{
+  SpecEval r; r.val = v4s(0.0f); r.pdf = 0.0f;
+  if (m.mtype == MAT_TYPE_DIFFUSE) {
+    float lambertVal = HPT_INV_PI;
+    if ((m.cflags & GLTF_COMPONENT_ORENNAYAR) != 0) lambertVal *= orennayarFunc(l, v, n, m.data[0]);
+    r.val = lambertVal * matColorSpectrum(S, m, waves, 0, 0);               // (not multiplied by the texture in spectral mode, :259-260)
+    r.pdf = absf(dot(l, n)) * HPT_INV_PI;
+  } else if (m.mtype == MAT_TYPE_CONDUCTOR) {
+    if (!(smax(m.data[1], m.data[0]) < 1e-3f)) {                            // trEffectivelySmooth: the smooth conductor evaluates to zero
+      const V4 etaSpec = matParamSpectrum(S, m, waves, 2, 0), kSpec = matParamSpectrum(S, m, waves, 3, 1);
+      const V2 alpha = v2(smin(m.data[0], texColor3.x), smin(m.data[1], texColor3.y));
+      V3 nx, ny;
+      coordinateSystemV2(n, nx, ny);
+      const V3 wo = v3(dot(v, nx), dot(v, ny), dot(v, n)), wi = v3(dot(l, nx), dot(l, ny), dot(l, n));
+      if (wo.z * wi.z < 0.0f) return r;
+      V3 wm = wo + wi;
+      if (dot(wm, wm) == 0) return r;
+      wm = normalize(wm);
+      r.val = v4(conductorRoughEvalInternal(wo, wi, wm, alpha, cx(etaSpec.x, kSpec.x)), conductorRoughEvalInternal(wo, wi, wm, alpha, cx(etaSpec.y, kSpec.y)),
+                 conductorRoughEvalInternal(wo, wi, wm, alpha, cx(etaSpec.z, kSpec.z)), conductorRoughEvalInternal(wo, wi, wm, alpha, cx(etaSpec.w, kSpec.w))) * ld4(m.colors[0]);
+      if (dot(wm, v3(0.0f, 0.0f, 1.0f)) < 0.f) wm = (-1.0f) * wm;
+      r.pdf = trPDF(wo, wm, alpha) / (4.0f * absf(dot(wo, wm)));
+    }
+  }
+  return r;
+}
+// MaterialSampleAndEval, spectral (integrator_pt_mat.cpp:184-196, 252-263 with cmat_conductor.h:7-100, cmat_diffuse.h:8-24)
+HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V4 waves, V4 rands, V3 v, V3 n, V3 texColor3, uint flags0)
+{
+  SpecSample r; r.val = v4s(0.0f); r.pdf = 1.0f; r.dir = v3(0, 1, 0); r.flags = flags0;
+  if (m.mtype == MAT_TYPE_DIFFUSE) {
+    const V3 lambertDir = mapSampleToCosineDistribution(rands.x, rands.y, n, n, 1.0f);
+    r.dir = lambertDir;
+    r.val = HPT_INV_PI * matColorSpectrum(S, m, waves, 0, 0);
+    r.pdf = absf(dot(lambertDir, n)) * HPT_INV_PI;
+    r.flags = RAY_FLAG_HAS_NON_SPEC;
+    if ((m.cflags & GLTF_COMPONENT_ORENNAYAR) != 0) r.val = r.val * orennayarFunc(lambertDir, (-1.0f) * v, n, m.data[0]);
+  } else if (m.mtype == MAT_TYPE_CONDUCTOR) {
+    const V4 etaSpec = matParamSpectrum(S, m, waves, 2, 0), kSpec = matParamSpectrum(S, m, waves, 3, 1);
+    if (smax(m.data[1], m.data[0]) < 1e-3f) {
+      const V3 pefReflDir = reflect((-1.0f) * v, n);
+      const float cosThetaOut = dot(pefReflDir, n);
+      float val[4];
+      for (int i = 0; i < 4; i++) {
+        val[i] = frComplexConductor(cosThetaOut, cx(comp(etaSpec, i), comp(kSpec, i)));
+        val[i] = (cosThetaOut <= 1e-6f) ? 0.0f : (val[i] / smax(cosThetaOut, 1e-6f));
+      }
+      r.val = v4(val[0], val[1], val[2], val[3]) * ld4(m.colors[0]);
+      r.dir = pefReflDir; r.pdf = 1.0f; r.flags = RAY_EVENT_S;
+    } else {
+      if (v.z == 0) return r;
+      const V2 alpha = v2(smin(m.data[0], texColor3.x), smin(m.data[1], texColor3.y));
+      V3 nx, ny;
+      coordinateSystemV2(n, nx, ny);
+      const V3 wo = v3(dot(v, nx), dot(v, ny), dot(v, n));
+      if (wo.z == 0) return r;
+      const V3 wm = trSample(wo, v2(rands.x, rands.y), alpha);
+      const V3 wi = reflect((-1.0f) * wo, wm);
+      if (wo.z * wi.z < 0) return r;
+      r.val = v4(conductorRoughEvalInternal(wo, wi, wm, alpha, cx(etaSpec.x, kSpec.x)), conductorRoughEvalInternal(wo, wi, wm, alpha, cx(etaSpec.y, kSpec.y)),
+                 conductorRoughEvalInternal(wo, wi, wm, alpha, cx(etaSpec.z, kSpec.z)), conductorRoughEvalInternal(wo, wi, wm, alpha, cx(etaSpec.w, kSpec.w))) * ld4(m.colors[0]);
+      r.dir = normalize(wi.x * nx + wi.y * ny + wi.z * n);
+      r.pdf = trPDF(wo, wm, alpha) / (4.0f * absf(dot(wo, wm)));
+      r.flags = RAY_FLAG_HAS_NON_SPEC;
+    }
+  }
+  return r;
+}
+
+// One path per pass, one thread per pixel of the call (the pixel's generator continues from pass to pass as in the RGB kernels).
+template <bool DEEP, bool FLAT, bool SWEEP>
+__global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene S, const Job job)
+{
+  __shared__ uint stackMem[LDS_STACK * 256];
+  const uint glane = blockIdx.x * 256u + threadIdx.x;
+  TravStack stk; stk.lds = &stackMem[threadIdx.x]; stk.ovf = job.stackOverflow + glane; stk.ovfStride = job.gridLanes;
+  TravStats st; st.nodes = st.tris = st.insts = st.waveNodeIters = st.waveTriIters = 0;
+  const uint k = glane;
+  bool valid = k < job.tidCount;
+  uint tid = 0;
+  if (valid) { tid = job.tidBegin + (k / job.tidChunk) * job.tidChunk * job.tidStride + (k % job.tidChunk); valid = tid < job.tidEnd; }
+  Rng gen; gen.sx = gen.sy = 0;
+  uint XY = 0, pixel = 0;
+  float pix[3] = { 0.0f, 0.0f, 0.0f };
+  if (valid) {
+    XY = job.packedXY[tid]; gen = job.gens[tid];
+    pixel = ((XY & 0xFFFF0000u) >> 16) * (uint)S.winWidth + (XY & 0x0000FFFFu);
+    if (job.channels == 1) pix[0] = job.outColor[pixel];
+    else if (job.channels <= 4) { const float* o = job.outColor + (size_t)pixel * job.channels; pix[0] = o[0]; pix[1] = o[1]; pix[2] = o[2]; }
+  }
+  for (uint pass = 0; pass < job.passNum; pass++) {
+    V3 rpos = v3(0, 0, 0), rdir = v3(0, 0, 1);
+    V4 waves = v4s(0.0f), accum = v4s(0.0f), thr = v4s(1.0f);
+    float misPdf = 1.0f;
+    uint flags = 0;
+    bool alive = valid;
+    if (valid) {
+      const V4 lens = rng_float4(gen);                                       // GetRandomNumbersLens, then GetRandomNumbersSpec (integrator_pt.cpp:114-118)
+      cameraRay<false>(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
+      waves = sampleWavelengths(rng_float1(gen), LAMBDA_MIN, LAMBDA_MAX);
+    }
+    for (uint bounce = 0; bounce < S.traceDepth; bounce++) {
+      if (!__any(alive)) break;
+      HitRec hit; hit.inst = 0xFFFFFFFFu; hit.prim = 0; hit.t = 0; hit.u = hit.v = 0;
+      if (alive) traceAny<false, false, DEEP, FLAT, false, SWEEP>(S, rpos, rdir, 0.0f, HPT_FLT_MAX, hit, stk, st);
+      bool wantShadow = false;
+      V3 shPos = v3(0, 0, 0), shDir = v3(0, 0, 1); float shFar = 0.0f;
+      V4 contrib = v4s(0.0f);
+      if (alive) {
+        if (hit.inst == 0xFFFFFFFFu) {
+          flags |= (bounce == 0) ? (RAY_FLAG_PRIME_RAY_MISS | RAY_FLAG_IS_DEAD | RAY_FLAG_OUT_OF_SCENE) : (RAY_FLAG_IS_DEAD | RAY_FLAG_OUT_OF_SCENE);
+        } else {
+          // -- surface attributes (integrator_pt.cpp:238-311), as in shadeVertex --
+          const uint instId = hit.inst;
+          const uint geomId = S.insts[instId].geomId;
+          const uint triOffset = S.matVertOffset[2 * geomId + 0], vertOffset = S.matVertOffset[2 * geomId + 1];
+          const V3 hitPos = rpos + hit.t * (1.f - 1e-6f) * rdir;
+          const float uvx = hit.v, uvy = hit.u;
+          const uint A = S.triIndices[(triOffset + hit.prim) * 3 + 0], B = S.triIndices[(triOffset + hit.prim) * 3 + 1], C = S.triIndices[(triOffset + hit.prim) * 3 + 2];
+          const float4 nA = ((const float4*)S.vData8f)[2 * (A + vertOffset)], nB = ((const float4*)S.vData8f)[2 * (B + vertOffset)], nC = ((const float4*)S.vData8f)[2 * (C + vertOffset)];
+          const float tyA = S.vData8f[8 * (A + vertOffset) + 7], tyB = S.vData8f[8 * (B + vertOffset) + 7], tyC = S.vData8f[8 * (C + vertOffset) + 7];
+          const float wA = 1.0f - uvx - uvy;
+          const V3 nrmO = v3(wA * nA.x + uvy * nB.x + uvx * nC.x, wA * nA.y + uvy * nB.y + uvx * nC.y, wA * nA.z + uvy * nB.z + uvx * nC.z);
+          const V2 uv = v2(wA * nA.w + uvy * nB.w + uvx * nC.w, wA * tyA + uvy * tyB + uvx * tyC);
+          const float* nm = S.normMat + 12 * instId;
+          V3 hitNorm = normalize(v3(nm[0] * nrmO.x + nm[1] * nrmO.y + nm[2] * nrmO.z, nm[4] * nrmO.x + nm[5] * nrmO.y + nm[6] * nrmO.z, nm[8] * nrmO.x + nm[9] * nrmO.y + nm[10] * nrmO.z));
+          const float flipNorm = dot(rdir, hitNorm) > 0.001f ? -1.0f : 1.0f;
+          hitNorm = flipNorm * hitNorm;
+          if (flipNorm < 0.0f) flags |= RAY_FLAG_HAS_INV_NORMAL; else flags &= ~RAY_FLAG_HAS_INV_NORMAL;
+          const uint matId = remapMaterialId(S, S.matIdByPrimId[triOffset + hit.prim], instId) & 0x00FFFFFFu;
+          const MaterialRec& m = S.materials[matId];
+          const uint mtype = m.mtype;
+          const V3 vdir = (-1.0f) * rdir;
+          V4 texColor = v4(1, 1, 1, 1);
+          if (mtype != MAT_TYPE_LIGHT_SOURCE) texColor = texSample(S.textures, m.texid[0], mulRows2x4(m.row0[0], m.row1[0], uv));
+          const V3 tex3 = v3(texColor.x, texColor.y, texColor.z);
+
+          // -- kernel_SampleLightSource (integrator_pt.cpp:350-424) --
+          V4 shade = v4s(0.0f);
+          {
+            const float rndId = rng_float1(gen);
+            const V4 r4 = rng_float4(gen);
+            const int nLights = (int)S.numLights;
+            const int lightId = min((int)floorf(rndId * float(nLights)), nLights - 1);
+            if (lightId >= 0 && mtype != MAT_TYPE_LIGHT_SOURCE) {
+              const LightRec& L = S.lights[lightId];
+              const LightSam ls = lightSampleRev(L, v3(r4.x, r4.y, r4.z), hitPos);
+              const V3 dlt = hitPos - ls.pos;
+              const float hitDist = sqrtf_(dot(dlt, dlt));
+              const V3 shadowRayDir = normalize(ls.pos - hitPos);
+              const V3 shadowRayPos = hitPos + hitNorm * smax(maxcomp(hitPos), 1.0f) * 5e-6f;
+              const bool inIllumArea = (dot(shadowRayDir, ls.norm) < 0.0f) || ls.isOmni || ls.hasIES;
+              if (inIllumArea) {
+                const SpecEval bv = materialEvalSpec(S, m, waves, shadowRayDir, vdir, hitNorm, tex3);
+                const float cosThetaOut = smax(dot(shadowRayDir, hitNorm), 0.0f);
+                float lgtPdfW = (1.0f / float(nLights)) * lightEvalPDF(L, shadowRayPos, shadowRayDir, ls.pos, ls.norm, ls.pdf);
+                float misWeight = (S.integratorType == INTEGRATOR_MIS_PT) ? misWeightHeuristic(lgtPdfW, bv.pdf) : 1.0f;
+                if (L.geomType == LIGHT_GEOM_DIRECT) { misWeight = 1.0f; lgtPdfW = 1.0f; }
+                else if (L.geomType == LIGHT_GEOM_POINT) misWeight = 1.0f;
+                const bool isDirectLight = (flags & RAY_FLAG_HAS_NON_SPEC) == 0;
+                if ((S.renderLayer == FB_DIRECT && !isDirectLight) || (S.renderLayer == FB_INDIRECT && isDirectLight)) misWeight = 0.0f;
+                const V4 lightColor = lightIntensitySpec(S, L, waves, shadowRayPos, shadowRayDir);
+                shade = ((lightColor * bv.val) / lgtPdfW) * cosThetaOut * misWeight;
+                wantShadow = true; shPos = shadowRayPos; shDir = shadowRayDir; shFar = hitDist * 0.9995f;
+              }
+            }
+          }
+          // -- kernel_NextBounce (integrator_pt.cpp:426-548) --
+          if (mtype == MAT_TYPE_LIGHT_SOURCE) {
+            const V4 tc = texSample(S.textures, m.texid[0], mulRows2x4(m.row0[0], m.row1[0], uv));
+            const uint lightId = (uint)S.remapInst[2 * instId + 1];
+            V4 lightInt = ld4(m.colors[0]) * tc;
+            float misWeight = 1.0f;
+            if (lightId != 0xFFFFFFFFu) {
+              const LightRec& L = S.lights[lightId];
+              const float lightCos = dot(rdir, ld3(L.norm));
+              const float atten = (lightCos < 0.0f || L.geomType == LIGHT_GEOM_SPHERE) ? 1.0f : 0.0f;
+              lightInt = lightIntensitySpec(S, L, waves, rpos, rdir) * atten;
+            }
+            if (S.integratorType == INTEGRATOR_MIS_PT) {
+              if (bounce > 0 && lightId != 0xFFFFFFFFu) {
+                const float lgtPdf = (1.0f / float(S.numLights)) * lightEvalPDF(S.lights[lightId], rpos, rdir, hitPos, hitNorm, 1.0f);
+                misWeight = misWeightHeuristic(misPdf, lgtPdf);
+                if (misPdf <= 0.0f) misWeight = 1.0f;
+              }
+            } else if (S.integratorType == INTEGRATOR_SHADOW_PT && (flags & RAY_FLAG_HAS_NON_SPEC) != 0) misWeight = 0.0f;
+            const bool isDirectLight = (flags & RAY_FLAG_HAS_NON_SPEC) == 0, isFirstNonSpec = (flags & RAY_FLAG_FIRST_NON_SPEC) != 0;
+            if (S.renderLayer == FB_INDIRECT && (isDirectLight || isFirstNonSpec)) misWeight = 0.0f;
+            accum = accum + thr * lightInt * misWeight;
+            flags |= (RAY_FLAG_IS_DEAD | RAY_FLAG_HIT_LIGHT);
+            wantShadow = false;
+          } else {
+            const V4 rands = rng_float4(gen);                                // GetRandomNumbersMats
+            const SpecSample ms = materialSampleSpec(S, m, waves, rands, vdir, hitNorm, tex3, (flags & 0xFF000000u) | matId);
+            const float invPdf = 1.0f / smax(ms.pdf, 1e-20f);
+            const V4 bxdfVal = ms.val * invPdf;
+            const float cosTheta = absf(dot(ms.dir, hitNorm));
+            misPdf = (ms.flags & RAY_EVENT_S) != 0 ? -1.0f : ms.pdf;
+            if (S.integratorType == INTEGRATOR_STUPID_PT) { thr = thr * (cosTheta * bxdfVal); wantShadow = false; }
+            else { contrib = thr * shade; thr = thr * cosTheta * bxdfVal; }
+            V3 hp = hitPos;
+            if ((ms.flags & RAY_EVENT_T) != 0) hp = hp + hit.t * rdir * 2.0f * 1e-6f;
+            rpos = offsRayPos(hp, hitNorm, ms.dir);
+            rdir = ms.dir;
+            uint nextFlags = ((flags & ~RAY_FLAG_FIRST_NON_SPEC) | ms.flags);
+            if (S.renderLayer == FB_DIRECT && (flags & RAY_FLAG_HAS_NON_SPEC) != 0) nextFlags |= RAY_FLAG_IS_DEAD;
+            else if ((flags & RAY_FLAG_HAS_NON_SPEC) == 0 && (nextFlags & RAY_FLAG_HAS_NON_SPEC) != 0) nextFlags |= RAY_FLAG_FIRST_NON_SPEC;
+            flags = nextFlags;
+          }
+        }
+      }
+      if (wantShadow) {
+        HitRec sh;
+        const bool occluded = traceAny<true, false, DEEP, FLAT, false, SWEEP>(S, shPos, shDir, 0.0f, shFar, sh, stk, st);
+        if (!occluded) accum = accum + contrib;
+      }
+      if (alive && (flags & RAY_FLAG_IS_DEAD) != 0) alive = false;
+    }
+    if (valid) {
+      // kernel_HitEnvironment with the constant colour (the environment spectrum m_envSpecId is not in this kernel's scope)
+      if ((flags & RAY_FLAG_OUT_OF_SCENE) != 0) {
+        const V4 env = ld4(S.envColor);
+        if (S.integratorType == INTEGRATOR_STUPID_PT) accum = thr * env; else accum = accum + thr * env;
+      }
+      // kernel_ContributeToImage (integrator_pt.cpp:598-657), spectral
+      if (job.channels == 1) pix[0] += accum.x * S.exposureMult;
+      else if (job.channels > 4) {                                           // "always spectral rendering": one layer of W x H per wavelength bin
+        const V4 color = accum * S.exposureMult;
+        for (int i = 0; i < 4; i++) {
+          const float t = (comp(waves, i) - LAMBDA_MIN) / (LAMBDA_MAX - LAMBDA_MIN);
+          const int channelId = min(int(float(job.channels) * t), int(job.channels) - 1);
+          job.outColor[(size_t)channelId * (size_t)(S.winWidth * S.winHeight) + pixel] += comp(color, i);   // the pixel is this thread's alone
+        }
+      }
+      else { const V3 rgb = spectralCamResponseToRGB(S, accum, waves); pix[0] += S.exposureMult * rgb.x; pix[1] += S.exposureMult * rgb.y; pix[2] += S.exposureMult * rgb.z; }
+    }
+  }
+  if (valid) {
+    if (job.channels == 1) job.outColor[pixel] = pix[0];
+    else if (job.channels <= 4) { float* o = job.outColor + (size_t)pixel * job.channels; o[0] = pix[0]; o[1] = pix[1]; o[2] = pix[2]; }
+    job.gens[tid] = gen;
+  }
+}
+
+template __global__ void pathTraceSpectralKernel<false, false, false>(const DevScene, const Job);
+template __global__ void pathTraceSpectralKernel<true,  false, false>(const DevScene, const Job);
+template __global__ void pathTraceSpectralKernel<false, true,  false>(const DevScene, const Job);
+template __global__ void pathTraceSpectralKernel<true,  true,  false>(const DevScene, const Job);
+template __global__ void pathTraceSpectralKernel<false, false, true>(const DevScene, const Job);
+
+} // namespace hpt

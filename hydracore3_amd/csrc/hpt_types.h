@@ -102,6 +102,15 @@ struct DevScene
   float              physSize[2]; // m_physSize
   uint               padLens;
 
+  // spectral rendering (m_spectral_mode, hpt_spectral.hip): every spectrum resampled at 1 nm from LAMBDA_MIN (m_spec_values), {offset, size} per spectrum
+  // id (m_spec_offset_sz), the CIE 1931 observer at 1 nm (m_cie_xyz), the camera's response spectra (m_camResponseSpectrumId, -1: none)
+  const float*       specValues;
+  const uint*        specOffsetSz;
+  const float4*      cieXYZ;
+  uint               numCieXYZ, numSpectra;
+  int                camResponseSpectrumId[3];
+  uint               camResponseType, spectralMode;
+
   // plain-data members (UpdateMembersPlainData)
   float projInv[16], worldViewInv[16];
   int   winStartX, winStartY, winWidth, winHeight, fbWidth, fbHeight;

@@ -89,7 +89,11 @@ class SceneDesc(C.Structure):
                 ("materials", C.c_void_p), ("numMaterials", C.c_uint32), ("numLights", C.c_uint32),
                 ("lights", C.c_void_p), ("textures", C.POINTER(TextureDesc)),
                 ("numTextures", C.c_uint32), ("numArrays1f", C.c_uint32), ("arrays1f", C.c_void_p),
-                ("instMatricesMotion", C.c_void_p), ("instHasMotion", C.c_void_p), ("normMatrices2Offs", C.c_uint32), ("reserved", C.c_uint32)]
+                ("instMatricesMotion", C.c_void_p), ("instHasMotion", C.c_void_p), ("normMatrices2Offs", C.c_uint32), ("reserved", C.c_uint32),
+                # spectral rendering: m_spec_values, m_spec_offset_sz, m_cie_xyz, m_camResponseSpectrumId / m_camResponseType
+                ("specValues", C.c_void_p), ("specOffsetSz", C.c_void_p), ("numSpecValues", C.c_uint32), ("numSpectra", C.c_uint32),
+                ("cieXYZ", C.c_void_p), ("numCieXYZ", C.c_uint32), ("camResponseSpectrumId", C.c_int32 * 3),
+                ("camResponseType", C.c_uint32), ("reserved2", C.c_uint32)]
 
 
 class Params(C.Structure):
@@ -454,6 +458,14 @@ class SceneData:
         self.inst_geom, self.inst_matrices, self.remap_inst = [], [], []
         self.lens_lines, self.phys_size = np.zeros((0, 4), np.float32), (0.0, 0.0)   # lens simulation: m_lines {radius, thickness, ior, aperture}, m_physSize
         self.inst_motion = {}                                 # instance id -> matrix at the end of the motion (hydraxml.h:170-176 <motion matrix=..>)
+        # spectral rendering (m_spectral_mode): spectra resampled at 1 nm from LAMBDA_MIN (spectrum.cpp: ResampleUniform), {offset, size} per id,
+        # the CIE 1931 observer (the reference embeds the tabulated one; without a copy of it in this image: the analytic fit, see cie_xyz_fit)
+        self.spectral_mode = 0
+        self.spec_values = np.zeros(0, np.float32)
+        self.spec_offset_sz = []
+        self.cie_xyz = None
+        self.cam_response_spectrum_id = (-1, -1, -1)
+        self.cam_response_type = 0
         self.all_remap_lists = np.zeros((1,), np.int32)     # no lists: just the trailing offset 0
         self.all_remap_lists_size = 0
         self.materials, self.lights = [], []
@@ -641,7 +653,7 @@ class SceneData:
         p.integratorType = integrator
         p.renderLayer = render_layer
         p.tileSize = self.tile_size()
-        p.spectralMode = 0
+        p.spectralMode = int(self.spectral_mode)
         p.exposureMult = self.exposure_mult
         p.camLensRadius = self.cam_lens_radius
         p.camTargetDist = float(np.linalg.norm(np.asarray(self.cam_look_at, float) - np.asarray(self.cam_pos, float)))
@@ -699,6 +711,14 @@ class SceneData:
         k.append(tarr)
         d.textures, d.numTextures = tarr, len(self.textures)
         d.arrays1f, d.numArrays1f = (ptr(self.arrays1f.astype(np.float32)), int(self.arrays1f.size)) if self.arrays1f.size else (None, 0)
+        d.specValues, d.specOffsetSz, d.numSpecValues, d.numSpectra, d.cieXYZ, d.numCieXYZ = None, None, 0, 0, None, 0
+        d.camResponseSpectrumId = (C.c_int32 * 3)(-1, -1, -1); d.camResponseType = 0
+        if self.spec_offset_sz:
+            d.specValues = ptr(np.asarray(self.spec_values, np.float32)); d.numSpecValues = int(np.asarray(self.spec_values).size)
+            d.specOffsetSz = ptr(np.asarray(self.spec_offset_sz, np.uint32).reshape(-1, 2)); d.numSpectra = len(self.spec_offset_sz)
+            cie = self.cie_xyz if self.cie_xyz is not None else cie_xyz_fit()
+            d.cieXYZ = ptr(np.asarray(cie, np.float32).reshape(-1, 4)); d.numCieXYZ = int(np.asarray(cie).reshape(-1, 4).shape[0])
+            d.camResponseSpectrumId = (C.c_int32 * 3)(*[int(v) for v in self.cam_response_spectrum_id]); d.camResponseType = int(self.cam_response_type)
         return d
 
 
@@ -730,6 +750,63 @@ def load_image4ub(path):
     raw = open(path, "rb").read()
     w, h = struct.unpack_from("<II", raw, 0)
     return np.frombuffer(raw, "<u4", w * h, 8).reshape(h, w)
+
+
+LAMBDA_MIN, LAMBDA_MAX = 360.0, 830.0            # include/cglobals.h:22-23
+
+
+def resample_uniform(wavelengths, values):
+    """Spectrum::ResampleUniform over Spectrum::Sample (spectrum.cpp:7-48): 471 float32 values at LAMBDA_MIN + c nm; zero outside the tabulated
+    range, linear in between, in float arithmetic as the reference evaluates it."""
+    w = np.asarray(wavelengths, np.float32); v = np.asarray(values, np.float32)
+    out = np.zeros(int(LAMBDA_MAX - LAMBDA_MIN + 1), np.float32)
+    if w.size == 0:
+        return out
+    for c in range(out.size):
+        lam = np.float32(LAMBDA_MIN + float(c))
+        if lam < w[0] or lam > w[-1]:
+            continue
+        # BinarySearch (spectrum.h:26-40): the last index o in [0, n - 2] with w[o] <= lam
+        last, first = w.size - 2, 1
+        while last > 0:
+            half = last >> 1
+            middle = first + half
+            if w[middle] <= lam:
+                first = middle + 1; last = last - (half + 1)
+            else:
+                last = half
+        o = min(max(first - 1, 0), w.size - 2)
+        t = (lam - w[o]) / (w[o + 1] - w[o])
+        out[c] = v[o] + t * (v[o + 1] - v[o])                          # LiteMath lerp(a, b, t) = a + t (b - a)
+    return out
+
+
+def load_spd(path):
+    """LoadSPDFromFile (spectrum.cpp:50-71): 'lambda value' per line, '#' comments."""
+    w, v = [], []
+    for line in open(path):
+        line = line.rstrip("\n")
+        if not line or line[0] == "#":
+            continue
+        a, b = line.split(" ", 1)
+        w.append(float(a)); v.append(float(b))
+    return w, v
+
+
+def cie_xyz_fit():
+    """The CIE 1931 2-degree observer at 360..830 nm, float32 [471, 4] = {x, y, z, 0}. The reference carries the tabulated functions in its
+    source (spectrum.cpp) and hands them to the integrator as m_cie_xyz; no other copy exists in this image, so the fixture loaders use the
+    analytic multi-lobe fit of Wyman, Sloan and Shirley (JCGT 2013; within about 1 % of the tables). A HydraCore3 host passes its own table
+    through hpt_scene_desc::cieXYZ - the kernels only ever read what they are given, and the parity tests feed both sides the same table."""
+    lam = np.arange(int(LAMBDA_MAX - LAMBDA_MIN + 1), dtype=np.float64) + LAMBDA_MIN
+
+    def g(mu, s1, s2):
+        t = (lam - mu) / np.where(lam < mu, s1, s2)
+        return np.exp(-0.5 * t * t)
+    x = 1.056 * g(599.8, 37.9, 31.0) + 0.362 * g(442.0, 16.0, 26.7) - 0.065 * g(501.1, 20.4, 26.2)
+    y = 0.821 * g(568.8, 46.9, 40.5) + 0.286 * g(530.9, 16.3, 31.1)
+    z = 1.217 * g(437.0, 11.8, 36.0) + 0.681 * g(459.0, 26.0, 13.8)
+    return np.stack([x, y, z, np.zeros_like(x)], 1).astype(np.float32)
 
 
 def decode_ldr_image(path, raw):
@@ -865,7 +942,7 @@ def _f(s):
     return [float(v) for v in s.split()]
 
 
-def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
+def load_hydra_xml(xml_path: str, width=None, height=None, spectral=False) -> SceneData:
     folder = os.path.dirname(os.path.abspath(xml_path))
     text = open(xml_path, encoding="utf-8").read()
     text = text.replace('<?xml version="1.0"?>', "")
@@ -901,6 +978,31 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
             tex_info.append((path, w, h, int(t.get("bytesize", 0)) // (w * h)))
     tex_cache = {}
     addr_modes = {"clamp": ADDR_CLAMP, "wrap": ADDR_WRAP}
+
+    # LoadSceneSpectrumData (integrator_pt_scene.cpp:358-419): every <spectrum> resampled at 1 nm; one {offset, size} per node, in node order
+    sc.spectral_mode = 1 if spectral else 0
+    spec_vals = []
+    for sn in root.findall("spectra_lib/spectrum"):
+        if sn.get("lambda_ref_ids") is not None:                              # a spectrum given by textures: outside the path (offset 0xFFFFFFFF as in the reference)
+            sc.spec_offset_sz.append((UINT_MAX, 0))
+            continue
+        if sn.get("value") is not None:                                       # ParseSpectrumStr: "lambda value lambda value ..."
+            nums = _f(sn.get("value"))
+            wl, vl = nums[0::2], nums[1::2]
+        else:
+            wl, vl = load_spd(os.path.join(folder, sn.get("loc")))
+        u = resample_uniform(wl, vl)
+        sc.spec_offset_sz.append((sum(len(v) for v in spec_vals), len(u)))
+        spec_vals.append(u)
+    if not sc.spec_offset_sz:                                                 # "if no spectra are loaded add uniform 1.0 spectrum" (:406-418)
+        u = resample_uniform([200.0, 400.0, 600.0, 800.0], [1.0, 1.0, 1.0, 1.0])
+        sc.spec_offset_sz.append((0, len(u))); spec_vals.append(u)
+    sc.spec_values = np.concatenate(spec_vals).astype(np.float32) if spec_vals else np.zeros(0, np.float32)
+
+    def spectrum_id(node):
+        """GetSpectrumIdFromNode (integrator_pt_scene_mat.cpp:109-119)."""
+        sn = node.find("spectrum") if node is not None else None
+        return int(sn.get("id")) & UINT_MAX if sn is not None else UINT_MAX
 
     def read_sampler(node):
         """ReadSamplerFromColorNode (integrator_pt_scene_mat.cpp:32-91): (key, row0, row1, disable_gamma) or None without a <texture>."""
@@ -980,7 +1082,7 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
         m = np.asarray(_f(linst.get("matrix"))).reshape(4, 4)
         ltype, shape, dist = lnode.get("type"), lnode.get("shape"), lnode.get("distribution")
         inten = lnode.find("intensity")
-        color = _f(inten.find("color").get("val"))
+        color = list(color4(inten.find("color")))                             # GetColorFromNode: one value splats over all four components
         mult_node = inten.find("multiplier")
         power = float(mult_node.get("val")) if mult_node is not None else 1.0
         if ltype == "sky":                  # LIGHT_GEOM_ENV (integrator_pt_scene_lgt.cpp:36-59, integrator_pt_scene.cpp:441-486)
@@ -1016,6 +1118,9 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
                 if proj is not None:
                     set_projective(lt, m, float(val1f(proj.find("fov"))), float(val1f(proj.find("nearClipPlane"))), float(val1f(proj.find("farClipPlane"))),
                                    load_texture_from_node(proj)[2] if proj.find("texture") is not None else UINT_MAX)
+        lt["specId"] = spectrum_id(inten.find("color"))                      # LoadLightSourceFromNode (integrator_pt_scene_lgt.cpp:22-25)
+        if len(_f(inten.find("color").get("val"))) != 3:
+            lt["intensity"] = color                                           # float4(v) / float4 as given (three values keep w = 0)
         ies = lnode.find("ies")
         if ies is not None:
             img = ies_spherical_texture(os.path.join(folder, ies.get("loc")))
@@ -1122,7 +1227,8 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
             au, av = attr_float(mnode.find("alpha_u")), attr_float(mnode.find("alpha_v"))
         mat["data"][0], mat["data"][1] = au, av                                # CONDUCTOR_ROUGH_U, CONDUCTOR_ROUGH_V
         mat["data"][2], mat["data"][3] = attr_float(mnode.find("eta")), attr_float(mnode.find("k"))
-        if mnode.find("reflectance") is not None:
+        mat["spdid"][0], mat["spdid"][1] = spectrum_id(mnode.find("eta")), spectrum_id(mnode.find("k"))      # (:493-497)
+        if mnode.find("reflectance") is not None and not spectral:           # (the reflectance colour is only read in RGB mode, :507-510)
             mat["colors"][0] = color4(mnode.find("reflectance"))
         return mat
 
@@ -1141,6 +1247,7 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
         if rn is not None:
             mat["colors"][0] = color4(rn)
             bind_texture(mat, 0, rn)
+            mat["spdid"][0] = spectrum_id(rn)                                 # (:559-560)
         return mat
 
     def load_dielectric(mnode):
@@ -1201,6 +1308,7 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
             if 0 <= lid < len(sc.lights):
                 mat["colors"][EMISSION_COLOR] = sc.lights[lid]["intensity"]
                 mat["data"][EMISSION_MULT] = sc.lights[lid]["mult"]
+                mat["spdid"][0] = sc.lights[lid]["specId"]
                 sc.lights[lid]["matId"] = len(sc.materials)
             sc.materials.append(mat)
             continue
@@ -1226,7 +1334,7 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
             bind_texture(mat, 0, cnode)                                       # rows of the node's sampler (default rows without a texture)
             mat["colors"][EMISSION_COLOR] = color
             mat["lightId"] = int(mnode.get("light_id")) & UINT_MAX if mnode.get("light_id") is not None else UINT_MAX
-            mat["spdid"][0] = UINT_MAX
+            mat["spdid"][0] = spectrum_id(cnode)                               # GetSpectrumIdFromNode(nodeEmissColor) (:319-320)
             mat["mtype"] = MAT_TYPE_LIGHT_SOURCE
             mult = cnode.find("multiplier") if cnode is not None else None
             mat["data"][EMISSION_MULT] = val1f(mult) if mult is not None else 1.0
@@ -1305,9 +1413,10 @@ def load_hydra_xml(xml_path: str, width=None, height=None) -> SceneData:
         apply_normal_map(mat, mnode)
         if mat["mtype"] == MAT_TYPE_LIGHT_SOURCE:
             lid = int(mnode.get("light_id", -1))
-            if 0 <= lid < len(sc.lights):                                     # LoadScene :973-996: the light's intensity wins
+            if 0 <= lid < len(sc.lights):                                     # LoadScene :973-996: the light's intensity, multiplier and spectrum win
                 mat["colors"][EMISSION_COLOR] = sc.lights[lid]["intensity"]
                 mat["data"][EMISSION_MULT] = sc.lights[lid]["mult"]
+                mat["spdid"][0] = sc.lights[lid]["specId"]
                 sc.lights[lid]["matId"] = len(sc.materials)
         sc.materials.append(mat)
 

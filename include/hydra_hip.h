@@ -71,6 +71,18 @@ typedef struct hpt_scene_desc {
   const uint32_t* instHasMotion;      /* numInsts flags */
   uint32_t        normMatrices2Offs;  /* m_normMatrices2Offs */
   uint32_t        reserved;
+  /* spectral rendering (integrator_pt.h: m_spec_values, m_spec_offset_sz, m_cie_xyz, m_camResponseSpectrumId / m_camResponseType): all may be
+   * NULL / 0 for RGB rendering. specValues: every spectrum resampled at 1 nm from LAMBDA_MIN = 360 (Spectrum::ResampleUniform, 471 floats each);
+   * specOffsetSz: uint2 {offset, size} per spectrum id (0xFFFFFFFF offset: a spectrum given by textures, outside this path's scope);
+   * cieXYZ: float4 {x, y, z, 0} x 471, the CIE 1931 observer at 360..830 nm (LoadScene fills it from Get_CIE_X/Y/Z, integrator_pt_scene.cpp:962-969). */
+  const float*    specValues;
+  const uint32_t* specOffsetSz;
+  uint32_t        numSpecValues, numSpectra;
+  const float*    cieXYZ;
+  uint32_t        numCieXYZ;
+  int32_t         camResponseSpectrumId[3];   /* -1: none (then SpectrumToXYZ + XYZToRGB) */
+  uint32_t        camResponseType;            /* 0 RGB, 1 XYZ (CAM_RESPONCE_XYZ) */
+  uint32_t        reserved2;
 } hpt_scene_desc;
 
 /* The plain-data members UpdateMembersPlainData() refreshes before every *Block call (integrator_pt.h:268, main.cpp:398). */
@@ -82,7 +94,8 @@ typedef struct hpt_params {
   uint32_t integratorType;    /* m_intergatorType: 0 naive, 1 shadow, 2 MIS (integrator_pt.h:330-332) */
   uint32_t renderLayer;       /* m_renderLayer: FB_COLOR / FB_DIRECT / FB_INDIRECT (integrator_pt.h:406-408) */
   uint32_t tileSize;          /* m_tileSize */
-  uint32_t spectralMode;      /* m_spectral_mode; must be 0 (spectral rendering is out of scope) */
+  uint32_t spectralMode;      /* m_spectral_mode: 0 = RGB; 1 = four wavelengths per path (needs hpt_scene_desc's spectral tables; scenes of diffuse, conductor
+                               * and emissive materials, <= 4 output channels - anything else is refused with HPT_ERR_UNSUPPORTED) */
   uint32_t reserved0;
   float    exposureMult, camLensRadius, camTargetDist, reserved1;
   float    camRespoceRGB[4];  /* m_camRespoceRGB */

@@ -53,6 +53,15 @@ typedef struct orc_scene_desc {
   const uint32_t* instHasMotion;      // numInsts flags (may be NULL)
   uint32_t        normMatrices2Offs;  // m_normMatrices2Offs
   uint32_t        reserved;
+  // spectral rendering: m_spec_values (1 nm from 360), m_spec_offset_sz (uint2 per spectrum), m_cie_xyz (float4 x 471), camera response ids
+  const float*    specValues;
+  const uint32_t* specOffsetSz;
+  uint32_t        numSpecValues, numSpectra;
+  const float*    cieXYZ;
+  uint32_t        numCieXYZ;
+  int32_t         camResponseSpectrumId[3];
+  uint32_t        camResponseType;
+  uint32_t        reserved2;
 } orc_scene_desc;
 
 typedef struct orc_params {
@@ -63,7 +72,7 @@ typedef struct orc_params {
   uint32_t integratorType;    // m_intergatorType: 0 naive, 1 shadow, 2 MIS
   uint32_t renderLayer;       // m_renderLayer: 0 colour, 1 direct, 2 indirect
   uint32_t tileSize;          // m_tileSize
-  uint32_t spectralMode;      // must be 0
+  uint32_t spectralMode;      // m_spectral_mode
   uint32_t reserved0;
   float    exposureMult, camLensRadius, camTargetDist, reserved1;
   float    camRespoceRGB[4];

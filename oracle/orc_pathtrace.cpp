@@ -163,10 +163,92 @@ struct Ctx
     return PdfAtoW(L.pdfA, hitDist, cosVal);
   }
 
-  f4 LightIntensity(uint a_lightId, f3 a_rayPos, f3 a_rayDir) const   // :109-173 (RGB mode; env / projective textures out of scope)
+  // ---- spectral rendering (m_spectral_mode != 0): spectrum.h + integrator_spectrum.cpp --------------------------------------
+  // Restated for what the reference's own spectral fixture exercises: diffuse and conductor BSDFs, emissive surfaces, analytic lights.
+  // The other BSDFs keep their RGB parameters here; spectral textures (lambda_ref_ids), thin films and the environment spectrum are not restated.
+  static constexpr float LAMBDA_MIN = 360.0f, LAMBDA_MAX = 830.0f;     // include/cglobals.h:22-23
+  static f4 SampleWavelengths(float u, float a, float b)               // spectrum.h:58-75
+  {
+    float res[4];
+    res[0] = lerpf(a, b, u);
+    const float delta = (b - a) / 4.0f;
+    for (int i = 1; i < 4; ++i) { res[i] = res[i - 1] + delta; if (res[i] > b) res[i] = a + (res[i] - b); }
+    return mk4(res[0], res[1], res[2], res[3]);
+  }
+  f4 SampleUniformSpectrum(uint a_offset, f4 a_wavelengths) const      // spectrum.h:106-126
+  {
+    const int WAVESN = int(LAMBDA_MAX - LAMBDA_MIN);
+    const float* w = &a_wavelengths.x;
+    float r[4];
+    for (int i = 0; i < 4; i++) {
+      const int index1 = int(std::min(std::max(w[i] - LAMBDA_MIN, 0.0f), float(WAVESN - 1)));
+      const int index2 = std::min(index1 + 1, WAVESN - 1);
+      const float x1 = LAMBDA_MIN + float(index1);
+      const float y1 = sc.specValues[a_offset + (uint)index1], y2 = sc.specValues[a_offset + (uint)index2];
+      r[i] = y1 + (w[i] - x1) * (y2 - y1);
+    }
+    return mk4(r[0], r[1], r[2], r[3]);
+  }
+  f4 SampleMatColorSpectrumTexture(uint matId, f4 a_wavelengths, uint paramId, uint paramSpecId) const   // integrator_spectrum.cpp:128-171, without spectral textures
+  {
+    f4 res = sc.materials[matId].colors[paramId];
+    if (a_wavelengths.x == 0.0f) return res;
+    const uint specId = sc.materials[matId].spdid[paramSpecId];
+    if (specId < 0xFFFFFFFFu) res = SampleUniformSpectrum(sc.specOffsetSz[2 * specId], a_wavelengths);
+    return res;
+  }
+  f4 SampleMatParamSpectrum(uint matId, f4 a_wavelengths, uint paramId, uint paramSpecId) const          // integrator_spectrum.cpp:25-44
+  {
+    f4 res = splat4(sc.materials[matId].data[paramId]);
+    if (a_wavelengths.x == 0.0f) return res;
+    const uint specId = sc.materials[matId].spdid[paramSpecId];
+    if (specId < 0xFFFFFFFFu) res = SampleUniformSpectrum(sc.specOffsetSz[2 * specId], a_wavelengths);
+    return res;
+  }
+  f3 SpectrumToXYZ(f4 spec4, f4 lambda4, bool terminate_waves) const   // spectrum.h:151-203
+  {
+    float pdf[4] = { 1.0f / (LAMBDA_MAX - LAMBDA_MIN), 1.0f / (LAMBDA_MAX - LAMBDA_MIN), 1.0f / (LAMBDA_MAX - LAMBDA_MIN), 1.0f / (LAMBDA_MAX - LAMBDA_MIN) };
+    const float CIE_Y_integral = 106.856895f;
+    const uint nCIESamples = 471;
+    float spec[4] = { spec4.x, spec4.y, spec4.z, spec4.w };
+    const float* lambda = &lambda4.x;
+    if (terminate_waves) { pdf[0] /= 4.0f; for (int i = 1; i < 4; ++i) pdf[i] = 0.0f; }
+    for (int i = 0; i < 4; ++i) spec[i] = (pdf[i] != 0) ? spec[i] / pdf[i] : 0.0f;
+    float X[4], Y[4], Z[4];
+    for (int i = 0; i < 4; ++i) {
+      const uint offset = uint(float(std::floor(lambda[i] + 0.5f)) - LAMBDA_MIN);
+      const bool out = offset >= nCIESamples || offset >= sc.cieXYZ.size();
+      const f4 XYZ = out ? mk4(0, 0, 0, 0) : sc.cieXYZ[offset];
+      X[i] = XYZ.x; Y[i] = XYZ.y; Z[i] = XYZ.z;
+    }
+    for (int i = 0; i < 4; ++i) { X[i] *= spec[i]; Y[i] *= spec[i]; Z[i] *= spec[i]; }
+    auto average = [](const float* v) { float sum = v[0]; for (int i = 1; i < 4; ++i) sum += v[i]; return sum / 4.0f; };   // SpectrumAverage (:143-149)
+    return mk3(average(X) / CIE_Y_integral, average(Y) / CIE_Y_integral, average(Z) / CIE_Y_integral);
+  }
+  static f3 XYZToRGB(f3 xyz)                                           // spectrum.h:206-214
+  {
+    return mk3(+3.240479f * xyz.x - 1.537150f * xyz.y - 0.498535f * xyz.z,
+               -0.969256f * xyz.x + 1.875991f * xyz.y + 0.041556f * xyz.z,
+               +0.055648f * xyz.x - 0.204043f * xyz.y + 1.057311f * xyz.z);
+  }
+  f3 SpectralCamRespoceToRGB(f4 specSamples, f4 waves, uint rayFlags) const   // integrator_spectrum.cpp:68-124
+  {
+    if (sc.camResponseSpectrumId[0] < 0) return XYZToRGB(SpectrumToXYZ(specSamples, waves, (rayFlags & RAY_FLAG_WAVES_DIVERGED) != 0));
+    f4 responceX, responceY, responceZ;
+    responceX = SampleUniformSpectrum(sc.specOffsetSz[2 * sc.camResponseSpectrumId[0]], waves);
+    responceY = sc.camResponseSpectrumId[1] >= 0 ? SampleUniformSpectrum(sc.specOffsetSz[2 * sc.camResponseSpectrumId[1]], waves) : responceX;
+    responceZ = sc.camResponseSpectrumId[2] >= 0 ? SampleUniformSpectrum(sc.specOffsetSz[2 * sc.camResponseSpectrumId[2]], waves) : responceY;
+    f3 xyz = mk3(0, 0, 0);
+    const float* sp = &specSamples.x; const float* rx = &responceX.x; const float* ry = &responceY.x; const float* rz = &responceZ.x;
+    for (int i = 0; i < 4; ++i) { xyz.x += sp[i] * rx[i]; xyz.y += sp[i] * ry[i]; xyz.z += sp[i] * rz[i]; }
+    return sc.camResponseType == 1u ? XYZToRGB(xyz) : xyz;             // CAM_RESPONCE_XYZ
+  }
+
+  f4 LightIntensity(uint a_lightId, f3 a_rayPos, f3 a_rayDir, f4 a_wavelengths = f4{0, 0, 0, 0}) const   // :109-173
   {
     const LightSource& L = sc.lights[a_lightId];
     f4 lightColor = L.intensity;
+    if (p.spectralMode != 0 && L.specId < 0xFFFFFFFFu) lightColor = SampleUniformSpectrum(sc.specOffsetSz[2 * L.specId], a_wavelengths);   // :115-123
     lightColor = lightColor * L.mult;
     const uint iesId = L.iesId;
     if (iesId != uint(-1)) {
@@ -244,7 +326,7 @@ struct Ctx
     return normalize(w);
   }
 
-  BsdfSample MaterialSampleAndEval(uint a_materialId, RandomGen* a_gen, f3 v, f3 n, f3 tan, f2 tc, MisData* a_misPrev, uint a_currRayFlags, Record* rec, uint bounce) const   // :109-306
+  BsdfSample MaterialSampleAndEval(uint a_materialId, RandomGen* a_gen, f3 v, f3 n, f3 tan, f2 tc, MisData* a_misPrev, uint a_currRayFlags, Record* rec, uint bounce, f4 wavelengths = f4{0, 0, 0, 0}) const   // :109-306
   {
     BsdfSample res;
     res.val = mk4(0, 0, 0, 0); res.pdf = 1.0f; res.dir = mk3(0, 1, 0); res.ior = 1.0f; res.flags = a_currRayFlags;
@@ -279,13 +361,13 @@ struct Ctx
       case MAT_TYPE_CONDUCTOR: {
         const f3 alphaTex = xyz(texColor);
         const f2 alpha = mk2(m.data[CONDUCTOR_ROUGH_V], m.data[CONDUCTOR_ROUGH_U]);
-        const f4 etaSpec = splat4(m.data[CONDUCTOR_ETA]), kSpec = splat4(m.data[CONDUCTOR_K]);   // integrator_spectrum.cpp:25-29 RGB early-out
+        const f4 etaSpec = SampleMatParamSpectrum(currMatId, wavelengths, CONDUCTOR_ETA, 0), kSpec = SampleMatParamSpectrum(currMatId, wavelengths, CONDUCTOR_K, 1);
         if (trEffectivelySmooth(alpha)) conductorSmoothSampleAndEval(m, etaSpec, kSpec, rands, v, shadeNormal, tc, &res);
         else                            conductorRoughSampleAndEval(m, etaSpec, kSpec, rands, v, shadeNormal, tc, alphaTex, &res);
       } break;
       case MAT_TYPE_DIFFUSE: {
-        f4 reflSpec = m.colors[DIFFUSE_COLOR];                                                     // integrator_spectrum.cpp:128-133
-        reflSpec = reflSpec * texColor;
+        f4 reflSpec = SampleMatColorSpectrumTexture(currMatId, wavelengths, DIFFUSE_COLOR, 0);      // integrator_pt_mat.cpp:256-260
+        if (p.spectralMode == 0) reflSpec = reflSpec * texColor;
         diffuseSampleAndEval(m, reflSpec, rands, v, shadeNormal, tc, &res);
       } break;
       case MAT_TYPE_GLASS: glassSampleAndEval(m, rands, v, geomNormal, &res, &a_misPrev->ior); break;    // integrator_pt_mat.cpp:178-183: the geometric normal
@@ -310,7 +392,7 @@ struct Ctx
     return res;
   }
 
-  BsdfEval MaterialEval(uint a_materialId, f3 l, f3 v, f3 n, f3 tan, f2 tc) const   // :308-528
+  BsdfEval MaterialEval(uint a_materialId, f3 l, f3 v, f3 n, f3 tan, f2 tc, f4 wavelengths = f4{0, 0, 0, 0}) const   // :308-528
   {
     BsdfEval res; res.val = mk4(0, 0, 0, 0); res.pdf = 0.0f;
     // blend tree walk (:316-333, 511-527): a stack of (material id, weight) pairs, BLEND_STACK_SIZE deep
@@ -346,15 +428,15 @@ struct Ctx
           const f3 alphaTex = xyz(texColor);
           const f2 alpha = mk2(m.data[CONDUCTOR_ROUGH_V], m.data[CONDUCTOR_ROUGH_U]);
           if (!trEffectivelySmooth(alpha)) {
-            const f4 etaSpec = splat4(m.data[CONDUCTOR_ETA]), kSpec = splat4(m.data[CONDUCTOR_K]);
+            const f4 etaSpec = SampleMatParamSpectrum(currMat.id, wavelengths, CONDUCTOR_ETA, 0), kSpec = SampleMatParamSpectrum(currMat.id, wavelengths, CONDUCTOR_K, 1);
             conductorRoughEval(m, etaSpec, kSpec, l, v, shadeNormal, tc, alphaTex, &currVal);
           }
           res.val = res.val + currVal.val * weight * bumpCosMult;
           res.pdf += currVal.pdf * weight;
         } break;
         case MAT_TYPE_DIFFUSE: {
-          f4 reflSpec = m.colors[DIFFUSE_COLOR];
-          reflSpec = reflSpec * texColor;
+          f4 reflSpec = SampleMatColorSpectrumTexture(currMat.id, wavelengths, DIFFUSE_COLOR, 0);   // integrator_pt_mat.cpp:474-477
+          if (p.spectralMode == 0) reflSpec = reflSpec * texColor;
           diffuseEval(m, reflSpec, l, v, shadeNormal, tc, &currVal);
           res.val = res.val + currVal.val * weight * bumpCosMult;
           res.pdf += currVal.pdf * weight;
@@ -387,6 +469,7 @@ struct Ctx
     RandomGen gen; MisData mis; uint rayFlags;
     f4 hit1, hit2, hit3; uint instId;
     float time;                                   // motion blur: the path's time in [0, 1] (integrator_pt.cpp:112-115)
+    f4 wavelengths = f4{0, 0, 0, 0};              // spectral rendering: the path's four wavelengths (zero in RGB mode, :145-148)
   };
 
   static inline bool isDeadRay(uint f) { return (f & RAY_FLAG_IS_DEAD) != 0; }
@@ -500,6 +583,7 @@ struct Ctx
     if (rec && rec->enabled) rec->lens = pixelOffsets;
     CameraRay(tid, pixelOffsets, &s->rayPosAndNear, &s->rayDirAndFar);
     s->time = sc.motion ? rndFloat1(&genLocal) : 0.0f;  // GetRandomNumbersTime: only when m_normMatrices2Offs != 0 (:114-115)
+    s->wavelengths = p.spectralMode != 0 ? SampleWavelengths(rndFloat1(&genLocal), LAMBDA_MIN, LAMBDA_MAX) : mk4(0, 0, 0, 0);   // GetRandomNumbersSpec (:116-118, 145-148)
     s->gen = genLocal;
   }
 
@@ -582,7 +666,7 @@ struct Ctx
     const bool needShade = inIllumArea && !sc.any_hit(xyzw(shadowRayPos, 0.0f), xyzw(shadowRayDir, hitDist * 0.9995f), false, s->time);
     if (rec && rec->enabled) rec->inShadow[bounce] = needShade ? 0 : 1;
     if (needShade) {
-      const BsdfEval bsdfV = MaterialEval(matId, shadowRayDir, (-1.0f) * ray_dir, hnorm, htang, huv);
+      const BsdfEval bsdfV = MaterialEval(matId, shadowRayDir, (-1.0f) * ray_dir, hnorm, htang, huv, s->wavelengths);
       const float cosThetaOut = std::max(dot(shadowRayDir, hnorm), 0.0f);
       float lgtPdfW = LightPdfSelectRev(lightId) * LightEvalPDF(lightId, shadowRayPos, shadowRayDir, lSam.pos, lSam.norm, lSam.pdf);
       float misWeight = (p.integratorType == INTEGRATOR_MIS_PT) ? misWeightHeuristic(lgtPdfW, bsdfV.pdf) : 1.0f;
@@ -592,7 +676,7 @@ struct Ctx
       else if (isPoint) misWeight = 1.0f;
       const bool isDirectLight = !hasNonSpecular(currRayFlags);
       if ((p.renderLayer == FB_DIRECT && !isDirectLight) || (p.renderLayer == FB_INDIRECT && isDirectLight)) misWeight = 0.0f;
-      const f4 lightColor = LightIntensity(lightId, shadowRayPos, shadowRayDir);
+      const f4 lightColor = LightIntensity(lightId, shadowRayPos, shadowRayDir, s->wavelengths);
       shade = (lightColor * bsdfV.val / lgtPdfW) * cosThetaOut * misWeight;
     }
     return shade;
@@ -620,7 +704,7 @@ struct Ctx
       if (lightId != 0xFFFFFFFFu) {
         const float lightCos = dot(ray_dir, xyz(sc.lights[lightId].norm));
         const float lightDirectionAtten = (lightCos < 0.0f || sc.lights[lightId].geomType == LIGHT_GEOM_SPHERE) ? 1.0f : 0.0f;
-        lightIntensity = LightIntensity(lightId, ray_pos, ray_dir) * lightDirectionAtten;
+        lightIntensity = LightIntensity(lightId, ray_pos, ray_dir, s->wavelengths) * lightDirectionAtten;
       }
       float misWeight = 1.0f;
       if (p.integratorType == INTEGRATOR_MIS_PT) {
@@ -638,7 +722,7 @@ struct Ctx
       return;
     }
 
-    const BsdfSample matSam = MaterialSampleAndEval(matId, &s->gen, (-1.0f) * ray_dir, hnorm, htang, huv, &s->mis, currRayFlags, rec, bounce);
+    const BsdfSample matSam = MaterialSampleAndEval(matId, &s->gen, (-1.0f) * ray_dir, hnorm, htang, huv, &s->mis, currRayFlags, rec, bounce, s->wavelengths);
     const f4 bxdfVal = matSam.val * (1.0f / std::max(matSam.pdf, 1e-20f));
     const float cosTheta = std::abs(dot(matSam.dir, hnorm));
     s->mis.matSamplePdf = (matSam.flags & RAY_EVENT_S) != 0 ? -1.0f : matSam.pdf;
@@ -687,8 +771,19 @@ struct Ctx
     const uint XY = packedXY[tid];
     const uint x = (XY & 0x0000FFFFu), y = (XY & 0xFFFF0000u) >> 16;
     const f4 tmpVal = s->accumColor * p.camRespoceRGB;
-    const f4 colorRes = p.exposureMult * mk4(tmpVal.x, tmpVal.y, tmpVal.z, 1.0f);
+    f3 rgb = xyz(tmpVal);
+    if (p.spectralMode != 0) rgb = SpectralCamRespoceToRGB(s->accumColor, s->wavelengths, s->rayFlags);   // :618-625
+    const f4 colorRes = p.exposureMult * mk4(rgb.x, rgb.y, rgb.z, 1.0f);
     if (channels == 1) out_color[y * p.winWidth + x] += s->accumColor.x * p.exposureMult;
+    else if (channels > 4) {                         // "always spectral rendering" (:642-654): one W x H layer per wavelength bin
+      const f4 color = s->accumColor * p.exposureMult;
+      const float* waves = &s->wavelengths.x; const float* cv = &color.x;
+      for (int i = 0; i < 4; i++) {
+        const float t = (waves[i] - LAMBDA_MIN) / (LAMBDA_MAX - LAMBDA_MIN);
+        const int channelId = std::min(int(float(channels) * t), int(channels) - 1);
+        out_color[(size_t)channelId * p.winWidth * p.winHeight + (size_t)y * p.winWidth + x] += cv[i];
+      }
+    }
     else {
       out_color[(y * p.winWidth + x) * channels + 0] += colorRes.x;
       out_color[(y * p.winWidth + x) * channels + 1] += colorRes.y;
@@ -1213,6 +1308,8 @@ int orc_probe(const char* name, const float* a, float* out)
     }
     return 0;
   }
+  if (n == "SampleWavelengths") { const f4 r = Ctx::SampleWavelengths(a[0], a[1], a[2]); out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w; return 0; }
+  if (n == "XYZToRGB") { const f3 r = Ctx::XYZToRGB(mk3(a[0], a[1], a[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; return 0; }
   if (n == "orennayarFunc") { out[0] = orennayarFunc(mk3(a[0], a[1], a[2]), mk3(a[3], a[4], a[5]), mk3(0, 0, 1), a[6]); return 0; }
   return 1;
 }

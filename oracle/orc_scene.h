@@ -179,6 +179,12 @@ struct Scene
   std::vector<LightSource> lights;
   std::vector<Texture>  textures;
   std::vector<float>    arrays1f;        // m_arrays1f
+  // spectral rendering (integrator_pt.h: m_spec_values, m_spec_offset_sz, m_cie_xyz, m_camResponseSpectrumId, m_camResponseType)
+  std::vector<float>    specValues;
+  std::vector<uint>     specOffsetSz;    // uint2 per spectrum
+  std::vector<f4>       cieXYZ;
+  int                   camResponseSpectrumId[3] = { -1, -1, -1 };
+  uint                  camResponseType = 0;
 
   std::vector<SimpleBvh> blas;            // per geom
   SimpleBvh              tlas;
@@ -223,6 +229,13 @@ struct Scene
     }
     arrays1f.clear();
     if (s->arrays1f && s->numArrays1f) arrays1f.assign(s->arrays1f, s->arrays1f + s->numArrays1f);
+    specValues.clear(); specOffsetSz.clear(); cieXYZ.clear();
+    if (s->specValues && s->numSpecValues) specValues.assign(s->specValues, s->specValues + s->numSpecValues);
+    if (s->specOffsetSz && s->numSpectra) specOffsetSz.assign(s->specOffsetSz, s->specOffsetSz + 2 * (size_t)s->numSpectra);
+    if (s->cieXYZ && s->numCieXYZ) cieXYZ.assign((const f4*)s->cieXYZ, (const f4*)s->cieXYZ + s->numCieXYZ);
+    cieXYZ.resize(std::max<size_t>(cieXYZ.size(), 472), mk4(0, 0, 0, 0));   // SpectrumToXYZ reads entry `offset` before testing offset >= 471
+    for (int k = 0; k < 3; k++) camResponseSpectrumId[k] = s->specValues ? s->camResponseSpectrumId[k] : -1;
+    camResponseType = s->camResponseType;
     instMatricesInv.resize(instMatrices.size());
     for (size_t i = 0; i < instMatrices.size(); i++) instMatricesInv[i] = affine_inverse(instMatrices[i]);
     build_accel();

@@ -619,3 +619,70 @@ def test_ldr_image_files_decode_to_the_containers_texels(tmp_path):
     assert np.array_equal(decode_ldr_image("x.bmp", bmp), want)
     with pytest.raises(NotImplementedError):
         decode_ldr_image("x.jpg", b"")
+
+
+# ---- spectral rendering: tables and the oracle's restatement --------------------------------------------------------------------
+def test_spectrum_resampling_and_wavelength_placement():
+    """Spectrum::ResampleUniform (471 samples at 1 nm from 360 nm: linear between the tabulated points, zero outside them) and
+    SampleWavelengths (spectrum.h:58-75: one offset, three rotations by a quarter of the range, wrapped into [a, b])."""
+    from oracle.orc import probe
+    u = S.resample_uniform([400.0, 500.0, 700.0], [1.0, 3.0, 1.0])
+    assert u.shape == (471,) and u.dtype == np.float32
+    assert u[0] == 0.0 and u[39] == 0.0 and u[40] == 1.0 and u[140] == 3.0 and u[340] == 1.0 and u[341] == 0.0
+    assert u[90] == pytest.approx(2.0) and u[240] == pytest.approx(2.0)
+    w = probe("SampleWavelengths", 0.5, 360.0, 830.0)[:4]
+    assert list(w) == [595.0, 712.5, 830.0, 477.5]                       # 830 is not > b: kept; the next one wraps to a + 117.5
+    w = probe("SampleWavelengths", 0.0, 360.0, 830.0)[:4]
+    assert list(w) == [360.0, 477.5, 595.0, 712.5]
+    # XYZToRGB: the D65 white point (0.9505, 1, 1.089) maps to about (1, 1, 1)
+    assert np.allclose(probe("XYZToRGB", 0.9505, 1.0, 1.089)[:3], 1.0, atol=2e-3)
+
+
+def test_cie_observer_fit_is_close_to_the_tabulated_one():
+    """The fixture loaders' m_cie_xyz: the multi-lobe fit integrates to the reference's CIE_Y_integral (106.856895, spectrum.h:154) within
+    0.5 % and peaks where the photopic curve does."""
+    cie = S.cie_xyz_fit()
+    assert cie.shape == (471, 4) and cie.dtype == np.float32
+    assert cie[:, 1].sum() == pytest.approx(106.856895, rel=5e-3)
+    assert 553 <= 360 + int(np.argmax(cie[:, 1])) <= 557
+    assert cie[:, 0].sum() == pytest.approx(cie[:, 1].sum(), rel=0.01)    # equal-energy white: X = Y = Z
+    assert cie[:, 2].sum() == pytest.approx(cie[:, 1].sum(), rel=0.01)
+
+
+def test_spectral_fixture_tables():
+    """LoadSceneSpectrumData on the reference's spectral fixture: seven spectra of 471 samples each, ids wired into the materials and the
+    light as the XML names them."""
+    sc = S.load_hydra_xml(scene_path("test_spectral"), 32, 32, spectral=True)
+    assert sc.spectral_mode == 1 and sc.params().spectralMode == 1
+    assert [tuple(v) for v in sc.spec_offset_sz] == [(471 * i, 471) for i in range(7)]
+    assert sc.spec_values.shape == (7 * 471,) and np.isfinite(sc.spec_values).all() and sc.spec_values.max() > 0
+    assert int(sc.lights[0]["specId"]) == 4
+    cond = [m for m in sc.materials if int(m["mtype"]) == S.MAT_TYPE_CONDUCTOR]
+    assert len(cond) == 1 and list(cond[0]["spdid"][:2]) == [5, 6]
+    diff = [int(m["spdid"][0]) for m in sc.materials if int(m["mtype"]) == S.MAT_TYPE_DIFFUSE]
+    assert sorted(diff) == [1, 2, 3]
+    d = sc.desc()
+    assert d.numSpectra == 7 and d.numSpecValues == 7 * 471 and d.numCieXYZ == 471
+    rgb = S.load_hydra_xml(scene_path("test_spectral"), 32, 32)
+    assert rgb.spectral_mode == 0 and rgb.params().spectralMode == 0
+
+
+def test_oracle_spectral_render_of_grey_scene_keeps_the_luminance():
+    """A consistency property of the restated spectral path: with every spectrum removed the fixture is grey (reflectances and emission
+    are single values splat over the four wavelengths), each path carries the same radiance L at its four wavelengths, and the CIE
+    observer turns that into Y = L * mean(ybar) * (830 - 360) / 106.857 = L in expectation - so the spectral image's luminance equals
+    the RGB image of the same scene up to Monte-Carlo noise."""
+    from oracle.orc import OracleIntegrator
+    imgs = {}
+    for spectral in (False, True):
+        sc = S.load_hydra_xml(scene_path("test_spectral"), 48, 48, spectral=spectral)
+        for m in sc.materials: m["spdid"] = 0xFFFFFFFF
+        for l in sc.lights: l["specId"] = 0xFFFFFFFF
+        img = OracleIntegrator(sc).render(32)[..., :3] / 32
+        imgs[spectral] = img
+    rgb = imgs[False]
+    assert np.allclose(rgb[..., 0], rgb[..., 1]) and rgb.mean() > 1e-3
+    M = np.array([[3.240479, -1.537150, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]])
+    y_spec = (imgs[True].reshape(-1, 3) @ np.linalg.inv(M).T)[:, 1].mean()
+    print(f"mean luminance: spectral {y_spec:.5f}, rgb {rgb[..., 1].mean():.5f}")
+    assert y_spec == pytest.approx(rgb[..., 1].mean(), rel=0.03)

@@ -1,0 +1,170 @@
+"""Spectral rendering (m_spectral_mode = 1) of the HIP path against the CPU oracle: the reference's own spectral fixture
+(scenes/test_spectral/spectral_cornell_conductor.xml: reflectance spectra on the walls, a rough conductor with eta / k spectra, an area
+light with an emission spectrum), its variants, the three framebuffer forms of kernel_ContributeToImage and the refusals."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import scene_path
+from hydracore3_amd.scene import load_hydra_xml, MAT_TYPE_CONDUCTOR
+
+pytestmark = pytest.mark.gpu
+
+SPECTRAL_XML = scene_path("test_spectral")
+
+
+def _l2(a, b, spp):
+    d = (a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64)) / spp
+    return float(np.sqrt(np.mean(np.sum(d * d, axis=-1))))
+
+
+def _pair(sc, **kw):
+    from hydracore3_amd.api import HipIntegrator
+    from oracle.orc import OracleIntegrator
+    return HipIntegrator(sc, **kw), OracleIntegrator(sc)
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2, 3])
+def test_spectral_fixture_matches_oracle(layout):
+    """Four wavelengths per path, spectra looked up per wavelength, CIE observer at the end: per-pixel L2 < 1e-3 of the mean radiance
+    scale, most pixels bit-identical, generator streams identical wherever the paths did not diverge - in every acceleration layout."""
+    sc = load_hydra_xml(SPECTRAL_XML, 96, 96, spectral=True)
+    gpu, cpu = _pair(sc, accel_layout=layout)
+    spp = 16
+    a, b = gpu.render(spp), cpu.render(spp)
+    assert np.isfinite(a).all() and a[..., :3].mean() > 0
+    l2 = _l2(a, b, spp)
+    same = float(np.mean(np.all(a[..., :3] == b[..., :3], axis=-1)))
+    same_rng = float(np.mean(np.all(gpu.random_gens() == cpu.random_gens(), axis=1)))
+    print(f"layout {layout}: per-pixel L2 = {l2:.3e} (mean {b[..., :3].mean() / spp:.4f}), bit-identical pixels {same * 100:.2f} %, identical generators {same_rng * 100:.2f} %")
+    assert l2 < 1e-3
+    assert same > 0.2
+    assert same_rng > 0.99
+
+
+def test_spectral_draws_one_more_random_number_per_path():
+    """GetRandomNumbersSpec (integrator_pt.cpp:116-118): with a trace depth of 0 a path is the lens draw plus the wavelength draw, so the
+    generators after one pass differ from the RGB mode's and equal the oracle's bit for bit."""
+    sc = load_hydra_xml(SPECTRAL_XML, 32, 32, spectral=True)
+    sc.trace_depth = 0
+    gpu, cpu = _pair(sc)
+    gpu.render(1); cpu.render(1)
+    assert np.array_equal(gpu.random_gens(), cpu.random_gens())
+    rgb = load_hydra_xml(SPECTRAL_XML, 32, 32, spectral=False)
+    rgb.trace_depth = 0
+    g2, _ = _pair(rgb)
+    g2.render(1)
+    assert not np.array_equal(g2.random_gens(), gpu.random_gens())
+
+
+def test_monochrome_and_wavelength_layer_framebuffers():
+    """kernel_ContributeToImage's other two forms (integrator_pt.cpp:631-654): channels == 1 adds the first wavelength's sample, channels > 4
+    adds every sample to the layer of its wavelength bin ([channels][H][W])."""
+    sc = load_hydra_xml(SPECTRAL_XML, 64, 64, spectral=True)
+    spp = 8
+    for channels in (1, 3, 16):
+        gpu, cpu = _pair(sc)
+        a = np.zeros(64 * 64 * channels, np.float32); b = a.copy()
+        gpu.PathTraceBlock(gpu.N, channels, a, spp)
+        cpu.path_trace_block(b, spp, channels=channels)
+        assert np.isfinite(a).all() and a.sum() > 0
+        if channels == 16:
+            la, lb = a.reshape(16, 64, 64), b.reshape(16, 64, 64)
+            assert (la.sum(axis=(1, 2)) > 0).all()                    # every wavelength bin received samples
+            d = (la.astype(np.float64) - lb) / spp
+            err = float(np.sqrt(np.mean(np.sum(d * d, axis=0))))
+            scale = float(np.sum(lb, axis=0).mean() / spp)
+        else:
+            ia, ib = a.reshape(64, 64, channels), b.reshape(64, 64, channels)
+            d = (ia.astype(np.float64) - ib) / spp
+            err = float(np.sqrt(np.mean(np.sum(d * d, axis=-1))))
+            scale = float(ib.sum(axis=-1).mean() / spp)
+        print(f"channels {channels}: per-pixel L2 {err:.3e}, scale {scale:.4f}, bit-identical values {np.mean(a == b) * 100:.2f} %")
+        assert err < 1e-3 * max(scale, 1.0)
+        assert np.mean(a == b) > 0.5
+        assert np.mean(np.all(gpu.random_gens() == cpu.random_gens(), axis=1)) > 0.99
+
+
+def test_spectral_accumulates_and_tid_windows_compose():
+    sc = load_hydra_xml(SPECTRAL_XML, 64, 64, spectral=True)
+    from hydracore3_amd.api import HipIntegrator
+    one, two = HipIntegrator(sc), HipIntegrator(sc)
+    full = one.render(6)
+    img = np.zeros_like(full)
+    half = (two.N // 2 // 64) * 64
+    for _ in range(2):                                                  # 2 x 3 passes over two windows == 6 passes over the frame
+        two.PathTraceBlock(half, 4, img, 3, tid_begin=0)
+        two.PathTraceBlock(two.N - half, 4, img, 3, tid_begin=half)
+    assert np.array_equal(img, full)
+    assert np.array_equal(one.random_gens(), two.random_gens())
+
+
+def test_smooth_conductor_and_constant_parameters():
+    """The fixture's conductor made mirror-smooth (conductorSmoothSampleAndEval with eta / k per wavelength) and a conductor without spectra
+    (SampleMatParamSpectrum falls back to the scalar eta / k)."""
+    for variant in ("smooth", "no-spectra"):
+        sc = load_hydra_xml(SPECTRAL_XML, 64, 64, spectral=True)
+        n = 0
+        for m in sc.materials:
+            if int(m["mtype"]) == MAT_TYPE_CONDUCTOR:
+                n += 1
+                if variant == "smooth": m["data"][0] = m["data"][1] = 0.0
+                else: m["spdid"][0] = m["spdid"][1] = 0xFFFFFFFF
+        assert n == 1
+        gpu, cpu = _pair(sc)
+        a, b = gpu.render(8), cpu.render(8)
+        l2 = _l2(a, b, 8)
+        print(f"{variant}: per-pixel L2 = {l2:.3e}, identical generators {np.mean(np.all(gpu.random_gens() == cpu.random_gens(), axis=1)) * 100:.2f} %")
+        assert l2 < 1e-3
+
+
+def test_camera_response_spectra():
+    """SpectralCamRespoceToRGB with m_camResponseSpectrumId set (integrator_spectrum.cpp:76-121): the response spectra replace the CIE
+    observer; both response types (XYZ -> RGB matrix, or taken as RGB)."""
+    for ids, rtype in (((1, 2, 3), 0), ((1, -1, -1), 1)):
+        sc = load_hydra_xml(SPECTRAL_XML, 48, 48, spectral=True)
+        sc.cam_response_spectrum_id = ids
+        sc.cam_response_type = rtype
+        gpu, cpu = _pair(sc)
+        a, b = gpu.render(8), cpu.render(8)
+        scale = max(float(np.abs(b[..., :3]).mean() / 8), 1.0)
+        assert _l2(a, b, 8) < 1e-3 * scale
+        assert np.mean(np.all(a[..., :3] == b[..., :3], axis=-1)) > 0.2
+
+
+def test_same_scene_in_rgb_mode_still_matches():
+    sc = load_hydra_xml(SPECTRAL_XML, 64, 64, spectral=False)
+    gpu, cpu = _pair(sc)
+    a, b = gpu.render(8), cpu.render(8)
+    assert _l2(a, b, 8) < 1e-3
+
+
+def test_spectral_mode_refusals():
+    """What the spectral kernel does not cover is refused by name (never rendered in RGB instead)."""
+    from hydracore3_amd.api import HipIntegrator, HydraHipError
+    # a scene whose surfaces use the gltf BSDF
+    sc = load_hydra_xml(scene_path("test_035"), 32, 32)
+    sc.spectral_mode = 1
+    with pytest.raises(HydraHipError, match="spectral"):
+        HipIntegrator(sc)
+    # a scene that came without spectral tables
+    sc = load_hydra_xml(SPECTRAL_XML, 32, 32, spectral=True)
+    sc.spec_offset_sz = []
+    with pytest.raises(HydraHipError, match="spectral"):
+        HipIntegrator(sc)
+    # the other integrators
+    sc = load_hydra_xml(SPECTRAL_XML, 32, 32, spectral=True)
+    gpu = HipIntegrator(sc)
+    img = np.zeros((32, 32, 4), np.float32)
+    with pytest.raises(HydraHipError, match="spectral"):
+        gpu.NaivePathTraceBlock(gpu.N, 4, img, 1)
+    # more than four channels only in spectral mode
+    rgb = HipIntegrator(load_hydra_xml(SPECTRAL_XML, 32, 32, spectral=False))
+    with pytest.raises(HydraHipError, match="channels"):
+        rgb.PathTraceBlock(rgb.N, 16, np.zeros(32 * 32 * 16, np.float32), 1)
+    # a spectrum id past the table
+    sc = load_hydra_xml(SPECTRAL_XML, 32, 32, spectral=True)
+    sc.lights[0]["specId"] = 1000
+    with pytest.raises(HydraHipError, match="spectrum"):
+        HipIntegrator(sc)

@@ -203,7 +203,7 @@ class HipIntegrator:
         return out
 
     def set_random_gens(self, gens):
-        gens = np.ascontiguousarray(gens, np.uint32)
+        gens = np.ascontiguousarray(gens, np.uint32).reshape(-1, 2)      # one uint2 per thread
         self._chk(self.L.hpt_set_random_gens(self.h, gens.ctypes.data, gens.shape[0]))
 
     def Update_m_materials(self, first, mats):

@@ -103,7 +103,7 @@ class OracleIntegrator:
         return out
 
     def set_random_gens(self, gens):
-        gens = np.ascontiguousarray(gens, np.uint32)
+        gens = np.ascontiguousarray(gens, np.uint32).reshape(-1, 2)      # one uint2 per thread
         self.L.orc_set_random_gens(self.h, gens.ctypes.data, gens.shape[0])
 
     def path_trace_block(self, out_color, pass_num, tid_begin=0, tid_count=None, channels=4, naive=False):

@@ -931,7 +931,8 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
         if (list >= 0 && d->allRemapLists && (uint)list + 1 + d->allRemapListsSize < d->allRemapListsLen) {
           rOff = d->allRemapLists[d->allRemapListsSize + list]; rSize = (d->allRemapLists[d->allRemapListsSize + list + 1] - rOff) / 2;
         }
-        const uint t0 = d->matVertOffset[2 * g], t1 = std::min(t0 + d->geomTriCount[g], d->numTris);
+        const uint t0 = d->matVertOffset[2 * g];
+        const uint t1 = std::min(d->geomTriCount ? t0 + d->geomTriCount[g] : (g + 1 < d->numGeoms ? d->matVertOffset[2 * (g + 1)] : d->numTris), d->numTris);
         for (uint t = t0; t < t1; t++) {
           uint id = d->matIdByPrimId[t];
           for (int k2 = 0; k2 < rSize; k2++) if ((uint)d->allRemapLists[rOff + 2 * k2] == id) { id = (uint)d->allRemapLists[rOff + 2 * k2 + 1]; break; }

@@ -122,7 +122,7 @@ HPT_DEV V3 spectralCamResponseToRGB(const DevScene& S, V4 spec, V4 waves)
   rZ = S.camResponseSpectrumId[2] >= 0 ? sampleUniformSpectrum(S.specValues, S.specOffsetSz[2 * S.camResponseSpectrumId[2]], waves) : rY;
   V3 xyz = v3(0, 0, 0);
   for (int i = 0; i < 4; i++) { xyz.x += comp(spec, i) * comp(rX, i); xyz.y += comp(spec, i) * comp(rY, i); xyz.z += comp(spec, i) * comp(rZ, i); }
-  if (S.camResponseType == 1u)                                              // CAM_RESPONCE_XYZ
+  if (S.camResponseType == 0u)                                              // CAM_RESPONCE_XYZ = 0, CAM_RESPONCE_RGB = 1 (integrator_pt.h:531-532)
     return v3(+3.240479f * xyz.x - 1.537150f * xyz.y - 0.498535f * xyz.z, -0.969256f * xyz.x + 1.875991f * xyz.y + 0.041556f * xyz.z, +0.055648f * xyz.x - 0.204043f * xyz.y + 1.057311f * xyz.z);
   return xyz;
 }

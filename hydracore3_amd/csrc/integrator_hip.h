@@ -134,6 +134,12 @@ public:
     d.textures = td.data(); d.numTextures = uint32_t(td.size());
     d.arrays1f = m_arrays1f.empty() ? nullptr : m_arrays1f.data(); d.numArrays1f = uint32_t(m_arrays1f.size());   // pdf table of a sampled environment map, plastic tables
     d.normMatrices2Offs = m_normMatrices2Offs;                              // the moving instances themselves went in through AddInstanceMotion
+    // spectral rendering: the tables LoadScene builds (integrator_pt_scene.cpp:358-419, 962-969), as the host holds them
+    d.specValues = m_spec_values.empty() ? nullptr : m_spec_values.data(); d.numSpecValues = uint32_t(m_spec_values.size());
+    d.specOffsetSz = m_spec_offset_sz.empty() ? nullptr : m_spec_offset_sz.data(); d.numSpectra = uint32_t(m_spec_offset_sz.size() / 2);
+    d.cieXYZ = m_cie_xyz.empty() ? nullptr : m_cie_xyz.data(); d.numCieXYZ = uint32_t(m_cie_xyz.size() / 4);
+    for (int k = 0; k < 3; k++) d.camResponseSpectrumId[k] = m_camResponseSpectrumId[k];
+    d.camResponseType = uint32_t(m_camResponseType);
     report(hpt_upload_scene(m_ctx, &d), "CommitDeviceData");
     if (m_randomGensInit != m_maxThreadId) { hpt_init_random_gens(m_ctx, m_maxThreadId); m_randomGensInit = m_maxThreadId; }   // InitRandomGens
   }
@@ -189,6 +195,11 @@ public:
   std::vector<float4x4>    m_normMatrices;
   uint32_t                 m_normMatrices2Offs = 0;   // integrator_pt.h:498: where the end-of-motion normal matrices start (0: no motion blur)
   std::vector<float>       m_arrays1f;                // integrator_pt.h:485
+  std::vector<float>       m_spec_values;             // integrator_pt.h:580: every spectrum at 1 nm from LAMBDA_MIN
+  std::vector<uint32_t>    m_spec_offset_sz;          // integrator_pt.h:581: uint2 {offset, size} per spectrum
+  std::vector<float>       m_cie_xyz;                 // integrator_pt.h:585: float4 {x, y, z, 0} per nm, 471 entries
+  int                      m_camResponseSpectrumId[3] = {-1, -1, -1};   // integrator_pt.h:533
+  int                      m_camResponseType = 0;     // integrator_pt.h:534: 0 = CAM_RESPONCE_XYZ, 1 = CAM_RESPONCE_RGB
   std::vector<uint32_t>    m_instGeomId;
   std::vector<TextureData> m_textures;
   BVH2SceneHIP*            m_pAccelStruct = nullptr;

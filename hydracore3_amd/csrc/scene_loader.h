@@ -192,6 +192,10 @@ struct LoadedScene
   float envSamRow0[4] = {1, 0, 0, 0}, envSamRow1[4] = {0, 1, 0, 0};
   std::vector<float> arrays1f;
   std::vector<float> lensLines; float physSize[2] = {0, 0};   // lens simulation: m_lines as {curvatureRadius, thickness, eta, apertureRadius}, m_physSize
+  // spectral rendering (LoadSceneSpectrumData, integrator_pt_scene.cpp:358-419; the camera's <sensor><response>, :688-711)
+  uint32_t spectralMode = 0;
+  std::vector<float> specValues; std::vector<uint32_t> specOffsetSz; std::vector<float> cieXYZ;
+  int32_t camResponseSpectrumId[3] = {-1, -1, -1}; uint32_t camResponseType = 0; float camRespoceRGB[4] = {1, 1, 1, 1};
   std::vector<hpt_texture_desc> texDescs;                 // filled by desc(): points into `textures`
 
   hpt_scene_desc desc()
@@ -215,6 +219,14 @@ struct LoadedScene
     d.textures = texDescs.data(); d.numTextures = (uint32_t)texDescs.size();
     d.arrays1f = arrays1f.empty() ? nullptr : arrays1f.data(); d.numArrays1f = (uint32_t)arrays1f.size();
     if (normMatrices2Offs) { d.instMatricesMotion = instMatricesMotion.data(); d.instHasMotion = instHasMotion.data(); d.normMatrices2Offs = normMatrices2Offs; }
+    for (int k = 0; k < 3; k++) d.camResponseSpectrumId[k] = -1;
+    if (!specOffsetSz.empty()) {
+      d.specValues = specValues.data(); d.numSpecValues = (uint32_t)specValues.size();
+      d.specOffsetSz = specOffsetSz.data(); d.numSpectra = (uint32_t)(specOffsetSz.size() / 2);
+      d.cieXYZ = cieXYZ.data(); d.numCieXYZ = (uint32_t)(cieXYZ.size() / 4);
+      for (int k = 0; k < 3; k++) d.camResponseSpectrumId[k] = camResponseSpectrumId[k];
+      d.camResponseType = camResponseType;
+    }
     return d;
   }
 
@@ -245,9 +257,9 @@ struct LoadedScene
     wv.m[2][3] = (f[0] * camPos[0] + f[1] * camPos[1] + f[2] * camPos[2]);
     m4ToColMajor(m4Inverse(proj), p.projInv); m4ToColMajor(m4Inverse(wv), p.worldViewInv);
     p.winStartX = p.winStartY = 0; p.winWidth = p.fbWidth = width; p.winHeight = p.fbHeight = height;
-    p.traceDepth = traceDepth; p.integratorType = integratorType; p.renderLayer = renderLayer; p.tileSize = tileSize(); p.spectralMode = 0;
+    p.traceDepth = traceDepth; p.integratorType = integratorType; p.renderLayer = renderLayer; p.tileSize = tileSize(); p.spectralMode = spectralMode;
     p.exposureMult = 1.0f; p.camLensRadius = 0.0f; p.camTargetDist = (float)fl;
-    for (int k = 0; k < 4; k++) { p.camRespoceRGB[k] = 1.0f; p.envColor[k] = envColor[k]; p.envSamRow0[k] = envSamRow0[k]; p.envSamRow1[k] = envSamRow1[k]; }
+    for (int k = 0; k < 4; k++) { p.camRespoceRGB[k] = camRespoceRGB[k]; p.envColor[k] = envColor[k]; p.envSamRow0[k] = envSamRow0[k]; p.envSamRow1[k] = envSamRow1[k]; }
     p.envTexId = envTexId; p.envLightId = envLightId; p.envCamBackId = envCamBackId; p.envEnableSam = envEnableSam;
     return p;
   }
@@ -394,6 +406,57 @@ inline bool decodeBmp(const std::vector<uint8_t>& f, uint32_t& w, uint32_t& h, s
 }
 inline bool endsWithNoCase(const std::string& s, const char* ext) { const size_t n = std::strlen(ext); if (s.size() < n) return false; for (size_t i = 0; i < n; i++) if (std::tolower((unsigned char)s[s.size() - n + i]) != ext[i]) return false; return true; }
 
+// ---- spectra (spectrum.cpp) ----
+static const float kLambdaMin = 360.0f, kLambdaMax = 830.0f;            // include/cglobals.h:22-23
+// Spectrum::ResampleUniform over Spectrum::Sample (spectrum.cpp:7-48): 471 values at LAMBDA_MIN + c nm, zero outside the tabulated range,
+// linear in between - in float, as the reference evaluates it
+inline std::vector<float> resampleUniform(const std::vector<float>& w, const std::vector<float>& v)
+{
+  std::vector<float> out((size_t)(kLambdaMax - kLambdaMin + 1.0f), 0.0f);
+  if (w.empty()) return out;
+  for (size_t c = 0; c < out.size(); c++) {
+    const float lam = kLambdaMin + float(c);
+    if (lam < w.front() || lam > w.back()) continue;
+    int last = (int)w.size() - 2, first = 1;                            // BinarySearch (spectrum.h:26-40)
+    while (last > 0) {
+      const int half = last >> 1, middle = first + half;
+      if (w[(size_t)middle] <= lam) { first = middle + 1; last = last - (half + 1); } else last = half;
+    }
+    const int o = std::min(std::max(first - 1, 0), (int)w.size() - 2);
+    const float t = (lam - w[(size_t)o]) / (w[(size_t)o + 1] - w[(size_t)o]);
+    out[c] = v[(size_t)o] + t * (v[(size_t)o + 1] - v[(size_t)o]);
+  }
+  return out;
+}
+// LoadSPDFromFile (spectrum.cpp:50-71): "lambda value" per line, '#' comments
+inline bool loadSpd(const std::string& path, std::vector<float>& w, std::vector<float>& v)
+{
+  std::vector<uint8_t> raw; if (!readFile(path, raw)) return false;
+  std::istringstream is(std::string(raw.begin(), raw.end())); std::string line;
+  while (std::getline(is, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    if (line.empty() || line[0] == '#') continue;
+    const size_t sp = line.find(' ');
+    if (sp == std::string::npos) continue;
+    w.push_back((float)std::atof(line.substr(0, sp).c_str())); v.push_back((float)std::atof(line.substr(sp + 1).c_str()));
+  }
+  return true;
+}
+// m_cie_xyz for the fixture tools: the reference carries the tabulated CIE 1931 observer in its source; this image has no other copy, so the
+// loaders use the multi-lobe analytic fit of Wyman, Sloan and Shirley (JCGT 2013). A HydraCore3 host passes its own table instead.
+inline std::vector<float> cieXyzFit()
+{
+  std::vector<float> t(471 * 4, 0.0f);
+  auto g = [](double lam, double mu, double s1, double s2) { const double q = (lam - mu) / (lam < mu ? s1 : s2); return std::exp(-0.5 * q * q); };
+  for (int c = 0; c < 471; c++) {
+    const double lam = 360.0 + c;
+    t[4 * c + 0] = (float)(1.056 * g(lam, 599.8, 37.9, 31.0) + 0.362 * g(lam, 442.0, 16.0, 26.7) - 0.065 * g(lam, 501.1, 20.4, 26.2));
+    t[4 * c + 1] = (float)(0.821 * g(lam, 568.8, 46.9, 40.5) + 0.286 * g(lam, 530.9, 16.3, 31.1));
+    t[4 * c + 2] = (float)(1.217 * g(lam, 437.0, 11.8, 36.0) + 0.681 * g(lam, 459.0, 26.0, 13.8));
+  }
+  return t;
+}
+
 inline bool iesSphericalTexture(const std::string& path, LoadedTexture& tex, std::string& err)
 {
   std::vector<uint8_t> raw; if (!readFile(path, raw)) { err = "cannot read " + path; return false; }
@@ -426,7 +489,7 @@ inline bool iesSphericalTexture(const std::string& path, LoadedTexture& tex, std
 
 } // namespace detail
 
-inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, LoadedScene& sc, std::string& err)
+inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, LoadedScene& sc, std::string& err, bool spectral = false)
 {
   using namespace detail;
   std::vector<uint8_t> raw; if (!readFile(xmlPath, raw)) { err = "cannot read " + xmlPath; return false; }
@@ -541,6 +604,40 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
     return true;
   };
 
+  // LoadSceneSpectrumData (integrator_pt_scene.cpp:358-419): every <spectrum> resampled at 1 nm, one {offset, size} per node in node order
+  sc.spectralMode = spectral ? 1u : 0u;
+  if (const XmlNode* lib = root.child("spectra_lib")) for (const XmlNode* sn : lib->all("spectrum")) {
+    if (sn->has("lambda_ref_ids")) { sc.specOffsetSz.push_back(0xFFFFFFFFu); sc.specOffsetSz.push_back(0u); continue; }   // given by textures: outside the path
+    std::vector<float> w, v;
+    if (sn->has("value")) { const auto nums = parseFloats(sn->get("value")); for (size_t k = 0; k + 1 < nums.size(); k += 2) { w.push_back((float)nums[k]); v.push_back((float)nums[k + 1]); } }
+    else if (!loadSpd(folder + "/" + sn->get("loc"), w, v)) { err = "cannot read spectrum " + sn->get("loc"); return false; }
+    const std::vector<float> u = resampleUniform(w, v);
+    sc.specOffsetSz.push_back((uint32_t)sc.specValues.size()); sc.specOffsetSz.push_back((uint32_t)u.size());
+    sc.specValues.insert(sc.specValues.end(), u.begin(), u.end());
+  }
+  if (sc.specOffsetSz.empty()) {                                              // "if no spectra are loaded add uniform 1.0 spectrum" (:406-418)
+    const std::vector<float> u = resampleUniform({200.0f, 400.0f, 600.0f, 800.0f}, {1.0f, 1.0f, 1.0f, 1.0f});
+    sc.specOffsetSz.push_back(0u); sc.specOffsetSz.push_back((uint32_t)u.size()); sc.specValues = u;
+  }
+  sc.cieXYZ = cieXyzFit();
+  auto spectrumId = [](const XmlNode* n) -> uint32_t {                        // GetSpectrumIdFromNode (integrator_pt_scene_mat.cpp:109-119)
+    const XmlNode* sn = n ? n->child("spectrum") : nullptr;
+    return sn ? (uint32_t)std::atoi(sn->get("id").c_str()) : 0xFFFFFFFFu;
+  };
+  if (const XmlNode* sensor = cam->child("sensor")) if (const XmlNode* resp = sensor->child("response")) {   // integrator_pt_scene.cpp:688-711
+    const std::string rt = resp->get("type");
+    sc.camResponseType = (rt == "xyz" || rt == "XYZ") ? 0u : 1u;              // CAM_RESPONCE_XYZ = 0, CAM_RESPONCE_RGB = 1
+    int id = 0;
+    for (const XmlNode* spn : resp->all("spectrum")) { sc.camResponseSpectrumId[id++] = std::atoi(spn->get("id").c_str()); if (id >= 3) break; }
+    float rgb[4] = {0, 0, 0, 0};
+    if (const XmlNode* cn = resp->child("color")) if (cn->has("val")) {
+      const auto cv = parseFloats(cn->get("val"));
+      if (cv.size() == 1) rgb[0] = rgb[1] = rgb[2] = (float)cv[0]; else if (cv.size() >= 3) for (int k = 0; k < 3; k++) rgb[k] = (float)cv[k];
+    }
+    for (int k = 0; k < 3; k++) sc.camRespoceRGB[k] = rgb[k];
+    sc.camRespoceRGB[3] = 1.0f;
+  }
+
   // lights first: emissive materials copy intensity from them (integrator_pt_scene.cpp:973-996, 575-599)
   std::map<int, const XmlNode*> lightNodes;
   if (const XmlNode* lib = root.child("lights_lib")) for (const XmlNode* l : lib->all("light")) lightNodes[std::atoi(l->get("id").c_str())] = l;
@@ -553,8 +650,10 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
     const std::string ltype = ln->get("type"), shape = ln->get("shape"), dist = ln->get("distribution");
     const XmlNode* inten = ln->child("intensity");
     if (!inten || !inten->child("color")) { err = "xml: light without intensity"; return false; }
-    const auto color = parseFloats(inten->child("color")->get("val"));
+    auto color = parseFloats(inten->child("color")->get("val"));
     const double power = inten->child("multiplier") ? std::atof(inten->child("multiplier")->get("val").c_str()) : 1.0;
+    const bool splat = color.size() == 1;                                     // GetColorFromNode: one value fills all four components
+    if (splat) color.assign(4, color[0]);
     if (color.size() < 3) { err = "xml: light colour"; return false; }
     if (ltype == "sky") {                                                     // LIGHT_GEOM_ENV (integrator_pt_scene_lgt.cpp:36-59, integrator_pt_scene.cpp:441-486)
       for (int k = 0; k < 3; k++) sc.envColor[k] = (float)color[k];
@@ -604,6 +703,8 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
     LightSource lt = blankLight();
     lightFrame(m, lt);
     for (int k = 0; k < 3; k++) lt.intensity[k] = (float)color[k];
+    if (color.size() >= 4) lt.intensity[3] = (float)color[3];
+    lt.specId = spectrumId(inten->child("color"));                            // LoadLightSourceFromNode (integrator_pt_scene_lgt.cpp:22-25)
     lt.mult = (float)power;
     const XmlNode* size = ln->child("size");
     if (ltype == "directional") lt.geomType = 4;
@@ -746,13 +847,14 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
         if (mat.texid[0] != 0) au = av = 1.0f;
       } else { au = attrFloat(mn->child("alpha_u")); av = attrFloat(mn->child("alpha_v")); }
       mat.data[0] = au; mat.data[1] = av; mat.data[2] = attrFloat(mn->child("eta")); mat.data[3] = attrFloat(mn->child("k"));
-      if (const XmlNode* rc = mn->child("reflectance")) color4(rc, mat.colors[0]);
+      mat.spdid[0] = spectrumId(mn->child("eta")); mat.spdid[1] = spectrumId(mn->child("k"));                 // (:493-497)
+      if (const XmlNode* rc = mn->child("reflectance")) if (!spectral) color4(rc, mat.colors[0]);             // (read in RGB mode only, :507-510)
     } else if (type == "diffuse") {                                           // LoadDiffuseMaterial (:516-571), RGB mode
       for (int k = 0; k < 4; k++) mat.colors[0][k] = 1.0f;
       mat.mtype = 4; mat.lightId = 0xFFFFFFFFu;
       const XmlNode* bsdf = mn->child("bsdf");
       if (bsdf && bsdf->get("type") == "oren-nayar") { mat.cflags = 16u; if (const XmlNode* r = mn->child("roughness")) mat.data[0] = val1f(r); }
-      if (const XmlNode* rc = mn->child("reflectance")) { color4(rc, mat.colors[0]); if (!loadTextureFromNode(rc, mat.row0[0], mat.row1[0], mat.texid[0])) return false; }
+      if (const XmlNode* rc = mn->child("reflectance")) { color4(rc, mat.colors[0]); if (!loadTextureFromNode(rc, mat.row0[0], mat.row1[0], mat.texid[0])) return false; mat.spdid[0] = spectrumId(rc); }
     } else if (type == "dielectric") {                                        // LoadDielectricMaterial (:574-616), RGB mode
       for (int k = 0; k < 4; k++) { mat.colors[0][k] = 1.0f; mat.colors[1][k] = 1.0f; }
       mat.mtype = 7; mat.lightId = 0xFFFFFFFFu; mat.data[0] = 1.00028f; mat.data[1] = 1.5046f;
@@ -796,6 +898,7 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
       if (lid >= 0 && lid < (int)sc.lights.size()) {
         for (int k = 0; k < 4; k++) mat.colors[0][k] = sc.lights[(size_t)lid].intensity[k];
         mat.data[0] = sc.lights[(size_t)lid].mult;
+        mat.spdid[0] = sc.lights[(size_t)lid].specId;
         sc.lights[(size_t)lid].matId = (uint32_t)sc.materials.size();
       }
       sc.materials.push_back(mat);
@@ -814,7 +917,7 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
       if (!loadTextureFromNode(cn, mat.row0[0], mat.row1[0], mat.texid[0])) return false;
       for (int k = 0; k < 4; k++) mat.colors[0][k] = color[k];
       mat.lightId = mn->has("light_id") ? (uint32_t)std::atoi(mn->get("light_id").c_str()) : 0xFFFFFFFFu;
-      mat.spdid[0] = 0xFFFFFFFFu;
+      mat.spdid[0] = spectrumId(cn);                                          // GetSpectrumIdFromNode(nodeEmissColor) (:319-320)
       mat.mtype = 0xEFFFFFFFu;
       const XmlNode* mult = cn ? cn->child("multiplier") : nullptr;
       mat.data[0] = mult ? val1f(mult) : 1.0f;

@@ -465,7 +465,8 @@ class SceneData:
         self.spec_offset_sz = []
         self.cie_xyz = None
         self.cam_response_spectrum_id = (-1, -1, -1)
-        self.cam_response_type = 0
+        self.cam_response_type = 0                            # CAM_RESPONCE_XYZ = 0, CAM_RESPONCE_RGB = 1 (integrator_pt.h:531-534)
+        self.cam_respoce_rgb = (1.0, 1.0, 1.0, 1.0)           # m_camRespoceRGB
         self.all_remap_lists = np.zeros((1,), np.int32)     # no lists: just the trailing offset 0
         self.all_remap_lists_size = 0
         self.materials, self.lights = [], []
@@ -657,7 +658,7 @@ class SceneData:
         p.exposureMult = self.exposure_mult
         p.camLensRadius = self.cam_lens_radius
         p.camTargetDist = float(np.linalg.norm(np.asarray(self.cam_look_at, float) - np.asarray(self.cam_pos, float)))
-        p.camRespoceRGB[:] = [1.0, 1.0, 1.0, 1.0]
+        p.camRespoceRGB[:] = [float(v) for v in self.cam_respoce_rgb]
         p.envColor[:] = list(self.env_color)
         p.envTexId, p.envLightId, p.envCamBackId, p.envEnableSam = self.env_tex_id, self.env_light_id, self.env_cam_back_id, self.env_enable_sam
         p.envSamRow0[:] = list(self.env_sam_row0)
@@ -1072,6 +1073,15 @@ def load_hydra_xml(xml_path: str, width=None, height=None, spectral=False) -> Sc
     def length(v):          # LiteMath length in float
         v = np.asarray(v, np.float32)
         return np.sqrt(np.float32(np.dot(v, v)), dtype=np.float32)
+
+    # <sensor><response> of the camera (integrator_pt_scene.cpp:688-711): response type, up to three response spectra, m_camRespoceRGB
+    resp = cam.find("sensor/response")
+    if resp is not None:
+        sc.cam_response_type = 0 if resp.get("type", "") in ("xyz", "XYZ") else 1
+        ids = [int(sn.get("id")) for sn in resp.findall("spectrum")][:3]
+        sc.cam_response_spectrum_id = tuple(ids + [-1] * (3 - len(ids)))
+        rgb = color4(resp.find("color"))
+        sc.cam_respoce_rgb = (float(rgb[0]), float(rgb[1]), float(rgb[2]), 1.0)
 
     # lights first: materials with light_id copy intensity from them (integrator_pt_scene.cpp:973-996, 575-599)
     scene_node = root.find("scenes/scene")

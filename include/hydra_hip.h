@@ -81,7 +81,7 @@ typedef struct hpt_scene_desc {
   const float*    cieXYZ;
   uint32_t        numCieXYZ;
   int32_t         camResponseSpectrumId[3];   /* -1: none (then SpectrumToXYZ + XYZToRGB) */
-  uint32_t        camResponseType;            /* 0 RGB, 1 XYZ (CAM_RESPONCE_XYZ) */
+  uint32_t        camResponseType;            /* m_camResponseType: 0 = CAM_RESPONCE_XYZ, 1 = CAM_RESPONCE_RGB (integrator_pt.h:531-534) */
   uint32_t        reserved2;
 } hpt_scene_desc;
 

@@ -241,7 +241,7 @@ struct Ctx
     f3 xyz = mk3(0, 0, 0);
     const float* sp = &specSamples.x; const float* rx = &responceX.x; const float* ry = &responceY.x; const float* rz = &responceZ.x;
     for (int i = 0; i < 4; ++i) { xyz.x += sp[i] * rx[i]; xyz.y += sp[i] * ry[i]; xyz.z += sp[i] * rz[i]; }
-    return sc.camResponseType == 1u ? XYZToRGB(xyz) : xyz;             // CAM_RESPONCE_XYZ
+    return sc.camResponseType == 0u ? XYZToRGB(xyz) : xyz;             // CAM_RESPONCE_XYZ = 0, CAM_RESPONCE_RGB = 1 (integrator_pt.h:531-532)
   }
 
   f4 LightIntensity(uint a_lightId, f3 a_rayPos, f3 a_rayDir, f4 a_wavelengths = f4{0, 0, 0, 0}) const   // :109-173

@@ -12,14 +12,14 @@
 
 using namespace hydra_hip;
 
-// adapter_demo <scene.xml> <width> <height> <spp> <out.bin>: a whole Hydra scene through the ADAPTER CLASSES only - geometry and (moving)
+// adapter_demo <scene.xml> <width> <height> <spp> <out.bin> [--spectral]: a whole Hydra scene through the ADAPTER CLASSES only - geometry and (moving)
 // instances through BVH2SceneHIP (AddGeom_Triangles3f / AddInstance / AddInstanceMotion / CommitScene), the scene vectors through the
 // Integrator-named members (m_materials ... m_arrays1f, m_normMatrices + m_normMatrices2Offs, the m_env* ids), then CommitDeviceData,
 // PackXYBlock, UpdateMembersPlainData, PathTraceBlock - the calls main.cpp makes. The test compares the frame with the ctypes front end.
-static int renderScene(const char* xml, int W, int H, int spp, const char* out)
+static int renderScene(const char* xml, int W, int H, int spp, const char* out, bool spectral)
 {
   LoadedScene sc; std::string err;
-  if (!LoadHydraXml(xml, W, H, sc, err)) { std::printf("adapter_demo: %s\n", err.c_str()); return 1; }
+  if (!LoadHydraXml(xml, W, H, sc, err, spectral)) { std::printf("adapter_demo: %s\n", err.c_str()); return 1; }
   IntegratorHIP integ(W * H, 0);
   if (!integ.valid()) { std::printf("adapter_demo: no GPU\n"); return 2; }
   BVH2SceneHIP* acc = integ.m_pAccelStruct;
@@ -41,6 +41,11 @@ static int renderScene(const char* xml, int W, int H, int spp, const char* out)
   integ.m_instGeomId = sc.instGeomId; integ.m_remapInst.assign(sc.remapInst.begin(), sc.remapInst.end());
   integ.m_allRemapLists.assign(sc.allRemapLists.begin(), sc.allRemapLists.end()); integ.m_allRemapListsSize = sc.allRemapListsSize;
   integ.m_materials = sc.materials; integ.m_lights = sc.lights; integ.m_arrays1f = sc.arrays1f;
+  // spectral rendering: m_spec_values / m_spec_offset_sz / m_cie_xyz and the camera response, then m_spectral_mode (main.cpp: --spectral)
+  integ.m_spec_values = sc.specValues; integ.m_spec_offset_sz = sc.specOffsetSz; integ.m_cie_xyz = sc.cieXYZ;
+  for (int k = 0; k < 3; k++) integ.m_camResponseSpectrumId[k] = sc.camResponseSpectrumId[k];
+  integ.m_camResponseType = int(sc.camResponseType); std::memcpy(integ.m_camRespoceRGB, sc.camRespoceRGB, 16);
+  integ.m_spectral_mode = int(sc.spectralMode);
   integ.m_textures.clear();
   for (const LoadedTexture& t : sc.textures) { TextureData d; d.width = t.width; d.height = t.height; d.format = t.format; d.flags = t.flags; d.addressU = t.addressU; d.addressV = t.addressV; d.filter = t.filter; d.texels = t.bytes; integ.m_textures.push_back(d); }
   const hpt_params p = sc.params();
@@ -75,7 +80,7 @@ static float4x4 identity() { float4x4 r{}; r.m[0] = r.m[5] = r.m[10] = r.m[15] =
 
 int main(int argc, char** argv)
 {
-  if (argc >= 6) return renderScene(argv[1], std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]), argv[5]);
+  if (argc >= 6) return renderScene(argv[1], std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]), argv[5], argc > 6 && std::string(argv[6]) == "--spectral");
   const int W = 64, H = 64, SPP = 4;
   IntegratorHIP integ(W * H, 0);
   if (!integ.valid()) { std::printf("adapter_demo: no GPU\n"); return 2; }

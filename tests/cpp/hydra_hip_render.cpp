@@ -1,7 +1,8 @@
-// Renders a Hydra XML scene through the C ABI without Python:  hydra_hip_render <scene.xml> <width> <height> <spp> <out.bin> [--tables | --ppm preview.ppm]
+// Renders a Hydra XML scene through the C ABI without Python:  hydra_hip_render <scene.xml> <width> <height> <spp> <out.bin> [--tables | --ppm preview.ppm] [--spectral]
 //   default   : scene_loader.h -> LoadedScene::upload -> hpt_path_trace_block; writes the raw float4 frame (un-normalised, as the callee
 //               accumulates it) to <out.bin> and prints the mean radiance per sample
 //   --tables  : no GPU needed - dumps the loaded tables as [name '\0'][u64 byte count][bytes] records for the loader test
+//   --spectral: m_spectral_mode = 1 (four wavelengths per path; the scene's spectra, the CIE observer fit of scene_loader.h)
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -17,8 +18,10 @@ int main(int argc, char** argv)
   if (argc < 6) { std::fprintf(stderr, "usage: %s <scene.xml> <width> <height> <spp> <out.bin> [--tables | --ppm preview.ppm]\n", argv[0]); return 2; }
   const int W = std::atoi(argv[2]), H = std::atoi(argv[3]), spp = std::atoi(argv[4]);
   const bool tables = argc > 6 && std::string(argv[6]) == "--tables";
+  bool spectral = false;
+  for (int k = 6; k < argc; k++) spectral = spectral || std::string(argv[k]) == "--spectral";
   hydra_hip::LoadedScene sc; std::string err;
-  if (!hydra_hip::LoadHydraXml(argv[1], W, H, sc, err)) { std::fprintf(stderr, "[hydra_hip_render]: %s\n", err.c_str()); return 1; }
+  if (!hydra_hip::LoadHydraXml(argv[1], W, H, sc, err, spectral)) { std::fprintf(stderr, "[hydra_hip_render]: %s\n", err.c_str()); return 1; }
   FILE* f = std::fopen(argv[5], "wb");
   if (!f) { std::fprintf(stderr, "cannot write %s\n", argv[5]); return 1; }
   if (tables) {
@@ -33,6 +36,8 @@ int main(int argc, char** argv)
     blob(f, "lensLines", sc.lensLines); blob(f, "physSize", std::vector<float>(sc.physSize, sc.physSize + 2));
     blob(f, "instMatricesMotion", sc.instMatricesMotion); blob(f, "instHasMotion", sc.instHasMotion);
     blob(f, "normMatrices2Offs", std::vector<uint32_t>(1, sc.normMatrices2Offs));
+    blob(f, "specValues", sc.specValues); blob(f, "specOffsetSz", sc.specOffsetSz); blob(f, "cieXYZ", sc.cieXYZ);
+    blob(f, "camResponse", std::vector<int32_t>{ sc.camResponseSpectrumId[0], sc.camResponseSpectrumId[1], sc.camResponseSpectrumId[2], (int32_t)sc.camResponseType });
     for (size_t i = 0; i < sc.textures.size(); i++) {
       const hydra_hip::LoadedTexture& t = sc.textures[i];
       blob(f, "texHeader", std::vector<uint32_t>{ t.width, t.height, t.format, t.flags, t.addressU, t.addressV, t.filter });

@@ -383,7 +383,7 @@ def _read_blobs(path):
     return out
 
 
-@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures"])
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures", "test_spectral", "test_spectral+spectral"])
 def test_cpp_scene_loader_produces_the_same_tables(scene_name, tmp_path):
     """hydracore3_amd/csrc/scene_loader.h (Hydra XML + VSGF + image4ub + IES in C++) == the Python fixture loader:
     every table byte for byte, matrices and light frames to float rounding (both invert in double)."""
@@ -394,12 +394,19 @@ def test_cpp_scene_loader_produces_the_same_tables(scene_name, tmp_path):
     g.build()
     tool = os.path.join(ROOT, "hydracore3_amd", "hydra_hip_render")
     out = str(tmp_path / "tables.bin")
-    r = subprocess.run([tool, scene_path(scene_name), "96", "64", "1", out, "--tables"], capture_output=True, text=True)
+    spectral = scene_name.endswith("+spectral")                          # m_spectral_mode = 1: the same tables, the reflectance colour of conductors unread
+    scene_name = scene_name.split("+")[0]
+    r = subprocess.run([tool, scene_path(scene_name), "96", "64", "1", out, "--tables"] + (["--spectral"] if spectral else []), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     blobs = _read_blobs(out)
     named = {k: v for k, v in blobs if not k.startswith("tex")}
-    sc = S.load_hydra_xml(scene_path(scene_name), 96, 64)
+    sc = S.load_hydra_xml(scene_path(scene_name), 96, 64, spectral=spectral)
     d = sc.desc()
+    # spectra: resampled in float on both sides - bit for bit; the observer fit goes through exp() of two libms - to rounding
+    assert named["specValues"] == np.ascontiguousarray(sc.spec_values, np.float32).tobytes()
+    assert named["specOffsetSz"] == np.asarray(sc.spec_offset_sz, np.uint32).tobytes()
+    assert np.allclose(np.frombuffer(named["cieXYZ"], np.float32), S.cie_xyz_fit().reshape(-1), rtol=1e-6, atol=1e-9)
+    assert list(np.frombuffer(named["camResponse"], np.int32)) == [*sc.cam_response_spectrum_id, sc.cam_response_type]
 
     def arr(ptr, dtype, count):
         return np.frombuffer((C.c_char * (np.dtype(dtype).itemsize * count)).from_address(ptr), dtype=dtype, count=count).copy() if count else np.zeros(0, dtype)

@@ -355,7 +355,7 @@ def test_path_trace_from_input_rays_block_matches_oracle(cornell):
         assert np.array_equal(gpu.random_gens(), cpu.random_gens())
 
 
-@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures"])
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures", "test_spectral", "test_spectral+spectral"])
 def test_cpp_scene_ingestion_renders_like_the_python_path(scene_name, tmp_path):
     """hydra_hip_render: scene_loader.h (C++) -> C ABI -> frame, no Python in the loop; the frame equals the one rendered from the
     Python loader's tables (same tables up to float rounding of inverted matrices: the image bar applies)."""
@@ -365,11 +365,13 @@ def test_cpp_scene_ingestion_renders_like_the_python_path(scene_name, tmp_path):
     from hydracore3_amd.api import HipIntegrator
     tool = os.path.join(ROOT, "hydracore3_amd", "hydra_hip_render")
     out = str(tmp_path / "frame.bin")
-    r = subprocess.run([tool, scene_path(scene_name), "96", "64", "6", out], capture_output=True, text=True)
+    spectral = scene_name.endswith("+spectral")
+    scene_name = scene_name.split("+")[0]
+    r = subprocess.run([tool, scene_path(scene_name), "96", "64", "6", out] + (["--spectral"] if spectral else []), capture_output=True, text=True)
     print(r.stdout.strip())
     assert r.returncode == 0, r.stdout + r.stderr
     frame = np.fromfile(out, np.float32).reshape(64, 96, 4)
-    ref = HipIntegrator(load_hydra_xml(scene_path(scene_name), 96, 64)).render(6)
+    ref = HipIntegrator(load_hydra_xml(scene_path(scene_name), 96, 64, spectral=spectral)).render(6)
     assert per_pixel_l2(frame, ref, 6) < 1e-3
     assert float(frame[..., :3].mean()) > 0.0
 
@@ -1220,22 +1222,25 @@ def test_wavefront_round_cap_reports_an_incomplete_frame():
 
 
 # ---- the C++ adapter with everything the ctypes path can do -----------------------------------------------------------------------------------
-@pytest.mark.parametrize("xml", [scene_path("env_map"), MOTION_XML, scene_path("typed_materials")])
+@pytest.mark.parametrize("xml", [scene_path("env_map"), MOTION_XML, scene_path("typed_materials"), scene_path("test_spectral") + "+spectral"])
 def test_cpp_adapter_renders_whole_scenes_like_the_ctypes_path(xml, tmp_path):
     """tests/cpp/adapter_demo.cpp in scene mode: IntegratorHIP / BVH2SceneHIP only (AddGeom / AddInstance / AddInstanceMotion, the
     Integrator-named vectors incl. m_arrays1f and m_normMatrices2Offs, CommitDeviceData, UpdateMembersPlainData, PackXYBlock, PathTraceBlock)
-    on the sampled environment map (pdf table in m_arrays1f), the reference's moving-instance fixture and the plastic / blend scene; the frame
-    equals the one the ctypes front end renders from the same file."""
+    on the sampled environment map (pdf table in m_arrays1f), the reference's moving-instance fixture, the plastic / blend scene and the
+    spectral fixture (m_spec_values, m_spec_offset_sz, m_cie_xyz, m_spectral_mode = 1); the frame equals the one the ctypes front end renders
+    from the same file."""
     import subprocess
     from conftest import ROOT
     from hydracore3_amd.api import HipIntegrator
     tool = os.path.join(ROOT, "hydracore3_amd", "adapter_demo")
     out = str(tmp_path / "frame.bin")
-    r = subprocess.run([tool, xml, "96", "64", "6", out], capture_output=True, text=True)
+    spectral = xml.endswith("+spectral")
+    xml = xml.split("+")[0]
+    r = subprocess.run([tool, xml, "96", "64", "6", out] + (["--spectral"] if spectral else []), capture_output=True, text=True)
     print(r.stdout.strip())
     assert r.returncode == 0 and "IntegratorHIP::" not in r.stdout, r.stdout + r.stderr
     frame = np.fromfile(out, np.float32).reshape(64, 96, 4)
-    ref = HipIntegrator(load_hydra_xml(xml, 96, 64)).render(6)
+    ref = HipIntegrator(load_hydra_xml(xml, 96, 64, spectral=spectral)).render(6)
     assert per_pixel_l2(frame, ref, 6) < 1e-3
     assert float(frame[..., :3].mean()) > 0.0
 

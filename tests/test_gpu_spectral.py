@@ -121,7 +121,7 @@ def test_smooth_conductor_and_constant_parameters():
 
 def test_camera_response_spectra():
     """SpectralCamRespoceToRGB with m_camResponseSpectrumId set (integrator_spectrum.cpp:76-121): the response spectra replace the CIE
-    observer; both response types (XYZ -> RGB matrix, or taken as RGB)."""
+    observer; both response types (0 = CAM_RESPONCE_XYZ: through XYZToRGB, 1 = CAM_RESPONCE_RGB: taken as it is)."""
     for ids, rtype in (((1, 2, 3), 0), ((1, -1, -1), 1)):
         sc = load_hydra_xml(SPECTRAL_XML, 48, 48, spectral=True)
         sc.cam_response_spectrum_id = ids

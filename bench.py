@@ -41,8 +41,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 SIMDS = 1024               # 256 CUs x 4 SIMDs
-F_CLK_GHZ = 2.4            # max shader clock; a wave64 VALU instruction occupies its SIMD for 4 cycles
-VALU_PEAK_GINST = SIMDS * F_CLK_GHZ / 4.0     # wave-instructions per ns the chip can issue = 614.4 G/s
+F_CLK_GHZ = 2.4            # max shader clock
+# A wave64 VALU instruction issues over 2 cycles (32 lanes per cycle; MI355X_MICROARCH.md, execution model): 1228.8 G wave-instructions/s.
+# What straight-line independent f32 code sustains in practice is about 3.1 cycles per instruction (profiles/probes/halfwave_probe.hip),
+# so a frac of ~0.65 is where a VALU-only kernel tops out; the spec figure is the peak quoted.
+VALU_PEAK_GINST = SIMDS * F_CLK_GHZ / 2.0
 
 
 # ---- host CPU ---------------------------------------------------------------------------------------------------------------------------
@@ -166,7 +169,7 @@ def make_roofline(workload, integ, torch, dev, stream, N, W, H, spp, t_count, ke
     pmc = load_profile(f"pmc_{workload}.json")
     if sched_used == 1 and pmc and pmc.get("valu_insts_per_path"):
         # VALU-issue roofline: wave-instructions the kernel issues (profiled count per path, a property of binary + scene) over the
-        # LIVE kernel time, against 1024 SIMDs x f_clk / 4 cycles per wave64 instruction
+        # LIVE kernel time, against 1024 SIMDs x f_clk / 2 cycles per wave64 instruction
         ginst = pmc["valu_insts_per_path"] * paths / (k_ms * 1e-3) / 1e9
         return dict({"bound": "valu", "achieved": round(ginst, 2), "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwaveinst/s",
                      "frac": round(ginst / VALU_PEAK_GINST, 4), "traffic": traffic, "traffic_source": traffic_src,

@@ -1322,9 +1322,24 @@ HPT_DEV void triangleTestInOrder(const float4 a, const float4 b, const float4 c,
   const V3 qvec = cross(tvec, e1);
   const float vv = dot(d, qvec) * inv;
   const float tt = dot(e2, qvec) * inv;
-  const bool closer = found ? (tt < bestT) : (tt <= bestT);
-  const bool ok = (det != 0.0f) && (uu >= 0.0f) && (vv >= 0.0f) && (uu + vv <= 1.0f) && (tt >= tnear) && closer;
+  // (non-short-circuit on purpose: the conditions become lane masks combined on the scalar unit instead of selects of 0 / 1 in VGPRs)
+  const bool closer = (tt < bestT) | (!found & (tt == bestT));              // = found ? tt < bestT : tt <= bestT
+  const bool ok = (det != 0.0f) & (uu >= 0.0f) & (vv >= 0.0f) & (uu + vv <= 1.0f) & (tt >= tnear) & closer;
   if (ok) { bestT = tt; bestPrim = __float_as_uint(a.w); bestInst = inst; bestU = uu; bestV = vv; found = true; }
+}
+// the same test for occlusion queries: any triangle with t in [tnear, tfar] ends the search, so nothing but the flag is kept
+HPT_DEV bool triangleOccludes(const float4 a, const float4 b, const float4 c, const V3 o, const V3 d, const float tnear, const float tfar)
+{
+  const V3 e1 = v3(b.x, b.y, b.z), e2 = v3(c.x, c.y, c.z);
+  const V3 pvec = cross(d, e2);
+  const float det = dot(e1, pvec);
+  const float inv = 1.0f / det;
+  const V3 tvec = o - v3(a.x, a.y, a.z);
+  const float uu = dot(tvec, pvec) * inv;
+  const V3 qvec = cross(tvec, e1);
+  const float vv = dot(d, qvec) * inv;
+  const float tt = dot(e2, qvec) * inv;
+  return (det != 0.0f) & (uu >= 0.0f) & (vv >= 0.0f) & (uu + vv <= 1.0f) & (tt >= tnear) & (tt <= tfar);
 }
 
 template <bool ANY, bool STATS>
@@ -1348,6 +1363,12 @@ HPT_DEV bool traceSweep(const DevScene& S, const V3 wo, const V3 wd, const float
       // six scalar loads, one wait: two triangles per trip
       const float4 a0 = ldc4(tp), b0 = ldc4(tp + 1), c0 = ldc4(tp + 2), a1 = ldc4(tp + 3), b1 = ldc4(tp + 4), c1 = ldc4(tp + 5);
       if (STATS) { st.tris += 2; if (firstActiveLane()) st.waveTriIters += 2; }
+      if (ANY) {
+        found |= triangleOccludes(a0, b0, c0, o, d, tnear, tfar);
+        found |= triangleOccludes(a1, b1, c1, o, d, tnear, tfar);
+        if (__ballot(!found) == 0ull) return true;                         // every lane of the wave that traces a ray has its occluder
+        continue;
+      }
       triangleTestInOrder(a0, b0, c0, o, d, tnear, i, hit.t, hit.prim, hit.inst, hit.u, hit.v, found);
       triangleTestInOrder(a1, b1, c1, o, d, tnear, i, hit.t, hit.prim, hit.inst, hit.u, hit.v, found);
       if (ANY && __ballot(!found) == 0ull) return true;                    // every lane of the wave that traces a ray has its occluder

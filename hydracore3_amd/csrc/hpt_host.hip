@@ -476,9 +476,12 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   // typed_materials 1031 -> 1127, legacy_materials 1574 -> 1752, env_map 1526 -> 1670 Mpaths/s (profiles/ab_layout.sh), the instance
   // enter / leave trips outweigh the looser boxes once a ray meets several overlapping BLAS boxes.
   // ... and so does the 8 202-triangle test_228 with its 3 instances (megakernel: two-level 617, single-level 667 Mpaths/s).
-  const bool autoFlat = instTris >= FLAT_AUTO_TRIS || c->insts.size() >= MANY_INSTANCES;
+  // Scenes with moving instances keep the two-level layout unless told otherwise: there the ray is taken to the instance's space at the
+  // path's time once per instance visit, under the single-level layout once per triangle record (legacy_materials, one moving sphere of
+  // ten instances: two-level 1797, single-level 1065 Mpaths/s - profiles/ab_layout_full.sh).
   c->anyMotion = false;
   for (const Inst& in : c->insts) c->anyMotion = c->anyMotion || in.motion;
+  const bool autoFlat = !c->anyMotion && (instTris >= FLAT_AUTO_TRIS || c->insts.size() >= MANY_INSTANCES);
   const bool flat = instTris <= FLAT_TRI_BUDGET && (c->accelLayout == 2 || (c->accelLayout == 0 && autoFlat));
   {                                                          // object->world rows (3x4) at both keys for the moving instances (both layouts read them)
     const size_t nim = c->insts.size();
@@ -565,6 +568,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
     c->sahVisits = sah_node_visits(tree);
     c->S.nodeMin = c->nodeMinOverride >= 0 ? (uint)c->nodeMinOverride : (c->sahVisits >= HEAVY_SAH_VISITS ? 16u : 0u);
     c->stackNeeded = tree.depth + 1u;
+    if (std::getenv("HPT_DEBUG_ACCEL")) std::fprintf(stderr, "[hydra_hip] single-level BVH: %zu triangles, %zu nodes, depth %u, stack %u (LDS part %d), sah visits %.2f, nodeMin %u\n", instTris, tree.nodes.size(), tree.depth, c->stackNeeded, LDS_STACK, c->sahVisits, c->S.nodeMin);
     if (c->stackNeeded > MAX_STACK) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: BVH deeper than the 64-entry traversal stack");
     c->accelCommitted = true;
     return HPT_OK;
@@ -656,6 +660,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   c->flatRefittable = false;
   c->tCommit[0] = float(now_ms() - tBuild0); c->tCommit[1] = 0.0f; c->tCommit[2] = 0.0f; c->tCommit[3] = 0.0f;
   c->stackNeeded = tlas.depth + 1u + maxBlasDepth + 1u;
+  if (std::getenv("HPT_DEBUG_ACCEL")) std::fprintf(stderr, "[hydra_hip] two-level BVH: %zu instances, TLAS depth %u, deepest BLAS %u, stack %u (LDS part %d)\n", ni, tlas.depth, maxBlasDepth, c->stackNeeded, LDS_STACK);
   if (c->stackNeeded > MAX_STACK) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: BVH deeper than the 64-entry traversal stack");
   c->accelCommitted = true;
   return HPT_OK;

@@ -65,7 +65,10 @@ if glob.glob(os.path.join(src, "pmc_sq1", "*", "*counter_collection.csv")):
     clk_ghz = sq.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / (k_ms * 1e6)       # effective shader clock (MI355X_MICROARCH.md, DVFS): sum over 8 XCDs
     pj = {"workload": workload, "commit": commit, "from": f"gpurun_out/{tag}/pmc_sq1, pmc_sq2 (profiles/collect.sh)", "paths": paths, "kernel_ms": k_ms,
           "counters": sq, "valu_insts_per_path": sq["SQ_INSTS_VALU"] / paths, "lane_utilisation": round(lane, 4),
-          "valu_busy_at_2p4GHz": round(4.0 * sq["SQ_INSTS_VALU"] / (1024 * 2.4e9 * k_ms * 1e-3), 4),
+          # issue-slot occupancy at the spec rate (2 cycles per wave64 instruction: MI355X_MICROARCH.md) and at the 4 cycles VERDICT r1 priced it with
+          "valu_issue_frac_2cyc_at_2p4GHz": round(2.0 * sq["SQ_INSTS_VALU"] / (1024 * 2.4e9 * k_ms * 1e-3), 4),
+          "valu_busy_4cyc_at_2p4GHz": round(4.0 * sq["SQ_INSTS_VALU"] / (1024 * 2.4e9 * k_ms * 1e-3), 4),
+          "cycles_per_valu_inst_per_simd_at_2p4GHz": round(1024 * 2.4e9 * k_ms * 1e-3 / sq["SQ_INSTS_VALU"], 3),
           "effective_clock_GHz": round(clk_ghz, 3) if clk_ghz else None,
           "wait_any_frac": round(sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], 4), "active_inst_frac": round(sq["SQ_ACTIVE_INST_ANY"] / sq["SQ_WAVE_CYCLES"], 4)}
     json.dump(pj, open(os.path.join(root, "profiles", f"pmc_{workload}.json"), "w"), indent=1)

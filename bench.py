@@ -434,16 +434,25 @@ def run_dr(args, workload, rank, world, dev, dist, backend, steps, warmup, spp_a
     what = (f"synthetic 1M-triangle interior + {tw}x{tw}x4 differentiable albedo, {W}x{H} @ {spp} spp" if big
             else f"scenes/test_228 + 256x256x4 differentiable albedo, {W}x{H} @ {spp} spp")
     k_ms = float(np.mean(kms))
-    # gradient scatter priced as the guide prices float atomics: one dword per lane per atomic instruction against ~1.3 TB/s chip-wide
+    roof = {"bound": "valu", "achieved": None, "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwaveinst/s", "frac": None, "traffic": None,
+            "kernel": "pathTraceKernel<DR>" if integ.last_schedule()[0] == 1 else "wavefront DR", "kernel_ms": round(k_ms, 3),
+            "note": "no PMC profile of this DR configuration is committed: unpriced"}
+    pmc = load_profile("pmc_dr.json") if not big else None
+    if pmc and pmc.get("valu_insts_per_path") and integ.last_schedule()[0] == 1 and world == 1:
+        # as for the forward kernel: profiled VALU wave-instructions per path x this launch's paths over the live kernel time
+        ginst = pmc["valu_insts_per_path"] * float(N * spp) / (k_ms * 1e-3) / 1e9
+        tj = load_profile("traffic_dr.json")
+        roof.update({"achieved": round(ginst, 2), "frac": round(ginst / VALU_PEAK_GINST, 4), "lane_utilisation": pmc.get("lane_utilisation"),
+                     "traffic": tj["hbm_bytes_per_launch"] * float(N * spp) / float(tj["paths_per_launch"]) if tj else None,
+                     "pmc_source": f"profiles/pmc_dr.json, collected at commit {pmc.get('commit')}; the kernel time is measured in this run",
+                     "note": "forward walk + reverse sweep + gradient scatter in one kernel; float atomics execute at the memory side and are not VALU work"})
     return {"metric": "Mpaths/s (fwd+bwd grad, IntegratorDR::PathTraceDR + Adam)", "value": round(value, 2), "unit": "Mpaths/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": what + ", PathTraceDR fwd+bwd + Adam", "paths_per_step": int(paths_per_step), "trace_depth": sc.trace_depth, "grad_floats": int(size),
                        "sharding": "single GPU" if world == 1 else (("sample" if samples else "pixel") + f" sharding over {world} ranks ({args.scaling}) + all_reduce(SUM) of a_dataGrad and the loss"),
                        "loss_per_step": [round(v, 6) for v in losses]},
-            "roofline": {"bound": "valu", "achieved": None, "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwaveinst/s", "frac": None, "traffic": None,
-                         "kernel": "pathTraceKernel<DR>" if integ.last_schedule()[0] == 1 else "wavefront DR", "kernel_ms": round(k_ms, 3),
-                         "note": "no PMC profile of the DR kernels is committed: unpriced"}}
+            "roofline": roof}
 
 
 def compact(r):

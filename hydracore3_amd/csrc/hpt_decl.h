@@ -116,7 +116,7 @@ struct WfJob
 __global__ void wfInitKernel(WfPool P, uint n, uint passNum);
 template <bool DR, bool LEAN, bool MOTION = false>
 __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const WfPool P, const WfJob job);
-template <bool DEEP, bool FLAT, bool STATS, bool MOTION = false>
+template <bool DEEP, bool FLAT, bool STATS, bool MOTION = false, bool WIDE = false>   // WIDE: walk DevScene::nodes4 (4-wide compressed nodes) instead of the BVH2
 __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScene S, const WfPool P, uint iter, uint refillBelow, uint grace,
                                                                    uint* stackOverflow, uint gridLanes, Counters* counters);
 __global__ void __launch_bounds__(256) wfLossReduceKernel(const float* lossSlot, uint n, double* acc);

@@ -143,6 +143,25 @@ __global__ void refitTriBoxesKernel(const BvhTri* tris, const float* instMat, ui
   float* o = triBox + 6u * (size_t)k;
   o[0] = lo[0]; o[1] = hi[0]; o[2] = lo[1]; o[3] = hi[1]; o[4] = lo[2]; o[5] = hi[2];
 }
+// after the level passes: every 4-wide node requantises its children's boxes from the BVH2 nodes they come from (src = node << 1 | side)
+__global__ void refitNodes4Kernel(BvhNode4* nodes4, const uint* src, const BvhNode* nodes2, uint count)
+{
+  const uint i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  BvhNode4 nd = nodes4[i];
+  float lo[4][3], hi[4][3];
+  const uint valid = nd.exps >> 24;
+  for (int c = 0; c < 4; c++) {
+    if (!(valid & (1u << c))) continue;
+    const uint sidx = src[4u * (size_t)i + c];
+    const float* q = nodes2[sidx >> 1].q + 6u * (sidx & 1u);
+    for (int a = 0; a < 3; a++) { lo[c][a] = q[2 * a]; hi[c][a] = q[2 * a + 1]; }
+  }
+  uint keep[4]; for (int c = 0; c < 4; c++) keep[c] = nd.ref[c];
+  quantizeNode4(lo, hi, valid, nd);
+  for (int c = 0; c < 4; c++) nd.ref[c] = keep[c];
+  nodes4[i] = nd;
+}
 __global__ void refitLevelKernel(BvhNode* nodes, const uint* ids, uint count, const float* triBox, float* bounds)
 {
   const uint i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -97,6 +97,9 @@ struct hpt_ctx
   DevBuf<float> dInstMotion, dNormMat2;                  // motion blur: key matrices of the moving instances, end-of-motion normal matrices
   // device refit of the single-level layout (refit_flat): the committed tree's nodes grouped by level, scratch boxes, what the tree was built for
   DevBuf<uint> dLevelNodes; DevBuf<float> dTriBox, dNodeBounds, dInstO2W;
+  DevBuf<BvhNode4> dNodes4; DevBuf<uint> dNodes4Src;     // the single-level tree collapsed to 4-wide compressed nodes; per child the BVH2 (node << 1 | side) its box comes from
+  uint nodes4Count = 0, stackNeeded4 = 0;                // (0: no wide tree)
+  bool wideEnabled = true;                               // hpt_set_option("wide_nodes", 0): the trace kernel walks the BVH2
   std::vector<uint> levelOffsets;                        // nodes of level l = dLevelNodes[levelOffsets[l] .. levelOffsets[l + 1])
   std::vector<BvhTri> flatTris;                         // host copy of the single-level layout's triangle records (BVH order)
   bool flatRefittable = false;                           // a single-level tree is committed and nothing but instance matrices / vertex positions changed since
@@ -178,6 +181,7 @@ extern "C" int hpt_create(int device, hpt_ctx** out)
   (void)hipEventCreate(&c->ev0); (void)hipEventCreate(&c->ev1);
   if (const char* e = std::getenv("HPT_NODE_MIN")) c->nodeMinOverride = std::atoi(e) & 63;
   if (const char* e = std::getenv("HPT_WF_GRACE")) c->wfGrace = (uint)std::atoi(e);
+  if (const char* e = std::getenv("HPT_WIDE_NODES")) c->wideEnabled = std::atoi(e) != 0;
   std::memset(&c->S, 0, sizeof(DevScene));
   c->S.rootRef = REF_NONE;
   *out = c;
@@ -190,7 +194,7 @@ extern "C" void hpt_destroy(hpt_ctx* c)
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   (void)hpt_comm_destroy(c);
-  c->dNodes.release(); c->dTris.release(); c->dInsts.release(); c->dSweepInsts.release(); c->dSweepTris.release(); c->dLevelNodes.release(); c->dTriBox.release(); c->dNodeBounds.release(); c->dInstO2W.release(); c->dTriIndices.release(); c->dMatIdByPrim.release();
+  c->dNodes.release(); c->dTris.release(); c->dInsts.release(); c->dSweepInsts.release(); c->dSweepTris.release(); c->dLevelNodes.release(); c->dNodes4.release(); c->dNodes4Src.release(); c->dTriBox.release(); c->dNodeBounds.release(); c->dInstO2W.release(); c->dTriIndices.release(); c->dMatIdByPrim.release();
   c->dMatVertOffset.release(); c->dPackedXY.release(); c->dVData.release(); c->dNormMat.release(); c->dRemapInst.release();
   c->dRemapLists.release(); c->dMaterials.release(); c->dLights.release(); c->dTextures.release(); c->dArrays1f.release(); c->dSpecValues.release(); c->dSpecOffsetSz.release(); c->dCieXYZ.release(); c->dGens.release();
   c->dQueue.release(); c->dStackOvf.release(); c->dCounters.release(); c->dFrame.release(); c->dRecord.release(); c->dRef.release(); c->dData.release();
@@ -427,6 +431,7 @@ static int refit_flat(hpt_ctx* c)
     const uint cnt = c->levelOffsets[l + 1] - c->levelOffsets[l];
     if (cnt) refitLevelKernel<<<dim3((cnt + 255u) / 256u), dim3(256), 0, 0>>>(c->dNodes.p, c->dLevelNodes.p + c->levelOffsets[l], cnt, c->dTriBox.p, c->dNodeBounds.p);
   }
+  if (c->nodes4Count) refitNodes4Kernel<<<dim3((c->nodes4Count + 255u) / 256u), dim3(256), 0, 0>>>(c->dNodes4.p, c->dNodes4Src.p, c->dNodes.p, c->nodes4Count);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipDeviceSynchronize());
   c->S.insts = c->dInsts.p;
@@ -540,6 +545,56 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
     HIPCHK(c, c->dNodes.upload(nodes.data(), nodes.size()));
     HIPCHK(c, c->dTris.upload(tris.data(), tris.size()));
     HIPCHK(c, c->dInsts.upload(dinst.data(), dinst.size()));
+    // ---- the same tree as 4-wide compressed nodes (BvhNode4, hpt_types.h) for the heavy-scene trace kernel ----
+    // Collapse: a node adopts its grandchildren, largest surface first, until it has four children or only leaves are left. Child boxes are
+    // the (padded) BVH2 child boxes, quantised outwards in the node's frame; `src` remembers where each box lives so that a refit can requantise.
+    c->nodes4Count = 0; c->stackNeeded4 = 0; c->S.nodes4 = nullptr; c->S.root4 = REF_NONE;
+    if (tree.rootRef != REF_NONE && !(tree.rootRef & REF_LEAF) && !c->anyMotion) {
+      std::vector<BvhNode4> n4; std::vector<uint> src4; n4.reserve(tree.nodes.size() / 2 + 1); src4.reserve(2 * tree.nodes.size() + 4);
+      struct Item { uint node2, idx4, depth; };
+      std::vector<Item> todo; todo.push_back({ tree.rootRef, 0u, 1u });
+      n4.push_back(BvhNode4()); src4.resize(4, 0xFFFFFFFFu);
+      uint depth4 = 1;
+      auto area = [&](uint node2, uint side) { const float* q = tree.nodes[node2].q + 6 * side; const float dx = q[1] - q[0], dy = q[3] - q[2], dz = q[5] - q[4]; return dx * dy + dy * dz + dz * dx; };
+      while (!todo.empty()) {
+        const Item it = todo.back(); todo.pop_back();
+        depth4 = std::max(depth4, it.depth);
+        uint kids[4]; int nk = 2;                                  // each kid = (BVH2 node << 1 | side)
+        kids[0] = it.node2 << 1; kids[1] = (it.node2 << 1) | 1u;
+        auto refOf = [&](uint k) { const BvhNode& n = tree.nodes[k >> 1]; return (k & 1u) ? n.ref1 : n.ref0; };
+        while (nk < 4) {
+          int best = -1; float bestA = -1.0f;
+          for (int k = 0; k < nk; k++) { const uint r = refOf(kids[k]); if (r != REF_NONE && !(r & REF_LEAF)) { const float a = area(kids[k] >> 1, kids[k] & 1u); if (a > bestA) { bestA = a; best = k; } } }
+          if (best < 0) break;
+          const uint inner = refOf(kids[best]);
+          kids[best] = inner << 1; kids[nk++] = (inner << 1) | 1u;
+        }
+        float lo[4][3], hi[4][3]; uint valid = 0;
+        BvhNode4 nd; std::memset(&nd, 0, sizeof(nd));
+        for (int k = 0; k < 4; k++) nd.ref[k] = REF_NONE;
+        for (int k = 0; k < nk; k++) {
+          const uint r = refOf(kids[k]);
+          if (r == REF_NONE) continue;
+          const float* q = tree.nodes[kids[k] >> 1].q + 6 * (kids[k] & 1u);
+          for (int a = 0; a < 3; a++) { lo[k][a] = q[2 * a]; hi[k][a] = q[2 * a + 1]; }
+          valid |= 1u << k;
+          src4[4 * (size_t)it.idx4 + k] = kids[k];
+          if (r & REF_LEAF) nd.ref[k] = r;
+          else { nd.ref[k] = (uint)n4.size(); todo.push_back({ r, (uint)n4.size(), it.depth + 1u }); n4.push_back(BvhNode4()); src4.resize(src4.size() + 4, 0xFFFFFFFFu); }
+        }
+        uint keep[4]; for (int k = 0; k < 4; k++) keep[k] = nd.ref[k];
+        quantizeNode4(lo, hi, valid, nd);
+        for (int k = 0; k < 4; k++) nd.ref[k] = keep[k];
+        n4[it.idx4] = nd;
+      }
+      if (n4.size() < (size_t(1) << 31)) {
+        HIPCHK(c, c->dNodes4.upload(n4.data(), n4.size()));
+        HIPCHK(c, c->dNodes4Src.upload(src4.data(), src4.size()));
+        c->nodes4Count = (uint)n4.size(); c->stackNeeded4 = 3u * depth4 + 1u;       // a visit leaves at most three children waiting
+        c->S.nodes4 = c->dNodes4.p; c->S.root4 = 0u;
+        if (std::getenv("HPT_DEBUG_ACCEL")) std::fprintf(stderr, "[hydra_hip] 4-wide tree: %zu nodes (BVH2: %zu), depth %u, stack bound %u\n", n4.size(), tree.nodes.size(), depth4, c->stackNeeded4);
+      }
+    }
     {                                                          // what refit_flat needs: the nodes grouped by level, scratch for the boxes
       std::vector<uint> level(tree.nodes.size(), 0u), order; order.reserve(tree.nodes.size());
       uint maxLevel = 0;
@@ -657,6 +712,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   HIPCHK(c, c->dInsts.upload(dinst.data(), dinst.size()));
   c->S.nodes = c->dNodes.p; c->S.tris = c->dTris.p; c->S.insts = c->dInsts.p;
   c->S.rootRef = rootRef; c->S.numInsts = (uint)ni; c->S.flatMode = 0;
+  c->nodes4Count = 0; c->stackNeeded4 = 0; c->S.nodes4 = nullptr; c->S.root4 = REF_NONE;
   c->flatRefittable = false;
   c->tCommit[0] = float(now_ms() - tBuild0); c->tCommit[1] = 0.0f; c->tCommit[2] = 0.0f; c->tCommit[3] = 0.0f;
   c->stackNeeded = tlas.depth + 1u + maxBlasDepth + 1u;
@@ -669,7 +725,8 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
 // HBM part of the traversal stacks for a grid of `lanes` lanes (only touched by lanes whose stack outgrows LDS_STACK)
 static hipError_t ensureStackOverflow(hpt_ctx* c, size_t lanes)
 {
-  const size_t extra = c->stackNeeded > (uint)LDS_STACK ? c->stackNeeded - LDS_STACK : 1;
+  const uint need = std::max(c->stackNeeded, c->stackNeeded4);                  // either tree may be walked
+  const size_t extra = need > (uint)LDS_STACK ? need - LDS_STACK : 1;
   return c->dStackOvf.alloc(extra * lanes);
 }
 
@@ -1256,6 +1313,9 @@ static bool useWavefront(hpt_ctx* c, bool naive, bool dr, bool stats, uint tidCo
   return c->sahVisits >= HEAVY_SAH_VISITS && tidCount >= WF_AUTO_PIXELS;
 }
 
+static bool wfWide(const hpt_ctx* c) { return c->wideEnabled && c->S.flatMode != 0u && c->S.motion == 0u && c->nodes4Count != 0u; }
+static uint wfStackNeeded(const hpt_ctx* c) { return std::max(std::max(c->stackNeeded, wfWide(c) ? c->stackNeeded4 : 0u), 1u); }   // entries a suspended ray may have to save
+
 template <bool STATS>
 static void launchWfTrace(hpt_ctx* c, const WfPool& P, uint iter, int blocks, hipStream_t st, bool deep, uint* ovf)
 {
@@ -1269,6 +1329,11 @@ static void launchWfTrace(hpt_ctx* c, const WfPool& P, uint iter, int blocks, hi
       if (deep) wfTraceKernel<true, false, false, true><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
       else      wfTraceKernel<false, false, false, true><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
     }
+    return;
+  }
+  if (!STATS && wfWide(c)) {                                    // the 4-wide compressed tree (static single-level scenes)
+    if (c->stackNeeded4 > (uint)LDS_STACK) wfTraceKernel<true, true, false, false, true><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
+    else                                   wfTraceKernel<false, true, false, false, true><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
     return;
   }
   if (c->S.flatMode) {
@@ -1332,7 +1397,7 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr)
     live++;
     for (int i = 0; i < 8; i++) HIPCHK(c, g.f4[i].alloc(g.itemCount));
     for (int i = 0; i < 3; i++) HIPCHK(c, g.u[i].alloc(g.itemCount));
-    const size_t maxSusp = (size_t)traceBlocks * 256, suspWords = (WF_SUSP_WORDS + (size_t)std::max(c->stackNeeded, 1u)) * maxSusp;
+    const size_t maxSusp = (size_t)traceBlocks * 256, suspWords = (WF_SUSP_WORDS + (size_t)wfStackNeeded(c)) * maxSusp;
     HIPCHK(c, g.u[3].alloc(2 * (size_t)g.itemCount + maxSusp)); HIPCHK(c, g.u[5].alloc(2 * (size_t)g.itemCount + maxSusp));
     HIPCHK(c, g.u[4].alloc(2 * WF_CTR_WORDS));
     HIPCHK(c, g.u[6].alloc(g.itemCount));
@@ -1343,7 +1408,7 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr)
     P.rayO = g.f4[0].p; P.rayD = g.f4[1].p; P.thr = g.f4[2].p; P.acc = g.f4[3].p;
     P.shO = g.f4[4].p; P.shD = g.f4[5].p; P.contrib = g.f4[6].p; P.hit = g.f4[7].p;
     P.hitInst = g.u[0].p; P.occl = g.u[1].p; P.lossSlot = dr ? g.lossSlot.p : nullptr; P.time = c->S.motion ? g.time.p : nullptr; P.status = g.u[2].p; P.rayQ[0] = g.u[3].p; P.rayQ[1] = g.u[5].p; P.ctr = g.u[4].p; P.inflight = g.u[6].p;
-    P.susp[0] = g.u[7].p; P.susp[1] = g.u[8].p; P.maxSusp = (uint)maxSusp; P.suspStack = std::max(c->stackNeeded, 1u);
+    P.susp[0] = g.u[7].p; P.susp[1] = g.u[8].p; P.maxSusp = (uint)maxSusp; P.suspStack = wfStackNeeded(c);
     HIPCHK(c, hipStreamWaitEvent(g.stream, c->wfFork, 0));
     HIPCHK(c, hipMemsetAsync(P.ctr, 0, 2 * WF_CTR_WORDS * sizeof(uint), g.stream));
     wfInitKernel<<<dim3((g.itemCount + 255u) / 256u), dim3(256), 0, g.stream>>>(P, g.itemCount, job.passNum);
@@ -1729,6 +1794,7 @@ extern "C" int hpt_set_option(hpt_ctx* c, const char* name, int value)
   else if (k == "dbg_no_normal_lerp") { if (c->S.motion) c->S.motion = value ? 3u : 1u; }   // diagnostic: moving instances without the reference's normal interpolation (bit 1 of DevScene::motion)
   else if (k == "dbg_wf_iter_cap") c->wfIterCap = (uint)value;                         // diagnostic: make the wavefront loop's safety net reachable in a test
   else if (k == "dr_skip_nonfinite") c->drSkipNonFinite = value != 0;                  // PathTraceDR: drop samples whose radiance is not finite (default 0: PixelLossPT as in the reference)
+  else if (k == "wide_nodes") c->wideEnabled = value != 0;                             // 0: the wavefront trace kernel walks the BVH2 instead of the 4-wide compressed tree (A/B, diagnosis)
   else if (k == "force_full_materials") c->forceFull = value != 0;                     // diagnostic: never pick the lean (gltf + emissive) kernels
   else return c->fail(HPT_ERR_ARG, "hpt_set_option: unknown option " + k);
   return HPT_OK;

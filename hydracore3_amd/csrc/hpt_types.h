@@ -5,6 +5,7 @@
 // Update_m_materials / Update_m_lights partial-update hooks stay trivial.
 #pragma once
 #include <stdint.h>
+#include <math.h>
 
 namespace hpt {
 
@@ -49,6 +50,58 @@ static const int  BVH_LEAF_MAX = 2;   // measured on MI355X: 4 -> 1371, 2 -> 180
 struct BvhNode { float q[12]; uint ref0, ref1, pad0, pad1; };   // q = child 0 {lo.x hi.x lo.y hi.y lo.z hi.z}, child 1 {same}: (lo, hi) pairs feed v_pk_* slab tests
 static_assert(sizeof(BvhNode) == 64, "BVH2 node must be one 64-byte line");
 
+// 64-byte 4-wide node for the heavy-scene trace kernel (single-level layout): up to four children, their boxes as 8-bit offsets in the node's
+// own frame. org = lower corner of the children's union; per axis a power-of-two scale 2^(b - 127) (b = byte a of `exps`, so the float is b << 23);
+// q[0..2] = lower bounds x / y / z, q[3..5] = upper bounds, byte c of each word = child c; a bound decodes as fma(q, scale, org) in float - the
+// quantiser (quantizeNode4, below) rounds outwards and CHECKS the decoded value with the same fma, so a decoded box always contains the (padded)
+// BVH2 child box it came from. Boxes only cull, hits are decided by the exact triangle test: the compressed tree returns bit for bit what the
+// BVH2 returns. One node = one 64-byte line = four 16-byte loads, half the lines and half the dependent steps of the BVH2 walk.
+struct BvhNode4 { float org[3]; uint exps; uint q[6]; uint pad[2]; uint ref[4]; };   // exps byte 3: bit c set = child c exists; ref as in BvhNode (inner: BvhNode4 index)
+static_assert(sizeof(BvhNode4) == 64, "4-wide node must be one 64-byte line");
+
+#if defined(__HIPCC__)
+#define HPT_HD __host__ __device__ inline
+#else
+#define HPT_HD inline
+#endif
+HPT_HD float hptBitsToFloat(uint b) { union { uint u; float f; } c; c.u = b; return c.f; }
+HPT_HD uint  hptFloatToBits(float f) { union { uint u; float f; } c; c.f = f; return c.u; }
+// lo[c][a], hi[c][a]: the boxes of the children with bit c set in `valid` (the others are ignored); refs are not touched
+HPT_HD void quantizeNode4(const float lo[4][3], const float hi[4][3], uint valid, BvhNode4& out)
+{
+  float org[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, top[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+  for (int c = 0; c < 4; c++) if (valid & (1u << c)) for (int a = 0; a < 3; a++) { org[a] = lo[c][a] < org[a] ? lo[c][a] : org[a]; top[a] = hi[c][a] > top[a] ? hi[c][a] : top[a]; }
+  uint exps = valid << 24;
+  for (int w = 0; w < 6; w++) out.q[w] = 0u;
+  for (int a = 0; a < 3; a++) {
+    out.org[a] = org[a];
+    const float x = (top[a] - org[a]) * (1.0f / 254.0f);              // scale must exceed extent / 255: take the next power of two above extent / 254
+    uint b = ((hptFloatToBits(x) >> 23) & 0xFFu) + 1u;
+    if (b < 1u) b = 1u;
+    if (b > 254u) b = 254u;
+    for (int attempt = 0; attempt < 4; attempt++) {
+      const float s = hptBitsToFloat(b << 23);
+      bool ok = true;
+      uint wlo = 0u, whi = 0u;
+      for (int c = 0; c < 4; c++) {
+        if (!(valid & (1u << c))) continue;
+        float fl = floorf((lo[c][a] - org[a]) / s), fh = ceilf((hi[c][a] - org[a]) / s);
+        fl = fl < 0.0f ? 0.0f : (fl > 255.0f ? 255.0f : fl);
+        fh = fh < 0.0f ? 0.0f : fh;
+        while (fl > 0.0f && fmaf(fl, s, org[a]) > lo[c][a]) fl -= 1.0f;        // decoded lower bound must not exceed the true one (org itself never does)
+        while (fh <= 255.0f && fmaf(fh, s, org[a]) < hi[c][a]) fh += 1.0f;     // decoded upper bound must reach the true one
+        if (fh > 255.0f) { ok = false; break; }
+        wlo |= (uint)fl << (8 * c); whi |= (uint)fh << (8 * c);
+      }
+      if (ok) { out.q[a] = wlo; out.q[3 + a] = whi; break; }
+      b = b < 254u ? b + 1u : b;                                         // coarser grid and again (at most a step or two: rounding at the top end)
+      if (attempt == 3) { out.q[a] = 0u; out.q[3 + a] = 0xFFFFFFFFu; }   // cannot happen for finite boxes; the whole node range stays conservative
+    }
+    exps |= b << (8 * a);
+  }
+  out.exps = exps;
+}
+
 // 48-byte triangle: v0, e1 = v1-v0, e2 = v2-v0 (what Moeller-Trumbore consumes), primId in the spare lane
 struct BvhTri { float v0[3]; uint primId; float e1[3]; uint instId; float e2[3]; uint pad1; };   // instId: flat (single-level) mode only
 static_assert(sizeof(BvhTri) == 48, "triangle record must be 48 bytes");
@@ -77,6 +130,9 @@ struct DevScene
   uint           numInsts;
   uint           nodeMin;         // traversal leaves its inner-node loop when fewer lanes than this still hold an inner node (0: never)
   uint           flatMode;        // 1: one world-space BVH2 over all instanced triangles (leaf triangles carry their instance id)
+  const BvhNode4* nodes4;         // single-level layout, static scenes: the same tree collapsed to 4-wide compressed nodes (wfTraceKernel<WIDE>), or null
+  uint           root4;           // its root (a BvhNode4 index)
+  uint           padWide;
 
   const uint*    triIndices;      // m_triIndices
   const float*   vData8f;         // m_vData8f (8 floats per vertex)

@@ -693,3 +693,13 @@ def test_oracle_spectral_render_of_grey_scene_keeps_the_luminance():
     y_spec = (imgs[True].reshape(-1, 3) @ np.linalg.inv(M).T)[:, 1].mean()
     print(f"mean luminance: spectral {y_spec:.5f}, rgb {rgb[..., 1].mean():.5f}")
     assert y_spec == pytest.approx(rgb[..., 1].mean(), rel=0.03)
+
+
+def test_wide_node_quantiser_is_conservative(tmp_path):
+    """quantizeNode4 (csrc/hpt_types.h), the host / device routine behind the 4-wide compressed nodes of the heavy-scene trace kernel: two million
+    random child bounds - flat, point-sized, far from the origin, tiny next to huge - decode (fma(byte, 2^(b - 127), org), as the kernel does it) to
+    boxes that contain the originals and are at most two grid steps looser (tests/cpp/quantize_test.cpp, plain g++)."""
+    exe = str(tmp_path / "quantize_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(ROOT, "tests", "cpp", "quantize_test.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "all conservative" in r.stdout, r.stdout + r.stderr

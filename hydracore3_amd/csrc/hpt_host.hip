@@ -549,7 +549,9 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
     // Collapse: a node adopts its grandchildren, largest surface first, until it has four children or only leaves are left. Child boxes are
     // the (padded) BVH2 child boxes, quantised outwards in the node's frame; `src` remembers where each box lives so that a refit can requantise.
     c->nodes4Count = 0; c->stackNeeded4 = 0; c->S.nodes4 = nullptr; c->S.root4 = REF_NONE;
+    double collapseMs = 0.0;
     if (tree.rootRef != REF_NONE && !(tree.rootRef & REF_LEAF) && !c->anyMotion) {
+      const double tC0 = now_ms();
       std::vector<BvhNode4> n4; std::vector<uint> src4; n4.reserve(tree.nodes.size() / 2 + 1); src4.reserve(2 * tree.nodes.size() + 4);
       struct Item { uint node2, idx4, depth; };
       std::vector<Item> todo; todo.push_back({ tree.rootRef, 0u, 1u });
@@ -587,6 +589,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
         for (int k = 0; k < 4; k++) nd.ref[k] = keep[k];
         n4[it.idx4] = nd;
       }
+      collapseMs = now_ms() - tC0;
       if (n4.size() < (size_t(1) << 31)) {
         HIPCHK(c, c->dNodes4.upload(n4.data(), n4.size()));
         HIPCHK(c, c->dNodes4Src.upload(src4.data(), src4.size()));
@@ -617,11 +620,13 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
       c->flatTris.swap(tris);
       c->flatRefittable = tree.rootRef != REF_NONE && !(tree.rootRef & REF_LEAF) && instTris > 0 && !c->anyMotion;   // (the refit kernels know one key only)
     }
-    c->tCommit[0] = float(tUp0 - tBuild0); c->tCommit[1] = float(now_ms() - tUp0); c->tCommit[2] = 0.0f; c->tCommit[3] = 0.0f;
+    c->tCommit[0] = float(tUp0 - tBuild0 + collapseMs); c->tCommit[1] = float(now_ms() - tUp0 - collapseMs); c->tCommit[2] = 0.0f; c->tCommit[3] = 0.0f;   // the collapse is host build time
     c->S.nodes = c->dNodes.p; c->S.tris = c->dTris.p; c->S.insts = c->dInsts.p;
     c->S.rootRef = tree.rootRef; c->S.numInsts = (uint)ni; c->S.flatMode = 1; c->S.sweep = 0; c->S.sweepInsts = nullptr; c->S.sweepTris = nullptr;
     c->sahVisits = sah_node_visits(tree);
     c->S.nodeMin = c->nodeMinOverride >= 0 ? (uint)c->nodeMinOverride : (c->sahVisits >= HEAVY_SAH_VISITS ? 16u : 0u);
+    // the 4-wide walk votes earlier: 1M triangles, node_min 0 / 8 / 16 / 24 / 32 / 48 -> 176 / 254 / 273 / 286 / 288 / 269 Mpaths/s (profiles/sweep_wide.sh)
+    c->S.nodeMin4 = c->nodeMinOverride >= 0 ? (uint)c->nodeMinOverride : (c->sahVisits >= HEAVY_SAH_VISITS ? 32u : 0u);
     c->stackNeeded = tree.depth + 1u;
     if (std::getenv("HPT_DEBUG_ACCEL")) std::fprintf(stderr, "[hydra_hip] single-level BVH: %zu triangles, %zu nodes, depth %u, stack %u (LDS part %d), sah visits %.2f, nodeMin %u\n", instTris, tree.nodes.size(), tree.depth, c->stackNeeded, LDS_STACK, c->sahVisits, c->S.nodeMin);
     if (c->stackNeeded > MAX_STACK) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: BVH deeper than the 64-entry traversal stack");
@@ -712,7 +717,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   HIPCHK(c, c->dInsts.upload(dinst.data(), dinst.size()));
   c->S.nodes = c->dNodes.p; c->S.tris = c->dTris.p; c->S.insts = c->dInsts.p;
   c->S.rootRef = rootRef; c->S.numInsts = (uint)ni; c->S.flatMode = 0;
-  c->nodes4Count = 0; c->stackNeeded4 = 0; c->S.nodes4 = nullptr; c->S.root4 = REF_NONE;
+  c->nodes4Count = 0; c->stackNeeded4 = 0; c->S.nodes4 = nullptr; c->S.root4 = REF_NONE; c->S.nodeMin4 = 0;
   c->flatRefittable = false;
   c->tCommit[0] = float(now_ms() - tBuild0); c->tCommit[1] = 0.0f; c->tCommit[2] = 0.0f; c->tCommit[3] = 0.0f;
   c->stackNeeded = tlas.depth + 1u + maxBlasDepth + 1u;

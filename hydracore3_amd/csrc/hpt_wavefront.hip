@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
         while ((cur & REF_LEAF) == 0u) {
           if (WIDE) {
             wideNodeStep<DEEP>(S, stk, wo, id, hitT, cur, sp);
-            if (S.nodeMin != 0u && (uint)__popcll(__ballot((cur & REF_LEAF) == 0u)) < S.nodeMin) break;
+            if (S.nodeMin4 != 0u && (uint)__popcll(__ballot((cur & REF_LEAF) == 0u)) < S.nodeMin4) break;
             continue;
           }
           const float4* np = (const float4*)(S.nodes + cur);

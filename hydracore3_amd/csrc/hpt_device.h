@@ -1081,6 +1081,9 @@ HPT_DEV uint stkPop(const TravStack& k, int sp)
 // (HPT_PACKED_SLABS: v_pk_add_f32 / v_pk_mul_f32, 12 instructions instead of 24, same rounding) - measured slower, off by default. Boxes were padded by the builder; the interval is widened a little more so that rounding (and the 1-ulp reciprocal)
 // can only make the test more conservative than the exact triangle test.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef HPT_FLAT_WIDE
+#define HPT_FLAT_WIDE 0      // 1: the megakernel's single-level traversal also walks the 4-wide compressed tree when the scene has one
+#endif
 #ifndef HPT_PACKED_SLABS
 #define HPT_PACKED_SLABS 0   // measured: v_pk_add/mul_f32 (12 instead of 24 instructions) is NOT faster here: Cornell 1805 vs 1820, 1M triangles 200 vs 206
 #endif
@@ -1237,6 +1240,41 @@ HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, 
   return found;
 }
 
+// One visit of a 4-wide compressed node (BvhNode4, hpt_types.h): decode the four child boxes (v_cvt_f32_ubyteN + one fma per bound), slab-test
+// them like nodeSlabs does (same widening, so the test stays conservative with respect to the exact triangle test), sort the children that
+// were hit by entry distance with a five-exchange network on (distance bits | child index, reference) pairs, continue with the nearest and
+// push the others farthest first. Traversal ORDER never changes a result: the closest hit is min t with ties broken by (instId, primId).
+HPT_DEV float ubyteToFloat(uint w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }      // v_cvt_f32_ubyte<k>
+template <bool DEEP>
+HPT_DEV void wideNodeStep(const DevScene& S, const TravStack& stk, const V3 org, const V3 id, const float best, uint& cur, int& sp, const float tnear = 0.0f)
+{
+  const uint4* np = (const uint4*)(S.nodes4 + cur);
+  const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+  const float sx = __uint_as_float((w0.w & 0xFFu) << 23), sy = __uint_as_float(((w0.w >> 8) & 0xFFu) << 23), sz = __uint_as_float(((w0.w >> 16) & 0xFFu) << 23);
+  const float bx = __uint_as_float(w0.x), by = __uint_as_float(w0.y), bz = __uint_as_float(w0.z);
+  uint key[4], ref[4] = { w3.x, w3.y, w3.z, w3.w };
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const float lx = __builtin_fmaf(ubyteToFloat(w1.x, c), sx, bx), ly = __builtin_fmaf(ubyteToFloat(w1.y, c), sy, by), lz = __builtin_fmaf(ubyteToFloat(w1.z, c), sz, bz);
+    const float hx = __builtin_fmaf(ubyteToFloat(w1.w, c), sx, bx), hy = __builtin_fmaf(ubyteToFloat(w2.x, c), sy, by), hz = __builtin_fmaf(ubyteToFloat(w2.y, c), sz, bz);
+    const float ax0 = (lx - org.x) * id.x, ax1 = (hx - org.x) * id.x, ay0 = (ly - org.y) * id.y, ay1 = (hy - org.y) * id.y, az0 = (lz - org.z) * id.z, az1 = (hz - org.z) * id.z;
+    const float tn = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), tnear));
+    const float tf = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), best));
+    const bool hit = (tn * 0.999999f <= tf * 1.000001f) & (((w0.w >> (24 + c)) & 1u) != 0u);
+    key[c] = hit ? (((__float_as_uint(tn) & 0x7FFFFFFCu)) | (uint)c) : 0xFFFFFFFFu;        // tn >= 0: its bit pattern orders like the value
+  }
+#define HPT_CE(a, b) do { const bool sw = key[b] < key[a]; const uint ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b], ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b]; \
+                          key[a] = ka; key[b] = kb; ref[a] = ra; ref[b] = rb; } while (0)
+  HPT_CE(0, 1); HPT_CE(2, 3); HPT_CE(0, 2); HPT_CE(1, 3); HPT_CE(1, 2);
+#undef HPT_CE
+  if (key[3] != 0xFFFFFFFFu) { if (DEEP) stkPush(stk, sp, ref[3]); else stk.lds[sp * 256] = ref[3]; sp++; }
+  if (key[2] != 0xFFFFFFFFu) { if (DEEP) stkPush(stk, sp, ref[2]); else stk.lds[sp * 256] = ref[2]; sp++; }
+  if (key[1] != 0xFFFFFFFFu) { if (DEEP) stkPush(stk, sp, ref[1]); else stk.lds[sp * 256] = ref[1]; sp++; }
+  if (key[0] != 0xFFFFFFFFu) cur = ref[0];
+  else if (sp > 0) { sp--; cur = DEEP ? stkPop(stk, sp) : stk.lds[sp * 256]; }
+  else cur = REF_NONE;
+}
+
 // ---- single-level variant ---------------------------------------------------------------------------------------------------
 // For static scenes whose instanced triangle count fits the budget (hpt_host.hip: FLAT_TRI_BUDGET) the host builds ONE BVH2 over
 // all instanced triangles with WORLD-space boxes: no TLAS/BLAS box overlap, no instance enter / leave trips through the loop.
@@ -1256,8 +1294,15 @@ HPT_DEV bool traceRayFlat(const DevScene& S, const V3 wo, const V3 wd, float tne
   int sp = 0;
 #define HPT_PUSH(v) do { if (DEEP) stkPush(stk, sp, (v)); else stk.lds[sp * 256] = (v); sp++; } while (0)
 #define HPT_POP()   do { sp--; cur = DEEP ? stkPop(stk, sp) : stk.lds[sp * 256]; } while (0)
+  const bool wide = HPT_FLAT_WIDE && !MOTION && !STATS && S.nodes4 != nullptr;   // wave-uniform: the 4-wide compressed tree of the same scene
+  if (wide) cur = S.root4;
   while (true) {
-    if (S.nodeMin == 0u) {
+    if (wide) {
+      while ((cur & REF_LEAF) == 0u) {
+        wideNodeStep<DEEP>(S, stk, wo, id, hit.t, cur, sp, tnear);
+        if (S.nodeMin4 != 0u && (uint)__popcll(__ballot((cur & REF_LEAF) == 0u)) < S.nodeMin4) break;
+      }
+    } else if (S.nodeMin == 0u) {
       while ((cur & REF_LEAF) == 0u) { HPT_NODE_STEP(wo) }
     } else {
       while ((cur & REF_LEAF) == 0u) {

@@ -728,6 +728,8 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
 }
 
 // HBM part of the traversal stacks for a grid of `lanes` lanes (only touched by lanes whose stack outgrows LDS_STACK)
+// stack entries a megakernel traversal may need: with HPT_FLAT_WIDE the single-level walk uses the 4-wide tree when the scene has one
+static uint megaStackNeeded(const hpt_ctx* c) { return (HPT_FLAT_WIDE && c->S.flatMode != 0u && c->S.motion == 0u && c->nodes4Count != 0u) ? std::max(c->stackNeeded, c->stackNeeded4) : c->stackNeeded; }
 static hipError_t ensureStackOverflow(hpt_ctx* c, size_t lanes)
 {
   const uint need = std::max(c->stackNeeded, c->stackNeeded4);                  // either tree may be walked
@@ -1252,7 +1254,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
     job.gens = c->dGens.p; job.packedXY = c->dPackedXY.p; job.packedCount = c->packedCount;
     HIPCHK(c, ensureStackOverflow(c, (size_t)sblocks * 256));
     job.stackOverflow = c->dStackOvf.p; job.gridLanes = (uint)sblocks * 256u;
-    const bool sdeep = c->stackNeeded > (uint)LDS_STACK;
+    const bool sdeep = megaStackNeeded(c) > (uint)LDS_STACK;
     c->lastSchedule = 1;
     HIPCHK(c, hipEventRecord(c->ev0, st));
     if (c->S.sweep)          pathTraceSpectralKernel<false, false, true><<<dim3(sblocks), dim3(256), 0, st>>>(c->S, job);
@@ -1283,7 +1285,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   HIPCHK(c, ensureStackOverflow(c, (size_t)blocks * 256));
   job.stackOverflow = c->dStackOvf.p; job.gridLanes = (uint)blocks * 256u;
   HIPCHK(c, hipEventRecord(c->ev0, st));
-  const bool deep = c->stackNeeded > (uint)LDS_STACK;
+  const bool deep = megaStackNeeded(c) > (uint)LDS_STACK;
   if (motion) {
     if (inRays) launchPTMotion<2>(c->S, job, blocks, st, deep); else if (naive) launchPTMotion<1>(c->S, job, blocks, st, deep); else launchPTMotion<0>(c->S, job, blocks, st, deep);
   }

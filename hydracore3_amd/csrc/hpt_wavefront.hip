@@ -193,41 +193,6 @@ __global__ void wfLossFinishKernel(const double* acc, float* loss) { *loss += (f
 #ifndef HPT_WF_XCD_RANGES
 #define HPT_WF_XCD_RANGES 1
 #endif
-// One visit of a 4-wide compressed node (BvhNode4, hpt_types.h): decode the four child boxes (v_cvt_f32_ubyteN + one fma per bound), slab-test
-// them like nodeSlabs does (same widening, so the test stays conservative with respect to the exact triangle test), sort the children that
-// were hit by entry distance with a five-exchange network on (distance bits | child index, reference) pairs, continue with the nearest and
-// push the others farthest first. Traversal ORDER never changes a result: the closest hit is min t with ties broken by (instId, primId).
-HPT_DEV float ubyteToFloat(uint w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }      // v_cvt_f32_ubyte<k>
-template <bool DEEP>
-HPT_DEV void wideNodeStep(const DevScene& S, const TravStack& stk, const V3 org, const V3 id, const float best, uint& cur, int& sp)
-{
-  const uint4* np = (const uint4*)(S.nodes4 + cur);
-  const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
-  const float sx = __uint_as_float((w0.w & 0xFFu) << 23), sy = __uint_as_float(((w0.w >> 8) & 0xFFu) << 23), sz = __uint_as_float(((w0.w >> 16) & 0xFFu) << 23);
-  const float bx = __uint_as_float(w0.x), by = __uint_as_float(w0.y), bz = __uint_as_float(w0.z);
-  uint key[4], ref[4] = { w3.x, w3.y, w3.z, w3.w };
-#pragma unroll
-  for (int c = 0; c < 4; c++) {
-    const float lx = __builtin_fmaf(ubyteToFloat(w1.x, c), sx, bx), ly = __builtin_fmaf(ubyteToFloat(w1.y, c), sy, by), lz = __builtin_fmaf(ubyteToFloat(w1.z, c), sz, bz);
-    const float hx = __builtin_fmaf(ubyteToFloat(w1.w, c), sx, bx), hy = __builtin_fmaf(ubyteToFloat(w2.x, c), sy, by), hz = __builtin_fmaf(ubyteToFloat(w2.y, c), sz, bz);
-    const float ax0 = (lx - org.x) * id.x, ax1 = (hx - org.x) * id.x, ay0 = (ly - org.y) * id.y, ay1 = (hy - org.y) * id.y, az0 = (lz - org.z) * id.z, az1 = (hz - org.z) * id.z;
-    const float tn = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), 0.0f));
-    const float tf = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), best));
-    const bool hit = (tn * 0.999999f <= tf * 1.000001f) & (((w0.w >> (24 + c)) & 1u) != 0u);
-    key[c] = hit ? (((__float_as_uint(tn) & 0x7FFFFFFCu)) | (uint)c) : 0xFFFFFFFFu;        // tn >= 0: its bit pattern orders like the value
-  }
-#define HPT_CE(a, b) do { const bool sw = key[b] < key[a]; const uint ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b], ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b]; \
-                          key[a] = ka; key[b] = kb; ref[a] = ra; ref[b] = rb; } while (0)
-  HPT_CE(0, 1); HPT_CE(2, 3); HPT_CE(0, 2); HPT_CE(1, 3); HPT_CE(1, 2);
-#undef HPT_CE
-  if (key[3] != 0xFFFFFFFFu) { if (DEEP) stkPush(stk, sp, ref[3]); else stk.lds[sp * 256] = ref[3]; sp++; }
-  if (key[2] != 0xFFFFFFFFu) { if (DEEP) stkPush(stk, sp, ref[2]); else stk.lds[sp * 256] = ref[2]; sp++; }
-  if (key[1] != 0xFFFFFFFFu) { if (DEEP) stkPush(stk, sp, ref[1]); else stk.lds[sp * 256] = ref[1]; sp++; }
-  if (key[0] != 0xFFFFFFFFu) cur = ref[0];
-  else if (sp > 0) { sp--; cur = DEEP ? stkPop(stk, sp) : stk.lds[sp * 256]; }
-  else cur = REF_NONE;
-}
-
 template <bool DEEP, bool FLAT, bool STATS, bool MOTION, bool WIDE>
 __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScene S, const WfPool P, uint iter, uint refillBelow, uint grace,
                                                                    uint* stackOverflow, uint gridLanes, Counters* counters)

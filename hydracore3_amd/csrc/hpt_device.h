@@ -1294,11 +1294,12 @@ HPT_DEV bool traceRayFlat(const DevScene& S, const V3 wo, const V3 wd, float tne
   int sp = 0;
 #define HPT_PUSH(v) do { if (DEEP) stkPush(stk, sp, (v)); else stk.lds[sp * 256] = (v); sp++; } while (0)
 #define HPT_POP()   do { sp--; cur = DEEP ? stkPop(stk, sp) : stk.lds[sp * 256]; } while (0)
-  const bool wide = HPT_FLAT_WIDE && !MOTION && !STATS && S.nodes4 != nullptr;   // wave-uniform: the 4-wide compressed tree of the same scene
+  const bool wide = ((HPT_FLAT_WIDE && !STATS) || (STATS && S.statsWide != 0u)) && !MOTION && S.nodes4 != nullptr;   // wave-uniform: the 4-wide compressed tree of the same scene
   if (wide) cur = S.root4;
   while (true) {
     if (wide) {
       while ((cur & REF_LEAF) == 0u) {
+        if (STATS) { st.nodes++; if (firstActiveLane()) st.waveNodeIters++; }
         wideNodeStep<DEEP>(S, stk, wo, id, hit.t, cur, sp, tnear);
         if (S.nodeMin4 != 0u && (uint)__popcll(__ballot((cur & REF_LEAF) == 0u)) < S.nodeMin4) break;
       }

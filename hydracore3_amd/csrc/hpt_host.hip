@@ -548,7 +548,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
     // ---- the same tree as 4-wide compressed nodes (BvhNode4, hpt_types.h) for the heavy-scene trace kernel ----
     // Collapse: a node adopts its grandchildren, largest surface first, until it has four children or only leaves are left. Child boxes are
     // the (padded) BVH2 child boxes, quantised outwards in the node's frame; `src` remembers where each box lives so that a refit can requantise.
-    c->nodes4Count = 0; c->stackNeeded4 = 0; c->S.nodes4 = nullptr; c->S.root4 = REF_NONE;
+    c->nodes4Count = 0; c->stackNeeded4 = 0; c->S.nodes4 = nullptr; c->S.root4 = REF_NONE; c->S.statsWide = 0;
     double collapseMs = 0.0;
     if (tree.rootRef != REF_NONE && !(tree.rootRef & REF_LEAF) && !c->anyMotion) {
       const double tC0 = now_ms();
@@ -717,7 +717,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   HIPCHK(c, c->dInsts.upload(dinst.data(), dinst.size()));
   c->S.nodes = c->dNodes.p; c->S.tris = c->dTris.p; c->S.insts = c->dInsts.p;
   c->S.rootRef = rootRef; c->S.numInsts = (uint)ni; c->S.flatMode = 0;
-  c->nodes4Count = 0; c->stackNeeded4 = 0; c->S.nodes4 = nullptr; c->S.root4 = REF_NONE; c->S.nodeMin4 = 0;
+  c->nodes4Count = 0; c->stackNeeded4 = 0; c->S.nodes4 = nullptr; c->S.root4 = REF_NONE; c->S.statsWide = 0; c->S.nodeMin4 = 0;
   c->flatRefittable = false;
   c->tCommit[0] = float(now_ms() - tBuild0); c->tCommit[1] = 0.0f; c->tCommit[2] = 0.0f; c->tCommit[3] = 0.0f;
   c->stackNeeded = tlas.depth + 1u + maxBlasDepth + 1u;
@@ -1194,6 +1194,7 @@ static int gridBlocks(hpt_ctx* c, bool dr, bool fullMaterials = false)
 }
 
 static bool useWavefront(hpt_ctx* c, bool naive, bool dr, bool stats, uint tidCount);
+static bool wfWide(const hpt_ctx* c);
 static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr);
 
 // DEEP: the scene's BVH can need more than LDS_STACK stack entries, so pushes / pops check for the HBM overflow part
@@ -1292,7 +1293,13 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   else if (dr)     launchPT<false, true, 0>(c->S, job, blocks, st, deep);
   else if (inRays) launchPT<false, false, 2>(c->S, job, blocks, st, deep);
   else if (naive)  launchPT<false, false, 1>(c->S, job, blocks, st, deep);
-  else if (stats)  launchPT<true, false, 0>(c->S, job, blocks, st, deep);
+  else if (stats) {
+    // the counting probe follows the walk an uninstrumented call would do: where that is the wavefront trace kernel on the 4-wide tree, the
+    // probe's single-level traversal walks that tree too (node visits = 64-byte lines of the tree actually used)
+    DevScene Sp = c->S;
+    Sp.statsWide = (wfWide(c) && useWavefront(c, naive, dr, false, job.tidCount)) ? 1u : 0u;
+    launchPT<true, false, 0>(Sp, job, blocks, st, deep || (Sp.statsWide && c->stackNeeded4 > (uint)LDS_STACK));
+  }
   else if (c->leanMaterials && !c->forceFull && c->S.lensCount == 0u) launchPT<false, false, 3>(c->S, job, blocks, st, deep);
   else             launchPT<false, false, 0>(c->S, job, blocks, st, deep);
   HIPCHK(c, hipGetLastError());

@@ -11,7 +11,7 @@ set -o pipefail
 TAG=${1:-r2}; WL=${2:-cornell}; SPP=${3:-1024}; SQSPP=${4:-64}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
-mkdir -p $OUT
+rm -rf $OUT && mkdir -p $OUT        # a re-collection under the same tag must not mix with the previous one
 python3 __graft_entry__.py > $OUT/build.log 2>&1 || { echo "build failed"; exit 1; }
 CMD="python3 bench.py --workload $WL --steps 2 --warmup 1 --spp $SPP --no-cpu-baseline --no-also --no-build"
 SQ="python3 bench.py --workload $WL --steps 1 --warmup 0 --spp $SQSPP --no-cpu-baseline --no-also --no-build"

@@ -145,7 +145,8 @@ def make_roofline(workload, integ, torch, dev, stream, N, W, H, spp, t_count, ke
     import numpy as np
     sched_used, wf_rounds = integ.last_schedule()
     probe_spp = min(spp, 8)
-    integ.set_schedule(1)                                     # the instrumented build is the megakernel: same rays, same node / triangle visits
+    integ.set_schedule(1)                                     # the instrumented build is the megakernel: same rays, same triangle visits ...
+    integ.set_option("stats_wide", 1 if sched_used == 2 else 0)   # ... and the node walk of the tree the timed call used (wavefront: the 4-wide compressed one, where the scene has it)
     integ.set_instrumentation(True)
     integ.InitRandomGens(N)
     integ.set_tid_interleave(0, 1)

@@ -1082,7 +1082,7 @@ HPT_DEV uint stkPop(const TravStack& k, int sp)
 // can only make the test more conservative than the exact triangle test.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef HPT_FLAT_WIDE
-#define HPT_FLAT_WIDE 0      // 1: the megakernel's single-level traversal also walks the 4-wide compressed tree when the scene has one
+#define HPT_FLAT_WIDE 0      // 1: the megakernel's single-level traversal walks the 4-wide compressed tree on EVERY scene that has one (default: heavy scenes only, DevScene::megaWide)
 #endif
 #ifndef HPT_PACKED_SLABS
 #define HPT_PACKED_SLABS 0   // measured: v_pk_add/mul_f32 (12 instead of 24 instructions) is NOT faster here: Cornell 1805 vs 1820, 1M triangles 200 vs 206
@@ -1294,7 +1294,7 @@ HPT_DEV bool traceRayFlat(const DevScene& S, const V3 wo, const V3 wd, float tne
   int sp = 0;
 #define HPT_PUSH(v) do { if (DEEP) stkPush(stk, sp, (v)); else stk.lds[sp * 256] = (v); sp++; } while (0)
 #define HPT_POP()   do { sp--; cur = DEEP ? stkPop(stk, sp) : stk.lds[sp * 256]; } while (0)
-  const bool wide = ((HPT_FLAT_WIDE && !STATS) || (STATS && S.statsWide != 0u)) && !MOTION && S.nodes4 != nullptr;   // wave-uniform: the 4-wide compressed tree of the same scene
+  const bool wide = (((HPT_FLAT_WIDE || S.megaWide != 0u) && !STATS) || (STATS && S.statsWide != 0u)) && !MOTION && S.nodes4 != nullptr;   // wave-uniform: the 4-wide compressed tree of the same scene
   if (wide) cur = S.root4;
   while (true) {
     if (wide) {

@@ -99,6 +99,7 @@ struct hpt_ctx
   DevBuf<uint> dLevelNodes; DevBuf<float> dTriBox, dNodeBounds, dInstO2W;
   DevBuf<BvhNode4> dNodes4; DevBuf<uint> dNodes4Src;     // the single-level tree collapsed to 4-wide compressed nodes; per child the BVH2 (node << 1 | side) its box comes from
   uint nodes4Count = 0, stackNeeded4 = 0;                // (0: no wide tree)
+  bool statsWide = false;                                // hpt_set_option("stats_wide", 1): the instrumented probe walks the 4-wide tree (what a wavefront call on this scene does)
   bool wideEnabled = true;                               // hpt_set_option("wide_nodes", 0): the trace kernel walks the BVH2
   std::vector<uint> levelOffsets;                        // nodes of level l = dLevelNodes[levelOffsets[l] .. levelOffsets[l + 1])
   std::vector<BvhTri> flatTris;                         // host copy of the single-level layout's triangle records (BVH order)
@@ -548,7 +549,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
     // ---- the same tree as 4-wide compressed nodes (BvhNode4, hpt_types.h) for the heavy-scene trace kernel ----
     // Collapse: a node adopts its grandchildren, largest surface first, until it has four children or only leaves are left. Child boxes are
     // the (padded) BVH2 child boxes, quantised outwards in the node's frame; `src` remembers where each box lives so that a refit can requantise.
-    c->nodes4Count = 0; c->stackNeeded4 = 0; c->S.nodes4 = nullptr; c->S.root4 = REF_NONE; c->S.statsWide = 0;
+    c->nodes4Count = 0; c->stackNeeded4 = 0; c->S.nodes4 = nullptr; c->S.root4 = REF_NONE; c->S.statsWide = 0; c->S.megaWide = 0;
     double collapseMs = 0.0;
     if (tree.rootRef != REF_NONE && !(tree.rootRef & REF_LEAF) && !c->anyMotion) {
       const double tC0 = now_ms();
@@ -595,6 +596,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
         HIPCHK(c, c->dNodes4Src.upload(src4.data(), src4.size()));
         c->nodes4Count = (uint)n4.size(); c->stackNeeded4 = 3u * depth4 + 1u;       // a visit leaves at most three children waiting
         c->S.nodes4 = c->dNodes4.p; c->S.root4 = 0u;
+        c->S.megaWide = (c->wideEnabled && sah_node_visits(tree) >= HEAVY_SAH_VISITS) ? 1u : 0u;   // heavy scenes rendered by the megakernel (calls below the wavefront's pixel threshold) walk it too
         if (std::getenv("HPT_DEBUG_ACCEL")) std::fprintf(stderr, "[hydra_hip] 4-wide tree: %zu nodes (BVH2: %zu), depth %u, stack bound %u\n", n4.size(), tree.nodes.size(), depth4, c->stackNeeded4);
       }
     }
@@ -717,7 +719,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   HIPCHK(c, c->dInsts.upload(dinst.data(), dinst.size()));
   c->S.nodes = c->dNodes.p; c->S.tris = c->dTris.p; c->S.insts = c->dInsts.p;
   c->S.rootRef = rootRef; c->S.numInsts = (uint)ni; c->S.flatMode = 0;
-  c->nodes4Count = 0; c->stackNeeded4 = 0; c->S.nodes4 = nullptr; c->S.root4 = REF_NONE; c->S.statsWide = 0; c->S.nodeMin4 = 0;
+  c->nodes4Count = 0; c->stackNeeded4 = 0; c->S.nodes4 = nullptr; c->S.root4 = REF_NONE; c->S.statsWide = 0; c->S.megaWide = 0; c->S.nodeMin4 = 0;
   c->flatRefittable = false;
   c->tCommit[0] = float(now_ms() - tBuild0); c->tCommit[1] = 0.0f; c->tCommit[2] = 0.0f; c->tCommit[3] = 0.0f;
   c->stackNeeded = tlas.depth + 1u + maxBlasDepth + 1u;
@@ -729,7 +731,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
 
 // HBM part of the traversal stacks for a grid of `lanes` lanes (only touched by lanes whose stack outgrows LDS_STACK)
 // stack entries a megakernel traversal may need: with HPT_FLAT_WIDE the single-level walk uses the 4-wide tree when the scene has one
-static uint megaStackNeeded(const hpt_ctx* c) { return (HPT_FLAT_WIDE && c->S.flatMode != 0u && c->S.motion == 0u && c->nodes4Count != 0u) ? std::max(c->stackNeeded, c->stackNeeded4) : c->stackNeeded; }
+static uint megaStackNeeded(const hpt_ctx* c) { return ((HPT_FLAT_WIDE || c->S.megaWide != 0u) && c->S.flatMode != 0u && c->S.motion == 0u && c->nodes4Count != 0u) ? std::max(c->stackNeeded, c->stackNeeded4) : c->stackNeeded; }
 static hipError_t ensureStackOverflow(hpt_ctx* c, size_t lanes)
 {
   const uint need = std::max(c->stackNeeded, c->stackNeeded4);                  // either tree may be walked
@@ -1297,7 +1299,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
     // the counting probe follows the walk an uninstrumented call would do: where that is the wavefront trace kernel on the 4-wide tree, the
     // probe's single-level traversal walks that tree too (node visits = 64-byte lines of the tree actually used)
     DevScene Sp = c->S;
-    Sp.statsWide = (wfWide(c) && useWavefront(c, naive, dr, false, job.tidCount)) ? 1u : 0u;
+    Sp.statsWide = (wfWide(c) && (c->statsWide || useWavefront(c, naive, dr, false, job.tidCount))) ? 1u : 0u;   // "stats_wide": the caller says the measured call ran there
     launchPT<true, false, 0>(Sp, job, blocks, st, deep || (Sp.statsWide && c->stackNeeded4 > (uint)LDS_STACK));
   }
   else if (c->leanMaterials && !c->forceFull && c->S.lensCount == 0u) launchPT<false, false, 3>(c->S, job, blocks, st, deep);
@@ -1808,6 +1810,7 @@ extern "C" int hpt_set_option(hpt_ctx* c, const char* name, int value)
   else if (k == "dbg_no_normal_lerp") { if (c->S.motion) c->S.motion = value ? 3u : 1u; }   // diagnostic: moving instances without the reference's normal interpolation (bit 1 of DevScene::motion)
   else if (k == "dbg_wf_iter_cap") c->wfIterCap = (uint)value;                         // diagnostic: make the wavefront loop's safety net reachable in a test
   else if (k == "dr_skip_nonfinite") c->drSkipNonFinite = value != 0;                  // PathTraceDR: drop samples whose radiance is not finite (default 0: PixelLossPT as in the reference)
+  else if (k == "stats_wide") c->statsWide = value != 0;
   else if (k == "wide_nodes") c->wideEnabled = value != 0;                             // 0: the wavefront trace kernel walks the BVH2 instead of the 4-wide compressed tree (A/B, diagnosis)
   else if (k == "force_full_materials") c->forceFull = value != 0;                     // diagnostic: never pick the lean (gltf + emissive) kernels
   else return c->fail(HPT_ERR_ARG, "hpt_set_option: unknown option " + k);

@@ -132,6 +132,7 @@ struct DevScene
   uint           flatMode;        // 1: one world-space BVH2 over all instanced triangles (leaf triangles carry their instance id)
   const BvhNode4* nodes4;         // single-level layout, static scenes: the same tree collapsed to 4-wide compressed nodes (wfTraceKernel<WIDE>), or null
   uint           root4;           // its root (a BvhNode4 index)
+  uint           megaWide;        // the megakernel's single-level traversal walks nodes4 too (heavy scenes: set with nodeMin4)
   uint           statsWide;       // instrumented megakernel only: count the walk over nodes4 (what the wavefront trace kernel does on this scene)
   uint           nodeMin4;        // nodeMin for the walk over nodes4 (a 4-wide visit is three times the work of a BVH2 one: the vote pays earlier)
 

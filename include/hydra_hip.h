@@ -259,6 +259,9 @@ int  hpt_set_schedule(hpt_ctx* ctx, int schedule, int refillBelow, int traceBloc
  *   "dr_skip_nonfinite"     PathTraceDR: 1 = a sample whose radiance is not finite contributes neither colour, loss nor gradient (what an
  *                           optimisation loop wants: one NaN poisons Adam's moments for good); 0 (default) = PixelLossPT as the reference
  *                           has it, which adds every sample (diff_render/integrator_dr.cpp:1124-1131)
+ *   "wide_nodes"            0: the wavefront trace kernel walks the BVH2 instead of the 4-wide compressed tree of static single-level scenes
+ *                           (kernel studies; environment: HPT_WIDE_NODES=0)
+ *   "stats_wide"            1: the instrumented probe (hpt_set_instrumentation) counts the walk over the 4-wide tree
  *   "force_full_materials"  1: never pick the kernels specialised for gltf + emissive scenes (kernel studies)
  *   "dbg_no_normal_lerp"    1: moving instances without the reference's normal interpolation (integrator_pt.cpp:285-292); the checker has the
  *                           same switch (ORC_DBG_NO_NORMAL_LERP) - used to show where the rare path divergences under motion blur come from */

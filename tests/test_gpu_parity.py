@@ -1309,3 +1309,39 @@ def test_update_instance_refits_the_single_level_tree_on_the_device():
     d = moved.desc(); d.vPos4f = None; live._desc = d; live.CommitDeviceData(); live.InitRandomGens(live.N)
     assert live.commit_time()["refitted"]
     assert np.array_equal(live.render(3), HipIntegrator(moved).render(3))
+
+
+def test_wide_compressed_tree_returns_what_the_bvh2_returns():
+    """The 4-wide compressed tree of heavy single-level scenes (BvhNode4: 8-bit child bounds in the node's frame, hpt_types.h) only culls: ray queries
+    through it equal the oracle's brute force and the BVH2 walk bit for bit, and frames and generators under either schedule equal the ones
+    rendered with `wide_nodes` off - also after a device refit has requantised the nodes."""
+    from hydracore3_amd.api import HipIntegrator
+    from hydracore3_amd import scene as S, synth
+    from oracle.orc import OracleIntegrator
+    sc = synth.interior_scene(160, 96, subdiv=1, tex_size=16)                   # 17 K triangles in 206 instances, SAH estimate ~40
+    wide, narrow = HipIntegrator(sc), HipIntegrator(sc)
+    narrow.set_option("wide_nodes", 0)
+    assert wide.accel_info()["layout"] == "flat" and wide.accel_info()["sah_node_visits"] >= 20.0        # heavy: the megakernel walks the wide tree too
+    pos, dr = random_rays(30000, 23, -5.0, 5.0)
+    hw, hn = wide.RayQuery_NearestHit(pos, dr), narrow.RayQuery_NearestHit(pos, dr)
+    assert (hw["geomId"] != 0xFFFFFFFF).mean() > 0.5
+    assert np.array_equal(hw.view(np.uint8), hn.view(np.uint8))
+    hc = OracleIntegrator(sc).ray_nearest(pos[:4000], dr[:4000], brute=True)
+    for f in ("primId", "instId", "geomId"):
+        assert np.array_equal(hw[f][:4000], hc[f])
+    assert np.array_equal(hw["t"][:4000].view(np.uint32), hc["t"].view(np.uint32))
+    dr2 = dr.copy(); dr2[:, 3] = np.random.default_rng(4).uniform(0.3, 9.0, dr.shape[0]).astype(np.float32)
+    assert np.array_equal(wide.RayQuery_AnyHit(pos, dr2), narrow.RayQuery_AnyHit(pos, dr2))
+    for sched in (1, 2):
+        a, b = HipIntegrator(sc), HipIntegrator(sc)
+        b.set_option("wide_nodes", 0)
+        a.set_schedule(sched); b.set_schedule(sched)
+        assert np.array_equal(a.render(3), b.render(3)) and np.array_equal(a.random_gens(), b.random_gens())
+        assert a.last_schedule()[0] == sched
+    # refit: the requantised nodes still contain their subtrees
+    m = S.translate(0.4, 0.1, -0.5) @ np.asarray(sc.inst_matrices[6]) @ S.scale(1.3, 0.8, 1.1)
+    for g in (wide, narrow):
+        g.UpdateInstance(6, m); g.CommitScene()
+    assert wide.commit_time()["refitted"]
+    assert np.array_equal(wide.RayQuery_NearestHit(pos, dr).view(np.uint8), narrow.RayQuery_NearestHit(pos, dr).view(np.uint8))
+    assert not np.array_equal(wide.RayQuery_NearestHit(pos, dr).view(np.uint8), hw.view(np.uint8))

@@ -182,7 +182,7 @@ extern "C" int hpt_create(int device, hpt_ctx** out)
   (void)hipEventCreate(&c->ev0); (void)hipEventCreate(&c->ev1);
   if (const char* e = std::getenv("HPT_NODE_MIN")) c->nodeMinOverride = std::atoi(e) & 63;
   if (const char* e = std::getenv("HPT_WF_GRACE")) c->wfGrace = (uint)std::atoi(e);
-  if (const char* e = std::getenv("HPT_WIDE_NODES")) c->wideEnabled = std::atoi(e) != 0;
+  if (const char* e = std::getenv("HPT_WIDE_NODES")) c->wideEnabled = std::atoi(e) != 0;   // (read before any scene is committed: CommitScene derives DevScene::megaWide from it)
   std::memset(&c->S, 0, sizeof(DevScene));
   c->S.rootRef = REF_NONE;
   *out = c;
@@ -1811,7 +1811,7 @@ extern "C" int hpt_set_option(hpt_ctx* c, const char* name, int value)
   else if (k == "dbg_wf_iter_cap") c->wfIterCap = (uint)value;                         // diagnostic: make the wavefront loop's safety net reachable in a test
   else if (k == "dr_skip_nonfinite") c->drSkipNonFinite = value != 0;                  // PathTraceDR: drop samples whose radiance is not finite (default 0: PixelLossPT as in the reference)
   else if (k == "stats_wide") c->statsWide = value != 0;
-  else if (k == "wide_nodes") c->wideEnabled = value != 0;                             // 0: the wavefront trace kernel walks the BVH2 instead of the 4-wide compressed tree (A/B, diagnosis)
+  else if (k == "wide_nodes") { c->wideEnabled = value != 0; c->S.megaWide = (c->wideEnabled && c->nodes4Count != 0u && c->S.flatMode != 0u && c->sahVisits >= HEAVY_SAH_VISITS) ? 1u : 0u; }   // both users of the tree, at once                             // 0: the wavefront trace kernel walks the BVH2 instead of the 4-wide compressed tree (A/B, diagnosis)
   else if (k == "force_full_materials") c->forceFull = value != 0;                     // diagnostic: never pick the lean (gltf + emissive) kernels
   else return c->fail(HPT_ERR_ARG, "hpt_set_option: unknown option " + k);
   return HPT_OK;

@@ -12,8 +12,7 @@
 //
 // Scope of this kernel: the BSDFs of the reference's own spectral fixture (scenes/test_spectral/spectral_cornell_conductor.xml) -
 // diffuse (Lambert / Oren-Nayar) with a reflectance spectrum, smooth and rough conductors with eta / k spectra, emissive surfaces and
-// every analytic light with an intensity spectrum - in a plain one-thread-per-pixel kernel (no path regeneration, no work queue): a first
-// correct path, not yet a tuned one. hpt_update_params refuses spectral mode for scenes with other materials, spectral textures
+// every analytic light with an intensity spectrum - in a one-thread-per-pixel kernel with in-place path regeneration (no work queue). hpt_update_params refuses spectral mode for scenes with other materials, spectral textures
 // (lambda_ref_ids) or dispersion. With more than four channels the output is the reference's stack of wavelength layers.
 #include <hip/hip_runtime.h>
 #include "hpt_decl.h"
@@ -201,7 +200,7 @@ HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V
   return r;
 }
 
-// One path per pass, one thread per pixel of the call (the pixel's generator continues from pass to pass as in the RGB kernels).
+// One thread per pixel of the call, its passes one after the other (the pixel's generator continues from pass to pass as in the RGB kernels).
 template <bool DEEP, bool FLAT, bool SWEEP>
 __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene S, const Job job)
 {
@@ -222,19 +221,24 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
     if (job.channels == 1) pix[0] = job.outColor[pixel];
     else if (job.channels <= 4) { const float* o = job.outColor + (size_t)pixel * job.channels; pix[0] = o[0]; pix[1] = o[1]; pix[2] = o[2]; }
   }
-  for (uint pass = 0; pass < job.passNum; pass++) {
-    V3 rpos = v3(0, 0, 0), rdir = v3(0, 0, 1);
-    V4 waves = v4s(0.0f), accum = v4s(0.0f), thr = v4s(1.0f);
-    float misPdf = 1.0f;
-    uint flags = 0;
-    bool alive = valid;
-    if (valid) {
+  // In-place regeneration, as in the RGB megakernel but without its work queue: a lane whose path has ended starts its pixel's next pass at
+  // the top of the loop instead of waiting for the longest path of the wave, so every trip traces a ray for (nearly) all lanes.
+  V3 rpos = v3(0, 0, 0), rdir = v3(0, 0, 1);
+  V4 waves = v4s(0.0f), accum = v4s(0.0f), thr = v4s(1.0f);
+  float misPdf = 1.0f;
+  uint flags = 0, bounce = 0, passesLeft = valid ? job.passNum : 0u;
+  bool alive = false;
+  while (true) {
+    if (!alive && passesLeft != 0u) {
+      passesLeft--;
       const V4 lens = rng_float4(gen);                                       // GetRandomNumbersLens, then GetRandomNumbersSpec (integrator_pt.cpp:114-118)
       cameraRay<false>(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
       waves = sampleWavelengths(rng_float1(gen), LAMBDA_MIN, LAMBDA_MAX);
+      accum = v4s(0.0f); thr = v4s(1.0f); misPdf = 1.0f; flags = 0; bounce = 0;
+      alive = true;
     }
-    for (uint bounce = 0; bounce < S.traceDepth; bounce++) {
-      if (!__any(alive)) break;
+    if (!__any(alive)) break;
+    if (S.traceDepth != 0u) {                                                // (depth 0: the path is its camera ray and ends below)
       HitRec hit; hit.inst = 0xFFFFFFFFu; hit.prim = 0; hit.t = 0; hit.u = hit.v = 0;
       if (alive) traceAny<false, false, DEEP, FLAT, false, SWEEP>(S, rpos, rdir, 0.0f, HPT_FLT_MAX, hit, stk, st);
       bool wantShadow = false;
@@ -348,9 +352,10 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
         const bool occluded = traceAny<true, false, DEEP, FLAT, false, SWEEP>(S, shPos, shDir, 0.0f, shFar, sh, stk, st);
         if (!occluded) accum = accum + contrib;
       }
-      if (alive && (flags & RAY_FLAG_IS_DEAD) != 0) alive = false;
+      bounce++;
     }
-    if (valid) {
+    if (alive && ((flags & RAY_FLAG_IS_DEAD) != 0 || bounce >= S.traceDepth)) {
+      alive = false;
       // kernel_HitEnvironment with the constant colour (the environment spectrum m_envSpecId is not in this kernel's scope)
       if ((flags & RAY_FLAG_OUT_OF_SCENE) != 0) {
         const V4 env = ld4(S.envColor);

@@ -29,6 +29,7 @@ for seed in range(first, first + count):
     for l in sc.lights:
         l["flags"] = int(l["flags"]) & ~2; l["texId"] = 0xFFFFFFFF
     sc.inst_motion = {}
+    sc.lens_lines, sc.phys_size = np.zeros((0, 4), np.float32), (0.0, 0.0)      # (one fuzz scene in seven has a lens stack: not differentiated)
     g, c = HipIntegrator(sc), OracleIntegrator(sc)
     og, sg = g.PutDiffTex2D(1, 4, 4, 4)
     rc, oc, so = c.put_diff_tex2d(1, 4, 4, 4)

@@ -11,7 +11,7 @@
 // The tables (m_spec_values, m_spec_offset_sz, m_cie_xyz) come in through the C ABI with the other scene vectors: the host owns them.
 //
 // Scope of this kernel: the BSDFs of the reference's own spectral fixture (scenes/test_spectral/spectral_cornell_conductor.xml) -
-// diffuse (Lambert / Oren-Nayar) with a reflectance spectrum, smooth and rough conductors with eta / k spectra, emissive surfaces and
+// diffuse (Lambert / Oren-Nayar) and plastic with a reflectance spectrum, smooth and rough conductors with eta / k spectra, emissive surfaces and
 // every analytic light with an intensity spectrum - in a one-thread-per-pixel kernel with in-place path regeneration (no work queue). hpt_update_params refuses spectral mode for scenes with other materials, spectral textures
 // (lambda_ref_ids) or dispersion. With more than four channels the output is the reference's stack of wavelength layers.
 #include <hip/hip_runtime.h>
@@ -138,6 +138,14 @@ HPT_DEV SpecEval materialEvalSpec(const DevScene& S, const MaterialRec& m, V4 wa
     if ((m.cflags & GLTF_COMPONENT_ORENNAYAR) != 0) lambertVal *= orennayarFunc(l, v, n, m.data[0]);
     r.val = lambertVal * matColorSpectrum(S, m, waves, 0, 0);               // (not multiplied by the texture in spectral mode, :259-260)
     r.pdf = absf(dot(l, n)) * HPT_INV_PI;
+  } else if (m.mtype == MAT_TYPE_PLASTIC) {
+    // plasticEval on float4 (cmat_plastic.h:102-191): the reflectance enters channel by channel and nothing else depends on it, so the four
+    // wavelengths are two passes through the RGB routine - (x, y, z), then w in every slot - with the same arithmetic per channel
+    const V4 refl = matColorSpectrum(S, m, waves, 0, 0);                     // PLASTIC_COLOR; not multiplied by the texture in spectral mode (integrator_pt_mat.cpp:490-493)
+    BsdfE a, b; a.val = v3(0, 0, 0); a.pdf = 0.0f; a.dval = v3(0, 0, 0); b = a;
+    plasticEval(m, v3(refl.x, refl.y, refl.z), l, v, n, a, S.arrays1f, m.datai[0]);
+    plasticEval(m, v3(refl.w, refl.w, refl.w), l, v, n, b, S.arrays1f, m.datai[0]);
+    r.val = v4(a.val.x, a.val.y, a.val.z, b.val.x); r.pdf = a.pdf;
   } else if (m.mtype == MAT_TYPE_CONDUCTOR) {
     if (!(smax(m.data[1], m.data[0]) < 1e-3f)) {                            // trEffectivelySmooth: the smooth conductor evaluates to zero
       const V4 etaSpec = matParamSpectrum(S, m, waves, 2, 0), kSpec = matParamSpectrum(S, m, waves, 3, 1);
@@ -168,6 +176,13 @@ HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V
     r.pdf = absf(dot(lambertDir, n)) * HPT_INV_PI;
     r.flags = RAY_FLAG_HAS_NON_SPEC;
     if ((m.cflags & GLTF_COMPONENT_ORENNAYAR) != 0) r.val = r.val * orennayarFunc(lambertDir, (-1.0f) * v, n, m.data[0]);
+  } else if (m.mtype == MAT_TYPE_PLASTIC) {                                  // plasticSampleAndEval on float4 (cmat_plastic.h:7-99), as in materialEvalSpec
+    const V4 refl = matColorSpectrum(S, m, waves, 0, 0);
+    BsdfS a; a.val = v3(0, 0, 0); a.dval = v3(0, 0, 0); a.pdf = 1.0f; a.dir = v3(0, 1, 0); a.flags = flags0; a.ior = 1.0f;
+    BsdfS b = a;
+    plasticSampleAndEval(m, v3(refl.x, refl.y, refl.z), rands, v, n, a, S.arrays1f, m.datai[0]);
+    plasticSampleAndEval(m, v3(refl.w, refl.w, refl.w), rands, v, n, b, S.arrays1f, m.datai[0]);
+    r.val = v4(a.val.x, a.val.y, a.val.z, b.val.x); r.dir = a.dir; r.pdf = a.pdf; r.flags = a.flags;
   } else if (m.mtype == MAT_TYPE_CONDUCTOR) {
     const V4 etaSpec = matParamSpectrum(S, m, waves, 2, 0), kSpec = matParamSpectrum(S, m, waves, 3, 1);
     if (smax(m.data[1], m.data[0]) < 1e-3f) {

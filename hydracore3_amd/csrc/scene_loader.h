@@ -872,6 +872,21 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
       if (const XmlNode* nl = mn->child("nonlinear")) mat.nonlinear = (uint32_t)std::atof((nl->has("val") ? nl->get("val") : nl->text).c_str());
       const plastic::CoatPrecomputed pre = plastic::fresnelCoatPrecompute(mat.data[0], intIor, extIor, mat.colors[0], one4);
       mat.data[3] = pre.internalReflectance; mat.data[2] = pre.specularSamplingWeight;
+      mat.spdid[0] = spectrumId(mn->child("reflectance"));                    // (:704-705)
+      if (spectral) {
+        // mi::fresnel_coat_precompute in spectral mode (mi_materials.cpp:383-404): s_mean = 1 over four components, d_mean = the mean of the
+        // reflectance spectrum (mi::spectrum_mean: trapezoid rule over 360 .. 830 nm in double), 0.5 without one
+        float dMean = 0.5f;
+        const uint32_t sid = mat.spdid[0];
+        if (sid != 0xFFFFFFFFu && 2 * (size_t)sid + 1 < sc.specOffsetSz.size() && sc.specOffsetSz[2 * sid] != 0xFFFFFFFFu) {
+          const float* v = sc.specValues.data() + sc.specOffsetSz[2 * sid]; const size_t n = sc.specOffsetSz[2 * sid + 1];
+          const double interval = (double(kLambdaMax) - double(kLambdaMin)) / double(n - 1);
+          double integral = 0.0;
+          for (size_t i = 0; i + 1 < n; i++) integral += 0.5 * interval * ((double)v[i] + (double)v[i + 1]);
+          dMean = float(integral) / (kLambdaMax - kLambdaMin);
+        }
+        mat.data[2] = 1.0f / (dMean + 1.0f);
+      }
       mat.datai[0] = (uint32_t)sc.arrays1f.size();
       sc.arrays1f.insert(sc.arrays1f.end(), pre.transmittance, pre.transmittance + plastic::TRANSMITTANCE_RES);
     } else if (type == "blend") {                                             // LoadBlendMaterial (:619-647)

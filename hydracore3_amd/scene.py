@@ -794,6 +794,21 @@ def load_spd(path):
     return w, v
 
 
+def spectrum_mean(values):
+    """mi::spectrum_mean (mi_materials.cpp:331-374): trapezoid integral of the resampled spectrum over [LAMBDA_MIN, LAMBDA_MAX] in double,
+    divided by the range in float."""
+    v = np.asarray(values, np.float32).astype(np.float64)
+    if v.size < 2 or (v < 0).any():
+        raise ValueError("spectrum_mean: a spectrum needs two non-negative samples at least")
+    interval = (float(LAMBDA_MAX) - float(LAMBDA_MIN)) / (v.size - 1)
+    integral = 0.0
+    for i in range(v.size - 1):                                           # summed in the reference's order
+        integral += 0.5 * interval * (v[i] + v[i + 1])
+    if integral <= 0.0:
+        raise ValueError("spectrum_mean: no probability mass")
+    return np.float32(np.float32(integral) / np.float32(LAMBDA_MAX - LAMBDA_MIN))
+
+
 def cie_xyz_fit():
     """The CIE 1931 2-degree observer at 360..830 nm, float32 [471, 4] = {x, y, z, 0}. The reference carries the tabulated functions in its
     source (spectrum.cpp) and hands them to the integrator as m_cie_xyz; no other copy exists in this image, so the fixture loaders use the
@@ -1298,8 +1313,19 @@ def load_hydra_xml(xml_path: str, width=None, height=None, spectral=False) -> Sc
         r0, r1, tid = load_texture_from_node(rn) if rn is not None else ((0, 0, 0, 0), (0, 0, 0, 0), 0)
         nl = mnode.find("nonlinear")
         nonlinear = int(float(nl.get("val") if nl.get("val") is not None else (nl.text or 0))) if nl is not None else 0
-        return sc.material_plastic(color, float(val1f(mnode.find("alpha"), 0.1)), float(val1f(mnode.find("int_ior"), 1.49)),
-                                   float(val1f(mnode.find("ext_ior"), 1.000277)), nonlinear, tid, r0, r1)
+        mat = sc.material_plastic(color, float(val1f(mnode.find("alpha"), 0.1)), float(val1f(mnode.find("int_ior"), 1.49)),
+                                  float(val1f(mnode.find("ext_ior"), 1.000277)), nonlinear, tid, r0, r1)
+        mat["spdid"][0] = spectrum_id(rn)                                     # (:704-705)
+        if spectral:
+            # mi::fresnel_coat_precompute in spectral mode (mi_materials.cpp:383-404): the specular reflectance (1, 1, 1, 1) averages to 1 over FOUR
+            # components, the diffuse mean is the mean of the reflectance spectrum (trapezoid rule over 360 .. 830 nm), or 0.5 without one
+            sid = int(mat["spdid"][0])
+            d_mean = np.float32(0.5)
+            if sid != UINT_MAX and sc.spec_offset_sz[sid][0] != UINT_MAX:
+                off, sz = sc.spec_offset_sz[sid]
+                d_mean = spectrum_mean(sc.spec_values[off:off + sz])
+            mat["data"][2] = np.float32(1.0) / (d_mean + np.float32(1.0))      # PLASTIC_SPEC_SAMPLE_WEIGHT = s_mean / (d_mean + s_mean)
+        return mat
 
     typed_loaders = {"plastic": load_plastic, "gltf": convert_gltf, "rough_conductor": load_rough_conductor, "diffuse": load_diffuse,
                      "dielectric": load_dielectric, "blend": load_blend}

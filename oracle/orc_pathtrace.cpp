@@ -164,7 +164,7 @@ struct Ctx
   }
 
   // ---- spectral rendering (m_spectral_mode != 0): spectrum.h + integrator_spectrum.cpp --------------------------------------
-  // Restated for what the reference's own spectral fixture exercises: diffuse and conductor BSDFs, emissive surfaces, analytic lights.
+  // Restated for what the reference's own spectral fixture exercises - diffuse and conductor BSDFs, emissive surfaces, analytic lights - and plastic.
   // The other BSDFs keep their RGB parameters here; spectral textures (lambda_ref_ids), thin films and the environment spectrum are not restated.
   static constexpr float LAMBDA_MIN = 360.0f, LAMBDA_MAX = 830.0f;     // include/cglobals.h:22-23
   static f4 SampleWavelengths(float u, float a, float b)               // spectrum.h:58-75
@@ -372,7 +372,8 @@ struct Ctx
       } break;
       case MAT_TYPE_GLASS: glassSampleAndEval(m, rands, v, geomNormal, &res, &a_misPrev->ior); break;    // integrator_pt_mat.cpp:178-183: the geometric normal
       case MAT_TYPE_PLASTIC: {                                                                     // :270-282 (RGB mode)
-        const f4 reflSpec = m.colors[0] * texColor;                                                  // PLASTIC_COLOR x texture (integrator_spectrum.cpp:128-133 RGB early-out)
+        f4 reflSpec = SampleMatColorSpectrumTexture(currMatId, wavelengths, 0, 0);                  // PLASTIC_COLOR (integrator_pt_mat.cpp:268-271)
+        if (p.spectralMode == 0) reflSpec = reflSpec * texColor;
         plasticSampleAndEval(m, reflSpec, rands, v, shadeNormal, &res, sc.arrays1f.data(), m.datai[0]);
       } break;
       case MAT_TYPE_DIELECTRIC: {
@@ -442,7 +443,8 @@ struct Ctx
           res.pdf += currVal.pdf * weight;
         } break;
         case MAT_TYPE_PLASTIC: {                                                      // :484-499
-          const f4 reflSpec = m.colors[0] * texColor;
+          f4 reflSpec = SampleMatColorSpectrumTexture(currMat.id, wavelengths, 0, 0);               // (integrator_pt_mat.cpp:490-493)
+          if (p.spectralMode == 0) reflSpec = reflSpec * texColor;
           plasticEval(m, reflSpec, l, v, shadeNormal, &currVal, sc.arrays1f.data(), m.datai[0]);
           res.val = res.val + currVal.val * weight * bumpCosMult;
           res.pdf += currVal.pdf * weight;

@@ -119,6 +119,28 @@ def test_smooth_conductor_and_constant_parameters():
         assert l2 < 1e-3
 
 
+def test_spectral_plastic_matches_oracle():
+    """The `plastic` node in spectral mode (integrator_pt_mat.cpp:264-275, 486-500; mi::fresnel_coat_precompute's spectral branch,
+    mi_materials.cpp:383-404): a rough plastic sphere with a reflectance spectrum and the nonlinear colour shift, smooth grey plastic walls
+    without a spectrum (tests/golden/scenes/spectral_plastic, derived from the reference's spectral fixture by make_spectral_plastic_scene.py).
+    The kernel runs the RGB routine twice per vertex - (x, y, z), then w - which is the float4 arithmetic channel by channel."""
+    xml = scene_path("spectral_plastic")
+    for spectral in (True, False):
+        sc = load_hydra_xml(xml, 96, 96, spectral=spectral)
+        gpu, cpu = _pair(sc)
+        a, b = gpu.render(12), cpu.render(12)
+        l2 = _l2(a, b, 12)
+        same = float(np.mean(np.all(a[..., :3] == b[..., :3], axis=-1)))
+        gens = float(np.mean(np.all(gpu.random_gens() == cpu.random_gens(), axis=1)))
+        print(f"spectral={spectral}: per-pixel L2 = {l2:.3e} (mean {b[..., :3].mean() / 12:.4f}), bit-identical pixels {same * 100:.2f} %, identical generators {gens * 100:.2f} %")
+        assert np.isfinite(a).all() and a[..., :3].mean() > 0
+        assert l2 < 1e-3 and same > 0.1 and gens > 0.99
+    # the sampling weight of the spectral precomputation: 1 / (mean of the reflectance spectrum + 1), 1 / 1.5 without a spectrum
+    sc = load_hydra_xml(xml, 32, 32, spectral=True)
+    w = sorted(float(m["data"][2]) for m in sc.materials if int(m["mtype"]) == 5)
+    assert w[0] == pytest.approx(1.0 / 1.5) and 0.8 < w[1] < 0.95
+
+
 def test_camera_response_spectra():
     """SpectralCamRespoceToRGB with m_camResponseSpectrumId set (integrator_spectrum.cpp:76-121): the response spectra replace the CIE
     observer; both response types (0 = CAM_RESPONCE_XYZ: through XYZToRGB, 1 = CAM_RESPONCE_RGB: taken as it is)."""

@@ -11,9 +11,9 @@
 // The tables (m_spec_values, m_spec_offset_sz, m_cie_xyz) come in through the C ABI with the other scene vectors: the host owns them.
 //
 // Scope of this kernel: the BSDFs of the reference's own spectral fixture (scenes/test_spectral/spectral_cornell_conductor.xml) -
-// diffuse (Lambert / Oren-Nayar) and plastic with a reflectance spectrum, smooth and rough conductors with eta / k spectra, emissive surfaces and
-// every analytic light with an intensity spectrum - in a one-thread-per-pixel kernel with in-place path regeneration (no work queue). hpt_update_params refuses spectral mode for scenes with other materials, spectral textures
-// (lambda_ref_ids) or dispersion. With more than four channels the output is the reference's stack of wavelength layers.
+// diffuse (Lambert / Oren-Nayar) and plastic with a reflectance spectrum, smooth dielectrics with an IOR spectrum (dispersion), smooth and rough conductors with eta / k spectra, emissive surfaces and
+// every analytic light with an intensity spectrum - in a one-thread-per-pixel kernel with in-place path regeneration (no work queue). hpt_update_params refuses spectral mode for scenes with other materials or spectral textures
+// (lambda_ref_ids). With more than four channels the output is the reference's stack of wavelength layers.
 #include <hip/hip_runtime.h>
 #include "hpt_decl.h"
 
@@ -92,14 +92,16 @@ HPT_DEV V4 lightIntensitySpec(const DevScene& S, const LightRec& L, V4 waves, V3
 }
 
 // SpectrumToXYZ + XYZToRGB (spectrum.h:151-214), all four wavelengths alive (no dispersion in scope)
-HPT_DEV V3 spectrumToRGB(const DevScene& S, V4 spec, V4 lambda)
+HPT_DEV V3 spectrumToRGB(const DevScene& S, V4 spec, V4 lambda, bool terminateWaves)
 {
-  const float pdf = 1.0f / (LAMBDA_MAX - LAMBDA_MIN);
+  const float pdf0 = 1.0f / (LAMBDA_MAX - LAMBDA_MIN);
   const float CIE_Y_integral = 106.856895f;
   float X = 0.0f, Y = 0.0f, Z = 0.0f;
   float xs[4], ys[4], zs[4];
   for (int i = 0; i < 4; i++) {
-    const float s = comp(spec, i) / pdf;
+    // a path that met a dispersive surface keeps its first wavelength only (terminate_waves: pdf[0] / 4, the others 0 and their samples dropped)
+    const float pdf = terminateWaves ? (i == 0 ? pdf0 / 4.0f : 0.0f) : pdf0;
+    const float s = (pdf != 0.0f) ? comp(spec, i) / pdf : 0.0f;
     const uint offset = (uint)(floorf(comp(lambda, i) + 0.5f) - LAMBDA_MIN);
     float cx = 0.0f, cy = 0.0f, cz = 0.0f;
     if (offset < 471u && offset < S.numCieXYZ) { const float4 c = S.cieXYZ[offset]; cx = c.x; cy = c.y; cz = c.z; }
@@ -112,9 +114,9 @@ HPT_DEV V3 spectrumToRGB(const DevScene& S, V4 spec, V4 lambda)
   return v3(+3.240479f * x - 1.537150f * y - 0.498535f * z, -0.969256f * x + 1.875991f * y + 0.041556f * z, +0.055648f * x - 0.204043f * y + 1.057311f * z);
 }
 // SpectralCamRespoceToRGB (integrator_spectrum.cpp:68-124)
-HPT_DEV V3 spectralCamResponseToRGB(const DevScene& S, V4 spec, V4 waves)
+HPT_DEV V3 spectralCamResponseToRGB(const DevScene& S, V4 spec, V4 waves, uint rayFlags)
 {
-  if (S.camResponseSpectrumId[0] < 0) return spectrumToRGB(S, spec, waves);
+  if (S.camResponseSpectrumId[0] < 0) return spectrumToRGB(S, spec, waves, (rayFlags & RAY_FLAG_WAVES_DIVERGED) != 0u);
   V4 rX = v4s(1.0f), rY, rZ;
   rX = sampleUniformSpectrum(S.specValues, S.specOffsetSz[2 * S.camResponseSpectrumId[0]], waves);
   rY = S.camResponseSpectrumId[1] >= 0 ? sampleUniformSpectrum(S.specValues, S.specOffsetSz[2 * S.camResponseSpectrumId[1]], waves) : rX;
@@ -127,7 +129,7 @@ HPT_DEV V3 spectralCamResponseToRGB(const DevScene& S, V4 spec, V4 waves)
 }
 
 struct SpecEval { V4 val; float pdf; };
-struct SpecSample { V4 val; V3 dir; float pdf; uint flags; };
+struct SpecSample { V4 val; V3 dir; float pdf; uint flags; float ior; };
 
 // MaterialEval, spectral (integrator_pt_mat.cpp:405-420, 471-482 with cmat_conductor.h:103-137, cmat_diffuse.h:27-39)
 HPT_DEV SpecEval materialEvalSpec(const DevScene& S, const MaterialRec& m, V4 waves, V3 l, V3 v, V3 n, V3 texColor3)
@@ -166,9 +168,9 @@ HPT_DEV SpecEval materialEvalSpec(const DevScene& S, const MaterialRec& m, V4 wa
   return r;
 }
 // MaterialSampleAndEval, spectral (integrator_pt_mat.cpp:184-196, 252-263 with cmat_conductor.h:7-100, cmat_diffuse.h:8-24)
-HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V4 waves, V4 rands, V3 v, V3 n, V3 texColor3, uint flags0)
+HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V4 waves, V4 rands, V3 v, V3 n, V3 texColor3, uint flags0, float prevIor)
 {
-  SpecSample r; r.val = v4s(0.0f); r.pdf = 1.0f; r.dir = v3(0, 1, 0); r.flags = flags0;
+  SpecSample r; r.val = v4s(0.0f); r.pdf = 1.0f; r.dir = v3(0, 1, 0); r.flags = flags0; r.ior = 1.0f;
   if (m.mtype == MAT_TYPE_DIFFUSE) {
     const V3 lambertDir = mapSampleToCosineDistribution(rands.x, rands.y, n, n, 1.0f);
     r.dir = lambertDir;
@@ -176,6 +178,13 @@ HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V
     r.pdf = absf(dot(lambertDir, n)) * HPT_INV_PI;
     r.flags = RAY_FLAG_HAS_NON_SPEC;
     if ((m.cflags & GLTF_COMPONENT_ORENNAYAR) != 0) r.val = r.val * orennayarFunc(lambertDir, (-1.0f) * v, n, m.data[0]);
+  } else if (m.mtype == MAT_TYPE_DIELECTRIC) {
+    // dielectricSmoothSampleAndEval (cmat_dielectric.h:8-56): the IOR of the FIRST wavelength decides the direction; a surface whose IOR is a
+    // spectrum marks the path (RAY_FLAG_WAVES_DIVERGED): only that wavelength reaches the image (integrator_pt_mat.cpp:277-287)
+    const V4 etaSpec = matParamSpectrum(S, m, waves, 1, 0);                  // DIELECTRIC_ETA_INT
+    BsdfS a; a.val = v3(0, 0, 0); a.dval = v3(0, 0, 0); a.pdf = 1.0f; a.dir = v3(0, 1, 0); a.flags = flags0; a.ior = 1.0f;
+    dielectricSmoothSampleAndEval(m, etaSpec.x, prevIor, rands, v, n, a);
+    r.val = v4s(a.val.x); r.dir = a.dir; r.pdf = a.pdf; r.flags = a.flags | ((m.spdid[0] < 0xFFFFFFFFu) ? RAY_FLAG_WAVES_DIVERGED : 0u); r.ior = a.ior;
   } else if (m.mtype == MAT_TYPE_PLASTIC) {                                  // plasticSampleAndEval on float4 (cmat_plastic.h:7-99), as in materialEvalSpec
     const V4 refl = matColorSpectrum(S, m, waves, 0, 0);
     BsdfS a; a.val = v3(0, 0, 0); a.dval = v3(0, 0, 0); a.pdf = 1.0f; a.dir = v3(0, 1, 0); a.flags = flags0; a.ior = 1.0f;
@@ -240,7 +249,7 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
   // the top of the loop instead of waiting for the longest path of the wave, so every trip traces a ray for (nearly) all lanes.
   V3 rpos = v3(0, 0, 0), rdir = v3(0, 0, 1);
   V4 waves = v4s(0.0f), accum = v4s(0.0f), thr = v4s(1.0f);
-  float misPdf = 1.0f;
+  float misPdf = 1.0f, misIor = 1.0f;                                        // MisData: matSamplePdf, ior (the medium the ray travels in)
   uint flags = 0, bounce = 0, passesLeft = valid ? job.passNum : 0u;
   bool alive = false;
   while (true) {
@@ -249,7 +258,7 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
       const V4 lens = rng_float4(gen);                                       // GetRandomNumbersLens, then GetRandomNumbersSpec (integrator_pt.cpp:114-118)
       cameraRay<false>(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
       waves = sampleWavelengths(rng_float1(gen), LAMBDA_MIN, LAMBDA_MAX);
-      accum = v4s(0.0f); thr = v4s(1.0f); misPdf = 1.0f; flags = 0; bounce = 0;
+      accum = v4s(0.0f); thr = v4s(1.0f); misPdf = 1.0f; misIor = 1.0f; flags = 0; bounce = 0;
       alive = true;
     }
     if (!__any(alive)) break;
@@ -344,7 +353,8 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
             wantShadow = false;
           } else {
             const V4 rands = rng_float4(gen);                                // GetRandomNumbersMats
-            const SpecSample ms = materialSampleSpec(S, m, waves, rands, vdir, hitNorm, tex3, (flags & 0xFF000000u) | matId);
+            const SpecSample ms = materialSampleSpec(S, m, waves, rands, vdir, hitNorm, tex3, (flags & 0xFF000000u) | matId, misIor);
+            if (mtype == MAT_TYPE_DIELECTRIC) misIor = ms.ior;
             const float invPdf = 1.0f / smax(ms.pdf, 1e-20f);
             const V4 bxdfVal = ms.val * invPdf;
             const float cosTheta = absf(dot(ms.dir, hitNorm));
@@ -386,7 +396,7 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
           job.outColor[(size_t)channelId * (size_t)(S.winWidth * S.winHeight) + pixel] += comp(color, i);   // the pixel is this thread's alone
         }
       }
-      else { const V3 rgb = spectralCamResponseToRGB(S, accum, waves); pix[0] += S.exposureMult * rgb.x; pix[1] += S.exposureMult * rgb.y; pix[2] += S.exposureMult * rgb.z; }
+      else { const V3 rgb = spectralCamResponseToRGB(S, accum, waves, flags); pix[0] += S.exposureMult * rgb.x; pix[1] += S.exposureMult * rgb.y; pix[2] += S.exposureMult * rgb.z; }
     }
   }
   if (valid) {

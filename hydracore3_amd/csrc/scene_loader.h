@@ -858,7 +858,7 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
     } else if (type == "dielectric") {                                        // LoadDielectricMaterial (:574-616), RGB mode
       for (int k = 0; k < 4; k++) { mat.colors[0][k] = 1.0f; mat.colors[1][k] = 1.0f; }
       mat.mtype = 7; mat.lightId = 0xFFFFFFFFu; mat.data[0] = 1.00028f; mat.data[1] = 1.5046f;
-      if (const XmlNode* n = mn->child("int_ior")) mat.data[1] = attrFloat(n);
+      if (const XmlNode* n = mn->child("int_ior")) { mat.data[1] = attrFloat(n); mat.spdid[0] = spectrumId(n); }   // dispersion: an IOR spectrum (:590-595)
       if (const XmlNode* n = mn->child("ext_ior")) mat.data[0] = attrFloat(n);
       if (const XmlNode* n = mn->child("reflectance")) color4(n, mat.colors[0]);
       if (const XmlNode* n = mn->child("transmittance")) color4(n, mat.colors[1]);

@@ -1284,6 +1284,7 @@ def load_hydra_xml(xml_path: str, width=None, height=None, spectral=False) -> Sc
         mat["data"][0], mat["data"][1] = 1.00028, 1.5046                       # DIELECTRIC_ETA_EXT (air), DIELECTRIC_ETA_INT (bk7)
         if mnode.find("int_ior") is not None:
             mat["data"][1] = attr_float(mnode.find("int_ior"))
+            mat["spdid"][0] = spectrum_id(mnode.find("int_ior"))               # dispersion: an IOR spectrum (:590-595)
         if mnode.find("ext_ior") is not None:
             mat["data"][0] = attr_float(mnode.find("ext_ior"))
         if mnode.find("reflectance") is not None:

@@ -377,7 +377,7 @@ struct Ctx
         plasticSampleAndEval(m, reflSpec, rands, v, shadeNormal, &res, sc.arrays1f.data(), m.datai[0]);
       } break;
       case MAT_TYPE_DIELECTRIC: {
-        const f4 intIORSpec = splat4(m.data[DIELECTRIC_ETA_INT]);
+        const f4 intIORSpec = SampleMatParamSpectrum(currMatId, wavelengths, DIELECTRIC_ETA_INT, 0);   // (integrator_pt_mat.cpp:280)
         const uint specId = m.spdid[0];
         dielectricSmoothSampleAndEval(m, intIORSpec, a_misPrev->ior, rands, v, shadeNormal, tc, &res);
         res.flags |= (specId < 0xFFFFFFFFu) ? RAY_FLAG_WAVES_DIVERGED : 0;

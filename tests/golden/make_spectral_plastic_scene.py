@@ -1,4 +1,4 @@
-"""Writes tests/golden/scenes/spectral_plastic/statex_00001.xml: the reference's spectral Cornell fixture (tests/golden/scenes/test_spectral,
+"""Writes tests/golden/scenes/spectral_plastic/statex_00001.xml and tests/golden/scenes/spectral_glass/statex_00001.xml: the reference's spectral Cornell fixture (tests/golden/scenes/test_spectral,
 = scenes/test_spectral/spectral_cornell_conductor.xml) with its sphere turned into a rough plastic with a reflectance SPECTRUM (nonlinear
 colour shift on) and its white walls into a smooth plastic with a plain grey reflectance - the two forms of the `plastic` node the
 reference's spectral test list exercises (testing/run_tests.py:480-511: PlasticRough-025_sphere, Spectral-plastic-sphere). Meshes, spectra and
@@ -36,4 +36,21 @@ out = material(out, 3, '''<material id="3" name="white_plastic" type="plastic">
 dst = os.path.join(here, "scenes", "spectral_plastic", "statex_00001.xml")
 os.makedirs(os.path.dirname(dst), exist_ok=True)
 open(dst, "w", encoding="utf-8").write(out)
+print("wrote", dst)
+
+# tests/golden/scenes/spectral_glass: the sphere as a smooth dielectric whose interior IOR is a SPECTRUM given inline (ParseSpectrumStr's
+# "lambda value ..." form; a flint-like dispersion curve) - the dispersive case: the first wavelength's IOR bends the ray and the path keeps
+# that wavelength only (RAY_FLAG_WAVES_DIVERGED) - and the short box as a plain dielectric without a spectrum (testing/run_tests.py:482-483,
+# 502-503: Spectral-ior-sphere, Spectral-ior-model)
+glass = src.replace('loc="data/', 'loc="../test_spectral/data/')
+glass = glass.replace("</spectra_lib>", '  <spectrum id="7" name="flint_ior" value="360 1.70 400 1.68 450 1.66 500 1.645 550 1.635 600 1.628 650 1.623 700 1.619 760 1.615 830 1.612" />\n</spectra_lib>')
+glass = material(glass, 4, '''<material id="4" name="dispersive_glass" type="dielectric">
+    <int_ior val="1.63">
+      <spectrum id="7" type="ref"/>
+    </int_ior>
+    <ext_ior val="1.00028" />
+  </material>''')
+dst = os.path.join(here, "scenes", "spectral_glass", "statex_00001.xml")
+os.makedirs(os.path.dirname(dst), exist_ok=True)
+open(dst, "w", encoding="utf-8").write(glass)
 print("wrote", dst)

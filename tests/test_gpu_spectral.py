@@ -141,6 +141,37 @@ def test_spectral_plastic_matches_oracle():
     assert w[0] == pytest.approx(1.0 / 1.5) and 0.8 < w[1] < 0.95
 
 
+def test_dispersive_dielectric_matches_oracle():
+    """A smooth dielectric whose interior IOR is a spectrum (cmat_dielectric.h:8-56, integrator_pt_mat.cpp:277-287): the first wavelength's IOR
+    bends the ray, the path is marked RAY_FLAG_WAVES_DIVERGED and SpectrumToXYZ keeps that wavelength only, at four times the weight
+    (spectrum.h:157-170). Own fixture (make_spectral_plastic_scene.py): the reference's spectral Cornell box with a flint-like glass sphere."""
+    xml = scene_path("spectral_glass")
+    for spectral, channels in ((True, 4), (True, 16), (False, 4)):
+        sc = load_hydra_xml(xml, 96, 96, spectral=spectral)
+        gpu, cpu = _pair(sc)
+        a = np.zeros(96 * 96 * channels, np.float32); b = a.copy()
+        gpu.PathTraceBlock(gpu.N, channels, a, 12)
+        cpu.path_trace_block(b, 12, channels=channels)
+        gens = float(np.mean(np.all(gpu.random_gens() == cpu.random_gens(), axis=1)))
+        if channels == 4:
+            ia, ib = a.reshape(96, 96, 4), b.reshape(96, 96, 4)
+            l2 = _l2(ia, ib, 12)
+        else:
+            d = (a.reshape(16, 96, 96).astype(np.float64) - b.reshape(16, 96, 96)) / 12
+            l2 = float(np.sqrt(np.mean(np.sum(d * d, axis=0))))
+        print(f"spectral={spectral}, channels={channels}: per-pixel L2 = {l2:.3e}, bit-identical values {np.mean(a == b) * 100:.2f} %, identical generators {gens * 100:.2f} %")
+        assert np.isfinite(a).all() and a.sum() > 0
+        assert l2 < 1e-3 and np.mean(a == b) > 0.3 and gens > 0.99
+    # dispersion is there: the sphere's pixels differ between the dispersive glass and the same glass with a constant IOR
+    sc = load_hydra_xml(xml, 64, 64, spectral=True)
+    from hydracore3_amd.api import HipIntegrator
+    disp = HipIntegrator(sc).render(16)
+    for m in sc.materials:
+        if int(m["mtype"]) == 7: m["spdid"][0] = 0xFFFFFFFF
+    flat = HipIntegrator(sc).render(16)
+    assert not np.array_equal(disp, flat)
+
+
 def test_camera_response_spectra():
     """SpectralCamRespoceToRGB with m_camResponseSpectrumId set (integrator_spectrum.cpp:76-121): the response spectra replace the CIE
     observer; both response types (0 = CAM_RESPONCE_XYZ: through XYZToRGB, 1 = CAM_RESPONCE_RGB: taken as it is)."""

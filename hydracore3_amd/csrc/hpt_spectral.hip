@@ -91,7 +91,7 @@ HPT_DEV V4 lightIntensitySpec(const DevScene& S, const LightRec& L, V4 waves, V3
   return lightColor;
 }
 
-// SpectrumToXYZ + XYZToRGB (spectrum.h:151-214), all four wavelengths alive (no dispersion in scope)
+// SpectrumToXYZ + XYZToRGB (spectrum.h:151-214); terminateWaves: the path met a dispersive surface (RAY_FLAG_WAVES_DIVERGED)
 HPT_DEV V3 spectrumToRGB(const DevScene& S, V4 spec, V4 lambda, bool terminateWaves)
 {
   const float pdf0 = 1.0f / (LAMBDA_MAX - LAMBDA_MIN);

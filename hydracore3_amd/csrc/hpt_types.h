@@ -45,7 +45,10 @@ static_assert(sizeof(LightRec) == 320, "LightSource record must stay 320 bytes")
 static const uint REF_LEAF    = 0x80000000u;
 static const uint REF_RESTORE = 0xFFFFFFFFu;
 static const uint REF_NONE    = 0xFFFFFFFEu;   // empty scene
-static const int  BVH_LEAF_MAX = 2;   // measured on MI355X: 4 -> 1371, 2 -> 1800, 1 -> 1676 Mpaths/s (Cornell); no effect on the 1M-triangle scene
+#ifndef HPT_BVH_LEAF_MAX
+#define HPT_BVH_LEAF_MAX 2
+#endif
+static const int  BVH_LEAF_MAX = HPT_BVH_LEAF_MAX;   // measured on MI355X: 4 -> 1371, 2 -> 1800, 1 -> 1676 Mpaths/s (Cornell, round 1); 1M triangles on the 4-wide tree: 1 / 2 / 3 / 4 -> 280 / 288 / 281 / 273
 
 struct BvhNode { float q[12]; uint ref0, ref1, pad0, pad1; };   // q = child 0 {lo.x hi.x lo.y hi.y lo.z hi.z}, child 1 {same}: (lo, hi) pairs feed v_pk_* slab tests
 static_assert(sizeof(BvhNode) == 64, "BVH2 node must be one 64-byte line");

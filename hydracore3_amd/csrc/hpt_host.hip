@@ -1052,6 +1052,7 @@ extern "C" int hpt_update_params(hpt_ctx* c, const hpt_params* p)
   if (p->spectralMode > 1) return c->fail(HPT_ERR_ARG, "bad spectral mode");
   if (p->spectralMode == 1 && !c->sceneUploaded) return c->fail(HPT_ERR_STATE, "UpdateMembersPlainData with m_spectral_mode before CommitDeviceData");
   if (p->spectralMode == 1 && !c->spectralOk) return c->fail(HPT_ERR_UNSUPPORTED, "spectral rendering: " + c->spectralWhyNot);
+  if (p->spectralMode == 1 && p->envSpecIdPlus1 != 0u && p->envSpecIdPlus1 - 1u >= c->S.numSpectra) return c->fail(HPT_ERR_ARG, "m_envSpecId refers to a spectrum that does not exist");
   if (p->winWidth <= 0 || p->winHeight <= 0 || p->fbWidth <= 0 || p->fbHeight <= 0 || p->winWidth > 65535 || p->winHeight > 65535) return c->fail(HPT_ERR_ARG, "bad viewport");
   if (p->tileSize != 1 && p->tileSize != 2 && p->tileSize != 4 && p->tileSize != 8) return c->fail(HPT_ERR_ARG, "bad tile size");
   // kernel_PackXY tiles the window without a remainder (integrator_rt.cpp:13-31); SetViewport only ever picks a tile size that divides both
@@ -1064,6 +1065,7 @@ extern "C" int hpt_update_params(hpt_ctx* c, const hpt_params* p)
   S.traceDepth = p->traceDepth; S.integratorType = p->integratorType; S.renderLayer = p->renderLayer; S.tileSize = p->tileSize;
   S.exposureMult = p->exposureMult; S.camLensRadius = p->camLensRadius; S.camTargetDist = p->camTargetDist;
   S.spectralMode = p->spectralMode;
+  S.envSpecId = p->envSpecIdPlus1 - 1u; S.envSpecMult = p->envSpecMult;   // (0 -> 0xFFFFFFFF: none)
   std::memcpy(S.camRespoceRGB, p->camRespoceRGB, 16); std::memcpy(S.envColor, p->envColor, 16);
   // the environment map (integrator_pt_scene.cpp:441-478): ids are checked against what CommitDeviceData uploaded
   if ((p->envTexId != 0xFFFFFFFFu || p->envCamBackId != 0xFFFFFFFFu || p->envLightId != 0xFFFFFFFFu) && !c->sceneUploaded)

@@ -381,9 +381,10 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
     }
     if (alive && ((flags & RAY_FLAG_IS_DEAD) != 0 || bounce >= S.traceDepth)) {
       alive = false;
-      // kernel_HitEnvironment with the constant colour (the environment spectrum m_envSpecId is not in this kernel's scope)
+      // kernel_HitEnvironment / EnvironmentColor without a map (integrator_pt_lgt.cpp:175-189): the constant colour, or the environment's spectrum
       if ((flags & RAY_FLAG_OUT_OF_SCENE) != 0) {
-        const V4 env = ld4(S.envColor);
+        V4 env = ld4(S.envColor);
+        if (S.envSpecId != 0xFFFFFFFFu) env = sampleUniformSpectrum(S.specValues, S.specOffsetSz[2u * S.envSpecId], waves) * (S.envSpecMult / 106.856895f);
         if (S.integratorType == INTEGRATOR_STUPID_PT) accum = thr * env; else accum = accum + thr * env;
       }
       // kernel_ContributeToImage (integrator_pt.cpp:598-657), spectral

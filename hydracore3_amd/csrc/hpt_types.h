@@ -180,6 +180,7 @@ struct DevScene
   float camRespoceRGB[4], envColor[4];
   uint  envTexId, envLightId, envCamBackId, envEnableSam;   // m_envTexId, m_envLightId, m_envCamBackId, m_envEnableSam (0xFFFFFFFF: none)
   float envSamRow0[4], envSamRow1[4];
+  uint  envSpecId; float envSpecMult;                        // m_envSpecId (0xFFFFFFFF: none), m_envSpecMult: the environment's spectrum in spectral mode
 };
 
 struct Counters { unsigned long long v[16]; };  // rays, nodes, tris, surfaceHits, shadowRays, paths, instEnter, texFetch,

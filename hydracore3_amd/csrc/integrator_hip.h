@@ -150,6 +150,7 @@ public:
     std::memcpy(p.projInv, m_projInv.m, 64); std::memcpy(p.worldViewInv, m_worldViewInv.m, 64);
     p.winStartX = m_winStartX; p.winStartY = m_winStartY; p.winWidth = m_winWidth; p.winHeight = m_winHeight; p.fbWidth = m_fbWidth; p.fbHeight = m_fbHeight;
     p.traceDepth = m_traceDepth; p.integratorType = m_intergatorType; p.renderLayer = m_renderLayer; p.tileSize = m_tileSize; p.spectralMode = uint32_t(m_spectral_mode);
+    p.envSpecIdPlus1 = m_envSpecId + 1u; p.envSpecMult = m_envSpecMult;     // (uint(-1) + 1 = 0: none)
     p.exposureMult = m_exposureMult; p.camLensRadius = m_camLensRadius; p.camTargetDist = m_camTargetDist;
     std::memcpy(p.camRespoceRGB, m_camRespoceRGB, 16); std::memcpy(p.envColor, m_envColor, 16);
     p.envTexId = m_envTexId; p.envLightId = m_envLightId; p.envCamBackId = m_envCamBackId; p.envEnableSam = m_envEnableSam;
@@ -213,6 +214,7 @@ public:
   float    m_camRespoceRGB[4] = {1, 1, 1, 1}, m_envColor[4] = {0, 0, 0, 0};
   uint32_t m_envTexId = 0xFFFFFFFFu, m_envLightId = 0xFFFFFFFFu, m_envCamBackId = 0xFFFFFFFFu, m_envEnableSam = 0;   // integrator_pt.h (environment map)
   float    m_envSamRow0[4] = {1, 0, 0, 0}, m_envSamRow1[4] = {0, 1, 0, 0};
+  uint32_t m_envSpecId = 0xFFFFFFFFu; float m_envSpecMult = 1.0f;          // integrator_pt.h:524-525: the environment's spectrum (spectral mode)
 
   hpt_ctx* context() const { return m_ctx; }
 

@@ -190,6 +190,7 @@ struct LoadedScene
   // the environment map of LoadSceneLights (integrator_pt_scene.cpp:441-478) and m_arrays1f (its pdf table)
   uint32_t envTexId = 0xFFFFFFFFu, envLightId = 0xFFFFFFFFu, envCamBackId = 0xFFFFFFFFu, envEnableSam = 0;
   float envSamRow0[4] = {1, 0, 0, 0}, envSamRow1[4] = {0, 1, 0, 0};
+  uint32_t envSpecId = 0xFFFFFFFFu; float envSpecMult = 1.0f;   // m_envSpecId, m_envSpecMult (integrator_pt_scene.cpp:456-457)
   std::vector<float> arrays1f;
   std::vector<float> lensLines; float physSize[2] = {0, 0};   // lens simulation: m_lines as {curvatureRadius, thickness, eta, apertureRadius}, m_physSize
   // spectral rendering (LoadSceneSpectrumData, integrator_pt_scene.cpp:358-419; the camera's <sensor><response>, :688-711)
@@ -258,6 +259,7 @@ struct LoadedScene
     m4ToColMajor(m4Inverse(proj), p.projInv); m4ToColMajor(m4Inverse(wv), p.worldViewInv);
     p.winStartX = p.winStartY = 0; p.winWidth = p.fbWidth = width; p.winHeight = p.fbHeight = height;
     p.traceDepth = traceDepth; p.integratorType = integratorType; p.renderLayer = renderLayer; p.tileSize = tileSize(); p.spectralMode = spectralMode;
+    p.envSpecIdPlus1 = envSpecId + 1u; p.envSpecMult = envSpecMult;
     p.exposureMult = 1.0f; p.camLensRadius = 0.0f; p.camTargetDist = (float)fl;
     for (int k = 0; k < 4; k++) { p.camRespoceRGB[k] = camRespoceRGB[k]; p.envColor[k] = envColor[k]; p.envSamRow0[k] = envSamRow0[k]; p.envSamRow1[k] = envSamRow1[k]; }
     p.envTexId = envTexId; p.envLightId = envLightId; p.envCamBackId = envCamBackId; p.envEnableSam = envEnableSam;
@@ -659,6 +661,7 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
       for (int k = 0; k < 3; k++) sc.envColor[k] = (float)color[k];
       sc.envColor[3] = color.size() >= 4 ? (float)color[3] : 0.0f;
       const XmlNode* cn = inten->child("color");
+      sc.envSpecId = spectrumId(cn); sc.envSpecMult = (float)power;          // m_envSpecId = lightSource.specId, m_envSpecMult = lightSource.mult
       float row0[4] = {1, 0, 0, 0}, row1[4] = {0, 1, 0, 0};
       uint32_t envTex = 0xFFFFFFFFu, backTex = 0xFFFFFFFFu;
       bool sample = false;

@@ -101,8 +101,8 @@ class Params(C.Structure):
                 ("winStartX", C.c_int32), ("winStartY", C.c_int32), ("winWidth", C.c_int32), ("winHeight", C.c_int32),
                 ("fbWidth", C.c_int32), ("fbHeight", C.c_int32),
                 ("traceDepth", C.c_uint32), ("integratorType", C.c_uint32), ("renderLayer", C.c_uint32),
-                ("tileSize", C.c_uint32), ("spectralMode", C.c_uint32), ("reserved0", C.c_uint32),
-                ("exposureMult", C.c_float), ("camLensRadius", C.c_float), ("camTargetDist", C.c_float), ("reserved1", C.c_float),
+                ("tileSize", C.c_uint32), ("spectralMode", C.c_uint32), ("envSpecIdPlus1", C.c_uint32),
+                ("exposureMult", C.c_float), ("camLensRadius", C.c_float), ("camTargetDist", C.c_float), ("envSpecMult", C.c_float),
                 ("camRespoceRGB", C.c_float * 4), ("envColor", C.c_float * 4),
                 ("envTexId", C.c_uint32), ("envLightId", C.c_uint32), ("envCamBackId", C.c_uint32), ("envEnableSam", C.c_uint32),
                 ("envSamRow0", C.c_float * 4), ("envSamRow1", C.c_float * 4)]
@@ -467,6 +467,7 @@ class SceneData:
         self.cam_response_spectrum_id = (-1, -1, -1)
         self.cam_response_type = 0                            # CAM_RESPONCE_XYZ = 0, CAM_RESPONCE_RGB = 1 (integrator_pt.h:531-534)
         self.cam_respoce_rgb = (1.0, 1.0, 1.0, 1.0)           # m_camRespoceRGB
+        self.env_spec_id, self.env_spec_mult = UINT_MAX, 1.0  # m_envSpecId, m_envSpecMult: the sky light's spectrum and multiplier (integrator_pt_scene.cpp:456-457)
         self.all_remap_lists = np.zeros((1,), np.int32)     # no lists: just the trailing offset 0
         self.all_remap_lists_size = 0
         self.materials, self.lights = [], []
@@ -655,6 +656,8 @@ class SceneData:
         p.renderLayer = render_layer
         p.tileSize = self.tile_size()
         p.spectralMode = int(self.spectral_mode)
+        p.envSpecIdPlus1 = (int(self.env_spec_id) + 1) & UINT_MAX
+        p.envSpecMult = float(self.env_spec_mult)
         p.exposureMult = self.exposure_mult
         p.camLensRadius = self.cam_lens_radius
         p.camTargetDist = float(np.linalg.norm(np.asarray(self.cam_look_at, float) - np.asarray(self.cam_pos, float)))
@@ -1123,6 +1126,7 @@ def load_hydra_xml(xml_path: str, width=None, height=None, spectral=False) -> Sc
             if lnode.find("back") is not None:
                 back_tex = load_texture_from_node(lnode.find("back"))[2]
             lid = sc.set_environment(color4(cnode), env_tex, power, env_rows[0], env_rows[1], back_tex, env_sample)
+            sc.env_spec_id, sc.env_spec_mult = spectrum_id(cnode), power       # m_envSpecId = lightSource.specId, m_envSpecMult = lightSource.mult
             old_to_new.append(lid)          # a plain-colour or LDR environment is not a light to sample
             continue
         size = lnode.find("size")

@@ -96,8 +96,8 @@ typedef struct hpt_params {
   uint32_t tileSize;          /* m_tileSize */
   uint32_t spectralMode;      /* m_spectral_mode: 0 = RGB; 1 = four wavelengths per path (needs hpt_scene_desc's spectral tables; scenes of diffuse, conductor
                                * and emissive materials, <= 4 output channels - anything else is refused with HPT_ERR_UNSUPPORTED) */
-  uint32_t reserved0;
-  float    exposureMult, camLensRadius, camTargetDist, reserved1;
+  uint32_t envSpecIdPlus1;    /* m_envSpecId + 1 (integrator_pt.h:524; 0 = none, so that a zeroed struct means "no environment spectrum") */
+  float    exposureMult, camLensRadius, camTargetDist, envSpecMult;   /* envSpecMult: m_envSpecMult (spectral mode: the environment spectrum's multiplier) */
   float    camRespoceRGB[4];  /* m_camRespoceRGB */
   float    envColor[4];       /* m_envColor */
   /* the environment of LoadSceneLights (integrator_pt_scene.cpp:441-478), read by EnvironmentColor / kernel_HitEnvironment

@@ -73,8 +73,8 @@ typedef struct orc_params {
   uint32_t renderLayer;       // m_renderLayer: 0 colour, 1 direct, 2 indirect
   uint32_t tileSize;          // m_tileSize
   uint32_t spectralMode;      // m_spectral_mode
-  uint32_t reserved0;
-  float    exposureMult, camLensRadius, camTargetDist, reserved1;
+  uint32_t envSpecIdPlus1;    // m_envSpecId + 1 (0 = none)
+  float    exposureMult, camLensRadius, camTargetDist, envSpecMult;   // m_envSpecMult
   float    camRespoceRGB[4];
   float    envColor[4];
   uint32_t envTexId, envLightId, envCamBackId, envEnableSam;   // m_envTexId, m_envLightId, m_envCamBackId, m_envEnableSam (0xFFFFFFFF: none)

@@ -29,6 +29,7 @@ struct Params
   f4 camRespoceRGB, envColor;
   uint envTexId, envLightId, envCamBackId, envEnableSam;
   f4 envSamRow0, envSamRow1;
+  uint envSpecId; float envSpecMult;           // m_envSpecId, m_envSpecMult
 };
 
 // IntegratorDR::TexInfo (diff_render/integrator_dr.h:56-64)
@@ -280,9 +281,13 @@ struct Ctx
     return lightColor;
   }
 
-  f4 EnvironmentColor(f3 a_dir, float& outPdf) const   // :175-210 (RGB mode)
+  f4 EnvironmentColor(f3 a_dir, float& outPdf, f4 a_wavelengths = f4{0, 0, 0, 0}) const   // :175-210
   {
     f4 color = p.envColor;
+    if (p.spectralMode != 0 && p.envSpecId != uint(-1)) {                    // :181-188: the environment's spectrum
+      color = SampleUniformSpectrum(sc.specOffsetSz[2 * p.envSpecId], a_wavelengths);
+      color = color * (p.envSpecMult / 106.856895f);
+    }
     const uint envTexId = p.envTexId;
     if (envTexId != uint(-1)) {
       float sinTheta = 1.0f;
@@ -748,7 +753,7 @@ struct Ctx
   {
     if ((s->rayFlags & RAY_FLAG_OUT_OF_SCENE) == 0) return;
     float envPdf = 1.0f;
-    f4 envColor = EnvironmentColor(xyz(s->rayDirAndFar), envPdf);
+    f4 envColor = EnvironmentColor(xyz(s->rayDirAndFar), envPdf, s->wavelengths);
     const bool isSpec = s->mis.matSamplePdf < 0.0f;                    // isSpecular (cglobals.h:300)
     const bool exitZero = (s->rayFlags & RAY_FLAG_PRIME_RAY_MISS) != 0;
     if (p.integratorType == INTEGRATOR_MIS_PT && p.envEnableSam != 0 && !isSpec && !exitZero) {
@@ -1032,6 +1037,7 @@ static void copy_params(Params& p, const orc_params* s)
   std::memcpy(&p.envColor, s->envColor, 16);
   p.envTexId = s->envTexId; p.envLightId = s->envLightId; p.envCamBackId = s->envCamBackId; p.envEnableSam = s->envEnableSam;
   std::memcpy(&p.envSamRow0, s->envSamRow0, 16); std::memcpy(&p.envSamRow1, s->envSamRow1, 16);
+  p.envSpecId = s->envSpecIdPlus1 - 1u; p.envSpecMult = s->envSpecMult;
 }
 
 extern "C" {

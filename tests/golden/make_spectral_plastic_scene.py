@@ -54,3 +54,23 @@ dst = os.path.join(here, "scenes", "spectral_glass", "statex_00001.xml")
 os.makedirs(os.path.dirname(dst), exist_ok=True)
 open(dst, "w", encoding="utf-8").write(glass)
 print("wrote", dst)
+
+# tests/golden/scenes/spectral_sky: the reference's fixture with its area light dimmed and a `sky` light whose colour carries a spectrum (D65) and
+# a multiplier - m_envSpecId / m_envSpecMult (integrator_pt_scene.cpp:456-457, integrator_pt_lgt.cpp:181-188): rays that leave the open box see it
+sky = src.replace('loc="data/', 'loc="../test_spectral/data/')
+sky = sky.replace("</spectra_lib>", '  <spectrum id="7" name="d65" loc="../test_spectral/data/spd/cie.stdillum.D6500.spd" />\n</spectra_lib>')
+sky = sky.replace("</lights_lib>", '''  <light id="1" name="sky" type="sky" shape="point" distribution="uniform">
+    <intensity>
+      <color val="1 1 1">
+        <spectrum id="7" type="ref"/>
+      </color>
+      <multiplier val="0.8" />
+    </intensity>
+  </light>
+</lights_lib>''')
+assert sky.count('<instance_light id="0"') == 1
+sky = re.sub(r'(<instance_light id="0"[^>]*/>)', r'\1\n    <instance_light id="1" light_id="1" matrix="1 0 0 0 0 1 0 0 0 0 1 0 0 0 0 1" lgroup_id="-1" />', sky, count=1)
+dst = os.path.join(here, "scenes", "spectral_sky", "statex_00001.xml")
+os.makedirs(os.path.dirname(dst), exist_ok=True)
+open(dst, "w", encoding="utf-8").write(sky)
+print("wrote", dst)

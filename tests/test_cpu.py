@@ -383,7 +383,7 @@ def _read_blobs(path):
     return out
 
 
-@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures", "test_spectral", "test_spectral+spectral", "spectral_plastic+spectral", "spectral_glass+spectral"])
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures", "test_spectral", "test_spectral+spectral", "spectral_plastic+spectral", "spectral_glass+spectral", "spectral_sky+spectral"])
 def test_cpp_scene_loader_produces_the_same_tables(scene_name, tmp_path):
     """hydracore3_amd/csrc/scene_loader.h (Hydra XML + VSGF + image4ub + IES in C++) == the Python fixture loader:
     every table byte for byte, matrices and light frames to float rounding (both invert in double)."""

@@ -172,6 +172,30 @@ def test_dispersive_dielectric_matches_oracle():
     assert not np.array_equal(disp, flat)
 
 
+def test_environment_spectrum_matches_oracle():
+    """A `sky` light whose colour carries a spectrum (m_envSpecId / m_envSpecMult, integrator_pt_scene.cpp:456-457): rays that leave the open
+    Cornell box pick up SampleUniformSpectrum(envSpec) * mult / 106.856895 (integrator_pt_lgt.cpp:181-188). Own fixture spectral_sky."""
+    from hydracore3_amd.api import HipIntegrator, HydraHipError
+    xml = scene_path("spectral_sky")
+    for spectral in (True, False):
+        sc = load_hydra_xml(xml, 96, 96, spectral=spectral)
+        assert sc.env_spec_id == 7 and sc.params().envSpecIdPlus1 == 8 and sc.params().envSpecMult == pytest.approx(0.8)
+        gpu, cpu = _pair(sc)
+        a, b = gpu.render(12), cpu.render(12)
+        l2 = _l2(a, b, 12)
+        gens = float(np.mean(np.all(gpu.random_gens() == cpu.random_gens(), axis=1)))
+        print(f"spectral={spectral}: per-pixel L2 = {l2:.3e} (mean {b[..., :3].mean() / 12:.4f}), identical generators {gens * 100:.2f} %")
+        assert l2 < 1e-3 and gens > 0.99 and np.mean(np.all(a[..., :3] == b[..., :3], axis=-1)) > 0.2
+    # the sky is seen: brighter than the same scene without its spectrum id
+    sc = load_hydra_xml(xml, 64, 64, spectral=True)
+    with_sky = HipIntegrator(sc).render(8)[..., :3].mean()
+    sc.env_spec_id = 0xFFFFFFFF; sc.env_color = (0.0, 0.0, 0.0, 0.0)
+    assert with_sky > 1.2 * HipIntegrator(sc).render(8)[..., :3].mean()
+    sc.env_spec_id = 99
+    with pytest.raises(HydraHipError, match="m_envSpecId"):
+        HipIntegrator(sc)
+
+
 def test_camera_response_spectra():
     """SpectralCamRespoceToRGB with m_camResponseSpectrumId set (integrator_spectrum.cpp:76-121): the response spectra replace the CIE
     observer; both response types (0 = CAM_RESPONCE_XYZ: through XYZToRGB, 1 = CAM_RESPONCE_RGB: taken as it is)."""

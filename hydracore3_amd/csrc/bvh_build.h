@@ -15,6 +15,8 @@
 #include <cmath>
 #include <cfloat>
 #include <cstring>
+#include <thread>
+#include <atomic>
 
 namespace hpt {
 
@@ -53,33 +55,73 @@ class Bvh2Builder
 public:
   // leafMax: max primitives per leaf (<= 4 for triangles, 1 for instances); maxDepth: cap on inner levels.
   // instanceLeaves: encode leaves as instance references (count field 0).
-  static Bvh2 build(const std::vector<Aabb>& boxes, int leafMax, int maxDepth, bool instanceLeaves)
+  // threads > 1: the top of the tree is built by the caller's thread down to subtrees of at most n / (8 * threads) primitives; those subtrees
+  // - disjoint ranges of the primitive order - are built by worker threads into node arrays of their own and appended afterwards. The
+  // splits, and so the tree, are the ones the sequential build makes; only the numbering of the nodes differs.
+  static Bvh2 build(const std::vector<Aabb>& boxes, int leafMax, int maxDepth, bool instanceLeaves, int threads = 1)
   {
     Bvh2 out;
     out.bounds.reset();
     const size_t n = boxes.size();
     if (n == 0) return out;
-    Bvh2Builder b(boxes, leafMax, maxDepth, instanceLeaves, out);
+    std::vector<float> cent(3 * n);
     out.order.resize(n);
     for (size_t i = 0; i < n; i++) { out.order[i] = (uint)i; out.bounds.merge(boxes[i]); }
-    b.cent.resize(3 * n);
-    for (size_t i = 0; i < n; i++) for (int a = 0; a < 3; a++) b.cent[3 * i + a] = 0.5f * (boxes[i].lo[a] + boxes[i].hi[a]);
+    for (size_t i = 0; i < n; i++) for (int a = 0; a < 3; a++) cent[3 * i + a] = 0.5f * (boxes[i].lo[a] + boxes[i].hi[a]);
     out.nodes.reserve(n);
+    Bvh2Builder b(boxes, cent, leafMax, maxDepth, instanceLeaves, out.order, out.nodes, out.depth);
+    if (threads > 1 && n >= 65536) b.jobLimit = std::max<size_t>(n / (8 * (size_t)threads), 4096);
     out.rootRef = b.buildRange(0, (uint)n, 0);
+    if (!b.jobs.empty()) {
+      struct Sub { std::vector<BvhNode> nodes; uint depth = 0, ref = REF_NONE; };
+      std::vector<Sub> subs(b.jobs.size());
+      std::atomic<size_t> next(0);
+      auto work = [&]() {
+        for (size_t j = next.fetch_add(1); j < b.jobs.size(); j = next.fetch_add(1)) {
+          Bvh2Builder sb(boxes, cent, leafMax, maxDepth, instanceLeaves, out.order, subs[j].nodes, subs[j].depth);
+          subs[j].nodes.reserve(b.jobs[j].count);
+          subs[j].ref = sb.buildRange(b.jobs[j].first, b.jobs[j].count, b.jobs[j].depth);
+        }
+      };
+      std::vector<std::thread> pool;
+      for (int t = 1; t < threads; t++) pool.emplace_back(work);
+      work();
+      for (std::thread& t : pool) t.join();
+      for (size_t j = 0; j < subs.size(); j++) {                             // append, shifting the subtree's inner references
+        const uint base = (uint)out.nodes.size();
+        for (BvhNode nd : subs[j].nodes) {
+          if (nd.ref0 != REF_NONE && !(nd.ref0 & REF_LEAF)) nd.ref0 += base;
+          if (nd.ref1 != REF_NONE && !(nd.ref1 & REF_LEAF)) nd.ref1 += base;
+          out.nodes.push_back(nd);
+        }
+        const uint ref = (subs[j].ref != REF_NONE && !(subs[j].ref & REF_LEAF)) ? subs[j].ref + base : subs[j].ref;
+        if (b.jobs[j].parent == 0xFFFFFFFFu) out.rootRef = ref;
+        else if (b.jobs[j].side == 0) out.nodes[b.jobs[j].parent].ref0 = ref; else out.nodes[b.jobs[j].parent].ref1 = ref;
+        out.depth = std::max(out.depth, subs[j].depth);
+      }
+    }
     return out;
   }
 
 private:
-  Bvh2Builder(const std::vector<Aabb>& bx, int lm, int md, bool il, Bvh2& o) : boxes(bx), leafMax(lm), maxDepth(md), instLeaves(il), out(o) {}
+  Bvh2Builder(const std::vector<Aabb>& bx, const std::vector<float>& ce, int lm, int md, bool il, std::vector<uint>& ord, std::vector<BvhNode>& nd, uint& dp)
+    : boxes(bx), cent(ce), leafMax(lm), maxDepth(md), instLeaves(il), order(ord), nodes(nd), depthOut(dp) {}
 
   const std::vector<Aabb>& boxes;
-  std::vector<float> cent;
+  const std::vector<float>& cent;
   int leafMax, maxDepth; bool instLeaves;
-  Bvh2& out;
+  std::vector<uint>& order;          // shared: every builder works on its own range of it
+  std::vector<BvhNode>& nodes;       // this builder's node array
+  uint& depthOut;
+  // deferred subtrees (parallel build): ranges of at most jobLimit primitives are not built by the top-level pass
+  struct Job { uint first, count; int depth; uint parent; int side; };
+  std::vector<Job> jobs;
+  size_t jobLimit = 0;
+  static const uint REF_JOB = 0x7FF00000u;                                   // placeholder reference: REF_JOB + job index (node ids stay far below)
 
   uint leafRef(uint first, uint count) const
   {
-    if (instLeaves) return REF_LEAF | (out.order[first] & 0x0FFFFFFFu);
+    if (instLeaves) return REF_LEAF | (order[first] & 0x0FFFFFFFu);
     return REF_LEAF | (count << 28) | (first & 0x0FFFFFFFu);
   }
 
@@ -88,12 +130,16 @@ private:
 
   uint buildRange(uint first, uint count, int depth)
   {
-    if ((int)count <= leafMax) { out.depth = std::max(out.depth, (uint)depth); return leafRef(first, count); }
+    if ((int)count <= leafMax) { depthOut = std::max(depthOut, (uint)depth); return leafRef(first, count); }
+    if (jobLimit != 0 && count <= jobLimit && jobs.size() < 0xFFFFFu) {       // a subtree for the workers
+      jobs.push_back({ first, count, depth, 0xFFFFFFFFu, 0 });
+      return REF_JOB + (uint)(jobs.size() - 1);
+    }
 
     // centroid bounds
     float clo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, chi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
     for (uint i = first; i < first + count; i++) {
-      const float* c = &cent[3 * out.order[i]];
+      const float* c = &cent[3 * order[i]];
       for (int a = 0; a < 3; a++) { clo[a] = std::min(clo[a], c[a]); chi[a] = std::max(chi[a], c[a]); }
     }
     // binned SAH over the three axes
@@ -109,7 +155,7 @@ private:
       for (int k = 0; k < NB; k++) { bb[k].reset(); bc[k] = 0; }
       const float scale = float(NB) / ext;
       for (uint i = first; i < first + count; i++) {
-        const uint p = out.order[i];
+        const uint p = order[i];
         int k = (int)((cent[3 * p + a] - clo[a]) * scale);
         k = std::min(std::max(k, 0), NB - 1);
         bb[k].merge(boxes[p]); bc[k]++;
@@ -132,7 +178,7 @@ private:
       const float ext = chi[bestAxis] - clo[bestAxis];
       const float scale = float(NB) / ext;
       const float lo = clo[bestAxis];
-      uint* b = out.order.data() + first;
+      uint* b = order.data() + first;
       uint* e = std::partition(b, b + count, [&](uint p) {
         int k = (int)((cent[3 * p + bestAxis] - lo) * scale);
         k = std::min(std::max(k, 0), NB - 1);
@@ -148,19 +194,21 @@ private:
       if (ex[1] > ex[axis]) axis = 1;
       if (ex[2] > ex[axis]) axis = 2;
       mid = first + count / 2;
-      std::nth_element(out.order.begin() + first, out.order.begin() + mid, out.order.begin() + first + count,
+      std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
                        [&](uint p, uint q) { return cent[3 * p + axis] < cent[3 * q + axis]; });
     }
 
-    const uint id = (uint)out.nodes.size();
-    out.nodes.push_back(BvhNode());
+    const uint id = (uint)nodes.size();
+    nodes.push_back(BvhNode());
     Aabb b0, b1; b0.reset(); b1.reset();
-    for (uint i = first; i < mid; i++) b0.merge(boxes[out.order[i]]);
-    for (uint i = mid; i < first + count; i++) b1.merge(boxes[out.order[i]]);
+    for (uint i = first; i < mid; i++) b0.merge(boxes[order[i]]);
+    for (uint i = mid; i < first + count; i++) b1.merge(boxes[order[i]]);
     b0.pad(); b1.pad();
     const uint r0 = buildRange(first, mid - first, depth + 1);
     const uint r1 = buildRange(mid, first + count - mid, depth + 1);
-    BvhNode& nd = out.nodes[id];
+    if (r0 >= REF_JOB && r0 < REF_LEAF) { jobs[r0 - REF_JOB].parent = id; jobs[r0 - REF_JOB].side = 0; }
+    if (r1 >= REF_JOB && r1 < REF_LEAF) { jobs[r1 - REF_JOB].parent = id; jobs[r1 - REF_JOB].side = 1; }
+    BvhNode& nd = nodes[id];
     // (lo, hi) pairs per axis: child 0 = q[0..5], child 1 = q[6..11] - the layout the packed slab test consumes (hpt_device.h: nodeSlabs)
     for (int a = 0; a < 3; a++) { nd.q[2 * a] = b0.lo[a]; nd.q[2 * a + 1] = b0.hi[a]; nd.q[6 + 2 * a] = b1.lo[a]; nd.q[6 + 2 * a + 1] = b1.hi[a]; }
     nd.ref0 = r0; nd.ref1 = r1; nd.pad0 = nd.pad1 = 0;

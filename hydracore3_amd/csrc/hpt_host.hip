@@ -10,6 +10,9 @@
 #include <set>
 #include <chrono>
 #include <dlfcn.h>
+#include <sched.h>
+#include <thread>
+#include <atomic>
 
 #include "../../include/hydra_hip.h"
 #include "hpt_decl.h"
@@ -99,6 +102,7 @@ struct hpt_ctx
   DevBuf<uint> dLevelNodes; DevBuf<float> dTriBox, dNodeBounds, dInstO2W;
   DevBuf<BvhNode4> dNodes4; DevBuf<uint> dNodes4Src;     // the single-level tree collapsed to 4-wide compressed nodes; per child the BVH2 (node << 1 | side) its box comes from
   uint nodes4Count = 0, stackNeeded4 = 0;                // (0: no wide tree)
+  int  buildThreads = 0;                                 // hpt_set_option("build_threads", n): host threads of CommitScene (0: automatic)
   bool statsWide = false;                                // hpt_set_option("stats_wide", 1): the instrumented probe walks the 4-wide tree (what a wavefront call on this scene does)
   bool wideEnabled = true;                               // hpt_set_option("wide_nodes", 0): the trace kernel walks the BVH2
   std::vector<uint> levelOffsets;                        // nodes of level l = dLevelNodes[levelOffsets[l] .. levelOffsets[l + 1])
@@ -398,6 +402,27 @@ static void inst_o2w_rows(const std::vector<Inst>& insts, std::vector<float>& ou
 // UpdateInstance / UpdateGeom_Triangles3f + CommitScene on a committed single-level scene (CrossRT.h:85-86, 134, 110): the tree's topology stays,
 // its boxes are recomputed on the device (refitTriBoxesKernel + one refitLevelKernel per level, deepest first). The host only inverts the
 // instance matrices again and, for meshes whose vertices moved, rewrites their triangle records.
+// host threads for CommitScene (hpt_set_option("build_threads", n); default: the cores this process may use, at most 16)
+static int buildThreads(const hpt_ctx* c)
+{
+  if (c->buildThreads > 0) return c->buildThreads;
+  unsigned n = std::thread::hardware_concurrency();
+  cpu_set_t set; CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int k = CPU_COUNT(&set); if (k > 0) n = std::min<unsigned>(n ? n : (unsigned)k, (unsigned)k); }
+  return (int)std::min<unsigned>(std::max<unsigned>(n, 1u), 16u);
+}
+
+// contiguous chunks of [0, n) on `threads` host threads (fn(begin, end)); small ranges stay on the caller's thread
+template <class F> static void parallelRanges(size_t n, int threads, F fn)
+{
+  if (threads <= 1 || n < 32768) { fn((size_t)0, n); return; }
+  std::vector<std::thread> pool;
+  const size_t per = (n + (size_t)threads - 1) / (size_t)threads;
+  for (int t = 1; t < threads; t++) { const size_t b = std::min(n, per * (size_t)t), e = std::min(n, b + per); if (b < e) pool.emplace_back([=]() { fn(b, e); }); }
+  fn((size_t)0, std::min(n, per));
+  for (std::thread& t : pool) t.join();
+}
+
 static int refit_flat(hpt_ctx* c)
 {
   const double t0 = now_ms();
@@ -450,8 +475,14 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   c->dirtyGeoms.clear();
   // ---- bottom level: one BVH2 per mesh over object-space triangles ----
   uint maxBlasDepth = 0;
-  for (Geom& g : c->geoms) {
-    if (!g.dirty) { maxBlasDepth = std::max(maxBlasDepth, g.bvh.depth); continue; }
+  const int nThreads = buildThreads(c);
+  // meshes are independent: the dirty ones are built by a pool of host threads (a mesh's own build stays sequential; a single big mesh - and
+  // the single-level tree below - is split into subtrees instead, Bvh2Builder::build)
+  std::vector<size_t> todo;
+  size_t biggest = 0;
+  for (size_t gi = 0; gi < c->geoms.size(); gi++) if (c->geoms[gi].dirty) { todo.push_back(gi); biggest = std::max(biggest, c->geoms[gi].idx.size() / 3); }
+  const bool meshParallel = nThreads > 1 && todo.size() >= 4;
+  auto buildMesh = [&](Geom& g, int threadsInside) {
     const size_t nt = g.idx.size() / 3;
     std::vector<Aabb> boxes(nt);
     for (size_t t = 0; t < nt; t++) {
@@ -459,7 +490,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
       for (int k = 0; k < 3; k++) boxes[t].grow(&g.pos[3 * g.idx[3 * t + k]]);
     }
     const int depthCap = std::max(24, ceil_log2((nt + BVH_LEAF_MAX - 1) / BVH_LEAF_MAX) + 2);
-    g.bvh = Bvh2Builder::build(boxes, BVH_LEAF_MAX, depthCap, false);
+    g.bvh = Bvh2Builder::build(boxes, BVH_LEAF_MAX, depthCap, false, threadsInside);
     g.tris.resize(nt);
     for (size_t i = 0; i < nt; i++) {
       const uint p = g.bvh.order[i];
@@ -469,8 +500,16 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
       t.primId = p; t.instId = 0; t.pad1 = 0;
     }
     g.dirty = false;
-    maxBlasDepth = std::max(maxBlasDepth, g.bvh.depth);
-  }
+  };
+  if (meshParallel) {
+    std::atomic<size_t> next(0);
+    auto work = [&]() { for (size_t k = next.fetch_add(1); k < todo.size(); k = next.fetch_add(1)) buildMesh(c->geoms[todo[k]], 1); };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nThreads; t++) pool.emplace_back(work);
+    work();
+    for (std::thread& t : pool) t.join();
+  } else for (size_t gi : todo) buildMesh(c->geoms[gi], nThreads);
+  for (const Geom& g : c->geoms) maxBlasDepth = std::max(maxBlasDepth, g.bvh.depth);
   // ---- single-level layout: one BVH2 over all instanced triangles, world-space boxes, object-space triangle records ----
   size_t instTris = 0;
   for (const Inst& in : c->insts) instTris += c->geoms[in.geomId].idx.size() / 3;
@@ -502,38 +541,44 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   }
   if (flat) {
     const size_t ni = c->insts.size();
-    std::vector<Aabb> boxes; boxes.reserve(instTris);
-    std::vector<uint> triInst, triPrim; triInst.reserve(instTris); triPrim.reserve(instTris);
-    for (size_t i = 0; i < ni; i++) {
-      const Geom& g = c->geoms[c->insts[i].geomId];
-      const size_t nt = g.idx.size() / 3;
-      for (size_t t = 0; t < nt; t++) {
+    std::vector<Aabb> boxes(instTris);
+    std::vector<uint> triInst(instTris), triPrim(instTris);
+    {
+      size_t k = 0;
+      for (size_t i = 0; i < ni; i++) { const size_t nt = c->geoms[c->insts[i].geomId].idx.size() / 3; for (size_t t = 0; t < nt; t++, k++) { triInst[k] = (uint)i; triPrim[k] = (uint)t; } }
+    }
+    parallelRanges(instTris, nThreads, [&](size_t kb, size_t ke) {
+      for (size_t k = kb; k < ke; k++) {
+        const size_t i = triInst[k], t = triPrim[k];
+        const Geom& g = c->geoms[c->insts[i].geomId];
         Aabb b; b.reset();
         // a moving instance: every point travels on the segment between its two key positions, so the box over both keys bounds the triangle at any time
         for (int key = 0; key < (c->insts[i].motion ? 2 : 1); key++) {
           const float* m = key ? c->insts[i].m1 : c->insts[i].m;
-          for (int k = 0; k < 3; k++) {
-            const float* p = &g.pos[3 * g.idx[3 * t + k]];
+          for (int kk = 0; kk < 3; kk++) {
+            const float* p = &g.pos[3 * g.idx[3 * t + kk]];
             const float q[3] = { m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12], m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13], m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14] };
             b.grow(q);
           }
         }
         b.pad();                                            // covers the rounding of the world-space vertex positions too
-        boxes.push_back(b); triInst.push_back((uint)i); triPrim.push_back((uint)t);
+        boxes[k] = b;
       }
-    }
+    });
     const int depthCap = std::max(24, ceil_log2((instTris + BVH_LEAF_MAX - 1) / BVH_LEAF_MAX) + 2);
-    Bvh2 tree = Bvh2Builder::build(boxes, BVH_LEAF_MAX, depthCap, false);
+    Bvh2 tree = Bvh2Builder::build(boxes, BVH_LEAF_MAX, depthCap, false, nThreads);
     std::vector<BvhTri> tris(std::max<size_t>(instTris, 1));
-    for (size_t k = 0; k < instTris; k++) {
-      const uint src = tree.order[k];
-      const uint i = triInst[src], p = triPrim[src];
-      const Geom& g = c->geoms[c->insts[i].geomId];
-      const float* A = &g.pos[3 * g.idx[3 * p + 0]]; const float* B = &g.pos[3 * g.idx[3 * p + 1]]; const float* C = &g.pos[3 * g.idx[3 * p + 2]];
-      BvhTri& t = tris[k];
-      for (int a = 0; a < 3; a++) { t.v0[a] = A[a]; t.e1[a] = B[a] - A[a]; t.e2[a] = C[a] - A[a]; }   // same object-space record as the two-level path
-      t.primId = p; t.instId = i; t.pad1 = 0;
-    }
+    parallelRanges(instTris, nThreads, [&](size_t kb, size_t ke) {
+      for (size_t k = kb; k < ke; k++) {
+        const uint src = tree.order[k];
+        const uint i = triInst[src], p = triPrim[src];
+        const Geom& g = c->geoms[c->insts[i].geomId];
+        const float* A = &g.pos[3 * g.idx[3 * p + 0]]; const float* B = &g.pos[3 * g.idx[3 * p + 1]]; const float* C = &g.pos[3 * g.idx[3 * p + 2]];
+        BvhTri& t = tris[k];
+        for (int a = 0; a < 3; a++) { t.v0[a] = A[a]; t.e1[a] = B[a] - A[a]; t.e2[a] = C[a] - A[a]; }   // same object-space record as the two-level path
+        t.primId = p; t.instId = i; t.pad1 = 0;
+      }
+    });
     std::vector<BvhNode> nodes(tree.nodes);
     if (nodes.empty()) nodes.push_back(BvhNode());
     if (tris.size() >= (size_t(1) << 28)) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: scene too large for 28-bit triangle references");
@@ -1812,6 +1857,7 @@ extern "C" int hpt_set_option(hpt_ctx* c, const char* name, int value)
   else if (k == "dbg_no_normal_lerp") { if (c->S.motion) c->S.motion = value ? 3u : 1u; }   // diagnostic: moving instances without the reference's normal interpolation (bit 1 of DevScene::motion)
   else if (k == "dbg_wf_iter_cap") c->wfIterCap = (uint)value;                         // diagnostic: make the wavefront loop's safety net reachable in a test
   else if (k == "dr_skip_nonfinite") c->drSkipNonFinite = value != 0;                  // PathTraceDR: drop samples whose radiance is not finite (default 0: PixelLossPT as in the reference)
+  else if (k == "build_threads") c->buildThreads = std::min(value, 64);                // host threads CommitScene builds its trees with (0: the usable cores, at most 16)
   else if (k == "stats_wide") c->statsWide = value != 0;
   else if (k == "wide_nodes") { c->wideEnabled = value != 0; c->S.megaWide = (c->wideEnabled && c->nodes4Count != 0u && c->S.flatMode != 0u && c->sahVisits >= HEAVY_SAH_VISITS) ? 1u : 0u; }   // both users of the tree, at once                             // 0: the wavefront trace kernel walks the BVH2 instead of the 4-wide compressed tree (A/B, diagnosis)
   else if (k == "force_full_materials") c->forceFull = value != 0;                     // diagnostic: never pick the lean (gltf + emissive) kernels

@@ -16,3 +16,9 @@ for layout in (1, 2):
             m = S.translate(0.3, 0.0, 0.1) @ np.asarray(sc.inst_matrices[40])
             t4 = time.time(); g.UpdateInstance(40, m); g.CommitScene(); t5 = time.time()
             print(f"   UpdateInstance + CommitScene, refit={refit}: {(t5 - t4) * 1e3:.1f} ms wall; {g.commit_time()}", flush=True)
+# host threads of CommitScene (single-level layout, the collapse to the 4-wide tree included)
+for n in (1, 2, 4, 8, 16):
+    g = HipIntegrator(sc, accel_layout=2)
+    g.set_option("build_threads", n); g.set_option("refit", 0)
+    g.UpdateInstance(40, np.asarray(sc.inst_matrices[40])); g.CommitScene()
+    print(f"   build_threads {n}: CommitScene {g.commit_time()}", flush=True)

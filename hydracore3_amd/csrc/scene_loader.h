@@ -406,6 +406,92 @@ inline bool decodeBmp(const std::vector<uint8_t>& f, uint32_t& w, uint32_t& h, s
   }
   return true;
 }
+// OpenEXR, the subset the reference reads through tinyexr's LoadEXR (imageutils.cpp:317-392): single-part scanline files, NONE / ZIPS / ZIP
+// compression, HALF / FLOAT / UINT channels. rgba: w * h * 4 floats in FILE order (top scanline first), as LoadEXR hands them out:
+// R, G, B (, A = 1 when absent); a single-channel file fills all four components with its value.
+inline float halfToFloat(uint16_t hbits)
+{
+  const uint32_t sign = (uint32_t)(hbits & 0x8000u) << 16, exp = (hbits >> 10) & 0x1Fu, man = hbits & 0x3FFu;
+  uint32_t f;
+  if (exp == 0) {
+    if (man == 0) f = sign;
+    else { int e = -1; uint32_t m = man; do { e++; m <<= 1; } while (!(m & 0x400u)); f = sign | ((uint32_t)(127 - 15 - e) << 23) | ((m & 0x3FFu) << 13); }   // subnormal
+  } else if (exp == 31) f = sign | 0x7F800000u | (man << 13);
+  else f = sign | ((exp + 112u) << 23) | (man << 13);
+  float r; std::memcpy(&r, &f, 4); return r;
+}
+inline bool decodeExr(const std::vector<uint8_t>& f, uint32_t& w, uint32_t& h, std::vector<float>& rgba, std::string& err)
+{
+  static const uint8_t magic[4] = { 0x76, 0x2f, 0x31, 0x01 };
+  if (f.size() < 16 || std::memcmp(f.data(), magic, 4) != 0) { err = "exr: not an OpenEXR file"; return false; }
+  uint32_t version; std::memcpy(&version, f.data() + 4, 4);
+  if (version & 0x1A00u) { err = "exr: tiled / multi-part / deep files are not read"; return false; }
+  size_t p = 8;
+  struct Chan { std::string name; int type; };
+  std::vector<Chan> chans; int comp = -1; int32_t dw[4] = {0, 0, -1, -1};
+  auto cstr = [&](size_t& q, const std::vector<uint8_t>& b, size_t end, std::string& out) { out.clear(); while (q < end && b[q] != 0) out.push_back((char)b[q++]); q++; return q <= end; };
+  while (p < f.size() && f[p] != 0) {
+    std::string name, type;
+    if (!cstr(p, f, f.size(), name) || !cstr(p, f, f.size(), type) || p + 4 > f.size()) { err = "exr: broken header"; return false; }
+    int32_t size; std::memcpy(&size, f.data() + p, 4); p += 4;
+    if (size < 0 || p + (size_t)size > f.size()) { err = "exr: broken header"; return false; }
+    if (name == "channels") {
+      size_t q = p; const size_t end = p + (size_t)size;
+      while (q < end && f[q] != 0) {
+        Chan c; if (!cstr(q, f, end, c.name) || q + 16 > end) { err = "exr: broken channel list"; return false; }
+        int32_t pt, xs, ys; std::memcpy(&pt, f.data() + q, 4); std::memcpy(&xs, f.data() + q + 8, 4); std::memcpy(&ys, f.data() + q + 12, 4); q += 16;
+        if (xs != 1 || ys != 1 || pt < 0 || pt > 2) { err = "exr: subsampled channels are not read"; return false; }
+        c.type = pt; chans.push_back(c);
+      }
+    } else if (name == "compression" && size >= 1) comp = f[p];
+    else if (name == "dataWindow" && size == 16) std::memcpy(dw, f.data() + p, 16);
+    p += (size_t)size;
+  }
+  p++;
+  const int lpb = comp == 0 ? 1 : (comp == 2 ? 1 : (comp == 3 ? 16 : 0));
+  if (!lpb) { err = "exr: compression " + std::to_string(comp) + " is not read (NONE, ZIPS, ZIP are)"; return false; }
+  if (chans.empty() || dw[2] < dw[0] || dw[3] < dw[1]) { err = "exr: no channels / empty data window"; return false; }
+  w = (uint32_t)(dw[2] - dw[0] + 1); h = (uint32_t)(dw[3] - dw[1] + 1);
+  if (w > 65536u || h > 65536u) { err = "exr: unreasonable size"; return false; }
+  const size_t nblocks = (h + (uint32_t)lpb - 1) / (uint32_t)lpb;
+  if (p + 8 * nblocks > f.size()) { err = "exr: truncated offset table"; return false; }
+  size_t lineBytes = 0; for (const Chan& c : chans) lineBytes += (c.type == 1 ? 2u : 4u) * (size_t)w;
+  std::vector<std::vector<float>> planes(chans.size(), std::vector<float>((size_t)w * h, 0.0f));
+  std::vector<uint8_t> tmp, raw;
+  for (size_t b = 0; b < nblocks; b++) {
+    uint64_t off; std::memcpy(&off, f.data() + p + 8 * b, 8);
+    if (off + 8 > f.size()) { err = "exr: chunk offset past the end"; return false; }
+    int32_t y, size; std::memcpy(&y, f.data() + off, 4); std::memcpy(&size, f.data() + off + 4, 4);
+    if (size < 0 || off + 8 + (uint64_t)size > f.size() || y < dw[1] || y > dw[3]) { err = "exr: broken chunk"; return false; }
+    const size_t nl = (size_t)std::min<int64_t>(lpb, (int64_t)dw[3] - y + 1), need = nl * lineBytes;
+    const uint8_t* data = f.data() + off + 8;
+    if (comp != 0 && (size_t)size < need) {
+      tmp.resize(need); uLongf got = (uLongf)need;
+      if (uncompress(tmp.data(), &got, data, (uLong)size) != Z_OK || got != need) { err = "exr: zlib"; return false; }
+      for (size_t i = 1; i < need; i++) tmp[i] = (uint8_t)(tmp[i - 1] + tmp[i] - 128);        // predictor
+      raw.resize(need);
+      const size_t half = (need + 1) / 2;
+      for (size_t i = 0, a = 0, c = half; i < need;) { raw[i++] = tmp[a++]; if (i < need) raw[i++] = tmp[c++]; }   // the two byte halves interleaved again
+      data = raw.data();
+    } else if ((size_t)size < need) { err = "exr: short chunk"; return false; }
+    size_t q = 0;
+    for (size_t l = 0; l < nl; l++) for (size_t ci = 0; ci < chans.size(); ci++) {
+      float* dst = planes[ci].data() + ((size_t)(y - dw[1]) + l) * w;
+      for (uint32_t x = 0; x < w; x++) {
+        if (chans[ci].type == 1) { uint16_t v; std::memcpy(&v, data + q, 2); q += 2; dst[x] = halfToFloat(v); }
+        else if (chans[ci].type == 2) { std::memcpy(&dst[x], data + q, 4); q += 4; }
+        else { uint32_t v; std::memcpy(&v, data + q, 4); q += 4; dst[x] = (float)v; }
+      }
+    }
+  }
+  rgba.assign((size_t)w * h * 4, 0.0f);
+  auto find = [&](const char* n) -> const float* { for (size_t ci = 0; ci < chans.size(); ci++) if (chans[ci].name == n) return planes[ci].data(); return nullptr; };
+  if (chans.size() == 1) { for (size_t i = 0; i < (size_t)w * h; i++) for (int k = 0; k < 4; k++) rgba[4 * i + k] = planes[0][i]; return true; }
+  const float* src[4] = { find("R"), find("G"), find("B"), find("A") };
+  for (size_t i = 0; i < (size_t)w * h; i++) for (int k = 0; k < 4; k++) rgba[4 * i + k] = src[k] ? src[k][i] : (k == 3 ? 1.0f : 0.0f);
+  return true;
+}
+
 inline bool endsWithNoCase(const std::string& s, const char* ext) { const size_t n = std::strlen(ext); if (s.size() < n) return false; for (size_t i = 0; i < n; i++) if (std::tolower((unsigned char)s[s.size() - n + i]) != ext[i]) return false; return true; }
 
 // ---- spectra (spectrum.cpp) ----
@@ -584,10 +670,25 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
     std::vector<uint8_t> img;
     if (!readFile(ti.path, img) || img.size() < 8) { err = "cannot read " + ti.path; return false; }
     LoadedTexture t; t.addressU = au; t.addressV = av; t.filter = filt;
-    if (ti.path.find(".image") == std::string::npos) {                        // LDR files through LiteImage::LoadImage<uint32_t> (:24-33)
+    if (ti.path.find(".exr") != std::string::npos) {                          // LoadImage4fFromEXR / LoadImage1fFromEXR (imageutils.cpp:317-392): tinyexr's rows, flipped
+      uint32_t w = 0, h = 0; std::vector<float> rgba; std::string derr;
+      if (!decodeExr(img, w, h, rgba, derr)) { err = "texture file '" + ti.path + "': " + derr; return false; }
+      t.width = w; t.height = h; t.flags = 0u;
+      if (ti.bpp == 16) {
+        t.format = 1u; t.bytes.resize((size_t)w * h * 16);
+        for (uint32_t y = 0; y < h; y++) std::memcpy(t.bytes.data() + (size_t)(h - 1 - y) * w * 16, rgba.data() + (size_t)y * w * 4, (size_t)w * 16);
+      } else {                                                               // one float per texel: R, infinities and values beyond the half range clamped
+        t.format = 2u; t.bytes.resize((size_t)w * h * 4);
+        for (uint32_t y = 0; y < h; y++) for (uint32_t x = 0; x < w; x++) {
+          float v = rgba[((size_t)(h - 1 - y) * w + x) * 4];
+          v = std::isinf(v) ? 65504.0f : std::min(std::max(v, 0.0f), 65504.0f);
+          std::memcpy(t.bytes.data() + ((size_t)y * w + x) * 4, &v, 4);
+        }
+      }
+    } else if (ti.path.find(".image") == std::string::npos) {                 // LDR files through LiteImage::LoadImage<uint32_t> (:24-33)
       uint32_t w = 0, h = 0; std::vector<uint8_t> rgba; std::string derr;
       const bool ok = endsWithNoCase(ti.path, ".png") ? decodePng(img, w, h, rgba, derr) : endsWithNoCase(ti.path, ".ppm") ? decodePpm(img, w, h, rgba, derr)
-                    : endsWithNoCase(ti.path, ".bmp") ? decodeBmp(img, w, h, rgba, derr) : (derr = "only .image4ub / .image4f / .png / .ppm / .bmp are read here (no JPEG / EXR decoder in this image)", false);
+                    : endsWithNoCase(ti.path, ".bmp") ? decodeBmp(img, w, h, rgba, derr) : (derr = "only .image4ub / .image4f / .exr / .png / .ppm / .bmp are read here (no JPEG decoder in this image)", false);
       if (!ok) { err = "texture file '" + ti.path + "': " + derr; return false; }
       t.width = w; t.height = h; t.format = 0u; t.flags = disableGamma ? 0u : 1u; t.bytes.swap(rgba);
     } else {

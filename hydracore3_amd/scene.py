@@ -828,6 +828,71 @@ def cie_xyz_fit():
     return np.stack([x, y, z, np.zeros_like(x)], 1).astype(np.float32)
 
 
+def decode_exr(raw):
+    """OpenEXR, the subset tinyexr's LoadEXR is used for by the reference (imageutils.cpp:317-392): single-part scanline files, NONE / ZIPS / ZIP
+    compression, HALF / FLOAT / UINT channels. Returns float32 [h, w, 4] in FILE order (top scanline first) the way LoadEXR hands it out:
+    R, G, B (, A = 1 when absent); a single-channel file fills all four components with its value."""
+    import zlib
+    if raw[:4] != b"\x76\x2f\x31\x01":
+        raise ValueError("not an OpenEXR file")
+    version, = struct.unpack_from("<I", raw, 4)
+    if version & 0x1A00:                                              # 0x200 tiled, 0x800 deep, 0x1000 multi-part (0x400 = long names: fine)
+        raise NotImplementedError("EXR: tiled / multi-part / deep files are not read")
+    p, attrs = 8, {}
+    while raw[p] != 0:
+        e = raw.index(b"\0", p); name = raw[p:e].decode(); p = e + 1
+        e = raw.index(b"\0", p); typ = raw[p:e].decode(); p = e + 1
+        size, = struct.unpack_from("<i", raw, p); p += 4
+        attrs[name] = (typ, raw[p:p + size]); p += size
+    p += 1
+    chans, q, cd = [], 0, attrs["channels"][1]
+    while cd[q] != 0:
+        e = cd.index(b"\0", q); cname = cd[q:e].decode(); q = e + 1
+        ptype, _plin, xs, ys = struct.unpack_from("<iB3xii", cd, q); q += 16
+        if xs != 1 or ys != 1:
+            raise NotImplementedError("EXR: subsampled channels are not read")
+        chans.append((cname, ptype))
+    comp = attrs["compression"][1][0]
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    lines_per_block = {0: 1, 2: 1, 3: 16}.get(comp)
+    if lines_per_block is None:
+        raise NotImplementedError(f"EXR: compression {comp} is not read (NONE, ZIPS, ZIP are)")
+    nblocks = (h + lines_per_block - 1) // lines_per_block
+    offsets = struct.unpack_from(f"<{nblocks}Q", raw, p)
+    bytes_per = {0: 4, 1: 2, 2: 4}
+    line_bytes = sum(bytes_per[t] * w for _n, t in chans)
+    planes = {n: np.zeros((h, w), np.float32) for n, _t in chans}
+    for off in offsets:
+        y, size = struct.unpack_from("<ii", raw, off)
+        data = raw[off + 8:off + 8 + size]
+        nl = min(lines_per_block, y1 - y + 1)
+        if comp != 0 and size < nl * line_bytes:                       # stored raw when compression does not shrink the block
+            t = np.frombuffer(zlib.decompress(data), np.uint8).astype(np.int32)
+            t = np.cumsum(np.concatenate([t[:1], t[1:] - 128])) & 0xFF       # predictor: d[i] = d[i - 1] + t[i] - 128
+            t = t.astype(np.uint8)
+            half = (t.size + 1) // 2
+            out = np.empty(t.size, np.uint8); out[0::2] = t[:half]; out[1::2] = t[half:]   # de-interleave the two byte halves
+            data = out.tobytes()
+        q = 0
+        for l in range(nl):
+            for n, t in chans:                                           # channels are stored in alphabetical order, one run per scanline
+                if t == 1: v = np.frombuffer(data, "<f2", w, q).astype(np.float32)
+                elif t == 2: v = np.frombuffer(data, "<f4", w, q)
+                else: v = np.frombuffer(data, "<u4", w, q).astype(np.float32)
+                planes[n][y - y0 + l] = v
+                q += bytes_per[t] * w
+    img = np.zeros((h, w, 4), np.float32)
+    names = [n for n, _t in chans]
+    if len(names) == 1:
+        img[...] = planes[names[0]][..., None]
+    else:
+        for k, n in enumerate(("R", "G", "B")):
+            if n in planes: img[..., k] = planes[n]
+        img[..., 3] = planes["A"] if "A" in planes else 1.0
+    return img
+
+
 def decode_ldr_image(path, raw):
     """.png / .ppm / .bmp -> uint32 [h, w] RGBA8 (r in the low byte), rows in file order - the same decoders as csrc/scene_loader.h
     (8-bit non-interlaced PNG through zlib, binary PPM, uncompressed 24 / 32-bit BMP); no JPEG / EXR decoder in this image."""
@@ -927,7 +992,7 @@ def decode_ldr_image(path, raw):
         rows = np.frombuffer(raw, np.uint8, stride * h, off).reshape(h, stride)[:, :w * bs].reshape(h, w, bs).astype(np.uint32)
         a = rows[..., 3] if bs == 4 else np.full((h, w), 255, np.uint32)
         return (rows[..., 2] | (rows[..., 1] << 8) | (rows[..., 0] << 16) | (a << 24)).astype(np.uint32)
-    raise NotImplementedError(f"texture file '{path}': only .image4ub / .image4f / .png / .ppm / .bmp are read here (no JPEG / EXR decoder in this image)")
+    raise NotImplementedError(f"texture file '{path}': only .image4ub / .image4f / .exr / .png / .ppm / .bmp are read here (no JPEG decoder in this image)")
 
 
 def ies_spherical_texture(path):
@@ -1059,6 +1124,15 @@ def load_hydra_xml(xml_path: str, width=None, height=None, spectral=False) -> Sc
         if key not in tex_cache:
             path, w, h, bpp = tex_info[key[0]]
             raw = open(path, "rb").read()
+            if ".exr" in path:                                                 # LoadImage4fFromEXR / LoadImage1fFromEXR (imageutils.cpp:317-392): tinyexr's rows, flipped
+                img = decode_exr(raw)[::-1]
+                if bpp == 16:
+                    tex = Texture(np.ascontiguousarray(img), TEX_RGBA32F, False, key[1], key[2], key[4])
+                else:                                                          # one float per texel: R, infinities and values beyond the half range clamped
+                    r = np.where(np.isinf(img[..., 0]), np.float32(65504.0), np.clip(img[..., 0], 0.0, 65504.0)).astype(np.float32)
+                    tex = Texture(np.ascontiguousarray(r), TEX_R32F, False, key[1], key[2], key[4])
+                tex_cache[key] = sc.add_texture(tex)
+                return tuple(row0), tuple(row1), tex_cache[key]
             if ".image" not in path:                                           # LDR files through LiteImage::LoadImage<uint32_t> (:24-33)
                 tex = Texture(decode_ldr_image(path, raw), TEX_RGBA8, not disable_gamma, key[1], key[2], key[4])
                 tex_cache[key] = sc.add_texture(tex)

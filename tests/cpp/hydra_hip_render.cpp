@@ -15,6 +15,13 @@ template <class T> static void blob(FILE* f, const char* name, const std::vector
 
 int main(int argc, char** argv)
 {
+  if (argc == 4 && std::string(argv[1]) == "--exr") {                                  // decoder check: hydra_hip_render --exr <file.exr> <out.bin> = {w, h, w * h * 4 floats in file order}
+    std::vector<uint8_t> raw; std::vector<float> rgba; uint32_t w = 0, h = 0; std::string err;
+    if (!hydra_hip::detail::readFile(argv[2], raw) || !hydra_hip::detail::decodeExr(raw, w, h, rgba, err)) { std::fprintf(stderr, "[hydra_hip_render]: %s\n", err.c_str()); return 1; }
+    FILE* f = std::fopen(argv[3], "wb"); if (!f) return 1;
+    std::fwrite(&w, 4, 1, f); std::fwrite(&h, 4, 1, f); std::fwrite(rgba.data(), 4, rgba.size(), f); std::fclose(f);
+    return 0;
+  }
   if (argc < 6) { std::fprintf(stderr, "usage: %s <scene.xml> <width> <height> <spp> <out.bin> [--tables | --ppm preview.ppm]\n", argv[0]); return 2; }
   const int W = std::atoi(argv[2]), H = std::atoi(argv[3]), spp = std::atoi(argv[4]);
   const bool tables = argc > 6 && std::string(argv[6]) == "--tables";

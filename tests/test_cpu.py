@@ -383,7 +383,7 @@ def _read_blobs(path):
     return out
 
 
-@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures", "test_spectral", "test_spectral+spectral", "spectral_plastic+spectral", "spectral_glass+spectral", "spectral_sky+spectral"])
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures", "test_spectral", "test_spectral+spectral", "spectral_plastic+spectral", "spectral_glass+spectral", "spectral_sky+spectral", "exr_sky"])
 def test_cpp_scene_loader_produces_the_same_tables(scene_name, tmp_path):
     """hydracore3_amd/csrc/scene_loader.h (Hydra XML + VSGF + image4ub + IES in C++) == the Python fixture loader:
     every table byte for byte, matrices and light frames to float rounding (both invert in double)."""
@@ -703,3 +703,35 @@ def test_wide_node_quantiser_is_conservative(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(ROOT, "tests", "cpp", "quantize_test.cpp"), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "all conservative" in r.stdout, r.stdout + r.stderr
+
+
+def test_exr_decoders_agree_and_read_what_was_written(tmp_path):
+    """OpenEXR textures (LoadImage4fFromEXR / LoadImage1fFromEXR through tinyexr in the reference, imageutils.cpp:317-392): the Python and the C++
+    decoder read tests/golden/exr/*.exr (written by make_exr_scene.py: ZIPS + HALF RGB, NONE + FLOAT single channel with an infinity, ZIP + HALF
+    RGBA over three 16-line blocks) to the arrays that went in, and the exr_sky fixture's map equals the env_map fixture's .image4f one."""
+    import __graft_entry__ as g
+    g.build()
+    tool = os.path.join(ROOT, "hydracore3_amd", "hydra_hip_render")
+    rng = np.random.default_rng(7)
+    a = rng.uniform(0, 4, (5, 7, 3)).astype(np.float32)
+    y = rng.uniform(0, 1e5, (9, 6)).astype(np.float32); y[2, 3] = np.inf
+    b = rng.uniform(0, 2, (40, 12, 4)).astype(np.float32)
+    h16 = lambda v: v.astype(np.float16).astype(np.float32)
+    expect = {"zips_half_rgb": np.concatenate([h16(a), np.ones((5, 7, 1), np.float32)], -1),
+              "none_float_y": np.repeat(y[..., None], 4, -1),
+              "zip_half_rgba": h16(b)}
+    for name, ref in expect.items():
+        path = os.path.join(GOLD, "exr", name + ".exr")
+        img = S.decode_exr(open(path, "rb").read())
+        assert img.shape == ref.shape and np.array_equal(img, ref), name
+        out = str(tmp_path / (name + ".bin"))
+        r = subprocess.run([tool, "--exr", path, out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        raw = open(out, "rb").read()
+        w, h = np.frombuffer(raw, np.uint32, 2)
+        assert (h, w) == ref.shape[:2]
+        assert np.array_equal(np.frombuffer(raw, np.float32, offset=8).reshape(h, w, 4), ref), name
+    sky_a = S.load_hydra_xml(scene_path("env_map"), 32, 32)
+    sky_b = S.load_hydra_xml(scene_path("exr_sky"), 32, 32)
+    assert all(np.array_equal(p.data, q.data) and p.fmt == q.fmt for p, q in zip(sky_a.textures, sky_b.textures))
+    assert sky_b.env_enable_sam == 1 and np.array_equal(sky_a.arrays1f, sky_b.arrays1f)

@@ -355,7 +355,7 @@ def test_path_trace_from_input_rays_block_matches_oracle(cornell):
         assert np.array_equal(gpu.random_gens(), cpu.random_gens())
 
 
-@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures", "test_spectral", "test_spectral+spectral", "spectral_plastic+spectral", "spectral_glass+spectral", "spectral_sky+spectral"])
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures", "test_spectral", "test_spectral+spectral", "spectral_plastic+spectral", "spectral_glass+spectral", "spectral_sky+spectral", "exr_sky"])
 def test_cpp_scene_ingestion_renders_like_the_python_path(scene_name, tmp_path):
     """hydra_hip_render: scene_loader.h (C++) -> C ABI -> frame, no Python in the loop; the frame equals the one rendered from the
     Python loader's tables (same tables up to float rounding of inverted matrices: the image bar applies)."""
@@ -1345,3 +1345,13 @@ def test_wide_compressed_tree_returns_what_the_bvh2_returns():
     assert wide.commit_time()["refitted"]
     assert np.array_equal(wide.RayQuery_NearestHit(pos, dr).view(np.uint8), narrow.RayQuery_NearestHit(pos, dr).view(np.uint8))
     assert not np.array_equal(wide.RayQuery_NearestHit(pos, dr).view(np.uint8), hw.view(np.uint8))
+
+
+def test_exr_environment_map_renders_like_the_image4f_one():
+    """tests/golden/scenes/exr_sky = the env_map fixture with its sky stored as an OpenEXR file (ZIP, FLOAT; rows flipped as LoadImage4fFromEXR
+    flips them): the map is sampled explicitly because its path says .exr (integrator_pt_scene.cpp:460-462), and the frame is the env_map
+    fixture's frame bit for bit."""
+    from hydracore3_amd.api import HipIntegrator
+    a = HipIntegrator(load_hydra_xml(scene_path("env_map"), 96, 64)).render(6)
+    b = HipIntegrator(load_hydra_xml(scene_path("exr_sky"), 96, 64)).render(6)
+    assert np.array_equal(a, b) and a[..., :3].mean() > 0

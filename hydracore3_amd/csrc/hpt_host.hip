@@ -1339,7 +1339,13 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   if (motion) {
     if (inRays) launchPTMotion<2>(c->S, job, blocks, st, deep); else if (naive) launchPTMotion<1>(c->S, job, blocks, st, deep); else launchPTMotion<0>(c->S, job, blocks, st, deep);
   }
-  else if (dr)     launchPT<false, true, 0>(c->S, job, blocks, st, deep);
+  else if (dr) {
+    // the DR kernel's waves are emptier than the forward kernel's (lane utilisation 0.25), so leaving the inner-node loop when fewer than four
+    // lanes still walk pays even on light scenes: test_228 class 346 -> 364 Mpaths/s (forward: 698 -> 699; profiles/vote_medium.sh)
+    DevScene Sd = c->S;
+    if (c->nodeMinOverride < 0 && Sd.nodeMin < 4u) Sd.nodeMin = 4u;
+    launchPT<false, true, 0>(Sd, job, blocks, st, deep);
+  }
   else if (inRays) launchPT<false, false, 2>(c->S, job, blocks, st, deep);
   else if (naive)  launchPT<false, false, 1>(c->S, job, blocks, st, deep);
   else if (stats) {

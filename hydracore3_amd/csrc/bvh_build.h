@@ -84,7 +84,7 @@ public:
         }
       };
       std::vector<std::thread> pool;
-      for (int t = 1; t < threads; t++) pool.emplace_back(work);
+      try { for (int t = 1; t < threads; t++) pool.emplace_back(work); } catch (...) {}   // jobs are drawn dynamically: the caller's thread does what no worker takes
       work();
       for (std::thread& t : pool) t.join();
       for (size_t j = 0; j < subs.size(); j++) {                             // append, shifting the subtree's inner references

@@ -416,10 +416,12 @@ static int buildThreads(const hpt_ctx* c)
 template <class F> static void parallelRanges(size_t n, int threads, F fn)
 {
   if (threads <= 1 || n < 32768) { fn((size_t)0, n); return; }
+  const size_t per = std::max<size_t>(n / (8 * (size_t)threads), 4096);       // chunks are handed out dynamically: a thread that could not be started costs nothing
+  std::atomic<size_t> next(0);
+  auto work = [&]() { for (size_t b = next.fetch_add(per); b < n; b = next.fetch_add(per)) fn(b, std::min(n, b + per)); };
   std::vector<std::thread> pool;
-  const size_t per = (n + (size_t)threads - 1) / (size_t)threads;
-  for (int t = 1; t < threads; t++) { const size_t b = std::min(n, per * (size_t)t), e = std::min(n, b + per); if (b < e) pool.emplace_back([=]() { fn(b, e); }); }
-  fn((size_t)0, std::min(n, per));
+  try { for (int t = 1; t < threads; t++) pool.emplace_back(work); } catch (...) {}   // (no thread to be had: the caller's thread does the rest)
+  work();
   for (std::thread& t : pool) t.join();
 }
 
@@ -505,7 +507,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
     std::atomic<size_t> next(0);
     auto work = [&]() { for (size_t k = next.fetch_add(1); k < todo.size(); k = next.fetch_add(1)) buildMesh(c->geoms[todo[k]], 1); };
     std::vector<std::thread> pool;
-    for (int t = 1; t < nThreads; t++) pool.emplace_back(work);
+    try { for (int t = 1; t < nThreads; t++) pool.emplace_back(work); } catch (...) {}
     work();
     for (std::thread& t : pool) t.join();
   } else for (size_t gi : todo) buildMesh(c->geoms[gi], nThreads);

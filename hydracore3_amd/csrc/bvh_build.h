@@ -216,6 +216,51 @@ private:
   }
 };
 
+// The same tree as 4-wide compressed nodes (BvhNode4, hpt_types.h) for the heavy-scene kernels. A node adopts its grandchildren, largest surface
+// first, until it has four children or only leaves are left. Child boxes are the (padded) BVH2 child boxes, quantised outwards in the node's frame
+// (quantizeNode4); src[4 * node + child] = (BVH2 node << 1 | side) remembers where each box lives so that a refit can requantise. `tree` must have
+// an inner root. depth = inner levels of the wide tree (a traversal leaves at most three children waiting per level).
+inline void collapseToWide(const Bvh2& tree, std::vector<BvhNode4>& n4, std::vector<uint>& src4, uint& depth4)
+{
+  n4.clear(); src4.clear(); depth4 = 1;
+  n4.reserve(tree.nodes.size() / 2 + 1); src4.reserve(2 * tree.nodes.size() + 4);
+  struct Item { uint node2, idx4, depth; };
+  std::vector<Item> todo; todo.push_back({ tree.rootRef, 0u, 1u });
+  n4.push_back(BvhNode4()); src4.resize(4, 0xFFFFFFFFu);
+  auto area = [&](uint node2, uint side) { const float* q = tree.nodes[node2].q + 6 * side; const float dx = q[1] - q[0], dy = q[3] - q[2], dz = q[5] - q[4]; return dx * dy + dy * dz + dz * dx; };
+  auto refOf = [&](uint k) { const BvhNode& n = tree.nodes[k >> 1]; return (k & 1u) ? n.ref1 : n.ref0; };
+  while (!todo.empty()) {
+    const Item it = todo.back(); todo.pop_back();
+    depth4 = std::max(depth4, it.depth);
+    uint kids[4]; int nk = 2;                                      // each kid = (BVH2 node << 1 | side)
+    kids[0] = it.node2 << 1; kids[1] = (it.node2 << 1) | 1u;
+    while (nk < 4) {
+      int best = -1; float bestA = -1.0f;
+      for (int k = 0; k < nk; k++) { const uint r = refOf(kids[k]); if (r != REF_NONE && !(r & REF_LEAF)) { const float a = area(kids[k] >> 1, kids[k] & 1u); if (a > bestA) { bestA = a; best = k; } } }
+      if (best < 0) break;
+      const uint inner = refOf(kids[best]);
+      kids[best] = inner << 1; kids[nk++] = (inner << 1) | 1u;
+    }
+    float lo[4][3], hi[4][3]; uint valid = 0;
+    BvhNode4 nd; std::memset(&nd, 0, sizeof(nd));
+    for (int k = 0; k < 4; k++) nd.ref[k] = REF_NONE;
+    for (int k = 0; k < nk; k++) {
+      const uint r = refOf(kids[k]);
+      if (r == REF_NONE) continue;
+      const float* q = tree.nodes[kids[k] >> 1].q + 6 * (kids[k] & 1u);
+      for (int a = 0; a < 3; a++) { lo[k][a] = q[2 * a]; hi[k][a] = q[2 * a + 1]; }
+      valid |= 1u << k;
+      src4[4 * (size_t)it.idx4 + k] = kids[k];
+      if (r & REF_LEAF) nd.ref[k] = r;
+      else { nd.ref[k] = (uint)n4.size(); todo.push_back({ r, (uint)n4.size(), it.depth + 1u }); n4.push_back(BvhNode4()); src4.resize(src4.size() + 4, 0xFFFFFFFFu); }
+    }
+    uint keep[4]; for (int k = 0; k < 4; k++) keep[k] = nd.ref[k];
+    quantizeNode4(lo, hi, valid, nd);
+    for (int k = 0; k < 4; k++) nd.ref[k] = keep[k];
+    n4[it.idx4] = nd;
+  }
+}
+
 // shift a tree's local references so that it can live at nodeBase / triBase of the shared arrays
 inline uint patchRef(uint ref, uint nodeBase, uint triBase)
 {

@@ -740,8 +740,9 @@ def test_exr_decoders_agree_and_read_what_was_written(tmp_path):
 def test_parallel_bvh_build_equals_the_sequential_one(tmp_path):
     """Bvh2Builder's thread pool (csrc/bvh_build.h): the top of the tree by the calling thread, subtrees of disjoint primitive ranges by worker
     threads, appended afterwards - same primitive order, depth and, node for node, the same child boxes and leaves as the sequential build,
-    on random boxes and on a regular grid with many equal centroids (tests/cpp/bvh_build_test.cpp, plain g++)."""
+    on random boxes and on a regular grid with many equal centroids; and collapseToWide's 4-wide tree of each: every BVH2 leaf reachable exactly
+    once, two to four children per node, every decoded child box around its BVH2 source box (tests/cpp/bvh_build_test.cpp, plain g++)."""
     exe = str(tmp_path / "bvh_build_test")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", os.path.join(ROOT, "tests", "cpp", "bvh_build_test.cpp"), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True)
-    assert r.returncode == 0 and r.stdout.count("equal the sequential one") == 3, r.stdout + r.stderr
+    assert r.returncode == 0 and r.stdout.count("equal the sequential one") == 3 and r.stdout.count("every leaf once") == 3, r.stdout + r.stderr

@@ -106,12 +106,15 @@ struct WfJob
 #define HPT_WF_SHADE_FULL_WAVES 3      // the shade kernel with every BSDF branch: 1 M-triangle interior forced onto it 209 (4 waves) -> 214 Mpaths/s (profiles/ab_wfs.sh)
 #endif
 #ifndef HPT_WF_SHADE_WAVES
-#define HPT_WF_SHADE_WAVES 4
+#define HPT_WF_SHADE_WAVES 5           // the lean forward shade kernel (98 VGPRs, no spills): 1 M triangles 4 / 5 / 6 waves -> 286.8 / 291.8 / 270.4 Mpaths/s (profiles/ab.sh)
+#endif
+#ifndef HPT_WF_SHADE_DR_WAVES
+#define HPT_WF_SHADE_DR_WAVES 4        // the DR shade kernel holds the adjoint record's terms as well (112 VGPRs)
 #endif
 #ifndef HPT_WF_WAVES
 #define HPT_WF_WAVES 5   // measured on the 1M-triangle scene: 4 -> 213, 5 -> 224, 6 -> 217 Mpaths/s (96 VGPRs: no spills; 24 KB of LDS per block)
 #endif
-#define HPT_WFS_BOUNDS(DR, LEAN) __launch_bounds__(256, ((DR) || (LEAN)) ? HPT_WF_SHADE_WAVES : HPT_WF_SHADE_FULL_WAVES)
+#define HPT_WFS_BOUNDS(DR, LEAN) __launch_bounds__(256, (DR) ? HPT_WF_SHADE_DR_WAVES : ((LEAN) ? HPT_WF_SHADE_WAVES : HPT_WF_SHADE_FULL_WAVES))
 
 __global__ void wfInitKernel(WfPool P, uint n, uint passNum);
 template <bool DR, bool LEAN, bool MOTION = false>

@@ -1043,7 +1043,7 @@ HPT_DEV uint remapMaterialId(const DevScene& S, uint a_mId, uint a_instId)
 // Semantics of the Embree backend (EmbreeRT.cpp:310-484): two-level scene, ray taken into object space with the inverse
 // instance matrix, t shared between spaces, no back-face culling, hit iff tnear <= t <= tfar.
 // Closest hit = min t with ties broken by (instId, primId): independent of tree shape and traversal order.
-struct HitRec { float t; uint prim, inst; float u, v; };   // inst == 0xFFFFFFFF: miss
+struct HitRec { float t; uint prim, inst; float u, v; uint slot = 0xFFFFFFFFu; };   // inst == 0xFFFFFFFF: miss; slot: the hit's triangle record (single-level layout), for DevScene::shadeTris
 
 struct TravStats { uint nodes, tris, insts, waveNodeIters, waveTriIters; };   // wave*: counted by the first active lane of each trip
 HPT_DEV bool firstActiveLane() { const uint l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); return l == (uint)__builtin_amdgcn_readfirstlane((int)l); }
@@ -1328,7 +1328,9 @@ HPT_DEV bool traceRayFlat(const DevScene& S, const V3 wo, const V3 wd, float tne
           else toObjectSpace(S.insts, inst, wo, wd, o, d);
           curInst = inst;
         }
-        if (triangleTest(a, b, c, o, d, tnear, inst, hit.t, hit.prim, hit.inst, hit.u, hit.v, found) && ANY) return true;
+        const bool upd = triangleTest(a, b, c, o, d, tnear, inst, hit.t, hit.prim, hit.inst, hit.u, hit.v, found);
+        if (upd) hit.slot = first + k;
+        if (upd && ANY) return true;
       }
       if (sp > 0) HPT_POP(); else break;
     }

@@ -143,6 +143,23 @@ __global__ void refitTriBoxesKernel(const BvhTri* tris, const float* instMat, ui
   float* o = triBox + 6u * (size_t)k;
   o[0] = lo[0]; o[1] = hi[0]; o[2] = lo[1]; o[3] = hi[1]; o[4] = lo[2]; o[5] = hi[2];
 }
+// DevScene::shadeTris: one 64-byte record per triangle record of the single-level layout (see hpt_types.h)
+__global__ void buildShadeTrisKernel(const DevScene S, uint n, float4* out)
+{
+  const uint k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const BvhTri t = S.tris[k];
+  const uint instId = t.instId, prim = t.primId;
+  const uint geomId = S.insts[instId].geomId;
+  const uint triOffset = S.matVertOffset[2 * geomId + 0], vertOffset = S.matVertOffset[2 * geomId + 1];
+  const uint A = S.triIndices[(triOffset + prim) * 3 + 0], B = S.triIndices[(triOffset + prim) * 3 + 1], C = S.triIndices[(triOffset + prim) * 3 + 2];
+  const float4 nA = ((const float4*)S.vData8f)[2 * (A + vertOffset)], nB = ((const float4*)S.vData8f)[2 * (B + vertOffset)], nC = ((const float4*)S.vData8f)[2 * (C + vertOffset)];
+  const float tyA = S.vData8f[8 * (A + vertOffset) + 7], tyB = S.vData8f[8 * (B + vertOffset) + 7], tyC = S.vData8f[8 * (C + vertOffset) + 7];
+  const uint matId = remapMaterialId(S, S.matIdByPrimId[triOffset + prim], instId) & 0x00FFFFFFu;
+  float4* o = out + 4u * (size_t)k;
+  o[0] = nA; o[1] = nB; o[2] = nC; o[3] = make_float4(tyA, tyB, tyC, __uint_as_float(matId));
+}
+
 // after the level passes: every 4-wide node requantises its children's boxes from the BVH2 nodes they come from (src = node << 1 | side)
 __global__ void refitNodes4Kernel(BvhNode4* nodes4, const uint* src, const BvhNode* nodes2, uint count)
 {

@@ -102,6 +102,8 @@ struct hpt_ctx
   DevBuf<uint> dLevelNodes; DevBuf<float> dTriBox, dNodeBounds, dInstO2W;
   DevBuf<BvhNode4> dNodes4; DevBuf<uint> dNodes4Src;     // the single-level tree collapsed to 4-wide compressed nodes; per child the BVH2 (node << 1 | side) its box comes from
   uint nodes4Count = 0, stackNeeded4 = 0;                // (0: no wide tree)
+  DevBuf<float4> dShadeTris;                             // DevScene::shadeTris (64 B per triangle record of the single-level layout), built lazily before a launch
+  bool shadeTrisDirty = true, shadeTrisEnabled = true;   // (hpt_set_option("shade_records", 0): the kernels gather vertex data through the index chain)
   int  buildThreads = 0;                                 // hpt_set_option("build_threads", n): host threads of CommitScene (0: automatic)
   bool statsWide = false;                                // hpt_set_option("stats_wide", 1): the instrumented probe walks the 4-wide tree (what a wavefront call on this scene does)
   bool wideEnabled = true;                               // hpt_set_option("wide_nodes", 0): the trace kernel walks the BVH2
@@ -186,6 +188,7 @@ extern "C" int hpt_create(int device, hpt_ctx** out)
   (void)hipEventCreate(&c->ev0); (void)hipEventCreate(&c->ev1);
   if (const char* e = std::getenv("HPT_NODE_MIN")) c->nodeMinOverride = std::atoi(e) & 63;
   if (const char* e = std::getenv("HPT_WF_GRACE")) c->wfGrace = (uint)std::atoi(e);
+  if (const char* e = std::getenv("HPT_SHADE_RECORDS")) c->shadeTrisEnabled = std::atoi(e) != 0;
   if (const char* e = std::getenv("HPT_WIDE_NODES")) c->wideEnabled = std::atoi(e) != 0;   // (read before any scene is committed: CommitScene derives DevScene::megaWide from it)
   std::memset(&c->S, 0, sizeof(DevScene));
   c->S.rootRef = REF_NONE;
@@ -199,7 +202,7 @@ extern "C" void hpt_destroy(hpt_ctx* c)
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   (void)hpt_comm_destroy(c);
-  c->dNodes.release(); c->dTris.release(); c->dInsts.release(); c->dSweepInsts.release(); c->dSweepTris.release(); c->dLevelNodes.release(); c->dNodes4.release(); c->dNodes4Src.release(); c->dTriBox.release(); c->dNodeBounds.release(); c->dInstO2W.release(); c->dTriIndices.release(); c->dMatIdByPrim.release();
+  c->dNodes.release(); c->dTris.release(); c->dInsts.release(); c->dSweepInsts.release(); c->dSweepTris.release(); c->dLevelNodes.release(); c->dShadeTris.release(); c->dNodes4.release(); c->dNodes4Src.release(); c->dTriBox.release(); c->dNodeBounds.release(); c->dInstO2W.release(); c->dTriIndices.release(); c->dMatIdByPrim.release();
   c->dMatVertOffset.release(); c->dPackedXY.release(); c->dVData.release(); c->dNormMat.release(); c->dRemapInst.release();
   c->dRemapLists.release(); c->dMaterials.release(); c->dLights.release(); c->dTextures.release(); c->dArrays1f.release(); c->dSpecValues.release(); c->dSpecOffsetSz.release(); c->dCieXYZ.release(); c->dGens.release();
   c->dQueue.release(); c->dStackOvf.release(); c->dCounters.release(); c->dFrame.release(); c->dRecord.release(); c->dRef.release(); c->dData.release();
@@ -464,7 +467,7 @@ static int refit_flat(hpt_ctx* c)
   HIPCHK(c, hipDeviceSynchronize());
   c->S.insts = c->dInsts.p;
   c->tCommit[0] = float(t1 - t0); c->tCommit[1] = float(t2 - t1); c->tCommit[2] = float(now_ms() - t2); c->tCommit[3] = 1.0f;
-  c->accelCommitted = true;
+  c->accelCommitted = true; c->shadeTrisDirty = true;
   return HPT_OK;
 }
 
@@ -645,7 +648,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
     c->stackNeeded = tree.depth + 1u;
     if (std::getenv("HPT_DEBUG_ACCEL")) std::fprintf(stderr, "[hydra_hip] single-level BVH: %zu triangles, %zu nodes, depth %u, stack %u (LDS part %d), sah visits %.2f, nodeMin %u\n", instTris, tree.nodes.size(), tree.depth, c->stackNeeded, LDS_STACK, c->sahVisits, c->S.nodeMin);
     if (c->stackNeeded > MAX_STACK) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: BVH deeper than the 64-entry traversal stack");
-    c->accelCommitted = true;
+    c->accelCommitted = true; c->shadeTrisDirty = true;
     return HPT_OK;
   }
   // ---- top level over the instances' world boxes ----
@@ -738,7 +741,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   c->stackNeeded = tlas.depth + 1u + maxBlasDepth + 1u;
   if (std::getenv("HPT_DEBUG_ACCEL")) std::fprintf(stderr, "[hydra_hip] two-level BVH: %zu instances, TLAS depth %u, deepest BLAS %u, stack %u (LDS part %d)\n", ni, tlas.depth, maxBlasDepth, c->stackNeeded, LDS_STACK);
   if (c->stackNeeded > MAX_STACK) return c->fail(HPT_ERR_UNSUPPORTED, "CommitScene: BVH deeper than the 64-entry traversal stack");
-  c->accelCommitted = true;
+  c->accelCommitted = true; c->shadeTrisDirty = true;
   return HPT_OK;
 }
 
@@ -1054,7 +1057,7 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
   for (uint i = 0; i < d->numLights; i++) c->hLightGeom[i] = ((const LightRec*)d->lights)[i].geomType;
   // a new scene invalidates the environment ids of the previous UpdateMembersPlainData until the next one
   S.envTexId = S.envLightId = S.envCamBackId = 0xFFFFFFFFu; S.envEnableSam = 0;
-  c->sceneUploaded = true;
+  c->sceneUploaded = true; c->shadeTrisDirty = true;
   c->tPathTrace[1] = c->tNaive[1] = c->tDR[1] = float(now_ms() - t0);   // host -> device time of the scene commit
   return HPT_OK;
 }
@@ -1151,6 +1154,7 @@ extern "C" int hpt_update_mat_id_offsets(hpt_ctx* c, const uint32_t* mvo, size_t
   }
   (void)hipSetDevice(c->device);
   HIPCHK(c, hipMemcpy(c->dMatVertOffset.p, mvo, 2 * numGeoms * sizeof(uint32_t), hipMemcpyHostToDevice));
+  c->shadeTrisDirty = true;                                   // the shading records were gathered through the old offsets
   return HPT_OK;
 }
 
@@ -1242,6 +1246,25 @@ static void launchPTMotion(const DevScene& S, const Job& job, int blocks, hipStr
   }
 }
 
+// DevScene::shadeTris for this launch: gltf / emissive scenes on the single-level layout get one 64-byte record of shading data per triangle
+// record (rebuilt on the device after a commit or a table upload); everything else leaves the pointer null and gathers through the index chain
+static int ensureShadeTris(hpt_ctx* c, hipStream_t st)
+{
+  const bool want = c->shadeTrisEnabled && c->S.flatMode != 0u && c->S.motion == 0u && c->leanMaterials && !c->forceFull && c->S.lensCount == 0u &&
+                    c->instTris > 0 && c->instTris < (size_t(1) << 28) && c->sceneUploaded && c->accelCommitted;
+  if (!want) { c->S.shadeTris = nullptr; return HPT_OK; }
+  if (c->shadeTrisDirty || c->dShadeTris.n < 4 * c->instTris) {
+    HIPCHK(c, c->dShadeTris.alloc(4 * c->instTris));
+    DevScene Sb = c->S; Sb.shadeTris = nullptr;
+    const uint n = (uint)c->instTris;
+    buildShadeTrisKernel<<<dim3((n + 255u) / 256u), dim3(256), 0, st>>>(Sb, n, c->dShadeTris.p);
+    HIPCHK(c, hipGetLastError());
+    c->shadeTrisDirty = false;
+  }
+  c->S.shadeTris = c->dShadeTris.p;
+  return HPT_OK;
+}
+
 static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStream_t st)
 {
   const bool inRays = job.inRayPos != nullptr;
@@ -1282,6 +1305,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
     HIPCHK(c, hipEventRecord(c->ev1, st));
     return HPT_OK;
   }
+  { const int rcS = ensureShadeTris(c, st); if (rcS != HPT_OK) return rcS; }
   const bool motion = c->S.motion != 0;
   const bool fullMaterials = motion || !dr && !(c->leanMaterials && !c->forceFull && c->S.lensCount == 0u && !naive && !inRays && !(c->instrument && !dr));   // MODE 0 / 1 / 2 / STATS kernels
   const int blocks = (int)std::min<size_t>((size_t)gridBlocks(c, dr, fullMaterials), ((size_t)job.tidCount + 255) / 256);
@@ -1831,6 +1855,7 @@ extern "C" int hpt_set_option(hpt_ctx* c, const char* name, int value)
   else if (k == "dbg_no_normal_lerp") { if (c->S.motion) c->S.motion = value ? 3u : 1u; }   // diagnostic: moving instances without the reference's normal interpolation (bit 1 of DevScene::motion)
   else if (k == "dbg_wf_iter_cap") c->wfIterCap = (uint)value;                         // diagnostic: make the wavefront loop's safety net reachable in a test
   else if (k == "dr_skip_nonfinite") c->drSkipNonFinite = value != 0;                  // PathTraceDR: drop samples whose radiance is not finite (default 0: PixelLossPT as in the reference)
+  else if (k == "shade_records") c->shadeTrisEnabled = value != 0;                     // 0: no DevScene::shadeTris (A/B, diagnosis)
   else if (k == "build_threads") c->buildThreads = std::min(value, 64);                // host threads CommitScene builds its trees with (0: the usable cores, at most 16)
   else if (k == "stats_wide") c->statsWide = value != 0;
   else if (k == "wide_nodes") { c->wideEnabled = value != 0; c->S.megaWide = (c->wideEnabled && c->nodes4Count != 0u && c->S.flatMode != 0u && c->sahVisits >= HEAVY_SAH_VISITS) ? 1u : 0u; }   // both users of the tree, at once                             // 0: the wavefront trace kernel walks the BVH2 instead of the 4-wide compressed tree (A/B, diagnosis)

@@ -235,15 +235,26 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
   {
     // -- surface attributes (integrator_pt.cpp:238-311) --
     const uint instId = hit.inst;
-    const uint geomId = S.insts[instId].geomId;
-    const uint triOffset = S.matVertOffset[2 * geomId + 0], vertOffset = S.matVertOffset[2 * geomId + 1];
     const V3 hitPos = rpos + hit.t * (1.f - 1e-6f) * rdir;
     const float uvx = hit.v, uvy = hit.u;                              // coords[0] = v, coords[1] = u (EmbreeRT.cpp:350-352)
-    const uint A = S.triIndices[(triOffset + hit.prim) * 3 + 0];
-    const uint B = S.triIndices[(triOffset + hit.prim) * 3 + 1];
-    const uint C = S.triIndices[(triOffset + hit.prim) * 3 + 2];
-    const float4 nA = ((const float4*)S.vData8f)[2 * (A + vertOffset)], nB = ((const float4*)S.vData8f)[2 * (B + vertOffset)], nC = ((const float4*)S.vData8f)[2 * (C + vertOffset)];
-    const float tyA = S.vData8f[8 * (A + vertOffset) + 7], tyB = S.vData8f[8 * (B + vertOffset) + 7], tyC = S.vData8f[8 * (C + vertOffset) + 7];
+    // gltf / emissive kernels on the single-level layout: the three vertices' shading data and the material id come from ONE 64-byte record
+    // per triangle (DevScene::shadeTris) instead of the chain instance -> mesh offsets -> indices -> vertices / primitive -> id -> remap
+    const bool packed = (DR || LEAN) && !MOTION && S.shadeTris != nullptr && hit.slot != 0xFFFFFFFFu;
+    uint geomId = 0, triOffset = 0, vertOffset = 0, A = 0, B = 0, C = 0, packedMat = 0;
+    float4 nA, nB, nC; float tyA, tyB, tyC;
+    if (packed) {
+      const float4* sp = S.shadeTris + 4u * (size_t)hit.slot;
+      const float4 q3 = sp[3];
+      nA = sp[0]; nB = sp[1]; nC = sp[2]; tyA = q3.x; tyB = q3.y; tyC = q3.z; packedMat = __float_as_uint(q3.w);
+    } else {
+      geomId = S.insts[instId].geomId;
+      triOffset = S.matVertOffset[2 * geomId + 0]; vertOffset = S.matVertOffset[2 * geomId + 1];
+      A = S.triIndices[(triOffset + hit.prim) * 3 + 0];
+      B = S.triIndices[(triOffset + hit.prim) * 3 + 1];
+      C = S.triIndices[(triOffset + hit.prim) * 3 + 2];
+      nA = ((const float4*)S.vData8f)[2 * (A + vertOffset)]; nB = ((const float4*)S.vData8f)[2 * (B + vertOffset)]; nC = ((const float4*)S.vData8f)[2 * (C + vertOffset)];
+      tyA = S.vData8f[8 * (A + vertOffset) + 7]; tyB = S.vData8f[8 * (B + vertOffset) + 7]; tyC = S.vData8f[8 * (C + vertOffset) + 7];
+    }
     const float wA = 1.0f - uvx - uvy;
     const V3 nrmO = v3(wA * nA.x + uvy * nB.x + uvx * nC.x, wA * nA.y + uvy * nB.y + uvx * nC.y, wA * nA.z + uvy * nB.z + uvx * nC.z);
     const V2 uv = v2(wA * nA.w + uvy * nB.w + uvx * nC.w, wA * tyA + uvy * tyB + uvx * tyC);
@@ -262,7 +273,7 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
     const float flipNorm = dot(rdir, hitNorm) > 0.001f ? -1.0f : 1.0f;
     hitNorm = flipNorm * hitNorm;
     if (flipNorm < 0.0f) flags |= RAY_FLAG_HAS_INV_NORMAL; else flags &= ~RAY_FLAG_HAS_INV_NORMAL;
-    const uint matId = remapMaterialId(S, S.matIdByPrimId[triOffset + hit.prim], instId) & 0x00FFFFFFu;
+    const uint matId = packed ? packedMat : (remapMaterialId(S, S.matIdByPrimId[triOffset + hit.prim], instId) & 0x00FFFFFFu);
     const MaterialRec& m = S.materials[matId];
     const uint mtype = m.mtype;
     const V3 vdir = (-1.0f) * rdir;

@@ -105,6 +105,11 @@ HPT_HD void quantizeNode4(const float lo[4][3], const float hi[4][3], uint valid
   out.exps = exps;
 }
 
+// 64 bytes of shading data per triangle record of the single-level layout, in the records' order: what kernel_RayTrace2 gathers through five
+// dependent fetches (instance -> mesh offsets -> three indices -> three vertices, primitive -> material id -> remap list) in ONE line:
+//   q0 = (nA.xyz, txA)  q1 = (nB.xyz, txB)  q2 = (nC.xyz, txC)  q3 = (tyA, tyB, tyC, material id after the instance's remap list)
+// - the values themselves, so the interpolation is the same arithmetic on the same numbers. Built on the device (buildShadeTrisKernel).
+
 // 48-byte triangle: v0, e1 = v1-v0, e2 = v2-v0 (what Moeller-Trumbore consumes), primId in the spare lane
 struct BvhTri { float v0[3]; uint primId; float e1[3]; uint instId; float e2[3]; uint pad1; };   // instId: flat (single-level) mode only
 static_assert(sizeof(BvhTri) == 48, "triangle record must be 48 bytes");
@@ -135,6 +140,7 @@ struct DevScene
   uint           flatMode;        // 1: one world-space BVH2 over all instanced triangles (leaf triangles carry their instance id)
   const BvhNode4* nodes4;         // single-level layout, static scenes: the same tree collapsed to 4-wide compressed nodes (wfTraceKernel<WIDE>), or null
   uint           root4;           // its root (a BvhNode4 index)
+  const float4*  shadeTris;       // single-level layout, gltf / emissive scenes: 64 B of shading data per triangle record (same index as `tris`): see ShadeTri
   uint           megaWide;        // the megakernel's single-level traversal walks nodes4 too (heavy scenes: set with nodeMin4)
   uint           statsWide;       // instrumented megakernel only: count the walk over nodes4 (what the wavefront trace kernel does on this scene)
   uint           nodeMin4;        // nodeMin for the walk over nodes4 (a 4-wide visit is three times the work of a BVH2 one: the vote pays earlier)

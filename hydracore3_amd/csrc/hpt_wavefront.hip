@@ -104,6 +104,7 @@ __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const W
       rpos = v3(ro.x, ro.y, ro.z); misPdf = ro.w; rdir = v3(rd.x, rd.y, rd.z); misIor = rd.w;
       thr = v3(t4.x, t4.y, t4.z); flags = __float_as_uint(t4.w);
       HitRec hit; hit.t = h4.x; hit.u = h4.y; hit.v = h4.z; hit.prim = __float_as_uint(h4.w); hit.inst = P.hitInst[s];
+      if (S.shadeTris != nullptr) hit.slot = __float_as_uint(h4.w);      // (with the shading records in use the trace pass reports the hit's record, not its primitive id)
       V3 rA = v3(0, 0, 0), rS = v3(0, 0, 0), rdA = v3(0, 0, 0), rdS = v3(0, 0, 0); Taps taps; uint recTex = 0xFFFFFFFFu;   // adjoint record of this vertex (DR)
       for (int k = 0; k < 4; k++) { taps.off[k] = 0; taps.w[k] = 0.0f; }
       const V3 thrBefore = thr;
@@ -234,7 +235,7 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
   uint slot = 0, cur = REF_NONE, curInst = 0xFFFFFFFFu;
   int  sp = 0;
   V3 wo = v3(0, 0, 0), wd = v3(0, 0, 1), o = wo, d = wd, id = v3(0, 0, 0);
-  float hitT = 0.0f, hitU = 0.0f, hitV = 0.0f; uint hitPrim = 0, hitInst = 0xFFFFFFFFu;
+  float hitT = 0.0f, hitU = 0.0f, hitV = 0.0f; uint hitPrim = 0, hitInst = 0xFFFFFFFFu, hitSlot = 0xFFFFFFFFu;
   unsigned long long nodeLane = 0, nodeWave = 0, triLane = 0, triWave = 0, refills = 0, suspended = 0;
   unsigned long long tPh[4] = {0, 0, 0, 0}, tPrev = 0, trips = 0;            // STATS: wave cycles in refill / node loop / leaves / ray end
 #define WSTAMP(i) do { if (STATS) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tPh[i] += tn - tPrev; tPrev = tn; } } while (0)
@@ -298,12 +299,12 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
           slot = q & 0x3FFFFFFFu; isAny = (q >> 31) != 0u; resumed = (q & 0x40000000u) != 0u;
           o = wo; d = wd; id = rcp3(wd);
           cur = WIDE ? S.root4 : S.rootRef; curInst = 0xFFFFFFFFu; sp = 0; found = false;
-          hitPrim = 0xFFFFFFFFu; hitInst = 0xFFFFFFFFu; hitU = 0.0f; hitV = 0.0f;
+          hitPrim = 0xFFFFFFFFu; hitInst = 0xFFFFFFFFu; hitSlot = 0xFFFFFFFFu; hitU = 0.0f; hitV = 0.0f;
           if (resumed) {                                                    // pick the traversal up where the last pass left it
             const uint* r = suspIn + __float_as_uint(hitT);
             cur = r[0 * SM]; sp = (int)r[1 * SM]; curInst = r[2 * SM];
             hitT = __uint_as_float(r[3 * SM]); hitU = __uint_as_float(r[4 * SM]); hitV = __uint_as_float(r[5 * SM]);
-            hitPrim = r[6 * SM]; hitInst = r[7 * SM]; found = r[8 * SM] != 0u;
+            hitPrim = r[6 * SM]; hitInst = r[7 * SM]; found = r[8 * SM] != 0u; hitSlot = r[9 * SM];
             for (int k = 0; k < sp; k++) { const uint v = r[(WF_SUSP_WORDS + k) * SM]; if (DEEP) stkPush(stk, k, v); else stk.lds[k * 256] = v; }
             if (FLAT) curInst = 0xFFFFFFFFu;                                 // the object-space ray is rebuilt at the next triangle
             else if (curInst != 0xFFFFFFFFu) {
@@ -370,7 +371,7 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
                   curInst = inst;
                 }
               }
-              (void)triangleTest(a, b, c, o, d, 0.0f, inst, hitT, hitPrim, hitInst, hitU, hitV, found);
+              if (triangleTest(a, b, c, o, d, 0.0f, inst, hitT, hitPrim, hitInst, hitU, hitV, found)) hitSlot = first + k;
             }
             if (isAny && found) done = true;
             else if (sp > 0) HPT_POP(); else done = true;
@@ -390,7 +391,7 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
         WSTAMP(2);
         if (done) {
           if (isAny) P.occl[slot] = found ? 1u : 0u;
-          else { P.hit[slot] = make_float4(hitT, hitU, hitV, __uint_as_float(hitPrim)); P.hitInst[slot] = found ? hitInst : 0xFFFFFFFFu; }
+          else { P.hit[slot] = make_float4(hitT, hitU, hitV, __uint_as_float((FLAT && S.shadeTris != nullptr) ? hitSlot : hitPrim)); P.hitInst[slot] = found ? hitInst : 0xFFFFFFFFu; }
           if (resumed) atomicAnd(&P.inflight[slot], isAny ? ~2u : ~1u);
           has = false;
           break;
@@ -413,7 +414,7 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
         uint* r = suspOut + rec;
         r[0 * SM] = cur; r[1 * SM] = (uint)sp; r[2 * SM] = curInst;
         r[3 * SM] = __float_as_uint(hitT); r[4 * SM] = __float_as_uint(hitU); r[5 * SM] = __float_as_uint(hitV);
-        r[6 * SM] = hitPrim; r[7 * SM] = hitInst; r[8 * SM] = found ? 1u : 0u;
+        r[6 * SM] = hitPrim; r[7 * SM] = hitInst; r[8 * SM] = found ? 1u : 0u; r[9 * SM] = hitSlot;
         for (int k = 0; k < sp; k++) r[(WF_SUSP_WORDS + k) * SM] = DEEP ? stkPop(stk, k) : stk.lds[k * 256];
         atomicOr(&P.inflight[slot], isAny ? 2u : 1u);
         has = false;

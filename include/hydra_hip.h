@@ -259,6 +259,8 @@ int  hpt_set_schedule(hpt_ctx* ctx, int schedule, int refillBelow, int traceBloc
  *   "dr_skip_nonfinite"     PathTraceDR: 1 = a sample whose radiance is not finite contributes neither colour, loss nor gradient (what an
  *                           optimisation loop wants: one NaN poisons Adam's moments for good); 0 (default) = PixelLossPT as the reference
  *                           has it, which adds every sample (diff_render/integrator_dr.cpp:1124-1131)
+ *   "shade_records"         0: gltf / emissive scenes on the single-level layout gather vertex data through the index chain instead of the 64-byte
+ *                           per-triangle shading records (kernel studies; environment: HPT_SHADE_RECORDS=0)
  *   "build_threads"         n: host threads CommitScene builds its trees with (meshes in parallel, big trees split into subtrees); 0 = the cores this
  *                           process may use, at most 16. The tree is the same whatever n is (only the numbering of its nodes differs)
  *   "wide_nodes"            0: the wavefront trace kernel walks the BVH2 instead of the 4-wide compressed tree of static single-level scenes

@@ -41,7 +41,7 @@ struct Job
 #endif
 // MODE: 0 = PathTrace (MIS / shadow / stupid by m_intergatorType), 1 = NaivePathTrace, 2 = PathTraceFromInputRays (the caller's rays
 // instead of camera rays, linear tid -> output index, raw accumColor: integrator_pt.cpp:159-199, 659-676, 761-798),
-// 3 = PathTrace for scenes with gltf + emissive materials only (shadeVertex<LEAN>)
+// 3 = PathTrace for scenes with gltf + emissive materials only (shadeVertex<LEAN>), 4 / 5 / 6 = 0 / 1 / 2 for scenes with thin films (shadeVertex<FILM>)
 // waves per SIMD the kernels with every BSDF branch (MODE 0 / 1 / 2) are compiled for; the lean and DR kernels keep HPT_MIN_WAVES.
 // Measured (profiles/ab_full.sh, 1024^2 x 64 spp, Mpaths/s at 4 / 3 / 2 waves): Cornell forced onto this kernel 1410 / 1531 / 1264,
 // legacy_materials 1585 / 1714 / 1528, env_map 1425 / 1507 / 1369, typed_materials 1123 / 1125 / 1105.

@@ -1,6 +1,7 @@
 // Host side of the C ABI (include/hydra_hip.h): context, BVH2 build + upload, scene tables, launches, timing.
 // Compiled by hipcc together with the kernels; exports only the extern "C" hpt_* symbols.
 #include "plastic_precompute.h"
+#include "film_precompute.h"
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -95,6 +96,10 @@ struct hpt_ctx
   std::vector<void*> texData; std::vector<TexRec> hTextures;
   DevBuf<float> dSpecValues; DevBuf<uint> dSpecOffsetSz; DevBuf<float4> dCieXYZ;   // spectral tables (m_spec_values, m_spec_offset_sz, m_cie_xyz)
   bool spectralOk = false; std::string spectralWhyNot;   // whether the uploaded scene is within the spectral kernel's scope
+  // thin films (integrator_pt.h:587-590): the tables a film material indexes, and what the uploaded materials say about them
+  DevBuf<float> dFilmsEtaK, dPrecompFilms; DevBuf<uint> dFilmsSpecId;
+  std::vector<uint> hFilmsSpecId; size_t numFilmsEtaK = 0, numPrecompFilms = 0; uint numSpectraHost = 0;
+  bool hasFilm = false, filmTablesRGB = true, filmTablesSpectral = true;   // a MAT_TYPE_THIN_FILM is in the table; its precomputed tables have the size RGB / spectral rendering reads
   DevBuf<float> dArrays1f; size_t numArrays1f = 0;       // m_arrays1f (pdf table of a sampled environment map)
   DevBuf<float4> dLensLines;                             // m_lines of the lens simulation (hpt_set_optics)
   DevBuf<float> dInstMotion, dNormMat2;                  // motion blur: key matrices of the moving instances, end-of-motion normal matrices
@@ -204,7 +209,7 @@ extern "C" void hpt_destroy(hpt_ctx* c)
   (void)hpt_comm_destroy(c);
   c->dNodes.release(); c->dTris.release(); c->dInsts.release(); c->dSweepInsts.release(); c->dSweepTris.release(); c->dLevelNodes.release(); c->dShadeTris.release(); c->dNodes4.release(); c->dNodes4Src.release(); c->dTriBox.release(); c->dNodeBounds.release(); c->dInstO2W.release(); c->dTriIndices.release(); c->dMatIdByPrim.release();
   c->dMatVertOffset.release(); c->dPackedXY.release(); c->dVData.release(); c->dNormMat.release(); c->dRemapInst.release();
-  c->dRemapLists.release(); c->dMaterials.release(); c->dLights.release(); c->dTextures.release(); c->dArrays1f.release(); c->dSpecValues.release(); c->dSpecOffsetSz.release(); c->dCieXYZ.release(); c->dGens.release();
+  c->dRemapLists.release(); c->dMaterials.release(); c->dLights.release(); c->dTextures.release(); c->dArrays1f.release(); c->dSpecValues.release(); c->dSpecOffsetSz.release(); c->dCieXYZ.release(); c->dFilmsEtaK.release(); c->dPrecompFilms.release(); c->dFilmsSpecId.release(); c->dGens.release();
   c->dQueue.release(); c->dStackOvf.release(); c->dCounters.release(); c->dFrame.release(); c->dRecord.release(); c->dRef.release(); c->dData.release();
   c->dGrad.release(); c->dLoss.release(); c->dLossAcc.release();
   for (hpt_ctx::WfGroup* g : c->wfGroups) {
@@ -233,6 +238,23 @@ extern "C" int hpt_device_info(hpt_ctx* c, int* numCUs, int* wavefront, char* na
   if (wavefront) *wavefront = 64;
   if (name && nameLen) { std::strncpy(name, c->devName.c_str(), nameLen - 1); name[nameLen - 1] = 0; }
   return HPT_OK;
+}
+
+// ---- precomputeThinFilmSpectral / precomputeThinFilmRGB for the scene loaders (host only, no device needed) ------------------------------------
+extern "C" int hpt_film_precompute(const hpt_film_params* fp, float* outTable, uint64_t outCapacity, uint64_t* outCount, int* outPrecomputed)
+{
+  if (!fp || !outCount) return HPT_ERR_ARG;
+  hydra_hip::film::Params p;
+  p.spectralMode = fp->spectralMode; p.extIOR = fp->extIOR; p.layers = fp->layers; p.eta = fp->eta; p.k = fp->k; p.etaSpecId = fp->etaSpecId; p.kSpecId = fp->kSpecId;
+  p.thickness = fp->thickness; p.thicknessMap = fp->thicknessMap; p.thicknessMin = fp->thicknessMin; p.thicknessMax = fp->thicknessMax;
+  p.specValues = fp->specValues; p.specOffsetSz = fp->specOffsetSz; p.numSpectra = fp->numSpectra; p.cieXYZ = fp->cieXYZ;
+  if (p.layers < 1 || p.layers > hydra_hip::film::MAX_LAYERS) return HPT_ERR_ARG;
+  const bool pre = hydra_hip::film::precomputed(p);
+  if (outPrecomputed) *outPrecomputed = pre ? 1 : 0;
+  *outCount = pre ? (uint64_t)hydra_hip::film::tableSize(p) : 0u;
+  if (!pre || !outTable) return HPT_OK;                        // (a size query)
+  if (outCapacity < *outCount) return HPT_ERR_ARG;
+  return hydra_hip::film::precompute(p, outTable) ? HPT_OK : HPT_ERR_ARG;
 }
 
 // ---- mi::fresnel_coat_precompute for the scene loaders (host only, no device needed) --------------------------------------------------------
@@ -799,8 +821,33 @@ static int check_materials(hpt_ctx* c, const MaterialRec* m, size_t n, size_t nu
       if (m[i].texid[0] >= numTex) return c->fail(HPT_ERR_ARG, "material refers to a texture that does not exist");
       continue;
     }
+    if (t == MAT_TYPE_THIN_FILM) {                            // every index filmArgs / filmReflTrans follow (hpt_film.h)
+      auto bits = [](float f) { uint u; std::memcpy(&u, &f, 4); return u; };
+      const uint layers = bits(m[i].data[FILM_LAYERS_COUNT]);
+      if (layers < 1u || layers > 64u) return c->fail(HPT_ERR_ARG, "thin film: FILM_LAYERS_COUNT must be 1..64");
+      if ((uint64_t)bits(m[i].data[FILM_ETA_OFFSET]) + layers > c->numFilmsEtaK || (uint64_t)bits(m[i].data[FILM_K_OFFSET]) + layers > c->numFilmsEtaK)
+        return c->fail(HPT_ERR_ARG, "thin film: eta / k offsets reach past m_films_eta_k_vec");
+      if ((uint64_t)bits(m[i].data[FILM_ETA_SPECID_OFFSET]) + layers > c->hFilmsSpecId.size() || (uint64_t)bits(m[i].data[FILM_K_SPECID_OFFSET]) + layers > c->hFilmsSpecId.size())
+        return c->fail(HPT_ERR_ARG, "thin film: spectrum id offsets reach past m_films_spec_id_vec");
+      for (uint l2 = 0; l2 < layers; l2++) for (int w = 0; w < 2; w++) {
+        const uint id = c->hFilmsSpecId[bits(m[i].data[w ? FILM_K_SPECID_OFFSET : FILM_ETA_SPECID_OFFSET]) + l2];
+        if (id != 0xFFFFFFFFu && id >= c->numSpectraHost) return c->fail(HPT_ERR_ARG, "thin film: layer refers to a spectrum that does not exist");
+      }
+      const bool tmap = bits(m[i].data[FILM_THICKNESS_MAP]) != 0u, pre = bits(m[i].data[FILM_PRECOMP_FLAG]) != 0u;
+      if (tmap && m[i].texid[2] >= numTex) return c->fail(HPT_ERR_ARG, "thin film: the thickness map does not exist");
+      if (m[i].texid[0] >= numTex) return c->fail(HPT_ERR_ARG, "material refers to a texture that does not exist");
+      const uint64_t off = bits(m[i].data[FILM_PRECOMP_OFFSET]);
+      if (pre && off > c->numPrecompFilms) return c->fail(HPT_ERR_ARG, "thin film: FILM_PRECOMP_OFFSET reaches past m_precomp_thin_films");
+      // the loader sizes a material's table by the mode it loads for (LoadThinFilmMaterial, integrator_pt_scene_mat.cpp:1147-1186): RGB reads
+      // 4 x FILM_ANGLE_RES x 3 (x FILM_THICKNESS_RES with a thickness map), spectral 4 x FILM_ANGLE_RES x FILM_LENGTH_RES or no table at all
+      const uint64_t avail = pre ? c->numPrecompFilms - off : 0u;
+      if (avail < 4ull * FILM_ANGLE_RES * 3ull * (tmap ? (uint64_t)FILM_THICKNESS_RES : 1ull)) c->filmTablesRGB = false;
+      if (pre && avail < 4ull * FILM_ANGLE_RES * FILM_LENGTH_RES) c->filmTablesSpectral = false;
+      c->hasFilm = true;
+      continue;
+    }
     if (t != MAT_TYPE_GLTF && t != MAT_TYPE_GLASS && t != MAT_TYPE_CONDUCTOR && t != MAT_TYPE_DIFFUSE && t != MAT_TYPE_DIELECTRIC && t != MAT_TYPE_PLASTIC && t != MAT_TYPE_LIGHT_SOURCE)
-      return c->fail(HPT_ERR_UNSUPPORTED, "material type " + std::to_string(t) + " (thin film) is outside the hot path's scope");
+      return c->fail(HPT_ERR_UNSUPPORTED, "material type " + std::to_string(t) + " is not one of the reference's");
     if (t == MAT_TYPE_PLASTIC && (uint64_t)m[i].datai[0] + (uint64_t)MI_ROUGH_TRANSMITTANCE_RES > numArrays1f)
       return c->fail(HPT_ERR_ARG, "plastic material: transmittance table outside m_arrays1f");
     if (m[i].texid[1] != 0xFFFFFFFFu && m[i].texid[1] >= numTex) return c->fail(HPT_ERR_ARG, "material refers to a normal map that does not exist");
@@ -893,6 +940,11 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
   (void)hipSetDevice(c->device);
   const double t0 = now_ms();
   if (d->numTextures == 0 || !d->textures) return c->fail(HPT_ERR_ARG, "m_textures must at least hold the white dummy texture");
+  // the film tables first: check_materials follows a film material's indices into them
+  c->numFilmsEtaK = d->filmsEtaK ? d->numFilmsEtaK : 0u; c->numPrecompFilms = d->precompThinFilms ? d->numPrecompThinFilms : 0u;
+  c->hFilmsSpecId.assign(d->filmsSpecId ? d->filmsSpecId : nullptr, d->filmsSpecId ? d->filmsSpecId + d->numFilmsSpecId : nullptr);
+  c->numSpectraHost = (d->specValues && d->specOffsetSz) ? d->numSpectra : 0u;
+  c->hasFilm = false; c->filmTablesRGB = true; c->filmTablesSpectral = true;
   int rc = check_materials(c, (const MaterialRec*)d->materials, d->numMaterials, d->numTextures, d->numMaterials, d->numArrays1f); if (rc) return rc;
   c->leanMaterials = lean_materials((const MaterialRec*)d->materials, d->numMaterials);
   { std::vector<MaterialRec> hm((const MaterialRec*)d->materials, (const MaterialRec*)d->materials + d->numMaterials);
@@ -991,6 +1043,11 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
   { std::vector<float> a(d->numArrays1f ? d->arrays1f : nullptr, d->numArrays1f ? d->arrays1f + d->numArrays1f : nullptr); if (a.empty()) a.push_back(0.0f);
     HIPCHK(c, c->dArrays1f.upload(a.data(), a.size())); }
   S.arrays1f = c->dArrays1f.p;
+  { std::vector<float> ek(d->filmsEtaK ? d->filmsEtaK : nullptr, d->filmsEtaK ? d->filmsEtaK + d->numFilmsEtaK : nullptr), pf(d->precompThinFilms ? d->precompThinFilms : nullptr, d->precompThinFilms ? d->precompThinFilms + d->numPrecompThinFilms : nullptr);
+    std::vector<uint> si(c->hFilmsSpecId);
+    if (ek.empty()) ek.push_back(0.0f); if (pf.empty()) pf.push_back(0.0f); if (si.empty()) si.push_back(0xFFFFFFFFu);
+    HIPCHK(c, c->dFilmsEtaK.upload(ek.data(), ek.size())); HIPCHK(c, c->dPrecompFilms.upload(pf.data(), pf.size())); HIPCHK(c, c->dFilmsSpecId.upload(si.data(), si.size()));
+    S.filmsEtaK = c->dFilmsEtaK.p; S.precompThinFilms = c->dPrecompFilms.p; S.filmsSpecId = c->dFilmsSpecId.p; }
   // ---- spectral tables (all optional: RGB rendering does not read them) ----
   {
     const uint WAVES = 471u;                                   // LAMBDA_MAX - LAMBDA_MIN + 1 samples per spectrum (Spectrum::ResampleUniform)
@@ -1032,7 +1089,7 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
       for (int k2 = 0; k2 < 4; k2++) if (d->specValues && !specIdOk(mm[i].spdid[k2])) return c->fail(HPT_ERR_ARG, "material " + std::to_string(i) + " refers to a spectrum that does not exist");
       if (!reached[i]) continue;
       const uint t = mm[i].mtype;
-      if (c->spectralOk && t != MAT_TYPE_DIFFUSE && t != MAT_TYPE_CONDUCTOR && t != MAT_TYPE_PLASTIC && t != MAT_TYPE_DIELECTRIC && t != MAT_TYPE_LIGHT_SOURCE) { c->spectralOk = false; c->spectralWhyNot = "material " + std::to_string(i) + " (type " + std::to_string(t) + ") is not diffuse, conductor, plastic, dielectric or emissive"; }
+      if (c->spectralOk && t != MAT_TYPE_DIFFUSE && t != MAT_TYPE_CONDUCTOR && t != MAT_TYPE_PLASTIC && t != MAT_TYPE_DIELECTRIC && t != MAT_TYPE_THIN_FILM && t != MAT_TYPE_LIGHT_SOURCE) { c->spectralOk = false; c->spectralWhyNot = "material " + std::to_string(i) + " (type " + std::to_string(t) + ") is not diffuse, conductor, plastic, dielectric, thin film or emissive"; }
       if (c->spectralOk && t != MAT_TYPE_LIGHT_SOURCE && mm[i].texid[1] != 0xFFFFFFFFu) { c->spectralOk = false; c->spectralWhyNot = "normal maps are not in the spectral kernel"; }
     }
     const LightRec* ll2 = (const LightRec*)d->lights;
@@ -1291,6 +1348,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
     if (dr || naive || inRays) return c->fail(HPT_ERR_UNSUPPORTED, "spectral rendering: PathTraceBlock only (not the naive, input-ray or differentiable integrators)");
     if (c->S.motion) return c->fail(HPT_ERR_UNSUPPORTED, "spectral rendering: moving instances are not in the spectral kernel");
     if (c->S.lensCount || c->S.envTexId != 0xFFFFFFFFu || c->S.envCamBackId != 0xFFFFFFFFu) return c->fail(HPT_ERR_UNSUPPORTED, "spectral rendering: lens simulation / environment maps are not in the spectral kernel");
+    if (c->hasFilm && !c->filmTablesSpectral) return c->fail(HPT_ERR_ARG, "thin film: m_precomp_thin_films was precomputed for RGB rendering (LoadScene sizes the tables by m_spectral_mode)");
     const int sblocks = (int)(((size_t)job.tidCount + 255) / 256);
     job.gens = c->dGens.p; job.packedXY = c->dPackedXY.p; job.packedCount = c->packedCount;
     HIPCHK(c, ensureStackOverflow(c, (size_t)sblocks * 256));
@@ -1307,7 +1365,11 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   }
   { const int rcS = ensureShadeTris(c, st); if (rcS != HPT_OK) return rcS; }
   const bool motion = c->S.motion != 0;
-  const bool fullMaterials = motion || !dr && !(c->leanMaterials && !c->forceFull && c->S.lensCount == 0u && !naive && !inRays && !(c->instrument && !dr));   // MODE 0 / 1 / 2 / STATS kernels
+  const bool film = c->hasFilm;                                // MODE 4 / 5 / 6 kernels: static scenes, megakernel schedule
+  if (film && !c->filmTablesRGB) return c->fail(HPT_ERR_ARG, "thin film: m_precomp_thin_films holds no RGB table for a film (LoadScene precomputes every film in RGB mode, sized by its thickness map)");
+  if (film && motion) return c->fail(HPT_ERR_UNSUPPORTED, "thin films in a scene with moving instances: no kernel variant holds both");
+  if (film && c->instrument && !dr) return c->fail(HPT_ERR_UNSUPPORTED, "thin films: the instrumented probe has no film variant");
+  const bool fullMaterials = film || motion || !dr && !(c->leanMaterials && !c->forceFull && c->S.lensCount == 0u && !naive && !inRays && !(c->instrument && !dr));   // MODE 0 / 1 / 2 / STATS kernels
   const int blocks = (int)std::min<size_t>((size_t)gridBlocks(c, dr, fullMaterials), ((size_t)job.tidCount + 255) / 256);
   HIPCHK(c, c->dQueue.alloc(1));
   HIPCHK(c, hipMemsetAsync(c->dQueue.p, 0, 4, st));
@@ -1317,7 +1379,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   job.drSkipNonFinite = c->drSkipNonFinite ? 1u : 0u;
   const bool stats = c->instrument && !dr;
   c->lastSchedule = 1;
-  if (!inRays && useWavefront(c, naive, dr, stats && c->schedule != 2, job.tidCount)) { c->lastSchedule = 2; return launch_wavefront(c, job, st, dr); }
+  if (!inRays && !film && useWavefront(c, naive, dr, stats && c->schedule != 2, job.tidCount)) { c->lastSchedule = 2; return launch_wavefront(c, job, st, dr); }
   if (stats) { HIPCHK(c, c->dCounters.alloc(1)); HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(Counters), st)); job.counters = c->dCounters.p; }
   if (dr) {
     job.recordLanes = (uint)blocks * 256u;
@@ -1337,6 +1399,9 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
     DevScene Sd = c->S;
     if (c->nodeMinOverride < 0 && Sd.nodeMin < 4u) Sd.nodeMin = 4u;
     launchPT<false, true, 0>(Sd, job, blocks, st, deep);
+  }
+  else if (film) {
+    if (inRays) launchPT<false, false, 6>(c->S, job, blocks, st, deep); else if (naive) launchPT<false, false, 5>(c->S, job, blocks, st, deep); else launchPT<false, false, 4>(c->S, job, blocks, st, deep);
   }
   else if (inRays) launchPT<false, false, 2>(c->S, job, blocks, st, deep);
   else if (naive)  launchPT<false, false, 1>(c->S, job, blocks, st, deep);

@@ -23,7 +23,7 @@ namespace hpt {
 template <bool STATS, bool DR, int MODE, bool DEEP, bool FLAT, bool MOTION, bool SWEEP>
 __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const Job job)
 {
-  constexpr bool NAIVE = (MODE == 1), INRAYS = (MODE == 2), LEAN = (MODE == 3);
+  constexpr bool NAIVE = (MODE == 1 || MODE == 5), INRAYS = (MODE == 2 || MODE == 6), LEAN = (MODE == 3), FILM = (MODE >= 4);
   __shared__ uint stackMem[LDS_STACK * 256];
   const uint glane = blockIdx.x * 256u + threadIdx.x;                    // slot in the per-lane HBM buffers
   TravStack stk; stk.lds = &stackMem[threadIdx.x]; stk.ovf = job.stackOverflow + glane; stk.ovfStride = job.gridLanes;
@@ -132,7 +132,7 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
 
     if (alive) {
       if (STATS && hit.inst != 0xFFFFFFFFu) nHits++;
-      didBounce = shadeVertex<DR, NAIVE, LEAN, MOTION>(S, job.data, hit, rpos, rdir, accum, thr, misPdf, misIor, flags, bounce, gen,
+      didBounce = shadeVertex<DR, NAIVE, LEAN, MOTION, FILM>(S, job.data, hit, rpos, rdir, accum, thr, misPdf, misIor, flags, bounce, gen,
                                                  wantShadow, shPos, shDir, shFar, contrib, recA, recS, recdA, recdS, recTaps, recTex, tailR, pathTime);
     }
 
@@ -226,7 +226,7 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
   template __global__ void pathTraceKernel<STATS, DR, MODE, true,  true,  false>(const DevScene, const Job); \
   template __global__ void pathTraceKernel<STATS, DR, MODE, false, false, false, true>(const DevScene, const Job);   /* the triangle sweep of tiny scenes */
 #ifndef HPT_INST_GROUP
-#error "compile hpt_kernels.hip with -DHPT_INST_GROUP=1..8"
+#error "compile hpt_kernels.hip with -DHPT_INST_GROUP=1..11"
 #endif
 #if HPT_INST_GROUP == 1      // gltf + emissive scenes (every benchmark workload)
 HPT_INST4(false, false, 3)
@@ -240,6 +240,12 @@ HPT_INST4(false, false, 2)
 HPT_INST4(true, false, 0)
 #elif HPT_INST_GROUP == 6    // PathTraceDR
 HPT_INST4(false, true, 0)
+#elif HPT_INST_GROUP == 9    // scenes with thin films (MODE 4 / 5 / 6 = 0 / 1 / 2 + MAT_TYPE_THIN_FILM)
+HPT_INST4(false, false, 4)
+#elif HPT_INST_GROUP == 10
+HPT_INST4(false, false, 5)
+#elif HPT_INST_GROUP == 11
+HPT_INST4(false, false, 6)
 #elif HPT_INST_GROUP == 7    // moving instances
 template __global__ void pathTraceKernel<false, false, 0, false, false, true>(const DevScene, const Job);
 template __global__ void pathTraceKernel<false, false, 0, true,  false, true>(const DevScene, const Job);

@@ -4,6 +4,7 @@
 // candidate contribution has to survive the any-hit traversal.
 #pragma once
 #include "hpt_device.h"
+#include "hpt_film.h"
 
 namespace hpt {
 
@@ -184,6 +185,7 @@ HPT_DEV void leafTextures(const DevScene& S, const MaterialRec& m, V2 uv, V3& te
   }
 }
 // MaterialEval of a blend tree: a stack of (material id, weight) pairs, BLEND_STACK_SIZE deep, in the reference's visiting order
+template <bool FILM>
 HPT_DEV void blendTreeEval(const DevScene& S, uint rootId, V2 uv, V3 l, V3 v, V3 gn, V3 tan, BsdfE& res)
 {
   uint stackId[BLEND_STACK_SIZE]; float stackW[BLEND_STACK_SIZE];
@@ -205,6 +207,10 @@ HPT_DEV void blendTreeEval(const DevScene& S, uint rootId, V2 uv, V3 l, V3 v, V3
     }
     else if (t == MAT_TYPE_DIFFUSE) { diffuseEval(m, ld3(m.colors[0]) * tex3, l, v, n, cv); res.val = res.val + cv.val * curW * bm; res.pdf += cv.pdf * curW; }
     else if (t == MAT_TYPE_PLASTIC) { plasticEval(m, ld3(m.colors[0]) * tex3, l, v, n, cv, S.arrays1f, m.datai[0]); res.val = res.val + cv.val * curW * bm; res.pdf += cv.pdf * curW; }
+    else if (FILM && t == MAT_TYPE_THIN_FILM) {              // the geometric normal (integrator_pt_mat.cpp:464)
+      if (!(smax(m.data[1], m.data[0]) < 1e-3f)) { const FilmArgs fa = filmArgs(S, m, uv, 0.0f); filmRoughEval(m, fa, l, v, gn, tex3, cv); }
+      res.val = res.val + cv.val * curW * bm; res.pdf += cv.pdf * curW;
+    }
     else if (t == MAT_TYPE_BLEND) {                          // BlendEval: first child next (no pop), second child waits on the stack
       const float w = m.data[0] * tex3.x;
       const uint id1 = m.datai[0], id2 = m.datai[1];
@@ -221,7 +227,8 @@ HPT_DEV void blendTreeEval(const DevScene& S, uint rootId, V2 uv, V3 l, V3 v, V3
 // MOTION: moving instances - the normal (and tangent) are interpolated at the path's `time` (see hitTangent).
 // LEAN: the scene holds gltf and emissive materials only (the host checked): the conductor / diffuse / glass / dielectric branches are
 // compiled out - fewer live registers and spills in the kernels every benchmark scene runs (the DR variant is lean by definition).
-template <bool DR, bool NAIVE, bool LEAN = false, bool MOTION = false>
+// FILM: the scene holds thin films (MAT_TYPE_THIN_FILM, hpt_film.h): their branches exist in the FILM variants only.
+template <bool DR, bool NAIVE, bool LEAN = false, bool MOTION = false, bool FILM = false>
 HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec& hit,
                          V3& rpos, V3& rdir, V3& accum, V3& thr, float& misPdf, float& misIor, uint& flags, const uint bounce, Rng& gen,
                          bool& wantShadow, V3& shPos, V3& shDir, float& shFar, V3& contrib,
@@ -325,7 +332,10 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
           }
           else if (!(DR || LEAN) && mtype == MAT_TYPE_DIFFUSE) diffuseEval(m, ld3(m.colors[0]) * tex3, shadowRayDir, vdir, evalNorm, bv);
           else if (!(DR || LEAN) && mtype == MAT_TYPE_PLASTIC) plasticEval(m, ld3(m.colors[0]) * tex3, shadowRayDir, vdir, evalNorm, bv, S.arrays1f, m.datai[0]);
-          else if (!(DR || LEAN) && mtype == MAT_TYPE_BLEND) blendTreeEval(S, matId, uv, shadowRayDir, vdir, hitNorm, hitTang, bv);
+          else if (FILM && mtype == MAT_TYPE_THIN_FILM) {                 // rough films only; the geometric normal (integrator_pt_mat.cpp:422-470)
+            if (!(smax(m.data[1], m.data[0]) < 1e-3f)) { const FilmArgs fa = filmArgs(S, m, uv, 0.0f); filmRoughEval(m, fa, shadowRayDir, vdir, hitNorm, tex3, bv); }
+          }
+          else if (!(DR || LEAN) && mtype == MAT_TYPE_BLEND) blendTreeEval<FILM>(S, matId, uv, shadowRayDir, vdir, hitNorm, hitTang, bv);
           if (!(DR || LEAN) && mtype != MAT_TYPE_BLEND) bv.val = bv.val * bumpMult;     // res.val += currVal.val * weight * bumpCosMult, weight 1
           const float cosThetaOut = smax(dot(shadowRayDir, hitNorm), 0.0f);
           float lgtPdfW = (1.0f / float(nLights)) * lightEvalPDF(L, shadowRayPos, shadowRayDir, ls.pos, ls.norm, ls.pdf);
@@ -404,6 +414,13 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
       else if (!(DR || LEAN) && lt == MAT_TYPE_DIELECTRIC) {
         dielectricSmoothSampleAndEval(ml, ml.data[1], misIor, rands, vdir, sNorm, ms);
         ms.flags |= (ml.spdid[0] < 0xFFFFFFFFu) ? RAY_FLAG_WAVES_DIVERGED : 0u;
+        misIor = ms.ior;
+      }
+      else if (FILM && lt == MAT_TYPE_THIN_FILM) {                       // integrator_pt_mat.cpp:197-249: the geometric normal, always "diverged"
+        const FilmArgs fa = filmArgs(S, ml, uv, 0.0f);
+        if (smax(ml.data[1], ml.data[0]) < 1e-3f) filmSmoothSampleAndEval(ml, fa, misIor, rands, vdir, hitNorm, ms);
+        else                                      filmRoughSampleAndEval(ml, fa, misIor, rands, vdir, hitNorm, ltex3, ms);
+        ms.flags |= RAY_FLAG_WAVES_DIVERGED;
         misIor = ms.ior;
       }
       if (leafBump) {                                                  // the caller multiplies by the cosine to the geometric normal (:298-303)

@@ -19,7 +19,6 @@
 
 namespace hpt {
 
-static constexpr float LAMBDA_MIN = 360.0f, LAMBDA_MAX = 830.0f;          // include/cglobals.h:22-23
 HPT_DEV V4 operator+(V4 a, V4 b) { return v4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 HPT_DEV V4 operator*(V4 a, V4 b) { return v4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 HPT_DEV V4 operator*(V4 a, float s) { return v4(a.x * s, a.y * s, a.z * s, a.w * s); }
@@ -38,16 +37,7 @@ HPT_DEV V4 sampleWavelengths(float u, float a, float b)
   for (int i = 1; i < 4; i++) { r[i] = r[i - 1] + delta; if (r[i] > b) r[i] = a + (r[i] - b); }
   return v4(r[0], r[1], r[2], r[3]);
 }
-// SampleUniformSpectrum (spectrum.h:106-126): 1 nm table starting at LAMBDA_MIN, linear between neighbours
-HPT_DEV float sampleUniformSpectrum1(const float* vals, uint offset, float w)
-{
-  const int WAVESN = int(LAMBDA_MAX - LAMBDA_MIN);
-  const int i1 = (int)smin(smax(w - LAMBDA_MIN, 0.0f), float(WAVESN - 1));
-  const int i2 = min(i1 + 1, WAVESN - 1);
-  const float x1 = LAMBDA_MIN + float(i1);
-  const float y1 = vals[offset + (uint)i1], y2 = vals[offset + (uint)i2];
-  return y1 + (w - x1) * (y2 - y1);
-}
+// SampleUniformSpectrum (spectrum.h:106-126) over four wavelengths (the scalar form lives in hpt_film.h)
 HPT_DEV V4 sampleUniformSpectrum(const float* vals, uint offset, V4 w)
 { return v4(sampleUniformSpectrum1(vals, offset, w.x), sampleUniformSpectrum1(vals, offset, w.y), sampleUniformSpectrum1(vals, offset, w.z), sampleUniformSpectrum1(vals, offset, w.w)); }
 
@@ -132,7 +122,7 @@ struct SpecEval { V4 val; float pdf; };
 struct SpecSample { V4 val; V3 dir; float pdf; uint flags; float ior; };
 
 // MaterialEval, spectral (integrator_pt_mat.cpp:405-420, 471-482 with cmat_conductor.h:103-137, cmat_diffuse.h:27-39)
-HPT_DEV SpecEval materialEvalSpec(const DevScene& S, const MaterialRec& m, V4 waves, V3 l, V3 v, V3 n, V3 texColor3)
+HPT_DEV SpecEval materialEvalSpec(const DevScene& S, const MaterialRec& m, V4 waves, V3 l, V3 v, V3 n, V3 texColor3, V2 uv)
 {
   SpecEval r; r.val = v4s(0.0f); r.pdf = 0.0f;
   if (m.mtype == MAT_TYPE_DIFFUSE) {
@@ -164,11 +154,18 @@ HPT_DEV SpecEval materialEvalSpec(const DevScene& S, const MaterialRec& m, V4 wa
       if (dot(wm, v3(0.0f, 0.0f, 1.0f)) < 0.f) wm = (-1.0f) * wm;
       r.pdf = trPDF(wo, wm, alpha) / (4.0f * absf(dot(wo, wm)));
     }
+  } else if (m.mtype == MAT_TYPE_THIN_FILM) {                               // integrator_pt_mat.cpp:422-470: rough films only, the first wavelength only
+    if (!(smax(m.data[1], m.data[0]) < 1e-3f)) {
+      const FilmArgs fa = filmArgs(S, m, uv, waves.x);
+      BsdfE e; e.val = v3(0, 0, 0); e.pdf = 0.0f; e.dval = v3(0, 0, 0);
+      filmRoughEval(m, fa, l, v, n, texColor3, e);
+      r.val = v4(e.val.x, 0.0f, 0.0f, 0.0f); r.pdf = e.pdf;
+    }
   }
   return r;
 }
 // MaterialSampleAndEval, spectral (integrator_pt_mat.cpp:184-196, 252-263 with cmat_conductor.h:7-100, cmat_diffuse.h:8-24)
-HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V4 waves, V4 rands, V3 v, V3 n, V3 texColor3, uint flags0, float prevIor)
+HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V4 waves, V4 rands, V3 v, V3 n, V3 texColor3, uint flags0, float prevIor, V2 uv)
 {
   SpecSample r; r.val = v4s(0.0f); r.pdf = 1.0f; r.dir = v3(0, 1, 0); r.flags = flags0; r.ior = 1.0f;
   if (m.mtype == MAT_TYPE_DIFFUSE) {
@@ -220,6 +217,12 @@ HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V
       r.pdf = trPDF(wo, wm, alpha) / (4.0f * absf(dot(wo, wm)));
       r.flags = RAY_FLAG_HAS_NON_SPEC;
     }
+  } else if (m.mtype == MAT_TYPE_THIN_FILM) {                               // integrator_pt_mat.cpp:197-249
+    const FilmArgs fa = filmArgs(S, m, uv, waves.x);
+    BsdfS a; a.val = v3(0, 0, 0); a.dval = v3(0, 0, 0); a.pdf = 1.0f; a.dir = v3(0, 1, 0); a.flags = flags0; a.ior = 1.0f;
+    if (smax(m.data[1], m.data[0]) < 1e-3f) filmSmoothSampleAndEval(m, fa, prevIor, rands, v, n, a);
+    else                                    filmRoughSampleAndEval(m, fa, prevIor, rands, v, n, texColor3, a);
+    r.val = v4(a.val.x, 0.0f, 0.0f, 0.0f); r.dir = a.dir; r.pdf = a.pdf; r.flags = a.flags | RAY_FLAG_WAVES_DIVERGED; r.ior = a.ior;
   }
   return r;
 }
@@ -313,7 +316,7 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
               const V3 shadowRayPos = hitPos + hitNorm * smax(maxcomp(hitPos), 1.0f) * 5e-6f;
               const bool inIllumArea = (dot(shadowRayDir, ls.norm) < 0.0f) || ls.isOmni || ls.hasIES;
               if (inIllumArea) {
-                const SpecEval bv = materialEvalSpec(S, m, waves, shadowRayDir, vdir, hitNorm, tex3);
+                const SpecEval bv = materialEvalSpec(S, m, waves, shadowRayDir, vdir, hitNorm, tex3, uv);
                 const float cosThetaOut = smax(dot(shadowRayDir, hitNorm), 0.0f);
                 float lgtPdfW = (1.0f / float(nLights)) * lightEvalPDF(L, shadowRayPos, shadowRayDir, ls.pos, ls.norm, ls.pdf);
                 float misWeight = (S.integratorType == INTEGRATOR_MIS_PT) ? misWeightHeuristic(lgtPdfW, bv.pdf) : 1.0f;
@@ -353,8 +356,8 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
             wantShadow = false;
           } else {
             const V4 rands = rng_float4(gen);                                // GetRandomNumbersMats
-            const SpecSample ms = materialSampleSpec(S, m, waves, rands, vdir, hitNorm, tex3, (flags & 0xFF000000u) | matId, misIor);
-            if (mtype == MAT_TYPE_DIELECTRIC) misIor = ms.ior;
+            const SpecSample ms = materialSampleSpec(S, m, waves, rands, vdir, hitNorm, tex3, (flags & 0xFF000000u) | matId, misIor, uv);
+            if (mtype == MAT_TYPE_DIELECTRIC || mtype == MAT_TYPE_THIN_FILM) misIor = ms.ior;
             const float invPdf = 1.0f / smax(ms.pdf, 1e-20f);
             const V4 bxdfVal = ms.val * invPdf;
             const float cosTheta = absf(dot(ms.dir, hitNorm));

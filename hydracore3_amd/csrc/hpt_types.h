@@ -187,6 +187,10 @@ struct DevScene
   uint  envTexId, envLightId, envCamBackId, envEnableSam;   // m_envTexId, m_envLightId, m_envCamBackId, m_envEnableSam (0xFFFFFFFF: none)
   float envSamRow0[4], envSamRow1[4];
   uint  envSpecId; float envSpecMult;                        // m_envSpecId (0xFFFFFFFF: none), m_envSpecMult: the environment's spectrum in spectral mode
+  // thin films (integrator_pt.h:588-590, hpt_film.h; last, so that no other member moves): eta then k per layer, their spectrum ids, the loader's reflectance / transmittance tables
+  const float*       filmsEtaK;
+  const uint*        filmsSpecId;
+  const float*       precompThinFilms;
 };
 
 struct Counters { unsigned long long v[16]; };  // rays, nodes, tris, surfaceHits, shadowRays, paths, instEnter, texFetch,

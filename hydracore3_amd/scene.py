@@ -60,6 +60,10 @@ GLTF_COLOR_BASE, GLTF_COLOR_COAT, GLTF_COLOR_METAL = 0, 1, 2
 GLTF_FLOAT_MI_FDR_INT, GLTF_FLOAT_MI_FDR_EXT, GLTF_FLOAT_MI_SSW, GLTF_FLOAT_ALPHA = 0, 1, 2, 3
 GLTF_FLOAT_GLOSINESS, GLTF_FLOAT_IOR, GLTF_FLOAT_ROUGH_ORENNAYAR, GLTF_FLOAT_REFL_COAT = 4, 5, 6, 7
 EMISSION_COLOR, EMISSION_MULT = 0, 0
+# thin film (include/cmaterial.h:45, 164-179)
+MAT_TYPE_THIN_FILM = 8
+(FILM_ROUGH_U, FILM_ROUGH_V, FILM_PRECOMP_FLAG, FILM_PRECOMP_OFFSET, FILM_ETA_OFFSET, FILM_K_OFFSET, FILM_ETA_SPECID_OFFSET, FILM_K_SPECID_OFFSET, FILM_ETA_EXT,
+ FILM_THICKNESS_OFFSET, FILM_THICKNESS_MIN, FILM_THICKNESS_MAX, FILM_THICKNESS_MAP, FILM_THICKNESS, FILM_LAYERS_COUNT, FILM_TRANSPARENT) = range(16)
 # include/clight.h:5-17
 LIGHT_GEOM_RECT, LIGHT_GEOM_DISC, LIGHT_GEOM_SPHERE, LIGHT_GEOM_DIRECT, LIGHT_GEOM_POINT, LIGHT_GEOM_ENV = 1, 2, 3, 4, 5, 6
 LIGHT_DIST_LAMBERT, LIGHT_DIST_OMNI, LIGHT_DIST_SPOT = 0, 1, 2
@@ -93,7 +97,18 @@ class SceneDesc(C.Structure):
                 # spectral rendering: m_spec_values, m_spec_offset_sz, m_cie_xyz, m_camResponseSpectrumId / m_camResponseType
                 ("specValues", C.c_void_p), ("specOffsetSz", C.c_void_p), ("numSpecValues", C.c_uint32), ("numSpectra", C.c_uint32),
                 ("cieXYZ", C.c_void_p), ("numCieXYZ", C.c_uint32), ("camResponseSpectrumId", C.c_int32 * 3),
-                ("camResponseType", C.c_uint32), ("reserved2", C.c_uint32)]
+                ("camResponseType", C.c_uint32), ("reserved2", C.c_uint32),
+                # thin films: m_films_thickness_vec, m_films_spec_id_vec, m_films_eta_k_vec, m_precomp_thin_films
+                ("filmsThickness", C.c_void_p), ("filmsSpecId", C.c_void_p), ("filmsEtaK", C.c_void_p), ("precompThinFilms", C.c_void_p),
+                ("numFilmsThickness", C.c_uint32), ("numFilmsSpecId", C.c_uint32), ("numFilmsEtaK", C.c_uint32), ("numPrecompThinFilms", C.c_uint32)]
+
+
+class FilmParams(C.Structure):
+    """hpt_film_params (include/hydra_hip.h)."""
+    _fields_ = [("spectralMode", C.c_int32), ("extIOR", C.c_float), ("layers", C.c_uint32), ("thicknessMap", C.c_int32),
+                ("thicknessMin", C.c_float), ("thicknessMax", C.c_float), ("numSpectra", C.c_uint32), ("reserved", C.c_uint32),
+                ("eta", C.c_void_p), ("k", C.c_void_p), ("etaSpecId", C.c_void_p), ("kSpecId", C.c_void_p), ("thickness", C.c_void_p),
+                ("specValues", C.c_void_p), ("specOffsetSz", C.c_void_p), ("cieXYZ", C.c_void_p)]
 
 
 class Params(C.Structure):
@@ -468,6 +483,9 @@ class SceneData:
         self.cam_response_type = 0                            # CAM_RESPONCE_XYZ = 0, CAM_RESPONCE_RGB = 1 (integrator_pt.h:531-534)
         self.cam_respoce_rgb = (1.0, 1.0, 1.0, 1.0)           # m_camRespoceRGB
         self.env_spec_id, self.env_spec_mult = UINT_MAX, 1.0  # m_envSpecId, m_envSpecMult: the sky light's spectrum and multiplier (integrator_pt_scene.cpp:456-457)
+        # thin films (integrator_pt.h:587-590): thickness per film, eta then k per layer and their spectrum ids, the precomputed tables
+        self.films_thickness, self.films_spec_id, self.films_eta_k = [], [], []
+        self.precomp_thin_films = np.zeros(0, np.float32)
         self.all_remap_lists = np.zeros((1,), np.int32)     # no lists: just the trailing offset 0
         self.all_remap_lists_size = 0
         self.materials, self.lights = [], []
@@ -588,6 +606,77 @@ class SceneData:
         m["data"][3], m["data"][2] = refl.value, weight.value                 # PLASTIC_PRECOMP_REFLECTANCE, PLASTIC_SPEC_SAMPLE_WEIGHT
         m["datai"][0] = self.arrays1f.size
         self.arrays1f = np.concatenate([self.arrays1f, table]).astype(np.float32)
+        return m
+
+    def material_thin_film(self, layers, substrate=None, alpha=0.0, ext_ior=1.00028, transparent=0, thickness_map=None, alpha_tex=None):
+        """LoadThinFilmMaterial (integrator_pt_scene_mat.cpp:1020-1193): MAT_TYPE_THIN_FILM (include/cmat_film.h). `layers`: the films, outermost first,
+        as dicts {eta, k, thickness, eta_spec, k_spec}; `substrate`: {eta, k, eta_spec, k_spec} or None (the last film then stands for it, as in
+        the reference, where FILM_LAYERS_COUNT counts <layers> children plus the material's own <eta>). `alpha`: a number or (alpha_u, alpha_v);
+        thickness_map = (min, max, tex_id, row0, row1); alpha_tex = (tex_id, row0, row1). The reflectance / transmittance tables come from
+        hpt_film_precompute (csrc/film_precompute.h), the one implementation both loaders share, for the scene's CURRENT spectral_mode."""
+        from .api import load_library
+        m = np.zeros((), dtype=MATERIAL_DTYPE)
+        m["mtype"], m["lightId"] = MAT_TYPE_THIN_FILM, UINT_MAX
+        m["colors"][0] = (1, 1, 1, 0)
+        m["spdid"] = UINT_MAX
+        m["texid"] = (0, UINT_MAX, 0, 0)                                      # (the reference zeroes all four; slot 1 is the normal map: none)
+        for k in range(4):
+            m["row0"][k] = (1, 0, 0, 0); m["row1"][k] = (0, 1, 0, 0)
+        au, av = (alpha, alpha) if np.isscalar(alpha) else alpha
+        if alpha_tex is not None:
+            m["texid"][0], m["row0"][0], m["row1"][0] = alpha_tex
+            if alpha_tex[0] != 0:
+                au = av = 1.0
+        m["data"][FILM_ROUGH_U], m["data"][FILM_ROUGH_V] = au, av
+        fbits = lambda u: np.uint32(u).view(np.float32)
+        tmap = thickness_map is not None
+        if tmap:
+            m["data"][FILM_THICKNESS_MIN], m["data"][FILM_THICKNESS_MAX] = thickness_map[0], thickness_map[1]
+            m["texid"][2], m["row0"][2], m["row1"][2] = thickness_map[2], thickness_map[3], thickness_map[4]
+        m["data"][FILM_THICKNESS_MAP] = fbits(1 if tmap else 0)
+        m["data"][FILM_ETA_EXT] = np.float32(ext_ior)
+        t_off, s_off, e_off = len(self.films_thickness), len(self.films_spec_id), len(self.films_eta_k)
+        m["data"][FILM_THICKNESS_OFFSET], m["data"][FILM_ETA_SPECID_OFFSET], m["data"][FILM_ETA_OFFSET] = fbits(t_off), fbits(s_off), fbits(e_off)
+        stack = list(layers) + ([substrate] if substrate is not None else [])
+        for l in layers:
+            if "thickness" in l:
+                self.films_thickness.append(np.float32(l["thickness"]))
+        for l in stack:
+            self.films_eta_k.append(np.float32(l.get("eta", 0.0))); self.films_spec_id.append(int(l.get("eta_spec", UINT_MAX)))
+        if len(self.films_thickness) <= t_off:
+            raise ValueError("thin film: no layer carries a thickness (the reference reads m_films_thickness_vec past its end)")
+        n = len(stack)
+        m["data"][FILM_THICKNESS] = self.films_thickness[t_off]
+        m["data"][FILM_LAYERS_COUNT] = fbits(n)
+        m["data"][FILM_K_SPECID_OFFSET], m["data"][FILM_K_OFFSET] = fbits(len(self.films_spec_id)), fbits(len(self.films_eta_k))
+        for l in stack:
+            self.films_eta_k.append(np.float32(l.get("k", 0.0))); self.films_spec_id.append(int(l.get("k_spec", UINT_MAX)))
+        m["data"][FILM_TRANSPARENT] = fbits(int(transparent))
+        # the tables
+        keep = []
+        def arr(a, dt):
+            a = np.ascontiguousarray(a, dt); keep.append(a); return a.ctypes.data
+        fp = FilmParams()
+        fp.spectralMode, fp.extIOR, fp.layers, fp.thicknessMap = int(self.spectral_mode), float(np.float32(ext_ior)), n, int(tmap)
+        fp.thicknessMin, fp.thicknessMax = float(m["data"][FILM_THICKNESS_MIN]), float(m["data"][FILM_THICKNESS_MAX])
+        fp.eta, fp.k = arr(self.films_eta_k[e_off:e_off + n], np.float32), arr(self.films_eta_k[e_off + n:e_off + 2 * n], np.float32)
+        fp.etaSpecId, fp.kSpecId = arr(self.films_spec_id[s_off:s_off + n], np.uint32), arr(self.films_spec_id[s_off + n:s_off + 2 * n], np.uint32)
+        fp.thickness = arr(self.films_thickness[t_off:], np.float32)
+        fp.numSpectra = len(self.spec_offset_sz)
+        fp.specValues = arr(self.spec_values, np.float32) if len(self.spec_offset_sz) else None
+        fp.specOffsetSz = arr(np.asarray(self.spec_offset_sz, np.uint32).reshape(-1, 2), np.uint32) if len(self.spec_offset_sz) else None
+        fp.cieXYZ = arr(self.cie_xyz if self.cie_xyz is not None else cie_xyz_fit(), np.float32)
+        lib = load_library()
+        count, pre = C.c_uint64(0), C.c_int(0)
+        if lib.hpt_film_precompute(C.byref(fp), None, 0, C.byref(count), C.byref(pre)) != 0:
+            raise ValueError("hpt_film_precompute rejected the parameters")
+        m["data"][FILM_PRECOMP_FLAG] = fbits(pre.value)
+        m["data"][FILM_PRECOMP_OFFSET] = fbits(self.precomp_thin_films.size if pre.value else 0)
+        if pre.value:
+            table = np.zeros(count.value, np.float32)
+            if lib.hpt_film_precompute(C.byref(fp), table.ctypes.data, table.size, C.byref(count), C.byref(pre)) != 0:
+                raise ValueError("hpt_film_precompute failed")
+            self.precomp_thin_films = np.concatenate([self.precomp_thin_films, table]).astype(np.float32)
         return m
 
     def set_optics(self, lines, sensor_diagonal=0.035, scale=1.0, order="sensor_to_scene"):
@@ -723,6 +812,14 @@ class SceneData:
             cie = self.cie_xyz if self.cie_xyz is not None else cie_xyz_fit()
             d.cieXYZ = ptr(np.asarray(cie, np.float32).reshape(-1, 4)); d.numCieXYZ = int(np.asarray(cie).reshape(-1, 4).shape[0])
             d.camResponseSpectrumId = (C.c_int32 * 3)(*[int(v) for v in self.cam_response_spectrum_id]); d.camResponseType = int(self.cam_response_type)
+        d.filmsThickness, d.filmsSpecId, d.filmsEtaK, d.precompThinFilms = None, None, None, None
+        d.numFilmsThickness = d.numFilmsSpecId = d.numFilmsEtaK = d.numPrecompThinFilms = 0
+        if self.films_eta_k:
+            d.filmsThickness, d.numFilmsThickness = ptr(np.asarray(self.films_thickness, np.float32)), len(self.films_thickness)
+            d.filmsSpecId, d.numFilmsSpecId = ptr(np.asarray(self.films_spec_id, np.uint32)), len(self.films_spec_id)
+            d.filmsEtaK, d.numFilmsEtaK = ptr(np.asarray(self.films_eta_k, np.float32)), len(self.films_eta_k)
+            if self.precomp_thin_films.size:
+                d.precompThinFilms, d.numPrecompThinFilms = ptr(self.precomp_thin_films.astype(np.float32)), int(self.precomp_thin_films.size)
         return d
 
 
@@ -1406,7 +1503,36 @@ def load_hydra_xml(xml_path: str, width=None, height=None, spectral=False) -> Sc
             mat["data"][2] = np.float32(1.0) / (d_mean + np.float32(1.0))      # PLASTIC_SPEC_SAMPLE_WEIGHT = s_mean / (d_mean + s_mean)
         return mat
 
-    typed_loaders = {"plastic": load_plastic, "gltf": convert_gltf, "rough_conductor": load_rough_conductor, "diffuse": load_diffuse,
+    def load_thin_film(mnode):
+        """LoadThinFilmMaterial (integrator_pt_scene_mat.cpp:1020-1193)."""
+        def layer(n):
+            en, kn = n.find("eta"), n.find("k")
+            d = {"eta": float(val1f(en, 0.0)), "k": float(val1f(kn, 0.0)), "eta_spec": spectrum_id(en), "k_spec": spectrum_id(kn)}
+            if n.find("thickness") is not None:
+                d["thickness"] = float(val1f(n.find("thickness"), 0.0))
+            return d
+        ln = mnode.find("layers")
+        layers = [layer(c) for c in list(ln)] if ln is not None else []
+        substrate = layer(mnode) if mnode.find("eta") is not None else None
+        an = mnode.find("alpha")
+        alpha_tex = None
+        if an is not None:
+            alpha = float(val1f(an, 0.0))
+            r0, r1, tid = load_texture_from_node(an)
+            alpha_tex = (tid, r0, r1)
+        else:
+            alpha = (float(val1f(mnode.find("alpha_u"), 0.0)), float(val1f(mnode.find("alpha_v"), 0.0)))
+        tn = mnode.find("thickness_map")
+        tmap = None
+        if tn is not None:
+            r0, r1, tid = load_texture_from_node(tn)
+            tmap = (float(tn.get("min", 0.0)), float(tn.get("max", 0.0)), tid, r0, r1)
+        en = mnode.find("ext_ior")
+        trn = mnode.find("transparent")
+        return sc.material_thin_film(layers, substrate, alpha, float(val1f(en, 1.00028)) if en is not None else 1.00028,
+                                     int(float(trn.get("val", 0))) if trn is not None else 0, tmap, alpha_tex)
+
+    typed_loaders = {"thin_film": load_thin_film, "plastic": load_plastic, "gltf": convert_gltf, "rough_conductor": load_rough_conductor, "diffuse": load_diffuse,
                      "dielectric": load_dielectric, "blend": load_blend}
 
     # ConvertOldHydraMaterial (integrator_pt_scene_mat.cpp:280-450), every branch: emission, diffuse (+ Oren-Nayar), reflectivity with and

@@ -83,6 +83,14 @@ typedef struct hpt_scene_desc {
   int32_t         camResponseSpectrumId[3];   /* -1: none (then SpectrumToXYZ + XYZToRGB) */
   uint32_t        camResponseType;            /* m_camResponseType: 0 = CAM_RESPONCE_XYZ, 1 = CAM_RESPONCE_RGB (integrator_pt.h:531-534) */
   uint32_t        reserved2;
+  /* thin films (MAT_TYPE_THIN_FILM, integrator_pt.h:587-590): m_films_thickness_vec, m_films_spec_id_vec, m_films_eta_k_vec and the loader's
+   * reflectance / transmittance tables m_precomp_thin_films (LoadThinFilmMaterial, integrator_pt_scene_mat.cpp:1020-1193; hpt_film_precompute
+   * computes one material's). All may be NULL / 0 for scenes without films. */
+  const float*    filmsThickness;
+  const uint32_t* filmsSpecId;
+  const float*    filmsEtaK;
+  const float*    precompThinFilms;
+  uint32_t        numFilmsThickness, numFilmsSpecId, numFilmsEtaK, numPrecompThinFilms;
 } hpt_scene_desc;
 
 /* The plain-data members UpdateMembersPlainData() refreshes before every *Block call (integrator_pt.h:268, main.cpp:398). */
@@ -127,6 +135,18 @@ int  hpt_device_info(hpt_ctx* ctx, int* numCUs, int* wavefront, char* name, size
  * lens stack traced from the film by SampleCameraRay (integrator_pt.cpp:79-103, 806-938). lines4 = n x {curvatureRadius, thickness, eta,
  * apertureRadius}, film side first (radius 0 = the aperture stop); n = 0 switches the simulation off. Takes effect at the next call. */
 int  hpt_set_optics(hpt_ctx* ctx, const float* lines4, uint32_t n, float physSizeX, float physSizeY);
+/* precomputeThinFilmSpectral / precomputeThinFilmRGB (integrator_pt_scene_mat.cpp:791-1018), what LoadThinFilmMaterial (:1020-1193) appends to
+ * m_precomp_thin_films for one MAT_TYPE_THIN_FILM: reflectance / transmittance from outside and from inside over wavelength x angle (spectral
+ * mode) or [thickness x] angle x rgb (RGB mode). layers = the films plus the substrate (FILM_LAYERS_COUNT); eta / k / their spectrum ids per
+ * layer, thickness per film; cieXYZ (float4 x 471) is read in RGB mode only. outTable == NULL asks for the size; *outPrecomputed = 0 when the
+ * reference's loader would not precompute (spectral mode, one film with a thickness map: FILM_PRECOMP_FLAG stays 0). Host code; no context. */
+typedef struct hpt_film_params {
+  int32_t  spectralMode; float extIOR; uint32_t layers; int32_t thicknessMap;
+  float    thicknessMin, thicknessMax; uint32_t numSpectra, reserved;
+  const float* eta; const float* k; const uint32_t* etaSpecId; const uint32_t* kSpecId; const float* thickness;
+  const float* specValues; const uint32_t* specOffsetSz; const float* cieXYZ;
+} hpt_film_params;
+int  hpt_film_precompute(const hpt_film_params* params, float* outTable, uint64_t outCapacity, uint64_t* outCount, int* outPrecomputed);
 /* mi::fresnel_coat_precompute (mi_materials.cpp:377-451), what LoadPlasticMaterial (integrator_pt_scene_mat.cpp:675-757) stores for a
  * MAT_TYPE_PLASTIC: the 64-entry rough-transmittance table (appended to m_arrays1f, its offset in Material::datai[0]) and the two scalars
  * Material::data[PLASTIC_PRECOMP_REFLECTANCE = 3], data[PLASTIC_SPEC_SAMPLE_WEIGHT = 2]. Host code; no context, no device. RGB mode. */

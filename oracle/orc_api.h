@@ -62,6 +62,12 @@ typedef struct orc_scene_desc {
   int32_t         camResponseSpectrumId[3];
   uint32_t        camResponseType;
   uint32_t        reserved2;
+  // thin films (integrator_pt.h:587-590): m_films_thickness_vec, m_films_spec_id_vec, m_films_eta_k_vec, m_precomp_thin_films (all may be NULL / 0)
+  const float*    filmsThickness;
+  const uint32_t* filmsSpecId;
+  const float*    filmsEtaK;
+  const float*    precompThinFilms;
+  uint32_t        numFilmsThickness, numFilmsSpecId, numFilmsEtaK, numPrecompThinFilms;
 } orc_scene_desc;
 
 typedef struct orc_params {

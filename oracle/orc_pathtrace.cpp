@@ -206,6 +206,37 @@ struct Ctx
     if (specId < 0xFFFFFFFFu) res = SampleUniformSpectrum(sc.specOffsetSz[2 * specId], a_wavelengths);
     return res;
   }
+  f4 SampleFilmsSpectrum(uint matId, f4 a_wavelengths, uint paramId, uint paramSpecId, uint layer) const   // integrator_spectrum.cpp:46-65
+  {
+    f4 res = splat4(sc.filmsEtaK[as_uint_(sc.materials[matId].data[paramId]) + layer]);
+    const uint specId = sc.filmsSpecId[as_uint_(sc.materials[matId].data[paramSpecId]) + layer];
+    if (specId < 0xFFFFFFFFu) res = SampleUniformSpectrum(sc.specOffsetSz[2 * specId], a_wavelengths);   // (KSPEC_SPECTRAL_RENDERING != 0 holds on the CPU: in RGB mode too)
+    return res;
+  }
+  // what both film branches of integrator_pt_mat.cpp set up before the BSDF call (:203-237, 431-463)
+  struct FilmArgs { float extIOR, thickness; cplx intIOR, filmIOR; f4 wavelengths_spec; bool spectral_mode, precomp_flag; uint precomp_offset; };
+  FilmArgs filmArgs(uint matId, f2 tc, f4 wavelengths, bool evalBranch) const
+  {
+    const Material& m = sc.materials[matId];
+    FilmArgs a;
+    const uint layers = as_uint_(m.data[FILM_LAYERS_COUNT]);
+    a.spectral_mode = wavelengths.x > 0.0f;
+    a.wavelengths_spec = a.spectral_mode ? mk4(wavelengths.x, 0, 0, 0) : (evalBranch ? mk4(700.f, 525.f, 450.f, 0.0f) : mk4(645.f, 525.f, 445.f, 0.0f));
+    const f4 wavelengths_sample = a.spectral_mode ? mk4(wavelengths.x, 0, 0, 0) : mk4(525.f, 0, 0, 0);
+    a.extIOR = m.data[FILM_ETA_EXT];
+    a.intIOR = cmk(SampleFilmsSpectrum(matId, wavelengths_sample, FILM_ETA_OFFSET, FILM_ETA_SPECID_OFFSET, layers - 1).x,
+                   SampleFilmsSpectrum(matId, wavelengths_sample, FILM_K_OFFSET, FILM_K_SPECID_OFFSET, layers - 1).x);
+    a.filmIOR = cmk(SampleFilmsSpectrum(matId, wavelengths, FILM_ETA_OFFSET, FILM_ETA_SPECID_OFFSET, 0).x,
+                    SampleFilmsSpectrum(matId, wavelengths, FILM_K_OFFSET, FILM_K_SPECID_OFFSET, 0).x);
+    if (as_uint_(m.data[FILM_THICKNESS_MAP]) > 0u) {
+      const f4 thickness_val = sc.tex_sample(m.texid[2], mulRows2x4(m.row0[2], m.row1[2], tc));
+      const float thickness_max = m.data[FILM_THICKNESS_MAX], thickness_min = m.data[FILM_THICKNESS_MIN];
+      a.thickness = (thickness_max - thickness_min) * thickness_val.x + thickness_min;
+    } else a.thickness = m.data[FILM_THICKNESS];
+    a.precomp_flag = as_uint_(m.data[FILM_PRECOMP_FLAG]) > 0u;
+    a.precomp_offset = a.precomp_flag ? as_uint_(m.data[FILM_PRECOMP_OFFSET]) : 0;
+    return a;
+  }
   f3 SpectrumToXYZ(f4 spec4, f4 lambda4, bool terminate_waves) const   // spectrum.h:151-203
   {
     float pdf[4] = { 1.0f / (LAMBDA_MAX - LAMBDA_MIN), 1.0f / (LAMBDA_MAX - LAMBDA_MIN), 1.0f / (LAMBDA_MAX - LAMBDA_MIN), 1.0f / (LAMBDA_MAX - LAMBDA_MIN) };
@@ -388,6 +419,17 @@ struct Ctx
         res.flags |= (specId < 0xFFFFFFFFu) ? RAY_FLAG_WAVES_DIVERGED : 0;
         a_misPrev->ior = res.ior;
       } break;
+      case MAT_TYPE_THIN_FILM: {                                                                   // :197-249: the GEOMETRIC normal, always "diverged"
+        const f3 alphaTex = xyz(texColor);
+        const f2 alpha = mk2(m.data[FILM_ROUGH_V], m.data[FILM_ROUGH_U]);
+        const FilmArgs a = filmArgs(currMatId, tc, wavelengths, false);
+        if (trEffectivelySmooth(alpha))
+          filmSmoothSampleAndEval(m, a.extIOR, a.filmIOR, a.intIOR, a.thickness, a.wavelengths_spec, a_misPrev->ior, rands, v, n, &res, sc.precompThinFilms.data(), a.precomp_offset, a.spectral_mode, a.precomp_flag);
+        else
+          filmRoughSampleAndEval(m, a.extIOR, a.filmIOR, a.intIOR, a.thickness, a.wavelengths_spec, a_misPrev->ior, rands, v, n, alphaTex, &res, sc.precompThinFilms.data(), a.precomp_offset, a.spectral_mode, a.precomp_flag);
+        res.flags |= RAY_FLAG_WAVES_DIVERGED;
+        a_misPrev->ior = res.ior;
+      } break;
       default: break;
     }
     if (normalMapId != 0xFFFFFFFFu) {                   // :298-303: the caller multiplies by cos to the geometric normal
@@ -451,6 +493,16 @@ struct Ctx
           f4 reflSpec = SampleMatColorSpectrumTexture(currMat.id, wavelengths, 0, 0);               // (integrator_pt_mat.cpp:490-493)
           if (p.spectralMode == 0) reflSpec = reflSpec * texColor;
           plasticEval(m, reflSpec, l, v, shadeNormal, &currVal, sc.arrays1f.data(), m.datai[0]);
+          res.val = res.val + currVal.val * weight * bumpCosMult;
+          res.pdf += currVal.pdf * weight;
+        } break;
+        case MAT_TYPE_THIN_FILM: {                                                    // :422-470
+          const f3 alphaTex = xyz(texColor);
+          const f2 alpha = mk2(m.data[FILM_ROUGH_V], m.data[FILM_ROUGH_U]);
+          if (!trEffectivelySmooth(alpha)) {
+            const FilmArgs a = filmArgs(currMat.id, tc, wavelengths, true);
+            filmRoughEval(m, a.extIOR, a.filmIOR, a.intIOR, a.thickness, a.wavelengths_spec, l, v, n, alphaTex, &currVal, sc.precompThinFilms.data(), a.precomp_offset, a.spectral_mode, a.precomp_flag);
+          }
           res.val = res.val + currVal.val * weight * bumpCosMult;
           res.pdf += currVal.pdf * weight;
         } break;

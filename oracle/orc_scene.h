@@ -185,6 +185,9 @@ struct Scene
   std::vector<f4>       cieXYZ;
   int                   camResponseSpectrumId[3] = { -1, -1, -1 };
   uint                  camResponseType = 0;
+  // thin films (integrator_pt.h:587-590)
+  std::vector<float>    filmsThickness, filmsEtaK, precompThinFilms;
+  std::vector<uint>     filmsSpecId;
 
   std::vector<SimpleBvh> blas;            // per geom
   SimpleBvh              tlas;
@@ -236,6 +239,11 @@ struct Scene
     cieXYZ.resize(std::max<size_t>(cieXYZ.size(), 472), mk4(0, 0, 0, 0));   // SpectrumToXYZ reads entry `offset` before testing offset >= 471
     for (int k = 0; k < 3; k++) camResponseSpectrumId[k] = s->specValues ? s->camResponseSpectrumId[k] : -1;
     camResponseType = s->camResponseType;
+    filmsThickness.clear(); filmsEtaK.clear(); precompThinFilms.clear(); filmsSpecId.clear();
+    if (s->filmsThickness && s->numFilmsThickness) filmsThickness.assign(s->filmsThickness, s->filmsThickness + s->numFilmsThickness);
+    if (s->filmsSpecId && s->numFilmsSpecId) filmsSpecId.assign(s->filmsSpecId, s->filmsSpecId + s->numFilmsSpecId);
+    if (s->filmsEtaK && s->numFilmsEtaK) filmsEtaK.assign(s->filmsEtaK, s->filmsEtaK + s->numFilmsEtaK);
+    if (s->precompThinFilms && s->numPrecompThinFilms) precompThinFilms.assign(s->precompThinFilms, s->precompThinFilms + s->numPrecompThinFilms);
     instMatricesInv.resize(instMatrices.size());
     for (size_t i = 0; i < instMatrices.size(); i++) instMatricesInv[i] = affine_inverse(instMatrices[i]);
     build_accel();

@@ -813,6 +813,238 @@ static inline void plasticEval(const Material& m, f4 a_reflSpec, f3 l, f3 v, f3 
   pRes->pdf = pdf;
 }
 
+// ---- include/cmat_film.h, include/airy_reflectance.h, include/cmaterial.h:957-1036 (MAT_TYPE_THIN_FILM) ----------------------------------
+static const uint MAT_TYPE_THIN_FILM = 8;                                                              // include/cmaterial.h:45
+static const uint FILM_ANGLE_RES = 180, FILM_LENGTH_RES = 94, FILM_THICKNESS_RES = 32;                 // include/cglobals.h:19-21
+static const float FILM_LAMBDA_MIN = 360.0f, FILM_LAMBDA_MAX = 830.0f;                                 // include/cglobals.h:22-23
+static const int FILM_ROUGH_U = 0, FILM_ROUGH_V = 1, FILM_PRECOMP_FLAG = 2, FILM_PRECOMP_OFFSET = 3, FILM_ETA_OFFSET = 4, FILM_K_OFFSET = 5,
+                 FILM_ETA_SPECID_OFFSET = 6, FILM_K_SPECID_OFFSET = 7, FILM_ETA_EXT = 8, FILM_THICKNESS_OFFSET = 9, FILM_THICKNESS_MIN = 10,
+                 FILM_THICKNESS_MAX = 11, FILM_THICKNESS_MAP = 12, FILM_THICKNESS = 13, FILM_LAYERS_COUNT = 14, FILM_TRANSPARENT = 15;   // include/cmaterial.h:164-179
+static inline uint as_uint_(float f) { uint u; std::memcpy(&u, &f, 4); return u; }
+static inline float sum4(f4 v) { return v.x + v.y + v.z + v.w; }                                       // cmaterial.h:955
+struct FrReflRefr { float refl, refr; };                                                               // :962-965
+static inline float getRefractionFactor(float cosThetaI, cplx cosThetaT, cplx iorI, cplx iorT)         // :967-975
+{
+  const cplx mult = cosThetaT * iorT;
+  if (cosThetaI <= 1e-6f || mult.im > 1e-6f) return 0.0f;
+  return mult.re / (iorI.re * cosThetaI);
+}
+static inline cplx FrComplexRefl(cplx cosThetaI, cplx cosThetaT, cplx iorI, cplx iorT, int polP)       // :995-1010 (polP: 0 = PolarizationS, 1 = PolarizationP)
+{
+  if (cnorm(cosThetaI) < 1e-6f) return cmk(-1.0f, 0.0f);
+  if (!polP) return (iorI * cosThetaI - iorT * cosThetaT) / (iorI * cosThetaI + iorT * cosThetaT);
+  return (iorT * cosThetaI - iorI * cosThetaT) / (iorT * cosThetaI + iorI * cosThetaT);
+}
+static inline cplx FrComplexRefr(cplx cosThetaI, cplx cosThetaT, cplx iorI, cplx iorT, int polP)       // :1012-1031
+{
+  if (cnorm(cosThetaI) < 1e-6f) return (cnorm(iorI - iorT) < 1e-6f) ? cmk(1.0f, 0.0f) : cmk(0.0f, 0.0f);
+  if (!polP) return ((iorI * 2.0f) * cosThetaI) / (iorI * cosThetaI + iorT * cosThetaT);
+  return ((iorI * 2.0f) * cosThetaI) / (iorT * cosThetaI + iorI * cosThetaT);
+}
+static inline cplx filmPhaseDiff(cplx cosTheta, cplx eta, float thickness, float lambda)               // :1033-1036
+{ return (((eta * float(4 * M_PI)) * cosTheta) * thickness) / cmk(lambda, 0.0f); }
+// the cosines of the refracted directions inside the film and the substrate (airy_reflectance.h:11-15, 39-43, 69-73)
+static inline void filmCosines(float cosThetaI, cplx etaI, cplx etaF, cplx etaT, cplx* cosThetaF, cplx* cosThetaT)
+{
+  const cplx sinThetaI = cmk(1.0f - cosThetaI * cosThetaI, 0.0f);
+  const cplx sinThetaF = (sinThetaI * (etaI.re * etaI.re)) / (etaF * etaF);
+  *cosThetaF = csqrt_(rsub(1.0f, sinThetaF));
+  const cplx sinThetaT = (sinThetaI * (etaI.re * etaI.re)) / (etaT * etaT);
+  *cosThetaT = csqrt_(rsub(1.0f, sinThetaT));
+}
+static inline float FrFilmRefl(float cosThetaI, cplx etaI, cplx etaF, cplx etaT, float thickness, float lambda)   // airy_reflectance.h:9-33
+{
+  cplx cosThetaF, cosThetaT;
+  filmCosines(cosThetaI, etaI, etaF, etaT, &cosThetaF, &cosThetaT);
+  const cplx phaseDiff = filmPhaseDiff(cosThetaF, etaF, thickness, lambda);
+  float result = 0;
+  for (int p = 0; p <= 1; ++p) {
+    const cplx FrReflI = FrComplexRefl(cmk(cosThetaI, 0.0f), cosThetaF, etaI, etaF, p);
+    const cplx FrReflF = FrComplexRefl(cosThetaF, cosThetaT, etaF, etaT, p);
+    cplx FrRefl = (FrReflF * std::exp(-phaseDiff.im)) * cmk(std::cos(phaseDiff.re), std::sin(phaseDiff.re));
+    FrRefl = (FrReflI + FrRefl) / radd(1.0f, FrReflI * FrRefl);
+    result += cnorm(FrRefl);
+  }
+  return result / 2;
+}
+static inline FrReflRefr FrFilm(float cosThetaI, cplx etaI, cplx etaF, cplx etaT, float thickness, float lambda)  // airy_reflectance.h:67-106
+{
+  cplx cosThetaF, cosThetaT;
+  filmCosines(cosThetaI, etaI, etaF, etaT, &cosThetaF, &cosThetaT);
+  const cplx phaseDiff = filmPhaseDiff(cosThetaF, etaF, thickness, lambda);
+  FrReflRefr result = { 0, 0 };
+  for (int p = 0; p <= 1; ++p) {
+    const cplx FrReflI = FrComplexRefl(cmk(cosThetaI, 0.0f), cosThetaF, etaI, etaF, p);
+    const cplx FrReflF = FrComplexRefl(cosThetaF, cosThetaT, etaF, etaT, p);
+    const cplx FrRefrI = FrComplexRefr(cmk(cosThetaI, 0.0f), cosThetaF, etaI, etaF, p);
+    const cplx FrRefrF = FrComplexRefr(cosThetaF, cosThetaT, etaF, etaT, p);
+    const cplx exp_1 = cmk(std::cos(phaseDiff.re / 2), std::sin(phaseDiff.re / 2)) * std::exp(-phaseDiff.im / 2);
+    const cplx exp_2 = exp_1 * exp_1;
+    const cplx denom = radd(1.0f, (FrReflI * FrReflF) * exp_2);
+    if (cnorm(denom) < 1e-6f) result.refl += 0.5f;
+    else {
+      result.refl += cnorm((FrReflI + FrReflF * exp_2) / denom) / 2;
+      result.refr += cnorm(((FrRefrI * FrRefrF) * exp_1) / denom) / 2;
+    }
+  }
+  result.refr *= getRefractionFactor(cosThetaI, cosThetaT, etaI, etaT);
+  return result;
+}
+// The table look-ups of cmat_film.h (:41-143, 227-329, 461-535): the angle is the table's second axis; the first is the wavelength (spectral mode),
+// the thickness (RGB mode with a thickness map) or absent. Reflectance at refl_offset, transmittance at refr_offset (units of FILM_ANGLE_RES rows).
+static inline float filmThetaIndex(float cosThetaI)
+{ return clampf(float(double(std::acos(cosThetaI) * 2.f) / M_PI), 0.f, 1.f) * float(FILM_ANGLE_RES - 1); }
+static inline float filmLerp2D(const float* pre, uint base, uint rowLen, uint stride, uint ch, float x, float theta, uint xRes)
+{
+  const uint index1 = std::min(uint(x), uint(xRes - 2)), index2 = std::min(uint(theta), uint(FILM_ANGLE_RES - 2));
+  const float alpha = x - float(index1), beta = theta - float(index2);
+  const uint a = (base + index1 * rowLen + index2) * stride + ch, b = (base + (index1 + 1) * rowLen + index2) * stride + ch;
+  const uint c = (base + index1 * rowLen + index2 + 1) * stride + ch, d = (base + (index1 + 1) * rowLen + index2 + 1) * stride + ch;
+  const float v0 = lerpf(pre[a], pre[b], alpha), v1 = lerpf(pre[c], pre[d], alpha);
+  return lerpf(v0, v1, beta);
+}
+static inline void filmReflTrans(const Material& m, float cosThetaI, float extIOR, cplx filmIOR, cplx intIOR, float thickness, float lambda, bool reversed,
+                                 const float* pre, uint off, bool spectral_mode, bool precomputed, bool wantT, f4* R, f4* T)
+{
+  const uint refl_offset = reversed ? FILM_ANGLE_RES * 2 : 0, refr_offset = reversed ? FILM_ANGLE_RES * 3 : FILM_ANGLE_RES;
+  *R = mk4(0, 0, 0, 0); *T = mk4(0, 0, 0, 0);
+  if (spectral_mode) {
+    if (precomputed) {
+      const float w = clampf((lambda - FILM_LAMBDA_MIN) / (FILM_LAMBDA_MAX - FILM_LAMBDA_MIN), 0.f, 1.f) * float(FILM_LENGTH_RES - 1);
+      const float theta = filmThetaIndex(cosThetaI);
+      R->x = filmLerp2D(pre + off, refl_offset * FILM_LENGTH_RES, FILM_ANGLE_RES, 1, 0, w, theta, FILM_LENGTH_RES);
+      if (wantT) T->x = filmLerp2D(pre + off, refr_offset * FILM_LENGTH_RES, FILM_ANGLE_RES, 1, 0, w, theta, FILM_LENGTH_RES);
+    } else if (wantT) {
+      const FrReflRefr r = !reversed ? FrFilm(cosThetaI, cmk(extIOR, 0.0f), filmIOR, intIOR, thickness, lambda) : FrFilm(cosThetaI, intIOR, filmIOR, cmk(extIOR, 0.0f), thickness, lambda);
+      R->x = r.refl; T->x = r.refr;
+    } else
+      R->x = !reversed ? FrFilmRefl(cosThetaI, cmk(extIOR, 0.0f), filmIOR, intIOR, thickness, lambda) : FrFilmRefl(cosThetaI, intIOR, filmIOR, cmk(extIOR, 0.0f), thickness, lambda);
+  } else {
+    const float theta = filmThetaIndex(cosThetaI);
+    float* r = &R->x; float* t = &T->x;
+    if (as_uint_(m.data[FILM_THICKNESS_MAP]) == 1u) {
+      const float tmin = m.data[FILM_THICKNESS_MIN], tmax = m.data[FILM_THICKNESS_MAX];
+      const float tt = clampf((thickness - tmin) / (tmax - tmin), 0.f, 1.f) * float(FILM_THICKNESS_RES - 1);
+      for (uint ch = 0; ch < 3; ch++) {
+        r[ch] = filmLerp2D(pre + off, refl_offset * FILM_THICKNESS_RES, FILM_ANGLE_RES, 3, ch, tt, theta, FILM_THICKNESS_RES);
+        if (wantT) t[ch] = filmLerp2D(pre + off, refr_offset * FILM_THICKNESS_RES, FILM_ANGLE_RES, 3, ch, tt, theta, FILM_THICKNESS_RES);
+      }
+    } else {
+      const uint index = std::min(uint(theta), uint(FILM_ANGLE_RES - 2));
+      const float alpha = theta - float(index);
+      for (uint ch = 0; ch < 3; ch++) {
+        r[ch] = lerpf(pre[off + (refl_offset + index) * 3 + ch], pre[off + (refl_offset + index + 1) * 3 + ch], alpha);
+        if (wantT) t[ch] = lerpf(pre[off + (refr_offset + index) * 3 + ch], pre[off + (refr_offset + index + 1) * 3 + ch], alpha);
+      }
+    }
+  }
+}
+static inline void filmSmoothSampleAndEval(const Material& m, float extIOR, cplx filmIOR, cplx intIOR, float thickness, f4 a_wavelengths, float _extIOR, f4 rands, f3 v, f3 n,
+                                           BsdfSample* pRes, const float* pre, uint precompOffset, bool spectral_mode, bool precomputed)   // cmat_film.h:9-181
+{
+  const uint transparFlag = as_uint_(m.data[FILM_TRANSPARENT]);
+  if ((pRes->flags & RAY_FLAG_HAS_INV_NORMAL) != 0) n = (-1.0f) * n;
+  const bool reversed = dot(n, v) < 0.f && intIOR.im < 0.001f;
+  f3 s, t = n;
+  CoordinateSystemV2(n, &s, &t);
+  const f3 wi = mk3(dot(v, s), dot(v, t), dot(v, n));
+  const float cosThetaI = clampf(std::abs(wi.z), 0.0001f, 1.0f);
+  const float ior = intIOR.re / extIOR;
+  f4 R, T;
+  filmReflTrans(m, cosThetaI, extIOR, filmIOR, intIOR, thickness, a_wavelengths.x, reversed, pre, precompOffset, spectral_mode, precomputed, true, &R, &T);
+  if (intIOR.im > 0.001f || transparFlag == 0) {
+    const f3 wo = mk3(-wi.x, -wi.y, wi.z);
+    pRes->val = R; pRes->pdf = 1.f;
+    pRes->dir = normalize(wo.x * s + wo.y * t + wo.z * n);
+    pRes->flags |= RAY_EVENT_S; pRes->ior = _extIOR;
+  } else if (rands.x * (sum4(R) + sum4(T)) < sum4(R)) {
+    const f3 wo = mk3(-wi.x, -wi.y, wi.z);
+    pRes->val = R; pRes->pdf = sum4(R) / (sum4(R) + sum4(T));
+    pRes->dir = normalize(wo.x * s + wo.y * t + wo.z * n);
+    pRes->flags |= RAY_EVENT_S; pRes->ior = _extIOR;
+  } else {
+    const f4 fr = FrDielectricDetailedV2(wi.z, ior);
+    const f3 wo = refract_(wi, fr.y, fr.w);
+    pRes->val = T; pRes->pdf = sum4(T) / (sum4(R) + sum4(T));
+    pRes->dir = normalize(wo.x * s + wo.y * t + wo.z * n);
+    pRes->flags |= (RAY_EVENT_S | RAY_EVENT_T);
+    pRes->ior = (_extIOR == intIOR.re) ? extIOR : intIOR.re;
+  }
+  pRes->val = pRes->val / std::max(std::abs(dot(pRes->dir, n)), 1e-6f);
+}
+static inline float microfacet_G(f3 wi, f3 wo, f3 mm, f2 alpha) { return smith_g1(wi, mm, alpha) * smith_g1(wo, mm, alpha); }   // cmaterial.h:903-906
+static inline void filmRoughSampleAndEval(const Material& m, float extIOR, cplx filmIOR, cplx intIOR, float thickness, f4 a_wavelengths, float _extIOR, f4 rands, f3 v, f3 n,
+                                          f3 alpha_tex, BsdfSample* pRes, const float* pre, uint precompOffset, bool spectral_mode, bool precomputed)   // cmat_film.h:183-410
+{
+  const uint transparFlag = as_uint_(m.data[FILM_TRANSPARENT]);
+  if ((pRes->flags & RAY_FLAG_HAS_INV_NORMAL) != 0) n = (-1.0f) * n;
+  const bool reversed = dot(v, n) < 0.f && intIOR.im < 0.001f;
+  const f2 alpha = mk2(std::min(m.data[FILM_ROUGH_V], alpha_tex.x), std::min(m.data[FILM_ROUGH_U], alpha_tex.y));
+  f3 s, t = n;
+  CoordinateSystemV2(n, &s, &t);
+  f3 wi = mk3(dot(v, s), dot(v, t), dot(v, n));
+  float ior = intIOR.re / extIOR;
+  if (reversed) { wi = (-1.0f) * wi; ior = 1.f / ior; }
+  const f3 wm = trSample(wi, mk2(rands.x, rands.y), alpha);
+  const float cosThetaI = clampf(std::abs(dot(wi, wm)), 0.00001f, 1.0f);
+  f4 R, T;
+  filmReflTrans(m, cosThetaI, extIOR, filmIOR, intIOR, thickness, a_wavelengths.x, reversed, pre, precompOffset, spectral_mode, precomputed, true, &R, &T);
+  const bool opaque = intIOR.im > 0.001f || transparFlag == 0;
+  if (opaque || rands.w * (sum4(R) + sum4(T)) < sum4(R)) {
+    f3 wo = reflect((-1.0f) * wi, wm);
+    if (wi.z < 0.f || wo.z <= 0.f) return;
+    const float cos_theta_i = std::max(wi.z, EPSILON_32), cos_theta_o = std::max(wo.z, EPSILON_32);
+    pRes->pdf = trPDF(wi, wm, alpha) / (4.0f * std::abs(dot(wi, wm)));
+    if (!opaque) pRes->pdf = pRes->pdf * sum4(R) / (sum4(R) + sum4(T));
+    pRes->val = ((trD(wm, alpha) * microfacet_G(wi, wo, wm, alpha)) * R) / (4.0f * cos_theta_i * cos_theta_o);
+    if (reversed) wo = (-1.0f) * wo;
+    pRes->dir = normalize(wo.x * s + wo.y * t + wo.z * n);
+    pRes->flags = RAY_FLAG_HAS_NON_SPEC;
+    pRes->ior = _extIOR;
+  } else {
+    const f4 fr = FrDielectricDetailedV2(dot(wi, wm), ior);
+    const float cosThetaT = fr.y, eta_it = fr.z, eta_ti = fr.w;
+    f3 ws, wt;
+    CoordinateSystemV2(wm, &ws, &wt);
+    const f3 local_wi = mk3(dot(ws, wi), dot(wt, wi), dot(wm, wi));
+    const f3 local_wo = refract_(local_wi, cosThetaT, eta_ti);
+    f3 wo = local_wo.x * ws + local_wo.y * wt + local_wo.z * wm;
+    if (wo.z > 0.f) return;
+    const float cos_theta_i = std::max(wi.z, EPSILON_32), cos_theta_o = std::min(wo.z, -EPSILON_32);
+    if (std::abs(eta_it - 1.f) <= 1e-6f) {
+      pRes->pdf = trPDF(wi, wm, alpha) / (4.0f * std::abs(dot(wi, wm))) * sum4(T) / (sum4(R) + sum4(T));
+      pRes->val = ((trD(wm, alpha) * microfacet_G(wi, wo, wm, alpha)) * T) / (4.0f * -cos_theta_i * cos_theta_o);
+    } else {
+      const float sq = dot(wo, wm) + dot(wi, wm) / eta_it;
+      const float denom = sq * sq;
+      const float dwm_dwi = std::abs(dot(wo, wm)) / denom;
+      pRes->pdf = trPDF(wi, wm, alpha) * dwm_dwi * sum4(T) / (sum4(R) + sum4(T));
+      pRes->val = ((trD(wm, alpha) * microfacet_G(wi, wo, wm, alpha)) * T) * std::abs(dot(wi, wm) * dot(wo, wm) / (cos_theta_i * cos_theta_o * denom));
+    }
+    if (reversed) wo = (-1.0f) * wo;
+    pRes->dir = normalize(wo.x * s + wo.y * t + wo.z * n);
+    pRes->flags = RAY_FLAG_HAS_NON_SPEC;
+    pRes->ior = (_extIOR == intIOR.re) ? extIOR : intIOR.re;
+  }
+}
+static inline void filmRoughEval(const Material& m, float extIOR, cplx filmIOR, cplx intIOR, float thickness, f4 a_wavelengths, f3 l, f3 v, f3 n, f3 alpha_tex, BsdfEval* pRes,
+                                 const float* pre, uint precompOffset, bool spectral_mode, bool precomputed)   // cmat_film.h:413-544
+{
+  if (intIOR.im < 0.001f) return;                                   // a film on a dielectric evaluates to zero; `reversed` (:425-431) can then never hold
+  const f2 alpha = mk2(std::min(m.data[FILM_ROUGH_V], alpha_tex.x), std::min(m.data[FILM_ROUGH_U], alpha_tex.y));
+  f3 s, t = n;
+  CoordinateSystemV2(n, &s, &t);
+  const f3 wo = mk3(dot(l, s), dot(l, t), dot(l, n)), wi = mk3(dot(v, s), dot(v, t), dot(v, n));
+  const f3 wm = normalize(wo + wi);
+  if (wi.z * wo.z < 0.f) return;
+  const float cosThetaI = clampf(std::abs(dot(wo, wm)), 0.00001f, 1.0f);
+  f4 R, T;
+  filmReflTrans(m, cosThetaI, extIOR, filmIOR, intIOR, thickness, a_wavelengths.x, false, pre, precompOffset, spectral_mode, precomputed, false, &R, &T);
+  const float cos_theta_i = std::max(wi.z, EPSILON_32), cos_theta_o = std::max(wo.z, EPSILON_32);
+  pRes->pdf = trPDF(wi, wm, alpha) / (4.0f * std::abs(dot(wi, wm)));
+  pRes->val = ((trD(wm, alpha) * microfacet_G(wi, wo, wm, alpha)) * R) / (4.0f * cos_theta_i * cos_theta_o);
+}
+
 // ---- include/clight.h -----------------------------------------------------------------------------------------
 struct LightSample { f3 pos, norm; float pdf; bool isOmni, hasIES; };   // :58-65
 

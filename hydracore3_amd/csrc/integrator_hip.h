@@ -140,6 +140,11 @@ public:
     d.cieXYZ = m_cie_xyz.empty() ? nullptr : m_cie_xyz.data(); d.numCieXYZ = uint32_t(m_cie_xyz.size() / 4);
     for (int k = 0; k < 3; k++) d.camResponseSpectrumId[k] = m_camResponseSpectrumId[k];
     d.camResponseType = uint32_t(m_camResponseType);
+    // thin films: what LoadThinFilmMaterial appended (integrator_pt.h:587-590)
+    d.filmsThickness = m_films_thickness_vec.empty() ? nullptr : m_films_thickness_vec.data(); d.numFilmsThickness = uint32_t(m_films_thickness_vec.size());
+    d.filmsSpecId = m_films_spec_id_vec.empty() ? nullptr : m_films_spec_id_vec.data(); d.numFilmsSpecId = uint32_t(m_films_spec_id_vec.size());
+    d.filmsEtaK = m_films_eta_k_vec.empty() ? nullptr : m_films_eta_k_vec.data(); d.numFilmsEtaK = uint32_t(m_films_eta_k_vec.size());
+    d.precompThinFilms = m_precomp_thin_films.empty() ? nullptr : m_precomp_thin_films.data(); d.numPrecompThinFilms = uint32_t(m_precomp_thin_films.size());
     report(hpt_upload_scene(m_ctx, &d), "CommitDeviceData");
     if (m_randomGensInit != m_maxThreadId) { hpt_init_random_gens(m_ctx, m_maxThreadId); m_randomGensInit = m_maxThreadId; }   // InitRandomGens
   }
@@ -201,6 +206,10 @@ public:
   std::vector<float>       m_cie_xyz;                 // integrator_pt.h:585: float4 {x, y, z, 0} per nm, 471 entries
   int                      m_camResponseSpectrumId[3] = {-1, -1, -1};   // integrator_pt.h:533
   int                      m_camResponseType = 0;     // integrator_pt.h:534: 0 = CAM_RESPONCE_XYZ, 1 = CAM_RESPONCE_RGB
+  std::vector<float>       m_films_thickness_vec;     // integrator_pt.h:587-590: thin films
+  std::vector<uint32_t>    m_films_spec_id_vec;
+  std::vector<float>       m_films_eta_k_vec;
+  std::vector<float>       m_precomp_thin_films;
   std::vector<uint32_t>    m_instGeomId;
   std::vector<TextureData> m_textures;
   BVH2SceneHIP*            m_pAccelStruct = nullptr;

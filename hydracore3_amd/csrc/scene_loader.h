@@ -27,6 +27,7 @@
 #include <zlib.h>                       // inflate for PNG textures (link the tools with -lz)
 #include "integrator_hip.h"
 #include "plastic_precompute.h"
+#include "film_precompute.h"
 
 namespace hydra_hip {
 
@@ -192,6 +193,8 @@ struct LoadedScene
   float envSamRow0[4] = {1, 0, 0, 0}, envSamRow1[4] = {0, 1, 0, 0};
   uint32_t envSpecId = 0xFFFFFFFFu; float envSpecMult = 1.0f;   // m_envSpecId, m_envSpecMult (integrator_pt_scene.cpp:456-457)
   std::vector<float> arrays1f;
+  // thin films (integrator_pt.h:587-590): m_films_thickness_vec, m_films_spec_id_vec, m_films_eta_k_vec, m_precomp_thin_films
+  std::vector<float> filmsThickness, filmsEtaK, precompThinFilms; std::vector<uint32_t> filmsSpecId;
   std::vector<float> lensLines; float physSize[2] = {0, 0};   // lens simulation: m_lines as {curvatureRadius, thickness, eta, apertureRadius}, m_physSize
   // spectral rendering (LoadSceneSpectrumData, integrator_pt_scene.cpp:358-419; the camera's <sensor><response>, :688-711)
   uint32_t spectralMode = 0;
@@ -227,6 +230,12 @@ struct LoadedScene
       d.cieXYZ = cieXYZ.data(); d.numCieXYZ = (uint32_t)(cieXYZ.size() / 4);
       for (int k = 0; k < 3; k++) d.camResponseSpectrumId[k] = camResponseSpectrumId[k];
       d.camResponseType = camResponseType;
+    }
+    if (!filmsEtaK.empty()) {
+      d.filmsThickness = filmsThickness.data(); d.numFilmsThickness = (uint32_t)filmsThickness.size();
+      d.filmsSpecId = filmsSpecId.data(); d.numFilmsSpecId = (uint32_t)filmsSpecId.size();
+      d.filmsEtaK = filmsEtaK.data(); d.numFilmsEtaK = (uint32_t)filmsEtaK.size();
+      d.precompThinFilms = precompThinFilms.empty() ? nullptr : precompThinFilms.data(); d.numPrecompThinFilms = (uint32_t)precompThinFilms.size();
     }
     return d;
   }
@@ -993,6 +1002,52 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
       }
       mat.datai[0] = (uint32_t)sc.arrays1f.size();
       sc.arrays1f.insert(sc.arrays1f.end(), pre.transmittance, pre.transmittance + plastic::TRANSMITTANCE_RES);
+    } else if (type == "thin_film") {                                         // LoadThinFilmMaterial (:1020-1193)
+      auto fbits = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+      mat.mtype = 8; mat.lightId = 0xFFFFFFFFu;
+      mat.colors[0][0] = mat.colors[0][1] = mat.colors[0][2] = 1.0f; mat.colors[0][3] = 0.0f;
+      float au, av;
+      if (const XmlNode* an = mn->child("alpha")) {
+        au = av = attrFloat(an);
+        if (!loadTextureFromNode(an, mat.row0[0], mat.row1[0], mat.texid[0])) return false;
+        if (mat.texid[0] != 0) au = av = 1.0f;
+      } else { au = attrFloat(mn->child("alpha_u")); av = attrFloat(mn->child("alpha_v")); }
+      mat.data[0] = au; mat.data[1] = av;                                     // FILM_ROUGH_U, FILM_ROUGH_V
+      const XmlNode* tmapNode = mn->child("thickness_map");
+      if (tmapNode) {
+        mat.data[10] = (float)std::atof(tmapNode->get("min", "0").c_str()); mat.data[11] = (float)std::atof(tmapNode->get("max", "0").c_str());
+        if (!loadTextureFromNode(tmapNode, mat.row0[2], mat.row1[2], mat.texid[2])) return false;
+      }
+      mat.data[12] = fbits(tmapNode ? 1u : 0u);                               // FILM_THICKNESS_MAP
+      mat.data[8] = mn->child("ext_ior") ? attrFloat(mn->child("ext_ior")) : 1.00028f;   // FILM_ETA_EXT: air
+      const uint32_t tOff = (uint32_t)sc.filmsThickness.size(), sOff = (uint32_t)sc.filmsSpecId.size(), eOff = (uint32_t)sc.filmsEtaK.size();
+      mat.data[9] = fbits(tOff); mat.data[6] = fbits(sOff); mat.data[4] = fbits(eOff);   // FILM_THICKNESS_OFFSET, FILM_ETA_SPECID_OFFSET, FILM_ETA_OFFSET
+      std::vector<const XmlNode*> stack;                                      // the <layers> children, then the material's own <eta> / <k> (the substrate)
+      if (const XmlNode* ln = mn->child("layers")) for (const XmlNode& l : ln->children) stack.push_back(&l);
+      for (const XmlNode* l : stack) if (const XmlNode* t = l->child("thickness")) sc.filmsThickness.push_back(attrFloat(t));
+      if (mn->child("eta")) stack.push_back(mn);
+      const uint32_t layers = (uint32_t)stack.size();
+      if (layers < 1 || layers > film::MAX_LAYERS || sc.filmsThickness.size() <= tOff) { err = "thin_film material without layers or without a thickness"; return false; }
+      for (const XmlNode* l : stack) { sc.filmsEtaK.push_back(attrFloat(l->child("eta"))); sc.filmsSpecId.push_back(spectrumId(l->child("eta"))); }
+      mat.data[13] = sc.filmsThickness[tOff]; mat.data[14] = fbits(layers);   // FILM_THICKNESS, FILM_LAYERS_COUNT
+      mat.data[7] = fbits((uint32_t)sc.filmsSpecId.size()); mat.data[5] = fbits((uint32_t)sc.filmsEtaK.size());   // FILM_K_SPECID_OFFSET, FILM_K_OFFSET
+      for (const XmlNode* l : stack) { sc.filmsEtaK.push_back(attrFloat(l->child("k"))); sc.filmsSpecId.push_back(spectrumId(l->child("k"))); }
+      uint32_t transpar = 0;
+      if (const XmlNode* tn = mn->child("transparent")) transpar = (uint32_t)std::atoll(tn->get("val", "0").c_str());
+      mat.data[15] = fbits(transpar);                                         // FILM_TRANSPARENT
+      film::Params fp;
+      fp.spectralMode = spectral ? 1 : 0; fp.extIOR = mat.data[8]; fp.layers = layers;
+      fp.eta = sc.filmsEtaK.data() + eOff; fp.k = sc.filmsEtaK.data() + eOff + layers; fp.etaSpecId = sc.filmsSpecId.data() + sOff; fp.kSpecId = sc.filmsSpecId.data() + sOff + layers;
+      fp.thickness = sc.filmsThickness.data() + tOff; fp.thicknessMap = tmapNode ? 1 : 0; fp.thicknessMin = mat.data[10]; fp.thicknessMax = mat.data[11];
+      fp.specValues = sc.specValues.empty() ? nullptr : sc.specValues.data(); fp.specOffsetSz = sc.specOffsetSz.data(); fp.numSpectra = (uint32_t)(sc.specOffsetSz.size() / 2);
+      fp.cieXYZ = sc.cieXYZ.data();
+      const bool pre = film::precomputed(fp);
+      mat.data[2] = fbits(pre ? 1u : 0u); mat.data[3] = fbits(pre ? (uint32_t)sc.precompThinFilms.size() : 0u);   // FILM_PRECOMP_FLAG, FILM_PRECOMP_OFFSET
+      if (pre) {
+        const size_t at = sc.precompThinFilms.size();
+        sc.precompThinFilms.resize(at + film::tableSize(fp));
+        if (!film::precompute(fp, sc.precompThinFilms.data() + at)) { err = "thin_film material: the tables could not be computed"; return false; }
+      }
     } else if (type == "blend") {                                             // LoadBlendMaterial (:619-647)
       mat.mtype = 6; mat.data[0] = 1.0f;
       if (const XmlNode* n = mn->child("bsdf_1")) mat.datai[0] = (uint32_t)std::atoll(n->get("id", "0").c_str());

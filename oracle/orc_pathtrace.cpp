@@ -1370,6 +1370,10 @@ int orc_probe(const char* name, const float* a, float* out)
   }
   if (n == "SampleWavelengths") { const f4 r = Ctx::SampleWavelengths(a[0], a[1], a[2]); out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w; return 0; }
   if (n == "XYZToRGB") { const f3 r = Ctx::XYZToRGB(mk3(a[0], a[1], a[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; return 0; }
+  if (n == "FrFilm") {          // a: cosThetaI, etaI (re, im), etaF (re, im), etaT (re, im), thickness, lambda -> refl, refr, FrFilmRefl
+    const FrReflRefr r = FrFilm(a[0], cmk(a[1], a[2]), cmk(a[3], a[4]), cmk(a[5], a[6]), a[7], a[8]);
+    out[0] = r.refl; out[1] = r.refr; out[2] = FrFilmRefl(a[0], cmk(a[1], a[2]), cmk(a[3], a[4]), cmk(a[5], a[6]), a[7], a[8]); return 0;
+  }
   if (n == "orennayarFunc") { out[0] = orennayarFunc(mk3(a[0], a[1], a[2]), mk3(a[3], a[4], a[5]), mk3(0, 0, 1), a[6]); return 0; }
   return 1;
 }

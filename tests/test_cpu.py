@@ -383,7 +383,7 @@ def _read_blobs(path):
     return out
 
 
-@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures", "test_spectral", "test_spectral+spectral", "spectral_plastic+spectral", "spectral_glass+spectral", "spectral_sky+spectral", "exr_sky"])
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures", "test_spectral", "test_spectral+spectral", "spectral_plastic+spectral", "spectral_glass+spectral", "spectral_sky+spectral", "exr_sky", "thin_film", "thin_film+spectral", "thin_film_rough", "thin_film_rough+spectral"])
 def test_cpp_scene_loader_produces_the_same_tables(scene_name, tmp_path):
     """hydracore3_amd/csrc/scene_loader.h (Hydra XML + VSGF + image4ub + IES in C++) == the Python fixture loader:
     every table byte for byte, matrices and light frames to float rounding (both invert in double)."""
@@ -407,6 +407,13 @@ def test_cpp_scene_loader_produces_the_same_tables(scene_name, tmp_path):
     assert named["specOffsetSz"] == np.asarray(sc.spec_offset_sz, np.uint32).tobytes()
     assert np.allclose(np.frombuffer(named["cieXYZ"], np.float32), S.cie_xyz_fit().reshape(-1), rtol=1e-6, atol=1e-9)
     assert list(np.frombuffer(named["camResponse"], np.int32)) == [*sc.cam_response_spectrum_id, sc.cam_response_type]
+    # thin films: the index vectors bit for bit; the tables come from the one film_precompute.h on both sides, over observer fits that differ in
+    # the last place (RGB) - to rounding
+    assert named["filmsThickness"] == np.asarray(sc.films_thickness, np.float32).tobytes()
+    assert named["filmsSpecId"] == np.asarray(sc.films_spec_id, np.uint32).tobytes()
+    assert named["filmsEtaK"] == np.asarray(sc.films_eta_k, np.float32).tobytes()
+    pf = np.frombuffer(named["precompThinFilms"], np.float32)
+    assert pf.size == sc.precomp_thin_films.size and np.allclose(pf, sc.precomp_thin_films, rtol=1e-5, atol=1e-6)
 
     def arr(ptr, dtype, count):
         return np.frombuffer((C.c_char * (np.dtype(dtype).itemsize * count)).from_address(ptr), dtype=dtype, count=count).copy() if count else np.zeros(0, dtype)
@@ -746,3 +753,51 @@ def test_parallel_bvh_build_equals_the_sequential_one(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", os.path.join(ROOT, "tests", "cpp", "bvh_build_test.cpp"), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.count("equal the sequential one") == 3 and r.stdout.count("every leaf once") == 3, r.stdout + r.stderr
+
+
+def test_thin_film_airy_identities_and_tables():
+    """FrFilm / FrFilmRefl (include/airy_reflectance.h:9-106) in the oracle against the closed forms of a single film, and the product's table
+    builder (csrc/film_precompute.h through hpt_film_precompute, written apart from the oracle) against the oracle at the tables' nodes."""
+    import ctypes as C
+    from hydracore3_amd import scene as S
+    from oracle import orc
+    lam = 550.0
+    # (1) a film of the substrate's own index is no film: one Fresnel interface
+    for cos_i in (1.0, 0.8, 0.3):
+        r = orc.probe("FrFilm", cos_i, 1.0, 0.0, 1.5, 0.0, 1.5, 0.0, 200.0, lam)
+        s2 = (1 - cos_i * cos_i) / 1.5 ** 2; ct = np.sqrt(1 - s2)
+        rs = ((cos_i - 1.5 * ct) / (cos_i + 1.5 * ct)) ** 2; rp = ((1.5 * cos_i - ct) / (1.5 * cos_i + ct)) ** 2
+        assert abs(r[0] - 0.5 * (rs + rp)) < 2e-6 and abs(r[0] + r[1] - 1.0) < 2e-6 and abs(r[2] - r[0]) < 2e-6
+    # (2) normal incidence: the Airy formula; (3) a quarter-wave layer of index sqrt(n0 nT) cancels the reflection
+    for nf, nt, d in ((1.38, 1.52, 99.6), (2.2, 1.5, 140.0), (1.33, 1.0, 320.0)):
+        r = orc.probe("FrFilm", 1.0, 1.0, 0.0, nf, 0.0, nt, 0.0, d, lam)
+        r1, r2 = (1.0 - nf) / (1.0 + nf), (nf - nt) / (nf + nt)
+        delta = 4 * np.pi * nf * d / lam
+        airy = (r1 * r1 + r2 * r2 + 2 * r1 * r2 * np.cos(delta)) / (1 + r1 * r1 * r2 * r2 + 2 * r1 * r2 * np.cos(delta))
+        assert abs(r[0] - airy) < 5e-6 and abs(r[0] + r[1] - 1.0) < 5e-6, (nf, nt, d, r, airy)
+    nf = np.sqrt(1.0 * 1.69)
+    assert orc.probe("FrFilm", 1.0, 1.0, 0.0, nf, 0.0, 1.69, 0.0, lam / (4 * nf), lam)[0] < 1e-6
+    # (4) an absorbing substrate transmits nothing into it that FrFilm counts, and reflects more than the bare dielectric film
+    r = orc.probe("FrFilm", 0.7, 1.0, 0.0, 2.0, 0.0, 0.2, 3.0, 100.0, lam)
+    assert 0.5 < r[0] < 1.0 and abs(r[2] - r[0]) < 2e-6
+    # (5) the product's spectral table at its nodes == the oracle's FrFilm; a second film of the substrate's index changes nothing (multFrFilm == FrFilm)
+    sc = S.SceneData(); sc.spectral_mode = 1
+    sc.spec_offset_sz = [(0, 471)]; sc.spec_values = np.ones(471, np.float32)
+    sc.material_thin_film([{"eta": 1.7, "k": 0.02, "thickness": 260.0}], {"eta": 1.45, "k": 0.0}, alpha=0.0, transparent=1)
+    one = sc.precomp_thin_films.copy().reshape(4, 94, 180)
+    sc.material_thin_film([{"eta": 1.7, "k": 0.02, "thickness": 260.0}, {"eta": 1.45, "k": 0.0, "thickness": 75.0}], {"eta": 1.45, "k": 0.0}, alpha=0.0, transparent=1)
+    two = sc.precomp_thin_films[one.size:].reshape(4, 94, 180)
+    assert np.allclose(one[:, :, :170], two[:, :, :170], rtol=0, atol=2e-5)   # (at grazing angles inside the substrate the two routines guard a vanishing denominator differently)
+    for i in (0, 40, 93):
+        w = np.float32(469.0) / np.float32(93.0) * np.float32(i) + np.float32(360.0)
+        for j in (0, 60, 150, 179):
+            c = float(np.clip(np.cos(np.float32(np.pi / 2 / 179.0 * j)), 1e-3, 1.0))
+            f = orc.probe("FrFilm", c, 1.00028, 0.0, 1.7, 0.02, 1.45, 0.0, 260.0, float(w))
+            b = orc.probe("FrFilm", c, 1.45, 0.0, 1.7, 0.02, 1.00028, 0.0, 260.0, float(w))
+            assert np.allclose([one[0, i, j], one[1, i, j], one[2, i, j], one[3, i, j]], [f[0], f[1], b[0], b[1]], rtol=0, atol=2e-5), (i, j)
+    # (6) RGB tables: a lossless film keeps the white point (R + T = 1 in every channel up to the observer fit), from both sides
+    rgb = S.SceneData()
+    rgb.material_thin_film([{"eta": 1.33, "thickness": 300.0}], {"eta": 1.5}, alpha=0.0, transparent=1)
+    t = rgb.precomp_thin_films.reshape(4, 180, 3)
+    assert np.all(np.abs(t[0] + t[1] - 1.0) < 2e-3) and np.all(np.abs(t[2][:100] + t[3][:100] - 1.0) < 2e-3) and t[0].min() >= 0.0 and t[0].max() <= 1.0
+    assert np.ptp(t[0, 0]) > 0.01                                        # ... and it is coloured: interference

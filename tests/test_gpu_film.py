@@ -51,10 +51,21 @@ def test_film_fixtures_match_oracle(name, spectral, layout):
     scale = float(b[..., :3].mean() / spp)
     l2 = _l2(a, b, spp)
     same = float(np.mean(np.all(a[..., :3] == b[..., :3], axis=-1)))
-    same_rng = float(np.mean(np.all(gpu.random_gens() == cpu.random_gens(), axis=1)))
-    print(f"{name} spectral={spectral} layout {layout}: per-pixel L2 = {l2:.3e} (mean {scale:.4f}), bit-identical pixels {same * 100:.2f} %, identical generators {same_rng * 100:.2f} %")
-    assert l2 < 2e-3 * max(scale, 1.0)
-    assert same_rng > 0.98
+    eq = np.all(gpu.random_gens() == cpu.random_gens(), axis=1)
+    same_rng = float(np.mean(eq))
+    # a path that takes another branch on the device (its sinf / cosf / acosf / expf differ from glibc's in the last place: a sample on the other
+    # side of the reflect / refract choice or of a wo.z test) changes its pixel by a whole light's worth; such pixels are counted, the others
+    # must agree closely. The generator of a pixel tells: it has advanced differently where a path took another turn.
+    xy = cpu.packed_xy()
+    px = (xy >> 16).astype(np.int64) * sc.width + (xy & 0xFFFF).astype(np.int64)
+    ok = np.zeros(sc.width * sc.height, bool); ok[px] = eq
+    d = ((a[..., :3].astype(np.float64) - b[..., :3]) / spp).reshape(-1, 3)
+    l2_same = float(np.sqrt(np.mean(np.sum(d[ok] ** 2, axis=-1))))
+    print(f"{name} spectral={spectral} layout {layout}: per-pixel L2 = {l2:.3e} (mean {scale:.4f}; {l2_same:.3e} over the pixels with identical generators), "
+          f"bit-identical pixels {same * 100:.2f} %, identical generators {same_rng * 100:.2f} % ({int((~eq).sum())} pixels apart)")
+    assert l2_same < 2e-4 * max(scale, 1.0)
+    assert l2 < 3e-2 * max(scale, 1.0)
+    assert same_rng > 0.995
 
 
 def test_naive_and_other_integrators_with_films():

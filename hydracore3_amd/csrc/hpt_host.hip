@@ -838,12 +838,6 @@ static int check_materials(hpt_ctx* c, const MaterialRec* m, size_t n, size_t nu
       if (m[i].texid[0] >= numTex) return c->fail(HPT_ERR_ARG, "material refers to a texture that does not exist");
       const uint64_t off = bits(m[i].data[FILM_PRECOMP_OFFSET]);
       if (pre && off > c->numPrecompFilms) return c->fail(HPT_ERR_ARG, "thin film: FILM_PRECOMP_OFFSET reaches past m_precomp_thin_films");
-      // the loader sizes a material's table by the mode it loads for (LoadThinFilmMaterial, integrator_pt_scene_mat.cpp:1147-1186): RGB reads
-      // 4 x FILM_ANGLE_RES x 3 (x FILM_THICKNESS_RES with a thickness map), spectral 4 x FILM_ANGLE_RES x FILM_LENGTH_RES or no table at all
-      const uint64_t avail = pre ? c->numPrecompFilms - off : 0u;
-      if (avail < 4ull * FILM_ANGLE_RES * 3ull * (tmap ? (uint64_t)FILM_THICKNESS_RES : 1ull)) c->filmTablesRGB = false;
-      if (pre && avail < 4ull * FILM_ANGLE_RES * FILM_LENGTH_RES) c->filmTablesSpectral = false;
-      c->hasFilm = true;
       continue;
     }
     if (t != MAT_TYPE_GLTF && t != MAT_TYPE_GLASS && t != MAT_TYPE_CONDUCTOR && t != MAT_TYPE_DIFFUSE && t != MAT_TYPE_DIELECTRIC && t != MAT_TYPE_PLASTIC && t != MAT_TYPE_LIGHT_SOURCE)
@@ -855,6 +849,28 @@ static int check_materials(hpt_ctx* c, const MaterialRec* m, size_t n, size_t nu
     if ((m[i].cflags & FLAG_FOUR_TEXTURES) && (m[i].texid[2] >= numTex || m[i].texid[3] >= numTex)) return c->fail(HPT_ERR_ARG, "material refers to a texture that does not exist");
   }
   return HPT_OK;
+}
+// What the material table says about thin films: whether there is one, and whether each film's precomputed table has the size RGB / spectral
+// rendering reads. The loader sizes a table by the mode it loads for (LoadThinFilmMaterial, integrator_pt_scene_mat.cpp:1147-1186): RGB
+// 4 x FILM_ANGLE_RES x 3 (x FILM_THICKNESS_RES with a thickness map or a single layer), spectral 4 x FILM_ANGLE_RES x FILM_LENGTH_RES or no table
+// (one film with a thickness map). The tables lie back to back in m_precomp_thin_films, so a table ends where the next one starts.
+static void film_scan(hpt_ctx* c)
+{
+  auto bits = [](float f) { uint u; std::memcpy(&u, &f, 4); return u; };
+  c->hasFilm = false; c->filmTablesRGB = true; c->filmTablesSpectral = true;
+  std::set<uint64_t> starts;
+  for (const MaterialRec& m : c->hMaterials) if (m.mtype == MAT_TYPE_THIN_FILM && bits(m.data[FILM_PRECOMP_FLAG]) != 0u) starts.insert(bits(m.data[FILM_PRECOMP_OFFSET]));
+  starts.insert(c->numPrecompFilms);
+  for (const MaterialRec& m : c->hMaterials) {
+    if (m.mtype != MAT_TYPE_THIN_FILM) continue;
+    c->hasFilm = true;
+    const bool pre = bits(m.data[FILM_PRECOMP_FLAG]) != 0u, tmap = bits(m.data[FILM_THICKNESS_MAP]) != 0u;
+    const uint layers = bits(m.data[FILM_LAYERS_COUNT]);
+    uint64_t size = 0;
+    if (pre) { const uint64_t off = bits(m.data[FILM_PRECOMP_OFFSET]); auto it = starts.upper_bound(off); size = (it == starts.end() ? c->numPrecompFilms : *it) - off; }
+    if (size != 4ull * FILM_ANGLE_RES * 3ull * ((tmap || layers == 1u) ? (uint64_t)FILM_THICKNESS_RES : 1ull)) c->filmTablesRGB = false;
+    if (pre ? size != 4ull * FILM_ANGLE_RES * FILM_LENGTH_RES : !(tmap && layers <= 2u)) c->filmTablesSpectral = false;
+  }
 }
 // A blend refers to two other materials, possibly blends: the sampling loop of shadeVertex follows such references until it meets a
 // leaf, so a reference cycle would never end on the device. Three-colour depth-first search over the blend nodes.
@@ -944,12 +960,12 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
   c->numFilmsEtaK = d->filmsEtaK ? d->numFilmsEtaK : 0u; c->numPrecompFilms = d->precompThinFilms ? d->numPrecompThinFilms : 0u;
   c->hFilmsSpecId.assign(d->filmsSpecId ? d->filmsSpecId : nullptr, d->filmsSpecId ? d->filmsSpecId + d->numFilmsSpecId : nullptr);
   c->numSpectraHost = (d->specValues && d->specOffsetSz) ? d->numSpectra : 0u;
-  c->hasFilm = false; c->filmTablesRGB = true; c->filmTablesSpectral = true;
   int rc = check_materials(c, (const MaterialRec*)d->materials, d->numMaterials, d->numTextures, d->numMaterials, d->numArrays1f); if (rc) return rc;
   c->leanMaterials = lean_materials((const MaterialRec*)d->materials, d->numMaterials);
   { std::vector<MaterialRec> hm((const MaterialRec*)d->materials, (const MaterialRec*)d->materials + d->numMaterials);
     rc = check_blend_graph(c, hm); if (rc) return rc;
     c->hMaterials.swap(hm); }
+  film_scan(c);
   if (d->numArrays1f && !d->arrays1f) return c->fail(HPT_ERR_ARG, "m_arrays1f: count without data");
   rc = check_lights(c, (const LightRec*)d->lights, d->numLights, d->numTextures, d->numArrays1f); if (rc) return rc;
   rc = check_tables(c, d); if (rc) return rc;
@@ -1177,6 +1193,7 @@ extern "C" int hpt_update_materials(hpt_ctx* c, size_t first, size_t count, cons
     std::memcpy(hm.data() + first, mats, count * sizeof(MaterialRec));
     rc = check_blend_graph(c, hm); if (rc) return rc;
     c->hMaterials.swap(hm);
+    film_scan(c);
   }
   if (!lean_materials((const MaterialRec*)mats, count)) c->leanMaterials = false;      // (an update can only widen the set of BSDFs in use)
   (void)hipSetDevice(c->device);

@@ -16,6 +16,22 @@ def _l2(a, b, spp):
     return float(np.sqrt(np.mean(np.sum(d * d, axis=-1))))
 
 
+def _compare(tag, a, b, spp, max_apart):
+    """The smooth films are trig-free and agree to float rounding in every pixel. A rough film draws its micro-normal through sinf / cosf,
+    the device's and glibc's differ in the last place, and two refractions through a sphere amplify that: about 3 paths in 100 000 end up on the
+    other side of a silhouette and change their pixel by a light's worth (profiles/dbg_film.py lists them). Those pixels are counted; the
+    others must agree closely."""
+    d = np.sqrt(np.sum(((a[..., :3].astype(np.float64) - b[..., :3]) / spp) ** 2, axis=-1))
+    scale = max(float(b[..., :3].mean() / spp), 1.0)
+    apart = d > 1e-3 * scale
+    rest = float(np.sqrt(np.mean(d[~apart] ** 2)))
+    print(f"{tag}: per-pixel L2 {np.sqrt(np.mean(d * d)):.3e} (mean radiance {b[..., :3].mean() / spp:.4f}); {int(apart.sum())} of {d.size} pixels apart, L2 of the others {rest:.3e}, "
+          f"bit-identical pixels {np.mean(np.all(a[..., :3] == b[..., :3], axis=-1)) * 100:.2f} %")
+    assert np.isfinite(a).all() and a[..., :3].mean() > 0
+    assert int(apart.sum()) <= max_apart
+    assert rest < 5e-5 * scale
+
+
 def _pair(sc, **kw):
     from hydracore3_amd.api import HipIntegrator
     from oracle.orc import OracleIntegrator
@@ -47,25 +63,8 @@ def test_film_fixtures_match_oracle(name, spectral, layout):
     gpu, cpu = _pair(sc, accel_layout=layout)
     spp = 16
     a, b = gpu.render(spp), cpu.render(spp)
-    assert np.isfinite(a).all() and a[..., :3].mean() > 0
-    scale = float(b[..., :3].mean() / spp)
-    l2 = _l2(a, b, spp)
-    same = float(np.mean(np.all(a[..., :3] == b[..., :3], axis=-1)))
-    eq = np.all(gpu.random_gens() == cpu.random_gens(), axis=1)
-    same_rng = float(np.mean(eq))
-    # a path that takes another branch on the device (its sinf / cosf / acosf / expf differ from glibc's in the last place: a sample on the other
-    # side of the reflect / refract choice or of a wo.z test) changes its pixel by a whole light's worth; such pixels are counted, the others
-    # must agree closely. The generator of a pixel tells: it has advanced differently where a path took another turn.
-    xy = cpu.packed_xy()
-    px = (xy >> 16).astype(np.int64) * sc.width + (xy & 0xFFFF).astype(np.int64)
-    ok = np.zeros(sc.width * sc.height, bool); ok[px] = eq
-    d = ((a[..., :3].astype(np.float64) - b[..., :3]) / spp).reshape(-1, 3)
-    l2_same = float(np.sqrt(np.mean(np.sum(d[ok] ** 2, axis=-1))))
-    print(f"{name} spectral={spectral} layout {layout}: per-pixel L2 = {l2:.3e} (mean {scale:.4f}; {l2_same:.3e} over the pixels with identical generators), "
-          f"bit-identical pixels {same * 100:.2f} %, identical generators {same_rng * 100:.2f} % ({int((~eq).sum())} pixels apart)")
-    assert l2_same < 2e-4 * max(scale, 1.0)
-    assert l2 < 3e-2 * max(scale, 1.0)
-    assert same_rng > 0.995
+    _compare(f"{name} spectral={spectral} layout {layout}", a, b, spp, 0 if name == "thin_film" else 30)
+    assert float(np.mean(np.all(gpu.random_gens() == cpu.random_gens(), axis=1))) > 0.995
 
 
 def test_naive_and_other_integrators_with_films():
@@ -78,9 +77,12 @@ def test_naive_and_other_integrators_with_films():
     for params, naive in ((sc.params(integrator=INTEGRATOR_STUPID_PT), True), (sc.params(integrator=INTEGRATOR_SHADOW_PT), False), (sc.params(integrator=INTEGRATOR_STUPID_PT), False)):
         gpu, cpu = HipIntegrator(sc, params), OracleIntegrator(sc, params)
         a, b = gpu.render(16, naive=naive), cpu.render(16, naive=naive)
-        l2, scale = _l2(a, b, 16), float(b[..., :3].mean() / 16)
-        print(f"integrator {params.integratorType} naive={naive}: per-pixel L2 = {l2:.3e}, mean {scale:.4f}")
-        assert np.isfinite(a).all() and a[..., :3].mean() > 0 and l2 < 2e-3 * max(scale, 1.0)
+        _compare(f"integrator {params.integratorType} naive={naive}", a, b, 16, 2)     # (one path of 65 536 takes another turn in the naive run)
+    rough = load_hydra_xml(scene_path("thin_film_rough"), 64, 64, spectral=False)
+    _brighten(rough, 60.0)
+    p = rough.params(integrator=INTEGRATOR_STUPID_PT)
+    gpu, cpu = HipIntegrator(rough, p), OracleIntegrator(rough, p)
+    _compare("rough films, naive", gpu.render(16, naive=True), cpu.render(16, naive=True), 16, 12)
 
 
 def test_film_scene_with_other_mode_tables_is_refused():
@@ -113,5 +115,4 @@ def test_opaque_and_transparent_switch():
         if int(m["mtype"]) == MAT_TYPE_THIN_FILM:
             m["data"][FILM_TRANSPARENT] = np.uint32(0).view(np.float32)
     gpu, cpu = _pair(sc)
-    a, b = gpu.render(8), cpu.render(8)
-    assert _l2(a, b, 8) < 2e-3 * max(float(b[..., :3].mean() / 8), 1.0)
+    _compare("opaque films", gpu.render(8), cpu.render(8), 8, 0)

@@ -1062,7 +1062,7 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
     if (mtypeAttr != "hydra_material") {
       bool known = false;
       if (!loadTypedMaterial(mn, mtypeAttr, mat, known)) return false;
-      if (!known) { err = "xml: material type '" + mtypeAttr + "' is outside the path (thin_film: SURVEY.md 2a)"; return false; }
+      if (!known) { err = "xml: material type '" + mtypeAttr + "' is not one of the reference's"; return false; }
       for (int k = 0; k < 4; k++) {
         bool zero = true; for (int j = 0; j < 4; j++) zero = zero && mat.row0[k][j] == 0.0f && mat.row1[k][j] == 0.0f;
         if (zero) { mat.row0[k][0] = 1.0f; mat.row1[k][1] = 1.0f; }

@@ -27,6 +27,7 @@ ABI = {
     "hpt_device_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.c_char_p, _sz]),
     "hpt_set_optics": (_i, [_vp, _vp, _u32, _f, _f]),
     "hpt_plastic_precompute": (_i, [_f, _f, _f, _vp, _vp, _vp, C.POINTER(_f), C.POINTER(_f)]),
+    "hpt_decode_jpeg": (_i, [_vp, _u64, C.POINTER(_u32), C.POINTER(_u32), _vp, _u64]),
     "hpt_film_precompute": (_i, [_vp, _vp, _u64, C.POINTER(_u64), C.POINTER(_i)]),
     "hpt_device_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "hpt_device_free": (_i, [_vp, _vp]),

@@ -2,6 +2,7 @@
 // Compiled by hipcc together with the kernels; exports only the extern "C" hpt_* symbols.
 #include "plastic_precompute.h"
 #include "film_precompute.h"
+#include "jpeg_decode.h"
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -237,6 +238,19 @@ extern "C" int hpt_device_info(hpt_ctx* c, int* numCUs, int* wavefront, char* na
   if (numCUs) *numCUs = c->numCUs;
   if (wavefront) *wavefront = 64;
   if (name && nameLen) { std::strncpy(name, c->devName.c_str(), nameLen - 1); name[nameLen - 1] = 0; }
+  return HPT_OK;
+}
+
+// ---- the JPEG reader of the scene loaders (host only) ----------------------------------------------------------------------------------------
+extern "C" int hpt_decode_jpeg(const uint8_t* file, uint64_t fileSize, uint32_t* outWidth, uint32_t* outHeight, uint8_t* outRGBA8, uint64_t outCapacity)
+{
+  if (!file || !outWidth || !outHeight) return HPT_ERR_ARG;
+  std::vector<uint8_t> f(file, file + fileSize), rgba; std::string err; uint32_t w = 0, h = 0;
+  if (!hydra_hip::jpeg::decode(f, w, h, rgba, err)) return HPT_ERR_UNSUPPORTED;
+  *outWidth = w; *outHeight = h;
+  if (!outRGBA8) return HPT_OK;                                // (a size query)
+  if (outCapacity < rgba.size()) return HPT_ERR_ARG;
+  std::memcpy(outRGBA8, rgba.data(), rgba.size());
   return HPT_OK;
 }
 

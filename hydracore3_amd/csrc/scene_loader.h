@@ -28,6 +28,7 @@
 #include "integrator_hip.h"
 #include "plastic_precompute.h"
 #include "film_precompute.h"
+#include "jpeg_decode.h"
 
 namespace hydra_hip {
 
@@ -340,7 +341,7 @@ inline double colLen(const M4& m, int c) { return std::sqrt(m.m[0][c] * m.m[0][c
 // CreateSphericalTextureFromIES, axially symmetric photometry, normalised to max 1 (integrator_pt_scene_lgt.cpp:171-186)
 // ---- LDR image files of LoadTextureAndMakeCombined (integrator_pt_scene_tex.cpp:24-33: .png / .ppm / .bmp through LiteImage::LoadImage<uint32_t>) ----
 // RGBA8 texels, r in the low byte, rows in FILE order (PNG / PPM: top row first; BMP: as stored, bottom row first unless its height is negative).
-// LiteImage is absent from the tree, so the row order it hands out is unpinned; .jpg / .exr need decoders this image does not carry.
+// LiteImage is absent from the tree, so the row order it hands out is unpinned; .jpg / .jpeg: jpeg_decode.h.
 inline uint32_t be32(const uint8_t* p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | uint32_t(p[3]); }
 inline bool decodePng(const std::vector<uint8_t>& f, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba, std::string& err)
 {
@@ -697,7 +698,8 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
     } else if (ti.path.find(".image") == std::string::npos) {                 // LDR files through LiteImage::LoadImage<uint32_t> (:24-33)
       uint32_t w = 0, h = 0; std::vector<uint8_t> rgba; std::string derr;
       const bool ok = endsWithNoCase(ti.path, ".png") ? decodePng(img, w, h, rgba, derr) : endsWithNoCase(ti.path, ".ppm") ? decodePpm(img, w, h, rgba, derr)
-                    : endsWithNoCase(ti.path, ".bmp") ? decodeBmp(img, w, h, rgba, derr) : (derr = "only .image4ub / .image4f / .exr / .png / .ppm / .bmp are read here (no JPEG decoder in this image)", false);
+                    : endsWithNoCase(ti.path, ".bmp") ? decodeBmp(img, w, h, rgba, derr) : (endsWithNoCase(ti.path, ".jpg") || endsWithNoCase(ti.path, ".jpeg")) ? jpeg::decode(img, w, h, rgba, derr)
+                    : (derr = "only .image4ub / .image4f / .exr / .png / .jpg / .ppm / .bmp are read here", false);
       if (!ok) { err = "texture file '" + ti.path + "': " + derr; return false; }
       t.width = w; t.height = h; t.format = 0u; t.flags = disableGamma ? 0u : 1u; t.bytes.swap(rgba);
     } else {

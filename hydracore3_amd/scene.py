@@ -992,9 +992,20 @@ def decode_exr(raw):
 
 def decode_ldr_image(path, raw):
     """.png / .ppm / .bmp -> uint32 [h, w] RGBA8 (r in the low byte), rows in file order - the same decoders as csrc/scene_loader.h
-    (8-bit non-interlaced PNG through zlib, binary PPM, uncompressed 24 / 32-bit BMP); no JPEG / EXR decoder in this image."""
+    (8-bit non-interlaced PNG through zlib, binary PPM, uncompressed 24 / 32-bit BMP); JPEG through the library's own reader."""
     import zlib
     low = path.lower()
+    if low.endswith(".jpg") or low.endswith(".jpeg"):                        # csrc/jpeg_decode.h, the one JPEG reader of both loaders
+        from .api import load_library
+        lib = load_library()
+        buf = np.frombuffer(raw, np.uint8)
+        w, h = C.c_uint32(0), C.c_uint32(0)
+        if lib.hpt_decode_jpeg(buf.ctypes.data, buf.size, C.byref(w), C.byref(h), None, 0) != 0:
+            raise NotImplementedError(f"{path}: only 8-bit baseline / progressive Huffman JPEG files (grey or YCbCr) are read")
+        out = np.zeros((h.value, w.value, 4), np.uint8)
+        if lib.hpt_decode_jpeg(buf.ctypes.data, buf.size, C.byref(w), C.byref(h), out.ctypes.data, out.size) != 0:
+            raise ValueError(f"{path}: JPEG decode failed")
+        return np.ascontiguousarray(out).view(np.uint32).reshape(h.value, w.value)
     if low.endswith(".png"):
         if raw[:8] != b"\x89PNG\r\n\x1a\n":
             raise ValueError(f"{path}: not a PNG file")

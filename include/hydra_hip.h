@@ -147,6 +147,10 @@ typedef struct hpt_film_params {
   const float* specValues; const uint32_t* specOffsetSz; const float* cieXYZ;
 } hpt_film_params;
 int  hpt_film_precompute(const hpt_film_params* params, float* outTable, uint64_t outCapacity, uint64_t* outCount, int* outPrecomputed);
+/* The JPEG reader of the fixture loaders (LoadTextureAndMakeCombined reads ".jpg" / ".jpeg" through LiteImage, integrator_pt_scene_tex.cpp:24-33):
+ * 8-bit baseline / progressive Huffman JPEG, grey or YCbCr, to RGBA8 rows in file order (csrc/jpeg_decode.h). outRGBA8 == NULL asks for the
+ * size. HPT_ERR_UNSUPPORTED for files outside that subset. Host code; no context. */
+int  hpt_decode_jpeg(const uint8_t* file, uint64_t fileSize, uint32_t* outWidth, uint32_t* outHeight, uint8_t* outRGBA8, uint64_t outCapacity);
 /* mi::fresnel_coat_precompute (mi_materials.cpp:377-451), what LoadPlasticMaterial (integrator_pt_scene_mat.cpp:675-757) stores for a
  * MAT_TYPE_PLASTIC: the 64-entry rough-transmittance table (appended to m_arrays1f, its offset in Material::datai[0]) and the two scalars
  * Material::data[PLASTIC_PRECOMP_REFLECTANCE = 3], data[PLASTIC_SPEC_SAMPLE_WEIGHT = 2]. Host code; no context, no device. RGB mode. */

@@ -383,7 +383,7 @@ def _read_blobs(path):
     return out
 
 
-@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures", "test_spectral", "test_spectral+spectral", "spectral_plastic+spectral", "spectral_glass+spectral", "spectral_sky+spectral", "exr_sky", "thin_film", "thin_film+spectral", "thin_film_rough", "thin_film_rough+spectral"])
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures", "jpg_textures", "test_spectral", "test_spectral+spectral", "spectral_plastic+spectral", "spectral_glass+spectral", "spectral_sky+spectral", "exr_sky", "thin_film", "thin_film+spectral", "thin_film_rough", "thin_film_rough+spectral"])
 def test_cpp_scene_loader_produces_the_same_tables(scene_name, tmp_path):
     """hydracore3_amd/csrc/scene_loader.h (Hydra XML + VSGF + image4ub + IES in C++) == the Python fixture loader:
     every table byte for byte, matrices and light frames to float rounding (both invert in double)."""
@@ -633,6 +633,42 @@ def test_ldr_image_files_decode_to_the_containers_texels(tmp_path):
     assert np.array_equal(decode_ldr_image("x.bmp", bmp), want)
     with pytest.raises(NotImplementedError):
         decode_ldr_image("x.jpg", b"")
+
+
+def test_jpeg_reader_returns_libjpegs_texels():
+    """.jpg / .jpeg textures (the same LiteImage branch): csrc/jpeg_decode.h against PIL's libjpeg, texel for texel - baseline and progressive,
+    4:4:4 / 4:2:2 / 4:2:0 chroma, greyscale, optimised Huffman tables, restart markers, sizes that are no multiple of the MCU - and the
+    jpg_textures fixture's two files through the scene loader."""
+    import io
+    PILImage = pytest.importorskip("PIL.Image")
+    from hydracore3_amd.scene import decode_ldr_image, load_hydra_xml
+    rng = np.random.RandomState(3)
+
+    def picture(w, h):
+        y, x = np.mgrid[0:h, 0:w]
+        a = np.stack([128 + 100 * np.sin(x / 7.0) * np.cos(y / 5.0), 128 + 90 * np.cos((x + y) / 9.0), 60 + (x * 3 + y * 2) % 190], -1) + rng.randint(-20, 20, (h, w, 3))
+        return np.clip(a, 0, 255).astype(np.uint8)
+
+    variants = (("4:4:4", dict(subsampling=0)), ("4:2:2", dict(subsampling=1)), ("4:2:0", dict(subsampling=2)), ("4:2:0 progressive", dict(subsampling=2, progressive=True)),
+                ("4:4:4 progressive", dict(subsampling=0, progressive=True)), ("grey", dict()), ("4:2:0 optimised", dict(subsampling=2, optimize=True)),
+                ("4:2:0 restart", dict(subsampling=2, restart_marker_rows=1)), ("4:2:2 restart blocks", dict(subsampling=1, restart_marker_blocks=3)))
+    for w, h in ((64, 48), (37, 29), (17, 9), (3, 5), (1, 1)):
+        for name, kw in variants:
+            pic = picture(w, h)
+            im = PILImage.fromarray(pic[..., 0] if name == "grey" else pic)
+            buf = io.BytesIO(); im.save(buf, "JPEG", quality=85, **kw)
+            ref = np.asarray(PILImage.open(io.BytesIO(buf.getvalue())).convert("RGB")).astype(np.uint32)
+            mine = decode_ldr_image("x.jpg", buf.getvalue())
+            assert mine.shape == (h, w) and np.all((mine >> 24) == 255)
+            assert np.array_equal(mine & 0xFFFFFF, ref[..., 0] | (ref[..., 1] << 8) | (ref[..., 2] << 16)), (w, h, name)
+    sc = load_hydra_xml(scene_path("jpg_textures"), 32, 32)
+    folder = os.path.join(os.path.dirname(scene_path("jpg_textures")), "data")
+    for t in sc.textures[1:]:
+        f = "texture1.jpg" if t.width == 256 else "texture0.jpeg"
+        ref = np.asarray(PILImage.open(os.path.join(folder, f)).convert("RGB")).astype(np.uint32)
+        assert np.array_equal(t.data & 0xFFFFFF, ref[..., 0] | (ref[..., 1] << 8) | (ref[..., 2] << 16))
+    with pytest.raises(NotImplementedError):
+        decode_ldr_image("x.jpg", b"not a jpeg")
 
 
 # ---- spectral rendering: tables and the oracle's restatement --------------------------------------------------------------------

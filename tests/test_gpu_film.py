@@ -116,3 +116,19 @@ def test_opaque_and_transparent_switch():
             m["data"][FILM_TRANSPARENT] = np.uint32(0).view(np.float32)
     gpu, cpu = _pair(sc)
     _compare("opaque films", gpu.render(8), cpu.render(8), 8, 0)
+
+
+def test_films_as_blend_leaves():
+    """A film under MAT_TYPE_BLEND: the descent draws its generator step, the film leaf samples (integrator_pt_mat.cpp:123-130, 197-249) and
+    MaterialEval's tree walk reaches filmRoughEval through the (id, weight) stack (:316-333, 422-470)."""
+    from hydracore3_amd import scene as S
+    sc = load_hydra_xml(scene_path("thin_film"), 64, 64, spectral=False)
+    _brighten(sc, 60.0)
+    ids = [i for i, m in enumerate(sc.materials) if int(m["mtype"]) == MAT_TYPE_THIN_FILM]
+    white = next(i for i, m in enumerate(sc.materials) if int(m["mtype"]) == S.MAT_TYPE_DIFFUSE)
+    for i in ids[:2]:                                                    # the two wall films become film / diffuse mixes
+        sc.materials.append(sc.materials[i].copy())
+        sc.materials[i] = S.material_blend(white, len(sc.materials) - 1, 0.6)
+    gpu, cpu = _pair(sc)
+    _compare("films under blends", gpu.render(16), cpu.render(16), 16, 8)
+    assert float(np.mean(np.all(gpu.random_gens() == cpu.random_gens(), axis=1))) > 0.995

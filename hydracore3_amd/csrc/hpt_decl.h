@@ -117,7 +117,7 @@ struct WfJob
 #define HPT_WFS_BOUNDS(DR, LEAN) __launch_bounds__(256, (DR) ? HPT_WF_SHADE_DR_WAVES : ((LEAN) ? HPT_WF_SHADE_WAVES : HPT_WF_SHADE_FULL_WAVES))
 
 __global__ void wfInitKernel(WfPool P, uint n, uint passNum);
-template <bool DR, bool LEAN, bool MOTION = false>
+template <bool DR, bool LEAN, bool MOTION = false, bool FILM = false>   // FILM: shadeVertex<FILM> (thin films, hpt_film.h)
 __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const WfPool P, const WfJob job);
 template <bool DEEP, bool FLAT, bool STATS, bool MOTION = false, bool WIDE = false>   // WIDE: walk DevScene::nodes4 (4-wide compressed nodes) instead of the BVH2
 __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScene S, const WfPool P, uint iter, uint refillBelow, uint grace,

@@ -1396,9 +1396,8 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   }
   { const int rcS = ensureShadeTris(c, st); if (rcS != HPT_OK) return rcS; }
   const bool motion = c->S.motion != 0;
-  const bool film = c->hasFilm;                                // MODE 4 / 5 / 6 kernels: static scenes, megakernel schedule
+  const bool film = c->hasFilm;                                // MODE 4 / 5 / 6 kernels, wfShadeKernel<.., FILM>
   if (film && !c->filmTablesRGB) return c->fail(HPT_ERR_ARG, "thin film: m_precomp_thin_films holds no RGB table for a film (LoadScene precomputes every film in RGB mode, sized by its thickness map)");
-  if (film && motion) return c->fail(HPT_ERR_UNSUPPORTED, "thin films in a scene with moving instances: no kernel variant holds both");
   if (film && c->instrument && !dr) return c->fail(HPT_ERR_UNSUPPORTED, "thin films: the instrumented probe has no film variant");
   const bool fullMaterials = film || motion || !dr && !(c->leanMaterials && !c->forceFull && c->S.lensCount == 0u && !naive && !inRays && !(c->instrument && !dr));   // MODE 0 / 1 / 2 / STATS kernels
   const int blocks = (int)std::min<size_t>((size_t)gridBlocks(c, dr, fullMaterials), ((size_t)job.tidCount + 255) / 256);
@@ -1410,7 +1409,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   job.drSkipNonFinite = c->drSkipNonFinite ? 1u : 0u;
   const bool stats = c->instrument && !dr;
   c->lastSchedule = 1;
-  if (!inRays && !film && useWavefront(c, naive, dr, stats && c->schedule != 2, job.tidCount)) { c->lastSchedule = 2; return launch_wavefront(c, job, st, dr); }
+  if (!inRays && useWavefront(c, naive, dr, stats && c->schedule != 2, job.tidCount)) { c->lastSchedule = 2; return launch_wavefront(c, job, st, dr); }
   if (stats) { HIPCHK(c, c->dCounters.alloc(1)); HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(Counters), st)); job.counters = c->dCounters.p; }
   if (dr) {
     job.recordLanes = (uint)blocks * 256u;
@@ -1421,7 +1420,10 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   job.stackOverflow = c->dStackOvf.p; job.gridLanes = (uint)blocks * 256u;
   HIPCHK(c, hipEventRecord(c->ev0, st));
   const bool deep = megaStackNeeded(c) > (uint)LDS_STACK;
-  if (motion) {
+  if (motion && film) {
+    if (inRays) launchPTMotion<6>(c->S, job, blocks, st, deep); else if (naive) launchPTMotion<5>(c->S, job, blocks, st, deep); else launchPTMotion<4>(c->S, job, blocks, st, deep);
+  }
+  else if (motion) {
     if (inRays) launchPTMotion<2>(c->S, job, blocks, st, deep); else if (naive) launchPTMotion<1>(c->S, job, blocks, st, deep); else launchPTMotion<0>(c->S, job, blocks, st, deep);
   }
   else if (dr) {
@@ -1579,6 +1581,7 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr)
       wj.itemBase = g.itemBase; wj.itemCount = g.itemCount; wj.iter = (uint)g.it; wj.record = g.rec.p;
       const dim3 sg((g.itemCount + 255u) / 256u);
       if (dr)                    wfShadeKernel<true, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
+      else if (c->hasFilm)       { if (c->S.motion) wfShadeKernel<false, false, true, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj); else wfShadeKernel<false, false, false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj); }
       else if (c->S.motion)      wfShadeKernel<false, false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
       else if (c->leanMaterials && !c->forceFull && c->S.lensCount == 0u) wfShadeKernel<false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
       else                       wfShadeKernel<false, false><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
@@ -1608,6 +1611,7 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr)
           // rays the last trace pass suspended are already counted in the same word. Work left = an incomplete frame: say so.
           wj.iter = (uint)g.it;
           if (dr)                    wfShadeKernel<true, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
+          else if (c->hasFilm)       { if (c->S.motion) wfShadeKernel<false, false, true, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj); else wfShadeKernel<false, false, false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj); }
           else if (c->S.motion)      wfShadeKernel<false, false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
           else if (c->leanMaterials && !c->forceFull && c->S.lensCount == 0u) wfShadeKernel<false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
           else                       wfShadeKernel<false, false><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);

@@ -226,7 +226,7 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
   template __global__ void pathTraceKernel<STATS, DR, MODE, true,  true,  false>(const DevScene, const Job); \
   template __global__ void pathTraceKernel<STATS, DR, MODE, false, false, false, true>(const DevScene, const Job);   /* the triangle sweep of tiny scenes */
 #ifndef HPT_INST_GROUP
-#error "compile hpt_kernels.hip with -DHPT_INST_GROUP=1..11"
+#error "compile hpt_kernels.hip with -DHPT_INST_GROUP=1..13"
 #endif
 #if HPT_INST_GROUP == 1      // gltf + emissive scenes (every benchmark workload)
 HPT_INST4(false, false, 3)
@@ -246,6 +246,20 @@ HPT_INST4(false, false, 4)
 HPT_INST4(false, false, 5)
 #elif HPT_INST_GROUP == 11
 HPT_INST4(false, false, 6)
+#elif HPT_INST_GROUP == 12   // thin films and moving instances
+template __global__ void pathTraceKernel<false, false, 4, false, false, true>(const DevScene, const Job);
+template __global__ void pathTraceKernel<false, false, 4, true,  false, true>(const DevScene, const Job);
+template __global__ void pathTraceKernel<false, false, 5, false, false, true>(const DevScene, const Job);
+template __global__ void pathTraceKernel<false, false, 5, true,  false, true>(const DevScene, const Job);
+template __global__ void pathTraceKernel<false, false, 6, false, false, true>(const DevScene, const Job);
+template __global__ void pathTraceKernel<false, false, 6, true,  false, true>(const DevScene, const Job);
+#elif HPT_INST_GROUP == 13   // thin films and moving instances, single-level layout
+template __global__ void pathTraceKernel<false, false, 4, false, true, true>(const DevScene, const Job);
+template __global__ void pathTraceKernel<false, false, 4, true,  true, true>(const DevScene, const Job);
+template __global__ void pathTraceKernel<false, false, 5, false, true, true>(const DevScene, const Job);
+template __global__ void pathTraceKernel<false, false, 5, true,  true, true>(const DevScene, const Job);
+template __global__ void pathTraceKernel<false, false, 6, false, true, true>(const DevScene, const Job);
+template __global__ void pathTraceKernel<false, false, 6, true,  true, true>(const DevScene, const Job);
 #elif HPT_INST_GROUP == 7    // moving instances
 template __global__ void pathTraceKernel<false, false, 0, false, false, true>(const DevScene, const Job);
 template __global__ void pathTraceKernel<false, false, 0, true,  false, true>(const DevScene, const Job);

@@ -57,7 +57,7 @@ HPT_DEV void blockAppend(uint* counter, bool qNear, bool qShad, uint& posNear, u
   posShad = base + cn + mbcnt64(ms);
 }
 
-template <bool DR, bool LEAN, bool MOTION>
+template <bool DR, bool LEAN, bool MOTION, bool FILM>
 __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const WfPool P, const WfJob job)
 {
   __shared__ uint drStage[DR ? 4 * DR_STAGE_DWORDS : 1];                   // the waves' staging areas of the cooperative gradient scatter (drReverseSweep)
@@ -108,7 +108,7 @@ __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const W
       V3 rA = v3(0, 0, 0), rS = v3(0, 0, 0), rdA = v3(0, 0, 0), rdS = v3(0, 0, 0); Taps taps; uint recTex = 0xFFFFFFFFu;   // adjoint record of this vertex (DR)
       for (int k = 0; k < 4; k++) { taps.off[k] = 0; taps.w[k] = 0.0f; }
       const V3 thrBefore = thr;
-      const bool didBounce = shadeVertex<DR, false, LEAN, MOTION>(S, DR ? job.data : nullptr, hit, rpos, rdir, accum, thr, misPdf, misIor, flags, bounce, gen,
+      const bool didBounce = shadeVertex<DR, false, LEAN, MOTION, FILM>(S, DR ? job.data : nullptr, hit, rpos, rdir, accum, thr, misPdf, misIor, flags, bounce, gen,
                                                     wantShadow, shPos, shDir, shFar, contrib, rA, rS, rdA, rdS, taps, recTex, tailR, pathTime);
       if (DR && didBounce) {
         if (!wantShadow) { rS = v3(0, 0, 0); rdS = v3(0, 0, 0); }           // (an occluded sample is cleared when its shadow ray comes back)
@@ -453,6 +453,8 @@ template __global__ void wfShadeKernel<true, true>(const DevScene, const WfPool,
 template __global__ void wfShadeKernel<false, true>(const DevScene, const WfPool, const WfJob);
 template __global__ void wfShadeKernel<false, false>(const DevScene, const WfPool, const WfJob);
 template __global__ void wfShadeKernel<false, false, true>(const DevScene, const WfPool, const WfJob);     // moving instances (every BSDF branch)
+template __global__ void wfShadeKernel<false, false, false, true>(const DevScene, const WfPool, const WfJob);   // thin films
+template __global__ void wfShadeKernel<false, false, true, true>(const DevScene, const WfPool, const WfJob);    // thin films and moving instances
 #endif
 #if HPT_WF_INST == 0 || HPT_WF_INST == 2
 #define HPT_WFT(DEEP, FLAT, STATS) template __global__ void wfTraceKernel<DEEP, FLAT, STATS>(const DevScene, const WfPool, uint, uint, uint, uint*, uint, Counters*);

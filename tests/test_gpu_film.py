@@ -132,3 +132,30 @@ def test_films_as_blend_leaves():
     gpu, cpu = _pair(sc)
     _compare("films under blends", gpu.render(16), cpu.render(16), 16, 8)
     assert float(np.mean(np.all(gpu.random_gens() == cpu.random_gens(), axis=1))) > 0.995
+
+
+def test_films_under_the_wavefront_schedule_and_with_a_moving_instance():
+    """wfShadeKernel<.., FILM> renders the frame the megakernel renders, bit for bit, in both layouts; the sphere given a second key matrix
+    (AddInstanceMotion) runs the FILM + MOTION variants of both schedules, against the oracle."""
+    from hydracore3_amd.api import HipIntegrator
+    from hydracore3_amd import scene as S
+    sc = load_hydra_xml(scene_path("thin_film_rough"), 80, 80, spectral=False)
+    _brighten(sc, 60.0)
+    for layout in (1, 2):
+        mega, wf = HipIntegrator(sc, accel_layout=layout), HipIntegrator(sc, accel_layout=layout)
+        mega.set_schedule(1); wf.set_schedule(2)
+        a, b = mega.render(8), wf.render(8)
+        assert mega.last_schedule()[0] == 1 and wf.last_schedule()[0] == 2
+        assert np.array_equal(a, b) and np.array_equal(mega.random_gens(), wf.random_gens())
+    sphere = max(range(len(sc.inst_geom)), key=lambda i: sc.geom_tri_count[sc.inst_geom[i]])
+    m1 = np.asarray(sc.inst_matrices[sphere], np.float64).reshape(4, 4)
+    sc.inst_motion = {sphere: S.translate(1.2, 0.4, 0.0) @ m1}
+    gpu, cpu = _pair(sc)
+    a, b = gpu.render(16), cpu.render(16)
+    _compare("film sphere in motion", a, b, 16, 30)
+    for layout in (1, 2):
+        w2 = HipIntegrator(sc, accel_layout=layout); w2.set_schedule(2)
+        assert np.array_equal(w2.render(16), a)
+    still = load_hydra_xml(scene_path("thin_film_rough"), 80, 80, spectral=False)
+    _brighten(still, 60.0)
+    assert _l2(HipIntegrator(still).render(16), a, 16) > 1e-2            # ... and the motion is in the frame

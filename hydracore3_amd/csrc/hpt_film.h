@@ -113,15 +113,20 @@ HPT_DEV float sampleFilmsSpectrum(const DevScene& S, const MaterialRec& m, float
   if (specId < 0xFFFFFFFFu) res = sampleUniformSpectrum1(S.specValues, S.specOffsetSz[2u * specId], wavelength);   // (the CPU reference samples the spectrum in RGB mode too)
   return res;
 }
-HPT_DEV FilmArgs filmArgs(const DevScene& S, const MaterialRec& m, V2 uv, float wave0)
+// the substrate's index: at the path's first wavelength, or at 525 nm in RGB mode (integrator_pt_mat.cpp:209-213)
+HPT_DEV Cx filmIntIOR(const DevScene& S, const MaterialRec& m, float wave0)
+{
+  const uint layers = __float_as_uint(m.data[FILM_LAYERS_COUNT]);
+  const float waveSample = wave0 > 0.0f ? wave0 : 525.f;
+  return cx(sampleFilmsSpectrum(S, m, waveSample, FILM_ETA_OFFSET, FILM_ETA_SPECID_OFFSET, layers - 1), sampleFilmsSpectrum(S, m, waveSample, FILM_K_OFFSET, FILM_K_SPECID_OFFSET, layers - 1));
+}
+HPT_DEV FilmArgs filmArgs(const DevScene& S, const MaterialRec& m, V2 uv, float wave0, Cx intIOR)
 {
   FilmArgs a;
-  const uint layers = __float_as_uint(m.data[FILM_LAYERS_COUNT]);
   a.spectral = wave0 > 0.0f;
   a.lambda = wave0;                                                 // wavelengths_spec[0]; the RGB triples of :208 / :436 are never read
-  const float waveSample = a.spectral ? wave0 : 525.f;
   a.extIOR = m.data[FILM_ETA_EXT];
-  a.intIOR = cx(sampleFilmsSpectrum(S, m, waveSample, FILM_ETA_OFFSET, FILM_ETA_SPECID_OFFSET, layers - 1), sampleFilmsSpectrum(S, m, waveSample, FILM_K_OFFSET, FILM_K_SPECID_OFFSET, layers - 1));
+  a.intIOR = intIOR;
   a.precomp = __float_as_uint(m.data[FILM_PRECOMP_FLAG]) > 0u;
   a.filmIOR = cx(1.0f, 0.0f);
   if (!a.precomp) a.filmIOR = cx(sampleFilmsSpectrum(S, m, wave0, FILM_ETA_OFFSET, FILM_ETA_SPECID_OFFSET, 0), sampleFilmsSpectrum(S, m, wave0, FILM_K_OFFSET, FILM_K_SPECID_OFFSET, 0));   // (only the Airy summation reads it)
@@ -133,6 +138,10 @@ HPT_DEV FilmArgs filmArgs(const DevScene& S, const MaterialRec& m, V2 uv, float 
   a.pre = S.precompThinFilms + (a.precomp ? __float_as_uint(m.data[FILM_PRECOMP_OFFSET]) : 0u);
   return a;
 }
+HPT_DEV FilmArgs filmArgs(const DevScene& S, const MaterialRec& m, V2 uv, float wave0) { return filmArgs(S, m, uv, wave0, filmIntIOR(S, m, wave0)); }
+// MaterialEval's film branch (integrator_pt_mat.cpp:422-470): rough films only, and filmRoughEval returns zero over a dielectric - decided from
+// the substrate's index alone, before the thickness map and the tables are touched
+HPT_DEV void filmEvalBranch(const DevScene& S, const MaterialRec& m, V2 uv, float wave0, V3 l, V3 v, V3 n, V3 alpha_tex, BsdfE& res);
 // reflectance / transmittance at an angle (cmat_film.h:41-143, 227-329, 461-535); spectral mode fills .x only
 HPT_DEV void filmReflTrans(const MaterialRec& m, const FilmArgs& a, float cosThetaI, bool reversed, bool wantT, V3& R, V3& T)
 {
@@ -179,7 +188,7 @@ HPT_DEV void filmSmoothSampleAndEval(const MaterialRec& m, const FilmArgs& a, fl
   const float cosThetaI = clampf(absf(wi.z), 0.0001f, 1.0f);
   const float ior = a.intIOR.re / a.extIOR;
   V3 R, T;
-  filmReflTrans(m, a, cosThetaI, reversed, true, R, T);
+  filmReflTrans(m, a, cosThetaI, reversed, !(a.intIOR.im > 0.001f || transparFlag == 0), R, T);    // (an opaque film never reads its transmittance)
   const float sR = sum3(R), sT = sum3(T);
   if (a.intIOR.im > 0.001f || transparFlag == 0) {
     const V3 wo = v3(-wi.x, -wi.y, wi.z);
@@ -210,9 +219,9 @@ HPT_DEV void filmRoughSampleAndEval(const MaterialRec& m, const FilmArgs& a, flo
   const V3 wm = trSample(wi, v2(rands.x, rands.y), alpha);
   const float cosThetaI = clampf(absf(dot(wi, wm)), 0.00001f, 1.0f);
   V3 R, T;
-  filmReflTrans(m, a, cosThetaI, reversed, true, R, T);
-  const float sR = sum3(R), sT = sum3(T);
   const bool opaque = a.intIOR.im > 0.001f || transparFlag == 0;
+  filmReflTrans(m, a, cosThetaI, reversed, !opaque, R, T);          // (an opaque film never reads its transmittance)
+  const float sR = sum3(R), sT = sum3(T);
   if (opaque || rands.w * (sR + sT) < sR) {
     V3 wo = reflect((-1.0f) * wi, wm);
     if (wi.z < 0.f || wo.z <= 0.f) return;
@@ -266,6 +275,14 @@ HPT_DEV void filmRoughEval(const MaterialRec& m, const FilmArgs& a, V3 l, V3 v, 
   const float cos_theta_i = smax(wi.z, HPT_EPSILON_32), cos_theta_o = smax(wo.z, HPT_EPSILON_32);
   res.pdf = trPDF(wi, wm, alpha) / (4.0f * absf(dot(wi, wm)));
   res.val = ((trD(wm, alpha) * microfacet_G(wi, wo, wm, alpha)) * R) / (4.0f * cos_theta_i * cos_theta_o);
+}
+HPT_DEV void filmEvalBranch(const DevScene& S, const MaterialRec& m, V2 uv, float wave0, V3 l, V3 v, V3 n, V3 alpha_tex, BsdfE& res)
+{
+  if (smax(m.data[FILM_ROUGH_V], m.data[FILM_ROUGH_U]) < 1e-3f) return;                              // trEffectivelySmooth
+  const Cx intIOR = filmIntIOR(S, m, wave0);
+  if (intIOR.im < 0.001f) return;
+  const FilmArgs fa = filmArgs(S, m, uv, wave0, intIOR);
+  filmRoughEval(m, fa, l, v, n, alpha_tex, res);
 }
 
 } // namespace hpt

@@ -208,7 +208,7 @@ HPT_DEV void blendTreeEval(const DevScene& S, uint rootId, V2 uv, V3 l, V3 v, V3
     else if (t == MAT_TYPE_DIFFUSE) { diffuseEval(m, ld3(m.colors[0]) * tex3, l, v, n, cv); res.val = res.val + cv.val * curW * bm; res.pdf += cv.pdf * curW; }
     else if (t == MAT_TYPE_PLASTIC) { plasticEval(m, ld3(m.colors[0]) * tex3, l, v, n, cv, S.arrays1f, m.datai[0]); res.val = res.val + cv.val * curW * bm; res.pdf += cv.pdf * curW; }
     else if (FILM && t == MAT_TYPE_THIN_FILM) {              // the geometric normal (integrator_pt_mat.cpp:464)
-      if (!(smax(m.data[1], m.data[0]) < 1e-3f)) { const FilmArgs fa = filmArgs(S, m, uv, 0.0f); filmRoughEval(m, fa, l, v, gn, tex3, cv); }
+      filmEvalBranch(S, m, uv, 0.0f, l, v, gn, tex3, cv);
       res.val = res.val + cv.val * curW * bm; res.pdf += cv.pdf * curW;
     }
     else if (t == MAT_TYPE_BLEND) {                          // BlendEval: first child next (no pop), second child waits on the stack
@@ -333,7 +333,7 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
           else if (!(DR || LEAN) && mtype == MAT_TYPE_DIFFUSE) diffuseEval(m, ld3(m.colors[0]) * tex3, shadowRayDir, vdir, evalNorm, bv);
           else if (!(DR || LEAN) && mtype == MAT_TYPE_PLASTIC) plasticEval(m, ld3(m.colors[0]) * tex3, shadowRayDir, vdir, evalNorm, bv, S.arrays1f, m.datai[0]);
           else if (FILM && mtype == MAT_TYPE_THIN_FILM) {                 // rough films only; the geometric normal (integrator_pt_mat.cpp:422-470)
-            if (!(smax(m.data[1], m.data[0]) < 1e-3f)) { const FilmArgs fa = filmArgs(S, m, uv, 0.0f); filmRoughEval(m, fa, shadowRayDir, vdir, hitNorm, tex3, bv); }
+            filmEvalBranch(S, m, uv, 0.0f, shadowRayDir, vdir, hitNorm, tex3, bv);
           }
           else if (!(DR || LEAN) && mtype == MAT_TYPE_BLEND) blendTreeEval<FILM>(S, matId, uv, shadowRayDir, vdir, hitNorm, hitTang, bv);
           if (!(DR || LEAN) && mtype != MAT_TYPE_BLEND) bv.val = bv.val * bumpMult;     // res.val += currVal.val * weight * bumpCosMult, weight 1

@@ -155,12 +155,9 @@ HPT_DEV SpecEval materialEvalSpec(const DevScene& S, const MaterialRec& m, V4 wa
       r.pdf = trPDF(wo, wm, alpha) / (4.0f * absf(dot(wo, wm)));
     }
   } else if (m.mtype == MAT_TYPE_THIN_FILM) {                               // integrator_pt_mat.cpp:422-470: rough films only, the first wavelength only
-    if (!(smax(m.data[1], m.data[0]) < 1e-3f)) {
-      const FilmArgs fa = filmArgs(S, m, uv, waves.x);
-      BsdfE e; e.val = v3(0, 0, 0); e.pdf = 0.0f; e.dval = v3(0, 0, 0);
-      filmRoughEval(m, fa, l, v, n, texColor3, e);
-      r.val = v4(e.val.x, 0.0f, 0.0f, 0.0f); r.pdf = e.pdf;
-    }
+    BsdfE e; e.val = v3(0, 0, 0); e.pdf = 0.0f; e.dval = v3(0, 0, 0);
+    filmEvalBranch(S, m, uv, waves.x, l, v, n, texColor3, e);
+    r.val = v4(e.val.x, 0.0f, 0.0f, 0.0f); r.pdf = e.pdf;
   }
   return r;
 }

@@ -367,4 +367,17 @@ def random_scene(seed: int, width=48, height=32) -> S.SceneData:
         lines = [(0, rad, 4.0, 1.6, ap), (1, -rad * 2.5, 2.0, 1.0, ap), (2, 0.0, 2.0, 0.0, float(r.uniform(4.0, 8.0))), (3, rad * 2.5, 4.0, 1.6, ap),
                  (4, -rad, float(r.uniform(38.0, 46.0)), 1.0, ap)]
         sc.set_optics(lines, 0.035, 0.001, "scene_to_sensor")
+    # ... and three scenes in ten have one or two of their spheres coated with a thin film (drawn last, see above): one to three films on a
+    # dielectric or conducting substrate, smooth or rough (isotropic, anisotropic or textured), transparent or not, plain or mapped thickness
+    if r.uniform() < 0.3:
+        cand = [i for i in range(2, 2 + nobj) if int(M[i]["mtype"]) not in (S.MAT_TYPE_BLEND, S.MAT_TYPE_LIGHT_SOURCE)]
+        for i in list(r.permutation(cand))[:int(r.randint(1, 3))]:
+            films = [{"eta": float(r.uniform(1.2, 2.6)), "k": float(r.choice([0.0, 0.0, r.uniform(0.0, 0.05)])), "thickness": float(r.uniform(50.0, 700.0))}
+                     for _ in range(int(r.choice([1, 1, 2, 3])))]
+            sub = {"eta": float(r.uniform(1.3, 1.8)), "k": 0.0} if r.uniform() < 0.5 else {"eta": float(r.uniform(0.15, 2.0)), "k": float(r.uniform(1.5, 4.0))}
+            kind = r.randint(4)
+            alpha = 0.0 if kind == 0 else (float(r.uniform(0.05, 0.4)) if kind == 1 else (float(r.uniform(0.05, 0.4)), float(r.uniform(0.05, 0.4))))
+            atex = (tex, (1, 0, 0, 0), (0, 1, 0, 0)) if kind == 3 else None
+            tmap = (float(r.uniform(40.0, 200.0)), float(r.uniform(300.0, 800.0)), tex, (2, 0, 0, 0), (0, 2, 0, 0)) if r.uniform() < 0.4 else None
+            M[int(i)] = sc.material_thin_film(films, sub, 0.5 if kind == 3 else alpha, float(r.choice([1.0, 1.00028])), int(r.randint(2)), tmap, atex)
     return sc

@@ -457,12 +457,11 @@ struct BsdfE { V3 val; float pdf; V3 dval; };
 HPT_DEV V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
 
 // include/cmat_gltf.h:6-90
-HPT_DEV void gltfSampleAndEval(const MaterialRec& m, V4 rands, V3 v, V3 n, V3 baseColor, V3 fourParams, BsdfS& r)
+// (Mcol, coatCol: the material's metal and coat colours - the spectral kernel runs the routine a second time on their fourth components)
+HPT_DEV void gltfSampleAndEvalC(const MaterialRec& m, const V3 Mcol, const V3 coatCol, V4 rands, V3 v, V3 n, V3 baseColor, V3 fourParams, BsdfS& r)
 {
   const uint cflags = m.cflags;
-  const V3 Mcol = ld3(m.colors[GLTF_COLOR_METAL]);
   const V3 metalCol = baseColor * Mcol;
-  const V3 coatCol = ld3(m.colors[GLTF_COLOR_COAT]);
   const float roughness = clampf(1.0f - m.data[GLTF_FLOAT_GLOSINESS] * fourParams.x, 0.0f, 1.0f);
   float metalness = m.data[GLTF_FLOAT_ALPHA] * fourParams.y;
   const float coatValue = m.data[GLTF_FLOAT_REFL_COAT] * fourParams.z;
@@ -526,14 +525,14 @@ HPT_DEV void gltfSampleAndEval(const MaterialRec& m, V4 rands, V3 v, V3 n, V3 ba
   }
   r.pdf *= pdfSelect;
 }
+HPT_DEV void gltfSampleAndEval(const MaterialRec& m, V4 rands, V3 v, V3 n, V3 baseColor, V3 fourParams, BsdfS& r)
+{ gltfSampleAndEvalC(m, ld3(m.colors[GLTF_COLOR_METAL]), ld3(m.colors[GLTF_COLOR_COAT]), rands, v, n, baseColor, fourParams, r); }
 
 // include/cmat_gltf.h:93-147
-HPT_DEV void gltfEval(const MaterialRec& m, V3 l, V3 v, V3 n, V3 baseColor, V3 fourParams, BsdfE& res)
+HPT_DEV void gltfEvalC(const MaterialRec& m, const V3 Mcol, const V3 coatCol, V3 l, V3 v, V3 n, V3 baseColor, V3 fourParams, BsdfE& res)
 {
   const uint cflags = m.cflags;
-  const V3 Mcol = ld3(m.colors[GLTF_COLOR_METAL]);
   const V3 metalCol = baseColor * Mcol;
-  const V3 coatCol = ld3(m.colors[GLTF_COLOR_COAT]);
   const float roughness = clampf(1.0f - m.data[GLTF_FLOAT_GLOSINESS] * fourParams.x, 0.0f, 1.0f);
   float metalness = m.data[GLTF_FLOAT_ALPHA] * fourParams.y;
   const float coatValue = m.data[GLTF_FLOAT_REFL_COAT] * fourParams.z;
@@ -568,6 +567,8 @@ HPT_DEV void gltfEval(const MaterialRec& m, V3 l, V3 v, V3 n, V3 baseColor, V3 f
   res.dval = dfc * (ggxVal * metalness) + v3s(lambertVal * (1.0f - metalness));
   res.pdf = metalness * ggxPdf + (1.0f - metalness) * dielectricPdf;
 }
+HPT_DEV void gltfEval(const MaterialRec& m, V3 l, V3 v, V3 n, V3 baseColor, V3 fourParams, BsdfE& res)
+{ gltfEvalC(m, ld3(m.colors[GLTF_COLOR_METAL]), ld3(m.colors[GLTF_COLOR_COAT]), l, v, n, baseColor, fourParams, res); }
 
 // include/cmat_diffuse.h:8-39
 HPT_DEV void diffuseSampleAndEval(const MaterialRec& m, V3 reflSpec, V4 rands, V3 v, V3 n, BsdfS& r)

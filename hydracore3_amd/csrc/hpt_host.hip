@@ -1119,7 +1119,7 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
       for (int k2 = 0; k2 < 4; k2++) if (d->specValues && !specIdOk(mm[i].spdid[k2])) return c->fail(HPT_ERR_ARG, "material " + std::to_string(i) + " refers to a spectrum that does not exist");
       if (!reached[i]) continue;
       const uint t = mm[i].mtype;
-      if (c->spectralOk && t != MAT_TYPE_DIFFUSE && t != MAT_TYPE_CONDUCTOR && t != MAT_TYPE_PLASTIC && t != MAT_TYPE_DIELECTRIC && t != MAT_TYPE_THIN_FILM && t != MAT_TYPE_LIGHT_SOURCE) { c->spectralOk = false; c->spectralWhyNot = "material " + std::to_string(i) + " (type " + std::to_string(t) + ") is not diffuse, conductor, plastic, dielectric, thin film or emissive"; }
+      if (c->spectralOk && t != MAT_TYPE_GLTF && t != MAT_TYPE_DIFFUSE && t != MAT_TYPE_CONDUCTOR && t != MAT_TYPE_PLASTIC && t != MAT_TYPE_DIELECTRIC && t != MAT_TYPE_THIN_FILM && t != MAT_TYPE_LIGHT_SOURCE) { c->spectralOk = false; c->spectralWhyNot = "material " + std::to_string(i) + " (type " + std::to_string(t) + ") is not gltf, diffuse, conductor, plastic, dielectric, thin film or emissive"; }
       if (c->spectralOk && t != MAT_TYPE_LIGHT_SOURCE && mm[i].texid[1] != 0xFFFFFFFFu) { c->spectralOk = false; c->spectralWhyNot = "normal maps are not in the spectral kernel"; }
     }
     const LightRec* ll2 = (const LightRec*)d->lights;

@@ -10,8 +10,8 @@
 //     or adds the first sample (channels == 1).
 // The tables (m_spec_values, m_spec_offset_sz, m_cie_xyz) come in through the C ABI with the other scene vectors: the host owns them.
 //
-// Scope of this kernel: the BSDFs of the reference's own spectral fixture (scenes/test_spectral/spectral_cornell_conductor.xml) -
-// diffuse (Lambert / Oren-Nayar) and plastic with a reflectance spectrum, smooth dielectrics with an IOR spectrum (dispersion), smooth and rough conductors with eta / k spectra, emissive surfaces and
+// Scope of this kernel: the BSDFs of the reference's own spectral fixture (scenes/test_spectral/spectral_cornell_conductor.xml) and of its legacy scenes -
+// gltf (the colour carried as four samples), thin films (hpt_film.h), diffuse (Lambert / Oren-Nayar) and plastic with a reflectance spectrum, smooth dielectrics with an IOR spectrum (dispersion), smooth and rough conductors with eta / k spectra, emissive surfaces and
 // every analytic light with an intensity spectrum - in a one-thread-per-pixel kernel with in-place path regeneration (no work queue). hpt_update_params refuses spectral mode for scenes with other materials or spectral textures
 // (lambda_ref_ids). With more than four channels the output is the reference's stack of wavelength layers.
 #include <hip/hip_runtime.h>
@@ -122,9 +122,24 @@ struct SpecEval { V4 val; float pdf; };
 struct SpecSample { V4 val; V3 dir; float pdf; uint flags; float ior; };
 
 // MaterialEval, spectral (integrator_pt_mat.cpp:405-420, 471-482 with cmat_conductor.h:103-137, cmat_diffuse.h:27-39)
-HPT_DEV SpecEval materialEvalSpec(const DevScene& S, const MaterialRec& m, V4 waves, V3 l, V3 v, V3 n, V3 texColor3, V2 uv)
+// the "four scalar parameters" of a gltf material (integrator_pt_mat.cpp:151-167; hpt_shade.h: leafTextures)
+HPT_DEV V3 fourParamsSpec(const DevScene& S, const MaterialRec& m, V2 uv) { V3 t3, four; leafTextures(S, m, uv, t3, four); return four; }
+HPT_DEV SpecEval materialEvalSpec(const DevScene& S, const MaterialRec& m, V4 waves, V3 l, V3 v, V3 n, V4 texColor, V2 uv)
 {
+  const V3 texColor3 = v3(texColor.x, texColor.y, texColor.z);
   SpecEval r; r.val = v4s(0.0f); r.pdf = 0.0f;
+  if (m.mtype == MAT_TYPE_GLTF) {
+    // gltfEval on float4 (integrator_pt_mat.cpp:385-394): the base colour times the texel is taken as four spectral samples as it is (the
+    // reference's loader warns about such colours); nothing but the colours depends on the channel, so the four wavelengths are two passes
+    // through the RGB routine - (x, y, z), then w in every slot
+    const V4 base = ld4(m.colors[GLTF_COLOR_BASE]) * texColor, mc = ld4(m.colors[GLTF_COLOR_METAL]), cc = ld4(m.colors[GLTF_COLOR_COAT]);
+    const V3 four = fourParamsSpec(S, m, uv);
+    BsdfE a, b; a.val = v3(0, 0, 0); a.pdf = 0.0f; a.dval = v3(0, 0, 0); b = a;
+    gltfEvalC(m, v3(mc.x, mc.y, mc.z), v3(cc.x, cc.y, cc.z), l, v, n, v3(base.x, base.y, base.z), four, a);
+    gltfEvalC(m, v3s(mc.w), v3s(cc.w), l, v, n, v3s(base.w), four, b);
+    r.val = v4(a.val.x, a.val.y, a.val.z, b.val.x); r.pdf = a.pdf;
+    return r;
+  }
   if (m.mtype == MAT_TYPE_DIFFUSE) {
     float lambertVal = HPT_INV_PI;
     if ((m.cflags & GLTF_COMPONENT_ORENNAYAR) != 0) lambertVal *= orennayarFunc(l, v, n, m.data[0]);
@@ -162,9 +177,20 @@ HPT_DEV SpecEval materialEvalSpec(const DevScene& S, const MaterialRec& m, V4 wa
   return r;
 }
 // MaterialSampleAndEval, spectral (integrator_pt_mat.cpp:184-196, 252-263 with cmat_conductor.h:7-100, cmat_diffuse.h:8-24)
-HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V4 waves, V4 rands, V3 v, V3 n, V3 texColor3, uint flags0, float prevIor, V2 uv)
+HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V4 waves, V4 rands, V3 v, V3 n, V4 texColor, uint flags0, float prevIor, V2 uv)
 {
+  const V3 texColor3 = v3(texColor.x, texColor.y, texColor.z);
   SpecSample r; r.val = v4s(0.0f); r.pdf = 1.0f; r.dir = v3(0, 1, 0); r.flags = flags0; r.ior = 1.0f;
+  if (m.mtype == MAT_TYPE_GLTF) {                                           // gltfSampleAndEval on float4 (integrator_pt_mat.cpp:170-176), as in materialEvalSpec
+    const V4 base = ld4(m.colors[GLTF_COLOR_BASE]) * texColor, mc = ld4(m.colors[GLTF_COLOR_METAL]), cc = ld4(m.colors[GLTF_COLOR_COAT]);
+    const V3 four = fourParamsSpec(S, m, uv);
+    BsdfS a; a.val = v3(0, 0, 0); a.dval = v3(0, 0, 0); a.pdf = 1.0f; a.dir = v3(0, 1, 0); a.flags = flags0; a.ior = 1.0f;
+    BsdfS b = a;
+    gltfSampleAndEvalC(m, v3(mc.x, mc.y, mc.z), v3(cc.x, cc.y, cc.z), rands, v, n, v3(base.x, base.y, base.z), four, a);
+    gltfSampleAndEvalC(m, v3s(mc.w), v3s(cc.w), rands, v, n, v3s(base.w), four, b);
+    r.val = v4(a.val.x, a.val.y, a.val.z, b.val.x); r.dir = a.dir; r.pdf = a.pdf; r.flags = a.flags;
+    return r;
+  }
   if (m.mtype == MAT_TYPE_DIFFUSE) {
     const V3 lambertDir = mapSampleToCosineDistribution(rands.x, rands.y, n, n, 1.0f);
     r.dir = lambertDir;
@@ -295,7 +321,6 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
           const V3 vdir = (-1.0f) * rdir;
           V4 texColor = v4(1, 1, 1, 1);
           if (mtype != MAT_TYPE_LIGHT_SOURCE) texColor = texSample(S.textures, m.texid[0], mulRows2x4(m.row0[0], m.row1[0], uv));
-          const V3 tex3 = v3(texColor.x, texColor.y, texColor.z);
 
           // -- kernel_SampleLightSource (integrator_pt.cpp:350-424) --
           V4 shade = v4s(0.0f);
@@ -313,7 +338,7 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
               const V3 shadowRayPos = hitPos + hitNorm * smax(maxcomp(hitPos), 1.0f) * 5e-6f;
               const bool inIllumArea = (dot(shadowRayDir, ls.norm) < 0.0f) || ls.isOmni || ls.hasIES;
               if (inIllumArea) {
-                const SpecEval bv = materialEvalSpec(S, m, waves, shadowRayDir, vdir, hitNorm, tex3, uv);
+                const SpecEval bv = materialEvalSpec(S, m, waves, shadowRayDir, vdir, hitNorm, texColor, uv);
                 const float cosThetaOut = smax(dot(shadowRayDir, hitNorm), 0.0f);
                 float lgtPdfW = (1.0f / float(nLights)) * lightEvalPDF(L, shadowRayPos, shadowRayDir, ls.pos, ls.norm, ls.pdf);
                 float misWeight = (S.integratorType == INTEGRATOR_MIS_PT) ? misWeightHeuristic(lgtPdfW, bv.pdf) : 1.0f;
@@ -353,7 +378,7 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
             wantShadow = false;
           } else {
             const V4 rands = rng_float4(gen);                                // GetRandomNumbersMats
-            const SpecSample ms = materialSampleSpec(S, m, waves, rands, vdir, hitNorm, tex3, (flags & 0xFF000000u) | matId, misIor, uv);
+            const SpecSample ms = materialSampleSpec(S, m, waves, rands, vdir, hitNorm, texColor, (flags & 0xFF000000u) | matId, misIor, uv);
             if (mtype == MAT_TYPE_DIELECTRIC || mtype == MAT_TYPE_THIN_FILM) misIor = ms.ior;
             const float invPdf = 1.0f / smax(ms.pdf, 1e-20f);
             const V4 bxdfVal = ms.val * invPdf;

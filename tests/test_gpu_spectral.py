@@ -220,8 +220,8 @@ def test_same_scene_in_rgb_mode_still_matches():
 def test_spectral_mode_refusals():
     """What the spectral kernel does not cover is refused by name (never rendered in RGB instead)."""
     from hydracore3_amd.api import HipIntegrator, HydraHipError
-    # a scene whose surfaces use the gltf BSDF
-    sc = load_hydra_xml(scene_path("test_035"), 32, 32)
+    # a scene with legacy glass and blends (gltf surfaces are in: test_gltf_scenes_in_spectral_mode)
+    sc = load_hydra_xml(scene_path("legacy_materials"), 32, 32)
     sc.spectral_mode = 1
     with pytest.raises(HydraHipError, match="spectral"):
         HipIntegrator(sc)
@@ -245,3 +245,20 @@ def test_spectral_mode_refusals():
     sc.lights[0]["specId"] = 1000
     with pytest.raises(HydraHipError, match="spectrum"):
         HipIntegrator(sc)
+
+
+@pytest.mark.parametrize("name", ["test_035", "test_228"])
+def test_gltf_scenes_in_spectral_mode(name):
+    """Legacy hydra_material / gltf surfaces under m_spectral_mode = 1 (integrator_pt_mat.cpp:170-176, 385-394): the base colour times the texel is
+    carried as four spectral samples as it is (GetColorFromNode warns, integrator_pt_scene_mat.cpp:133-136), lights without a spectrum keep
+    their colour - the reference's Cornell box and its IES scene through the spectral kernel, against the oracle."""
+    sc = load_hydra_xml(scene_path(name), 96, 96, spectral=True)
+    gpu, cpu = _pair(sc)
+    spp = 16
+    a, b = gpu.render(spp), cpu.render(spp)
+    assert np.isfinite(a).all() and a[..., :3].mean() > 0
+    l2 = _l2(a, b, spp)
+    same_rng = float(np.mean(np.all(gpu.random_gens() == cpu.random_gens(), axis=1)))
+    print(f"{name}: per-pixel L2 = {l2:.3e} (mean {b[..., :3].mean() / spp:.4f}), identical generators {same_rng * 100:.2f} %")
+    assert l2 < 1e-3 * max(float(b[..., :3].mean() / spp), 1.0)
+    assert same_rng > 0.99

@@ -1091,41 +1091,12 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
     }
     auto specIdOk = [&](uint id) { return id == 0xFFFFFFFFu || id < d->numSpectra; };
     const MaterialRec* mm = (const MaterialRec*)d->materials;
-    // the materials a hit can reach: m_matIdByPrimId through the remap list of every instance of the mesh (RemapMaterialId); an entry of
-    // the library nothing resolves to - the fixture's own material 0, remapped to the conductor on its only instance - does not take
-    // the scene out of scope
-    std::vector<char> reached(d->numMaterials, 0);
-    if (c->spectralOk) {
-      std::set<std::pair<uint, int>> seen;
-      for (uint inst = 0; inst < d->numInsts; inst++) {
-        const uint g = d->instGeomId[inst];
-        const int list = d->remapInst[2 * inst + 0];
-        if (g >= d->numGeoms || !seen.insert(std::make_pair(g, list)).second) continue;
-        int rOff = 0, rSize = 0;
-        if (list >= 0 && d->allRemapLists && (uint)list + 1 + d->allRemapListsSize < d->allRemapListsLen) {
-          rOff = d->allRemapLists[d->allRemapListsSize + list]; rSize = (d->allRemapLists[d->allRemapListsSize + list + 1] - rOff) / 2;
-        }
-        const uint t0 = d->matVertOffset[2 * g];
-        const uint t1 = std::min(d->geomTriCount ? t0 + d->geomTriCount[g] : (g + 1 < d->numGeoms ? d->matVertOffset[2 * (g + 1)] : d->numTris), d->numTris);
-        for (uint t = t0; t < t1; t++) {
-          uint id = d->matIdByPrimId[t];
-          for (int k2 = 0; k2 < rSize; k2++) if ((uint)d->allRemapLists[rOff + 2 * k2] == id) { id = (uint)d->allRemapLists[rOff + 2 * k2 + 1]; break; }
-          id &= 0x00FFFFFFu;
-          if (id < d->numMaterials) reached[id] = 1;
-        }
-      }
-    }
-    for (uint i = 0; i < d->numMaterials; i++) {
+    for (uint i = 0; i < d->numMaterials; i++)
       for (int k2 = 0; k2 < 4; k2++) if (d->specValues && !specIdOk(mm[i].spdid[k2])) return c->fail(HPT_ERR_ARG, "material " + std::to_string(i) + " refers to a spectrum that does not exist");
-      if (!reached[i]) continue;
-      const uint t = mm[i].mtype;
-      if (c->spectralOk && t != MAT_TYPE_GLTF && t != MAT_TYPE_DIFFUSE && t != MAT_TYPE_CONDUCTOR && t != MAT_TYPE_PLASTIC && t != MAT_TYPE_DIELECTRIC && t != MAT_TYPE_THIN_FILM && t != MAT_TYPE_LIGHT_SOURCE) { c->spectralOk = false; c->spectralWhyNot = "material " + std::to_string(i) + " (type " + std::to_string(t) + ") is not gltf, diffuse, conductor, plastic, dielectric, thin film or emissive"; }
-      if (c->spectralOk && t != MAT_TYPE_LIGHT_SOURCE && mm[i].texid[1] != 0xFFFFFFFFu) { c->spectralOk = false; c->spectralWhyNot = "normal maps are not in the spectral kernel"; }
-    }
+    // (every material type of the RGB kernels has its branch in the spectral kernel, blends and normal maps included)
     const LightRec* ll2 = (const LightRec*)d->lights;
     for (uint i = 0; i < d->numLights; i++) {
       if (d->specValues && !specIdOk(ll2[i].specId)) return c->fail(HPT_ERR_ARG, "light " + std::to_string(i) + " refers to a spectrum that does not exist");
-      if (c->spectralOk && ll2[i].geomType == LIGHT_GEOM_ENV) { c->spectralOk = false; c->spectralWhyNot = "sampled environment maps are not in the spectral kernel"; }
     }
     for (int k2 = 0; k2 < 3; k2++) if (d->camResponseSpectrumId[k2] >= (int)d->numSpectra) return c->fail(HPT_ERR_ARG, "m_camResponseSpectrumId refers to a spectrum that does not exist");
     std::vector<float> sv(d->specValues ? std::vector<float>(d->specValues, d->specValues + d->numSpecValues) : std::vector<float>());
@@ -1377,8 +1348,6 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   // full grid would let whichever waves ask first take all the work (a small multi-GPU share of a frame)
   if (c->S.spectralMode != 0u) {                               // four wavelengths per path: its own (plain) kernel
     if (dr || naive || inRays) return c->fail(HPT_ERR_UNSUPPORTED, "spectral rendering: PathTraceBlock only (not the naive, input-ray or differentiable integrators)");
-    if (c->S.motion) return c->fail(HPT_ERR_UNSUPPORTED, "spectral rendering: moving instances are not in the spectral kernel");
-    if (c->S.lensCount || c->S.envTexId != 0xFFFFFFFFu || c->S.envCamBackId != 0xFFFFFFFFu) return c->fail(HPT_ERR_UNSUPPORTED, "spectral rendering: lens simulation / environment maps are not in the spectral kernel");
     if (c->hasFilm && !c->filmTablesSpectral) return c->fail(HPT_ERR_ARG, "thin film: m_precomp_thin_films was precomputed for RGB rendering (LoadScene sizes the tables by m_spectral_mode)");
     const int sblocks = (int)(((size_t)job.tidCount + 255) / 256);
     job.gens = c->dGens.p; job.packedXY = c->dPackedXY.p; job.packedCount = c->packedCount;
@@ -1387,9 +1356,14 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
     const bool sdeep = megaStackNeeded(c) > (uint)LDS_STACK;
     c->lastSchedule = 1;
     HIPCHK(c, hipEventRecord(c->ev0, st));
-    if (c->S.sweep)          pathTraceSpectralKernel<false, false, true><<<dim3(sblocks), dim3(256), 0, st>>>(c->S, job);
-    else if (c->S.flatMode)  { if (sdeep) pathTraceSpectralKernel<true, true, false><<<dim3(sblocks), dim3(256), 0, st>>>(c->S, job); else pathTraceSpectralKernel<false, true, false><<<dim3(sblocks), dim3(256), 0, st>>>(c->S, job); }
-    else                     { if (sdeep) pathTraceSpectralKernel<true, false, false><<<dim3(sblocks), dim3(256), 0, st>>>(c->S, job); else pathTraceSpectralKernel<false, false, false><<<dim3(sblocks), dim3(256), 0, st>>>(c->S, job); }
+    const dim3 sg(sblocks), sb(256);
+    if (c->S.motion) {                                         // moving instances (never a sweep scene)
+      if (c->S.flatMode) { if (sdeep) pathTraceSpectralKernel<true, true, false, true><<<sg, sb, 0, st>>>(c->S, job); else pathTraceSpectralKernel<false, true, false, true><<<sg, sb, 0, st>>>(c->S, job); }
+      else               { if (sdeep) pathTraceSpectralKernel<true, false, false, true><<<sg, sb, 0, st>>>(c->S, job); else pathTraceSpectralKernel<false, false, false, true><<<sg, sb, 0, st>>>(c->S, job); }
+    }
+    else if (c->S.sweep)     pathTraceSpectralKernel<false, false, true><<<sg, sb, 0, st>>>(c->S, job);
+    else if (c->S.flatMode)  { if (sdeep) pathTraceSpectralKernel<true, true, false><<<sg, sb, 0, st>>>(c->S, job); else pathTraceSpectralKernel<false, true, false><<<sg, sb, 0, st>>>(c->S, job); }
+    else                     { if (sdeep) pathTraceSpectralKernel<true, false, false><<<sg, sb, 0, st>>>(c->S, job); else pathTraceSpectralKernel<false, false, false><<<sg, sb, 0, st>>>(c->S, job); }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, st));
     return HPT_OK;

@@ -10,10 +10,11 @@
 //     or adds the first sample (channels == 1).
 // The tables (m_spec_values, m_spec_offset_sz, m_cie_xyz) come in through the C ABI with the other scene vectors: the host owns them.
 //
-// Scope of this kernel: the BSDFs of the reference's own spectral fixture (scenes/test_spectral/spectral_cornell_conductor.xml) and of its legacy scenes -
-// gltf (the colour carried as four samples), thin films (hpt_film.h), diffuse (Lambert / Oren-Nayar) and plastic with a reflectance spectrum, smooth dielectrics with an IOR spectrum (dispersion), smooth and rough conductors with eta / k spectra, emissive surfaces and
-// every analytic light with an intensity spectrum - in a one-thread-per-pixel kernel with in-place path regeneration (no work queue). hpt_update_params refuses spectral mode for scenes with other materials or spectral textures
-// (lambda_ref_ids). With more than four channels the output is the reference's stack of wavelength layers.
+// Scope of this kernel: PathTraceBlock with everything the RGB kernels hold - every material type (gltf and the legacy glass carry their colours
+// as four samples as they are; thin films: hpt_film.h), blends, normal maps, every light type with an intensity spectrum, sampled environment
+// maps and back plates, a sky spectrum, moving instances, the lens stack - in a one-thread-per-pixel kernel with in-place path regeneration (no
+// work queue). hpt_update_params refuses spectral mode for scenes with spectral textures (lambda_ref_ids). With more than four channels the
+// output is the reference's stack of wavelength layers.
 #include <hip/hip_runtime.h>
 #include "hpt_decl.h"
 
@@ -78,7 +79,37 @@ HPT_DEV V4 lightIntensitySpec(const DevScene& S, const LightRec& L, V4 waves, V3
       lightColor = lightColor * texSample(S.textures, L.texId, v2(ndc.x * 0.5f + 0.5f, ndc.y * 0.5f + 0.5f));
     }
   }
+  else if (L.texId != 0xFFFFFFFFu)                                           // :163-170: the environment map seen along the shadow ray (all four components of the texel)
+    lightColor = lightColor * texSample(S.textures, L.texId, mulRows2x4(L.samplerRow0, L.samplerRow1, sphereMapTo2DTexCoord(a_rayDir)));
   return lightColor;
+}
+// kernel_HitEnvironment + EnvironmentColor (integrator_pt.cpp:550-595, integrator_pt_lgt.cpp:175-210) on four samples: the environment's
+// spectrum or m_envColor, times the map's texel, the MIS weight against the map's pdf table, the camera back plate (hpt_device.h: environmentRadiance)
+HPT_DEV V4 environmentRadianceSpec(const DevScene& S, V3 rdir, V4 waves, float misPdf, uint flags, uint XY)
+{
+  V4 color = ld4(S.envColor);
+  if (S.envSpecId != 0xFFFFFFFFu) color = sampleUniformSpectrum(S.specValues, S.specOffsetSz[2u * S.envSpecId], waves) * (S.envSpecMult / 106.856895f);
+  if (S.envTexId == 0xFFFFFFFFu && S.envCamBackId == 0xFFFFFFFFu) return color;
+  float envPdf = 1.0f;
+  if (S.envTexId != 0xFFFFFFFFu) {
+    const float sinTheta = sqrtf_(1.0f - rdir.y * rdir.y);
+    const V2 tcT = mulRows2x4(S.envSamRow0, S.envSamRow1, sphereMapTo2DTexCoord(rdir));
+    if (sinTheta != 0.f && S.envEnableSam != 0 && S.integratorType == INTEGRATOR_MIS_PT && S.envLightId != 0xFFFFFFFFu) {
+      const LightRec& L = S.lights[S.envLightId];
+      const float mapPdf = evalMap2DPdf(tcT, S.arrays1f + L.pdfTableOffset, (int)L.pdfTableSizeX, (int)L.pdfTableSizeY);
+      envPdf = (mapPdf * 1.0f) / (2.f * HPT_PI * HPT_PI * smax(absf(sinTheta), 1e-20f));
+    }
+    color = color * texSample(S.textures, S.envTexId, tcT);
+  }
+  const bool isSpec = misPdf < 0.0f, exitZero = (flags & RAY_FLAG_PRIME_RAY_MISS) != 0;
+  if (S.integratorType == INTEGRATOR_MIS_PT && S.envEnableSam != 0 && !isSpec && !exitZero)
+    color = color * misWeightHeuristic(misPdf, (1.0f / float(S.numLights)) * envPdf);
+  else if (S.integratorType == INTEGRATOR_SHADOW_PT && S.envEnableSam != 0) color = v4s(0.0f);
+  if (exitZero && S.envCamBackId != 0xFFFFFFFFu) {
+    const uint x = XY & 0x0000FFFFu, y = (XY & 0xFFFF0000u) >> 16;
+    color = texSample(S.textures, S.envCamBackId, v2((float(x) + 0.5f) / float(S.winWidth), (float(y) + 0.5f) / float(S.winHeight)));
+  }
+  return color;
 }
 
 // SpectrumToXYZ + XYZToRGB (spectrum.h:151-214); terminateWaves: the path met a dispersive surface (RAY_FLAG_WAVES_DIVERGED)
@@ -124,7 +155,8 @@ struct SpecSample { V4 val; V3 dir; float pdf; uint flags; float ior; };
 // MaterialEval, spectral (integrator_pt_mat.cpp:405-420, 471-482 with cmat_conductor.h:103-137, cmat_diffuse.h:27-39)
 // the "four scalar parameters" of a gltf material (integrator_pt_mat.cpp:151-167; hpt_shade.h: leafTextures)
 HPT_DEV V3 fourParamsSpec(const DevScene& S, const MaterialRec& m, V2 uv) { V3 t3, four; leafTextures(S, m, uv, t3, four); return four; }
-HPT_DEV SpecEval materialEvalSpec(const DevScene& S, const MaterialRec& m, V4 waves, V3 l, V3 v, V3 n, V4 texColor, V2 uv)
+// n: the shading normal (the leaf's normal map applied), gn: the geometric one (films)
+HPT_DEV SpecEval materialEvalSpec(const DevScene& S, const MaterialRec& m, V4 waves, V3 l, V3 v, V3 n, V3 gn, V4 texColor, V2 uv)
 {
   const V3 texColor3 = v3(texColor.x, texColor.y, texColor.z);
   SpecEval r; r.val = v4s(0.0f); r.pdf = 0.0f;
@@ -171,20 +203,63 @@ HPT_DEV SpecEval materialEvalSpec(const DevScene& S, const MaterialRec& m, V4 wa
     }
   } else if (m.mtype == MAT_TYPE_THIN_FILM) {                               // integrator_pt_mat.cpp:422-470: rough films only, the first wavelength only
     BsdfE e; e.val = v3(0, 0, 0); e.pdf = 0.0f; e.dval = v3(0, 0, 0);
-    filmEvalBranch(S, m, uv, waves.x, l, v, n, texColor3, e);
+    filmEvalBranch(S, m, uv, waves.x, l, v, gn, texColor3, e);
     r.val = v4(e.val.x, 0.0f, 0.0f, 0.0f); r.pdf = e.pdf;
   }
   return r;
 }
+// MaterialEval over a blend tree (integrator_pt_mat.cpp:316-333, 511-527; hpt_shade.h: blendTreeEval), spectral: a plain material is a tree of one
+// leaf. Each leaf fetches its own texel, bends the normal by its own map and scales by cos(shade) / cos(geom) (:341-355).
+HPT_DEV SpecEval materialEvalTreeSpec(const DevScene& S, uint rootId, V4 waves, V3 l, V3 v, V3 gn, V3 tan, V2 uv)
+{
+  SpecEval res; res.val = v4s(0.0f); res.pdf = 0.0f;
+  uint stackId[BLEND_STACK_SIZE]; float stackW[BLEND_STACK_SIZE];
+  uint curId = rootId; float curW = 1.0f;
+  stackId[0] = curId; stackW[0] = curW;
+  int top = 0; bool needPop = false;
+  do {
+    if (needPop) { top--; const int t = top > 0 ? top : 0; curId = stackId[t]; curW = stackW[t]; } else needPop = true;
+    const MaterialRec& m = S.materials[curId];
+    const V4 texColor = texSample(S.textures, m.texid[0], mulRows2x4(m.row0[0], m.row1[0], uv));
+    if (m.mtype == MAT_TYPE_BLEND) {                                        // BlendEval: first child next (no pop), second child waits on the stack
+      const float w = m.data[0] * texColor.x;
+      const uint id1 = m.datai[0], id2 = m.datai[1];
+      const float w1 = curW * (1.0f - w), w2 = curW * w;
+      curId = id1; curW = w1; needPop = false;
+      if (top + 1 <= (int)BLEND_STACK_SIZE) { stackId[top] = id2; stackW[top] = w2; top++; }
+      continue;
+    }
+    V3 n = gn; float bm = 1.0f;
+    if (m.texid[1] != 0xFFFFFFFFu) { n = bumpNormal(S, m, gn, tan, uv); bm = bumpCosMult(l, gn, n); }
+    const SpecEval cv = materialEvalSpec(S, m, waves, l, v, n, gn, texColor, uv);
+    res.val = res.val + cv.val * (curW * bm); res.pdf += cv.pdf * curW;
+  } while (top > 0);
+  return res;
+}
 // MaterialSampleAndEval, spectral (integrator_pt_mat.cpp:184-196, 252-263 with cmat_conductor.h:7-100, cmat_diffuse.h:8-24)
-HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V4 waves, V4 rands, V3 v, V3 n, V4 texColor, uint flags0, float prevIor, V2 uv)
+// n: the shading normal, gn: the geometric one (legacy glass and films sample about it); pdf0: what the blend descent left in the sample's pdf
+HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V4 waves, V4 rands, V3 v, V3 n, V3 gn, V4 texColor, uint flags0, float prevIor, V2 uv, float pdf0)
 {
   const V3 texColor3 = v3(texColor.x, texColor.y, texColor.z);
-  SpecSample r; r.val = v4s(0.0f); r.pdf = 1.0f; r.dir = v3(0, 1, 0); r.flags = flags0; r.ior = 1.0f;
+  SpecSample r; r.val = v4s(0.0f); r.pdf = pdf0; r.dir = v3(0, 1, 0); r.flags = flags0; r.ior = 1.0f;
+  if (m.mtype == MAT_TYPE_GLASS) {                                          // glassSampleAndEval on float4 (cmat_glass.h:236-277): the geometric normal (integrator_pt_mat.cpp:178-183)
+    const V4 colorReflect = ld4(m.colors[0]), colorTransp = ld4(m.colors[1]);
+    const float ior = m.data[2];
+    const V3 rayDir = (-1.0f) * v;
+    float relativeIor = ior / prevIor;
+    if ((r.flags & RAY_FLAG_HAS_INV_NORMAL) != 0) { if (prevIor == ior) relativeIor = 1.0f / ior; }
+    const float fresnel = fresnel2(v, gn, relativeIor);
+    V3 dir; r.ior = prevIor;
+    if (rands.w < fresnel) { dir = reflect2(rayDir, gn); r.val = colorReflect; r.flags |= RAY_EVENT_S; }
+    else { dir = refract2(rayDir, gn, relativeIor); r.val = colorTransp; r.ior = ior; r.flags |= (RAY_EVENT_S | RAY_EVENT_T); }
+    r.val = r.val / smax(absf(dot(dir, gn)), 1e-6f);
+    r.dir = dir; r.pdf = 1.0f;
+    return r;
+  }
   if (m.mtype == MAT_TYPE_GLTF) {                                           // gltfSampleAndEval on float4 (integrator_pt_mat.cpp:170-176), as in materialEvalSpec
     const V4 base = ld4(m.colors[GLTF_COLOR_BASE]) * texColor, mc = ld4(m.colors[GLTF_COLOR_METAL]), cc = ld4(m.colors[GLTF_COLOR_COAT]);
     const V3 four = fourParamsSpec(S, m, uv);
-    BsdfS a; a.val = v3(0, 0, 0); a.dval = v3(0, 0, 0); a.pdf = 1.0f; a.dir = v3(0, 1, 0); a.flags = flags0; a.ior = 1.0f;
+    BsdfS a; a.val = v3(0, 0, 0); a.dval = v3(0, 0, 0); a.pdf = pdf0; a.dir = v3(0, 1, 0); a.flags = flags0; a.ior = 1.0f;
     BsdfS b = a;
     gltfSampleAndEvalC(m, v3(mc.x, mc.y, mc.z), v3(cc.x, cc.y, cc.z), rands, v, n, v3(base.x, base.y, base.z), four, a);
     gltfSampleAndEvalC(m, v3s(mc.w), v3s(cc.w), rands, v, n, v3s(base.w), four, b);
@@ -202,12 +277,12 @@ HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V
     // dielectricSmoothSampleAndEval (cmat_dielectric.h:8-56): the IOR of the FIRST wavelength decides the direction; a surface whose IOR is a
     // spectrum marks the path (RAY_FLAG_WAVES_DIVERGED): only that wavelength reaches the image (integrator_pt_mat.cpp:277-287)
     const V4 etaSpec = matParamSpectrum(S, m, waves, 1, 0);                  // DIELECTRIC_ETA_INT
-    BsdfS a; a.val = v3(0, 0, 0); a.dval = v3(0, 0, 0); a.pdf = 1.0f; a.dir = v3(0, 1, 0); a.flags = flags0; a.ior = 1.0f;
+    BsdfS a; a.val = v3(0, 0, 0); a.dval = v3(0, 0, 0); a.pdf = pdf0; a.dir = v3(0, 1, 0); a.flags = flags0; a.ior = 1.0f;
     dielectricSmoothSampleAndEval(m, etaSpec.x, prevIor, rands, v, n, a);
     r.val = v4s(a.val.x); r.dir = a.dir; r.pdf = a.pdf; r.flags = a.flags | ((m.spdid[0] < 0xFFFFFFFFu) ? RAY_FLAG_WAVES_DIVERGED : 0u); r.ior = a.ior;
   } else if (m.mtype == MAT_TYPE_PLASTIC) {                                  // plasticSampleAndEval on float4 (cmat_plastic.h:7-99), as in materialEvalSpec
     const V4 refl = matColorSpectrum(S, m, waves, 0, 0);
-    BsdfS a; a.val = v3(0, 0, 0); a.dval = v3(0, 0, 0); a.pdf = 1.0f; a.dir = v3(0, 1, 0); a.flags = flags0; a.ior = 1.0f;
+    BsdfS a; a.val = v3(0, 0, 0); a.dval = v3(0, 0, 0); a.pdf = pdf0; a.dir = v3(0, 1, 0); a.flags = flags0; a.ior = 1.0f;
     BsdfS b = a;
     plasticSampleAndEval(m, v3(refl.x, refl.y, refl.z), rands, v, n, a, S.arrays1f, m.datai[0]);
     plasticSampleAndEval(m, v3(refl.w, refl.w, refl.w), rands, v, n, b, S.arrays1f, m.datai[0]);
@@ -242,16 +317,16 @@ HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V
     }
   } else if (m.mtype == MAT_TYPE_THIN_FILM) {                               // integrator_pt_mat.cpp:197-249
     const FilmArgs fa = filmArgs(S, m, uv, waves.x);
-    BsdfS a; a.val = v3(0, 0, 0); a.dval = v3(0, 0, 0); a.pdf = 1.0f; a.dir = v3(0, 1, 0); a.flags = flags0; a.ior = 1.0f;
-    if (smax(m.data[1], m.data[0]) < 1e-3f) filmSmoothSampleAndEval(m, fa, prevIor, rands, v, n, a);
-    else                                    filmRoughSampleAndEval(m, fa, prevIor, rands, v, n, texColor3, a);
+    BsdfS a; a.val = v3(0, 0, 0); a.dval = v3(0, 0, 0); a.pdf = pdf0; a.dir = v3(0, 1, 0); a.flags = flags0; a.ior = 1.0f;
+    if (smax(m.data[1], m.data[0]) < 1e-3f) filmSmoothSampleAndEval(m, fa, prevIor, rands, v, gn, a);
+    else                                    filmRoughSampleAndEval(m, fa, prevIor, rands, v, gn, texColor3, a);
     r.val = v4(a.val.x, 0.0f, 0.0f, 0.0f); r.dir = a.dir; r.pdf = a.pdf; r.flags = a.flags | RAY_FLAG_WAVES_DIVERGED; r.ior = a.ior;
   }
   return r;
 }
 
 // One thread per pixel of the call, its passes one after the other (the pixel's generator continues from pass to pass as in the RGB kernels).
-template <bool DEEP, bool FLAT, bool SWEEP>
+template <bool DEEP, bool FLAT, bool SWEEP, bool MOTION>
 __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene S, const Job job)
 {
   __shared__ uint stackMem[LDS_STACK * 256];
@@ -276,13 +351,15 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
   V3 rpos = v3(0, 0, 0), rdir = v3(0, 0, 1);
   V4 waves = v4s(0.0f), accum = v4s(0.0f), thr = v4s(1.0f);
   float misPdf = 1.0f, misIor = 1.0f;                                        // MisData: matSamplePdf, ior (the medium the ray travels in)
+  float pathTime = 0.0f;                                                     // motion blur: the path's time (MOTION variants only)
   uint flags = 0, bounce = 0, passesLeft = valid ? job.passNum : 0u;
   bool alive = false;
   while (true) {
     if (!alive && passesLeft != 0u) {
       passesLeft--;
       const V4 lens = rng_float4(gen);                                       // GetRandomNumbersLens, then GetRandomNumbersSpec (integrator_pt.cpp:114-118)
-      cameraRay<false>(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
+      cameraRay<true>(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
+      if (MOTION) pathTime = rng_float1(gen);                                // GetRandomNumbersTime, before the wavelength (integrator_pt.cpp:114-118)
       waves = sampleWavelengths(rng_float1(gen), LAMBDA_MIN, LAMBDA_MAX);
       accum = v4s(0.0f); thr = v4s(1.0f); misPdf = 1.0f; misIor = 1.0f; flags = 0; bounce = 0;
       alive = true;
@@ -290,7 +367,7 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
     if (!__any(alive)) break;
     if (S.traceDepth != 0u) {                                                // (depth 0: the path is its camera ray and ends below)
       HitRec hit; hit.inst = 0xFFFFFFFFu; hit.prim = 0; hit.t = 0; hit.u = hit.v = 0;
-      if (alive) traceAny<false, false, DEEP, FLAT, false, SWEEP>(S, rpos, rdir, 0.0f, HPT_FLT_MAX, hit, stk, st);
+      if (alive) traceAny<false, false, DEEP, FLAT, MOTION, SWEEP>(S, rpos, rdir, 0.0f, HPT_FLT_MAX, hit, stk, st, pathTime);
       bool wantShadow = false;
       V3 shPos = v3(0, 0, 0), shDir = v3(0, 0, 1); float shFar = 0.0f;
       V4 contrib = v4s(0.0f);
@@ -311,7 +388,13 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
           const V3 nrmO = v3(wA * nA.x + uvy * nB.x + uvx * nC.x, wA * nA.y + uvy * nB.y + uvx * nC.y, wA * nA.z + uvy * nB.z + uvx * nC.z);
           const V2 uv = v2(wA * nA.w + uvy * nB.w + uvx * nC.w, wA * tyA + uvy * tyB + uvx * tyC);
           const float* nm = S.normMat + 12 * instId;
-          V3 hitNorm = normalize(v3(nm[0] * nrmO.x + nm[1] * nrmO.y + nm[2] * nrmO.z, nm[4] * nrmO.x + nm[5] * nrmO.y + nm[6] * nrmO.z, nm[8] * nrmO.x + nm[9] * nrmO.y + nm[10] * nrmO.z));
+          V3 hitNorm = v3(nm[0] * nrmO.x + nm[1] * nrmO.y + nm[2] * nrmO.z, nm[4] * nrmO.x + nm[5] * nrmO.y + nm[6] * nrmO.z, nm[8] * nrmO.x + nm[9] * nrmO.y + nm[10] * nrmO.z);
+          if (MOTION && (S.motion & 2u) == 0u) {                             // integrator_pt.cpp:285-292, as in shadeVertex
+            const float* nm2 = S.normMat2 + 12 * instId;
+            const V3 n2 = v3(nm2[0] * hitNorm.x + nm2[1] * hitNorm.y + nm2[2] * hitNorm.z, nm2[4] * hitNorm.x + nm2[5] * hitNorm.y + nm2[6] * hitNorm.z, nm2[8] * hitNorm.x + nm2[9] * hitNorm.y + nm2[10] * hitNorm.z);
+            hitNorm = hitNorm + pathTime * (n2 - hitNorm);
+          }
+          hitNorm = normalize(hitNorm);
           const float flipNorm = dot(rdir, hitNorm) > 0.001f ? -1.0f : 1.0f;
           hitNorm = flipNorm * hitNorm;
           if (flipNorm < 0.0f) flags |= RAY_FLAG_HAS_INV_NORMAL; else flags &= ~RAY_FLAG_HAS_INV_NORMAL;
@@ -321,6 +404,8 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
           const V3 vdir = (-1.0f) * rdir;
           V4 texColor = v4(1, 1, 1, 1);
           if (mtype != MAT_TYPE_LIGHT_SOURCE) texColor = texSample(S.textures, m.texid[0], mulRows2x4(m.row0[0], m.row1[0], uv));
+          V3 hitTang = v3(0, 0, 0);                                          // only materials with a normal map (or a blend that may hold one) read it
+          if (mtype == MAT_TYPE_BLEND || (mtype != MAT_TYPE_LIGHT_SOURCE && m.texid[1] != 0xFFFFFFFFu)) hitTang = hitTangent(S, A, B, C, vertOffset, wA, uvx, uvy, nm, flipNorm, (MOTION && (S.motion & 2u) == 0u) ? S.normMat2 + 12 * instId : nullptr, pathTime);
 
           // -- kernel_SampleLightSource (integrator_pt.cpp:350-424) --
           V4 shade = v4s(0.0f);
@@ -331,14 +416,14 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
             const int lightId = min((int)floorf(rndId * float(nLights)), nLights - 1);
             if (lightId >= 0 && mtype != MAT_TYPE_LIGHT_SOURCE) {
               const LightRec& L = S.lights[lightId];
-              const LightSam ls = lightSampleRev(L, v3(r4.x, r4.y, r4.z), hitPos);
+              const LightSam ls = (L.geomType == LIGHT_GEOM_ENV) ? envLightSampleRev(S, L, v3(r4.x, r4.y, r4.z), hitPos) : lightSampleRev(L, v3(r4.x, r4.y, r4.z), hitPos);
               const V3 dlt = hitPos - ls.pos;
               const float hitDist = sqrtf_(dot(dlt, dlt));
               const V3 shadowRayDir = normalize(ls.pos - hitPos);
               const V3 shadowRayPos = hitPos + hitNorm * smax(maxcomp(hitPos), 1.0f) * 5e-6f;
               const bool inIllumArea = (dot(shadowRayDir, ls.norm) < 0.0f) || ls.isOmni || ls.hasIES;
               if (inIllumArea) {
-                const SpecEval bv = materialEvalSpec(S, m, waves, shadowRayDir, vdir, hitNorm, texColor, uv);
+                const SpecEval bv = materialEvalTreeSpec(S, matId, waves, shadowRayDir, vdir, hitNorm, hitTang, uv);
                 const float cosThetaOut = smax(dot(shadowRayDir, hitNorm), 0.0f);
                 float lgtPdfW = (1.0f / float(nLights)) * lightEvalPDF(L, shadowRayPos, shadowRayDir, ls.pos, ls.norm, ls.pdf);
                 float misWeight = (S.integratorType == INTEGRATOR_MIS_PT) ? misWeightHeuristic(lgtPdfW, bv.pdf) : 1.0f;
@@ -377,9 +462,29 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
             flags |= (RAY_FLAG_IS_DEAD | RAY_FLAG_HIT_LIGHT);
             wantShadow = false;
           } else {
+            // blend descent (BlendSampleAndEval, integrator_pt_mat.cpp:23-54, 123-130): one generator step per layer BEFORE the float4
+            const MaterialRec* lm = &m; uint lt = mtype; V4 ltexColor = texColor; float pdf0 = 1.0f;
+            if (mtype == MAT_TYPE_BLEND) {
+              while (lt == MAT_TYPE_BLEND) {
+                const V4 wd = texSample(S.textures, lm->texid[0], mulRows2x4(lm->row0[0], lm->row1[0], uv));
+                const float weight = lm->data[0] * wd.x;
+                const float select = rng_float1(gen);                        // GetRandomNumbersMatB (integrator_pt.cpp:37)
+                if (select < weight) { pdf0 *= weight; lm = &S.materials[lm->datai[1]]; }
+                else                 { pdf0 *= 1.0f - weight; lm = &S.materials[lm->datai[0]]; }
+                lt = lm->mtype;
+              }
+              ltexColor = texSample(S.textures, lm->texid[0], mulRows2x4(lm->row0[0], lm->row1[0], uv));
+            }
+            const MaterialRec& ml = *lm;
+            const bool leafBump = ml.texid[1] != 0xFFFFFFFFu;                // the leaf's normal map bends the shading normal (:131-139)
+            const V3 sNorm = leafBump ? bumpNormal(S, ml, hitNorm, hitTang, uv) : hitNorm;
             const V4 rands = rng_float4(gen);                                // GetRandomNumbersMats
-            const SpecSample ms = materialSampleSpec(S, m, waves, rands, vdir, hitNorm, texColor, (flags & 0xFF000000u) | matId, misIor, uv);
-            if (mtype == MAT_TYPE_DIELECTRIC || mtype == MAT_TYPE_THIN_FILM) misIor = ms.ior;
+            SpecSample ms = materialSampleSpec(S, ml, waves, rands, vdir, sNorm, hitNorm, ltexColor, (flags & 0xFF000000u) | matId, misIor, uv, pdf0);
+            if (lt == MAT_TYPE_DIELECTRIC || lt == MAT_TYPE_THIN_FILM || lt == MAT_TYPE_GLASS) misIor = ms.ior;
+            if (leafBump) {                                                  // the caller multiplies by the cosine to the geometric normal (:298-303)
+              const float c1 = absf(dot(ms.dir, hitNorm)), c2 = absf(dot(ms.dir, sNorm));
+              ms.val = ms.val * (c2 / smax(c1, 1e-10f));
+            }
             const float invPdf = 1.0f / smax(ms.pdf, 1e-20f);
             const V4 bxdfVal = ms.val * invPdf;
             const float cosTheta = absf(dot(ms.dir, hitNorm));
@@ -399,17 +504,15 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
       }
       if (wantShadow) {
         HitRec sh;
-        const bool occluded = traceAny<true, false, DEEP, FLAT, false, SWEEP>(S, shPos, shDir, 0.0f, shFar, sh, stk, st);
+        const bool occluded = traceAny<true, false, DEEP, FLAT, MOTION, SWEEP>(S, shPos, shDir, 0.0f, shFar, sh, stk, st, pathTime);
         if (!occluded) accum = accum + contrib;
       }
       bounce++;
     }
     if (alive && ((flags & RAY_FLAG_IS_DEAD) != 0 || bounce >= S.traceDepth)) {
       alive = false;
-      // kernel_HitEnvironment / EnvironmentColor without a map (integrator_pt_lgt.cpp:175-189): the constant colour, or the environment's spectrum
-      if ((flags & RAY_FLAG_OUT_OF_SCENE) != 0) {
-        V4 env = ld4(S.envColor);
-        if (S.envSpecId != 0xFFFFFFFFu) env = sampleUniformSpectrum(S.specValues, S.specOffsetSz[2u * S.envSpecId], waves) * (S.envSpecMult / 106.856895f);
+      if ((flags & RAY_FLAG_OUT_OF_SCENE) != 0) {                            // kernel_HitEnvironment
+        const V4 env = environmentRadianceSpec(S, rdir, waves, misPdf, flags, XY);
         if (S.integratorType == INTEGRATOR_STUPID_PT) accum = thr * env; else accum = accum + thr * env;
       }
       // kernel_ContributeToImage (integrator_pt.cpp:598-657), spectral
@@ -432,10 +535,14 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
   }
 }
 
-template __global__ void pathTraceSpectralKernel<false, false, false>(const DevScene, const Job);
-template __global__ void pathTraceSpectralKernel<true,  false, false>(const DevScene, const Job);
-template __global__ void pathTraceSpectralKernel<false, true,  false>(const DevScene, const Job);
-template __global__ void pathTraceSpectralKernel<true,  true,  false>(const DevScene, const Job);
-template __global__ void pathTraceSpectralKernel<false, false, true>(const DevScene, const Job);
+template __global__ void pathTraceSpectralKernel<false, false, false, false>(const DevScene, const Job);
+template __global__ void pathTraceSpectralKernel<true,  false, false, false>(const DevScene, const Job);
+template __global__ void pathTraceSpectralKernel<false, true,  false, false>(const DevScene, const Job);
+template __global__ void pathTraceSpectralKernel<true,  true,  false, false>(const DevScene, const Job);
+template __global__ void pathTraceSpectralKernel<false, false, true,  false>(const DevScene, const Job);
+template __global__ void pathTraceSpectralKernel<false, false, false, true>(const DevScene, const Job);    // moving instances
+template __global__ void pathTraceSpectralKernel<true,  false, false, true>(const DevScene, const Job);
+template __global__ void pathTraceSpectralKernel<false, true,  false, true>(const DevScene, const Job);
+template __global__ void pathTraceSpectralKernel<true,  true,  false, true>(const DevScene, const Job);
 
 } // namespace hpt

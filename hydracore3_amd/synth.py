@@ -255,13 +255,16 @@ def dr_scene(xml_path, width=512, height=512, tex_size=256, target=False) -> S.S
     return sc, tid
 
 
-def random_scene(seed: int, width=48, height=32) -> S.SceneData:
+def random_scene(seed: int, width=48, height=32, spectral=False) -> S.SceneData:
     """Seeded random small scene for fuzz parity: a floor + back wall, 3..7 transformed spheres with materials drawn from every
     constructor of the hot path with parameters that include the corners (metalness 0 / 1, glossiness 0 / 1, coat 0 / 1, smooth and
     rough conductors, Oren-Nayar, glass, plastic, blends, normal maps), an optional textured material, 1..3 lights of random types, random environment, random depth."""
     r = np.random.RandomState(seed)
     sc = S.SceneData()
     sc.width, sc.height = width, height
+    if spectral:                                                      # the same scene under m_spectral_mode = 1: colours carried as four samples, the loader's uniform spectrum
+        sc.spectral_mode = 1
+        sc.spec_offset_sz, sc.spec_values = [(0, 471)], np.ones(471, np.float32)
     sc.cam_pos = (float(r.uniform(-1, 1)), float(r.uniform(1.5, 3.0)), float(r.uniform(6.0, 8.0)))
     sc.cam_look_at, sc.cam_up = (0.0, 1.0, 0.0), (0.0, 1.0, 0.0)
     sc.fov, sc.trace_depth = float(r.uniform(35, 60)), int(r.choice([1, 3, 5, 6, 6]))

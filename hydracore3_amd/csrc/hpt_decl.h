@@ -53,7 +53,7 @@ template <bool STATS, bool DR, int MODE, bool DEEP, bool FLAT, bool MOTION = fal
 __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const Job job);
 
 // spectral rendering (hpt_spectral.hip): one thread per pixel, four wavelengths per path
-template <bool DEEP, bool FLAT, bool SWEEP, bool MOTION = false>
+template <bool DEEP, bool FLAT, bool SWEEP, bool MOTION, bool WIDE>   // WIDE: gltf / glass / blends / normal maps / environment maps / lens compiled in
 __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene S, const Job job);
 
 // ---- wavefront schedule (hpt_wavefront.hip) --------------------------------------------------------------------------------------------

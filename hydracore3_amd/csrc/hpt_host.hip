@@ -97,6 +97,7 @@ struct hpt_ctx
   std::vector<void*> texData; std::vector<TexRec> hTextures;
   DevBuf<float> dSpecValues; DevBuf<uint> dSpecOffsetSz; DevBuf<float4> dCieXYZ;   // spectral tables (m_spec_values, m_spec_offset_sz, m_cie_xyz)
   bool spectralOk = false; std::string spectralWhyNot;   // whether the uploaded scene is within the spectral kernel's scope
+  bool spectralWideMats = true;                          // a reachable material needs the WIDE instantiations of the spectral kernel (hpt_spectral.hip)
   // thin films (integrator_pt.h:587-590): the tables a film material indexes, and what the uploaded materials say about them
   DevBuf<float> dFilmsEtaK, dPrecompFilms; DevBuf<uint> dFilmsSpecId;
   std::vector<uint> hFilmsSpecId; size_t numFilmsEtaK = 0, numPrecompFilms = 0; uint numSpectraHost = 0;
@@ -1093,7 +1094,35 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
     const MaterialRec* mm = (const MaterialRec*)d->materials;
     for (uint i = 0; i < d->numMaterials; i++)
       for (int k2 = 0; k2 < 4; k2++) if (d->specValues && !specIdOk(mm[i].spdid[k2])) return c->fail(HPT_ERR_ARG, "material " + std::to_string(i) + " refers to a spectrum that does not exist");
-    // (every material type of the RGB kernels has its branch in the spectral kernel, blends and normal maps included)
+    // (every material type of the RGB kernels has its branch in the spectral kernel, blends and normal maps included.) Which instantiations a
+    // spectral call needs (hpt_spectral.hip: WIDE) is decided by the materials a hit can REACH: m_matIdByPrimId through the remap list of every
+    // instance of the mesh (RemapMaterialId), then through blends - an entry of the library nothing resolves to (the reference's spectral fixture
+    // keeps an unused legacy material 0) does not widen the kernel
+    {
+      std::vector<char> reached(d->numMaterials, 0);
+      std::set<std::pair<uint, int>> seen;
+      for (uint inst = 0; inst < d->numInsts; inst++) {
+        const uint g = d->instGeomId[inst];
+        const int list = d->remapInst[2 * inst + 0];
+        if (g >= d->numGeoms || !seen.insert(std::make_pair(g, list)).second) continue;
+        int rOff = 0, rSize = 0;
+        if (list >= 0 && d->allRemapLists && (uint)list + 1 + d->allRemapListsSize < d->allRemapListsLen) {
+          rOff = d->allRemapLists[d->allRemapListsSize + list]; rSize = (d->allRemapLists[d->allRemapListsSize + list + 1] - rOff) / 2;
+        }
+        const uint t0 = d->matVertOffset[2 * g];
+        const uint t1 = std::min(d->geomTriCount ? t0 + d->geomTriCount[g] : (g + 1 < d->numGeoms ? d->matVertOffset[2 * (g + 1)] : d->numTris), d->numTris);
+        for (uint t = t0; t < t1; t++) {
+          uint id = d->matIdByPrimId[t];
+          for (int k2 = 0; k2 < rSize; k2++) if ((uint)d->allRemapLists[rOff + 2 * k2] == id) { id = (uint)d->allRemapLists[rOff + 2 * k2 + 1]; break; }
+          id &= 0x00FFFFFFu;
+          if (id < d->numMaterials) reached[id] = 1;
+        }
+      }
+      c->spectralWideMats = false;
+      for (uint i = 0; i < d->numMaterials; i++)
+        if (reached[i] && (mm[i].mtype == MAT_TYPE_GLTF || mm[i].mtype == MAT_TYPE_GLASS || mm[i].mtype == MAT_TYPE_BLEND || (mm[i].mtype != MAT_TYPE_LIGHT_SOURCE && mm[i].texid[1] != 0xFFFFFFFFu)))
+          c->spectralWideMats = true;                          // (a reached blend is wide by itself, whatever its leaves are)
+    }
     const LightRec* ll2 = (const LightRec*)d->lights;
     for (uint i = 0; i < d->numLights; i++) {
       if (d->specValues && !specIdOk(ll2[i].specId)) return c->fail(HPT_ERR_ARG, "light " + std::to_string(i) + " refers to a spectrum that does not exist");
@@ -1181,6 +1210,7 @@ extern "C" int hpt_update_materials(hpt_ctx* c, size_t first, size_t count, cons
     film_scan(c);
   }
   if (!lean_materials((const MaterialRec*)mats, count)) c->leanMaterials = false;      // (an update can only widen the set of BSDFs in use)
+  for (size_t i = 0; i < count; i++) { const MaterialRec& m = ((const MaterialRec*)mats)[i]; if (m.mtype == MAT_TYPE_GLTF || m.mtype == MAT_TYPE_GLASS || m.mtype == MAT_TYPE_BLEND || (m.mtype != MAT_TYPE_LIGHT_SOURCE && m.texid[1] != 0xFFFFFFFFu)) c->spectralWideMats = true; }
   (void)hipSetDevice(c->device);
   HIPCHK(c, hipMemcpy(c->dMaterials.p + first, mats, count * sizeof(MaterialRec), hipMemcpyHostToDevice));
   return HPT_OK;
@@ -1292,6 +1322,19 @@ static void launchPT(const DevScene& S, const Job& job, int blocks, hipStream_t 
   }
 }
 
+template <bool WIDE>
+static void launchSpectral(const DevScene& S, const Job& job, int blocks, hipStream_t st, bool deep)
+{
+  const dim3 sg(blocks), sb(256);
+  if (S.motion) {                                              // moving instances (never a sweep scene)
+    if (S.flatMode) { if (deep) pathTraceSpectralKernel<true, true, false, true, WIDE><<<sg, sb, 0, st>>>(S, job); else pathTraceSpectralKernel<false, true, false, true, WIDE><<<sg, sb, 0, st>>>(S, job); }
+    else            { if (deep) pathTraceSpectralKernel<true, false, false, true, WIDE><<<sg, sb, 0, st>>>(S, job); else pathTraceSpectralKernel<false, false, false, true, WIDE><<<sg, sb, 0, st>>>(S, job); }
+  }
+  else if (S.sweep)     pathTraceSpectralKernel<false, false, true, false, WIDE><<<sg, sb, 0, st>>>(S, job);
+  else if (S.flatMode)  { if (deep) pathTraceSpectralKernel<true, true, false, false, WIDE><<<sg, sb, 0, st>>>(S, job); else pathTraceSpectralKernel<false, true, false, false, WIDE><<<sg, sb, 0, st>>>(S, job); }
+  else                  { if (deep) pathTraceSpectralKernel<true, false, false, false, WIDE><<<sg, sb, 0, st>>>(S, job); else pathTraceSpectralKernel<false, false, false, false, WIDE><<<sg, sb, 0, st>>>(S, job); }
+}
+
 // the MOTION variants: moving instances (two-level layout only), every BSDF branch
 template <int MODE>
 static void launchPTMotion(const DevScene& S, const Job& job, int blocks, hipStream_t st, bool deep)
@@ -1356,14 +1399,11 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
     const bool sdeep = megaStackNeeded(c) > (uint)LDS_STACK;
     c->lastSchedule = 1;
     HIPCHK(c, hipEventRecord(c->ev0, st));
-    const dim3 sg(sblocks), sb(256);
-    if (c->S.motion) {                                         // moving instances (never a sweep scene)
-      if (c->S.flatMode) { if (sdeep) pathTraceSpectralKernel<true, true, false, true><<<sg, sb, 0, st>>>(c->S, job); else pathTraceSpectralKernel<false, true, false, true><<<sg, sb, 0, st>>>(c->S, job); }
-      else               { if (sdeep) pathTraceSpectralKernel<true, false, false, true><<<sg, sb, 0, st>>>(c->S, job); else pathTraceSpectralKernel<false, false, false, true><<<sg, sb, 0, st>>>(c->S, job); }
-    }
-    else if (c->S.sweep)     pathTraceSpectralKernel<false, false, true><<<sg, sb, 0, st>>>(c->S, job);
-    else if (c->S.flatMode)  { if (sdeep) pathTraceSpectralKernel<true, true, false><<<sg, sb, 0, st>>>(c->S, job); else pathTraceSpectralKernel<false, true, false><<<sg, sb, 0, st>>>(c->S, job); }
-    else                     { if (sdeep) pathTraceSpectralKernel<true, false, false><<<sg, sb, 0, st>>>(c->S, job); else pathTraceSpectralKernel<false, false, false><<<sg, sb, 0, st>>>(c->S, job); }
+    // the wide instantiations when the scene holds what the narrow ones compile out (hpt_spectral.hip)
+    bool wide = c->S.lensCount != 0u || c->S.envTexId != 0xFFFFFFFFu || c->S.envCamBackId != 0xFFFFFFFFu;
+    for (const uint g : c->hLightGeom) wide = wide || g == LIGHT_GEOM_ENV;
+    wide = wide || c->spectralWideMats;
+    if (wide) launchSpectral<true>(c->S, job, sblocks, st, sdeep); else launchSpectral<false>(c->S, job, sblocks, st, sdeep);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, st));
     return HPT_OK;

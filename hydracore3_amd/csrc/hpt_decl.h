@@ -28,6 +28,7 @@ struct Job
   float* lossAccum;               // sum over samples of loss / passNum
   float* record;                  // per-lane, per-bounce adjoint records: [bounce][field][lane]
   uint   recordLanes;             // total lanes of the grid (stride of the record buffer)
+  uint   naive;                   // the spectral kernel only: NaivePathTrace (the RGB kernels have their own instantiations)
   uint   drSkipNonFinite;         // hpt_set_option("dr_skip_nonfinite"): samples whose radiance is not finite give neither loss, colour nor gradient
                                   // (0 = the reference's PixelLossPT, which adds them like any other)
   uint*  stackOverflow;           // HBM part of the traversal stacks: [depth - LDS_STACK][global lane]

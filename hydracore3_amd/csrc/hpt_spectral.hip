@@ -371,7 +371,9 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
       alive = true;
     }
     if (!__any(alive)) break;
-    if (S.traceDepth != 0u) {                                                // (depth 0: the path is its camera ray and ends below)
+    const bool naive = job.naive != 0u;                                      // NaivePathTrace (integrator_pt.cpp:681-717): no light sampling, one more bounce
+    const uint maxBounce = naive ? S.traceDepth + 1u : S.traceDepth;
+    if (maxBounce != 0u) {                                                   // (depth 0: the path is its camera ray and ends below)
       HitRec hit; hit.inst = 0xFFFFFFFFu; hit.prim = 0; hit.t = 0; hit.u = hit.v = 0;
       if (alive) traceAny<false, false, DEEP, FLAT, MOTION, SWEEP>(S, rpos, rdir, 0.0f, HPT_FLT_MAX, hit, stk, st, pathTime);
       bool wantShadow = false;
@@ -415,7 +417,7 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
 
           // -- kernel_SampleLightSource (integrator_pt.cpp:350-424) --
           V4 shade = v4s(0.0f);
-          {
+          if (!naive) {
             const float rndId = rng_float1(gen);
             const V4 r4 = rng_float4(gen);
             const int nLights = (int)S.numLights;
@@ -515,7 +517,7 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
       }
       bounce++;
     }
-    if (alive && ((flags & RAY_FLAG_IS_DEAD) != 0 || bounce >= S.traceDepth)) {
+    if (alive && ((flags & RAY_FLAG_IS_DEAD) != 0 || bounce >= maxBounce)) {
       alive = false;
       if ((flags & RAY_FLAG_OUT_OF_SCENE) != 0) {                            // kernel_HitEnvironment
         V4 env = ld4(S.envColor);

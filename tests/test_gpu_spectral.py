@@ -225,12 +225,13 @@ def test_spectral_mode_refusals():
     sc.spec_offset_sz = []
     with pytest.raises(HydraHipError, match="spectral"):
         HipIntegrator(sc)
-    # the other integrators
+    # the input-ray integrator
     sc = load_hydra_xml(SPECTRAL_XML, 32, 32, spectral=True)
     gpu = HipIntegrator(sc)
     img = np.zeros((32, 32, 4), np.float32)
+    rays = np.zeros((gpu.N, 4), np.float32); rays[:, 2] = -1.0
     with pytest.raises(HydraHipError, match="spectral"):
-        gpu.NaivePathTraceBlock(gpu.N, 4, img, 1)
+        gpu.PathTraceFromInputRaysBlock(gpu.N, 4, np.zeros((gpu.N, 4), np.float32), rays, img, 1)
     # more than four channels only in spectral mode
     rgb = HipIntegrator(load_hydra_xml(SPECTRAL_XML, 32, 32, spectral=False))
     with pytest.raises(HydraHipError, match="channels"):
@@ -322,3 +323,21 @@ def test_fuzzed_scenes_in_spectral_mode(seed):
     print(f"seed {seed}: depth {sc.trace_depth}, {len(sc.lights)} lights, L2 {l2:.2e} over the pixels with equal generators, pixels with a divergent path: {differ} of {gpu.N}")
     assert l2 < 1e-3 * max(float(b[..., :3].mean() / spp), 1.0)
     assert differ <= 2
+
+
+def test_naive_path_trace_in_spectral_mode():
+    """NaivePathTraceBlock under m_spectral_mode = 1 (integrator_pt.cpp:681-717 on four wavelengths): no light sampling, one more bounce; the
+    reference's fixture and the material fixture against the oracle, and the naive and MIS estimators converge to the same frame."""
+    from hydracore3_amd.scene import INTEGRATOR_STUPID_PT
+    for name, size in (("test_spectral", 64), ("typed_materials", 64)):
+        sc = load_hydra_xml(scene_path(name), size, size, spectral=True)
+        p = sc.params(integrator=INTEGRATOR_STUPID_PT)
+        from hydracore3_amd.api import HipIntegrator
+        from oracle.orc import OracleIntegrator
+        gpu, cpu = HipIntegrator(sc, p), OracleIntegrator(sc, p)
+        a, b = gpu.render(16, naive=True), cpu.render(16, naive=True)
+        l2 = _l2(a, b, 16)
+        same_rng = float(np.mean(np.all(gpu.random_gens() == cpu.random_gens(), axis=1)))
+        print(f"{name}, naive, spectral: per-pixel L2 = {l2:.3e} (mean {b[..., :3].mean() / 16:.4f}), identical generators {same_rng * 100:.2f} %")
+        assert np.isfinite(a).all() and a[..., :3].mean() > 0 and same_rng > 0.99
+        assert l2 < 1e-3 * max(float(b[..., :3].mean() / 16), 1.0)

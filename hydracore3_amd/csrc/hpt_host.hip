@@ -1390,7 +1390,8 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   // never more lanes than pixels: with fewer, the hardware's round-robin block placement spreads them evenly over the CUs, whereas a
   // full grid would let whichever waves ask first take all the work (a small multi-GPU share of a frame)
   if (c->S.spectralMode != 0u) {                               // four wavelengths per path: its own (plain) kernel
-    if (dr || inRays) return c->fail(HPT_ERR_UNSUPPORTED, "spectral rendering: PathTraceBlock and NaivePathTraceBlock only (not the input-ray or differentiable integrators)");
+    if (dr) return c->fail(HPT_ERR_UNSUPPORTED, "spectral rendering: not the differentiable integrator");
+    if (inRays && job.channels != 1u && job.channels != 4u) return c->fail(HPT_ERR_ARG, "PathTraceFromInputRays in spectral mode: 1 or 4 channels (kernel_CopyColorToOutput)");
     job.naive = naive ? 1u : 0u;
     if (c->hasFilm && !c->filmTablesSpectral) return c->fail(HPT_ERR_ARG, "thin film: m_precomp_thin_films was precomputed for RGB rendering (LoadScene sizes the tables by m_spectral_mode)");
     const int sblocks = (int)(((size_t)job.tidCount + 255) / 256);

@@ -345,12 +345,13 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
   if (valid) { tid = job.tidBegin + (k / job.tidChunk) * job.tidChunk * job.tidStride + (k % job.tidChunk); valid = tid < job.tidEnd; }
   Rng gen; gen.sx = gen.sy = 0;
   uint XY = 0, pixel = 0;
-  float pix[3] = { 0.0f, 0.0f, 0.0f };
+  float pix[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+  const bool inRays = job.inRayPos != nullptr;                               // PathTraceFromInputRays (integrator_pt.cpp:159-199, 659-676, 761-798): the caller's rays and wavelengths, raw samples out
   if (valid) {
-    XY = job.packedXY[tid]; gen = job.gens[tid];
-    pixel = ((XY & 0xFFFF0000u) >> 16) * (uint)S.winWidth + (XY & 0x0000FFFFu);
+    XY = inRays ? (tid < job.packedCount ? job.packedXY[tid] : 0u) : job.packedXY[tid]; gen = job.gens[tid];
+    pixel = inRays ? tid : ((XY & 0xFFFF0000u) >> 16) * (uint)S.winWidth + (XY & 0x0000FFFFu);
     if (job.channels == 1) pix[0] = job.outColor[pixel];
-    else if (job.channels <= 4) { const float* o = job.outColor + (size_t)pixel * job.channels; pix[0] = o[0]; pix[1] = o[1]; pix[2] = o[2]; }
+    else if (job.channels <= 4) { const float* o = job.outColor + (size_t)pixel * job.channels; pix[0] = o[0]; pix[1] = o[1]; pix[2] = o[2]; if (inRays && job.channels == 4) pix[3] = o[3]; }
   }
   // In-place regeneration, as in the RGB megakernel but without its work queue: a lane whose path has ended starts its pixel's next pass at
   // the top of the loop instead of waiting for the longest path of the wave, so every trip traces a ray for (nearly) all lanes.
@@ -363,10 +364,19 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
   while (true) {
     if (!alive && passesLeft != 0u) {
       passesLeft--;
-      const V4 lens = rng_float4(gen);                                       // GetRandomNumbersLens, then GetRandomNumbersSpec (integrator_pt.cpp:114-118)
-      cameraRay<WIDE>(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
-      if (MOTION) pathTime = rng_float1(gen);                                // GetRandomNumbersTime, before the wavelength (integrator_pt.cpp:114-118)
-      waves = sampleWavelengths(rng_float1(gen), LAMBDA_MIN, LAMBDA_MAX);
+      if (inRays) {                                                          // kernel_InitEyeRayFromInput: no generator step; every sample at the ray's own wavelength
+        const float4 ip = job.inRayPos[tid], id4 = job.inRayDir[tid];
+        const V3 org = v3(ip.x, ip.y, ip.z), dir = v3(id4.x, id4.y, id4.z);
+        const V3 p1 = mul4x3(S.worldViewInv, org), p2 = mul4x3(S.worldViewInv, org + 100.0f * dir);   // transform_ray3f (cglobals.h:254-263)
+        rpos = p1; rdir = normalize(p2 - p1);
+        if (MOTION) pathTime = id4.w;
+        waves = v4s(ip.w);
+      } else {
+        const V4 lens = rng_float4(gen);                                     // GetRandomNumbersLens, then GetRandomNumbersSpec (integrator_pt.cpp:114-118)
+        cameraRay<WIDE>(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
+        if (MOTION) pathTime = rng_float1(gen);                              // GetRandomNumbersTime, before the wavelength (integrator_pt.cpp:114-118)
+        waves = sampleWavelengths(rng_float1(gen), LAMBDA_MIN, LAMBDA_MAX);
+      }
       accum = v4s(0.0f); thr = v4s(1.0f); misPdf = 1.0f; misIor = 1.0f; flags = 0; bounce = 0;
       alive = true;
     }
@@ -525,8 +535,9 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
         else if (S.envSpecId != 0xFFFFFFFFu) env = sampleUniformSpectrum(S.specValues, S.specOffsetSz[2u * S.envSpecId], waves) * (S.envSpecMult / 106.856895f);
         if (S.integratorType == INTEGRATOR_STUPID_PT) accum = thr * env; else accum = accum + thr * env;
       }
-      // kernel_ContributeToImage (integrator_pt.cpp:598-657), spectral
-      if (job.channels == 1) pix[0] += accum.x * S.exposureMult;
+      // kernel_ContributeToImage (integrator_pt.cpp:598-657), spectral; input rays: kernel_CopyColorToOutput, the raw samples (:659-676)
+      if (inRays) { pix[0] += accum.x; pix[1] += accum.y; pix[2] += accum.z; pix[3] += accum.w; }
+      else if (job.channels == 1) pix[0] += accum.x * S.exposureMult;
       else if (job.channels > 4) {                                           // "always spectral rendering": one layer of W x H per wavelength bin
         const V4 color = accum * S.exposureMult;
         for (int i = 0; i < 4; i++) {
@@ -540,7 +551,7 @@ __global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene
   }
   if (valid) {
     if (job.channels == 1) job.outColor[pixel] = pix[0];
-    else if (job.channels <= 4) { float* o = job.outColor + (size_t)pixel * job.channels; o[0] = pix[0]; o[1] = pix[1]; o[2] = pix[2]; }
+    else if (job.channels <= 4) { float* o = job.outColor + (size_t)pixel * job.channels; o[0] = pix[0]; o[1] = pix[1]; o[2] = pix[2]; if (inRays && job.channels == 4) o[3] = pix[3]; }
     job.gens[tid] = gen;
   }
 }

@@ -882,6 +882,7 @@ struct Ctx
     s.rayPosAndNear = xyzw(rayPos, 0.0f);
     s.rayDirAndFar = xyzw(rayDir, FLT_MAX);
     s.time = sc.motion ? rayDirAndT[4 * tid + 3] : 0.0f;  // *time = rayDirData.time (:197)
+    s.wavelengths = p.spectralMode != 0 ? splat4(rayPosAndW[4 * tid + 3]) : mk4(0, 0, 0, 0);   // *wavelengths = float4(rayPosData.wave) (:181-193)
     s.gen = randomGens[tid];
     for (uint depth = 0; depth < p.traceDepth; depth++) {
       RayTrace2(depth, &s, nullptr);
@@ -893,6 +894,7 @@ struct Ctx
     HitEnvironment(tid, &s);
     if (channels == 1) out_color[tid] += s.accumColor.x;
     else { out_color[tid * channels + 0] += s.accumColor.x; out_color[tid * channels + 1] += s.accumColor.y; out_color[tid * channels + 2] += s.accumColor.z; }
+    if (channels == 4 && p.spectralMode != 0) out_color[tid * 4 + 3] += s.accumColor.w;   // kernel_CopyColorToOutput adds all four (:664-670): the fourth is a wavelength's sample here
     randomGens[tid] = s.gen;
   }
 

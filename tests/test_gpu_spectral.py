@@ -225,13 +225,12 @@ def test_spectral_mode_refusals():
     sc.spec_offset_sz = []
     with pytest.raises(HydraHipError, match="spectral"):
         HipIntegrator(sc)
-    # the input-ray integrator
+    # the input-ray integrator with three channels (kernel_CopyColorToOutput knows one and four)
     sc = load_hydra_xml(SPECTRAL_XML, 32, 32, spectral=True)
     gpu = HipIntegrator(sc)
-    img = np.zeros((32, 32, 4), np.float32)
     rays = np.zeros((gpu.N, 4), np.float32); rays[:, 2] = -1.0
     with pytest.raises(HydraHipError, match="spectral"):
-        gpu.PathTraceFromInputRaysBlock(gpu.N, 4, np.zeros((gpu.N, 4), np.float32), rays, img, 1)
+        gpu.PathTraceFromInputRaysBlock(gpu.N, 3, np.zeros((gpu.N, 4), np.float32), rays, np.zeros((gpu.N, 3), np.float32), 1)
     # more than four channels only in spectral mode
     rgb = HipIntegrator(load_hydra_xml(SPECTRAL_XML, 32, 32, spectral=False))
     with pytest.raises(HydraHipError, match="channels"):
@@ -341,3 +340,30 @@ def test_naive_path_trace_in_spectral_mode():
         print(f"{name}, naive, spectral: per-pixel L2 = {l2:.3e} (mean {b[..., :3].mean() / 16:.4f}), identical generators {same_rng * 100:.2f} %")
         assert np.isfinite(a).all() and a[..., :3].mean() > 0 and same_rng > 0.99
         assert l2 < 1e-3 * max(float(b[..., :3].mean() / 16), 1.0)
+
+
+def test_input_rays_in_spectral_mode():
+    """PathTraceFromInputRaysBlock under m_spectral_mode = 1 (integrator_pt.cpp:159-199, 659-676): the cam plugin's rays carry their wavelength
+    (RayPosAndW::wave), all four samples of a path sit at it, and kernel_CopyColorToOutput adds the four raw samples - no generator step for the
+    lens, the time or the wavelength."""
+    from hydracore3_amd.api import HipIntegrator
+    from oracle.orc import OracleIntegrator
+    for name in ("test_spectral", "typed_materials"):
+        sc = load_hydra_xml(scene_path(name), 64, 64, spectral=True)
+        gpu, cpu = HipIntegrator(sc), OracleIntegrator(sc)
+        n = 4096
+        rng = np.random.default_rng(5)
+        pos = np.zeros((n, 4), np.float32); dr = np.zeros((n, 4), np.float32)
+        pos[:, :2] = rng.uniform(-0.05, 0.05, (n, 2)); pos[:, 3] = rng.uniform(380.0, 780.0, n)
+        d = np.stack([rng.uniform(-0.3, 0.3, n), rng.uniform(-0.3, 0.3, n), -np.ones(n)], 1)
+        dr[:, :3] = d / np.linalg.norm(d, axis=1, keepdims=True)
+        for channels in (4, 1):
+            gpu.InitRandomGens(gpu.N); cpu.set_random_gens(gpu.random_gens())
+            og, oc = np.full((n, channels), 0.25, np.float32), np.full((n, channels), 0.25, np.float32)
+            gpu.PathTraceFromInputRaysBlock(n, channels, pos, dr, og, 6)
+            cpu.path_trace_from_input_rays_block(pos, dr, oc, 6, channels)
+            dlt = (og.astype(np.float64) - oc) / 6
+            l2 = float(np.sqrt(np.mean(np.sum(dlt * dlt, -1))))
+            print(f"{name}, input rays, {channels} channels: per-ray L2 = {l2:.3e} (mean {oc.mean() - 0.25:.4f})")
+            assert np.isfinite(og).all() and l2 < 1e-3 * max(float(np.abs(oc).mean()), 1.0) and float(np.mean(og[:, 0] - 0.25)) > 0.0
+            assert np.mean(np.all(gpu.random_gens()[:n] == cpu.random_gens()[:n], axis=1)) > 0.995

@@ -355,7 +355,7 @@ def test_path_trace_from_input_rays_block_matches_oracle(cornell):
         assert np.array_equal(gpu.random_gens(), cpu.random_gens())
 
 
-@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures", "jpg_textures", "test_spectral", "test_spectral+spectral", "spectral_plastic+spectral", "spectral_glass+spectral", "spectral_sky+spectral", "exr_sky"])
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures", "jpg_textures", "test_spectral", "test_spectral+spectral", "spectral_plastic+spectral", "spectral_glass+spectral", "spectral_sky+spectral", "exr_sky", "thin_film", "thin_film+spectral", "thin_film_rough", "legacy_materials+spectral"])
 def test_cpp_scene_ingestion_renders_like_the_python_path(scene_name, tmp_path):
     """hydra_hip_render: scene_loader.h (C++) -> C ABI -> frame, no Python in the loop; the frame equals the one rendered from the
     Python loader's tables (same tables up to float rounding of inverted matrices: the image bar applies)."""
@@ -1222,12 +1222,14 @@ def test_wavefront_round_cap_reports_an_incomplete_frame():
 
 
 # ---- the C++ adapter with everything the ctypes path can do -----------------------------------------------------------------------------------
-@pytest.mark.parametrize("xml", [scene_path("env_map"), MOTION_XML, scene_path("typed_materials"), scene_path("test_spectral") + "+spectral"])
+@pytest.mark.parametrize("xml", [scene_path("env_map"), MOTION_XML, scene_path("typed_materials"), scene_path("test_spectral") + "+spectral", scene_path("thin_film"), scene_path("thin_film_rough") + "+spectral",
+                                 scene_path("typed_materials") + "+spectral"])
 def test_cpp_adapter_renders_whole_scenes_like_the_ctypes_path(xml, tmp_path):
     """tests/cpp/adapter_demo.cpp in scene mode: IntegratorHIP / BVH2SceneHIP only (AddGeom / AddInstance / AddInstanceMotion, the
     Integrator-named vectors incl. m_arrays1f and m_normMatrices2Offs, CommitDeviceData, UpdateMembersPlainData, PackXYBlock, PathTraceBlock)
-    on the sampled environment map (pdf table in m_arrays1f), the reference's moving-instance fixture, the plastic / blend scene and the
-    spectral fixture (m_spec_values, m_spec_offset_sz, m_cie_xyz, m_spectral_mode = 1); the frame equals the one the ctypes front end renders
+    on the sampled environment map (pdf table in m_arrays1f), the reference's moving-instance fixture, the plastic / blend scene, the
+    spectral fixture (m_spec_values, m_spec_offset_sz, m_cie_xyz, m_spectral_mode = 1) and the film fixtures (m_films_* vectors,
+    m_precomp_thin_films); the frame equals the one the ctypes front end renders
     from the same file."""
     import subprocess
     from conftest import ROOT

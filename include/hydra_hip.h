@@ -102,8 +102,9 @@ typedef struct hpt_params {
   uint32_t integratorType;    /* m_intergatorType: 0 naive, 1 shadow, 2 MIS (integrator_pt.h:330-332) */
   uint32_t renderLayer;       /* m_renderLayer: FB_COLOR / FB_DIRECT / FB_INDIRECT (integrator_pt.h:406-408) */
   uint32_t tileSize;          /* m_tileSize */
-  uint32_t spectralMode;      /* m_spectral_mode: 0 = RGB; 1 = four wavelengths per path (needs hpt_scene_desc's spectral tables; scenes of diffuse, conductor
-                               * and emissive materials, <= 4 output channels - anything else is refused with HPT_ERR_UNSUPPORTED) */
+  uint32_t spectralMode;      /* m_spectral_mode: 0 = RGB; 1 = four wavelengths per path (needs hpt_scene_desc's spectral tables; PathTraceBlock, NaivePathTraceBlock and
+                               * PathTraceFromInputRaysBlock, every material / light / camera feature of the RGB path; channels: 1, 3 - 4, or more = wavelength layers;
+                               * spectra given by textures and PathTraceDR are refused with HPT_ERR_UNSUPPORTED) */
   uint32_t envSpecIdPlus1;    /* m_envSpecId + 1 (integrator_pt.h:524; 0 = none, so that a zeroed struct means "no environment spectrum") */
   float    exposureMult, camLensRadius, camTargetDist, envSpecMult;   /* envSpecMult: m_envSpecMult (spectral mode: the environment spectrum's multiplier) */
   float    camRespoceRGB[4];  /* m_camRespoceRGB */

@@ -99,7 +99,7 @@ struct hpt_ctx
   bool spectralOk = false; std::string spectralWhyNot;   // whether the uploaded scene is within the spectral kernel's scope
   bool spectralWideMats = true;                          // a reachable material needs the WIDE instantiations of the spectral kernel (hpt_spectral.hip)
   // thin films (integrator_pt.h:587-590): the tables a film material indexes, and what the uploaded materials say about them
-  DevBuf<float> dFilmsEtaK, dPrecompFilms; DevBuf<uint> dFilmsSpecId;
+  DevBuf<float> dFilmsEtaK, dPrecompFilms; DevBuf<uint> dFilmsSpecId, dSpecTexIdsWavelengths, dSpecTexOffsetSz;
   std::vector<uint> hFilmsSpecId; size_t numFilmsEtaK = 0, numPrecompFilms = 0; uint numSpectraHost = 0;
   bool hasFilm = false, filmTablesRGB = true, filmTablesSpectral = true;   // a MAT_TYPE_THIN_FILM is in the table; its precomputed tables have the size RGB / spectral rendering reads
   DevBuf<float> dArrays1f; size_t numArrays1f = 0;       // m_arrays1f (pdf table of a sampled environment map)
@@ -211,7 +211,7 @@ extern "C" void hpt_destroy(hpt_ctx* c)
   (void)hpt_comm_destroy(c);
   c->dNodes.release(); c->dTris.release(); c->dInsts.release(); c->dSweepInsts.release(); c->dSweepTris.release(); c->dLevelNodes.release(); c->dShadeTris.release(); c->dNodes4.release(); c->dNodes4Src.release(); c->dTriBox.release(); c->dNodeBounds.release(); c->dInstO2W.release(); c->dTriIndices.release(); c->dMatIdByPrim.release();
   c->dMatVertOffset.release(); c->dPackedXY.release(); c->dVData.release(); c->dNormMat.release(); c->dRemapInst.release();
-  c->dRemapLists.release(); c->dMaterials.release(); c->dLights.release(); c->dTextures.release(); c->dArrays1f.release(); c->dSpecValues.release(); c->dSpecOffsetSz.release(); c->dCieXYZ.release(); c->dFilmsEtaK.release(); c->dPrecompFilms.release(); c->dFilmsSpecId.release(); c->dGens.release();
+  c->dRemapLists.release(); c->dMaterials.release(); c->dLights.release(); c->dTextures.release(); c->dArrays1f.release(); c->dSpecValues.release(); c->dSpecOffsetSz.release(); c->dCieXYZ.release(); c->dFilmsEtaK.release(); c->dPrecompFilms.release(); c->dFilmsSpecId.release(); c->dSpecTexIdsWavelengths.release(); c->dSpecTexOffsetSz.release(); c->dGens.release();
   c->dQueue.release(); c->dStackOvf.release(); c->dCounters.release(); c->dFrame.release(); c->dRecord.release(); c->dRef.release(); c->dData.release();
   c->dGrad.release(); c->dLoss.release(); c->dLossAcc.release();
   for (hpt_ctx::WfGroup* g : c->wfGroups) {
@@ -1087,8 +1087,30 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
     std::vector<uint> so(2 * std::max(1u, d->numSpectra), 0u);
     for (uint i = 0; i < d->numSpectra && d->specOffsetSz; i++) {
       so[2 * i] = d->specOffsetSz[2 * i]; so[2 * i + 1] = d->specOffsetSz[2 * i + 1];
-      if (so[2 * i] == 0xFFFFFFFFu) { if (c->spectralOk) { c->spectralOk = false; c->spectralWhyNot = "spectra given by textures (lambda_ref_ids) are outside the path's scope"; } so[2 * i] = 0; continue; }
+      if (so[2 * i] == 0xFFFFFFFFu) {                            // a spectrum given by textures (lambda_ref_ids): its bands must come with it
+        so[2 * i] = 0;
+        const bool bands = d->specTexOffsetSz && d->specTexIdsWavelengths && d->specTexOffsetSz[2 * i + 1] >= 2u;
+        if (!bands && c->spectralOk) { c->spectralOk = false; c->spectralWhyNot = "spectrum " + std::to_string(i) + " is given by textures, but m_spec_tex_ids_wavelengths / m_spec_tex_offset_sz did not come with the scene"; }
+        continue;
+      }
       if ((uint64_t)so[2 * i] + std::max(so[2 * i + 1], WAVES - 1u) > d->numSpecValues) return c->fail(HPT_ERR_ARG, "m_spec_offset_sz: spectrum " + std::to_string(i) + " reaches past m_spec_values");
+    }
+    {
+      std::vector<uint> tos(2 * std::max(1u, d->numSpectra), 0u), tiw(2 * std::max(1u, d->specTexIdsWavelengths ? d->numSpecTexBands : 0u), 0u);
+      if (d->specTexIdsWavelengths && d->numSpecTexBands) std::memcpy(tiw.data(), d->specTexIdsWavelengths, 8 * (size_t)d->numSpecTexBands);
+      for (uint i = 0; i < d->numSpectra && d->specTexOffsetSz && d->specTexIdsWavelengths; i++) {
+        const uint off = d->specTexOffsetSz[2 * i], sz = d->specTexOffsetSz[2 * i + 1];
+        if (sz == 0u) continue;                                  // ({0xFFFFFFFF, 0}: a tabulated spectrum)
+        if (sz < 2u || (uint64_t)off + sz > d->numSpecTexBands) return c->fail(HPT_ERR_ARG, "m_spec_tex_offset_sz: spectrum " + std::to_string(i) + " reaches past m_spec_tex_ids_wavelengths (or holds fewer than two bands)");
+        for (uint k2 = 0; k2 < sz; k2++) {
+          // (LoadSpectralTextures resolves the bands' texture ids only when it loads for spectral rendering: a scene loaded for RGB keeps the XML's)
+          if (d->specTexIdsWavelengths[2 * (off + k2)] >= d->numTextures) { if (c->spectralOk) { c->spectralOk = false; c->spectralWhyNot = "m_spec_tex_ids_wavelengths refers to a texture that is not in m_textures (the scene was loaded for RGB rendering)"; } tiw[2 * (off + k2)] = 0u; }
+          if (k2 && d->specTexIdsWavelengths[2 * (off + k2) + 1] <= d->specTexIdsWavelengths[2 * (off + k2 - 1) + 1]) return c->fail(HPT_ERR_ARG, "m_spec_tex_ids_wavelengths: the bands of a spectrum must ascend in wavelength");
+        }
+        tos[2 * i] = off; tos[2 * i + 1] = sz;
+      }
+      HIPCHK(c, c->dSpecTexOffsetSz.upload(tos.data(), tos.size())); HIPCHK(c, c->dSpecTexIdsWavelengths.upload(tiw.data(), tiw.size()));
+      S.specTexOffsetSz = c->dSpecTexOffsetSz.p; S.specTexIdsWavelengths = c->dSpecTexIdsWavelengths.p;
     }
     auto specIdOk = [&](uint id) { return id == 0xFFFFFFFFu || id < d->numSpectra; };
     const MaterialRec* mm = (const MaterialRec*)d->materials;
@@ -1129,7 +1151,7 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
     }
     for (int k2 = 0; k2 < 3; k2++) if (d->camResponseSpectrumId[k2] >= (int)d->numSpectra) return c->fail(HPT_ERR_ARG, "m_camResponseSpectrumId refers to a spectrum that does not exist");
     std::vector<float> sv(d->specValues ? std::vector<float>(d->specValues, d->specValues + d->numSpecValues) : std::vector<float>());
-    if (sv.empty()) sv.push_back(0.0f);
+    if (sv.size() < WAVES) sv.resize(WAVES, 0.0f);             // (a spectrum id that stands for textures reads as offset 0 wherever a tabulated one is looked up)
     std::vector<float4> cie(std::max(d->numCieXYZ, 1u), make_float4(0, 0, 0, 0));
     for (uint i = 0; i < d->numCieXYZ && d->cieXYZ; i++) cie[i] = make_float4(d->cieXYZ[4 * i], d->cieXYZ[4 * i + 1], d->cieXYZ[4 * i + 2], d->cieXYZ[4 * i + 3]);
     HIPCHK(c, c->dSpecValues.upload(sv.data(), sv.size()));

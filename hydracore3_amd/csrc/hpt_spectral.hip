@@ -13,7 +13,7 @@
 // Scope of this kernel: PathTraceBlock with everything the RGB kernels hold - every material type (gltf and the legacy glass carry their colours
 // as four samples as they are; thin films: hpt_film.h), blends, normal maps, every light type with an intensity spectrum, sampled environment
 // maps and back plates, a sky spectrum, moving instances, the lens stack - in a one-thread-per-pixel kernel with in-place path regeneration (no
-// work queue). hpt_update_params refuses spectral mode for scenes with spectral textures (lambda_ref_ids). With more than four channels the
+// work queue). With more than four channels the
 // output is the reference's stack of wavelength layers.
 #include <hip/hip_runtime.h>
 #include "hpt_decl.h"
@@ -42,12 +42,41 @@ HPT_DEV V4 sampleWavelengths(float u, float a, float b)
 HPT_DEV V4 sampleUniformSpectrum(const float* vals, uint offset, V4 w)
 { return v4(sampleUniformSpectrum1(vals, offset, w.x), sampleUniformSpectrum1(vals, offset, w.y), sampleUniformSpectrum1(vals, offset, w.z), sampleUniformSpectrum1(vals, offset, w.w)); }
 
-// SampleMatColorSpectrumTexture / SampleMatColorParamSpectrum without spectral textures (integrator_spectrum.cpp:4-22, 128-145)
-HPT_DEV V4 matColorSpectrum(const DevScene& S, const MaterialRec& m, V4 waves, int paramId, int specSlot)
+// BinarySearchU2 (spectrum.h:42-55) with its probes kept inside the table: the reference shrinks the range by `last - half + 1` (pbrt's FindInterval:
+// `size - (half + 1)`), so for wavelengths in the upper part of a spectrum its probes run past the end; such a probe is answered "greater" here,
+// which ends the loop, and the clamp returns the interval the wavelength lies in - the reference's result wherever its own reads stay inside.
+HPT_DEV uint binarySearchU2(const uint* array2, uint a_offset, uint array_sz, float val)
+{
+  int last = int(array_sz) - 2, first = 1;
+  while (last > 0) {
+    const int half = last >> 1, middle = first + half;
+    const bool predResult = middle < int(array_sz) && float(array2[2u * (a_offset + (uint)middle) + 1u]) <= val;
+    first = predResult ? middle + 1 : first;
+    last = predResult ? last - half + 1 : half;
+  }
+  return (uint)min(max(first - 1, 0), int(array_sz) - 2);
+}
+// SampleMatColorSpectrumTexture (integrator_spectrum.cpp:128-180): the material's colour as a spectrum - tabulated, or (KSPEC_SPD_TEX) one texture
+// per wavelength band, linear between the two around each wavelength, zero outside the bands
+HPT_DEV V4 matColorSpectrum(const DevScene& S, const MaterialRec& m, V4 waves, int paramId, int specSlot, V2 uv)
 {
   const uint specId = m.spdid[specSlot];
-  if (specId < 0xFFFFFFFFu) return sampleUniformSpectrum(S.specValues, S.specOffsetSz[2u * specId], waves);
-  return ld4(m.colors[paramId]);
+  if (specId >= 0xFFFFFFFFu) return ld4(m.colors[paramId]);
+  const uint texSize = S.specTexOffsetSz[2u * specId + 1u];
+  if (texSize == 0u) return sampleUniformSpectrum(S.specValues, S.specOffsetSz[2u * specId], waves);
+  const uint texOffset = S.specTexOffsetSz[2u * specId];
+  const uint* tw = S.specTexIdsWavelengths;
+  const V2 tcT = mulRows2x4(m.row0[0], m.row1[0], uv);
+  float r[4];
+  for (int i = 0; i < 4; i++) {
+    const float w = comp(waves, i);
+    if (w < float(tw[2u * texOffset + 1u]) || w > float(tw[2u * (texOffset + texSize - 1u) + 1u])) { r[i] = 0.0f; continue; }
+    const uint o = binarySearchU2(tw, texOffset, texSize, w);
+    const uint y0 = tw[2u * (texOffset + o) + 1u], y1 = tw[2u * (texOffset + o + 1u) + 1u];
+    const V4 c1 = texSample(S.textures, tw[2u * (texOffset + o)], tcT), c2 = texSample(S.textures, tw[2u * (texOffset + o + 1u)], tcT);
+    r[i] = lerpf(c1.x, c2.x, (w - float(y0)) / float(y1 - y0));
+  }
+  return v4(r[0], r[1], r[2], r[3]);
 }
 // SampleMatParamSpectrum (:25-44)
 HPT_DEV V4 matParamSpectrum(const DevScene& S, const MaterialRec& m, V4 waves, int paramId, int specSlot)
@@ -177,12 +206,12 @@ HPT_DEV SpecEval materialEvalSpec(const DevScene& S, const MaterialRec& m, V4 wa
   if (m.mtype == MAT_TYPE_DIFFUSE) {
     float lambertVal = HPT_INV_PI;
     if ((m.cflags & GLTF_COMPONENT_ORENNAYAR) != 0) lambertVal *= orennayarFunc(l, v, n, m.data[0]);
-    r.val = lambertVal * matColorSpectrum(S, m, waves, 0, 0);               // (not multiplied by the texture in spectral mode, :259-260)
+    r.val = lambertVal * matColorSpectrum(S, m, waves, 0, 0, uv);               // (not multiplied by the texture in spectral mode, :259-260)
     r.pdf = absf(dot(l, n)) * HPT_INV_PI;
   } else if (m.mtype == MAT_TYPE_PLASTIC) {
     // plasticEval on float4 (cmat_plastic.h:102-191): the reflectance enters channel by channel and nothing else depends on it, so the four
     // wavelengths are two passes through the RGB routine - (x, y, z), then w in every slot - with the same arithmetic per channel
-    const V4 refl = matColorSpectrum(S, m, waves, 0, 0);                     // PLASTIC_COLOR; not multiplied by the texture in spectral mode (integrator_pt_mat.cpp:490-493)
+    const V4 refl = matColorSpectrum(S, m, waves, 0, 0, uv);                     // PLASTIC_COLOR; not multiplied by the texture in spectral mode (integrator_pt_mat.cpp:490-493)
     BsdfE a, b; a.val = v3(0, 0, 0); a.pdf = 0.0f; a.dval = v3(0, 0, 0); b = a;
     plasticEval(m, v3(refl.x, refl.y, refl.z), l, v, n, a, S.arrays1f, m.datai[0]);
     plasticEval(m, v3(refl.w, refl.w, refl.w), l, v, n, b, S.arrays1f, m.datai[0]);
@@ -272,7 +301,7 @@ HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V
   if (m.mtype == MAT_TYPE_DIFFUSE) {
     const V3 lambertDir = mapSampleToCosineDistribution(rands.x, rands.y, n, n, 1.0f);
     r.dir = lambertDir;
-    r.val = HPT_INV_PI * matColorSpectrum(S, m, waves, 0, 0);
+    r.val = HPT_INV_PI * matColorSpectrum(S, m, waves, 0, 0, uv);
     r.pdf = absf(dot(lambertDir, n)) * HPT_INV_PI;
     r.flags = RAY_FLAG_HAS_NON_SPEC;
     if ((m.cflags & GLTF_COMPONENT_ORENNAYAR) != 0) r.val = r.val * orennayarFunc(lambertDir, (-1.0f) * v, n, m.data[0]);
@@ -284,7 +313,7 @@ HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V
     dielectricSmoothSampleAndEval(m, etaSpec.x, prevIor, rands, v, n, a);
     r.val = v4s(a.val.x); r.dir = a.dir; r.pdf = a.pdf; r.flags = a.flags | ((m.spdid[0] < 0xFFFFFFFFu) ? RAY_FLAG_WAVES_DIVERGED : 0u); r.ior = a.ior;
   } else if (m.mtype == MAT_TYPE_PLASTIC) {                                  // plasticSampleAndEval on float4 (cmat_plastic.h:7-99), as in materialEvalSpec
-    const V4 refl = matColorSpectrum(S, m, waves, 0, 0);
+    const V4 refl = matColorSpectrum(S, m, waves, 0, 0, uv);
     BsdfS a; a.val = v3(0, 0, 0); a.dval = v3(0, 0, 0); a.pdf = pdf0; a.dir = v3(0, 1, 0); a.flags = flags0; a.ior = 1.0f;
     BsdfS b = a;
     plasticSampleAndEval(m, v3(refl.x, refl.y, refl.z), rands, v, n, a, S.arrays1f, m.datai[0]);

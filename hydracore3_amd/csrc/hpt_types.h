@@ -191,6 +191,9 @@ struct DevScene
   const float*       filmsEtaK;
   const uint*        filmsSpecId;
   const float*       precompThinFilms;
+  // spectra given by textures (m_spec_tex_ids_wavelengths, m_spec_tex_offset_sz: uint2 each), read by the spectral kernel's colour lookup
+  const uint*        specTexIdsWavelengths;
+  const uint*        specTexOffsetSz;
 };
 
 struct Counters { unsigned long long v[16]; };  // rays, nodes, tris, surfaceHits, shadowRays, paths, instEnter, texFetch,

@@ -145,6 +145,9 @@ public:
     d.filmsSpecId = m_films_spec_id_vec.empty() ? nullptr : m_films_spec_id_vec.data(); d.numFilmsSpecId = uint32_t(m_films_spec_id_vec.size());
     d.filmsEtaK = m_films_eta_k_vec.empty() ? nullptr : m_films_eta_k_vec.data(); d.numFilmsEtaK = uint32_t(m_films_eta_k_vec.size());
     d.precompThinFilms = m_precomp_thin_films.empty() ? nullptr : m_precomp_thin_films.data(); d.numPrecompThinFilms = uint32_t(m_precomp_thin_films.size());
+    if (!m_spec_tex_ids_wavelengths.empty() && m_spec_tex_offset_sz.size() == m_spec_offset_sz.size()) {   // spectra given by textures (integrator_pt.h: uint2 vectors)
+      d.specTexIdsWavelengths = m_spec_tex_ids_wavelengths.data(); d.numSpecTexBands = uint32_t(m_spec_tex_ids_wavelengths.size() / 2); d.specTexOffsetSz = m_spec_tex_offset_sz.data();
+    }
     report(hpt_upload_scene(m_ctx, &d), "CommitDeviceData");
     if (m_randomGensInit != m_maxThreadId) { hpt_init_random_gens(m_ctx, m_maxThreadId); m_randomGensInit = m_maxThreadId; }   // InitRandomGens
   }
@@ -206,6 +209,7 @@ public:
   std::vector<float>       m_cie_xyz;                 // integrator_pt.h:585: float4 {x, y, z, 0} per nm, 471 entries
   int                      m_camResponseSpectrumId[3] = {-1, -1, -1};   // integrator_pt.h:533
   int                      m_camResponseType = 0;     // integrator_pt.h:534: 0 = CAM_RESPONCE_XYZ, 1 = CAM_RESPONCE_RGB
+  std::vector<uint32_t>    m_spec_tex_ids_wavelengths, m_spec_tex_offset_sz;   // spectra given by textures: uint2 each (LoadSceneSpectrumData, integrator_pt_scene.cpp:363-377)
   std::vector<float>       m_films_thickness_vec;     // integrator_pt.h:587-590: thin films
   std::vector<uint32_t>    m_films_spec_id_vec;
   std::vector<float>       m_films_eta_k_vec;

@@ -29,6 +29,7 @@
 #include "plastic_precompute.h"
 #include "film_precompute.h"
 #include "jpeg_decode.h"
+#include <set>
 
 namespace hydra_hip {
 
@@ -196,6 +197,7 @@ struct LoadedScene
   std::vector<float> arrays1f;
   // thin films (integrator_pt.h:587-590): m_films_thickness_vec, m_films_spec_id_vec, m_films_eta_k_vec, m_precomp_thin_films
   std::vector<float> filmsThickness, filmsEtaK, precompThinFilms; std::vector<uint32_t> filmsSpecId;
+  std::vector<uint32_t> specTexIdsWavelengths, specTexOffsetSz;   // spectra given by textures: uint2 {texture, wavelength} per band, uint2 {first band, bands} per spectrum
   std::vector<float> lensLines; float physSize[2] = {0, 0};   // lens simulation: m_lines as {curvatureRadius, thickness, eta, apertureRadius}, m_physSize
   // spectral rendering (LoadSceneSpectrumData, integrator_pt_scene.cpp:358-419; the camera's <sensor><response>, :688-711)
   uint32_t spectralMode = 0;
@@ -231,6 +233,9 @@ struct LoadedScene
       d.cieXYZ = cieXYZ.data(); d.numCieXYZ = (uint32_t)(cieXYZ.size() / 4);
       for (int k = 0; k < 3; k++) d.camResponseSpectrumId[k] = camResponseSpectrumId[k];
       d.camResponseType = camResponseType;
+    }
+    if (!specTexIdsWavelengths.empty() && specTexOffsetSz.size() == specOffsetSz.size()) {
+      d.specTexIdsWavelengths = specTexIdsWavelengths.data(); d.numSpecTexBands = (uint32_t)(specTexIdsWavelengths.size() / 2); d.specTexOffsetSz = specTexOffsetSz.data();
     }
     if (!filmsEtaK.empty()) {
       d.filmsThickness = filmsThickness.data(); d.numFilmsThickness = (uint32_t)filmsThickness.size();
@@ -651,10 +656,12 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
   }
   std::map<std::array<uint32_t, 5>, uint32_t> texCache;
   // ReadSamplerFromColorNode (integrator_pt_scene_mat.cpp:32-91) + LoadTextureFromNode: rows of the node's sampler and the table index
-  auto loadTextureFromNode = [&](const XmlNode* node, float* row0, float* row1, uint32_t& outId) -> bool {
+  // (childName / forceXid / forceNoGamma: LoadSpectralTextures reads the sampler from the colour node's <spectrum> child, names the texture itself
+  // and never applies gamma - integrator_pt_scene_mat.cpp:144-173, LoadTextureById integrator_pt_scene_tex.cpp:129-144)
+  auto loadTex = [&](const XmlNode* node, const char* childName, int forceXid, bool forceNoGamma, float* row0, float* row1, uint32_t& outId) -> bool {
     outId = 0;
     row0[0] = 1.0f; row0[1] = row0[2] = row0[3] = 0.0f; row1[0] = 0.0f; row1[1] = 1.0f; row1[2] = row1[3] = 0.0f;
-    const XmlNode* tn = node ? node->child("texture") : nullptr;
+    const XmlNode* tn = node ? node->child(childName) : nullptr;
     if (!tn) return true;
     bool bad = false;
     auto addr = [&](const char* name, uint32_t dflt) -> uint32_t {
@@ -671,8 +678,8 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
     if (fm == "point" || fm == "nearest") filt = 0u;
     else if (fm == "cubic" || fm == "bicubic") { err = "xml: bicubic texture filtering is outside the path"; return false; }
     { const auto mv = parseFloats(tn->get("matrix")); for (size_t i = 0; i < mv.size() && i < 8; i++) (i < 4 ? row0 : row1)[i % 4] = (float)mv[i]; }
-    const bool disableGamma = tn->has("input_gamma") && (int)std::atof(tn->get("input_gamma").c_str()) == 1;
-    const uint32_t xid = (uint32_t)std::atoi(tn->get("id").c_str());
+    const bool disableGamma = forceNoGamma || (tn->has("input_gamma") && (int)std::atof(tn->get("input_gamma").c_str()) == 1);
+    const uint32_t xid = forceXid >= 0 ? (uint32_t)forceXid : (uint32_t)std::atoi(tn->get("id").c_str());
     const std::array<uint32_t, 5> key = { xid, au, av, aw, filt };
     auto it = texCache.find(key); if (it != texCache.end()) { outId = it->second; return true; }
     if (xid >= texInfo.size()) { err = "xml: texture id not in textures_lib"; return false; }
@@ -717,11 +724,31 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
     outId = texCache[key] = (uint32_t)sc.textures.size() - 1;
     return true;
   };
+  auto loadTextureFromNode = [&](const XmlNode* node, float* row0, float* row1, uint32_t& outId) -> bool { return loadTex(node, "texture", -1, false, row0, row1, outId); };
+  std::set<uint32_t> loadedSpectral;
+  auto loadSpectralTextures = [&](uint32_t specId, const XmlNode* colorNode) -> bool {      // LoadSpectralTextures (integrator_pt_scene_mat.cpp:144-173)
+    if (specId == 0xFFFFFFFFu || 2 * (size_t)specId + 1 >= sc.specTexOffsetSz.size() || sc.specTexOffsetSz[2 * specId + 1] == 0u || loadedSpectral.count(specId)) return true;
+    const uint32_t off = sc.specTexOffsetSz[2 * specId], n = sc.specTexOffsetSz[2 * specId + 1];
+    for (uint32_t k2 = 0; k2 < n; k2++) {
+      float r0[4], r1[4]; uint32_t id = 0;
+      if (!loadTex(colorNode, "spectrum", (int)sc.specTexIdsWavelengths[2 * (off + k2)], true, r0, r1, id)) return false;
+      sc.specTexIdsWavelengths[2 * (off + k2)] = id;
+    }
+    loadedSpectral.insert(specId);
+    return true;
+  };
 
   // LoadSceneSpectrumData (integrator_pt_scene.cpp:358-419): every <spectrum> resampled at 1 nm, one {offset, size} per node in node order
   sc.spectralMode = spectral ? 1u : 0u;
   if (const XmlNode* lib = root.child("spectra_lib")) for (const XmlNode* sn : lib->all("spectrum")) {
-    if (sn->has("lambda_ref_ids")) { sc.specOffsetSz.push_back(0xFFFFFFFFu); sc.specOffsetSz.push_back(0u); continue; }   // given by textures: outside the path
+    if (sn->has("lambda_ref_ids")) {                                          // given by textures (:363-377): "lambda texture lambda texture ..."
+      const auto refs = parseFloats(sn->get("lambda_ref_ids"));
+      sc.specTexOffsetSz.push_back((uint32_t)(sc.specTexIdsWavelengths.size() / 2)); sc.specTexOffsetSz.push_back((uint32_t)(refs.size() / 2));
+      for (size_t k2 = 0; k2 + 1 < refs.size(); k2 += 2) { sc.specTexIdsWavelengths.push_back((uint32_t)refs[k2 + 1]); sc.specTexIdsWavelengths.push_back((uint32_t)refs[k2]); }
+      sc.specOffsetSz.push_back(0xFFFFFFFFu); sc.specOffsetSz.push_back(0u);
+      continue;
+    }
+    sc.specTexOffsetSz.push_back(0xFFFFFFFFu); sc.specTexOffsetSz.push_back(0u);
     std::vector<float> w, v;
     if (sn->has("value")) { const auto nums = parseFloats(sn->get("value")); for (size_t k = 0; k + 1 < nums.size(); k += 2) { w.push_back((float)nums[k]); v.push_back((float)nums[k + 1]); } }
     else if (!loadSpd(folder + "/" + sn->get("loc"), w, v)) { err = "cannot read spectrum " + sn->get("loc"); return false; }
@@ -732,6 +759,7 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
   if (sc.specOffsetSz.empty()) {                                              // "if no spectra are loaded add uniform 1.0 spectrum" (:406-418)
     const std::vector<float> u = resampleUniform({200.0f, 400.0f, 600.0f, 800.0f}, {1.0f, 1.0f, 1.0f, 1.0f});
     sc.specOffsetSz.push_back(0u); sc.specOffsetSz.push_back((uint32_t)u.size()); sc.specValues = u;
+    sc.specTexOffsetSz.push_back(0xFFFFFFFFu); sc.specTexOffsetSz.push_back(0u);
   }
   sc.cieXYZ = cieXyzFit();
   auto spectrumId = [](const XmlNode* n) -> uint32_t {                        // GetSpectrumIdFromNode (integrator_pt_scene_mat.cpp:109-119)
@@ -969,7 +997,10 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
       mat.mtype = 4; mat.lightId = 0xFFFFFFFFu;
       const XmlNode* bsdf = mn->child("bsdf");
       if (bsdf && bsdf->get("type") == "oren-nayar") { mat.cflags = 16u; if (const XmlNode* r = mn->child("roughness")) mat.data[0] = val1f(r); }
-      if (const XmlNode* rc = mn->child("reflectance")) { color4(rc, mat.colors[0]); if (!loadTextureFromNode(rc, mat.row0[0], mat.row1[0], mat.texid[0])) return false; mat.spdid[0] = spectrumId(rc); }
+      if (const XmlNode* rc = mn->child("reflectance")) {
+        color4(rc, mat.colors[0]); if (!loadTextureFromNode(rc, mat.row0[0], mat.row1[0], mat.texid[0])) return false; mat.spdid[0] = spectrumId(rc);
+        if (spectral && !loadSpectralTextures(mat.spdid[0], rc)) return false;                                   // (:562-567)
+      }
     } else if (type == "dielectric") {                                        // LoadDielectricMaterial (:574-616), RGB mode
       for (int k = 0; k < 4; k++) { mat.colors[0][k] = 1.0f; mat.colors[1][k] = 1.0f; }
       mat.mtype = 7; mat.lightId = 0xFFFFFFFFu; mat.data[0] = 1.00028f; mat.data[1] = 1.5046f;
@@ -988,6 +1019,7 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
       const plastic::CoatPrecomputed pre = plastic::fresnelCoatPrecompute(mat.data[0], intIor, extIor, mat.colors[0], one4);
       mat.data[3] = pre.internalReflectance; mat.data[2] = pre.specularSamplingWeight;
       mat.spdid[0] = spectrumId(mn->child("reflectance"));                    // (:704-705)
+      if (spectral && !loadSpectralTextures(mat.spdid[0], mn->child("reflectance"))) return false;   // (:708-713)
       if (spectral) {
         // mi::fresnel_coat_precompute in spectral mode (mi_materials.cpp:383-404): s_mean = 1 over four components, d_mean = the mean of the
         // reflectance spectrum (mi::spectrum_mean: trapezoid rule over 360 .. 830 nm in double), 0.5 without one

@@ -100,7 +100,9 @@ class SceneDesc(C.Structure):
                 ("camResponseType", C.c_uint32), ("reserved2", C.c_uint32),
                 # thin films: m_films_thickness_vec, m_films_spec_id_vec, m_films_eta_k_vec, m_precomp_thin_films
                 ("filmsThickness", C.c_void_p), ("filmsSpecId", C.c_void_p), ("filmsEtaK", C.c_void_p), ("precompThinFilms", C.c_void_p),
-                ("numFilmsThickness", C.c_uint32), ("numFilmsSpecId", C.c_uint32), ("numFilmsEtaK", C.c_uint32), ("numPrecompThinFilms", C.c_uint32)]
+                ("numFilmsThickness", C.c_uint32), ("numFilmsSpecId", C.c_uint32), ("numFilmsEtaK", C.c_uint32), ("numPrecompThinFilms", C.c_uint32),
+                # spectra given by textures: m_spec_tex_ids_wavelengths, m_spec_tex_offset_sz
+                ("specTexIdsWavelengths", C.c_void_p), ("specTexOffsetSz", C.c_void_p), ("numSpecTexBands", C.c_uint32), ("reserved3", C.c_uint32)]
 
 
 class FilmParams(C.Structure):
@@ -484,6 +486,7 @@ class SceneData:
         self.cam_respoce_rgb = (1.0, 1.0, 1.0, 1.0)           # m_camRespoceRGB
         self.env_spec_id, self.env_spec_mult = UINT_MAX, 1.0  # m_envSpecId, m_envSpecMult: the sky light's spectrum and multiplier (integrator_pt_scene.cpp:456-457)
         # thin films (integrator_pt.h:587-590): thickness per film, eta then k per layer and their spectrum ids, the precomputed tables
+        self.spec_tex_ids_wavelengths, self.spec_tex_offset_sz = [], []   # spectra given by textures: (texture, wavelength) per band, (first band, bands) per spectrum id
         self.films_thickness, self.films_spec_id, self.films_eta_k = [], [], []
         self.precomp_thin_films = np.zeros(0, np.float32)
         self.all_remap_lists = np.zeros((1,), np.int32)     # no lists: just the trailing offset 0
@@ -812,6 +815,10 @@ class SceneData:
             cie = self.cie_xyz if self.cie_xyz is not None else cie_xyz_fit()
             d.cieXYZ = ptr(np.asarray(cie, np.float32).reshape(-1, 4)); d.numCieXYZ = int(np.asarray(cie).reshape(-1, 4).shape[0])
             d.camResponseSpectrumId = (C.c_int32 * 3)(*[int(v) for v in self.cam_response_spectrum_id]); d.camResponseType = int(self.cam_response_type)
+        d.specTexIdsWavelengths, d.specTexOffsetSz, d.numSpecTexBands = None, None, 0
+        if self.spec_tex_ids_wavelengths and len(self.spec_tex_offset_sz) == len(self.spec_offset_sz):
+            d.specTexIdsWavelengths, d.numSpecTexBands = ptr(np.asarray(self.spec_tex_ids_wavelengths, np.uint32).reshape(-1, 2)), len(self.spec_tex_ids_wavelengths)
+            d.specTexOffsetSz = ptr(np.asarray(self.spec_tex_offset_sz, np.uint32).reshape(-1, 2))
         d.filmsThickness, d.filmsSpecId, d.filmsEtaK, d.precompThinFilms = None, None, None, None
         d.numFilmsThickness = d.numFilmsSpecId = d.numFilmsEtaK = d.numPrecompThinFilms = 0
         if self.films_eta_k:
@@ -1175,9 +1182,13 @@ def load_hydra_xml(xml_path: str, width=None, height=None, spectral=False) -> Sc
     sc.spectral_mode = 1 if spectral else 0
     spec_vals = []
     for sn in root.findall("spectra_lib/spectrum"):
-        if sn.get("lambda_ref_ids") is not None:                              # a spectrum given by textures: outside the path (offset 0xFFFFFFFF as in the reference)
+        if sn.get("lambda_ref_ids") is not None:                              # a spectrum given by textures (:363-377): "lambda texture lambda texture ..."
+            refs = [int(v) for v in _f(sn.get("lambda_ref_ids"))]
+            sc.spec_tex_offset_sz.append((len(sc.spec_tex_ids_wavelengths), len(refs) // 2))
+            sc.spec_tex_ids_wavelengths += [[refs[2 * k + 1], refs[2 * k]] for k in range(len(refs) // 2)]      # {texture id of the XML, wavelength}
             sc.spec_offset_sz.append((UINT_MAX, 0))
             continue
+        sc.spec_tex_offset_sz.append((UINT_MAX, 0))
         if sn.get("value") is not None:                                       # ParseSpectrumStr: "lambda value lambda value ..."
             nums = _f(sn.get("value"))
             wl, vl = nums[0::2], nums[1::2]
@@ -1188,7 +1199,7 @@ def load_hydra_xml(xml_path: str, width=None, height=None, spectral=False) -> Sc
         spec_vals.append(u)
     if not sc.spec_offset_sz:                                                 # "if no spectra are loaded add uniform 1.0 spectrum" (:406-418)
         u = resample_uniform([200.0, 400.0, 600.0, 800.0], [1.0, 1.0, 1.0, 1.0])
-        sc.spec_offset_sz.append((0, len(u))); spec_vals.append(u)
+        sc.spec_offset_sz.append((0, len(u))); spec_vals.append(u); sc.spec_tex_offset_sz.append((UINT_MAX, 0))
     sc.spec_values = np.concatenate(spec_vals).astype(np.float32) if spec_vals else np.zeros(0, np.float32)
 
     def spectrum_id(node):
@@ -1196,9 +1207,9 @@ def load_hydra_xml(xml_path: str, width=None, height=None, spectral=False) -> Sc
         sn = node.find("spectrum") if node is not None else None
         return int(sn.get("id")) & UINT_MAX if sn is not None else UINT_MAX
 
-    def read_sampler(node):
-        """ReadSamplerFromColorNode (integrator_pt_scene_mat.cpp:32-91): (key, row0, row1, disable_gamma) or None without a <texture>."""
-        tnode = node.find("texture") if node is not None else None
+    def read_sampler(node, from_spectrum=False):
+        """ReadSamplerFromColorNode (integrator_pt_scene_mat.cpp:32-91): (key, row0, row1, disable_gamma) or None without a <texture> (a <spectrum>)."""
+        tnode = node.find("spectrum" if from_spectrum else "texture") if node is not None else None
         if tnode is None:
             return None
         def addr(name, default):
@@ -1229,6 +1240,24 @@ def load_hydra_xml(xml_path: str, width=None, height=None, spectral=False) -> Sc
         if sam is None:
             return (1, 0, 0, 0), (0, 1, 0, 0), 0
         key, row0, row1, disable_gamma = sam
+        return tuple(row0), tuple(row1), load_texture_by_key(key, disable_gamma)
+
+    loaded_spectral = set()
+
+    def load_spectral_textures(spec_id, color_node):
+        """LoadSpectralTextures (integrator_pt_scene_mat.cpp:144-173): the textures of a spectrum's bands enter the table with the sampler read
+        from the colour node's <spectrum> child (gamma never applied, LoadTextureById :129-144); the bands then name table entries."""
+        if spec_id == UINT_MAX or spec_id >= len(sc.spec_tex_offset_sz) or sc.spec_tex_offset_sz[spec_id][1] == 0 or spec_id in loaded_spectral:
+            return
+        sam = read_sampler(color_node, True)
+        off, n = sc.spec_tex_offset_sz[spec_id]
+        for k in range(n):
+            xml_id = sc.spec_tex_ids_wavelengths[off + k][0]
+            key = (xml_id, *sam[0][1:])
+            sc.spec_tex_ids_wavelengths[off + k][0] = load_texture_by_key(key, True)
+        loaded_spectral.add(spec_id)
+
+    def load_texture_by_key(key, disable_gamma):
         if key not in tex_cache:
             path, w, h, bpp = tex_info[key[0]]
             raw = open(path, "rb").read()
@@ -1240,11 +1269,11 @@ def load_hydra_xml(xml_path: str, width=None, height=None, spectral=False) -> Sc
                     r = np.where(np.isinf(img[..., 0]), np.float32(65504.0), np.clip(img[..., 0], 0.0, 65504.0)).astype(np.float32)
                     tex = Texture(np.ascontiguousarray(r), TEX_R32F, False, key[1], key[2], key[4])
                 tex_cache[key] = sc.add_texture(tex)
-                return tuple(row0), tuple(row1), tex_cache[key]
+                return tex_cache[key]
             if ".image" not in path:                                           # LDR files through LiteImage::LoadImage<uint32_t> (:24-33)
                 tex = Texture(decode_ldr_image(path, raw), TEX_RGBA8, not disable_gamma, key[1], key[2], key[4])
                 tex_cache[key] = sc.add_texture(tex)
-                return tuple(row0), tuple(row1), tex_cache[key]
+                return tex_cache[key]
             fw, fh = struct.unpack_from("<II", raw, 0)
             if fw == 0 or fh == 0:                                             # white float dummy (:67-73)
                 tex = Texture(np.ones((1, 1, 4), np.float32), TEX_RGBA32F, False, key[1], key[2], key[4])
@@ -1253,7 +1282,7 @@ def load_hydra_xml(xml_path: str, width=None, height=None, spectral=False) -> Sc
             else:
                 tex = Texture(np.frombuffer(raw, "<u4", fw * fh, 8).reshape(fh, fw).copy(), TEX_RGBA8, not disable_gamma, key[1], key[2], key[4])
             tex_cache[key] = sc.add_texture(tex)
-        return tuple(row0), tuple(row1), tex_cache[key]
+        return tex_cache[key]
 
     def color4(node):
         """GetColorFromNode (integrator_pt_scene_mat.cpp:124-143): one value splats, three get w = 0, four are taken as they are."""
@@ -1459,6 +1488,8 @@ def load_hydra_xml(xml_path: str, width=None, height=None, spectral=False) -> Sc
             mat["colors"][0] = color4(rn)
             bind_texture(mat, 0, rn)
             mat["spdid"][0] = spectrum_id(rn)                                 # (:559-560)
+            if spectral:
+                load_spectral_textures(int(mat["spdid"][0]), rn)              # (:562-567)
         return mat
 
     def load_dielectric(mnode):
@@ -1504,6 +1535,7 @@ def load_hydra_xml(xml_path: str, width=None, height=None, spectral=False) -> Sc
                                   float(val1f(mnode.find("ext_ior"), 1.000277)), nonlinear, tid, r0, r1)
         mat["spdid"][0] = spectrum_id(rn)                                     # (:704-705)
         if spectral:
+            load_spectral_textures(int(mat["spdid"][0]), rn)                  # (:708-713)
             # mi::fresnel_coat_precompute in spectral mode (mi_materials.cpp:383-404): the specular reflectance (1, 1, 1, 1) averages to 1 over FOUR
             # components, the diffuse mean is the mean of the reflectance spectrum (trapezoid rule over 360 .. 830 nm), or 0.5 without one
             sid = int(mat["spdid"][0])

@@ -73,7 +73,7 @@ typedef struct hpt_scene_desc {
   uint32_t        reserved;
   /* spectral rendering (integrator_pt.h: m_spec_values, m_spec_offset_sz, m_cie_xyz, m_camResponseSpectrumId / m_camResponseType): all may be
    * NULL / 0 for RGB rendering. specValues: every spectrum resampled at 1 nm from LAMBDA_MIN = 360 (Spectrum::ResampleUniform, 471 floats each);
-   * specOffsetSz: uint2 {offset, size} per spectrum id (0xFFFFFFFF offset: a spectrum given by textures, outside this path's scope);
+   * specOffsetSz: uint2 {offset, size} per spectrum id (0xFFFFFFFF offset: a spectrum given by textures, see specTexOffsetSz below);
    * cieXYZ: float4 {x, y, z, 0} x 471, the CIE 1931 observer at 360..830 nm (LoadScene fills it from Get_CIE_X/Y/Z, integrator_pt_scene.cpp:962-969). */
   const float*    specValues;
   const uint32_t* specOffsetSz;
@@ -91,6 +91,12 @@ typedef struct hpt_scene_desc {
   const float*    filmsEtaK;
   const float*    precompThinFilms;
   uint32_t        numFilmsThickness, numFilmsSpecId, numFilmsEtaK, numPrecompThinFilms;
+  /* spectra given by textures (KSPEC_SPD_TEX; LoadSceneSpectrumData, integrator_pt_scene.cpp:363-377): m_spec_tex_ids_wavelengths = uint2 {texture,
+   * wavelength in nm} per band, m_spec_tex_offset_sz = uint2 {first band, bands} per spectrum id ({0xFFFFFFFF, 0}: a tabulated spectrum). NULL / 0
+   * without such spectra. */
+  const uint32_t* specTexIdsWavelengths;
+  const uint32_t* specTexOffsetSz;
+  uint32_t        numSpecTexBands, reserved3;
 } hpt_scene_desc;
 
 /* The plain-data members UpdateMembersPlainData() refreshes before every *Block call (integrator_pt.h:268, main.cpp:398). */
@@ -104,7 +110,7 @@ typedef struct hpt_params {
   uint32_t tileSize;          /* m_tileSize */
   uint32_t spectralMode;      /* m_spectral_mode: 0 = RGB; 1 = four wavelengths per path (needs hpt_scene_desc's spectral tables; PathTraceBlock, NaivePathTraceBlock and
                                * PathTraceFromInputRaysBlock, every material / light / camera feature of the RGB path; channels: 1, 3 - 4, or more = wavelength layers;
-                               * spectra given by textures and PathTraceDR are refused with HPT_ERR_UNSUPPORTED) */
+                               * PathTraceDR is refused with HPT_ERR_UNSUPPORTED) */
   uint32_t envSpecIdPlus1;    /* m_envSpecId + 1 (integrator_pt.h:524; 0 = none, so that a zeroed struct means "no environment spectrum") */
   float    exposureMult, camLensRadius, camTargetDist, envSpecMult;   /* envSpecMult: m_envSpecMult (spectral mode: the environment spectrum's multiplier) */
   float    camRespoceRGB[4];  /* m_camRespoceRGB */

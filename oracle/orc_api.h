@@ -68,6 +68,12 @@ typedef struct orc_scene_desc {
   const float*    filmsEtaK;
   const float*    precompThinFilms;
   uint32_t        numFilmsThickness, numFilmsSpecId, numFilmsEtaK, numPrecompThinFilms;
+  /* spectra given by textures (KSPEC_SPD_TEX; LoadSceneSpectrumData, integrator_pt_scene.cpp:363-377): m_spec_tex_ids_wavelengths = uint2 {texture,
+   * wavelength in nm} per band, m_spec_tex_offset_sz = uint2 {first band, bands} per spectrum id ({0xFFFFFFFF, 0}: a tabulated spectrum). NULL / 0
+   * without such spectra. */
+  const uint32_t* specTexIdsWavelengths;
+  const uint32_t* specTexOffsetSz;
+  uint32_t        numSpecTexBands, reserved3;
 } orc_scene_desc;
 
 typedef struct orc_params {

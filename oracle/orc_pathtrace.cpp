@@ -190,12 +190,44 @@ struct Ctx
     }
     return mk4(r[0], r[1], r[2], r[3]);
   }
-  f4 SampleMatColorSpectrumTexture(uint matId, f4 a_wavelengths, uint paramId, uint paramSpecId) const   // integrator_spectrum.cpp:128-171, without spectral textures
+  // BinarySearchU2 (spectrum.h:42-55). The reference shrinks its range by `last - half + 1` where pbrt's FindInterval has `size - (half + 1)`: for
+  // wavelengths in the upper part of a spectrum its probes leave the table. A probe past the end is answered "greater" here (what a read of
+  // large garbage gives): the loop then ends, and the clamp at the bottom returns the interval the wavelength lies in - the reference's result
+  // wherever its own reads stay inside the table.
+  static uint BinarySearchU2(const uint* array2, int a_offset, uint array_sz, float val)
+  {
+    int last = int(array_sz) - 2, first = 1;
+    while (last > 0) {
+      const int half = last >> 1, middle = first + half;
+      const bool predResult = middle < int(array_sz) && float(array2[2 * (a_offset + middle) + 1]) <= val;
+      first = predResult ? middle + 1 : first;
+      last = predResult ? last - half + 1 : half;
+    }
+    return uint(std::min(std::max(first - 1, 0), int(array_sz) - 2));
+  }
+  f4 SampleMatColorSpectrumTexture(uint matId, f4 a_wavelengths, uint paramId, uint paramSpecId, f2 texCoords) const   // integrator_spectrum.cpp:128-180
   {
     f4 res = sc.materials[matId].colors[paramId];
     if (a_wavelengths.x == 0.0f) return res;
     const uint specId = sc.materials[matId].spdid[paramSpecId];
-    if (specId < 0xFFFFFFFFu) res = SampleUniformSpectrum(sc.specOffsetSz[2 * specId], a_wavelengths);
+    if (specId >= 0xFFFFFFFFu) return res;
+    const uint tex_size = 2 * (size_t)specId + 1 < sc.specTexOffsetSz.size() ? sc.specTexOffsetSz[2 * specId + 1] : 0u;
+    if (tex_size == 0u) return SampleUniformSpectrum(sc.specOffsetSz[2 * specId], a_wavelengths);
+    // a spectrum given by textures (KSPEC_SPD_TEX): one texture per wavelength band, linear between the two around the wavelength; every
+    // component of the tabulated lookup is overwritten (its table offset is 0xFFFFFFFF in the reference: not read here)
+    const uint tex_offset = sc.specTexOffsetSz[2 * specId];
+    const uint* tw = sc.specTexIdsWavelengths.data();
+    const Material& m = sc.materials[matId];
+    float* r = &res.x; const float* w = &a_wavelengths.x;
+    for (int i = 0; i < 4; ++i) {
+      if (w[i] < float(tw[2 * tex_offset + 1]) || w[i] > float(tw[2 * (tex_offset + tex_size - 1) + 1])) { r[i] = 0.0f; continue; }
+      const uint o = BinarySearchU2(tw, int(tex_offset), tex_size, w[i]);
+      const uint texID1 = tw[2 * (tex_offset + o)], texID2 = tw[2 * (tex_offset + o + 1)];
+      const f2 texCoordT = mulRows2x4(m.row0[0], m.row1[0], texCoords);
+      const f4 c1 = sc.tex_sample(texID1, texCoordT), c2 = sc.tex_sample(texID2, texCoordT);
+      const float t = (w[i] - float(tw[2 * (tex_offset + o) + 1])) / float(tw[2 * (tex_offset + o + 1) + 1] - tw[2 * (tex_offset + o) + 1]);
+      r[i] = lerpf(c1.x, c2.x, t);
+    }
     return res;
   }
   f4 SampleMatParamSpectrum(uint matId, f4 a_wavelengths, uint paramId, uint paramSpecId) const          // integrator_spectrum.cpp:25-44
@@ -402,13 +434,13 @@ struct Ctx
         else                            conductorRoughSampleAndEval(m, etaSpec, kSpec, rands, v, shadeNormal, tc, alphaTex, &res);
       } break;
       case MAT_TYPE_DIFFUSE: {
-        f4 reflSpec = SampleMatColorSpectrumTexture(currMatId, wavelengths, DIFFUSE_COLOR, 0);      // integrator_pt_mat.cpp:256-260
+        f4 reflSpec = SampleMatColorSpectrumTexture(currMatId, wavelengths, DIFFUSE_COLOR, 0, tc);      // integrator_pt_mat.cpp:256-260
         if (p.spectralMode == 0) reflSpec = reflSpec * texColor;
         diffuseSampleAndEval(m, reflSpec, rands, v, shadeNormal, tc, &res);
       } break;
       case MAT_TYPE_GLASS: glassSampleAndEval(m, rands, v, geomNormal, &res, &a_misPrev->ior); break;    // integrator_pt_mat.cpp:178-183: the geometric normal
       case MAT_TYPE_PLASTIC: {                                                                     // :270-282 (RGB mode)
-        f4 reflSpec = SampleMatColorSpectrumTexture(currMatId, wavelengths, 0, 0);                  // PLASTIC_COLOR (integrator_pt_mat.cpp:268-271)
+        f4 reflSpec = SampleMatColorSpectrumTexture(currMatId, wavelengths, 0, 0, tc);                  // PLASTIC_COLOR (integrator_pt_mat.cpp:268-271)
         if (p.spectralMode == 0) reflSpec = reflSpec * texColor;
         plasticSampleAndEval(m, reflSpec, rands, v, shadeNormal, &res, sc.arrays1f.data(), m.datai[0]);
       } break;
@@ -483,14 +515,14 @@ struct Ctx
           res.pdf += currVal.pdf * weight;
         } break;
         case MAT_TYPE_DIFFUSE: {
-          f4 reflSpec = SampleMatColorSpectrumTexture(currMat.id, wavelengths, DIFFUSE_COLOR, 0);   // integrator_pt_mat.cpp:474-477
+          f4 reflSpec = SampleMatColorSpectrumTexture(currMat.id, wavelengths, DIFFUSE_COLOR, 0, tc);   // integrator_pt_mat.cpp:474-477
           if (p.spectralMode == 0) reflSpec = reflSpec * texColor;
           diffuseEval(m, reflSpec, l, v, shadeNormal, tc, &currVal);
           res.val = res.val + currVal.val * weight * bumpCosMult;
           res.pdf += currVal.pdf * weight;
         } break;
         case MAT_TYPE_PLASTIC: {                                                      // :484-499
-          f4 reflSpec = SampleMatColorSpectrumTexture(currMat.id, wavelengths, 0, 0);               // (integrator_pt_mat.cpp:490-493)
+          f4 reflSpec = SampleMatColorSpectrumTexture(currMat.id, wavelengths, 0, 0, tc);               // (integrator_pt_mat.cpp:490-493)
           if (p.spectralMode == 0) reflSpec = reflSpec * texColor;
           plasticEval(m, reflSpec, l, v, shadeNormal, &currVal, sc.arrays1f.data(), m.datai[0]);
           res.val = res.val + currVal.val * weight * bumpCosMult;

@@ -188,6 +188,7 @@ struct Scene
   // thin films (integrator_pt.h:587-590)
   std::vector<float>    filmsThickness, filmsEtaK, precompThinFilms;
   std::vector<uint>     filmsSpecId;
+  std::vector<uint>     specTexIdsWavelengths, specTexOffsetSz;   // uint2 each (integrator_pt.h: m_spec_tex_ids_wavelengths, m_spec_tex_offset_sz)
 
   std::vector<SimpleBvh> blas;            // per geom
   SimpleBvh              tlas;
@@ -244,6 +245,9 @@ struct Scene
     if (s->filmsSpecId && s->numFilmsSpecId) filmsSpecId.assign(s->filmsSpecId, s->filmsSpecId + s->numFilmsSpecId);
     if (s->filmsEtaK && s->numFilmsEtaK) filmsEtaK.assign(s->filmsEtaK, s->filmsEtaK + s->numFilmsEtaK);
     if (s->precompThinFilms && s->numPrecompThinFilms) precompThinFilms.assign(s->precompThinFilms, s->precompThinFilms + s->numPrecompThinFilms);
+    specTexIdsWavelengths.clear(); specTexOffsetSz.clear();
+    if (s->specTexIdsWavelengths && s->numSpecTexBands) specTexIdsWavelengths.assign(s->specTexIdsWavelengths, s->specTexIdsWavelengths + 2 * (size_t)s->numSpecTexBands);
+    if (s->specTexOffsetSz && s->numSpectra) specTexOffsetSz.assign(s->specTexOffsetSz, s->specTexOffsetSz + 2 * (size_t)s->numSpectra);
     instMatricesInv.resize(instMatrices.size());
     for (size_t i = 0; i < instMatrices.size(); i++) instMatricesInv[i] = affine_inverse(instMatrices[i]);
     build_accel();

@@ -45,6 +45,7 @@ static int renderScene(const char* xml, int W, int H, int spp, const char* out, 
   integ.m_spec_values = sc.specValues; integ.m_spec_offset_sz = sc.specOffsetSz; integ.m_cie_xyz = sc.cieXYZ;
   for (int k = 0; k < 3; k++) integ.m_camResponseSpectrumId[k] = sc.camResponseSpectrumId[k];
   integ.m_camResponseType = int(sc.camResponseType); std::memcpy(integ.m_camRespoceRGB, sc.camRespoceRGB, 16);
+  integ.m_spec_tex_ids_wavelengths = sc.specTexIdsWavelengths; integ.m_spec_tex_offset_sz = sc.specTexOffsetSz;
   integ.m_films_thickness_vec = sc.filmsThickness; integ.m_films_spec_id_vec = sc.filmsSpecId; integ.m_films_eta_k_vec = sc.filmsEtaK; integ.m_precomp_thin_films = sc.precompThinFilms;
   integ.m_spectral_mode = int(sc.spectralMode); integ.m_envSpecId = sc.envSpecId; integ.m_envSpecMult = sc.envSpecMult;
   integ.m_textures.clear();

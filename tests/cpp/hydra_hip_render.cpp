@@ -44,6 +44,7 @@ int main(int argc, char** argv)
     blob(f, "instMatricesMotion", sc.instMatricesMotion); blob(f, "instHasMotion", sc.instHasMotion);
     blob(f, "normMatrices2Offs", std::vector<uint32_t>(1, sc.normMatrices2Offs));
     blob(f, "specValues", sc.specValues); blob(f, "specOffsetSz", sc.specOffsetSz); blob(f, "cieXYZ", sc.cieXYZ);
+    blob(f, "specTexIdsWavelengths", sc.specTexIdsWavelengths); blob(f, "specTexOffsetSz", sc.specTexOffsetSz);
     blob(f, "filmsThickness", sc.filmsThickness); blob(f, "filmsSpecId", sc.filmsSpecId); blob(f, "filmsEtaK", sc.filmsEtaK); blob(f, "precompThinFilms", sc.precompThinFilms);
     blob(f, "camResponse", std::vector<int32_t>{ sc.camResponseSpectrumId[0], sc.camResponseSpectrumId[1], sc.camResponseSpectrumId[2], (int32_t)sc.camResponseType });
     for (size_t i = 0; i < sc.textures.size(); i++) {

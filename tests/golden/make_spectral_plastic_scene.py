@@ -74,3 +74,41 @@ dst = os.path.join(here, "scenes", "spectral_sky", "statex_00001.xml")
 os.makedirs(os.path.dirname(dst), exist_ok=True)
 open(dst, "w", encoding="utf-8").write(sky)
 print("wrote", dst)
+
+# tests/golden/scenes/spectral_textures: the white walls' and the sphere's reflectance given by TEXTURES (KSPEC_SPD_TEX; LoadSceneSpectrumData's
+# lambda_ref_ids, integrator_pt_scene.cpp:363-377; SampleMatColorSpectrumTexture, integrator_spectrum.cpp:128-180): spectrum 7 = five 8 x 8 maps
+# at 400 / 480 / 560 / 640 / 720 nm on the diffuse walls (sampler attributes on the <spectrum> node: clamp, point filter), spectrum 8 = two maps
+# on the sphere turned plastic. Wavelengths outside a spectrum's bands read zero; the maps' red channel is the value (gamma never applied).
+import struct
+import numpy as np
+tex = src.replace('loc="data/', 'loc="../test_spectral/data/')
+folder = os.path.join(here, "scenes", "spectral_textures")
+os.makedirs(os.path.join(folder, "data"), exist_ok=True)
+v, u = np.mgrid[0:8, 0:8]
+lines = []
+for k, lam in enumerate((400, 480, 560, 640, 720)):
+    val = np.clip(0.25 + 0.55 * np.exp(-((lam - 400 - 40 * (u + v) / 2.0) / 120.0) ** 2) + 0.1 * ((u // 2 + v // 2 + k) % 2), 0.0, 1.0)
+    r = (val * 255.0 + 0.5).astype(np.uint32)
+    open(os.path.join(folder, "data", f"band_{lam}.image4ub"), "wb").write(struct.pack("<II", 8, 8) + (r | (r << 8) | (r << 16) | np.uint32(0xFF000000)).astype("<u4").tobytes())
+    lines.append(f'  <texture id="{k + 1}" name="band_{lam}" loc="data/band_{lam}.image4ub" offset="8" bytesize="256" width="8" height="8" dl="0" />')
+tex = tex.replace("</textures_lib>", "\n".join(lines) + "\n</textures_lib>")
+tex = tex.replace("</spectra_lib>", '  <spectrum id="7" name="wall_maps" lambda_ref_ids="400 1 480 2 560 3 640 4 720 5" />\n'
+                  '  <spectrum id="8" name="sphere_maps" lambda_ref_ids="450 2 650 4" />\n</spectra_lib>')
+tex = material(tex, 3, '''<material id="3" name="white" type="diffuse">
+    <reflectance val="0.5">
+      <spectrum id="7" type="ref" addressing_mode_u="clamp" addressing_mode_v="clamp" filter="point" matrix="1 0 0 0 0 1 0 0 0 0 1 0 0 0 0 1"/>
+      <texture id="0" type="texref" matrix="2 0 0 0 0 2 0 0 0 0 1 0 0 0 0 1" addressing_mode_u="wrap" addressing_mode_v="wrap" />
+    </reflectance>
+  </material>''')
+tex = material(tex, 4, '''<material id="4" name="mapped_plastic" type="plastic">
+    <reflectance val="0.5">
+      <spectrum id="8" type="ref"/>
+    </reflectance>
+    <alpha val="0.2" />
+    <int_ior val="1.49" />
+    <ext_ior val="1.000277" />
+    <nonlinear val="0" />
+  </material>''')
+dst = os.path.join(folder, "statex_00001.xml")
+open(dst, "w", encoding="utf-8").write(tex)
+print("wrote", dst)

@@ -383,7 +383,7 @@ def _read_blobs(path):
     return out
 
 
-@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures", "jpg_textures", "test_spectral", "test_spectral+spectral", "spectral_plastic+spectral", "spectral_glass+spectral", "spectral_sky+spectral", "exr_sky", "thin_film", "thin_film+spectral", "thin_film_rough", "thin_film_rough+spectral"])
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures", "jpg_textures", "test_spectral", "test_spectral+spectral", "spectral_plastic+spectral", "spectral_glass+spectral", "spectral_sky+spectral", "exr_sky", "thin_film", "thin_film+spectral", "thin_film_rough", "thin_film_rough+spectral", "spectral_textures", "spectral_textures+spectral"])
 def test_cpp_scene_loader_produces_the_same_tables(scene_name, tmp_path):
     """hydracore3_amd/csrc/scene_loader.h (Hydra XML + VSGF + image4ub + IES in C++) == the Python fixture loader:
     every table byte for byte, matrices and light frames to float rounding (both invert in double)."""
@@ -407,6 +407,9 @@ def test_cpp_scene_loader_produces_the_same_tables(scene_name, tmp_path):
     assert named["specOffsetSz"] == np.asarray(sc.spec_offset_sz, np.uint32).tobytes()
     assert np.allclose(np.frombuffer(named["cieXYZ"], np.float32), S.cie_xyz_fit().reshape(-1), rtol=1e-6, atol=1e-9)
     assert list(np.frombuffer(named["camResponse"], np.int32)) == [*sc.cam_response_spectrum_id, sc.cam_response_type]
+    # spectra given by textures: bands and their resolved table entries
+    assert named["specTexIdsWavelengths"] == np.asarray(sc.spec_tex_ids_wavelengths, np.uint32).tobytes()
+    assert named["specTexOffsetSz"] == np.asarray(sc.spec_tex_offset_sz, np.uint32).tobytes()
     # thin films: the index vectors bit for bit; the tables come from the one film_precompute.h on both sides, over observer fits that differ in
     # the last place (RGB) - to rounding
     assert named["filmsThickness"] == np.asarray(sc.films_thickness, np.float32).tobytes()

@@ -355,7 +355,7 @@ def test_path_trace_from_input_rays_block_matches_oracle(cornell):
         assert np.array_equal(gpu.random_gens(), cpu.random_gens())
 
 
-@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures", "jpg_textures", "test_spectral", "test_spectral+spectral", "spectral_plastic+spectral", "spectral_glass+spectral", "spectral_sky+spectral", "exr_sky", "thin_film", "thin_film+spectral", "thin_film_rough", "legacy_materials+spectral"])
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "legacy_materials", "typed_materials", "env_map", "png_textures", "jpg_textures", "test_spectral", "test_spectral+spectral", "spectral_plastic+spectral", "spectral_glass+spectral", "spectral_sky+spectral", "exr_sky", "thin_film", "thin_film+spectral", "thin_film_rough", "legacy_materials+spectral", "spectral_textures+spectral"])
 def test_cpp_scene_ingestion_renders_like_the_python_path(scene_name, tmp_path):
     """hydra_hip_render: scene_loader.h (C++) -> C ABI -> frame, no Python in the loop; the frame equals the one rendered from the
     Python loader's tables (same tables up to float rounding of inverted matrices: the image bar applies)."""

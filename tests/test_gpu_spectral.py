@@ -367,3 +367,28 @@ def test_input_rays_in_spectral_mode():
             print(f"{name}, input rays, {channels} channels: per-ray L2 = {l2:.3e} (mean {oc.mean() - 0.25:.4f})")
             assert np.isfinite(og).all() and l2 < 1e-3 * max(float(np.abs(oc).mean()), 1.0) and float(np.mean(og[:, 0] - 0.25)) > 0.0
             assert np.mean(np.all(gpu.random_gens()[:n] == cpu.random_gens()[:n], axis=1)) > 0.995
+
+
+@pytest.mark.parametrize("layout", [0, 2])
+def test_spectra_given_by_textures(layout):
+    """KSPEC_SPD_TEX (SampleMatColorSpectrumTexture, integrator_spectrum.cpp:128-180; LoadSceneSpectrumData's lambda_ref_ids): the walls' reflectance
+    from five maps at 400 ... 720 nm (sampler attributes on the <spectrum> node), the plastic sphere's from two; wavelengths outside the bands read
+    zero; the interval search keeps its probes inside the table (spectrum.h:42-55 does not). The fixture against the oracle, and a scene loaded
+    for RGB rendering (bands unresolved) refused in spectral mode."""
+    from hydracore3_amd.api import HipIntegrator, HydraHipError
+    sc = load_hydra_xml(scene_path("spectral_textures"), 96, 96, spectral=True)
+    assert len(sc.spec_tex_ids_wavelengths) == 7 and sc.spec_tex_offset_sz[7] == (0, 5) and sc.spec_tex_offset_sz[8] == (5, 2)
+    gpu, cpu = _pair(sc, accel_layout=layout)
+    spp = 16
+    a, b = gpu.render(spp), cpu.render(spp)
+    l2 = _l2(a, b, spp)
+    same_rng = float(np.mean(np.all(gpu.random_gens() == cpu.random_gens(), axis=1)))
+    print(f"spectral textures, layout {layout}: per-pixel L2 = {l2:.3e} (mean {b[..., :3].mean() / spp:.4f}), identical generators {same_rng * 100:.2f} %")
+    assert np.isfinite(a).all() and a[..., :3].mean() > 0 and l2 < 1e-3 and same_rng > 0.99
+    plain = load_hydra_xml(SPECTRAL_XML, 96, 96, spectral=True)
+    assert _l2(HipIntegrator(plain).render(spp), a, spp) > 1e-2          # ... and the maps are in the frame
+    rgb = load_hydra_xml(scene_path("spectral_textures"), 32, 32, spectral=False)
+    HipIntegrator(rgb).render(1)                                         # RGB rendering never looks at the bands
+    rgb.spectral_mode = 1
+    with pytest.raises(HydraHipError, match="spectral"):
+        HipIntegrator(rgb)

@@ -362,7 +362,7 @@ HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V
 // lens stack (the host looks): their code is in the WIDE instantiations only, the others keep the registers of the narrow kernel (test_spectral:
 // 370 Mpaths/s narrow, 322 with everything compiled in)
 template <bool DEEP, bool FLAT, bool SWEEP, bool MOTION, bool WIDE>
-__global__ void __launch_bounds__(256, 3) pathTraceSpectralKernel(const DevScene S, const Job job)
+__global__ void __launch_bounds__(256, WIDE ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAVES) pathTraceSpectralKernel(const DevScene S, const Job job)
 {
   __shared__ uint stackMem[LDS_STACK * 256];
   const uint glane = blockIdx.x * 256u + threadIdx.x;

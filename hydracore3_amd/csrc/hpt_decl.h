@@ -52,7 +52,10 @@ struct Job
 #ifndef HPT_FILM_WAVES
 #define HPT_FILM_WAVES 3   // the film kernels (MODE 4 / 5 / 6)
 #endif
-#define HPT_PT_BOUNDS(DR, MODE) __launch_bounds__(256, ((DR) || (MODE) == 3) ? HPT_MIN_WAVES : ((MODE) >= 4 ? HPT_FILM_WAVES : HPT_FULL_WAVES))
+#ifndef HPT_DR_WAVES
+#define HPT_DR_WAVES HPT_MIN_WAVES   // the PathTraceDR megakernel
+#endif
+#define HPT_PT_BOUNDS(DR, MODE) __launch_bounds__(256, (DR) ? HPT_DR_WAVES : ((MODE) == 3 ? HPT_MIN_WAVES : ((MODE) >= 4 ? HPT_FILM_WAVES : HPT_FULL_WAVES)))
 template <bool STATS, bool DR, int MODE, bool DEEP, bool FLAT, bool MOTION = false, bool SWEEP = false>
 __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const Job job);
 

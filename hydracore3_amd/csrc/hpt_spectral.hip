@@ -17,6 +17,9 @@
 // output is the reference's stack of wavelength layers.
 #include <hip/hip_runtime.h>
 #include "hpt_decl.h"
+#ifndef HPT_SPEC_FILM
+#define HPT_SPEC_FILM 1      // 0: an A/B build without the thin-film branches (what they cost the scenes that have none)
+#endif
 
 namespace hpt {
 
@@ -232,7 +235,7 @@ HPT_DEV SpecEval materialEvalSpec(const DevScene& S, const MaterialRec& m, V4 wa
       if (dot(wm, v3(0.0f, 0.0f, 1.0f)) < 0.f) wm = (-1.0f) * wm;
       r.pdf = trPDF(wo, wm, alpha) / (4.0f * absf(dot(wo, wm)));
     }
-  } else if (m.mtype == MAT_TYPE_THIN_FILM) {                               // integrator_pt_mat.cpp:422-470: rough films only, the first wavelength only
+  } else if (HPT_SPEC_FILM && m.mtype == MAT_TYPE_THIN_FILM) {                               // integrator_pt_mat.cpp:422-470: rough films only, the first wavelength only
     BsdfE e; e.val = v3(0, 0, 0); e.pdf = 0.0f; e.dval = v3(0, 0, 0);
     filmEvalBranch(S, m, uv, waves.x, l, v, gn, texColor3, e);
     r.val = v4(e.val.x, 0.0f, 0.0f, 0.0f); r.pdf = e.pdf;
@@ -347,7 +350,7 @@ HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V
       r.pdf = trPDF(wo, wm, alpha) / (4.0f * absf(dot(wo, wm)));
       r.flags = RAY_FLAG_HAS_NON_SPEC;
     }
-  } else if (m.mtype == MAT_TYPE_THIN_FILM) {                               // integrator_pt_mat.cpp:197-249
+  } else if (HPT_SPEC_FILM && m.mtype == MAT_TYPE_THIN_FILM) {                               // integrator_pt_mat.cpp:197-249
     const FilmArgs fa = filmArgs(S, m, uv, waves.x);
     BsdfS a; a.val = v3(0, 0, 0); a.dval = v3(0, 0, 0); a.pdf = pdf0; a.dir = v3(0, 1, 0); a.flags = flags0; a.ior = 1.0f;
     if (smax(m.data[1], m.data[0]) < 1e-3f) filmSmoothSampleAndEval(m, fa, prevIor, rands, v, gn, a);

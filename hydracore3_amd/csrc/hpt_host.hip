@@ -97,7 +97,7 @@ struct hpt_ctx
   std::vector<void*> texData; std::vector<TexRec> hTextures;
   DevBuf<float> dSpecValues; DevBuf<uint> dSpecOffsetSz; DevBuf<float4> dCieXYZ;   // spectral tables (m_spec_values, m_spec_offset_sz, m_cie_xyz)
   bool spectralOk = false; std::string spectralWhyNot;   // whether the uploaded scene is within the spectral kernel's scope
-  bool spectralWideMats = true;                          // a reachable material needs the WIDE instantiations of the spectral kernel (hpt_spectral.hip)
+  bool spectralGltfMats = true, spectralHeavyMats = true;   // a reachable material needs scope 1 (gltf) / scope 2 (glass, blend, normal map) of the spectral kernel (hpt_spectral.hip)
   // thin films (integrator_pt.h:587-590): the tables a film material indexes, and what the uploaded materials say about them
   DevBuf<float> dFilmsEtaK, dPrecompFilms; DevBuf<uint> dFilmsSpecId, dSpecTexIdsWavelengths, dSpecTexOffsetSz;
   std::vector<uint> hFilmsSpecId; size_t numFilmsEtaK = 0, numPrecompFilms = 0; uint numSpectraHost = 0;
@@ -1117,7 +1117,7 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
     for (uint i = 0; i < d->numMaterials; i++)
       for (int k2 = 0; k2 < 4; k2++) if (d->specValues && !specIdOk(mm[i].spdid[k2])) return c->fail(HPT_ERR_ARG, "material " + std::to_string(i) + " refers to a spectrum that does not exist");
     // (every material type of the RGB kernels has its branch in the spectral kernel, blends and normal maps included.) Which instantiations a
-    // spectral call needs (hpt_spectral.hip: WIDE) is decided by the materials a hit can REACH: m_matIdByPrimId through the remap list of every
+    // spectral call needs (hpt_spectral.hip: SCOPE) is decided by the materials a hit can REACH: m_matIdByPrimId through the remap list of every
     // instance of the mesh (RemapMaterialId), then through blends - an entry of the library nothing resolves to (the reference's spectral fixture
     // keeps an unused legacy material 0) does not widen the kernel
     {
@@ -1140,10 +1140,12 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
           if (id < d->numMaterials) reached[id] = 1;
         }
       }
-      c->spectralWideMats = false;
-      for (uint i = 0; i < d->numMaterials; i++)
-        if (reached[i] && (mm[i].mtype == MAT_TYPE_GLTF || mm[i].mtype == MAT_TYPE_GLASS || mm[i].mtype == MAT_TYPE_BLEND || (mm[i].mtype != MAT_TYPE_LIGHT_SOURCE && mm[i].texid[1] != 0xFFFFFFFFu)))
-          c->spectralWideMats = true;                          // (a reached blend is wide by itself, whatever its leaves are)
+      c->spectralGltfMats = c->spectralHeavyMats = false;
+      for (uint i = 0; i < d->numMaterials; i++) {
+        if (!reached[i]) continue;
+        if (mm[i].mtype == MAT_TYPE_GLTF) c->spectralGltfMats = true;
+        if (mm[i].mtype == MAT_TYPE_GLASS || mm[i].mtype == MAT_TYPE_BLEND || (mm[i].mtype != MAT_TYPE_LIGHT_SOURCE && mm[i].texid[1] != 0xFFFFFFFFu)) c->spectralHeavyMats = true;   // (a reached blend: whatever its leaves are)
+      }
     }
     const LightRec* ll2 = (const LightRec*)d->lights;
     for (uint i = 0; i < d->numLights; i++) {
@@ -1232,7 +1234,11 @@ extern "C" int hpt_update_materials(hpt_ctx* c, size_t first, size_t count, cons
     film_scan(c);
   }
   if (!lean_materials((const MaterialRec*)mats, count)) c->leanMaterials = false;      // (an update can only widen the set of BSDFs in use)
-  for (size_t i = 0; i < count; i++) { const MaterialRec& m = ((const MaterialRec*)mats)[i]; if (m.mtype == MAT_TYPE_GLTF || m.mtype == MAT_TYPE_GLASS || m.mtype == MAT_TYPE_BLEND || (m.mtype != MAT_TYPE_LIGHT_SOURCE && m.texid[1] != 0xFFFFFFFFu)) c->spectralWideMats = true; }
+  for (size_t i = 0; i < count; i++) {
+    const MaterialRec& m = ((const MaterialRec*)mats)[i];
+    if (m.mtype == MAT_TYPE_GLTF) c->spectralGltfMats = true;
+    if (m.mtype == MAT_TYPE_GLASS || m.mtype == MAT_TYPE_BLEND || (m.mtype != MAT_TYPE_LIGHT_SOURCE && m.texid[1] != 0xFFFFFFFFu)) c->spectralHeavyMats = true;
+  }
   (void)hipSetDevice(c->device);
   HIPCHK(c, hipMemcpy(c->dMaterials.p + first, mats, count * sizeof(MaterialRec), hipMemcpyHostToDevice));
   return HPT_OK;
@@ -1344,7 +1350,7 @@ static void launchPT(const DevScene& S, const Job& job, int blocks, hipStream_t 
   }
 }
 
-template <bool WIDE>
+template <int WIDE>
 static void launchSpectral(const DevScene& S, const Job& job, int blocks, hipStream_t st, bool deep)
 {
   const dim3 sg(blocks), sb(256);
@@ -1423,11 +1429,10 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
     const bool sdeep = megaStackNeeded(c) > (uint)LDS_STACK;
     c->lastSchedule = 1;
     HIPCHK(c, hipEventRecord(c->ev0, st));
-    // the wide instantiations when the scene holds what the narrow ones compile out (hpt_spectral.hip)
-    bool wide = c->S.lensCount != 0u || c->S.envTexId != 0xFFFFFFFFu || c->S.envCamBackId != 0xFFFFFFFFu;
-    for (const uint g : c->hLightGeom) wide = wide || g == LIGHT_GEOM_ENV;
-    wide = wide || c->spectralWideMats;
-    if (wide) launchSpectral<true>(c->S, job, sblocks, st, sdeep); else launchSpectral<false>(c->S, job, sblocks, st, sdeep);
+    // the scope the scene needs (hpt_spectral.hip: SCOPE): the narrowest instantiations that hold it
+    bool heavy = c->S.lensCount != 0u || c->S.envTexId != 0xFFFFFFFFu || c->S.envCamBackId != 0xFFFFFFFFu || c->spectralHeavyMats;
+    for (const uint g : c->hLightGeom) heavy = heavy || g == LIGHT_GEOM_ENV;
+    if (heavy) launchSpectral<2>(c->S, job, sblocks, st, sdeep); else if (c->spectralGltfMats) launchSpectral<1>(c->S, job, sblocks, st, sdeep); else launchSpectral<0>(c->S, job, sblocks, st, sdeep);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, st));
     return HPT_OK;

@@ -89,7 +89,7 @@ HPT_DEV V4 matParamSpectrum(const DevScene& S, const MaterialRec& m, V4 waves, i
   return v4s(m.data[paramId]);
 }
 // LightIntensity with the light's spectrum (integrator_pt_lgt.cpp:109-173): the scalar factors are those of the RGB path
-template <bool WIDE>
+template <int SCOPE>
 HPT_DEV V4 lightIntensitySpec(const DevScene& S, const LightRec& L, V4 waves, V3 a_rayPos, V3 a_rayDir)
 {
   V4 lightColor = ld4(L.intensity);
@@ -112,7 +112,7 @@ HPT_DEV V4 lightIntensitySpec(const DevScene& S, const LightRec& L, V4 waves, V3
       lightColor = lightColor * texSample(S.textures, L.texId, v2(ndc.x * 0.5f + 0.5f, ndc.y * 0.5f + 0.5f));
     }
   }
-  else if (WIDE && L.texId != 0xFFFFFFFFu)                                   // :163-170: the environment map seen along the shadow ray (all four components of the texel)
+  else if (SCOPE >= 2 && L.texId != 0xFFFFFFFFu)                                   // :163-170: the environment map seen along the shadow ray (all four components of the texel)
     lightColor = lightColor * texSample(S.textures, L.texId, mulRows2x4(L.samplerRow0, L.samplerRow1, sphereMapTo2DTexCoord(a_rayDir)));
   return lightColor;
 }
@@ -188,13 +188,13 @@ struct SpecSample { V4 val; V3 dir; float pdf; uint flags; float ior; };
 // MaterialEval, spectral (integrator_pt_mat.cpp:405-420, 471-482 with cmat_conductor.h:103-137, cmat_diffuse.h:27-39)
 // the "four scalar parameters" of a gltf material (integrator_pt_mat.cpp:151-167; hpt_shade.h: leafTextures)
 HPT_DEV V3 fourParamsSpec(const DevScene& S, const MaterialRec& m, V2 uv) { V3 t3, four; leafTextures(S, m, uv, t3, four); return four; }
-// n: the shading normal (the leaf's normal map applied), gn: the geometric one (films); WIDE: see pathTraceSpectralKernel
-template <bool WIDE>
+// n: the shading normal (the leaf's normal map applied), gn: the geometric one (films); SCOPE: see pathTraceSpectralKernel
+template <int SCOPE>
 HPT_DEV SpecEval materialEvalSpec(const DevScene& S, const MaterialRec& m, V4 waves, V3 l, V3 v, V3 n, V3 gn, V4 texColor, V2 uv)
 {
   const V3 texColor3 = v3(texColor.x, texColor.y, texColor.z);
   SpecEval r; r.val = v4s(0.0f); r.pdf = 0.0f;
-  if (WIDE && m.mtype == MAT_TYPE_GLTF) {
+  if (SCOPE >= 1 && m.mtype == MAT_TYPE_GLTF) {
     // gltfEval on float4 (integrator_pt_mat.cpp:385-394): the base colour times the texel is taken as four spectral samples as it is (the
     // reference's loader warns about such colours); nothing but the colours depends on the channel, so the four wavelengths are two passes
     // through the RGB routine - (x, y, z), then w in every slot
@@ -265,19 +265,19 @@ HPT_DEV SpecEval materialEvalTreeSpec(const DevScene& S, uint rootId, V4 waves, 
     }
     V3 n = gn; float bm = 1.0f;
     if (m.texid[1] != 0xFFFFFFFFu) { n = bumpNormal(S, m, gn, tan, uv); bm = bumpCosMult(l, gn, n); }
-    const SpecEval cv = materialEvalSpec<true>(S, m, waves, l, v, n, gn, texColor, uv);
+    const SpecEval cv = materialEvalSpec<2>(S, m, waves, l, v, n, gn, texColor, uv);
     res.val = res.val + cv.val * (curW * bm); res.pdf += cv.pdf * curW;
   } while (top > 0);
   return res;
 }
 // MaterialSampleAndEval, spectral (integrator_pt_mat.cpp:184-196, 252-263 with cmat_conductor.h:7-100, cmat_diffuse.h:8-24)
 // n: the shading normal, gn: the geometric one (legacy glass and films sample about it); pdf0: what the blend descent left in the sample's pdf
-template <bool WIDE>
+template <int SCOPE>
 HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V4 waves, V4 rands, V3 v, V3 n, V3 gn, V4 texColor, uint flags0, float prevIor, V2 uv, float pdf0)
 {
   const V3 texColor3 = v3(texColor.x, texColor.y, texColor.z);
   SpecSample r; r.val = v4s(0.0f); r.pdf = pdf0; r.dir = v3(0, 1, 0); r.flags = flags0; r.ior = 1.0f;
-  if (WIDE && m.mtype == MAT_TYPE_GLASS) {                                  // glassSampleAndEval on float4 (cmat_glass.h:236-277): the geometric normal (integrator_pt_mat.cpp:178-183)
+  if (SCOPE >= 2 && m.mtype == MAT_TYPE_GLASS) {                                  // glassSampleAndEval on float4 (cmat_glass.h:236-277): the geometric normal (integrator_pt_mat.cpp:178-183)
     const V4 colorReflect = ld4(m.colors[0]), colorTransp = ld4(m.colors[1]);
     const float ior = m.data[2];
     const V3 rayDir = (-1.0f) * v;
@@ -291,7 +291,7 @@ HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V
     r.dir = dir; r.pdf = 1.0f;
     return r;
   }
-  if (WIDE && m.mtype == MAT_TYPE_GLTF) {                                   // gltfSampleAndEval on float4 (integrator_pt_mat.cpp:170-176), as in materialEvalSpec
+  if (SCOPE >= 1 && m.mtype == MAT_TYPE_GLTF) {                                   // gltfSampleAndEval on float4 (integrator_pt_mat.cpp:170-176), as in materialEvalSpec
     const V4 base = ld4(m.colors[GLTF_COLOR_BASE]) * texColor, mc = ld4(m.colors[GLTF_COLOR_METAL]), cc = ld4(m.colors[GLTF_COLOR_COAT]);
     const V3 four = fourParamsSpec(S, m, uv);
     BsdfS a; a.val = v3(0, 0, 0); a.dval = v3(0, 0, 0); a.pdf = pdf0; a.dir = v3(0, 1, 0); a.flags = flags0; a.ior = 1.0f;
@@ -361,11 +361,13 @@ HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V
 }
 
 // One thread per pixel of the call, its passes one after the other (the pixel's generator continues from pass to pass as in the RGB kernels).
-// WIDE: the scene needs more than the reference's spectral fixtures do - gltf / legacy glass surfaces, blends, normal maps, environment maps or a
-// lens stack (the host looks): their code is in the WIDE instantiations only, the others keep the registers of the narrow kernel (test_spectral:
-// 370 Mpaths/s narrow, 322 with everything compiled in)
-template <bool DEEP, bool FLAT, bool SWEEP, bool MOTION, bool WIDE>
-__global__ void __launch_bounds__(256, WIDE ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAVES) pathTraceSpectralKernel(const DevScene S, const Job job)
+// SCOPE: what the scene needs (the host looks at the materials a hit can reach, the lights, the camera): 0 = what the reference's spectral fixtures
+// use (diffuse, conductor, plastic, dielectric, thin films, analytic lights, a sky spectrum); 1 = + gltf surfaces (legacy hydra_material scenes);
+// 2 = + legacy glass, blends, normal maps, environment maps, the lens stack. The code of a wider scope costs registers whether it runs or not:
+// test_spectral 446 Mpaths/s in scope 0 against 322 with everything compiled in; the Cornell box under spectral mode 2153 in scope 1 against
+// 1488 in scope 2 (scopes 0 / 1 are built for 4 waves per SIMD, scope 2 for 3).
+template <bool DEEP, bool FLAT, bool SWEEP, bool MOTION, int SCOPE>
+__global__ void __launch_bounds__(256, SCOPE >= 2 ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAVES) pathTraceSpectralKernel(const DevScene S, const Job job)
 {
   __shared__ uint stackMem[LDS_STACK * 256];
   const uint glane = blockIdx.x * 256u + threadIdx.x;
@@ -405,7 +407,7 @@ __global__ void __launch_bounds__(256, WIDE ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAV
         waves = v4s(ip.w);
       } else {
         const V4 lens = rng_float4(gen);                                     // GetRandomNumbersLens, then GetRandomNumbersSpec (integrator_pt.cpp:114-118)
-        cameraRay<WIDE>(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
+        cameraRay<(SCOPE >= 2)>(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
         if (MOTION) pathTime = rng_float1(gen);                              // GetRandomNumbersTime, before the wavelength (integrator_pt.cpp:114-118)
         waves = sampleWavelengths(rng_float1(gen), LAMBDA_MIN, LAMBDA_MAX);
       }
@@ -455,7 +457,7 @@ __global__ void __launch_bounds__(256, WIDE ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAV
           V4 texColor = v4(1, 1, 1, 1);
           if (mtype != MAT_TYPE_LIGHT_SOURCE) texColor = texSample(S.textures, m.texid[0], mulRows2x4(m.row0[0], m.row1[0], uv));
           V3 hitTang = v3(0, 0, 0);                                          // only materials with a normal map (or a blend that may hold one) read it
-          if (WIDE && (mtype == MAT_TYPE_BLEND || (mtype != MAT_TYPE_LIGHT_SOURCE && m.texid[1] != 0xFFFFFFFFu))) hitTang = hitTangent(S, A, B, C, vertOffset, wA, uvx, uvy, nm, flipNorm, (MOTION && (S.motion & 2u) == 0u) ? S.normMat2 + 12 * instId : nullptr, pathTime);
+          if (SCOPE >= 2 && (mtype == MAT_TYPE_BLEND || (mtype != MAT_TYPE_LIGHT_SOURCE && m.texid[1] != 0xFFFFFFFFu))) hitTang = hitTangent(S, A, B, C, vertOffset, wA, uvx, uvy, nm, flipNorm, (MOTION && (S.motion & 2u) == 0u) ? S.normMat2 + 12 * instId : nullptr, pathTime);
 
           // -- kernel_SampleLightSource (integrator_pt.cpp:350-424) --
           V4 shade = v4s(0.0f);
@@ -466,14 +468,14 @@ __global__ void __launch_bounds__(256, WIDE ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAV
             const int lightId = min((int)floorf(rndId * float(nLights)), nLights - 1);
             if (lightId >= 0 && mtype != MAT_TYPE_LIGHT_SOURCE) {
               const LightRec& L = S.lights[lightId];
-              const LightSam ls = (WIDE && L.geomType == LIGHT_GEOM_ENV) ? envLightSampleRev(S, L, v3(r4.x, r4.y, r4.z), hitPos) : lightSampleRev(L, v3(r4.x, r4.y, r4.z), hitPos);
+              const LightSam ls = (SCOPE >= 2 && L.geomType == LIGHT_GEOM_ENV) ? envLightSampleRev(S, L, v3(r4.x, r4.y, r4.z), hitPos) : lightSampleRev(L, v3(r4.x, r4.y, r4.z), hitPos);
               const V3 dlt = hitPos - ls.pos;
               const float hitDist = sqrtf_(dot(dlt, dlt));
               const V3 shadowRayDir = normalize(ls.pos - hitPos);
               const V3 shadowRayPos = hitPos + hitNorm * smax(maxcomp(hitPos), 1.0f) * 5e-6f;
               const bool inIllumArea = (dot(shadowRayDir, ls.norm) < 0.0f) || ls.isOmni || ls.hasIES;
               if (inIllumArea) {
-                const SpecEval bv = WIDE ? materialEvalTreeSpec(S, matId, waves, shadowRayDir, vdir, hitNorm, hitTang, uv) : materialEvalSpec<false>(S, m, waves, shadowRayDir, vdir, hitNorm, hitNorm, texColor, uv);
+                const SpecEval bv = SCOPE >= 2 ? materialEvalTreeSpec(S, matId, waves, shadowRayDir, vdir, hitNorm, hitTang, uv) : materialEvalSpec<SCOPE>(S, m, waves, shadowRayDir, vdir, hitNorm, hitNorm, texColor, uv);
                 const float cosThetaOut = smax(dot(shadowRayDir, hitNorm), 0.0f);
                 float lgtPdfW = (1.0f / float(nLights)) * lightEvalPDF(L, shadowRayPos, shadowRayDir, ls.pos, ls.norm, ls.pdf);
                 float misWeight = (S.integratorType == INTEGRATOR_MIS_PT) ? misWeightHeuristic(lgtPdfW, bv.pdf) : 1.0f;
@@ -481,7 +483,7 @@ __global__ void __launch_bounds__(256, WIDE ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAV
                 else if (L.geomType == LIGHT_GEOM_POINT) misWeight = 1.0f;
                 const bool isDirectLight = (flags & RAY_FLAG_HAS_NON_SPEC) == 0;
                 if ((S.renderLayer == FB_DIRECT && !isDirectLight) || (S.renderLayer == FB_INDIRECT && isDirectLight)) misWeight = 0.0f;
-                const V4 lightColor = lightIntensitySpec<WIDE>(S, L, waves, shadowRayPos, shadowRayDir);
+                const V4 lightColor = lightIntensitySpec<SCOPE>(S, L, waves, shadowRayPos, shadowRayDir);
                 shade = ((lightColor * bv.val) / lgtPdfW) * cosThetaOut * misWeight;
                 wantShadow = true; shPos = shadowRayPos; shDir = shadowRayDir; shFar = hitDist * 0.9995f;
               }
@@ -497,7 +499,7 @@ __global__ void __launch_bounds__(256, WIDE ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAV
               const LightRec& L = S.lights[lightId];
               const float lightCos = dot(rdir, ld3(L.norm));
               const float atten = (lightCos < 0.0f || L.geomType == LIGHT_GEOM_SPHERE) ? 1.0f : 0.0f;
-              lightInt = lightIntensitySpec<WIDE>(S, L, waves, rpos, rdir) * atten;
+              lightInt = lightIntensitySpec<SCOPE>(S, L, waves, rpos, rdir) * atten;
             }
             if (S.integratorType == INTEGRATOR_MIS_PT) {
               if (bounce > 0 && lightId != 0xFFFFFFFFu) {
@@ -514,7 +516,7 @@ __global__ void __launch_bounds__(256, WIDE ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAV
           } else {
             // blend descent (BlendSampleAndEval, integrator_pt_mat.cpp:23-54, 123-130): one generator step per layer BEFORE the float4
             const MaterialRec* lm = &m; uint lt = mtype; V4 ltexColor = texColor; float pdf0 = 1.0f;
-            if (WIDE && mtype == MAT_TYPE_BLEND) {
+            if (SCOPE >= 2 && mtype == MAT_TYPE_BLEND) {
               while (lt == MAT_TYPE_BLEND) {
                 const V4 wd = texSample(S.textures, lm->texid[0], mulRows2x4(lm->row0[0], lm->row1[0], uv));
                 const float weight = lm->data[0] * wd.x;
@@ -526,10 +528,10 @@ __global__ void __launch_bounds__(256, WIDE ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAV
               ltexColor = texSample(S.textures, lm->texid[0], mulRows2x4(lm->row0[0], lm->row1[0], uv));
             }
             const MaterialRec& ml = *lm;
-            const bool leafBump = WIDE && ml.texid[1] != 0xFFFFFFFFu;                // the leaf's normal map bends the shading normal (:131-139)
+            const bool leafBump = SCOPE >= 2 && ml.texid[1] != 0xFFFFFFFFu;                // the leaf's normal map bends the shading normal (:131-139)
             const V3 sNorm = leafBump ? bumpNormal(S, ml, hitNorm, hitTang, uv) : hitNorm;
             const V4 rands = rng_float4(gen);                                // GetRandomNumbersMats
-            SpecSample ms = materialSampleSpec<WIDE>(S, ml, waves, rands, vdir, sNorm, hitNorm, ltexColor, (flags & 0xFF000000u) | matId, misIor, uv, pdf0);
+            SpecSample ms = materialSampleSpec<SCOPE>(S, ml, waves, rands, vdir, sNorm, hitNorm, ltexColor, (flags & 0xFF000000u) | matId, misIor, uv, pdf0);
             if (lt == MAT_TYPE_DIELECTRIC || lt == MAT_TYPE_THIN_FILM || lt == MAT_TYPE_GLASS) misIor = ms.ior;
             if (leafBump) {                                                  // the caller multiplies by the cosine to the geometric normal (:298-303)
               const float c1 = absf(dot(ms.dir, hitNorm)), c2 = absf(dot(ms.dir, sNorm));
@@ -563,7 +565,7 @@ __global__ void __launch_bounds__(256, WIDE ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAV
       alive = false;
       if ((flags & RAY_FLAG_OUT_OF_SCENE) != 0) {                            // kernel_HitEnvironment
         V4 env = ld4(S.envColor);
-        if (WIDE) env = environmentRadianceSpec(S, rdir, waves, misPdf, flags, XY);
+        if (SCOPE >= 2) env = environmentRadianceSpec(S, rdir, waves, misPdf, flags, XY);
         else if (S.envSpecId != 0xFFFFFFFFu) env = sampleUniformSpectrum(S.specValues, S.specOffsetSz[2u * S.envSpecId], waves) * (S.envSpecMult / 106.856895f);
         if (S.integratorType == INTEGRATOR_STUPID_PT) accum = thr * env; else accum = accum + thr * env;
       }
@@ -588,25 +590,28 @@ __global__ void __launch_bounds__(256, WIDE ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAV
   }
 }
 
-// one translation unit per scope (-DHPT_SPEC_INST=1: narrow, 2: wide; 0: both), see __graft_entry__.build
+// one translation unit per scope (-DHPT_SPEC_INST=1 / 2 / 3: scope 0 / 1 / 2; 0: all), see __graft_entry__.build
 #ifndef HPT_SPEC_INST
 #define HPT_SPEC_INST 0
 #endif
-#define HPT_SPEC(WIDE) \
-  template __global__ void pathTraceSpectralKernel<false, false, false, false, WIDE>(const DevScene, const Job); \
-  template __global__ void pathTraceSpectralKernel<true,  false, false, false, WIDE>(const DevScene, const Job); \
-  template __global__ void pathTraceSpectralKernel<false, true,  false, false, WIDE>(const DevScene, const Job); \
-  template __global__ void pathTraceSpectralKernel<true,  true,  false, false, WIDE>(const DevScene, const Job); \
-  template __global__ void pathTraceSpectralKernel<false, false, true,  false, WIDE>(const DevScene, const Job); \
-  template __global__ void pathTraceSpectralKernel<false, false, false, true,  WIDE>(const DevScene, const Job);   /* moving instances */ \
-  template __global__ void pathTraceSpectralKernel<true,  false, false, true,  WIDE>(const DevScene, const Job); \
-  template __global__ void pathTraceSpectralKernel<false, true,  false, true,  WIDE>(const DevScene, const Job); \
-  template __global__ void pathTraceSpectralKernel<true,  true,  false, true,  WIDE>(const DevScene, const Job);
+#define HPT_SPEC(SCOPE) \
+  template __global__ void pathTraceSpectralKernel<false, false, false, false, SCOPE>(const DevScene, const Job); \
+  template __global__ void pathTraceSpectralKernel<true,  false, false, false, SCOPE>(const DevScene, const Job); \
+  template __global__ void pathTraceSpectralKernel<false, true,  false, false, SCOPE>(const DevScene, const Job); \
+  template __global__ void pathTraceSpectralKernel<true,  true,  false, false, SCOPE>(const DevScene, const Job); \
+  template __global__ void pathTraceSpectralKernel<false, false, true,  false, SCOPE>(const DevScene, const Job); \
+  template __global__ void pathTraceSpectralKernel<false, false, false, true,  SCOPE>(const DevScene, const Job);   /* moving instances */ \
+  template __global__ void pathTraceSpectralKernel<true,  false, false, true,  SCOPE>(const DevScene, const Job); \
+  template __global__ void pathTraceSpectralKernel<false, true,  false, true,  SCOPE>(const DevScene, const Job); \
+  template __global__ void pathTraceSpectralKernel<true,  true,  false, true,  SCOPE>(const DevScene, const Job);
 #if HPT_SPEC_INST == 0 || HPT_SPEC_INST == 1
-HPT_SPEC(false)
+HPT_SPEC(0)
 #endif
 #if HPT_SPEC_INST == 0 || HPT_SPEC_INST == 2
-HPT_SPEC(true)
+HPT_SPEC(1)
+#endif
+#if HPT_SPEC_INST == 0 || HPT_SPEC_INST == 3
+HPT_SPEC(2)
 #endif
 
 } // namespace hpt

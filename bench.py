@@ -5,7 +5,7 @@
 
 A *step* is one PathTraceBlock call over the whole frame (W*H pixels x spp passes, MIS path tracing) with the framebuffer,
 RNG states and scene resident in HBM. N = 1 runs BASELINE.json configs[1] (scenes/test_035 Cornell box, 1024 x 1024, 1024 spp)
-and appends ("also") short runs of configs[2] (1M-triangle interior, wavefront schedule) and configs[3] (PathTraceDR + Adam).
+and appends ("also") short runs of configs[2] (1M-triangle interior, wavefront schedule), configs[3] (PathTraceDR + Adam), the reference's spectral fixture and a thin-film fixture.
 
 N > 1: one rank per GPU (the scene is replicated, no data-path collective but ONE RCCL reduce(SUM) of the framebuffer per step).
 Started plainly (`python bench.py --gpus N`, WORLD_SIZE unset) the script spawns its N ranks itself through
@@ -456,6 +456,26 @@ def run_dr(args, workload, rank, world, dev, dist, backend, steps, warmup, spp_a
             "roofline": roof}
 
 
+def run_fixture(dev, scene_name, spectral, steps=3, size=1024, spp=64):
+    """An `also` entry for a fixture scene of the reference's feature branches (spectral rendering, thin films): `steps` PathTraceBlock calls on a
+    device-resident frame, timed with HIP events around each launch (HipIntegrator.last_kernel_ms)."""
+    import numpy as np
+    from hydracore3_amd.api import HipIntegrator
+    from hydracore3_amd.scene import load_hydra_xml
+    sc = load_hydra_xml(os.path.join(ROOT, "tests", "golden", "scenes", scene_name, "statex_00001.xml"), size, size, spectral=spectral)
+    integ = HipIntegrator(sc, device=dev.index)
+    frame = integ.dev_array(np.zeros((size, size, 4), np.float32))
+    integ.path_trace_block_dev(frame.ptr, 4)                       # warm-up
+    ms = []
+    for _ in range(steps):
+        integ.path_trace_block_dev(frame.ptr, spp)
+        ms.append(integ.last_kernel_ms())
+    mean_ms = sum(ms) / len(ms)
+    return {"workload": f"tests/golden/scenes/{scene_name} {size}x{size} @ {spp} spp, forward PathTraceBlock, " + ("m_spectral_mode = 1" if spectral else "RGB"),
+            "metric": "Mpaths/s (fwd PathTraceBlock, MIS path tracing)", "value": round(size * size * spp / mean_ms / 1e3, 2), "unit": "Mpaths/s", "steps": steps,
+            "ms_per_step": round(mean_ms, 3), "paths_per_step": size * size * spp, "sharding": "single GPU", "sharded_frame_verified": None, "roofline": None}
+
+
 def compact(r):
     """An `also` entry: the numbers of a secondary workload without the contract's boilerplate."""
     if r is None:
@@ -567,6 +587,9 @@ def main():
             also.append(compact(r))
             r = run_dr(args, "dr", rank, world, dev, dist, backend, 3, 1, 1024)
             also.append(compact(r))
+            # the reference's spectral fixture under m_spectral_mode = 1, and the thin-film fixture (RGB): short, kernel-timed
+            also.append(run_fixture(dev, "test_spectral", True))
+            also.append(run_fixture(dev, "thin_film", False))
         if out is not None and also:
             out["also"] = [a for a in also if a is not None]
 

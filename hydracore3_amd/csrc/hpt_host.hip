@@ -246,8 +246,11 @@ extern "C" int hpt_device_info(hpt_ctx* c, int* numCUs, int* wavefront, char* na
 extern "C" int hpt_decode_jpeg(const uint8_t* file, uint64_t fileSize, uint32_t* outWidth, uint32_t* outHeight, uint8_t* outRGBA8, uint64_t outCapacity)
 {
   if (!file || !outWidth || !outHeight) return HPT_ERR_ARG;
-  std::vector<uint8_t> f(file, file + fileSize), rgba; std::string err; uint32_t w = 0, h = 0;
-  if (!hydra_hip::jpeg::decode(f, w, h, rgba, err)) return HPT_ERR_UNSUPPORTED;
+  std::vector<uint8_t> rgba; std::string err; uint32_t w = 0, h = 0;
+  try {                                                        // (nothing throws across the C boundary)
+    std::vector<uint8_t> f(file, file + fileSize);
+    if (!hydra_hip::jpeg::decode(f, w, h, rgba, err)) return HPT_ERR_UNSUPPORTED;
+  } catch (const std::exception&) { return HPT_ERR_UNSUPPORTED; }
   *outWidth = w; *outHeight = h;
   if (!outRGBA8) return HPT_OK;                                // (a size query)
   if (outCapacity < rgba.size()) return HPT_ERR_ARG;
@@ -264,12 +267,13 @@ extern "C" int hpt_film_precompute(const hpt_film_params* fp, float* outTable, u
   p.thickness = fp->thickness; p.thicknessMap = fp->thicknessMap; p.thicknessMin = fp->thicknessMin; p.thicknessMax = fp->thicknessMax;
   p.specValues = fp->specValues; p.specOffsetSz = fp->specOffsetSz; p.numSpectra = fp->numSpectra; p.cieXYZ = fp->cieXYZ;
   if (p.layers < 1 || p.layers > hydra_hip::film::MAX_LAYERS) return HPT_ERR_ARG;
+  if (p.specValues && !p.specOffsetSz) return HPT_ERR_ARG;
   const bool pre = hydra_hip::film::precomputed(p);
   if (outPrecomputed) *outPrecomputed = pre ? 1 : 0;
   *outCount = pre ? (uint64_t)hydra_hip::film::tableSize(p) : 0u;
   if (!pre || !outTable) return HPT_OK;                        // (a size query)
   if (outCapacity < *outCount) return HPT_ERR_ARG;
-  return hydra_hip::film::precompute(p, outTable) ? HPT_OK : HPT_ERR_ARG;
+  try { return hydra_hip::film::precompute(p, outTable) ? HPT_OK : HPT_ERR_ARG; } catch (const std::exception&) { return HPT_ERR_ARG; }
 }
 
 // ---- mi::fresnel_coat_precompute for the scene loaders (host only, no device needed) --------------------------------------------------------

@@ -98,6 +98,7 @@ struct Decoder
     const int prec = u8(); H = u16(); W = u16(); nComp = u8();
     if (prec != 8) return fail("jpeg: only 8-bit samples are read");
     if (W <= 0 || H <= 0) return fail("jpeg: empty frame");
+    if ((uint64_t)W * (uint64_t)H > (uint64_t(1) << 28)) return fail("jpeg: frames beyond 2^28 pixels are not read");   // (coefficients and planes are held whole)
     if (nComp != 1 && nComp != 3) return fail("jpeg: only grey and YCbCr images are read");
     hmax = vmax = 1;
     for (int i = 0; i < nComp; i++) {

@@ -840,3 +840,20 @@ def test_thin_film_airy_identities_and_tables():
     t = rgb.precomp_thin_films.reshape(4, 180, 3)
     assert np.all(np.abs(t[0] + t[1] - 1.0) < 2e-3) and np.all(np.abs(t[2][:100] + t[3][:100] - 1.0) < 2e-3) and t[0].min() >= 0.0 and t[0].max() <= 1.0
     assert np.ptp(t[0, 0]) > 0.01                                        # ... and it is coloured: interference
+
+
+def test_jpeg_reader_refuses_what_it_does_not_read(tmp_path):
+    """Truncated, oversized and non-Huffman files come back as an error code through the C ABI, never as an exception or a crash."""
+    import ctypes as C
+    import struct
+    from hydracore3_amd.api import load_library
+    lib = load_library()
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    def rc(raw):
+        buf = np.frombuffer(raw, np.uint8) if len(raw) else np.zeros(1, np.uint8)
+        return lib.hpt_decode_jpeg(buf.ctypes.data, len(raw), C.byref(w), C.byref(h), None, 0)
+    assert rc(b"") != 0 and rc(b"\xff\xd8\xff\xd9") != 0
+    sof = lambda marker, hh, ww: b"\xff" + bytes([marker]) + struct.pack(">HBHHB", 11, 8, hh, ww, 1) + b"\x01\x11\x00"
+    assert rc(b"\xff\xd8" + sof(0xC0, 65535, 65535) + b"\xff\xd9") != 0          # 2^32 pixels: refused before anything is allocated
+    assert rc(b"\xff\xd8" + sof(0xC9, 8, 8) + b"\xff\xd9") != 0                  # arithmetic coding
+    assert rc(b"\xff\xd8" + sof(0xC0, 8, 8) + b"\xff\xda\x00\x08\x01\x01\x00\x00\x3f\x00" + b"\x00" * 8 + b"\xff\xd9") != 0   # a scan without tables

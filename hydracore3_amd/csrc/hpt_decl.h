@@ -42,7 +42,8 @@ struct Job
 #endif
 // MODE: 0 = PathTrace (MIS / shadow / stupid by m_intergatorType), 1 = NaivePathTrace, 2 = PathTraceFromInputRays (the caller's rays
 // instead of camera rays, linear tid -> output index, raw accumColor: integrator_pt.cpp:159-199, 659-676, 761-798),
-// 3 = PathTrace for scenes with gltf + emissive materials only (shadeVertex<LEAN>), 4 / 5 / 6 = 0 / 1 / 2 for scenes with thin films (shadeVertex<FILM>)
+// 3 = PathTrace for scenes with gltf + emissive materials only (shadeVertex<LEAN>), 4 / 5 / 6 = 0 / 1 / 2 for scenes with thin films (shadeVertex<FILM>), 7 = 0 built for one more wave per SIMD (scenes with few material types:
+// env_map 1584 -> 1670 Mpaths/s, while typed_materials loses 3 % there and stays on MODE 0)
 // waves per SIMD the kernels with every BSDF branch (MODE 0 / 1 / 2) are compiled for; the lean and DR kernels keep HPT_MIN_WAVES.
 // Measured (profiles/ab_full.sh, 1024^2 x 64 spp, Mpaths/s at 4 / 3 / 2 waves): Cornell forced onto this kernel 1410 / 1531 / 1264,
 // legacy_materials 1585 / 1714 / 1528, env_map 1425 / 1507 / 1369, typed_materials 1123 / 1125 / 1105.
@@ -55,7 +56,7 @@ struct Job
 #ifndef HPT_DR_WAVES
 #define HPT_DR_WAVES HPT_MIN_WAVES   // the PathTraceDR megakernel
 #endif
-#define HPT_PT_BOUNDS(DR, MODE) __launch_bounds__(256, (DR) ? HPT_DR_WAVES : ((MODE) == 3 ? HPT_MIN_WAVES : ((MODE) >= 4 ? HPT_FILM_WAVES : HPT_FULL_WAVES)))
+#define HPT_PT_BOUNDS(DR, MODE) __launch_bounds__(256, (DR) ? HPT_DR_WAVES : ((MODE) == 3 ? HPT_MIN_WAVES : ((MODE) == 7 ? HPT_FULL_WAVES + 1 : ((MODE) >= 4 ? HPT_FILM_WAVES : HPT_FULL_WAVES))))
 template <bool STATS, bool DR, int MODE, bool DEEP, bool FLAT, bool MOTION = false, bool SWEEP = false>
 __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const Job job);
 

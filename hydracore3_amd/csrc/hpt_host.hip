@@ -97,6 +97,7 @@ struct hpt_ctx
   std::vector<void*> texData; std::vector<TexRec> hTextures;
   DevBuf<float> dSpecValues; DevBuf<uint> dSpecOffsetSz; DevBuf<float4> dCieXYZ;   // spectral tables (m_spec_values, m_spec_offset_sz, m_cie_xyz)
   bool spectralOk = false; std::string spectralWhyNot;   // whether the uploaded scene is within the spectral kernel's scope
+  bool fewMaterialTypes = false;                         // at most three reachable material types, no blends / plastic / normal maps: the full-material kernel built for 4 waves (MODE 7)
   bool spectralGltfMats = true, spectralHeavyMats = true;   // a reachable material needs scope 1 (gltf) / scope 2 (glass, blend, normal map) of the spectral kernel (hpt_spectral.hip)
   // thin films (integrator_pt.h:587-590): the tables a film material indexes, and what the uploaded materials say about them
   DevBuf<float> dFilmsEtaK, dPrecompFilms; DevBuf<uint> dFilmsSpecId, dSpecTexIdsWavelengths, dSpecTexOffsetSz;
@@ -1145,11 +1146,15 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
         }
       }
       c->spectralGltfMats = c->spectralHeavyMats = false;
+      uint typeMask = 0u; bool rich = false;                    // the reachable material types, for the choice between MODE 0 and MODE 7 (hpt_decl.h)
       for (uint i = 0; i < d->numMaterials; i++) {
         if (!reached[i]) continue;
+        if (mm[i].mtype < 32u) typeMask |= 1u << mm[i].mtype;
+        if (mm[i].mtype == MAT_TYPE_BLEND || mm[i].mtype == MAT_TYPE_PLASTIC || (mm[i].mtype != MAT_TYPE_LIGHT_SOURCE && mm[i].texid[1] != 0xFFFFFFFFu)) rich = true;
         if (mm[i].mtype == MAT_TYPE_GLTF) c->spectralGltfMats = true;
         if (mm[i].mtype == MAT_TYPE_GLASS || mm[i].mtype == MAT_TYPE_BLEND || (mm[i].mtype != MAT_TYPE_LIGHT_SOURCE && mm[i].texid[1] != 0xFFFFFFFFu)) c->spectralHeavyMats = true;   // (a reached blend: whatever its leaves are)
       }
+      c->fewMaterialTypes = !rich && __builtin_popcount(typeMask) <= 3;
     }
     const LightRec* ll2 = (const LightRec*)d->lights;
     for (uint i = 0; i < d->numLights; i++) {
@@ -1243,6 +1248,7 @@ extern "C" int hpt_update_materials(hpt_ctx* c, size_t first, size_t count, cons
     if (m.mtype == MAT_TYPE_GLTF) c->spectralGltfMats = true;
     if (m.mtype == MAT_TYPE_GLASS || m.mtype == MAT_TYPE_BLEND || (m.mtype != MAT_TYPE_LIGHT_SOURCE && m.texid[1] != 0xFFFFFFFFu)) c->spectralHeavyMats = true;
   }
+  c->fewMaterialTypes = false;                                 // (an update may bring in any type)
   (void)hipSetDevice(c->device);
   HIPCHK(c, hipMemcpy(c->dMaterials.p + first, mats, count * sizeof(MaterialRec), hipMemcpyHostToDevice));
   return HPT_OK;
@@ -1447,7 +1453,9 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   if (film && !c->filmTablesRGB) return c->fail(HPT_ERR_ARG, "thin film: m_precomp_thin_films holds no RGB table for a film (LoadScene precomputes every film in RGB mode, sized by its thickness map)");
   if (film && c->instrument && !dr) return c->fail(HPT_ERR_UNSUPPORTED, "thin films: the instrumented probe has no film variant");
   const bool fullMaterials = film || motion || !dr && !(c->leanMaterials && !c->forceFull && c->S.lensCount == 0u && !naive && !inRays && !(c->instrument && !dr));   // MODE 0 / 1 / 2 / STATS kernels
-  const int blocks = (int)std::min<size_t>((size_t)gridBlocks(c, dr, fullMaterials), ((size_t)job.tidCount + 255) / 256);
+  // MODE 7: the kernel with every BSDF branch built for one more wave per SIMD, for scenes with few material types (hpt_decl.h)
+  const bool mode7 = fullMaterials && c->fewMaterialTypes && !c->forceFull && !film && !motion && !dr && !inRays && !naive && !(c->instrument && !dr);
+  const int blocks = (int)std::min<size_t>((size_t)gridBlocks(c, dr, fullMaterials && !mode7), ((size_t)job.tidCount + 255) / 256);
   HIPCHK(c, c->dQueue.alloc(1));
   HIPCHK(c, hipMemsetAsync(c->dQueue.p, 0, 4, st));
   job.queue = c->dQueue.p;
@@ -1493,6 +1501,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
     launchPT<true, false, 0>(Sp, job, blocks, st, deep || (Sp.statsWide && c->stackNeeded4 > (uint)LDS_STACK));
   }
   else if (c->leanMaterials && !c->forceFull && c->S.lensCount == 0u) launchPT<false, false, 3>(c->S, job, blocks, st, deep);
+  else if (mode7)  launchPT<false, false, 7>(c->S, job, blocks, st, deep);
   else             launchPT<false, false, 0>(c->S, job, blocks, st, deep);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev1, st));

@@ -23,7 +23,7 @@ namespace hpt {
 template <bool STATS, bool DR, int MODE, bool DEEP, bool FLAT, bool MOTION, bool SWEEP>
 __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const Job job)
 {
-  constexpr bool NAIVE = (MODE == 1 || MODE == 5), INRAYS = (MODE == 2 || MODE == 6), LEAN = (MODE == 3), FILM = (MODE >= 4);
+  constexpr bool NAIVE = (MODE == 1 || MODE == 5), INRAYS = (MODE == 2 || MODE == 6), LEAN = (MODE == 3), FILM = (MODE >= 4 && MODE <= 6);   // (MODE 7 = MODE 0 built for one more wave per SIMD)
   __shared__ uint stackMem[LDS_STACK * 256];
   const uint glane = blockIdx.x * 256u + threadIdx.x;                    // slot in the per-lane HBM buffers
   TravStack stk; stk.lds = &stackMem[threadIdx.x]; stk.ovf = job.stackOverflow + glane; stk.ovfStride = job.gridLanes;
@@ -226,7 +226,7 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
   template __global__ void pathTraceKernel<STATS, DR, MODE, true,  true,  false>(const DevScene, const Job); \
   template __global__ void pathTraceKernel<STATS, DR, MODE, false, false, false, true>(const DevScene, const Job);   /* the triangle sweep of tiny scenes */
 #ifndef HPT_INST_GROUP
-#error "compile hpt_kernels.hip with -DHPT_INST_GROUP=1..13"
+#error "compile hpt_kernels.hip with -DHPT_INST_GROUP=1..14"
 #endif
 #if HPT_INST_GROUP == 1      // gltf + emissive scenes (every benchmark workload)
 HPT_INST4(false, false, 3)
@@ -246,6 +246,8 @@ HPT_INST4(false, false, 4)
 HPT_INST4(false, false, 5)
 #elif HPT_INST_GROUP == 11
 HPT_INST4(false, false, 6)
+#elif HPT_INST_GROUP == 14   // every BSDF branch, built for 4 waves per SIMD (scenes with few material types)
+HPT_INST4(false, false, 7)
 #elif HPT_INST_GROUP == 12   // thin films and moving instances
 template __global__ void pathTraceKernel<false, false, 4, false, false, true>(const DevScene, const Job);
 template __global__ void pathTraceKernel<false, false, 4, true,  false, true>(const DevScene, const Job);

@@ -67,8 +67,8 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
 #ifndef HPT_SPEC_WIDE_WAVES
 #define HPT_SPEC_WIDE_WAVES 3   // ... scope 2
 #endif
-template <bool DEEP, bool FLAT, bool SWEEP, bool MOTION, int SCOPE>   // SCOPE 0: the reference's spectral fixtures' needs; 1: + gltf; 2: + glass / blends / normal maps / environment maps / lens
-__global__ void __launch_bounds__(256, SCOPE >= 2 ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAVES) pathTraceSpectralKernel(const DevScene S, const Job job);
+template <bool DEEP, bool FLAT, bool SWEEP, bool MOTION, int SCOPE>   // SCOPE 0: the reference's spectral fixtures' needs; 1: + gltf; 2: + glass / blends / normal maps / environment maps / lens; 3: the same at 4 waves per SIMD
+__global__ void __launch_bounds__(256, SCOPE == 2 ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAVES) pathTraceSpectralKernel(const DevScene S, const Job job);
 
 // ---- wavefront schedule (hpt_wavefront.hip) --------------------------------------------------------------------------------------------
 static const uint WF_RANGES = 64u;                   // the trace kernel pulls rays from this many ranges of the queue (work stealing)

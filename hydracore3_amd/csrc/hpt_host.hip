@@ -1442,7 +1442,8 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
     // the scope the scene needs (hpt_spectral.hip: SCOPE): the narrowest instantiations that hold it
     bool heavy = c->S.lensCount != 0u || c->S.envTexId != 0xFFFFFFFFu || c->S.envCamBackId != 0xFFFFFFFFu || c->spectralHeavyMats;
     for (const uint g : c->hLightGeom) heavy = heavy || g == LIGHT_GEOM_ENV;
-    if (heavy) launchSpectral<2>(c->S, job, sblocks, st, sdeep); else if (c->spectralGltfMats) launchSpectral<1>(c->S, job, sblocks, st, sdeep); else launchSpectral<0>(c->S, job, sblocks, st, sdeep);
+    if (heavy && c->fewMaterialTypes) launchSpectral<3>(c->S, job, sblocks, st, sdeep);
+    else if (heavy) launchSpectral<2>(c->S, job, sblocks, st, sdeep); else if (c->spectralGltfMats) launchSpectral<1>(c->S, job, sblocks, st, sdeep); else launchSpectral<0>(c->S, job, sblocks, st, sdeep);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, st));
     return HPT_OK;

@@ -365,10 +365,12 @@ HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V
 // use (diffuse, conductor, plastic, dielectric, thin films, analytic lights, a sky spectrum); 1 = + gltf surfaces (legacy hydra_material scenes);
 // 2 = + legacy glass, blends, normal maps, environment maps, the lens stack. The code of a wider scope costs registers whether it runs or not:
 // test_spectral 446 Mpaths/s in scope 0 against 322 with everything compiled in; the Cornell box under spectral mode 2153 in scope 1 against
-// 1488 in scope 2 (scopes 0 / 1 are built for 4 waves per SIMD, scope 2 for 3).
-template <bool DEEP, bool FLAT, bool SWEEP, bool MOTION, int SCOPE>
-__global__ void __launch_bounds__(256, SCOPE >= 2 ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAVES) pathTraceSpectralKernel(const DevScene S, const Job job)
+// 1488 in scope 2 (scopes 0 / 1 are built for 4 waves per SIMD, scope 2 for 3 - and once more for 4, template value 3, for scenes with few
+// material types: legacy_materials 1283 -> 1425, while typed_materials loses 6 % there).
+template <bool DEEP, bool FLAT, bool SWEEP, bool MOTION, int SCOPE_>
+__global__ void __launch_bounds__(256, SCOPE_ == 2 ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAVES) pathTraceSpectralKernel(const DevScene S, const Job job)
 {
+  constexpr int SCOPE = SCOPE_ == 3 ? 2 : SCOPE_;                            // (3 = scope 2 built for 4 waves per SIMD: scenes with few material types)
   __shared__ uint stackMem[LDS_STACK * 256];
   const uint glane = blockIdx.x * 256u + threadIdx.x;
   TravStack stk; stk.lds = &stackMem[threadIdx.x]; stk.ovf = job.stackOverflow + glane; stk.ovfStride = job.gridLanes;
@@ -590,7 +592,7 @@ __global__ void __launch_bounds__(256, SCOPE >= 2 ? HPT_SPEC_WIDE_WAVES : HPT_SP
   }
 }
 
-// one translation unit per scope (-DHPT_SPEC_INST=1 / 2 / 3: scope 0 / 1 / 2; 0: all), see __graft_entry__.build
+// one translation unit per scope (-DHPT_SPEC_INST=1 / 2 / 3 / 4: scope 0 / 1 / 2 / 2 at 4 waves; 0: all), see __graft_entry__.build
 #ifndef HPT_SPEC_INST
 #define HPT_SPEC_INST 0
 #endif
@@ -612,6 +614,9 @@ HPT_SPEC(1)
 #endif
 #if HPT_SPEC_INST == 0 || HPT_SPEC_INST == 3
 HPT_SPEC(2)
+#endif
+#if HPT_SPEC_INST == 0 || HPT_SPEC_INST == 4
+HPT_SPEC(3)
 #endif
 
 } // namespace hpt

@@ -72,6 +72,7 @@ ABI = {
     "hpt_get_execution_time": (_i, [_vp, C.c_char_p, C.POINTER(_f)]),
     "hpt_set_instrumentation": (_i, [_vp, _i]),
     "hpt_get_counters": (_i, [_vp, C.POINTER(_u64)]),
+    "hpt_get_dr_counters": (_i, [_vp, C.POINTER(_u64)]),
     "hpt_set_launch_config": (_i, [_vp, _i]),
     "hpt_set_accel_layout": (_i, [_vp, _i]),
     "hpt_set_schedule": (_i, [_vp, _i, _i, _i, _i]),
@@ -81,6 +82,7 @@ ABI = {
     "hpt_reduce_framebuffer": (_i, [_vp, _vp, _sz, _i, _vp]),
     "hpt_allreduce_grad": (_i, [_vp, _vp, _sz, _vp]),
     "hpt_get_schedule": (_i, [_vp, C.POINTER(_i), C.POINTER(_u32)]),
+    "hpt_get_last_launch": (_i, [_vp, C.POINTER(_u32)]),
     "hpt_get_accel_info": (_i, [_vp, C.POINTER(_f)]),
     "hpt_set_option": (_i, [_vp, C.c_char_p, _i]),
     "hpt_get_commit_time": (_i, [_vp, C.POINTER(_f)]),
@@ -334,6 +336,11 @@ class HipIntegrator:
         self._chk(self.L.hpt_get_counters(self.h, out))
         return dict(zip(COUNTER_NAMES, [int(v) for v in out]))
 
+    def dr_counters(self):
+        out = (_u64 * 8)()
+        self._chk(self.L.hpt_get_dr_counters(self.h, out))
+        return dict(zip(("records", "records_with_taps", "cyc_record_store", "cyc_sweep", "sweep_wave_trips", "sweep_lanes", "atomic_wave_insts", "sweep_bounces"), [int(v) for v in out]))
+
     def set_tid_interleave(self, chunk: int, stride: int):
         self._chk(self.L.hpt_set_tid_interleave(self.h, chunk, stride))
 
@@ -369,6 +376,12 @@ class HipIntegrator:
 
     def CommitScene(self):
         self._chk(self.L.hpt_commit_scene(self.h, 4))
+
+    def last_launch(self):
+        """What the last PathTrace* call walked: schedule, 4-wide compressed tree, 64-byte shading records, HBM part of the stacks."""
+        out = (C.c_uint32 * 4)()
+        self._chk(self.L.hpt_get_last_launch(self.h, out))
+        return {"schedule": int(out[0]), "wide_nodes": bool(out[1]), "shade_records": bool(out[2]), "deep_stack": bool(out[3])}
 
     def last_schedule(self):
         s, it = C.c_int(0), C.c_uint32(0)

@@ -201,7 +201,7 @@ HPT_DEV V2 sphereMapTo2DTexCoord(V3 ray_dir)                            // :335-
 }
 
 // ---- textures: LiteImage bilinear sampler as restated in-tree by Tex2DFetchAD (diff_render/integrator_dr.cpp:60-161) --
-struct Taps { int off[4]; float w[4]; };
+struct Taps { int off[4]; float w[4]; float fx, fy; uint base, ch; };   // fx, fy: the fractions the weights are products of; base / ch: first float of a parameter texture in a_data, its channels (texFetchAD)
 
 HPT_DEV int wrapi(int p, int n) { const int r = p % n; return r < 0 ? r + n : r; }
 
@@ -222,6 +222,7 @@ HPT_DEV Taps bilinearTaps(uint w, uint h, uint addrU, uint addrV, V2 uv)
   Taps r;
   r.off[0] = y0 * (int)w + x0; r.off[1] = y0 * (int)w + x1; r.off[2] = y1 * (int)w + x0; r.off[3] = y1 * (int)w + x1;
   r.w[0] = fx1 * fy1; r.w[1] = fx * fy1; r.w[2] = fx1 * fy; r.w[3] = fx * fy;
+  r.fx = fx; r.fy = fy; r.base = 0u; r.ch = 0u;
   return r;
 }
 

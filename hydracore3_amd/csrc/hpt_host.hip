@@ -156,6 +156,7 @@ struct hpt_ctx
   int  wfBlocksPerCU = 0;
   size_t instTris = 0;                   // instanced triangles of the committed scene
   uint lastSchedule = 1, lastWfIters = 0;
+  uint lastWide = 0, lastShadeRecords = 0, lastDeep = 0;          // what the last launch walked: 4-wide compressed tree, 64-byte shading records, HBM part of the stacks
 
   DevScene S;
   bool sceneUploaded = false, paramsSet = false;
@@ -1463,9 +1464,15 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   job.gens = c->dGens.p; job.packedXY = c->dPackedXY.p; job.packedCount = c->packedCount;
   job.counters = nullptr;
   job.drSkipNonFinite = c->drSkipNonFinite ? 1u : 0u;
-  const bool stats = c->instrument && !dr;
+  const bool stats = c->instrument;                            // (the DR probe exists as a megakernel only: hpt_kernels.hip, group 15)
   c->lastSchedule = 1;
-  if (!inRays && useWavefront(c, naive, dr, stats && c->schedule != 2, job.tidCount)) { c->lastSchedule = 2; return launch_wavefront(c, job, st, dr); }
+  c->lastShadeRecords = c->S.shadeTris != nullptr ? 1u : 0u;
+  if (!inRays && useWavefront(c, naive, dr, stats && c->schedule != 2, job.tidCount)) {
+    c->lastSchedule = 2; c->lastWide = (wfWide(c) && !c->instrument) ? 1u : 0u; c->lastDeep = (c->lastWide ? c->stackNeeded4 : c->stackNeeded) > (uint)LDS_STACK ? 1u : 0u;
+    return launch_wavefront(c, job, st, dr);
+  }
+  c->lastWide = (!stats && !motion && (HPT_FLAT_WIDE || c->S.megaWide != 0u) && c->S.flatMode != 0u && c->nodes4Count != 0u) ? 1u : 0u;
+  c->lastDeep = megaStackNeeded(c) > (uint)LDS_STACK ? 1u : 0u;
   if (stats) { HIPCHK(c, c->dCounters.alloc(1)); HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(Counters), st)); job.counters = c->dCounters.p; }
   if (dr) {
     job.recordLanes = (uint)blocks * 256u;
@@ -1487,7 +1494,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
     // lanes still walk pays even on light scenes: test_228 class 346 -> 364 Mpaths/s (forward: 698 -> 699; profiles/vote_medium.sh)
     DevScene Sd = c->S;
     if (c->nodeMinOverride < 0 && Sd.nodeMin < 4u) Sd.nodeMin = 4u;
-    launchPT<false, true, 0>(Sd, job, blocks, st, deep);
+    if (stats) launchPT<true, true, 0>(Sd, job, blocks, st, deep); else launchPT<false, true, 0>(Sd, job, blocks, st, deep);
   }
   else if (film) {
     if (inRays) launchPT<false, false, 6>(c->S, job, blocks, st, deep); else if (naive) launchPT<false, false, 5>(c->S, job, blocks, st, deep); else launchPT<false, false, 4>(c->S, job, blocks, st, deep);
@@ -1983,7 +1990,16 @@ extern "C" int hpt_get_counters(hpt_ctx* c, uint64_t out[16])
   (void)hipSetDevice(c->device);
   if (!c->dCounters.p) { for (int i = 0; i < 16; i++) out[i] = 0; return HPT_OK; }
   HIPCHK(c, hipDeviceSynchronize());
-  HIPCHK(c, hipMemcpy(out, c->dCounters.p, sizeof(Counters), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(out, c->dCounters.p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return HPT_OK;
+}
+extern "C" int hpt_get_dr_counters(hpt_ctx* c, uint64_t out[8])
+{
+  if (!c || !out) return HPT_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (!c->dCounters.p) { for (int i = 0; i < 8; i++) out[i] = 0; return HPT_OK; }
+  HIPCHK(c, hipDeviceSynchronize());
+  HIPCHK(c, hipMemcpy(out, (const uint64_t*)c->dCounters.p + 16, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return HPT_OK;
 }
 extern "C" int hpt_set_tid_interleave(hpt_ctx* c, uint32_t chunk, uint32_t stride)
@@ -2037,6 +2053,12 @@ extern "C" int hpt_get_schedule(hpt_ctx* c, int* lastSchedule, uint32_t* lastIte
   if (!c) return HPT_ERR_ARG;
   if (lastSchedule) *lastSchedule = (int)c->lastSchedule;
   if (lastIterations) *lastIterations = c->lastWfIters;
+  return HPT_OK;
+}
+extern "C" int hpt_get_last_launch(hpt_ctx* c, uint32_t out[4])
+{
+  if (!c || !out) return HPT_ERR_ARG;
+  out[0] = c->lastSchedule; out[1] = c->lastWide; out[2] = c->lastShadeRecords; out[3] = c->lastDeep;
   return HPT_OK;
 }
 extern "C" int hpt_set_accel_layout(hpt_ctx* c, int layout)

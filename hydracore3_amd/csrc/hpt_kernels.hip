@@ -50,7 +50,8 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
   float lossLocal = 0.0f;
   const uint maxBounce = NAIVE ? S.traceDepth + 1u : S.traceDepth;
   // diagnostic stamps (STATS build only; never in a timed kernel): where a wave's cycles go, phase by phase
-  unsigned long long tPh[5] = {0, 0, 0, 0, 0}, tTrips = 0, tPrev = 0;
+  unsigned long long tPh[7] = {0, 0, 0, 0, 0, 0, 0}, tTrips = 0, tPrev = 0;
+  unsigned long long nRec = 0, nRecTex = 0, nSweepTrips = 0, nSweepLanes = 0, nAtomInst = 0, nSweepBounces = 0;   // PathTraceDR probe (STATS && DR)
 #define STAMP(i) do { if (STATS) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tPh[i] += tn - tPrev; tPrev = tn; } } while (0)
   if (STATS) tPrev = __builtin_amdgcn_s_memtime();
 
@@ -129,6 +130,7 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
     const V3 thrBefore = thr;
     bool didBounce = false;
     for (int k = 0; k < 4; k++) { recTaps.off[k] = 0; recTaps.w[k] = 0.0f; }
+    recTaps.fx = recTaps.fy = 0.0f; recTaps.base = recTaps.ch = 0u;
 
     if (alive) {
       if (STATS && hit.inst != 0xFFFFFFFFu) nHits++;
@@ -147,12 +149,24 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
 
     STAMP(3);
     // ---- (7) bookkeeping: adjoint record, end of path ------------------------------------------------------------------------------
+    bool closing = false;                              // DR: this lane's path ended in this trip and its gradient is to be scattered
+    V3 sweepDiff = v3(0, 0, 0), sweepTail = v3(0, 0, 0);
+    DrRec lastRec = drEmptyRecord(); bool lastInRegs = false;
     if (alive) {
-      if (DR && didBounce) {
-        drStoreRecord(job.record, job.recordLanes, glane, bounce, recA, recS, recdA, recdS, thrBefore, recTex, recTaps);
-      }
       if (didBounce) bounce++;
-      if ((flags & RAY_FLAG_IS_DEAD) != 0 || bounce >= maxBounce) {
+      const bool ended = (flags & RAY_FLAG_IS_DEAD) != 0 || bounce >= maxBounce;
+      if (DR && didBounce) {
+        // the record of a bounce goes to HBM only when the path goes on: a path that ends here (bounce limit, FB_DIRECT) sweeps it from registers
+        lastRec = drMakeRecord(recA, recS, recdA, recdS, thrBefore, recTex, recTaps);
+        lastInRegs = ended;
+        STAMP(4);
+#ifndef HPT_DBG_DR_NOSTORE   // diagnostic builds only (profiles/dr_ab.sh): what do the record stores cost?
+        if (!ended) drStoreRecord(job.record, job.recordLanes, glane, bounce - 1u, lastRec);
+#endif
+        if (STATS) { nRec++; if (recTex != 0xFFFFFFFFu) nRecTex++; }
+        STAMP(5);
+      }
+      if (ended) {
         // kernel_HitEnvironment (integrator_pt.cpp:550-595), constant environment colour.
         // The DR replay adds the environment term unconditionally (diff_render/integrator_dr.cpp:1077-1098).
         const V3 env = DR ? ld3(S.envColor) : environmentRadiance(S, rdir, misPdf, flags, INRAYS ? (PIX_TID < job.packedCount ? job.packedXY[PIX_TID] : 0u) : PIX_XY);
@@ -161,14 +175,16 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
           if (S.integratorType == INTEGRATOR_STUPID_PT) accum = thr * env; else accum = accum + thr * env;
         }
         if (DR) {
-          // PixelLossPT (integrator_dr.cpp:1103-1132) + hand-derived reverse sweep replacing __enzyme_autodiff (:1172-1183).
-          // With T_0 = 1, T_{b+1} = T_b A_b and C = sum_b T_b S_b + T_n tail:
-          //   dC/dtex_b = T_b dS_b + T_b dA_b R_{b+1},   R_b = S_b + A_b R_{b+1},   R_n = tail
+          // PixelLossPT (integrator_dr.cpp:1103-1132) + hand-derived reverse sweep replacing __enzyme_autodiff (:1172-1183), see drReverseSweep
           const uint pitch = (uint)S.winWidth;
           const uint XY = PIX_XY;
           const uint yRef = (uint)S.winHeight - ((XY & 0xFFFF0000u) >> 16) - 1u;
           const float* rp = job.refImg + ((size_t)yRef * pitch + (XY & 0x0000FFFFu)) * job.channels;
+#ifdef HPT_DBG_DR_NOREF      // diagnostic builds only: the reference pixel's load at path end
+          const V3 diff = v3(accum.x - 0.25f, accum.y - 0.25f, accum.z - 0.25f); (void)rp;
+#else
           const V3 diff = v3(accum.x - rp[0], accum.y - rp[1], accum.z - rp[2]);
+#endif
           // PixelLossPT adds every sample, finite or not (integrator_dr.cpp:1124-1131): that is the default here too. One sample in ~1e8 on
           // the 1M-triangle scene comes out non-finite (a 0/0 in a grazing GGX term of the reference's formulas, unguarded there too) and in
           // an optimisation loop a single NaN gradient poisons Adam's moments for good, so hpt_set_option("dr_skip_nonfinite", 1) lets such
@@ -177,7 +193,7 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
           if (sane) {
             lossLocal += (diff.x * diff.x + diff.y * diff.y + diff.z * diff.z) / float(job.passNum);
             PIX(0) += accum.x; PIX(1) += accum.y; PIX(2) += accum.z;           // out_color += colorRend (:1124-1126)
-            drReverseSweep(S, job.record, job.recordLanes, glane, bounce, tailR + env, diff, job.grad, job.drSkipNonFinite != 0u, drStage + (threadIdx.x >> 6) * DR_STAGE_DWORDS);
+            closing = true; sweepDiff = diff; sweepTail = tailR + env;
           }
         } else {
           // kernel_ContributeToImage (integrator_pt.cpp:598-657)
@@ -188,6 +204,18 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
         }
         alive = false;
       }
+    }
+    if (DR) {
+      // the reverse sweep, by the whole wave: the lanes whose paths go on help scatter the gradients of those that closed one (drReverseSweep)
+      STAMP(4);
+      if (__any(closing)) {
+        if (STATS) { if (closing) { nSweepLanes++; nSweepBounces += bounce; } if (lane_id() == 0u) nSweepTrips++; }
+#ifndef HPT_DBG_DR_NOSWEEP   // diagnostic builds only
+        drReverseSweep(S, job.record, job.recordLanes, glane, closing, bounce, sweepTail, sweepDiff, job.grad, job.drSkipNonFinite != 0u,
+                       drStage + (threadIdx.x >> 6) * DR_STAGE_DWORDS, lastRec, lastInRegs, STATS ? &nAtomInst : nullptr);
+#endif
+      }
+      STAMP(6);
     }
     STAMP(4);
   }
@@ -204,6 +232,16 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
       for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
       if ((threadIdx.x & 63) == 0) { atomicAdd(&job.counters->v[14], a); atomicAdd(&job.counters->v[15], b); } }
     if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 5; i++) atomicAdd(&job.counters->v[8 + i], tPh[i]); atomicAdd(&job.counters->v[13], tTrips); }
+    if (DR) {
+      if ((threadIdx.x & 63) == 0) { atomicAdd(&job.counters->v[18], tPh[5]); atomicAdd(&job.counters->v[19], tPh[6]); }
+      unsigned long long w[6] = { nRec, nRecTex, nSweepTrips, nSweepLanes, nAtomInst, nSweepBounces };
+      const int slot[6] = { 16, 17, 20, 21, 22, 23 };
+      for (int i = 0; i < 6; i++) {
+        unsigned long long x = w[i];
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&job.counters->v[slot[i]], x);
+      }
+    }
     for (int i = 0; i < 8; i++) {
       unsigned long long x = v[i];
       for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
@@ -226,7 +264,7 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
   template __global__ void pathTraceKernel<STATS, DR, MODE, true,  true,  false>(const DevScene, const Job); \
   template __global__ void pathTraceKernel<STATS, DR, MODE, false, false, false, true>(const DevScene, const Job);   /* the triangle sweep of tiny scenes */
 #ifndef HPT_INST_GROUP
-#error "compile hpt_kernels.hip with -DHPT_INST_GROUP=1..14"
+#error "compile hpt_kernels.hip with -DHPT_INST_GROUP=1..15"
 #endif
 #if HPT_INST_GROUP == 1      // gltf + emissive scenes (every benchmark workload)
 HPT_INST4(false, false, 3)
@@ -240,6 +278,8 @@ HPT_INST4(false, false, 2)
 HPT_INST4(true, false, 0)
 #elif HPT_INST_GROUP == 6    // PathTraceDR
 HPT_INST4(false, true, 0)
+#elif HPT_INST_GROUP == 15   // PathTraceDR, instrumented (phase stamps, record / sweep / atomic counts: profiles/dr_phases.py)
+HPT_INST4(true, true, 0)
 #elif HPT_INST_GROUP == 9    // scenes with thin films (MODE 4 / 5 / 6 = 0 / 1 / 2 + MAT_TYPE_THIN_FILM)
 HPT_INST4(false, false, 4)
 #elif HPT_INST_GROUP == 10

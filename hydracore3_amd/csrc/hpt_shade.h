@@ -19,6 +19,7 @@ HPT_DEV V4 texFetchAD(const DevScene& S, const float* data, uint texId, V2 uv, T
   isParam = false;
   if (t.diffOffset != ~0ull && data != nullptr) {
     taps = bilinearTaps(t.diffW, t.diffH, t.addrU, t.addrV, uv);
+    taps.base = (uint)t.diffOffset; taps.ch = t.diffChannels;
     isParam = true;
     const float* d = data + t.diffOffset;
     if (t.diffChannels == 4) {
@@ -455,80 +456,114 @@ HPT_DEV bool shadeVertex(const DevScene& S, const float* diffData, const HitRec&
 }
 
 // ---- differentiable rendering: per-bounce adjoint record and the reverse sweep (shared by the megakernel and the wavefront shade pass) ----
-// Record of bounce b for path slot `idx` in a buffer laid out [bounce][field][slot] (stride = slots): coalesced, L2-resident.
-static const int REC_FIELDS = 24;   // A(3) S(3) T*dA(3) T*dS(3) texId tapOffsets(4) tapWeights(4) pad(3)
-HPT_DEV void drStoreRecord(float* record, size_t s, size_t idx, uint bounce, V3 recA, V3 recS, V3 recdA, V3 recdS, V3 thrBefore, uint recTex, const Taps& recTaps)
+// Record of bounce b for path slot `idx`: 17 dwords in five planes laid out [bounce][plane][slot] - four float4 planes and one dword plane,
+// so a wave stores a record with four 1-KB global_store_dwordx4 and one 256-B store (it was 21 dword stores: every store stays counted in
+// vmcnt until the memory side acknowledges it, and the next load the wave waits for waits for all of them):
+//   q0 = (A.xyz, S.x)  q1 = (S.yz, T*dA.xy)  q2 = (T*dA.z, T*dS.xyz)  q3 = (first gradient element of tap 0, element step to the tap in +x,
+//   element step to the tap in +y, fx)  e = fy
+// The four bilinear taps are kept as tap 0's element index in a_dataGrad plus the two steps (negative where the footprint wraps) and the
+// two fractions the weights are products of (bilinearTaps: w = {fx1 fy1, fx fy1, fx1 fy, fx fy}, recomputed with the same two products), so
+// the sweep needs neither the texture descriptor nor eight more dwords. q3.x = 0xFFFFFFFF: no parameter texture at this bounce; bit 31 set
+// otherwise: a one-channel texture (its rgb sum goes to one float).
+static const int REC_PLANES = 5;
+static const int REC_FIELDS = 4 * REC_PLANES;   // floats of buffer per slot and bounce (the last plane holds one dword per slot)
+struct DrRec { V3 A, S, TdA, TdS; uint e0; int dx, dy; float fx, fy; };
+HPT_DEV DrRec drEmptyRecord() { DrRec r; r.A = r.S = r.TdA = r.TdS = v3(0, 0, 0); r.e0 = 0xFFFFFFFFu; r.dx = r.dy = 0; r.fx = r.fy = 0.0f; return r; }
+HPT_DEV DrRec drMakeRecord(V3 recA, V3 recS, V3 recdA, V3 recdS, V3 thrBefore, uint recTex, const Taps& t)
 {
-  float* r = record + ((size_t)bounce * REC_FIELDS) * s + idx;
-  r[0 * s] = recA.x; r[1 * s] = recA.y; r[2 * s] = recA.z;
-  r[3 * s] = recS.x; r[4 * s] = recS.y; r[5 * s] = recS.z;
-  r[6 * s] = recdA.x * thrBefore.x; r[7 * s] = recdA.y * thrBefore.y; r[8 * s] = recdA.z * thrBefore.z;     // T_b * dA_b/dtex
-  r[9 * s] = recdS.x * thrBefore.x; r[10 * s] = recdS.y * thrBefore.y; r[11 * s] = recdS.z * thrBefore.z;   // T_b * dS_b/dtex
-  r[12 * s] = __uint_as_float(recTex);
+  DrRec r;
+  r.A = recA; r.S = recS; r.TdA = recdA * thrBefore; r.TdS = recdS * thrBefore;       // T_b * dA_b/dtex, T_b * dS_b/dtex
+  r.e0 = 0xFFFFFFFFu; r.dx = 0; r.dy = 0; r.fx = 0.0f; r.fy = 0.0f;
   if (recTex != 0xFFFFFFFFu) {
-    for (int k = 0; k < 4; k++) { r[(13 + k) * s] = __int_as_float(recTaps.off[k]); r[(17 + k) * s] = recTaps.w[k]; }
+    const int ch = (int)t.ch;
+    r.e0 = (t.base + (uint)t.off[0] * t.ch) | (t.ch == 4u ? 0u : 0x80000000u);
+    r.dx = (t.off[1] - t.off[0]) * ch; r.dy = (t.off[2] - t.off[0]) * ch;
+    r.fx = t.fx; r.fy = t.fy;
   }
+  return r;
+}
+HPT_DEV void drStoreRecord(float* record, size_t s, size_t idx, uint bounce, const DrRec& r)
+{
+  float4* q = (float4*)record + ((size_t)bounce * REC_PLANES) * s + idx;
+  q[0 * s] = make_float4(r.A.x, r.A.y, r.A.z, r.S.x);
+  q[1 * s] = make_float4(r.S.y, r.S.z, r.TdA.x, r.TdA.y);
+  if (r.e0 != 0xFFFFFFFFu) q[2 * s] = make_float4(r.TdA.z, r.TdS.x, r.TdS.y, r.TdS.z);   // (without a parameter texture the sweep reads neither derivative)
+  q[3 * s] = make_float4(__uint_as_float(r.e0), __int_as_float(r.dx), __int_as_float(r.dy), r.fx);
+  if (r.e0 != 0xFFFFFFFFu) *(float*)(q + 4 * s) = r.fy;
 }
 // the light sample of bounce b turned out occluded: its S term and derivative vanish
 HPT_DEV void drClearShadowTerm(float* record, size_t s, size_t idx, uint bounce)
 {
-  float* r = record + ((size_t)bounce * REC_FIELDS) * s + idx;
-  r[3 * s] = 0.0f; r[4 * s] = 0.0f; r[5 * s] = 0.0f; r[9 * s] = 0.0f; r[10 * s] = 0.0f; r[11 * s] = 0.0f;
+  float* q = (float*)((float4*)record + ((size_t)bounce * REC_PLANES) * s + idx);
+  q[3] = 0.0f;                                                              // S.x
+  q[4 * s + 0] = 0.0f; q[4 * s + 1] = 0.0f;                                 // S.yz
+  q[8 * s + 1] = 0.0f; q[8 * s + 2] = 0.0f; q[8 * s + 3] = 0.0f;            // T*dS
 }
 // Hand-derived reverse sweep replacing __enzyme_autodiff (integrator_dr.cpp:1172-1183). With T_0 = 1, T_{b+1} = T_b A_b and
 // C = sum_b T_b S_b + T_n tail:  dC/dtex_b = T_b dS_b + T_b dA_b R_{b+1},  R_b = S_b + A_b R_{b+1},  R_n = tail;  the loss gradient
 // 2 (C - ref) dC/dtex_b is scattered to the four bilinear taps with float atomics.
 //
-// The scatter is wave-cooperative. Float atomics execute at the memory side, one request per 64-byte line an instruction touches
-// (MI355X_MICROARCH.md, "Global float atomics": 64 lanes in 64 different rows run 17x below the contiguous rate), and a lane's own 12
-// adds - 4 taps x rgb - sit in two or three lines (rgb of a texel are adjacent, the taps of one row of the footprint usually are). Issued
-// lane by lane they were 12 instructions of up to 64 lines each. Here the lanes that have a gradient at this bounce stage their 12 values
-// and 4 element indices in LDS ([16][64] dwords per wave) and ALL lanes of the wave that are in the sweep then walk the staged pairs in
-// order - consecutive lanes take consecutive (tap, channel) elements of one source lane - so an instruction touches ~5x fewer lines, and
-// lanes without a gradient of their own help those that have one. `stage`: the wave's 1024-dword LDS area. Same sums, another order.
+// Called by ALL lanes of a wave, in wave-uniform control flow; `closing`: this lane has a path to close. Float atomics execute at the
+// memory side, one request per 64-byte line an instruction touches, every instruction stays counted in vmcnt for ~3000 cycles with the chip
+// busy and a wave stalls once 16..32 are outstanding (MI355X_MICROARCH.md, "Global float atomics"), so what counts is the NUMBER of atomic
+// instructions and the lines each one touches. The closing lanes that have a gradient at a bounce stage their 12 values (4 taps x rgb) and
+// tap 0's element index and steps in LDS, and ALL 64 lanes of the wave - also those whose paths go on - then walk the staged values in order:
+// consecutive lanes take consecutive (tap, channel) elements of one source lane, so an instruction covers 64 values in a few 16-byte runs.
+// (Round 2 ran this under the divergent "my path ended" branch: 13 of 64 lanes per atomic instruction on the test_228 class, 50
+// instructions per wave-trip; 360 -> see profiles/r3_measurements.md.) `last`: the record of the closing lane's last bounce when it is
+// still in registers (lastInRegs; it was never stored). `stage`: the wave's 1024-dword LDS area. Same sums, another order.
 static const uint DR_STAGE_DWORDS = 16u * 64u;
-HPT_DEV void drReverseSweep(const DevScene& S, const float* record, size_t s, size_t idx, uint bounce, V3 Rn, V3 diff, float* grad, const bool skipNonFinite, uint* stage)
+HPT_DEV void drReverseSweep(const DevScene& S, const float* record, size_t s, size_t idx, const bool closing, const uint bounceIn, V3 Rn, const V3 diff,
+                            float* grad, const bool skipNonFinite, uint* stage, const DrRec& last, const bool lastInRegs,
+                            unsigned long long* statAtomics = nullptr)
 {
-  const unsigned long long am = __ballot(true);                           // the lanes in this sweep (their paths ended in this trip)
-  const uint ne = (uint)__popcll(am), ra = mbcnt64(am);
+  const uint bounce = closing ? bounceIn : 0u;
+  const uint lane = lane_id();
   for (int b = (int)S.traceDepth - 1; b >= 0; b--) {                      // wave-uniform trip count; a lane joins at its own last bounce
     const bool mine = (uint)b < bounce;
-    V3 A = v3(0, 0, 0), Sb = v3(0, 0, 0);
-    uint texId = 0xFFFFFFFFu;
-    const float* r = record + ((size_t)b * REC_FIELDS) * s + idx;
-    if (mine) { A = v3(r[0 * s], r[1 * s], r[2 * s]); Sb = v3(r[3 * s], r[4 * s], r[5 * s]); texId = __float_as_uint(r[12 * s]); }
-    const bool has = mine && texId != 0xFFFFFFFFu;
+    if (__ballot(mine) == 0ull) continue;
+    const bool inRegs = mine && lastInRegs && (uint)b + 1u == bounce;
+    const bool load = mine && !inRegs;
+    V3 A = v3(0, 0, 0), Sb = v3(0, 0, 0), TdA = v3(0, 0, 0), TdS = v3(0, 0, 0);
+    uint e0 = 0xFFFFFFFFu; int dx = 0, dy = 0; float fx = 0.0f, fy = 0.0f;
+    const float4* q = (const float4*)record + ((size_t)b * REC_PLANES) * s + idx;
+    if (load) {
+      const float4 q0 = q[0 * s], q1 = q[1 * s], q3 = q[3 * s];
+      A = v3(q0.x, q0.y, q0.z); Sb = v3(q0.w, q1.x, q1.y); TdA.x = q1.z; TdA.y = q1.w;
+      e0 = __float_as_uint(q3.x); dx = __float_as_int(q3.y); dy = __float_as_int(q3.z); fx = q3.w;
+      if (e0 != 0xFFFFFFFFu) { const float4 q2 = q[2 * s]; TdA.z = q2.x; TdS = v3(q2.y, q2.z, q2.w); fy = *(const float*)(q + 4 * s); }
+    } else if (inRegs) { A = last.A; Sb = last.S; TdA = last.TdA; TdS = last.TdS; e0 = last.e0; dx = last.dx; dy = last.dy; fx = last.fx; fy = last.fy; }
+    const bool has = mine && e0 != 0xFFFFFFFFu;
     const unsigned long long hm = __ballot(has);
     if (hm != 0ull) {
       const uint n = (uint)__popcll(hm), rk = mbcnt64(hm);
       if (has) {
-        const V3 TdA = v3(r[6 * s], r[7 * s], r[8 * s]), TdS = v3(r[9 * s], r[10 * s], r[11 * s]);
         const V3 dC = TdS + TdA * Rn;
         V3 g = v3(2.0f * diff.x * dC.x, 2.0f * diff.y * dC.y, 2.0f * diff.z * dC.z);
         if (skipNonFinite && !__builtin_isfinite(g.x + g.y + g.z)) g = v3(0, 0, 0);   // (only with dr_skip_nonfinite: the reference scatters whatever comes out)
-        const TexRec t = S.textures[texId];
-        const bool four = t.diffChannels == 4;
+        const bool four = (e0 & 0x80000000u) == 0u;
+        const float fx1 = 1.0f - fx, fy1 = 1.0f - fy;
+        const float w[4] = { fx1 * fy1, fx * fy1, fx1 * fy, fx * fy };      // bilinearTaps' weights, the same products
+        float* sv = (float*)stage;
         for (int k = 0; k < 4; k++) {
-          const uint off = (uint)__float_as_int(r[(13 + k) * s]);
-          const float w = r[(17 + k) * s];
-          // element index of the tap's first float in a_dataGrad (bit 31: a one-channel texture, its sum goes to that single float)
-          stage[(12 + k) * 64 + rk] = four ? (uint)t.diffOffset + off * 4u : (((uint)t.diffOffset + off) | 0x80000000u);
-          float* sv = (float*)stage;
-          sv[(3 * k + 0) * 64 + rk] = four ? g.x * w : (g.x + g.y + g.z) * w;
-          sv[(3 * k + 1) * 64 + rk] = g.y * w;
-          sv[(3 * k + 2) * 64 + rk] = g.z * w;
+          sv[(3 * k + 0) * 64 + rk] = four ? g.x * w[k] : (g.x + g.y + g.z) * w[k];
+          sv[(3 * k + 1) * 64 + rk] = g.y * w[k];
+          sv[(3 * k + 2) * 64 + rk] = g.z * w[k];
         }
+        stage[12 * 64 + rk] = e0; stage[13 * 64 + rk] = (uint)dx; stage[14 * 64 + rk] = (uint)dy;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      for (uint p = ra; p < 12u * n; p += ne) {
+      if (statAtomics && lane == 0u) *statAtomics += (12u * n + 63u) / 64u;         // (instrumented build: atomic wave-instructions of this sweep)
+      for (uint p = lane; p < 12u * n; p += 64u) {
         const uint src = (p * 0xAAABu) >> 19;                             // p / 12 (p < 768)
         const uint e = p - 12u * src, tap = (e * 11u) >> 5, ch = e - 3u * tap;   // e / 3, e % 3 (e < 12)
-        const uint ix = stage[(12 + tap) * 64 + src];
+        const uint ix0 = stage[12 * 64 + src];
+        const uint ix = (ix0 & 0x7FFFFFFFu) + ((tap & 1u) ? stage[13 * 64 + src] : 0u) + ((tap & 2u) ? stage[14 * 64 + src] : 0u);   // (two's complement: negative steps wrap back)
         const float val = ((const float*)stage)[e * 64 + src];
 #ifndef HPT_DR_NO_ATOMICS    // diagnostic build only: how much of PathTraceDR is the gradient scatter?
-        if ((ix & 0x80000000u) == 0u) atomicAdd(grad + (size_t)ix + ch, val);
-        else if (ch == 0u) atomicAdd(grad + (size_t)(ix & 0x7FFFFFFFu), val);
+        if ((ix0 & 0x80000000u) == 0u) atomicAdd(grad + (size_t)ix + ch, val);
+        else if (ch == 0u) atomicAdd(grad + (size_t)ix, val);
 #else
         if (ix == 0x7FFFFFFFu) grad[0] = val;
 #endif

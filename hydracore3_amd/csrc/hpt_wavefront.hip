@@ -78,6 +78,9 @@ __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const W
   bool alive = (st & WF_ALIVE) != 0u, pend = (st & WF_PEND) != 0u, ending = (st & WF_ENDING) != 0u;
   const bool active = valid && (alive || pend || ending || passes != 0u);
   bool wantShadow = false;
+  // DR: the reverse sweep runs after the divergent part, by the whole wave (drReverseSweep); what a closing lane hands over to it
+  bool closing = false; uint sweepBounce = 0; V3 sweepDiff = v3(0, 0, 0), sweepTail = v3(0, 0, 0);
+  DrRec lastRec = drEmptyRecord(); bool lastInRegs = false;
 
   if (active) {
     Rng gen = job.gens[tid];
@@ -107,15 +110,20 @@ __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const W
       if (S.shadeTris != nullptr) hit.slot = __float_as_uint(h4.w);      // (with the shading records in use the trace pass reports the hit's record, not its primitive id)
       V3 rA = v3(0, 0, 0), rS = v3(0, 0, 0), rdA = v3(0, 0, 0), rdS = v3(0, 0, 0); Taps taps; uint recTex = 0xFFFFFFFFu;   // adjoint record of this vertex (DR)
       for (int k = 0; k < 4; k++) { taps.off[k] = 0; taps.w[k] = 0.0f; }
+      taps.fx = taps.fy = 0.0f; taps.base = taps.ch = 0u;
       const V3 thrBefore = thr;
       const bool didBounce = shadeVertex<DR, false, LEAN, MOTION, FILM>(S, DR ? job.data : nullptr, hit, rpos, rdir, accum, thr, misPdf, misIor, flags, bounce, gen,
                                                     wantShadow, shPos, shDir, shFar, contrib, rA, rS, rdA, rdS, taps, recTex, tailR, pathTime);
+      if (didBounce) bounce++;
+      const bool ended = (flags & RAY_FLAG_IS_DEAD) != 0 || bounce >= S.traceDepth;
       if (DR && didBounce) {
         if (!wantShadow) { rS = v3(0, 0, 0); rdS = v3(0, 0, 0); }           // (an occluded sample is cleared when its shadow ray comes back)
-        drStoreRecord(job.record, job.itemCount, s, bounce, rA, rS, rdA, rdS, thrBefore, recTex, taps);
+        lastRec = drMakeRecord(rA, rS, rdA, rdS, thrBefore, recTex, taps);
+        // a path that ends here with no shadow ray outstanding is swept in this pass: its last record never leaves the registers
+        lastInRegs = ended && !wantShadow;
+        if (!lastInRegs) drStoreRecord(job.record, job.itemCount, s, bounce - 1u, lastRec);
       }
-      if (didBounce) bounce++;
-      if ((flags & RAY_FLAG_IS_DEAD) != 0 || bounce >= S.traceDepth) {
+      if (ended) {
         if (!DR && (flags & RAY_FLAG_OUT_OF_SCENE) != 0) {                  // kernel_HitEnvironment (integrator_pt.cpp:550-595)
           const V3 env = environmentRadiance(S, rdir, misPdf, flags, XY);
           if (S.integratorType == INTEGRATOR_STUPID_PT) accum = thr * env; else accum = accum + thr * env;
@@ -136,7 +144,7 @@ __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const W
         P.lossSlot[s] += (diff.x * diff.x + diff.y * diff.y + diff.z * diff.z) / float(job.passNum);
         float* o = job.outColor + ((size_t)y * (uint)S.winWidth + x) * job.channels;
         o[0] += accum.x; o[1] += accum.y; o[2] += accum.z;
-        drReverseSweep(S, job.record, job.itemCount, s, bounce, tailR + env, diff, job.grad, job.drSkipNonFinite != 0u, drStage + (threadIdx.x >> 6) * DR_STAGE_DWORDS);
+        closing = true; sweepBounce = bounce; sweepDiff = diff; sweepTail = tailR + env;
       }
     } else if (finalize) {                                                   // kernel_ContributeToImage (integrator_pt.cpp:598-657)
       const uint pixel = ((XY & 0xFFFF0000u) >> 16) * (uint)S.winWidth + (XY & 0x0000FFFFu);
@@ -166,6 +174,9 @@ __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const W
     }
     P.status[s] = (passes << 8) | (alive ? WF_ALIVE : 0u) | (wantShadow ? WF_PEND : 0u) | (ending ? WF_ENDING : 0u);
   }
+  if (DR && __any(closing))
+    drReverseSweep(S, job.record, job.itemCount, s < job.itemCount ? s : 0u, closing, sweepBounce, sweepTail, sweepDiff, job.grad, job.drSkipNonFinite != 0u,
+                   drStage + (threadIdx.x >> 6) * DR_STAGE_DWORDS, lastRec, lastInRegs);
   // ray compaction: ballot + prefix sum, one atomic per wave and queue
   const bool qNear = active && alive, qShad = active && wantShadow;
   uint kn, ks;

@@ -261,6 +261,12 @@ int  hpt_get_execution_time(hpt_ctx* ctx, const char* funcName, float out[4]);
  * (lane utilisation of traversal = [1] / (64 * [14]), [2] / (64 * [15])). The instrumented kernel is a separate build: never timed. */
 int  hpt_set_instrumentation(hpt_ctx* ctx, int enabled);
 int  hpt_get_counters(hpt_ctx* ctx, uint64_t out[16]);
+/* The instrumented PathTraceDR launch (hpt_set_instrumentation(1) before hpt_path_trace_dr*; megakernel schedule) also fills: out[0] = adjoint
+ * records stored (one per bounce), out[1] = of those with a parameter texture (gradient taps), out[2] / out[3] = wave-cycles of the record
+ * stores / of the reverse sweeps (same clock as hpt_get_counters' phase slots, whose "path end" slot then excludes them), out[4] = wave-trips
+ * that ran a sweep, out[5] = lanes in those sweeps, out[6] = atomic wave-instructions issued, out[7] = bounces the sweeps walked.
+ * No counterpart in the reference (diff_render/integrator_dr.cpp:1135-1218 has no profile hooks). */
+int  hpt_get_dr_counters(hpt_ctx* ctx, uint64_t out[8]);
 /* Launch geometry of the persistent kernel: blocks per CU (0 = automatic). */
 int  hpt_set_launch_config(hpt_ctx* ctx, int blocksPerCU);
 /* Acceleration-structure layout chosen at the next hpt_commit_scene: 0 = automatic (the triangle sweep for scenes of <= 32 instanced
@@ -322,6 +328,10 @@ int  hpt_get_accel_info(hpt_ctx* ctx, float out[4]);
  * hpt_set_option("refit", 0) forces the build. */
 int  hpt_get_commit_time(hpt_ctx* ctx, float out[4]);
 int  hpt_get_schedule(hpt_ctx* ctx, int* lastSchedule, uint32_t* lastIterations);
+/* What the last hpt_path_trace_* call walked (no counterpart in the reference: lets a test assert WHICH kernels produced a frame):
+ * out[0] = schedule (1 / 2), out[1] = 1 when rays walked the 4-wide compressed tree, out[2] = 1 when surface data came from the 64-byte
+ * shading records, out[3] = 1 when the traversal stacks had an HBM part. */
+int  hpt_get_last_launch(hpt_ctx* ctx, uint32_t out[4]);
 /* Duration of the last path-tracing kernel, measured with HIP events on the stream it ran on (ms). */
 int  hpt_last_kernel_ms(hpt_ctx* ctx, float* ms);
 

@@ -5,15 +5,15 @@ fixtures are tests/golden/make_film_scene.py's, built on the reference's spectra
 import numpy as np
 import pytest
 
-from conftest import scene_path
+from conftest import scene_path, pixel_errors, assert_pixel_parity
 from hydracore3_amd.scene import load_hydra_xml, MAT_TYPE_THIN_FILM, FILM_PRECOMP_FLAG, FILM_TRANSPARENT
 
 pytestmark = pytest.mark.gpu
 
 
 def _l2(a, b, spp):
-    d = (a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64)) / spp
-    return float(np.sqrt(np.mean(np.sum(d * d, axis=-1))))
+    """the per-pixel bar: the LARGEST L2 norm of a pixel's RGB difference between the spp-normalised frames (conftest.pixel_errors)"""
+    return float(pixel_errors(a, b, spp).max())
 
 
 def _compare(tag, a, b, spp, max_apart):

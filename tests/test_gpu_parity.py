@@ -4,16 +4,23 @@ import os
 import numpy as np
 import pytest
 
-from conftest import scene_path
+from conftest import scene_path, pixel_errors, assert_pixel_parity
 from hydracore3_amd.scene import load_hydra_xml, INTEGRATOR_MIS_PT, INTEGRATOR_SHADOW_PT
 
 pytestmark = pytest.mark.gpu
 
 
 def per_pixel_l2(a, b, spp):
-    """RMS over pixels of the RGB difference of the spp-normalised images (north_star: per-pixel L2 < 1e-3)."""
-    d = (a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64)) / spp
-    return float(np.sqrt(np.mean(np.sum(d * d, axis=-1))))
+    """north_star's bar, per pixel: the LARGEST L2 norm of a pixel's RGB difference between the spp-normalised frames (not a mean over the
+    frame, which hides single pixels far above the bar). Tests that may meet a divergent path use conftest.assert_pixel_parity, which
+    holds every pixel whose generators agree to the bar and counts the others against a written bound."""
+    return float(pixel_errors(a, b, spp).max())
+
+
+def rms_l2(a, b, spp):
+    """RMS over the frame of the per-pixel L2 norms: a tighter, frame-wide figure some tests hold IN ADDITION to the per-pixel bar."""
+    e = pixel_errors(a, b, spp)
+    return float(np.sqrt(np.mean(e * e)))
 
 
 def random_rays(n, seed, lo=-6.0, hi=6.0):
@@ -71,10 +78,9 @@ def test_cornell_render_matches_oracle(cornell):
     sc, gpu, cpu = cornell
     spp = 16
     img_g, img_c = gpu.render(spp), cpu.render(spp)
-    l2 = per_pixel_l2(img_g, img_c, spp)
+    assert_pixel_parity(img_g, img_c, spp, gpu, cpu, max_divergent=0, what="test_035 128x128 @ 16 spp: ")
     same = np.mean(np.all(img_g[..., :3] == img_c[..., :3], axis=-1))
-    print(f"per-pixel L2 = {l2:.3e}, bit-identical pixels = {same * 100:.2f}%")
-    assert l2 < 1e-3
+    print(f"bit-identical pixels = {same * 100:.2f}%")
     assert same > 0.2     # the rest differ in the last bits only (device libm vs glibc sin/cos/pow)
     # the RNG streams advanced identically wherever the paths did not diverge
     assert np.mean(np.all(gpu.random_gens() == cpu.random_gens(), axis=1)) > 0.99
@@ -108,17 +114,15 @@ def test_tid_subranges_compose(cornell):
     assert np.array_equal(img, full)
 
 
-def _parity(sc, spp, params=None, naive=False, tol=1e-3):
+def _parity(sc, spp, params=None, naive=False, tol=1e-3, max_divergent=0):
     from hydracore3_amd.api import HipIntegrator
     from oracle.orc import OracleIntegrator
     gpu, cpu = HipIntegrator(sc, params), OracleIntegrator(sc, params)
     a, b = gpu.render(spp, naive=naive), cpu.render(spp, naive=naive)
     assert np.isfinite(a).all()
-    l2 = per_pixel_l2(a, b, spp)
     scale = max(float(np.mean(b[..., :3]) / spp), 1e-6)
-    same_rng = float(np.mean(np.all(gpu.random_gens() == cpu.random_gens(), axis=1)))
-    print(f"per-pixel L2 = {l2:.3e} (mean radiance {scale:.4f}), identical RNG streams = {same_rng * 100:.2f}%")
-    assert l2 < tol
+    print(f"mean radiance {scale:.4f}")
+    assert_pixel_parity(a, b, spp, gpu, cpu, tol=tol, max_divergent=max_divergent)
     return gpu, cpu, a, b
 
 
@@ -461,13 +465,11 @@ def test_fuzzed_scenes_match_oracle(seed):
     spp = 4
     a, b = gpu.render(spp), cpu.render(spp)
     assert np.isfinite(b).all()
-    l2 = per_pixel_l2(a, b, spp)
     # a path that takes another branch somewhere (device vs glibc sinf / cosf / powf differ in the last bit; a degenerate step amplifies it:
-    # DESIGN.md 3, profiles/fuzz_sweep.py - about one scene in 200) leaves its pixel's generator in another state: counted, not tolerated silently
-    differ = int(np.sum(np.any(gpu.random_gens() != cpu.random_gens(), axis=1)))
-    print(f"seed {seed}: depth {sc.trace_depth}, {len(sc.lights)} lights, L2 {l2:.2e}, pixels with a divergent path: {differ} of {gpu.N}")
-    assert l2 < 1e-3
-    assert differ <= 2
+    # DESIGN.md 3, profiles/fuzz_sweep.py - about one scene in 200) leaves its pixel's generator in another state: counted against a bound of 2
+    # pixels, every other pixel held to the 1e-3 bar on its own
+    print(f"seed {seed}: depth {sc.trace_depth}, {len(sc.lights)} lights")
+    assert_pixel_parity(a, b, spp, gpu, cpu, max_divergent=2, what=f"fuzz seed {seed}: ")
     pos, dr = random_rays(3000, seed, -5.0, 6.0)
     hg, hc = gpu.RayQuery_NearestHit(pos, dr), cpu.ray_nearest(pos, dr, brute=True)
     for f in ("primId", "instId", "geomId"):
@@ -665,13 +667,13 @@ def test_plastic_material_matches_oracle():
         a, b = gpu.render(8), cpu.render(8)
         l2 = per_pixel_l2(a, b, 8)
         print(f"plastic ({integ}): L2 {l2:.2e}, mean {a[..., :3].mean() / 8:.4f}")
-        assert l2 < 1e-4 and np.isfinite(a).all() and a[..., :3].mean() > 0.05
+        assert l2 < 1e-3 and rms_l2(a, b, 8) < 1e-4 and np.isfinite(a).all() and a[..., :3].mean() > 0.05
         assert np.array_equal(gpu.random_gens(), cpu.random_gens())
         wf = HipIntegrator(sc, prm); wf.set_schedule(2)
         assert np.array_equal(wf.render(8), a)
     gn, cn = HipIntegrator(sc), OracleIntegrator(sc)
     nv, nc = gn.render(4, naive=True), cn.render(4, naive=True)
-    assert per_pixel_l2(nv, nc, 4) < 1e-4 and np.array_equal(gn.random_gens(), cn.random_gens())
+    assert per_pixel_l2(nv, nc, 4) < 1e-3 and rms_l2(nv, nc, 4) < 1e-4 and np.array_equal(gn.random_gens(), cn.random_gens())
     # a table that does not fit m_arrays1f is refused, not read out of bounds
     from hydracore3_amd.api import HydraHipError
     bad = M[6].copy(); bad["datai"][0] = sc.arrays1f.size - 10
@@ -781,13 +783,13 @@ def test_blend_materials_match_oracle():
         a, b = gpu.render(8), cpu.render(8)
         l2 = per_pixel_l2(a, b, 8)
         print(f"blend ({integ}): L2 {l2:.2e}, mean {a[..., :3].mean() / 8:.4f}")
-        assert l2 < 1e-5 and np.isfinite(a).all() and a[..., :3].mean() > 0.05
+        assert l2 < 1e-3 and rms_l2(a, b, 8) < 1e-5 and np.isfinite(a).all() and a[..., :3].mean() > 0.05
         assert np.array_equal(gpu.random_gens(), cpu.random_gens())
         wf = HipIntegrator(sc, prm); wf.set_schedule(2)
         assert np.array_equal(wf.render(8), a)
     gn, cn = HipIntegrator(sc), OracleIntegrator(sc)
     nv, nc = gn.render(4, naive=True), cn.render(4, naive=True)
-    assert per_pixel_l2(nv, nc, 4) < 1e-5 and np.array_equal(gn.random_gens(), cn.random_gens())
+    assert per_pixel_l2(nv, nc, 4) < 1e-3 and rms_l2(nv, nc, 4) < 1e-5 and np.array_equal(gn.random_gens(), cn.random_gens())
     # a reference cycle among blends would never end on the device: refused at upload and at Update_m_materials
     from hydracore3_amd.api import HydraHipError
     import ctypes as C
@@ -832,7 +834,7 @@ def test_event_bits_inherit_material_id_bits():
             l2 = per_pixel_l2(a, b, 4)
             print(f"{kind} at material id {which}, naive {naive}: L2 {l2:.2e}")
             assert np.array_equal(gpu.random_gens(), cpu.random_gens()), (which, kind, naive)
-            assert l2 < 1e-5 and np.isfinite(a).all()
+            assert l2 < 1e-3 and rms_l2(a, b, 4) < 1e-5 and np.isfinite(a).all()
 
 
 def test_normal_map_bump_matches_oracle():
@@ -878,13 +880,13 @@ def test_normal_map_bump_matches_oracle():
         a, b = gpu.render(8), cpu.render(8)
         l2 = per_pixel_l2(a, b, 8)
         print(f"bump ({integ}): L2 {l2:.2e}, mean {a[..., :3].mean() / 8:.4f}")
-        assert l2 < 1e-4 and np.isfinite(a).all() and a[..., :3].mean() > 0.05
+        assert l2 < 1e-3 and rms_l2(a, b, 8) < 1e-4 and np.isfinite(a).all() and a[..., :3].mean() > 0.05
         assert np.array_equal(gpu.random_gens(), cpu.random_gens())
         wf = HipIntegrator(sc, prm); wf.set_schedule(2)
         assert np.array_equal(wf.render(8), a)
     gn, cn = HipIntegrator(sc), OracleIntegrator(sc)
     nv, nc = gn.render(4, naive=True), cn.render(4, naive=True)
-    assert per_pixel_l2(nv, nc, 4) < 1e-4 and np.array_equal(gn.random_gens(), cn.random_gens())
+    assert per_pixel_l2(nv, nc, 4) < 1e-3 and rms_l2(nv, nc, 4) < 1e-4 and np.array_equal(gn.random_gens(), cn.random_gens())
     # the maps matter: the same scene without them renders a different frame
     for m in sc.materials:
         m["texid"][1] = 0xFFFFFFFF
@@ -1063,10 +1065,11 @@ def test_motion_blur_matches_oracle():
         a, b = g.render(8), c.render(8)
         l2 = per_pixel_l2(a, b, 8)
         print(f"motion blur ({integ}): L2 {l2:.2e}")
-        assert l2 < 1e-4 and np.isfinite(a).all()
+        assert l2 < 1e-3 and rms_l2(a, b, 8) < 1e-4 and np.isfinite(a).all()
         assert np.array_equal(g.random_gens(), c.random_gens())
     gn, cn = HipIntegrator(sc), OracleIntegrator(sc)
-    assert per_pixel_l2(gn.render(4, naive=True), cn.render(4, naive=True), 4) < 1e-4 and np.array_equal(gn.random_gens(), cn.random_gens())
+    nv, nc = gn.render(4, naive=True), cn.render(4, naive=True)
+    assert per_pixel_l2(nv, nc, 4) < 1e-3 and rms_l2(nv, nc, 4) < 1e-4 and np.array_equal(gn.random_gens(), cn.random_gens())
     # the same scene frozen at time 0 renders differently (and draws one generator step less per path)
     still = _motion_scene(); still.inst_motion = {}
     s = HipIntegrator(still).render(8)
@@ -1130,6 +1133,8 @@ def test_cam_plugin_driver_loop_matches_the_camera_path(tmp_path):
 
 
 # ---- BASELINE configs[0] (C1) at its stated size ------------------------------------------------------------------------------------------
+INTERIOR_MAX_DIVERGENT = 2      # pixels of 15 360 x 8 spp whose path took another branch than the checker's (glossy / coated gltf lobes: sinf / cosf / powf); measured 0
+INTERIOR_MAX_OVER = 8           # ... and pixels over the 1e-3 bar (a shadow ray between 17 K triangles that came out the other way: same draws, one light sample apart); measured 3
 C1_MAX_DIVERGENT_PIXELS = 64     # measured 2026-10 (MI355X vs this oracle on x86-64 glibc): see the printed count; the bound leaves ~4x room
 
 
@@ -1145,16 +1150,13 @@ def test_c1_cornell_512x512_64spp_matches_oracle():
     spp = 64
     gpu, cpu = HipIntegrator(sc), OracleIntegrator(sc, threads=len(os.sched_getaffinity(0)))
     img_g, img_c = gpu.render(spp), cpu.render(spp)
-    l2 = per_pixel_l2(img_g, img_c, spp)
-    differ = int(np.sum(np.any(gpu.random_gens() != cpu.random_gens(), axis=1)))
-    worst = float(np.abs(img_g[..., :3] - img_c[..., :3]).max()) / spp
-    print(f"C1 512x512 @ 64 spp: per-pixel L2 = {l2:.3e}, worst pixel {worst:.3e}, pixels with a divergent path: {differ} of {gpu.N} ({differ / (gpu.N * spp) * 1e6:.2f} per million paths)")
-    assert l2 < 1e-3
-    assert differ <= C1_MAX_DIVERGENT_PIXELS
+    worst_ok, rms, over, differ = assert_pixel_parity(img_g, img_c, spp, gpu, cpu, max_divergent=C1_MAX_DIVERGENT_PIXELS, what="C1 512x512 @ 64 spp: ")
+    print(f"C1: {differ / (gpu.N * spp) * 1e6:.2f} divergent paths per million")
     assert np.all(img_g[..., 3] == 0)
 
 
 # ---- the reference's own motion-blur fixture -----------------------------------------------------------------------------------------------
+MOTION_FIXTURE_MAX_DIVERGENT = 30   # of 6144 pixels x 16 spp: was "identical generators > 99.5 %" (the interpolated normal of the moving box)
 MOTION_XML = os.path.join(os.path.dirname(scene_path("test_035")), "motion_test.xml")
 
 
@@ -1176,10 +1178,7 @@ def test_reference_motion_fixture_matches_oracle(tmp_path):
             assert np.array_equal(hg[f], hc[f]), (time, f)
     spp = 16
     a, b = gpu.render(spp), cpu.render(spp)
-    l2 = per_pixel_l2(a, b, spp)
-    same = float(np.mean(np.all(gpu.random_gens() == cpu.random_gens(), axis=1)))
-    print(f"motion_test.xml: per-pixel L2 = {l2:.2e}, identical generators {same * 100:.3f} %")
-    assert l2 < 1e-3 and same > 0.995
+    assert_pixel_parity(a, b, spp, gpu, cpu, max_divergent=MOTION_FIXTURE_MAX_DIVERGENT, what="motion_test.xml: ")
     still = load_hydra_xml(MOTION_XML, 96, 64); still.inst_motion = {}
     assert per_pixel_l2(HipIntegrator(still).render(spp), a, spp) > 3e-3          # the box really smears
     tool = os.path.join(ROOT, "hydracore3_amd", "hydra_hip_render")
@@ -1347,6 +1346,29 @@ def test_wide_compressed_tree_returns_what_the_bvh2_returns():
     assert wide.commit_time()["refitted"]
     assert np.array_equal(wide.RayQuery_NearestHit(pos, dr).view(np.uint8), narrow.RayQuery_NearestHit(pos, dr).view(np.uint8))
     assert not np.array_equal(wide.RayQuery_NearestHit(pos, dr).view(np.uint8), hw.view(np.uint8))
+
+
+def test_interior_frame_matches_oracle():
+    """The kernels BASELINE configs[2] / [4] are timed on - wfShadeKernel<LEAN> + wfTraceKernel<WIDE> on the 4-wide compressed tree with the
+    64-byte shading records - against the CPU oracle DIRECTLY (not through the chain wavefront == megakernel == BVH2 == oracle): a
+    17 K-triangle miniature of the interior (same generator, same materials, SAH estimate ~40: heavy), frame and generators, per pixel."""
+    from hydracore3_amd.api import HipIntegrator
+    from hydracore3_amd import synth
+    from oracle.orc import OracleIntegrator
+    sc = synth.interior_scene(160, 96, subdiv=1, tex_size=16)
+    gpu, cpu = HipIntegrator(sc), OracleIntegrator(sc, threads=len(os.sched_getaffinity(0)))
+    gpu.set_schedule(2)
+    spp = 8
+    a, b = gpu.render(spp), cpu.render(spp)
+    info = gpu.accel_info()
+    assert gpu.last_schedule()[0] == 2 and info["layout"] == "flat" and info["sah_node_visits"] >= 20.0
+    ll = gpu.last_launch()
+    assert ll["schedule"] == 2 and ll["wide_nodes"] and ll["shade_records"], ll
+    assert np.isfinite(a).all() and a[..., :3].mean() / spp > 0.05
+    assert_pixel_parity(a, b, spp, gpu, cpu, max_divergent=INTERIOR_MAX_DIVERGENT, max_over=INTERIOR_MAX_OVER, what="interior 160x96 @ 8 spp, wavefront + 4-wide tree + shading records: ")
+    # ... and the megakernel on the same tree gives the same frame bit for bit
+    mega = HipIntegrator(sc); mega.set_schedule(1)
+    assert np.array_equal(mega.render(spp), a) and np.array_equal(mega.random_gens(), gpu.random_gens())
 
 
 def test_exr_environment_map_renders_like_the_image4f_one():

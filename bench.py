@@ -5,20 +5,23 @@
 
 A *step* is one PathTraceBlock call over the whole frame (W*H pixels x spp passes, MIS path tracing) with the framebuffer,
 RNG states and scene resident in HBM. N = 1 runs BASELINE.json configs[1] (scenes/test_035 Cornell box, 1024 x 1024, 1024 spp)
-and appends ("also") short runs of configs[2] (1M-triangle interior, wavefront schedule), configs[3] (PathTraceDR + Adam), the reference's spectral fixture and a thin-film fixture.
+and appends ("also") the other configurations AT THEIR STATED SIZES: configs[2] (1M-triangle interior, 1920 x 1080 @ 1024 spp, wavefront
+schedule, one step), configs[3] (PathTraceDR + Adam on the test_228 class, 512^2 @ 256 spp), configs[4] (1M triangles, 4096^2 x 4 albedo,
+1920 x 1080 @ 512 spp, fwd + bwd + Adam, one step), the reference's spectral fixture and a thin-film fixture - each with its own roofline.
 
 N > 1: one rank per GPU (the scene is replicated, no data-path collective but ONE RCCL reduce(SUM) of the framebuffer per step).
 Started plainly (`python bench.py --gpus N`, WORLD_SIZE unset) the script spawns its N ranks itself through
 `python -m torch.distributed.run` BEFORE touching the GPU; started by torch.distributed.run it reads RANK / WORLD_SIZE.
 
   --scaling strong (default)  FIXED TOTAL WORK: one frame at --spp.
-        --shard samples (default)  every rank renders ALL pixels with spp / N passes from its own RNG sub-streams (generators seeded as
-                                   threads r*W*H.. of one big InitRandomGens call); the reduce adds the N partial frames. Per-GPU
-                                   parallelism stays at W*H pixels, so the per-GPU rate does not fall with N.
-        --shard pixels             the north-star split: rank r renders every N-th 1024-tid chunk of the swizzled pixel order at the full
-                                   --spp, bit-identical to the single-GPU frame. A pixel's passes are sequential (its RNG stream continues
-                                   from pass to pass), so small frames run out of independent paths per GPU ("multi-GPU").
-        The JSON line's `value` is the samples split; the pixels split is timed as well and reported under "also".
+        --shard pixels (default)   the north-star split: rank r renders every N-th 1024-tid chunk of the swizzled pixel order at the full
+                                   --spp into a zeroed full-size frame; the reduce(SUM) assembles the frame, BIT-IDENTICAL to the single-GPU
+                                   frame (the reference's result). A pixel's passes are sequential (its RNG stream continues from pass
+                                   to pass), so small frames run out of independent paths per GPU ("multi-GPU").
+        --shard samples            every rank renders ALL pixels with spp / N passes from its own RNG sub-streams (generators seeded as
+                                   threads r*W*H.. of one big InitRandomGens call); the reduce adds the N partial frames: a statistically
+                                   equivalent frame, not the reference's. Per-GPU parallelism stays at W*H pixels.
+        The JSON line's `value` is the pixels split; the samples split is timed as well and reported under "also".
   --scaling weak              every rank renders the whole frame at the full --spp (N x the samples in the same time): per-GPU work fixed.
 
 Sharded frames are verified on rank 0 after the timed region (at 8 spp; --no-verify skips it).
@@ -194,7 +197,7 @@ def make_roofline(workload, integ, torch, dev, stream, N, W, H, spp, t_count, ke
 
 
 # ---- forward workloads ------------------------------------------------------------------------------------------------------------------
-def run_forward(args, workload, rank, world, dev, dist, backend, steps, warmup, spp, shard, with_roofline=True):
+def run_forward(args, workload, rank, world, dev, dist, backend, steps, warmup, spp, shard, with_roofline=True, warmup_spp=None):
     """Times `steps` PathTraceBlock calls; returns the result dict (rank 0) or None."""
     import numpy as np
     import torch
@@ -238,10 +241,11 @@ def run_forward(args, workload, rank, world, dev, dist, backend, steps, warmup, 
             if rank == 0:
                 f.copy_(host)
 
-    def step():
+    def step(n_spp=None):
         frame.zero_()
-        if my_spp > 0:
-            integ.path_trace_block_dev(frame.data_ptr(), my_spp, t_begin, t_count, 4, False, stream)
+        n_spp = my_spp if n_spp is None else n_spp
+        if n_spp > 0:
+            integ.path_trace_block_dev(frame.data_ptr(), n_spp, t_begin, t_count, 4, False, stream)
         reduce_frame(frame)
 
     def sync():
@@ -250,7 +254,9 @@ def run_forward(args, workload, rank, world, dev, dist, backend, steps, warmup, 
         torch.cuda.synchronize()
 
     for _ in range(warmup):
-        step()
+        step(min(my_spp, warmup_spp) if warmup_spp else None)     # (secondary workloads warm up at fewer passes: allocations, first launches)
+    if warmup_spp:
+        integ.InitRandomGens(N, first_seed=(rank * N if (share > 1 and (weak or shard == "samples")) else 0))   # the timed frame starts from the seeds a fresh integrator has
     sync()
     kernel_ms = []
     t0 = time.perf_counter()
@@ -333,7 +339,25 @@ def run_forward(args, workload, rank, world, dev, dist, backend, steps, warmup, 
 
 
 # ---- differentiable rendering -----------------------------------------------------------------------------------------------------------
-def run_dr(args, workload, rank, world, dev, dist, backend, steps, warmup, spp_arg):
+def dr_algorithmic_bytes(c, d, paths, spp, shade_records):
+    """SURVEY.md 8d with the adjoint term, from the counters of an instrumented PathTraceDR launch (hpt_get_counters / hpt_get_dr_counters):
+    traversal 64 B per node visit + 48 B per triangle test (+ 64 B per instance entered); per surface hit the shading data (one 64-byte
+    shading record, or 12 B indices + 96 B vertices + 4 + 8 + 64 B through the index chain), the 320-byte Material, the 320-byte LightSource of
+    the light sample and the parameter texture's 4 taps x 16 B; per pixel 36 B once per call; per sample the 16-byte reference pixel; the
+    adjoint: 68-byte records written (a path's last one stays in registers) and read back by the sweep, and per record with a parameter
+    texture 4 taps x 3 channels x 4 B x 2 of atomic read-modify-write."""
+    trav = c["nodes"] * 64 + c["tris"] * 48 + c["instances_entered"] * 64
+    surf = c["surface_hits"] * ((64 if shade_records else (12 + 96 + 4 + 8 + 64)) + 320 + 320) + d["records_with_taps"] * 4 * 16
+    per_pixel = 36.0 * (paths / spp) + 16.0 * paths
+    rec = (d["records_stored"] + max(d["sweep_bounces"] - (d["records"] - d["records_stored"]), 0)) * 68
+    atom = d["records_with_taps"] * 4 * 3 * 4 * 2
+    total = trav + surf + per_pixel + rec + atom
+    return {"total": total / paths, "traversal": trav / paths, "surface": surf / paths, "records": rec / paths, "atomics": atom / paths,
+            "nodes_per_ray": c["nodes"] / max(c["rays"], 1), "tris_per_ray": c["tris"] / max(c["rays"], 1), "rays_per_path": c["rays"] / paths,
+            "records_per_path": d["records"] / paths}
+
+
+def run_dr(args, workload, rank, world, dev, dist, backend, steps, warmup, spp_arg, warmup_spp=None):
     """IntegratorDR fwd+bwd + Adam.  dr: BASELINE.json configs[3] (test_228-class scene, 256 x 256 x 4 albedo, 512^2 @ 256 spp);
     dr_interior: configs[4] (1M-triangle interior, tex_size^2 x 4 fp32 albedo bound to its 32 gltf materials, 1920x1080).
     One step = memset(grad) + PathTraceDR (record, replay and adjoint fused, gradient atomics into HBM) [+ all_reduce(SUM) of the
@@ -346,7 +370,7 @@ def run_dr(args, workload, rank, world, dev, dist, backend, steps, warmup, spp_a
     big = workload == "dr_interior"
     if big:
         W, H = args.width or 1920, args.height or 1080
-        spp = spp_arg if spp_arg != 1024 else 16
+        spp = spp_arg if spp_arg != 1024 else 512                   # BASELINE configs[4]: fwd+bwd at 512 spp
         ts = int(os.environ.get("HYDRA_BENCH_TEX", "4096"))
         sc = interior_scene(W, H, tex_size=ts)                      # the generated texture is the checker the optimisation should recover
         tex_id, tw = 1, ts                                          # (texture 0 is the white dummy)
@@ -389,12 +413,13 @@ def run_dr(args, workload, rank, world, dev, dist, backend, steps, warmup, spp_a
     L = integ.L
     losses = []
 
-    def step(it):
+    def step(it, n_spp=None):
         grad.zero_(); loss.zero_(); frame.zero_()
-        if my_spp:
-            integ._chk(L.hpt_path_trace_dr_dev(integ.h, t_begin, t_count, 4, frame.data_ptr(), my_spp, ref.data_ptr(), data.data_ptr(), grad.data_ptr(), size, loss.data_ptr(), stream))
+        n_spp = my_spp if n_spp is None else n_spp
+        if n_spp:
+            integ._chk(L.hpt_path_trace_dr_dev(integ.h, t_begin, t_count, 4, frame.data_ptr(), n_spp, ref.data_ptr(), data.data_ptr(), grad.data_ptr(), size, loss.data_ptr(), stream))
             if samples and not weak and world > 1:
-                loss.mul_(float(my_spp) / float(spp))              # PathTraceDR's loss is the sample mean over ITS passes: weight by the share
+                loss.mul_(float(n_spp) / float(spp))               # PathTraceDR's loss is the sample mean over ITS passes: weight by the share
         if dist is not None:                                       # a_dataGrad: ncclAllReduce(sum), once per optimisation iteration
             if backend == "nccl":
                 dist.all_reduce(grad, op=dist.ReduceOp.SUM); dist.all_reduce(loss, op=dist.ReduceOp.SUM)
@@ -412,7 +437,7 @@ def run_dr(args, workload, rank, world, dev, dist, backend, steps, warmup, spp_a
         torch.cuda.synchronize()
 
     for i in range(warmup):
-        step(i)
+        step(i, min(my_spp, warmup_spp) if warmup_spp else None)
     sync()
     kms = []
     t0 = time.perf_counter()
@@ -435,18 +460,52 @@ def run_dr(args, workload, rank, world, dev, dist, backend, steps, warmup, spp_a
     what = (f"synthetic 1M-triangle interior + {tw}x{tw}x4 differentiable albedo, {W}x{H} @ {spp} spp" if big
             else f"scenes/test_228 + 256x256x4 differentiable albedo, {W}x{H} @ {spp} spp")
     k_ms = float(np.mean(kms))
-    roof = {"bound": "valu", "achieved": None, "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwaveinst/s", "frac": None, "traffic": None,
-            "kernel": "pathTraceKernel<DR>" if integ.last_schedule()[0] == 1 else "wavefront DR", "kernel_ms": round(k_ms, 3),
-            "note": "no PMC profile of this DR configuration is committed: unpriced"}
-    pmc = load_profile("pmc_dr.json") if not big else None
-    if pmc and pmc.get("valu_insts_per_path") and integ.last_schedule()[0] == 1 and world == 1:
-        # as for the forward kernel: profiled VALU wave-instructions per path x this launch's paths over the live kernel time
-        ginst = pmc["valu_insts_per_path"] * float(N * spp) / (k_ms * 1e-3) / 1e9
-        tj = load_profile("traffic_dr.json")
-        roof.update({"achieved": round(ginst, 2), "frac": round(ginst / VALU_PEAK_GINST, 4), "lane_utilisation": pmc.get("lane_utilisation"),
-                     "traffic": tj["hbm_bytes_per_launch"] * float(N * spp) / float(tj["paths_per_launch"]) if tj else None,
-                     "pmc_source": f"profiles/pmc_dr.json, collected at commit {pmc.get('commit')}; the kernel time is measured in this run",
-                     "note": "forward walk + reverse sweep + gradient scatter in one kernel; float atomics execute at the memory side and are not VALU work"})
+    sched_used, wf_rounds = integ.last_schedule()
+    launch = integ.last_launch()
+    wl = "dr_interior" if big else "dr"
+    roof = {"kernel": "pathTraceKernel<DR>" if sched_used == 1 else f"wavefront DR: {wf_rounds} x (wfShadeKernel<DR> + wfTraceKernel)", "kernel_ms": round(k_ms, 3)}
+    if world == 1:
+        # the counting probe: the instrumented PathTraceDR megakernel on the same frame at a few passes (it walks the tree the timed call walked)
+        probe_spp = min(spp, 8)
+        integ.set_schedule(1); integ.set_option("stats_wide", 1 if launch["wide_nodes"] else 0); integ.set_instrumentation(True)
+        integ.InitRandomGens(N)
+        grad.zero_(); loss.zero_(); frame.zero_()
+        integ._chk(L.hpt_path_trace_dr_dev(integ.h, 0, N, 4, frame.data_ptr(), probe_spp, ref.data_ptr(), data.data_ptr(), grad.data_ptr(), size, loss.data_ptr(), stream))
+        torch.cuda.synchronize()
+        cnt, dcnt = integ.counters(), integ.dr_counters()
+        integ.set_instrumentation(False)
+        ab = dr_algorithmic_bytes(cnt, dcnt, float(N) * probe_spp, probe_spp, launch["shade_records"])
+        paths = float(N) * spp
+        hbm_alg = ab["total"] * paths / (k_ms * 1e-3) / 1e9
+        tj = load_profile(f"traffic_{wl}.json")
+        traffic = tj["hbm_bytes_per_launch"] * paths / float(tj["paths_per_launch"]) if tj else None
+        pmc = load_profile(f"pmc_{wl}.json")
+        detail = {"algorithmic_bytes_per_path": round(ab["total"], 1), "traversal_bytes_per_path": round(ab["traversal"], 1), "surface_bytes_per_path": round(ab["surface"], 1),
+                  "record_bytes_per_path": round(ab["records"], 1), "atomic_bytes_per_path": round(ab["atomics"], 1), "nodes_per_ray": round(ab["nodes_per_ray"], 2),
+                  "tris_per_ray": round(ab["tris_per_ray"], 2), "rays_per_path": round(ab["rays_per_path"], 2), "records_per_path": round(ab["records_per_path"], 2),
+                  "traffic": traffic, "traffic_over_algorithmic": round(traffic / (ab["total"] * paths), 3) if traffic else None,
+                  "traffic_source": (f"{tj.get('from')}, collected at commit {tj.get('commit')}: per-path counter bytes (FETCH_SIZE doubled + WRITE_SIZE) rescaled to this launch, not measured in this run" if tj else None),
+                  "hbm_counter_frac": round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None}
+        hbm = {"achieved": round(hbm_alg, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_alg / HBM_PEAK_GBS, 4)}
+        if sched_used == 2:
+            # heavy scene: the wavefront DR pair is priced against HBM like the forward pair (algorithmic bytes incl. the adjoint term over the live time)
+            roof.update(dict({"bound": "hbm"}, **hbm, **detail))
+            roof["note"] = "achieved / frac = ALGORITHMIC bytes (SURVEY 8d incl. records and gradient atomics) over the live launch time; hbm_counter_frac is the HBM-side figure"
+            if pmc:
+                roof["lane_utilisation"] = pmc.get("lane_utilisation"); roof["pmc_source"] = f"profiles/pmc_{wl}.json, commit {pmc.get('commit')}"
+        else:
+            # light scene (the test_228 class lives in L2): VALU issue binds, as for the forward megakernel; the HBM model is carried beside it
+            roof.update({"bound": "valu", "achieved": None, "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwaveinst/s", "frac": None})
+            if pmc and pmc.get("valu_insts_per_path"):
+                ginst = pmc["valu_insts_per_path"] * paths / (k_ms * 1e-3) / 1e9
+                roof.update({"achieved": round(ginst, 2), "frac": round(ginst / VALU_PEAK_GINST, 4), "lane_utilisation": pmc.get("lane_utilisation"),
+                             "useful_lane_frac": round(ginst / VALU_PEAK_GINST * pmc.get("lane_utilisation", 0.0), 4),
+                             "pmc_source": f"profiles/pmc_{wl}.json, collected at commit {pmc.get('commit')}: SQ_INSTS_VALU per path; the kernel time is measured in this run"})
+            roof["hbm_algorithmic"] = dict(hbm, note="SURVEY 8d algorithmic bytes incl. the adjoint term; the scene and the 1 MB gradient live in L2, the records in L2 / Infinity Cache")
+            roof.update(detail)
+            roof["note"] = "forward walk + reverse sweep + gradient scatter in one kernel; float atomics execute at the memory side and are not VALU work"
+    else:
+        roof.update({"bound": "valu" if sched_used == 1 else "hbm", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None, "note": "priced on the single-GPU run only"})
     return {"metric": "Mpaths/s (fwd+bwd grad, IntegratorDR::PathTraceDR + Adam)", "value": round(value, 2), "unit": "Mpaths/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -456,24 +515,42 @@ def run_dr(args, workload, rank, world, dev, dist, backend, steps, warmup, spp_a
             "roofline": roof}
 
 
-def run_fixture(dev, scene_name, spectral, steps=3, size=1024, spp=64):
+def run_fixture(dev, scene_name, spectral, steps=3, size=1024, spp=64, profile=None, warmup=1, warmup_spp=4):
     """An `also` entry for a fixture scene of the reference's feature branches (spectral rendering, thin films): `steps` PathTraceBlock calls on a
-    device-resident frame, timed with HIP events around each launch (HipIntegrator.last_kernel_ms)."""
+    device-resident frame, timed with HIP events around each launch (HipIntegrator.last_kernel_ms). `profile`: name of the committed PMC
+    profile (profiles/pmc_<profile>.json, collected with `bench.py --workload <profile>` under rocprofv3) that prices the VALU roofline."""
     import numpy as np
     from hydracore3_amd.api import HipIntegrator
     from hydracore3_amd.scene import load_hydra_xml
     sc = load_hydra_xml(os.path.join(ROOT, "tests", "golden", "scenes", scene_name, "statex_00001.xml"), size, size, spectral=spectral)
     integ = HipIntegrator(sc, device=dev.index)
     frame = integ.dev_array(np.zeros((size, size, 4), np.float32))
-    integ.path_trace_block_dev(frame.ptr, 4)                       # warm-up
+    for _ in range(warmup):
+        integ.path_trace_block_dev(frame.ptr, warmup_spp)
     ms = []
     for _ in range(steps):
         integ.path_trace_block_dev(frame.ptr, spp)
         ms.append(integ.last_kernel_ms())
     mean_ms = sum(ms) / len(ms)
+    paths = float(size) * size * spp
+    roof = None
+    pmc = load_profile(f"pmc_{profile}.json") if profile else None
+    if pmc and pmc.get("valu_insts_per_path"):
+        # these scenes (16 K triangles, tables of a few hundred KB) live in L2: VALU issue binds, priced as for the Cornell megakernel
+        ginst = pmc["valu_insts_per_path"] * paths / (mean_ms * 1e-3) / 1e9
+        tj = load_profile(f"traffic_{profile}.json")
+        traffic = tj["hbm_bytes_per_launch"] * paths / float(tj["paths_per_launch"]) if tj else None
+        roof = {"bound": "valu", "achieved": round(ginst, 2), "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwaveinst/s", "frac": round(ginst / VALU_PEAK_GINST, 4),
+                "traffic": traffic, "lane_utilisation": pmc.get("lane_utilisation"), "useful_lane_frac": round(ginst / VALU_PEAK_GINST * pmc.get("lane_utilisation", 0.0), 4),
+                "kernel": "pathTraceSpectralKernel" if spectral else "pathTraceKernel<MODE 4: thin films>", "kernel_ms": round(mean_ms, 3),
+                "hbm_counter_frac": round(traffic / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
+                "pmc_source": f"profiles/pmc_{profile}.json, collected at commit {pmc.get('commit')}: SQ_INSTS_VALU per path and lane utilisation; the kernel time is measured in this run"}
     return {"workload": f"tests/golden/scenes/{scene_name} {size}x{size} @ {spp} spp, forward PathTraceBlock, " + ("m_spectral_mode = 1" if spectral else "RGB"),
-            "metric": "Mpaths/s (fwd PathTraceBlock, MIS path tracing)", "value": round(size * size * spp / mean_ms / 1e3, 2), "unit": "Mpaths/s", "steps": steps,
-            "ms_per_step": round(mean_ms, 3), "paths_per_step": size * size * spp, "sharding": "single GPU", "sharded_frame_verified": None, "roofline": None}
+            "metric": "Mpaths/s (fwd PathTraceBlock, MIS path tracing)", "value": round(paths / mean_ms / 1e3, 2), "unit": "Mpaths/s", "steps": steps,
+            "ms_per_step": round(mean_ms, 3), "paths_per_step": int(paths), "sharding": "single GPU", "sharded_frame_verified": None, "roofline": roof}
+
+
+FIXTURES = {"spectral": ("test_spectral", True), "film": ("thin_film", False)}
 
 
 def compact(r):
@@ -490,7 +567,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cornell", choices=["cornell", "interior", "dr", "dr_interior"])
+    ap.add_argument("--workload", default="cornell", choices=["cornell", "interior", "dr", "dr_interior", "spectral", "film"])
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=1024)
@@ -504,9 +581,9 @@ def main():
     ap.add_argument("--trace-blocks-per-cu", type=int, default=0)
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="N > 1: strong = fixed total work (one frame at --spp, split by --shard); weak = every rank renders the whole frame at --spp")
-    ap.add_argument("--shard", default="samples", choices=["samples", "pixels"],
-                    help="how --scaling strong splits the frame: samples = all pixels x spp/N passes per rank (RNG sub-streams); pixels = interleaved "
-                         "1024-tid chunks at the full spp (the north-star split, bit-identical to the single-GPU frame)")
+    ap.add_argument("--shard", default="pixels", choices=["pixels", "samples"],
+                    help="how --scaling strong splits the frame: pixels = interleaved 1024-tid chunks at the full spp (the north-star split, bit-identical to "
+                         "the single-GPU frame); samples = all pixels x spp/N passes per rank (RNG sub-streams: an equivalent frame, not the same one)")
     ap.add_argument("--emulate-share", type=int, default=1, help="study only: render rank 0's share of a K-rank job on one GPU (value = K x its rate: the K-GPU rate without the reduce)")
     ap.add_argument("--accel-layout", type=int, default=0, help="0 automatic, 1 two-level TLAS/BLAS, 2 single-level world-space BVH")
     ap.add_argument("--groups", type=int, default=0, help="wavefront: concurrent pixel groups (streams) per call, 0 = automatic")
@@ -568,7 +645,17 @@ def main():
             dist.init_process_group("gloo")
         dist.barrier()
 
-    if args.workload in ("dr", "dr_interior"):
+    if args.workload in FIXTURES:                                 # a feature-branch fixture on its own (the form the PMC profiles are collected on)
+        name, spectral = FIXTURES[args.workload]
+        fspp = args.spp if args.spp != 1024 else 64
+        r = run_fixture(dev, name, spectral, steps=args.steps, spp=fspp, profile=args.workload, warmup=args.warmup, warmup_spp=fspp) if rank == 0 else None   # (equal launches: what profiles/summarize.py divides by)
+        out = None
+        if r is not None:
+            out = {"metric": r["metric"], "value": r["value"], "unit": "Mpaths/s", "n_gpus": 1, "steps": r["steps"], "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+                   "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                   "config": {"workload": r["workload"], "paths_per_step": r["paths_per_step"], "sharding": "single GPU"},
+                   "roofline": r["roofline"] or {"kernel_ms": r["ms_per_step"]}, "cpu_baseline": None}
+    elif args.workload in ("dr", "dr_interior"):
         out = run_dr(args, args.workload, rank, world, dev, dist, backend, args.steps, args.warmup, args.spp)
         if out is not None:
             out["cpu_baseline"] = None
@@ -577,19 +664,23 @@ def main():
         if out is not None:
             out["cpu_baseline"] = cpu
         also = []
-        if world > 1 and args.scaling == "strong" and args.shard == "samples" and not args.no_also:
-            # the north-star split of the same fixed work, timed beside it
-            r = run_forward(args, args.workload, rank, world, dev, dist, backend, args.steps, args.warmup, args.spp, "pixels", with_roofline=False)
+        if world > 1 and args.scaling == "strong" and args.shard == "pixels" and not args.no_also:
+            # the sample split of the same fixed work (an equivalent frame from other RNG sub-streams), timed beside the north-star split
+            r = run_forward(args, args.workload, rank, world, dev, dist, backend, args.steps, args.warmup, args.spp, "samples", with_roofline=False)
             also.append(compact(r))
         if world == 1 and args.workload == "cornell" and not args.no_also and not (args.width or args.height):
-            # configs[2] and configs[3], short: the numbers DESIGN.md quotes, timed by whoever runs this line
-            r = run_forward(args, "interior", rank, world, dev, dist, backend, 2, 1, 64, args.shard)
+            # BASELINE's other configurations at their stated sizes, timed by whoever runs this line (one long step each, warmed up at a few passes)
+            r = run_forward(args, "interior", rank, world, dev, dist, backend, 1, 1, 1024, args.shard, warmup_spp=16)     # configs[2]: 1920 x 1080 @ 1024 spp
             also.append(compact(r))
-            r = run_dr(args, "dr", rank, world, dev, dist, backend, 3, 1, 1024)
+            torch.cuda.empty_cache()
+            r = run_dr(args, "dr", rank, world, dev, dist, backend, 3, 1, 1024)                                           # configs[3]: 512^2 @ 256 spp + Adam
             also.append(compact(r))
+            r = run_dr(args, "dr_interior", rank, world, dev, dist, backend, 1, 1, 1024, warmup_spp=8)                    # configs[4]: 4096^2 x 4 albedo @ 512 spp + Adam
+            also.append(compact(r))
+            torch.cuda.empty_cache()
             # the reference's spectral fixture under m_spectral_mode = 1, and the thin-film fixture (RGB): short, kernel-timed
-            also.append(run_fixture(dev, "test_spectral", True))
-            also.append(run_fixture(dev, "thin_film", False))
+            also.append(run_fixture(dev, "test_spectral", True, profile="spectral"))
+            also.append(run_fixture(dev, "thin_film", False, profile="film"))
         if out is not None and also:
             out["also"] = [a for a in also if a is not None]
 

@@ -337,9 +337,9 @@ class HipIntegrator:
         return dict(zip(COUNTER_NAMES, [int(v) for v in out]))
 
     def dr_counters(self):
-        out = (_u64 * 8)()
+        out = (_u64 * 16)()
         self._chk(self.L.hpt_get_dr_counters(self.h, out))
-        return dict(zip(("records", "records_with_taps", "cyc_record_store", "cyc_sweep", "sweep_wave_trips", "sweep_lanes", "atomic_wave_insts", "sweep_bounces"), [int(v) for v in out]))
+        return dict(zip(("records", "records_with_taps", "cyc_record_store", "cyc_sweep", "sweep_wave_trips", "sweep_lanes", "atomic_wave_insts", "sweep_bounces", "records_stored"), [int(v) for v in out]))
 
     def set_tid_interleave(self, chunk: int, stride: int):
         self._chk(self.L.hpt_set_tid_interleave(self.h, chunk, stride))

@@ -1494,7 +1494,10 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
     // lanes still walk pays even on light scenes: test_228 class 346 -> 364 Mpaths/s (forward: 698 -> 699; profiles/vote_medium.sh)
     DevScene Sd = c->S;
     if (c->nodeMinOverride < 0 && Sd.nodeMin < 4u) Sd.nodeMin = 4u;
-    if (stats) launchPT<true, true, 0>(Sd, job, blocks, st, deep); else launchPT<false, true, 0>(Sd, job, blocks, st, deep);
+    if (stats) {                                                 // the counting probe follows the walk an uninstrumented call would do (see the forward probe below)
+      Sd.statsWide = (wfWide(c) && (c->statsWide || useWavefront(c, naive, dr, false, job.tidCount))) ? 1u : 0u;
+      launchPT<true, true, 0>(Sd, job, blocks, st, deep || (Sd.statsWide && c->stackNeeded4 > (uint)LDS_STACK));
+    } else launchPT<false, true, 0>(Sd, job, blocks, st, deep);
   }
   else if (film) {
     if (inRays) launchPT<false, false, 6>(c->S, job, blocks, st, deep); else if (naive) launchPT<false, false, 5>(c->S, job, blocks, st, deep); else launchPT<false, false, 4>(c->S, job, blocks, st, deep);
@@ -1993,13 +1996,13 @@ extern "C" int hpt_get_counters(hpt_ctx* c, uint64_t out[16])
   HIPCHK(c, hipMemcpy(out, c->dCounters.p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return HPT_OK;
 }
-extern "C" int hpt_get_dr_counters(hpt_ctx* c, uint64_t out[8])
+extern "C" int hpt_get_dr_counters(hpt_ctx* c, uint64_t out[16])
 {
   if (!c || !out) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
-  if (!c->dCounters.p) { for (int i = 0; i < 8; i++) out[i] = 0; return HPT_OK; }
+  if (!c->dCounters.p) { for (int i = 0; i < 16; i++) out[i] = 0; return HPT_OK; }
   HIPCHK(c, hipDeviceSynchronize());
-  HIPCHK(c, hipMemcpy(out, (const uint64_t*)c->dCounters.p + 16, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(out, (const uint64_t*)c->dCounters.p + 16, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return HPT_OK;
 }
 extern "C" int hpt_set_tid_interleave(hpt_ctx* c, uint32_t chunk, uint32_t stride)

@@ -51,7 +51,7 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
   const uint maxBounce = NAIVE ? S.traceDepth + 1u : S.traceDepth;
   // diagnostic stamps (STATS build only; never in a timed kernel): where a wave's cycles go, phase by phase
   unsigned long long tPh[7] = {0, 0, 0, 0, 0, 0, 0}, tTrips = 0, tPrev = 0;
-  unsigned long long nRec = 0, nRecTex = 0, nSweepTrips = 0, nSweepLanes = 0, nAtomInst = 0, nSweepBounces = 0;   // PathTraceDR probe (STATS && DR)
+  unsigned long long nRec = 0, nRecTex = 0, nSweepTrips = 0, nSweepLanes = 0, nAtomInst = 0, nSweepBounces = 0, nRecStored = 0;   // PathTraceDR probe (STATS && DR)
 #define STAMP(i) do { if (STATS) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tPh[i] += tn - tPrev; tPrev = tn; } } while (0)
   if (STATS) tPrev = __builtin_amdgcn_s_memtime();
 
@@ -163,7 +163,7 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
 #ifndef HPT_DBG_DR_NOSTORE   // diagnostic builds only (profiles/dr_ab.sh): what do the record stores cost?
         if (!ended) drStoreRecord(job.record, job.recordLanes, glane, bounce - 1u, lastRec);
 #endif
-        if (STATS) { nRec++; if (recTex != 0xFFFFFFFFu) nRecTex++; }
+        if (STATS) { nRec++; if (recTex != 0xFFFFFFFFu) nRecTex++; if (!ended) nRecStored++; }
         STAMP(5);
       }
       if (ended) {
@@ -234,9 +234,9 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
     if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 5; i++) atomicAdd(&job.counters->v[8 + i], tPh[i]); atomicAdd(&job.counters->v[13], tTrips); }
     if (DR) {
       if ((threadIdx.x & 63) == 0) { atomicAdd(&job.counters->v[18], tPh[5]); atomicAdd(&job.counters->v[19], tPh[6]); }
-      unsigned long long w[6] = { nRec, nRecTex, nSweepTrips, nSweepLanes, nAtomInst, nSweepBounces };
-      const int slot[6] = { 16, 17, 20, 21, 22, 23 };
-      for (int i = 0; i < 6; i++) {
+      unsigned long long w[7] = { nRec, nRecTex, nSweepTrips, nSweepLanes, nAtomInst, nSweepBounces, nRecStored };
+      const int slot[7] = { 16, 17, 20, 21, 22, 23, 24 };
+      for (int i = 0; i < 7; i++) {
         unsigned long long x = w[i];
         for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
         if ((threadIdx.x & 63) == 0 && x) atomicAdd(&job.counters->v[slot[i]], x);

@@ -196,9 +196,9 @@ struct DevScene
   const uint*        specTexOffsetSz;
 };
 
-struct Counters { unsigned long long v[24]; };  // rays, nodes, tris, surfaceHits, shadowRays, paths, instEnter, texFetch,
+struct Counters { unsigned long long v[32]; };  // rays, nodes, tris, surfaceHits, shadowRays, paths, instEnter, texFetch,
                                                 // then wave-cycles (s_memtime) of: queue+regen, closest-hit traversal, shading, shadow traversal, path end; loop trips;
                                                 // [16..23] PathTraceDR probe: records stored, records with a parameter texture, wave-cycles of the record stores, of the
-                                                // reverse sweeps, wave-trips with a sweep, lanes in those sweeps, atomic wave-instructions, bounces walked by sweeps
+                                                // reverse sweeps, wave-trips with a sweep, lanes in those sweeps, atomic wave-instructions, bounces walked by sweeps, [24] records written to HBM
 
 } // namespace hpt

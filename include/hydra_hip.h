@@ -264,9 +264,10 @@ int  hpt_get_counters(hpt_ctx* ctx, uint64_t out[16]);
 /* The instrumented PathTraceDR launch (hpt_set_instrumentation(1) before hpt_path_trace_dr*; megakernel schedule) also fills: out[0] = adjoint
  * records stored (one per bounce), out[1] = of those with a parameter texture (gradient taps), out[2] / out[3] = wave-cycles of the record
  * stores / of the reverse sweeps (same clock as hpt_get_counters' phase slots, whose "path end" slot then excludes them), out[4] = wave-trips
- * that ran a sweep, out[5] = lanes in those sweeps, out[6] = atomic wave-instructions issued, out[7] = bounces the sweeps walked.
+ * that ran a sweep, out[5] = lanes in those sweeps, out[6] = atomic wave-instructions issued, out[7] = bounces the sweeps walked,
+ * out[8] = records written to HBM (a path's last record stays in registers when the path ends in the same trip); out[9..15] reserved (0).
  * No counterpart in the reference (diff_render/integrator_dr.cpp:1135-1218 has no profile hooks). */
-int  hpt_get_dr_counters(hpt_ctx* ctx, uint64_t out[8]);
+int  hpt_get_dr_counters(hpt_ctx* ctx, uint64_t out[16]);
 /* Launch geometry of the persistent kernel: blocks per CU (0 = automatic). */
 int  hpt_set_launch_config(hpt_ctx* ctx, int blocksPerCU);
 /* Acceleration-structure layout chosen at the next hpt_commit_scene: 0 = automatic (the triangle sweep for scenes of <= 32 instanced

@@ -21,6 +21,10 @@ CALLS = 3     # profiles/collect.sh runs bench.py --steps 2 --warmup 1: three Pa
 def product_kernel(name):
     """Kernels of one PathTraceBlock call: the persistent megakernel, or the wavefront schedule's shade / trace / init kernels.
     The instrumented build (first template argument true / third for the trace kernel) is bench.py's counting probe, never timed."""
+    if workload == "spectral":
+        return "pathTraceSpectralKernel" in name
+    if workload == "film":
+        return "pathTraceKernel<false, false, 4" in name
     if workload.startswith("dr"):                 # bench.py renders the target image with the forward kernel first: not part of a PathTraceDR call
         return "pathTraceKernel<false, true" in name or ("wfShadeKernel<true" in name) or (workload == "dr_interior" and ("wfTraceKernel" in name or "wfInitKernel" in name))
     if "pathTraceKernel" in name:

@@ -938,15 +938,15 @@ def _bench_two_ranks(extra, timeout=900):
 
 def test_two_ranks_of_the_hip_path_reassemble_the_single_gpu_frame():
     """The multi-rank path of bench.py with the HIP kernels (two ranks sharing the box's one GPU, collectives staged over gloo - the rehearsal of
-    the RCCL run): plain `python bench.py --gpus 2` spawns the ranks itself; fixed total work split by SAMPLES (all pixels x spp / 2 per rank,
-    RNG sub-streams, frames summed) and by PIXELS (interleaved tid chunks, bit-identical to the single-GPU frame) - both verified by rank 0
-    against single-rank renderings of the same shares inside the run; weak scaling likewise."""
+    the RCCL run): plain `python bench.py --gpus 2` spawns the ranks itself; fixed total work split by PIXELS (the default and the line's value:
+    interleaved tid chunks, bit-identical to the single-GPU frame) and by SAMPLES (all pixels x spp / 2 per rank, RNG sub-streams, frames
+    summed; under "also") - both verified by rank 0 against single-rank renderings of the same shares inside the run; weak scaling likewise."""
     out = _bench_two_ranks(["--spp", "32"])
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
-    assert out["config"]["sharded_frame_verified"] is True and "sample sharding" in out["config"]["sharding"]
+    assert out["config"]["sharded_frame_verified"] is True and "pixel sharding" in out["config"]["sharding"]      # the north-star split is the headline
     assert out["config"]["paths_per_step"] == 1024 * 1024 * 32                      # fixed total work: not N x the samples
     also = out["also"][0]
-    assert also["sharded_frame_verified"] is True and "pixel sharding" in also["sharding"] and also["paths_per_step"] == 1024 * 1024 * 32
+    assert also["sharded_frame_verified"] is True and "sample sharding" in also["sharding"] and also["paths_per_step"] == 1024 * 1024 * 32
     weak = _bench_two_ranks(["--spp", "16", "--scaling", "weak", "--no-also"])
     assert weak["scaling"] == "weak" and weak["config"]["sharded_frame_verified"] is True and weak["config"]["paths_per_step"] == 2 * 1024 * 1024 * 16
 

@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <new>
+#include <stdexcept>
 #include <vector>
 #include <set>
 #include <chrono>
@@ -177,11 +179,27 @@ struct hpt_ctx
 
 #define HIPCHK(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) return (ctx)->hipFail(_e, #call); } while (0)
 
+// Nothing throws across the C boundary (include/hydra_hip.h): every extern "C" body is a function-try-block whose handler lands here. The host
+// side builds std::vector / std::string / std::thread objects (scene tables, BVH build), so std::bad_alloc and std::system_error are real
+// possibilities; they become an error code and a message for hpt_last_error like every other failure.
+static int hptGuard(hpt_ctx* c, const char* where)
+{
+  int code = HPT_ERR_STATE; std::string what = "unknown exception";
+  try { throw; }
+  catch (const std::bad_alloc&) { code = HPT_ERR_NOMEM; what = "out of host memory (std::bad_alloc): sizes too large for this host"; }
+  catch (const std::length_error& e) { code = HPT_ERR_NOMEM; what = std::string("container size limit exceeded (std::length_error): ") + e.what(); }
+  catch (const std::exception& e) { what = e.what(); }
+  catch (...) {}
+  if (c) { try { return c->fail(code, std::string(where) + ": " + what); } catch (...) {} }
+  return code;
+}
+
+
 // ---- lifetime -----------------------------------------------------------------------------------------------------------------
 extern "C" int hpt_comm_destroy(hpt_ctx* c);
 
 extern "C" int hpt_create(int device, hpt_ctx** out)
-{
+try {
   if (!out) return HPT_ERR_ARG;
   *out = nullptr;
   int n = 0;
@@ -204,9 +222,10 @@ extern "C" int hpt_create(int device, hpt_ctx** out)
   *out = c;
   return HPT_OK;
 }
+catch (...) { return hptGuard(nullptr, "hpt_create"); }
 
 extern "C" void hpt_destroy(hpt_ctx* c)
-{
+try {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
@@ -232,21 +251,24 @@ extern "C" void hpt_destroy(hpt_ctx* c)
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   delete c;
 }
+catch (...) { (void)hptGuard(c, "hpt_destroy"); }
 
-extern "C" const char* hpt_last_error(hpt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+extern "C" const char* hpt_last_error(hpt_ctx* c) try { return c ? c->err.c_str() : "null context"; }
+catch (...) { return ""; }
 
 extern "C" int hpt_device_info(hpt_ctx* c, int* numCUs, int* wavefront, char* name, size_t nameLen)
-{
+try {
   if (!c) return HPT_ERR_ARG;
   if (numCUs) *numCUs = c->numCUs;
   if (wavefront) *wavefront = 64;
   if (name && nameLen) { std::strncpy(name, c->devName.c_str(), nameLen - 1); name[nameLen - 1] = 0; }
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_device_info"); }
 
 // ---- the JPEG reader of the scene loaders (host only) ----------------------------------------------------------------------------------------
 extern "C" int hpt_decode_jpeg(const uint8_t* file, uint64_t fileSize, uint32_t* outWidth, uint32_t* outHeight, uint8_t* outRGBA8, uint64_t outCapacity)
-{
+try {
   if (!file || !outWidth || !outHeight) return HPT_ERR_ARG;
   std::vector<uint8_t> rgba; std::string err; uint32_t w = 0, h = 0;
   try {                                                        // (nothing throws across the C boundary)
@@ -259,10 +281,11 @@ extern "C" int hpt_decode_jpeg(const uint8_t* file, uint64_t fileSize, uint32_t*
   std::memcpy(outRGBA8, rgba.data(), rgba.size());
   return HPT_OK;
 }
+catch (...) { return hptGuard(nullptr, "hpt_decode_jpeg"); }
 
 // ---- precomputeThinFilmSpectral / precomputeThinFilmRGB for the scene loaders (host only, no device needed) ------------------------------------
 extern "C" int hpt_film_precompute(const hpt_film_params* fp, float* outTable, uint64_t outCapacity, uint64_t* outCount, int* outPrecomputed)
-{
+try {
   if (!fp || !outCount) return HPT_ERR_ARG;
   hydra_hip::film::Params p;
   p.spectralMode = fp->spectralMode; p.extIOR = fp->extIOR; p.layers = fp->layers; p.eta = fp->eta; p.k = fp->k; p.etaSpecId = fp->etaSpecId; p.kSpecId = fp->kSpecId;
@@ -277,11 +300,12 @@ extern "C" int hpt_film_precompute(const hpt_film_params* fp, float* outTable, u
   if (outCapacity < *outCount) return HPT_ERR_ARG;
   try { return hydra_hip::film::precompute(p, outTable) ? HPT_OK : HPT_ERR_ARG; } catch (const std::exception&) { return HPT_ERR_ARG; }
 }
+catch (...) { return hptGuard(nullptr, "hpt_film_precompute"); }
 
 // ---- mi::fresnel_coat_precompute for the scene loaders (host only, no device needed) --------------------------------------------------------
 extern "C" int hpt_plastic_precompute(float alpha, float intIor, float extIor, const float* diffuse4, const float* specular4,
                                       float* outTransmittance64, float* outInternalReflectance, float* outSpecularSamplingWeight)
-{
+try {
   if (!diffuse4 || !specular4 || !outTransmittance64 || !outInternalReflectance || !outSpecularSamplingWeight) return HPT_ERR_ARG;
   if (!(alpha > 0.0f) || !(intIor > 0.0f) || !(extIor > 0.0f)) return HPT_ERR_ARG;
   const hydra_hip::plastic::CoatPrecomputed p = hydra_hip::plastic::fresnelCoatPrecompute(alpha, intIor, extIor, diffuse4, specular4);
@@ -289,46 +313,52 @@ extern "C" int hpt_plastic_precompute(float alpha, float intIor, float extIor, c
   *outInternalReflectance = p.internalReflectance; *outSpecularSamplingWeight = p.specularSamplingWeight;
   return HPT_OK;
 }
+catch (...) { return hptGuard(nullptr, "hpt_plastic_precompute"); }
 
 // ---- device memory for callers of the *_dev entry points that do not link the HIP runtime themselves ---------------------------------
 extern "C" int hpt_device_malloc(hpt_ctx* c, size_t bytes, void** outDev)
-{
+try {
   if (!c || !outDev) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   *outDev = nullptr;
   HIPCHK(c, hipMalloc(outDev, bytes ? bytes : 4));
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_device_malloc"); }
 extern "C" int hpt_device_free(hpt_ctx* c, void* dev)
-{
+try {
   if (!c) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   if (dev) HIPCHK(c, hipFree(dev));
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_device_free"); }
 extern "C" int hpt_device_copy(hpt_ctx* c, void* dst, const void* src, size_t bytes, int kind)
-{
+try {
   if (!c || (bytes && (!dst || !src)) || kind < 1 || kind > 3) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   const hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
   if (bytes) HIPCHK(c, hipMemcpy(dst, src, bytes, k));                      // synchronous: orders after the asynchronous *_dev launches on the null stream
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_device_copy"); }
 extern "C" int hpt_device_memset(hpt_ctx* c, void* dev, int value, size_t bytes)
-{
+try {
   if (!c || (bytes && !dev)) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   if (bytes) HIPCHK(c, hipMemsetAsync(dev, value, bytes, nullptr));
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_device_memset"); }
 
 // ---- ISceneObject ---------------------------------------------------------------------------------------------------------------
 extern "C" int hpt_clear_geom(hpt_ctx* c)
-{
+try {
   if (!c) return HPT_ERR_ARG;
   c->geoms.clear(); c->insts.clear(); c->accelCommitted = false; c->flatRefittable = false;
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_clear_geom"); }
 
 static int fill_geom(hpt_ctx* c, Geom& g, const float* vpos, size_t nVert, const uint32_t* idx, size_t nIdx, size_t stride)
 {
@@ -345,7 +375,7 @@ static int fill_geom(hpt_ctx* c, Geom& g, const float* vpos, size_t nVert, const
 }
 
 extern "C" uint32_t hpt_add_geom_triangles3f(hpt_ctx* c, const float* vpos, size_t nVert, const uint32_t* idx, size_t nIdx, uint32_t, size_t stride)
-{
+try {
   if (!c) return 0xFFFFFFFFu;
   Geom g;
   if (fill_geom(c, g, vpos, nVert, idx, nIdx, stride) != HPT_OK) return 0xFFFFFFFFu;
@@ -353,9 +383,10 @@ extern "C" uint32_t hpt_add_geom_triangles3f(hpt_ctx* c, const float* vpos, size
   c->accelCommitted = false; c->flatRefittable = false;
   return (uint32_t)(c->geoms.size() - 1);
 }
+catch (...) { (void)hptGuard(c, "hpt_add_geom_triangles3f"); return 0xFFFFFFFFu; }
 
 extern "C" int hpt_update_geom_triangles3f(hpt_ctx* c, uint32_t geomId, const float* vpos, size_t nVert, const uint32_t* idx, size_t nIdx, uint32_t, size_t stride)
-{
+try {
   if (!c) return HPT_ERR_ARG;
   if (geomId >= c->geoms.size()) return c->fail(HPT_ERR_ARG, "UpdateGeom_Triangles3f: bad geomId");
   Geom& g = c->geoms[geomId];
@@ -366,20 +397,23 @@ extern "C" int hpt_update_geom_triangles3f(hpt_ctx* c, uint32_t geomId, const fl
   else c->dirtyGeoms.push_back(geomId);
   return fill_geom(c, g, vpos, nVert, idx, nIdx, stride);
 }
+catch (...) { return hptGuard(c, "hpt_update_geom_triangles3f"); }
 
-extern "C" int hpt_clear_scene(hpt_ctx* c) { if (!c) return HPT_ERR_ARG; c->insts.clear(); c->accelCommitted = false; c->flatRefittable = false; return HPT_OK; }
+extern "C" int hpt_clear_scene(hpt_ctx* c) try { if (!c) return HPT_ERR_ARG; c->insts.clear(); c->accelCommitted = false; c->flatRefittable = false; return HPT_OK; }
+catch (...) { return hptGuard(c, "hpt_clear_scene"); }
 
 extern "C" uint32_t hpt_add_instance(hpt_ctx* c, uint32_t geomId, const float m[16])
-{
+try {
   if (!c || !m || geomId >= c->geoms.size()) return 0xFFFFFFFFu;
   Inst in; in.geomId = geomId; std::memcpy(in.m, m, 64);
   c->insts.push_back(in);
   c->accelCommitted = false; c->flatRefittable = false;
   return (uint32_t)(c->insts.size() - 1);
 }
+catch (...) { (void)hptGuard(c, "hpt_add_instance"); return 0xFFFFFFFFu; }
 
 extern "C" uint32_t hpt_add_instance_motion(hpt_ctx* c, uint32_t geomId, const float* matrices, uint32_t matrixNumber)
-{
+try {
   if (!c || !matrices || geomId >= c->geoms.size() || matrixNumber == 0) return 0xFFFFFFFFu;
   if (matrixNumber == 1) return hpt_add_instance(c, geomId, matrices);
   if (matrixNumber != 2) { c->fail(HPT_ERR_UNSUPPORTED, "AddInstanceMotion: two key matrices are supported (what LoadSceneInstances passes)"); return 0xFFFFFFFFu; }
@@ -388,15 +422,17 @@ extern "C" uint32_t hpt_add_instance_motion(hpt_ctx* c, uint32_t geomId, const f
   c->accelCommitted = false; c->flatRefittable = false;
   return (uint32_t)(c->insts.size() - 1);
 }
+catch (...) { (void)hptGuard(c, "hpt_add_instance_motion"); return 0xFFFFFFFFu; }
 
 extern "C" int hpt_update_instance(hpt_ctx* c, uint32_t instId, const float m[16])
-{
+try {
   if (!c || !m) return HPT_ERR_ARG;
   if (instId >= c->insts.size()) return HPT_OK;          // the reference silently ignores it (EmbreeRT.cpp:302-303)
   std::memcpy(c->insts[instId].m, m, 64);
   c->accelCommitted = false;
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_update_instance"); }
 
 // Expected inner-node visits of a random ray through the root box (the surface-area heuristic the builder minimises): 1 for the root plus
 // area(child) / area(root) for every child that is an inner node. The number that tells a light scene from a heavy one better than the
@@ -515,7 +551,7 @@ static int refit_flat(hpt_ctx* c)
 }
 
 extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
-{
+try {
   if (!c) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   if (c->flatRefittable && c->refitEnabled && c->S.flatMode == 1u) return refit_flat(c);
@@ -787,6 +823,7 @@ extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
   c->accelCommitted = true; c->shadeTrisDirty = true;
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_commit_scene"); }
 
 // HBM part of the traversal stacks for a grid of `lanes` lanes (only touched by lanes whose stack outgrows LDS_STACK)
 // stack entries a megakernel traversal may need: with HPT_FLAT_WIDE the single-level walk uses the 4-wide tree when the scene has one
@@ -822,10 +859,14 @@ static int ray_query(hpt_ctx* c, const float* posNear, const float* dirFar, uint
   return HPT_OK;
 }
 
-extern "C" int hpt_ray_query_nearest(hpt_ctx* c, const float* p, const float* d, uint32_t n, hpt_hit* out) { return ray_query(c, p, d, n, out, 0); }
-extern "C" int hpt_ray_query_any(hpt_ctx* c, const float* p, const float* d, uint32_t n, uint32_t* out) { return ray_query(c, p, d, n, out, 1); }
-extern "C" int hpt_ray_query_nearest_motion(hpt_ctx* c, const float* p, const float* d, uint32_t n, float time, hpt_hit* out) { return ray_query(c, p, d, n, out, 0, time); }
-extern "C" int hpt_ray_query_any_motion(hpt_ctx* c, const float* p, const float* d, uint32_t n, float time, uint32_t* out) { return ray_query(c, p, d, n, out, 1, time); }
+extern "C" int hpt_ray_query_nearest(hpt_ctx* c, const float* p, const float* d, uint32_t n, hpt_hit* out) try { return ray_query(c, p, d, n, out, 0); }
+catch (...) { return hptGuard(c, "hpt_ray_query_nearest"); }
+extern "C" int hpt_ray_query_any(hpt_ctx* c, const float* p, const float* d, uint32_t n, uint32_t* out) try { return ray_query(c, p, d, n, out, 1); }
+catch (...) { return hptGuard(c, "hpt_ray_query_any"); }
+extern "C" int hpt_ray_query_nearest_motion(hpt_ctx* c, const float* p, const float* d, uint32_t n, float time, hpt_hit* out) try { return ray_query(c, p, d, n, out, 0, time); }
+catch (...) { return hptGuard(c, "hpt_ray_query_nearest_motion"); }
+extern "C" int hpt_ray_query_any_motion(hpt_ctx* c, const float* p, const float* d, uint32_t n, float time, uint32_t* out) try { return ray_query(c, p, d, n, out, 1, time); }
+catch (...) { return hptGuard(c, "hpt_ray_query_any_motion"); }
 
 // ---- scene tables -----------------------------------------------------------------------------------------------------------------
 static bool lean_materials(const MaterialRec* m, size_t n)
@@ -972,7 +1013,7 @@ static int check_tables(hpt_ctx* c, const hpt_scene_desc* d)
 }
 
 extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
-{
+try {
   if (!c || !d) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   const double t0 = now_ms();
@@ -1141,7 +1182,15 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
         const uint t1 = std::min(d->geomTriCount ? t0 + d->geomTriCount[g] : (g + 1 < d->numGeoms ? d->matVertOffset[2 * (g + 1)] : d->numTris), d->numTris);
         for (uint t = t0; t < t1; t++) {
           uint id = d->matIdByPrimId[t];
-          for (int k2 = 0; k2 < rSize; k2++) if ((uint)d->allRemapLists[rOff + 2 * k2] == id) { id = (uint)d->allRemapLists[rOff + 2 * k2 + 1]; break; }
+          if (list >= 0 && rSize > 0) {
+            // the device's RemapMaterialId exactly (hpt_device.h: remapMaterialId = integrator_pt_mat.cpp:530-573): a bisection over the list's INT
+            // count that indexes PAIRS, so its probes can land in the next list or in the zero padding behind the table - 'reached' must follow it
+            auto at = [&](long k) -> int { return (k >= 0 && (size_t)k < d->allRemapListsLen) ? d->allRemapLists[k] : 0; };
+            const int rInts = 2 * rSize;
+            int low = 0, high = rInts - 1;
+            while (low <= high) { const int mid = low + ((high - low) / 2); if ((uint)at((long)rOff + mid * 2) >= id) high = mid - 1; else low = mid + 1; }
+            if (high + 1 < rInts && (uint)at((long)rOff + (high + 1) * 2) == id) id = (uint)at((long)rOff + (high + 1) * 2 + 1);
+          }
           id &= 0x00FFFFFFu;
           if (id < d->numMaterials) reached[id] = 1;
         }
@@ -1182,9 +1231,10 @@ extern "C" int hpt_upload_scene(hpt_ctx* c, const hpt_scene_desc* d)
   c->tPathTrace[1] = c->tNaive[1] = c->tDR[1] = float(now_ms() - t0);   // host -> device time of the scene commit
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_upload_scene"); }
 
 extern "C" int hpt_update_params(hpt_ctx* c, const hpt_params* p)
-{
+try {
   if (!c || !p) return HPT_ERR_ARG;
   if (p->spectralMode > 1) return c->fail(HPT_ERR_ARG, "bad spectral mode");
   if (p->spectralMode == 1 && !c->sceneUploaded) return c->fail(HPT_ERR_STATE, "UpdateMembersPlainData with m_spectral_mode before CommitDeviceData");
@@ -1216,10 +1266,11 @@ extern "C" int hpt_update_params(hpt_ctx* c, const hpt_params* p)
   c->paramsSet = true;
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_update_params"); }
 
 // SetLines / SetPhysSize + m_enableOpticSim (integrator_pt.h:353-362, integrator_pt_scene.cpp:714-720, 1078-1141): n = 0 switches it off
 extern "C" int hpt_set_optics(hpt_ctx* c, const float* lines4, uint32_t n, float physSizeX, float physSizeY)
-{
+try {
   if (!c || (n && !lines4)) return HPT_ERR_ARG;
   if (n > 64) return c->fail(HPT_ERR_ARG, "SetLines: more than 64 lens interfaces");
   for (uint32_t i = 0; i < n; i++) if (!(lines4[4 * i + 3] >= 0.0f)) return c->fail(HPT_ERR_ARG, "SetLines: negative aperture radius");
@@ -1230,9 +1281,10 @@ extern "C" int hpt_set_optics(hpt_ctx* c, const float* lines4, uint32_t n, float
   c->S.lensLines = c->dLensLines.p; c->S.lensCount = n; c->S.physSize[0] = physSizeX; c->S.physSize[1] = physSizeY; c->S.padLens = 0;
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_set_optics"); }
 
 extern "C" int hpt_update_materials(hpt_ctx* c, size_t first, size_t count, const void* mats)
-{
+try {
   if (!c || !mats) return HPT_ERR_ARG;
   if (first + count > c->dMaterials.n) return c->fail(HPT_ERR_ARG, "Update_m_materials: range out of bounds");
   int rc = check_materials(c, (const MaterialRec*)mats, count, c->hTextures.size(), c->dMaterials.n, c->numArrays1f); if (rc) return rc;
@@ -1254,8 +1306,9 @@ extern "C" int hpt_update_materials(hpt_ctx* c, size_t first, size_t count, cons
   HIPCHK(c, hipMemcpy(c->dMaterials.p + first, mats, count * sizeof(MaterialRec), hipMemcpyHostToDevice));
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_update_materials"); }
 extern "C" int hpt_update_lights(hpt_ctx* c, size_t first, size_t count, const void* lights)
-{
+try {
   if (!c || !lights) return HPT_ERR_ARG;
   if (first + count > c->S.numLights) return c->fail(HPT_ERR_ARG, "Update_m_lights: range out of bounds");
   int rc = check_lights(c, (const LightRec*)lights, count, c->hTextures.size(), c->numArrays1f); if (rc) return rc;
@@ -1264,10 +1317,11 @@ extern "C" int hpt_update_lights(hpt_ctx* c, size_t first, size_t count, const v
   HIPCHK(c, hipMemcpy(c->dLights.p + first, lights, count * sizeof(LightRec), hipMemcpyHostToDevice));
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_update_lights"); }
 
 // Update_m_matIdOffsets (integrator_pt.h:470): m_matVertOffset changed on the host
 extern "C" int hpt_update_mat_id_offsets(hpt_ctx* c, const uint32_t* mvo, size_t numGeoms)
-{
+try {
   if (!c || !mvo) return HPT_ERR_ARG;
   if (!c->sceneUploaded) return c->fail(HPT_ERR_STATE, "Update_m_matIdOffsets before CommitDeviceData");
   if (2 * numGeoms != c->dMatVertOffset.n) return c->fail(HPT_ERR_ARG, "Update_m_matIdOffsets: geometry count differs from the committed scene");
@@ -1283,11 +1337,15 @@ extern "C" int hpt_update_mat_id_offsets(hpt_ctx* c, const uint32_t* mvo, size_t
   (void)hipSetDevice(c->device);
   HIPCHK(c, hipMemcpy(c->dMatVertOffset.p, mvo, 2 * numGeoms * sizeof(uint32_t), hipMemcpyHostToDevice));
   c->shadeTrisDirty = true;                                   // the shading records were gathered through the old offsets
+  // the meshes now point at other triangle ranges, i.e. at other materials: what a hit can REACH was scanned at hpt_upload_scene through the
+  // old offsets, so the kernels chosen by it widen to the ones that hold every branch (a scope-0 spectral kernel has no glass branch)
+  c->spectralGltfMats = c->spectralHeavyMats = true; c->fewMaterialTypes = false;
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_update_mat_id_offsets"); }
 
 extern "C" int hpt_pack_xy(hpt_ctx* c, uint32_t tidX, uint32_t tidY)
-{
+try {
   if (!c) return HPT_ERR_ARG;
   if (!c->paramsSet) return c->fail(HPT_ERR_STATE, "PackXYBlock before UpdateMembersPlainData");
   if ((int)tidX != c->S.winWidth || (int)tidY != c->S.winHeight) return c->fail(HPT_ERR_ARG, "PackXYBlock: size differs from the viewport");
@@ -1301,15 +1359,17 @@ extern "C" int hpt_pack_xy(hpt_ctx* c, uint32_t tidX, uint32_t tidY)
   c->packedCount = (uint)n;
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_pack_xy"); }
 extern "C" int hpt_get_packed_xy(hpt_ctx* c, uint32_t* out, uint32_t count)
-{
+try {
   if (!c || !out || count > c->packedCount) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   HIPCHK(c, hipMemcpy(out, c->dPackedXY.p, (size_t)count * 4, hipMemcpyDeviceToHost));
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_get_packed_xy"); }
 extern "C" int hpt_init_random_gens_from(hpt_ctx* c, uint32_t n, uint32_t firstSeed)
-{
+try {
   if (!c || n == 0) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   HIPCHK(c, c->dGens.alloc(n));
@@ -1317,22 +1377,26 @@ extern "C" int hpt_init_random_gens_from(hpt_ctx* c, uint32_t n, uint32_t firstS
   HIPCHK(c, hipGetLastError());
   return HPT_OK;
 }
-extern "C" int hpt_init_random_gens(hpt_ctx* c, uint32_t n) { return hpt_init_random_gens_from(c, n, 0u); }
+catch (...) { return hptGuard(c, "hpt_init_random_gens_from"); }
+extern "C" int hpt_init_random_gens(hpt_ctx* c, uint32_t n) try { return hpt_init_random_gens_from(c, n, 0u); }
+catch (...) { return hptGuard(c, "hpt_init_random_gens"); }
 extern "C" int hpt_get_random_gens(hpt_ctx* c, uint32_t* out, uint32_t count)
-{
+try {
   if (!c || !out || count > c->dGens.n) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   HIPCHK(c, hipMemcpy(out, c->dGens.p, (size_t)count * 8, hipMemcpyDeviceToHost));
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_get_random_gens"); }
 extern "C" int hpt_set_random_gens(hpt_ctx* c, const uint32_t* in, uint32_t count)
-{
+try {
   if (!c || !in) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   HIPCHK(c, c->dGens.alloc(count));
   HIPCHK(c, hipMemcpy(c->dGens.p, in, (size_t)count * 8, hipMemcpyHostToDevice));
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_set_random_gens"); }
 
 // ---- the hot path -------------------------------------------------------------------------------------------------------------------
 static int gridBlocks(hpt_ctx* c, bool dr, bool fullMaterials = false)
@@ -1418,6 +1482,9 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   if (!inRays && job.tidStride == 1 && (size_t)job.tidBegin + job.tidCount > c->packedCount) return c->fail(HPT_ERR_ARG, "PathTraceBlock: tid range exceeds the viewport");
   if (c->dGens.n < (inRays ? (size_t)job.tidEnd : (size_t)c->packedCount)) return c->fail(HPT_ERR_STATE, "PathTraceBlock: m_randomGens smaller than the thread range (InitRandomGens)");
   if (job.channels < 1 || (job.channels > 4 && c->S.spectralMode == 0u)) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceBlock: channels must be 1..4 (more are the wavelength layers of spectral rendering)");
+  // two channels: kernel_ContributeToImage writes three components at pixel * channels (integrator_pt.cpp:636-641), i.e. into the next pixel and,
+  // for the last one, past the buffer - refused rather than restated
+  if (job.channels == 2) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceBlock: a two-channel framebuffer cannot hold the three components written per pixel (1, 3 or 4 channels)");
   if (dr && (c->S.traceDepth == 0 || c->S.traceDepth > 16)) return c->fail(HPT_ERR_ARG, "PathTraceDR: trace depth must be 1..16");
   if (dr && c->S.lensCount) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceDR: the lens simulation is not differentiated");
   if (dr && c->S.motion) return c->fail(HPT_ERR_UNSUPPORTED, "PathTraceDR: motion blur is not differentiated");
@@ -1707,7 +1774,7 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr)
 }
 
 extern "C" int hpt_path_trace_block_dev(hpt_ctx* c, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* outDev, uint32_t passNum, int naive, void* stream)
-{
+try {
   if (!c || !outDev) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   if (tidCount == 0 || passNum == 0) return HPT_OK;
@@ -1715,6 +1782,7 @@ extern "C" int hpt_path_trace_block_dev(hpt_ctx* c, uint32_t tidBegin, uint32_t 
   job.tidBegin = tidBegin; job.tidCount = tidCount; job.passNum = passNum; job.channels = channels; job.outColor = outDev;
   return launch_path_trace(c, job, naive != 0, false, (hipStream_t)stream);
 }
+catch (...) { return hptGuard(c, "hpt_path_trace_block_dev"); }
 
 static int path_trace_host(hpt_ctx* c, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out, uint32_t passNum, int naive)
 {
@@ -1742,7 +1810,7 @@ static int path_trace_host(hpt_ctx* c, uint32_t tidBegin, uint32_t tidCount, uin
 
 // PathTraceFromInputRaysBlock (integrator_pt.h:261, integrator_pt_host.cpp:92-103): device and host-pointer forms
 extern "C" int hpt_path_trace_from_input_rays_block_dev(hpt_ctx* c, uint32_t tid, uint32_t channels, const float* rayPosDev, const float* rayDirDev, float* outDev, uint32_t passNum, void* stream)
-{
+try {
   if (!c || !rayPosDev || !rayDirDev || !outDev) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   if (tid == 0 || passNum == 0) return HPT_OK;
@@ -1751,8 +1819,9 @@ extern "C" int hpt_path_trace_from_input_rays_block_dev(hpt_ctx* c, uint32_t tid
   job.inRayPos = (const float4*)rayPosDev; job.inRayDir = (const float4*)rayDirDev;
   return launch_path_trace(c, job, false, false, (hipStream_t)stream);
 }
+catch (...) { return hptGuard(c, "hpt_path_trace_from_input_rays_block_dev"); }
 extern "C" int hpt_path_trace_from_input_rays_block(hpt_ctx* c, uint32_t tid, uint32_t channels, const float* rayPos, const float* rayDir, float* out, uint32_t passNum)
-{
+try {
   if (!c || !rayPos || !rayDir || !out) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   if (tid == 0 || passNum == 0) return HPT_OK;
@@ -1774,15 +1843,18 @@ extern "C" int hpt_path_trace_from_input_rays_block(hpt_ctx* c, uint32_t tid, ui
   dp.release(); dd.release(); dout.release();
   return rc;
 }
+catch (...) { return hptGuard(c, "hpt_path_trace_from_input_rays_block"); }
 
 extern "C" int hpt_path_trace_block(hpt_ctx* c, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out, uint32_t passNum)
-{ return path_trace_host(c, tidBegin, tidCount, channels, out, passNum, 0); }
+try { return path_trace_host(c, tidBegin, tidCount, channels, out, passNum, 0); }
+catch (...) { return hptGuard(c, "hpt_path_trace_block"); }
 extern "C" int hpt_naive_path_trace_block(hpt_ctx* c, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out, uint32_t passNum)
-{ return path_trace_host(c, tidBegin, tidCount, channels, out, passNum, 1); }
+try { return path_trace_host(c, tidBegin, tidCount, channels, out, passNum, 1); }
+catch (...) { return hptGuard(c, "hpt_naive_path_trace_block"); }
 
 // ---- differentiable rendering ---------------------------------------------------------------------------------------------------------
 extern "C" int hpt_reset_diff_tex(hpt_ctx* c)
-{
+try {
   if (!c) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   for (TexRec& t : c->hTextures) { t.diffOffset = ~0ull; t.diffW = t.diffH = t.diffChannels = 0; }
@@ -1790,9 +1862,10 @@ extern "C" int hpt_reset_diff_tex(hpt_ctx* c)
   if (!c->hTextures.empty()) HIPCHK(c, c->dTextures.upload(c->hTextures.data(), c->hTextures.size()));
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_reset_diff_tex"); }
 
 extern "C" int hpt_put_diff_tex2d(hpt_ctx* c, uint32_t texId, uint32_t w, uint32_t h, uint32_t channels, uint64_t* outOffset, uint64_t* outSize)
-{
+try {
   if (!c || !outOffset || !outSize) return HPT_ERR_ARG;
   if (texId >= c->hTextures.size()) {                                     // reference: prints and returns (size_t(-1), 0) (integrator_dr.cpp:35-39)
     *outOffset = ~0ull; *outSize = 0;
@@ -1810,10 +1883,11 @@ extern "C" int hpt_put_diff_tex2d(hpt_ctx* c, uint32_t texId, uint32_t w, uint32
   HIPCHK(c, c->dTextures.upload(c->hTextures.data(), c->hTextures.size()));
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_put_diff_tex2d"); }
 
 extern "C" int hpt_path_trace_dr_dev(hpt_ctx* c, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* outDev, uint32_t passNum,
                                      const float* refDev, const float* dataDev, float* gradDev, size_t gradSize, float* lossDev, void* stream)
-{
+try {
   if (!c || !outDev || !refDev || !dataDev || !gradDev || !lossDev) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   if (gradSize < c->gradSize) return c->fail(HPT_ERR_ARG, "PathTraceDR: a_gradSize smaller than the registered differentiable textures");
@@ -1824,10 +1898,11 @@ extern "C" int hpt_path_trace_dr_dev(hpt_ctx* c, uint32_t tidBegin, uint32_t tid
   job.refImg = refDev; job.data = dataDev; job.grad = gradDev; job.lossAccum = lossDev;
   return launch_path_trace(c, job, false, true, (hipStream_t)stream);
 }
+catch (...) { return hptGuard(c, "hpt_path_trace_dr_dev"); }
 
 extern "C" int hpt_path_trace_dr(hpt_ctx* c, uint32_t tidBegin, uint32_t tidCount, uint32_t channels, float* out, uint32_t passNum,
                                  const float* refImg, const float* data, float* dataGrad, size_t gradSize, float* outLoss)
-{
+try {
   if (!c || !out || !refImg || !data || !dataGrad) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   if (!c->paramsSet) return c->fail(HPT_ERR_STATE, "PathTraceDR before UpdateMembersPlainData");
@@ -1856,9 +1931,10 @@ extern "C" int hpt_path_trace_dr(hpt_ctx* c, uint32_t tidBegin, uint32_t tidCoun
   c->tDR[0] = kms; c->tDR[1] = float(t1 - t0); c->tDR[2] = float(t3 - t2); c->tDR[3] = float((t2 - t1) - kms);
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_path_trace_dr"); }
 
 extern "C" int hpt_adam_step_dev(hpt_ctx* c, float* state, const float* grad, float* momentum, float* gsq, size_t n, int iter, void* stream)
-{
+try {
   if (!c || !state || !grad || !momentum || !gsq) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   if (n == 0) return HPT_OK;
@@ -1868,9 +1944,10 @@ extern "C" int hpt_adam_step_dev(hpt_ctx* c, float* state, const float* grad, fl
   HIPCHK(c, hipGetLastError());
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_adam_step_dev"); }
 
 extern "C" int hpt_image2d4f_regularizer_dev(hpt_ctx* c, int w, int h, const float* data, float* grad, void* stream)
-{
+try {
   if (!c || !data || !grad || w < 0 || h < 0) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   if (w < 3 || h < 3) return HPT_OK;                                  // no interior pixel: the loss is identically zero
@@ -1878,9 +1955,10 @@ extern "C" int hpt_image2d4f_regularizer_dev(hpt_ctx* c, int w, int h, const flo
   HIPCHK(c, hipGetLastError());
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_image2d4f_regularizer_dev"); }
 
 extern "C" int hpt_image2d4f_regularizer(hpt_ctx* c, int w, int h, const float* data, float* grad)
-{
+try {
   if (!c || !data || !grad || w < 0 || h < 0) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   const size_t n = (size_t)w * h * 4;
@@ -1892,6 +1970,7 @@ extern "C" int hpt_image2d4f_regularizer(hpt_ctx* c, int w, int h, const float* 
   dd.release(); dg.release();
   return rc;
 }
+catch (...) { return hptGuard(c, "hpt_image2d4f_regularizer"); }
 
 // ---- multi-GPU: RCCL collectives behind the C ABI (one context = one GPU = one rank) ---------------------------------------------------
 // The path shards without any data-path exchange; what has to cross xGMI is one reduce(SUM) of the framebuffer per frame and,
@@ -1931,14 +2010,15 @@ int rcclFail(hpt_ctx* c, int r, const char* what) { return c->fail(HPT_ERR_HIP, 
 } // namespace
 
 extern "C" int hpt_comm_get_unique_id(hpt_ctx* c, void* id128)
-{
+try {
   if (!c || !id128) return HPT_ERR_ARG;
   int rc = loadRccl(c); if (rc) return rc;
   const int r = g_rccl.GetUniqueId(id128);
   return r ? rcclFail(c, r, "ncclGetUniqueId") : HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_comm_get_unique_id"); }
 extern "C" int hpt_comm_init(hpt_ctx* c, int nranks, int rank, const void* id128)
-{
+try {
   if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return HPT_ERR_ARG;
   if (c->comm) return c->fail(HPT_ERR_STATE, "hpt_comm_init: communicator already initialised");
   int rc = loadRccl(c); if (rc) return rc;
@@ -1949,32 +2029,36 @@ extern "C" int hpt_comm_init(hpt_ctx* c, int nranks, int rank, const void* id128
   c->commRanks = nranks; c->commRank = rank;
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_comm_init"); }
 extern "C" int hpt_comm_destroy(hpt_ctx* c)
-{
+try {
   if (!c) return HPT_ERR_ARG;
   if (c->comm) { (void)hipSetDevice(c->device); (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; c->commRanks = 0; }
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_comm_destroy"); }
 extern "C" int hpt_reduce_framebuffer(hpt_ctx* c, float* frameDev, size_t count, int root, void* stream)
-{
+try {
   if (!c || !frameDev) return HPT_ERR_ARG;
   if (!c->comm) return c->fail(HPT_ERR_STATE, "hpt_reduce_framebuffer before hpt_comm_init");
   (void)hipSetDevice(c->device);
   const int r = g_rccl.Reduce(frameDev, frameDev, count, RCCL_FLOAT32, RCCL_SUM, root, c->comm, (hipStream_t)stream);
   return r ? rcclFail(c, r, "ncclReduce") : HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_reduce_framebuffer"); }
 extern "C" int hpt_allreduce_grad(hpt_ctx* c, float* gradDev, size_t count, void* stream)
-{
+try {
   if (!c || !gradDev) return HPT_ERR_ARG;
   if (!c->comm) return c->fail(HPT_ERR_STATE, "hpt_allreduce_grad before hpt_comm_init");
   (void)hipSetDevice(c->device);
   const int r = g_rccl.AllReduce(gradDev, gradDev, count, RCCL_FLOAT32, RCCL_SUM, c->comm, (hipStream_t)stream);
   return r ? rcclFail(c, r, "ncclAllReduce") : HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_allreduce_grad"); }
 
 // ---- timing / instrumentation --------------------------------------------------------------------------------------------------------
 extern "C" int hpt_get_execution_time(hpt_ctx* c, const char* name, float out[4])
-{
+try {
   if (!c || !name || !out) return HPT_ERR_ARG;
   const std::string n(name);
   const float* src = nullptr;
@@ -1986,9 +2070,11 @@ extern "C" int hpt_get_execution_time(hpt_ctx* c, const char* name, float out[4]
   for (int i = 0; i < 4; i++) out[i] = src[i];
   return HPT_OK;
 }
-extern "C" int hpt_set_instrumentation(hpt_ctx* c, int enabled) { if (!c) return HPT_ERR_ARG; c->instrument = enabled != 0; return HPT_OK; }
+catch (...) { return hptGuard(c, "hpt_get_execution_time"); }
+extern "C" int hpt_set_instrumentation(hpt_ctx* c, int enabled) try { if (!c) return HPT_ERR_ARG; c->instrument = enabled != 0; return HPT_OK; }
+catch (...) { return hptGuard(c, "hpt_set_instrumentation"); }
 extern "C" int hpt_get_counters(hpt_ctx* c, uint64_t out[16])
-{
+try {
   if (!c || !out) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   if (!c->dCounters.p) { for (int i = 0; i < 16; i++) out[i] = 0; return HPT_OK; }
@@ -1996,8 +2082,9 @@ extern "C" int hpt_get_counters(hpt_ctx* c, uint64_t out[16])
   HIPCHK(c, hipMemcpy(out, c->dCounters.p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_get_counters"); }
 extern "C" int hpt_get_dr_counters(hpt_ctx* c, uint64_t out[16])
-{
+try {
   if (!c || !out) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   if (!c->dCounters.p) { for (int i = 0; i < 16; i++) out[i] = 0; return HPT_OK; }
@@ -2005,15 +2092,18 @@ extern "C" int hpt_get_dr_counters(hpt_ctx* c, uint64_t out[16])
   HIPCHK(c, hipMemcpy(out, (const uint64_t*)c->dCounters.p + 16, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_get_dr_counters"); }
 extern "C" int hpt_set_tid_interleave(hpt_ctx* c, uint32_t chunk, uint32_t stride)
-{
+try {
   if (!c || (stride > 1 && (chunk == 0 || chunk % 64 != 0))) return HPT_ERR_ARG;
   c->tidChunk = chunk; c->tidStride = stride ? stride : 1;
   return HPT_OK;
 }
-extern "C" int hpt_set_launch_config(hpt_ctx* c, int blocksPerCU) { if (!c || blocksPerCU < 0 || blocksPerCU > 8) return HPT_ERR_ARG; c->blocksPerCU = blocksPerCU; return HPT_OK; }
+catch (...) { return hptGuard(c, "hpt_set_tid_interleave"); }
+extern "C" int hpt_set_launch_config(hpt_ctx* c, int blocksPerCU) try { if (!c || blocksPerCU < 0 || blocksPerCU > 8) return HPT_ERR_ARG; c->blocksPerCU = blocksPerCU; return HPT_OK; }
+catch (...) { return hptGuard(c, "hpt_set_launch_config"); }
 extern "C" int hpt_set_schedule(hpt_ctx* c, int schedule, int refillBelow, int traceBlocksPerCU, int groups)
-{
+try {
   if (!c || schedule < 0 || schedule > 2 || refillBelow < 0 || refillBelow > 64 || traceBlocksPerCU < 0 || traceBlocksPerCU > 8 || groups < 0 || groups > 64) return HPT_ERR_ARG;
   c->wfGroupCount = groups;
   c->schedule = schedule;
@@ -2021,8 +2111,9 @@ extern "C" int hpt_set_schedule(hpt_ctx* c, int schedule, int refillBelow, int t
   c->wfBlocksPerCU = traceBlocksPerCU;
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_set_schedule"); }
 extern "C" int hpt_set_option(hpt_ctx* c, const char* name, int value)
-{
+try {
   if (!c || !name || value < 0) return HPT_ERR_ARG;
   const std::string k(name);
   if (k == "wf_grace") c->wfGrace = (uint)value;                                      // trips after the queue ran dry before a trace wave suspends its rays (0: never)
@@ -2039,39 +2130,45 @@ extern "C" int hpt_set_option(hpt_ctx* c, const char* name, int value)
   else return c->fail(HPT_ERR_ARG, "hpt_set_option: unknown option " + k);
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_set_option"); }
 extern "C" int hpt_get_accel_info(hpt_ctx* c, float out[4])
-{
+try {
   if (!c || !out) return HPT_ERR_ARG;
   out[0] = c->sahVisits; out[1] = (float)c->instTris; out[2] = (float)c->insts.size(); out[3] = c->S.sweep ? 2.0f : (c->S.flatMode ? 1.0f : 0.0f);
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_get_accel_info"); }
 extern "C" int hpt_get_commit_time(hpt_ctx* c, float out[4])
-{
+try {
   if (!c || !out) return HPT_ERR_ARG;
   for (int i = 0; i < 4; i++) out[i] = c->tCommit[i];
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_get_commit_time"); }
 extern "C" int hpt_get_schedule(hpt_ctx* c, int* lastSchedule, uint32_t* lastIterations)
-{
+try {
   if (!c) return HPT_ERR_ARG;
   if (lastSchedule) *lastSchedule = (int)c->lastSchedule;
   if (lastIterations) *lastIterations = c->lastWfIters;
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_get_schedule"); }
 extern "C" int hpt_get_last_launch(hpt_ctx* c, uint32_t out[4])
-{
+try {
   if (!c || !out) return HPT_ERR_ARG;
   out[0] = c->lastSchedule; out[1] = c->lastWide; out[2] = c->lastShadeRecords; out[3] = c->lastDeep;
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_get_last_launch"); }
 extern "C" int hpt_set_accel_layout(hpt_ctx* c, int layout)
-{
+try {
   if (!c || layout < 0 || layout > 3) return HPT_ERR_ARG;
   c->accelLayout = layout; c->accelCommitted = false; c->flatRefittable = false;
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_set_accel_layout"); }
 extern "C" int hpt_last_kernel_ms(hpt_ctx* c, float* ms)
-{
+try {
   if (!c || !ms) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   float k = 0.0f;
@@ -2081,3 +2178,4 @@ extern "C" int hpt_last_kernel_ms(hpt_ctx* c, float* ms)
   *ms = c->lastKernelMs = k;
   return HPT_OK;
 }
+catch (...) { return hptGuard(c, "hpt_last_kernel_ms"); }

@@ -347,6 +347,7 @@ inline double colLen(const M4& m, int c) { return std::sqrt(m.m[0][c] * m.m[0][c
 // ---- LDR image files of LoadTextureAndMakeCombined (integrator_pt_scene_tex.cpp:24-33: .png / .ppm / .bmp through LiteImage::LoadImage<uint32_t>) ----
 // RGBA8 texels, r in the low byte, rows in FILE order (PNG / PPM: top row first; BMP: as stored, bottom row first unless its height is negative).
 // LiteImage is absent from the tree, so the row order it hands out is unpinned; .jpg / .jpeg: jpeg_decode.h.
+static const uint64_t kMaxImagePixels = uint64_t(1) << 28;                  // every reader refuses larger images before it allocates (the JPEG reader's limit)
 inline uint32_t be32(const uint8_t* p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | uint32_t(p[3]); }
 inline bool decodePng(const std::vector<uint8_t>& f, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba, std::string& err)
 {
@@ -365,6 +366,7 @@ inline bool decodePng(const std::vector<uint8_t>& f, uint32_t& w, uint32_t& h, s
     p += 12 + (size_t)len;
   }
   if (w == 0 || h == 0 || depth != 8 || interlace != 0 || (ctype != 0 && ctype != 2 && ctype != 3 && ctype != 4 && ctype != 6)) { err = "PNG: only 8-bit non-interlaced images are read"; return false; }
+  if ((uint64_t)w * h > kMaxImagePixels) { err = "PNG: unreasonable size"; return false; }   // (a 60-byte file can claim 2^32 x 2^32)
   const uint32_t ch = ctype == 0 ? 1u : ctype == 2 ? 3u : ctype == 3 ? 1u : ctype == 4 ? 2u : 4u;
   const size_t stride = (size_t)w * ch;
   std::vector<uint8_t> raw((stride + 1) * h);
@@ -400,7 +402,7 @@ inline bool decodePpm(const std::vector<uint8_t>& f, uint32_t& w, uint32_t& h, s
   if (token() != "P6") { err = "PPM: only binary P6 is read"; return false; }
   w = (uint32_t)std::atoll(token().c_str()); h = (uint32_t)std::atoll(token().c_str()); const int maxv = std::atoi(token().c_str());
   p++;                                                                        // the single whitespace byte after the header
-  if (w == 0 || h == 0 || maxv != 255 || p + (size_t)w * h * 3 > f.size()) { err = "PPM: bad header or truncated"; return false; }
+  if (w == 0 || h == 0 || maxv != 255 || (uint64_t)w * h > kMaxImagePixels || p + (size_t)w * h * 3 > f.size()) { err = "PPM: bad header or truncated"; return false; }
   rgba.resize((size_t)w * h * 4);
   for (size_t i = 0; i < (size_t)w * h; i++) { rgba[4 * i] = f[p + 3 * i]; rgba[4 * i + 1] = f[p + 3 * i + 1]; rgba[4 * i + 2] = f[p + 3 * i + 2]; rgba[4 * i + 3] = 255; }
   return true;
@@ -410,8 +412,9 @@ inline bool decodeBmp(const std::vector<uint8_t>& f, uint32_t& w, uint32_t& h, s
   if (f.size() < 54 || f[0] != 'B' || f[1] != 'M') { err = "not a BMP file"; return false; }
   uint32_t off; int32_t sw, sh; uint16_t bpp; uint32_t comp;
   std::memcpy(&off, &f[10], 4); std::memcpy(&sw, &f[18], 4); std::memcpy(&sh, &f[22], 4); std::memcpy(&bpp, &f[28], 2); std::memcpy(&comp, &f[30], 4);
-  if (sw <= 0 || sh == 0 || (bpp != 24 && bpp != 32) || (comp != 0 && comp != 3)) { err = "BMP: only uncompressed 24 / 32-bit images are read"; return false; }
-  w = (uint32_t)sw; h = (uint32_t)std::abs(sh);
+  if (sw <= 0 || sh == 0 || sh == INT32_MIN || (bpp != 24 && bpp != 32) || (comp != 0 && comp != 3)) { err = "BMP: only uncompressed 24 / 32-bit images are read"; return false; }
+  w = (uint32_t)sw; h = (uint32_t)(sh < 0 ? -sh : sh);
+  if ((uint64_t)w * h > kMaxImagePixels) { err = "BMP: unreasonable size"; return false; }
   const size_t stride = (((size_t)w * (bpp / 8)) + 3) & ~size_t(3);
   if (off + stride * h > f.size()) { err = "BMP truncated"; return false; }
   rgba.resize((size_t)w * h * 4);
@@ -467,17 +470,19 @@ inline bool decodeExr(const std::vector<uint8_t>& f, uint32_t& w, uint32_t& h, s
   if (!lpb) { err = "exr: compression " + std::to_string(comp) + " is not read (NONE, ZIPS, ZIP are)"; return false; }
   if (chans.empty() || dw[2] < dw[0] || dw[3] < dw[1]) { err = "exr: no channels / empty data window"; return false; }
   w = (uint32_t)(dw[2] - dw[0] + 1); h = (uint32_t)(dw[3] - dw[1] + 1);
-  if (w > 65536u || h > 65536u) { err = "exr: unreasonable size"; return false; }
+  if (w > 65536u || h > 65536u || (uint64_t)w * h > kMaxImagePixels) { err = "exr: unreasonable size"; return false; }
   const size_t nblocks = (h + (uint32_t)lpb - 1) / (uint32_t)lpb;
   if (p + 8 * nblocks > f.size()) { err = "exr: truncated offset table"; return false; }
   size_t lineBytes = 0; for (const Chan& c : chans) lineBytes += (c.type == 1 ? 2u : 4u) * (size_t)w;
+  // before the planes are allocated: an uncompressed file holds every line, a compressed one at least a chunk header per block
+  if ((comp == 0 && (uint64_t)lineBytes * h > f.size()) || 8 * (uint64_t)nblocks > f.size()) { err = "exr: file shorter than its header says"; return false; }
   std::vector<std::vector<float>> planes(chans.size(), std::vector<float>((size_t)w * h, 0.0f));
   std::vector<uint8_t> tmp, raw;
   for (size_t b = 0; b < nblocks; b++) {
     uint64_t off; std::memcpy(&off, f.data() + p + 8 * b, 8);
-    if (off + 8 > f.size()) { err = "exr: chunk offset past the end"; return false; }
+    if (f.size() < 8 || off > f.size() - 8) { err = "exr: chunk offset past the end"; return false; }      // (not off + 8 > size: an offset near 2^64 wraps)
     int32_t y, size; std::memcpy(&y, f.data() + off, 4); std::memcpy(&size, f.data() + off + 4, 4);
-    if (size < 0 || off + 8 + (uint64_t)size > f.size() || y < dw[1] || y > dw[3]) { err = "exr: broken chunk"; return false; }
+    if (size < 0 || (uint64_t)size > f.size() - 8 - off || y < dw[1] || y > dw[3]) { err = "exr: broken chunk"; return false; }
     const size_t nl = (size_t)std::min<int64_t>(lpb, (int64_t)dw[3] - y + 1), need = nl * lineBytes;
     const uint8_t* data = f.data() + off + 8;
     if (comp != 0 && (size_t)size < need) {
@@ -516,7 +521,7 @@ static const float kLambdaMin = 360.0f, kLambdaMax = 830.0f;            // inclu
 inline std::vector<float> resampleUniform(const std::vector<float>& w, const std::vector<float>& v)
 {
   std::vector<float> out((size_t)(kLambdaMax - kLambdaMin + 1.0f), 0.0f);
-  if (w.empty()) return out;
+  if (w.size() < 2 || v.size() < w.size()) return out;                   // (an .spd with fewer than two samples: the reference indexes w[-1] there; here the spectrum reads zero)
   for (size_t c = 0; c < out.size(); c++) {
     const float lam = kLambdaMin + float(c);
     if (lam < w.front() || lam > w.back()) continue;

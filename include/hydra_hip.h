@@ -24,6 +24,7 @@ extern "C" {
 #define HPT_ERR_HIP       2   /* HIP runtime error */
 #define HPT_ERR_STATE     3   /* call order violated (e.g. render before CommitDeviceData) */
 #define HPT_ERR_UNSUPPORTED 4 /* scene uses a feature outside the hot path's scope */
+#define HPT_ERR_NOMEM     5   /* a host allocation failed (std::bad_alloc / std::length_error caught at the boundary: sizes no host can hold) */
 
 typedef struct hpt_ctx hpt_ctx;
 
@@ -177,7 +178,8 @@ int      hpt_update_geom_triangles3f(hpt_ctx* ctx, uint32_t geomId, const float*
 int      hpt_clear_scene(hpt_ctx* ctx);                                                  /* ClearScene           :105 */
 uint32_t hpt_add_instance(hpt_ctx* ctx, uint32_t geomId, const float matrix16[16]);      /* AddInstance          :118; returns instId or 0xFFFFFFFF */
 /* AddInstanceMotion :127 (EmbreeRT.cpp:264-292): matrixNumber key transforms, linearly interpolated at the ray's time; 2 are supported
- * (what LoadSceneInstances passes). Forces the two-level layout and the megakernel schedule. */
+ * (what LoadSceneInstances passes). The automatic layout choice keeps two-level for scenes with a moving instance (the single-level layout
+ * inverts the interpolated matrix per triangle record); both layouts and both schedules render them, bit-identically. */
 uint32_t hpt_add_instance_motion(hpt_ctx* ctx, uint32_t geomId, const float* matrices /* matrixNumber x 16, column-major */, uint32_t matrixNumber);
 int      hpt_update_instance(hpt_ctx* ctx, uint32_t instId, const float matrix16[16]);   /* UpdateInstance       :134 */
 int      hpt_commit_scene(hpt_ctx* ctx, uint32_t options);                               /* CommitScene          :110: builds + uploads the two-level BVH2 */
@@ -283,7 +285,7 @@ int  hpt_set_accel_layout(hpt_ctx* ctx, int layout);
  * 0 = keep): a trace wave refills from the ray queue when fewer lanes than this still hold a ray; traceBlocksPerCU 0 = automatic.
  * groups (0 = automatic): the pixels of a call are cut into this many groups with their own path pool, ray queue and HIP stream, so
  * that the tail of one group's trace pass (a few long rays) overlaps the other groups' shade and trace passes.
- * The naive integrator, input-ray batches and scenes with moving instances always use the megakernel; PathTraceDR follows the same
+ * The naive integrator and input-ray batches always use the megakernel (scenes with moving instances run under either); PathTraceDR follows the same
  * automatic choice as PathTraceBlock (its wavefront form keeps the adjoint records per pool slot). The wavefront call returns once the frame is nearly done
  * (it polls a device progress word); results are complete after the stream is synchronised, as for the megakernel. */
 int  hpt_set_schedule(hpt_ctx* ctx, int schedule, int refillBelow, int traceBlocksPerCU, int groups);

@@ -857,3 +857,30 @@ def test_jpeg_reader_refuses_what_it_does_not_read(tmp_path):
     assert rc(b"\xff\xd8" + sof(0xC0, 65535, 65535) + b"\xff\xd9") != 0          # 2^32 pixels: refused before anything is allocated
     assert rc(b"\xff\xd8" + sof(0xC9, 8, 8) + b"\xff\xd9") != 0                  # arithmetic coding
     assert rc(b"\xff\xd8" + sof(0xC0, 8, 8) + b"\xff\xda\x00\x08\x01\x01\x00\x00\x3f\x00" + b"\x00" * 8 + b"\xff\xd9") != 0   # a scan without tables
+
+
+def test_crafted_exr_with_wrapping_chunk_offset_is_refused(tmp_path):
+    """csrc/scene_loader.h: decodeExr checks a chunk offset as `off > size - 8`, not `off + 8 > size` (an offset near 2^64 wraps and the memcpy behind
+    the check reads out of bounds), and refuses a header whose data window the file cannot hold before it allocates the planes. A valid file
+    with its first chunk offset overwritten by 2^64 - 4 must come back as an error, not a crash."""
+    import __graft_entry__ as g
+    g.build()
+    tool = os.path.join(ROOT, "hydracore3_amd", "hydra_hip_render")
+    good = open(os.path.join(GOLD, "exr", "none_float_y.exr"), "rb").read()
+    # the offset table follows the header's terminating zero byte: find it by decoding once with the Python reader's layout knowledge -
+    # the first chunk's offset is the smallest table entry and points at its own scanline header (y, size)
+    import struct
+    # header: magic, version, attributes (name\0 type\0 size data) ..., \0
+    p = 8
+    while good[p] != 0:
+        e = good.index(b"\0", p); p = e + 1
+        e = good.index(b"\0", p); p = e + 1
+        size = struct.unpack_from("<i", good, p)[0]; p += 4 + size
+    p += 1
+    bad = bytearray(good); struct.pack_into("<Q", bad, p, 0xFFFFFFFFFFFFFFFC)
+    path = tmp_path / "wrap.exr"; path.write_bytes(bytes(bad))
+    r = subprocess.run([tool, "--exr", str(path), str(tmp_path / "o.bin")], capture_output=True, text=True)
+    assert r.returncode != 0 and r.returncode > 0 and "exr" in (r.stdout + r.stderr).lower(), (r.returncode, r.stdout, r.stderr)   # an error message, not a signal
+    short = tmp_path / "short.exr"; short.write_bytes(good[:p + 4])
+    r = subprocess.run([tool, "--exr", str(short), str(tmp_path / "o2.bin")], capture_output=True, text=True)
+    assert r.returncode > 0, (r.returncode, r.stdout, r.stderr)

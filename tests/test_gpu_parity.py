@@ -165,6 +165,10 @@ def test_one_and_three_channel_framebuffers(cornell):
         b = OracleIntegrator(sc).render(4, channels=ch)
         d = (a.astype(np.float64) - b) / 4
         assert np.sqrt(np.mean(d * d)) < 1e-3 and a.shape[-1] == ch
+    # two channels: the three components written at pixel * 2 would land in the next pixel and past the buffer - refused
+    from hydracore3_amd.api import HydraHipError
+    with pytest.raises(HydraHipError, match="two-channel"):
+        HipIntegrator(sc).render(1, channels=2)
 
 
 def test_instance_remap_lists():
@@ -1190,6 +1194,29 @@ def test_reference_motion_fixture_matches_oracle(tmp_path):
 
 
 # ---- the raw C ABI refuses what the front ends never send -----------------------------------------------------------------------------------
+def test_no_exception_crosses_the_c_boundary(cornell):
+    """include/hydra_hip.h promises that nothing throws across `extern "C"`: every entry point is a function-try-block (hptGuard). Forced here
+    through AddGeom_Triangles3f with vertex counts no host can hold: 2^44 vertices = 211 TB of positions (operator new fails: std::bad_alloc) and
+    2^61 (beyond vector::max_size: std::length_error) - both thrown by the std::vector the geometry is copied into, before a byte is read.
+    The call returns the reference's failure value (uint32_t(-1), EmbreeRT.cpp:144-159), hpt_last_error names the cause, the context stays usable."""
+    import ctypes as C
+    from hydracore3_amd.api import HipIntegrator
+    sc, _, _ = cornell
+    gpu = HipIntegrator(sc)
+    before = gpu.render(2)
+    pos = np.zeros(9, np.float32); idx = np.arange(3, dtype=np.uint32)
+    for n_vert, what in ((1 << 44, b"bad_alloc"), (1 << 61, b"length_error")):
+        rc = gpu.L.hpt_add_geom_triangles3f(gpu.h, pos.ctypes.data, n_vert, idx.ctypes.data, 3, 0, 12)
+        msg = gpu.L.hpt_last_error(gpu.h)
+        print(rc, msg)
+        assert rc == 0xFFFFFFFF and what in msg and b"hpt_add_geom_triangles3f" in msg
+    # the failed calls left no half-added geometry behind: the committed scene still renders what it rendered
+    again = HipIntegrator(sc).render(2)
+    assert np.array_equal(before, again)
+    gpu2 = HipIntegrator(sc)
+    assert np.array_equal(gpu2.render(2), before)
+
+
 def test_abi_refuses_tile_sizes_that_do_not_divide_the_viewport(cornell):
     """SetViewport only picks a tile size that divides width and height (integrator_pt.h:379-389); handed anything else, kernel_PackXY would
     index past W * H. hpt_update_params says no instead (the front ends apply the fallback themselves)."""

@@ -390,3 +390,53 @@ def test_spectra_given_by_textures(layout):
     rgb.spectral_mode = 1
     with pytest.raises(HydraHipError, match="spectral"):
         HipIntegrator(rgb)
+
+
+def test_offsets_update_onto_a_glass_material_widens_the_spectral_kernel():
+    """The spectral kernel's scope is chosen from the materials a hit can REACH at CommitDeviceData. Update_m_matIdOffsets (integrator_pt.h:470)
+    re-points a mesh at other triangle ranges - here at those of a twin mesh nothing instances, whose triangles carry a legacy GLASS material -
+    so afterwards a hit reaches a material type the chosen scope (diffuse only: no gltf, no glass branch) does not hold. The update must widen
+    the scope: the frame equals the oracle's rendering of a scene BUILT with those offsets, and differs from the frame before the update."""
+    from hydracore3_amd.api import HipIntegrator
+    from oracle.orc import OracleIntegrator
+    from hydracore3_amd import scene as S, synth
+
+    def build(swapped):
+        sc = S.SceneData()
+        sc.width, sc.height = 64, 48
+        sc.cam_pos, sc.cam_look_at, sc.cam_up = (0.0, 1.6, 6.0), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0)
+        sc.fov, sc.trace_depth = 40.0, 6
+        sc.env_color = (0.2, 0.25, 0.3, 0.0)
+        sc.spectral_mode = 1
+        sc.spec_offset_sz, sc.spec_values = [(0, 471)], np.ones(471, np.float32)     # the loader's uniform spectrum (integrator_pt_scene.cpp:406-418)
+        sc.materials.append(S.material_diffuse((0.7, 0.6, 0.5)))
+        sc.materials.append(S.material_diffuse((0.2, 0.5, 0.8)))
+        sc.materials.append(S.material_glass((1.0, 1.0, 1.0), (0.9, 1.0, 0.9), 1.5))
+        p, n, t, uv, idx = synth._quad((-8, 0, 6), (16, 0, 0), (0, 0, -14), 2, 2)
+        sc.add_instance(sc.add_mesh(p, n, t, uv, idx, [0]), np.eye(4))
+        sp = synth._sphere_mesh(2)
+        ntri = sp[4].size // 3
+        a = sc.add_mesh(sp[0], sp[1], sp[2], sp[3], sp[4], np.full(ntri, 1, np.uint32))        # the instanced sphere: diffuse
+        sc.add_mesh(sp[0], sp[1], sp[2], sp[3], sp[4], np.full(ntri, 2, np.uint32))            # its twin, never instanced: glass
+        sc.add_instance(a, S.translate(0.0, 1.0, 0.0))
+        sc.lights.append(S.light_rect(S.translate(0.0, 4.0, 1.0), 0.8, 0.8, (1, 1, 1), 15.0))
+        mvo = np.asarray(sc.mat_vert_offset, np.uint32).reshape(-1, 2).copy()
+        if swapped:
+            mvo[1] = mvo[2]
+            sc.mat_vert_offset = [tuple(int(v) for v in r) for r in mvo]
+        return sc, mvo
+
+    sc, mvo = build(False)
+    gpu = HipIntegrator(sc)
+    spp = 8
+    before = gpu.render(spp)
+    upd = HipIntegrator(sc)
+    swapped = mvo.copy(); swapped[1] = mvo[2]                    # mesh 1 now reads the twin's triangle range: the glass ids
+    upd.Update_m_matIdOffsets(swapped)
+    after = upd.render(spp)
+    sc2, _ = build(True)
+    ref = OracleIntegrator(sc2).render(spp)
+    built = HipIntegrator(sc2).render(spp)
+    assert np.isfinite(after).all() and _l2(after, before, spp) > 1e-2            # the sphere turned to glass
+    assert np.array_equal(after, built)                                          # the update == a scene built that way, bit for bit
+    assert _l2(after, ref, spp) < 1e-3

@@ -190,7 +190,9 @@ def make_roofline(workload, integ, torch, dev, stream, N, W, H, spp, t_count, ke
               "traversal_only_frac": round(ab["traversal"] * paths / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
               "hbm_counter_frac": round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
               "note": "achieved / frac = ALGORITHMIC bytes (SURVEY 8d) over the live launch time: the top of the BVH is served by L2 / Infinity Cache, "
-                      "so the counter fraction (FETCH_SIZE doubled per the gfx950 rule + WRITE_SIZE) is the HBM-side figure"}, **extra)
+                      "so the counter fraction (FETCH_SIZE under the rule calibrated in profiles/r3_hbm_counter_probe.json - exact for divergent 64-B record fetches, "
+                      "doubled for the shade kernel's coalesced streams - + WRITE_SIZE; Infinity-Cache hits are counted) is the memory-side figure. Random 64-B record "
+                      "fetches themselves top out at 1.1 TB/s from HBM, 3.6 TB/s from the Infinity Cache and 7.6 TB/s from L2 (same probe): the 8 TB/s peak is a streaming figure"}, **extra)
     if pmc:
         r["lane_utilisation"] = pmc.get("lane_utilisation"); r["pmc_source"] = f"profiles/pmc_{workload}.json, commit {pmc.get('commit')}"
     return r
@@ -484,7 +486,7 @@ def run_dr(args, workload, rank, world, dev, dist, backend, steps, warmup, spp_a
                   "record_bytes_per_path": round(ab["records"], 1), "atomic_bytes_per_path": round(ab["atomics"], 1), "nodes_per_ray": round(ab["nodes_per_ray"], 2),
                   "tris_per_ray": round(ab["tris_per_ray"], 2), "rays_per_path": round(ab["rays_per_path"], 2), "records_per_path": round(ab["records_per_path"], 2),
                   "traffic": traffic, "traffic_over_algorithmic": round(traffic / (ab["total"] * paths), 3) if traffic else None,
-                  "traffic_source": (f"{tj.get('from')}, collected at commit {tj.get('commit')}: per-path counter bytes (FETCH_SIZE doubled + WRITE_SIZE) rescaled to this launch, not measured in this run" if tj else None),
+                  "traffic_source": (f"{tj.get('from')}, collected at commit {tj.get('commit')}: per-path counter bytes ({tj.get('rule', 'FETCH_SIZE doubled + WRITE_SIZE')}) rescaled to this launch, not measured in this run" if tj else None),
                   "hbm_counter_frac": round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None}
         hbm = {"achieved": round(hbm_alg, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_alg / HBM_PEAK_GBS, 4)}
         if sched_used == 2:

@@ -366,7 +366,7 @@ class HipIntegrator:
         """The last CommitScene: host ms, upload ms, device refit ms, refitted (bool)."""
         out = (C.c_float * 4)()
         self._chk(self.L.hpt_get_commit_time(self.h, out))
-        return {"host_ms": out[0], "upload_ms": out[1], "refit_ms": out[2], "refitted": bool(out[3])}
+        return {"host_ms": out[0], "upload_ms": out[1], "refit_ms": out[2], "device_ms": out[2], "refitted": int(out[3]) == 1, "device_built": int(out[3]) == 2}
 
     def UpdateInstance(self, inst_id, matrix_rowmajor):
         """ISceneObject::UpdateInstance (CrossRT.h:134); takes effect at the next CommitScene."""
@@ -374,8 +374,10 @@ class HipIntegrator:
         cm = colmajor(np.asarray(matrix_rowmajor))
         self._chk(self.L.hpt_update_instance(self.h, inst_id, cm.ctypes.data))
 
-    def CommitScene(self):
-        self._chk(self.L.hpt_commit_scene(self.h, 4))
+    def CommitScene(self, options=4):
+        """ISceneObject::CommitScene (CrossRT.h:109); options as BuildOptions (:8-14): 1 BUILD_LOW, 2 BUILD_MEDIUM (the single-level tree is built on the
+        device), 4 BUILD_HIGH (the host's SAH build)."""
+        self._chk(self.L.hpt_commit_scene(self.h, options))
 
     def last_launch(self):
         """What the last PathTrace* call walked: schedule, 4-wide compressed tree, 64-byte shading records, HBM part of the stacks."""

@@ -22,6 +22,7 @@
 #include "hpt_decl.h"
 #include "hpt_helpers.hip"
 #include "bvh_build.h"
+#include "hpt_lbvh.h"
 
 static const uint MAX_STACK = 64;                           // traversal stack entries per lane: LDS_STACK in LDS + the rest in an HBM overflow buffer
 // Static scenes with at most this many INSTANCED triangles get the single-level world-space BVH (48 B + ~32 B of nodes per triangle:
@@ -157,6 +158,8 @@ struct hpt_ctx
   uint wfRefillBelow = 56;               // a trace wave refills from the queue when fewer lanes than this still hold a ray
   int  wfBlocksPerCU = 0;
   size_t instTris = 0;                   // instanced triangles of the committed scene
+  // CommitScene on the device (hpt_lbvh.hip): -1 = by CommitScene's options (BUILD_LOW / BUILD_MEDIUM without BUILD_HIGH), 0 = never, 1 = whenever the single-level layout is built
+  int deviceBuild = -1; void* lbvh = nullptr; unsigned long long geomVersion = 1, lbvhGeomVersion = 0; std::vector<size_t> lbvhPosOff, lbvhIdxOff;
   uint lastSchedule = 1, lastWfIters = 0;
   uint lastWide = 0, lastShadeRecords = 0, lastDeep = 0;          // what the last launch walked: 4-wide compressed tree, 64-byte shading records, HBM part of the stacks
 
@@ -230,6 +233,7 @@ try {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   (void)hpt_comm_destroy(c);
+  lbvhDestroy(c->lbvh); c->lbvh = nullptr;
   c->dNodes.release(); c->dTris.release(); c->dInsts.release(); c->dSweepInsts.release(); c->dSweepTris.release(); c->dLevelNodes.release(); c->dShadeTris.release(); c->dNodes4.release(); c->dNodes4Src.release(); c->dTriBox.release(); c->dNodeBounds.release(); c->dInstO2W.release(); c->dTriIndices.release(); c->dMatIdByPrim.release();
   c->dMatVertOffset.release(); c->dPackedXY.release(); c->dVData.release(); c->dNormMat.release(); c->dRemapInst.release();
   c->dRemapLists.release(); c->dMaterials.release(); c->dLights.release(); c->dTextures.release(); c->dArrays1f.release(); c->dSpecValues.release(); c->dSpecOffsetSz.release(); c->dCieXYZ.release(); c->dFilmsEtaK.release(); c->dPrecompFilms.release(); c->dFilmsSpecId.release(); c->dSpecTexIdsWavelengths.release(); c->dSpecTexOffsetSz.release(); c->dGens.release();
@@ -355,7 +359,7 @@ catch (...) { return hptGuard(c, "hpt_device_memset"); }
 extern "C" int hpt_clear_geom(hpt_ctx* c)
 try {
   if (!c) return HPT_ERR_ARG;
-  c->geoms.clear(); c->insts.clear(); c->accelCommitted = false; c->flatRefittable = false;
+  c->geoms.clear(); c->insts.clear(); c->accelCommitted = false; c->flatRefittable = false; c->geomVersion++;
   return HPT_OK;
 }
 catch (...) { return hptGuard(c, "hpt_clear_geom"); }
@@ -370,7 +374,7 @@ static int fill_geom(hpt_ctx* c, Geom& g, const float* vpos, size_t nVert, const
   for (size_t i = 0; i < nVert; i++) { g.pos[3 * i + 0] = vpos[fs * i + 0]; g.pos[3 * i + 1] = vpos[fs * i + 1]; g.pos[3 * i + 2] = vpos[fs * i + 2]; }
   g.idx.assign(idx, idx + (nIdx / 3) * 3);
   for (uint v : g.idx) if (v >= nVert) return c->fail(HPT_ERR_ARG, "AddGeom_Triangles3f: index out of range");
-  g.dirty = true;
+  g.dirty = true; c->geomVersion++;
   return HPT_OK;
 }
 
@@ -507,6 +511,66 @@ template <class F> static void parallelRanges(size_t n, int threads, F fn)
   for (std::thread& t : pool) t.join();
 }
 
+// ---- CommitScene on the device: hpt_lbvh.hip builds the single-level BVH2, its triangle records and the 4-wide compressed tree -------------
+static int commit_flat_on_device(hpt_ctx* c, size_t instTris, double tBuild0)
+{
+  if (!c->lbvh) c->lbvh = lbvhCreate();
+  std::string err;
+  if (c->lbvhGeomVersion != c->geomVersion) {                 // the meshes' positions and indices: uploaded once, kept until a mesh changes
+    std::vector<const float*> pos; std::vector<size_t> posN; std::vector<const uint*> idx; std::vector<size_t> idxN;
+    for (const Geom& g : c->geoms) { pos.push_back(g.pos.data()); posN.push_back(g.pos.size()); idx.push_back(g.idx.data()); idxN.push_back(g.idx.size()); }
+    if (!lbvhUploadGeometry(c->lbvh, pos, posN, idx, idxN, c->lbvhPosOff, c->lbvhIdxOff, err)) return c->fail(HPT_ERR_HIP, "CommitScene (device build): " + err);
+    c->lbvhGeomVersion = c->geomVersion;
+  }
+  const size_t ni = c->insts.size();
+  std::vector<LbvhInstance> li(ni);
+  std::vector<BvhInst> dinst(std::max<size_t>(ni, 1));
+  for (size_t i = 0; i < ni; i++) {
+    const float* m = c->insts[i].m;
+    for (int r = 0; r < 3; r++) { li[i].objectToWorld[4 * r + 0] = m[r]; li[i].objectToWorld[4 * r + 1] = m[4 + r]; li[i].objectToWorld[4 * r + 2] = m[8 + r]; li[i].objectToWorld[4 * r + 3] = m[12 + r]; }
+    const uint g = c->insts[i].geomId;
+    li[i].triCount = (uint)(c->geoms[g].idx.size() / 3); li[i].posOffset = c->lbvhPosOff[g]; li[i].idxOffset = c->lbvhIdxOff[g];
+    inverse_rows(m, dinst[i].row0, dinst[i].row1, dinst[i].row2);
+    dinst[i].root = REF_NONE; dinst[i].geomId = g; dinst[i].pad0 = 0u; dinst[i].pad1 = 0;
+  }
+  const uint n = (uint)instTris;
+  HIPCHK(c, c->dNodes.alloc(std::max<size_t>(n, 1)));
+  HIPCHK(c, c->dTris.alloc(std::max<size_t>(n, 1)));
+  const bool wantWide = true;
+  HIPCHK(c, c->dNodes4.alloc(std::max<size_t>(n, 1)));
+  HIPCHK(c, c->dInsts.upload(dinst.data(), dinst.size()));
+  {                                                          // (both layouts' kernels read the motion rows' pointer; none of these instances moves)
+    std::vector<float> mo(24 * std::max<size_t>(ni, 1), 0.0f);
+    for (size_t i = 0; i < ni; i++) for (int key = 0; key < 2; key++) for (int k = 0; k < 12; k++) mo[24 * i + 12 * (size_t)key + k] = li[i].objectToWorld[k];
+    HIPCHK(c, c->dInstMotion.upload(mo.data(), mo.size()));
+    c->S.instMotion = c->dInstMotion.p;
+  }
+  const double tDev0 = now_ms();
+  LbvhResult r;
+  if (!lbvhBuild(c->lbvh, li.data(), (uint)ni, n, c->dNodes.p, c->dTris.p, c->dNodes4.p, (uint)c->dNodes4.n, wantWide, r, err)) return c->fail(HPT_ERR_HIP, "CommitScene (device build): " + err);
+  const double tDev1 = now_ms();
+  if (r.depth + 1u > MAX_STACK) return HPT_ERR_STATE;         // a degenerate input (the Morton curve cannot separate it): the host's depth-capped build takes over
+  c->instTris = instTris; c->anyMotion = false;
+  c->nodes4Count = 0; c->stackNeeded4 = 0; c->S.nodes4 = nullptr; c->S.root4 = REF_NONE; c->S.statsWide = 0; c->S.megaWide = 0;
+  c->sahVisits = r.sahVisits;
+  if (r.nodes4Count != 0u && (r.rootRef & REF_LEAF) == 0u) {
+    c->nodes4Count = r.nodes4Count; c->stackNeeded4 = 3u * r.depth4 + 1u;
+    c->S.nodes4 = c->dNodes4.p; c->S.root4 = 0u;
+    c->S.megaWide = (c->wideEnabled && c->sahVisits >= HEAVY_SAH_VISITS) ? 1u : 0u;
+  }
+  c->flatTris.clear(); c->flatRefittable = false;             // (an update is answered by another device build, not by a refit)
+  c->S.nodes = c->dNodes.p; c->S.tris = c->dTris.p; c->S.insts = c->dInsts.p;
+  c->S.rootRef = r.rootRef; c->S.numInsts = (uint)ni; c->S.flatMode = 1; c->S.sweep = 0; c->S.sweepInsts = nullptr; c->S.sweepTris = nullptr;
+  c->S.nodeMin = c->nodeMinOverride >= 0 ? (uint)c->nodeMinOverride : (c->sahVisits >= HEAVY_SAH_VISITS ? 16u : 0u);
+  c->S.nodeMin4 = c->nodeMinOverride >= 0 ? (uint)c->nodeMinOverride : (c->sahVisits >= HEAVY_SAH_VISITS ? 32u : 0u);
+  c->stackNeeded = r.depth + 1u;
+  if (std::getenv("HPT_DEBUG_ACCEL")) std::fprintf(stderr, "[hydra_hip] device-built single-level BVH: %zu triangles, depth %u, sah visits %.2f; 4-wide: %u nodes, depth %u; %.2f ms of kernels\n",
+                                                  instTris, r.depth, c->sahVisits, r.nodes4Count, r.depth4, tDev1 - tDev0);
+  c->tCommit[0] = float(tDev0 - tBuild0); c->tCommit[1] = 0.0f; c->tCommit[2] = float(tDev1 - tDev0); c->tCommit[3] = 2.0f;   // host preparation + uploads, -, device build, "built on the device"
+  c->accelCommitted = true; c->shadeTrisDirty = true;
+  return HPT_OK;
+}
+
 static int refit_flat(hpt_ctx* c)
 {
   const double t0 = now_ms();
@@ -550,13 +614,28 @@ static int refit_flat(hpt_ctx* c)
   return HPT_OK;
 }
 
-extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t)
+static int commit_flat_on_device(hpt_ctx* c, size_t instTris, double tBuild0);
+
+extern "C" int hpt_commit_scene(hpt_ctx* c, uint32_t options)
 try {
   if (!c) return HPT_ERR_ARG;
   (void)hipSetDevice(c->device);
   if (c->flatRefittable && c->refitEnabled && c->S.flatMode == 1u) return refit_flat(c);
   const double tBuild0 = now_ms();
   c->dirtyGeoms.clear();
+  {
+    // CommitScene(BUILD_LOW | BUILD_MEDIUM) (CrossRT.h:8-14) or hpt_set_option("device_build", 1): the single-level tree is built by kernels
+    // (hpt_lbvh.hip: a few ms for 1 M triangles against a quarter of a second on the host; a linear BVH, coarser than the SAH tree)
+    size_t nTris = 0; bool moving = false;
+    for (const Inst& in : c->insts) { nTris += c->geoms[in.geomId].idx.size() / 3; moving = moving || in.motion; }
+    const bool wantFlat = nTris <= FLAT_TRI_BUDGET && nTris < (size_t(1) << 28) && !moving &&
+                          (c->accelLayout == 2 || (c->accelLayout == 0 && (nTris >= FLAT_AUTO_TRIS || c->insts.size() >= MANY_INSTANCES)));
+    const bool fast = (options & 3u) != 0u && (options & 4u) == 0u;
+    if (wantFlat && nTris > 0 && (c->deviceBuild == 1 || (c->deviceBuild < 0 && fast))) {
+      const int rc = commit_flat_on_device(c, nTris, tBuild0);
+      if (rc != HPT_ERR_STATE) return rc;                    // (HPT_ERR_STATE: the tree came out deeper than the traversal stack - the host's depth-capped build takes over)
+    }
+  }
   // ---- bottom level: one BVH2 per mesh over object-space triangles ----
   uint maxBlasDepth = 0;
   const int nThreads = buildThreads(c);
@@ -2125,6 +2204,7 @@ try {
   else if (k == "shade_records") c->shadeTrisEnabled = value != 0;                     // 0: no DevScene::shadeTris (A/B, diagnosis)
   else if (k == "build_threads") c->buildThreads = std::min(value, 64);                // host threads CommitScene builds its trees with (0: the usable cores, at most 16)
   else if (k == "stats_wide") c->statsWide = value != 0;
+  else if (k == "device_build") { if (value < -1 || value > 1) return c->fail(HPT_ERR_ARG, "device_build: -1 by CommitScene's options, 0 never, 1 always"); c->deviceBuild = value; c->accelCommitted = false; c->flatRefittable = false; }
   else if (k == "wide_nodes") { c->wideEnabled = value != 0; c->S.megaWide = (c->wideEnabled && c->nodes4Count != 0u && c->S.flatMode != 0u && c->sahVisits >= HEAVY_SAH_VISITS) ? 1u : 0u; }   // both users of the tree, at once                             // 0: the wavefront trace kernel walks the BVH2 instead of the 4-wide compressed tree (A/B, diagnosis)
   else if (k == "force_full_materials") c->forceFull = value != 0;                     // diagnostic: never pick the lean (gltf + emissive) kernels
   else return c->fail(HPT_ERR_ARG, "hpt_set_option: unknown option " + k);

@@ -182,7 +182,11 @@ uint32_t hpt_add_instance(hpt_ctx* ctx, uint32_t geomId, const float matrix16[16
  * inverts the interpolated matrix per triangle record); both layouts and both schedules render them, bit-identically. */
 uint32_t hpt_add_instance_motion(hpt_ctx* ctx, uint32_t geomId, const float* matrices /* matrixNumber x 16, column-major */, uint32_t matrixNumber);
 int      hpt_update_instance(hpt_ctx* ctx, uint32_t instId, const float matrix16[16]);   /* UpdateInstance       :134 */
-int      hpt_commit_scene(hpt_ctx* ctx, uint32_t options);                               /* CommitScene          :110: builds + uploads the two-level BVH2 */
+/* CommitScene :109-110. options = BuildOptions (CrossRT.h:8-14): BUILD_HIGH (4, the reference's default) or 0 build the tree with the host's binned-SAH
+ * builder; BUILD_LOW (1) / BUILD_MEDIUM (2) without BUILD_HIGH build the single-level tree ON THE DEVICE (a linear BVH and its 4-wide compressed form,
+ * milliseconds for 10^6 triangles: scenes whose topology changes every frame) when the scene takes the single-level layout (hpt_set_accel_layout) and no
+ * instance moves; hpt_set_option("device_build", 1 / 0) forces / forbids that whatever the options say. Hits never depend on which builder ran. */
+int      hpt_commit_scene(hpt_ctx* ctx, uint32_t options);
 /* RayQuery_NearestHit / RayQuery_AnyHit (:148,:165), batched: n rays from host memory, results to host memory. */
 int      hpt_ray_query_nearest(hpt_ctx* ctx, const float* posAndNear4, const float* dirAndFar4, uint32_t n, hpt_hit* out);
 int      hpt_ray_query_any(hpt_ctx* ctx, const float* posAndNear4, const float* dirAndFar4, uint32_t n, uint32_t* out);
@@ -327,8 +331,8 @@ int  hpt_allreduce_grad(hpt_ctx* ctx, float* gradDev, size_t count, void* stream
 int  hpt_get_accel_info(hpt_ctx* ctx, float out[4]);
 /* The last hpt_commit_scene: out[0] = host milliseconds (BVH build, or for a refit the matrix inversions and record updates), out[1] = upload ms,
  * out[2] = device refit ms, out[3] = 1 when the committed single-level tree was REFITTED on the device (UpdateInstance / UpdateGeom_Triangles3f
- * with unchanged topology: boxes recomputed bottom-up by two small kernels, CrossRT.h:85-86, 134) and 0 when it was built on the host.
- * hpt_set_option("refit", 0) forces the build. */
+ * with unchanged topology: boxes recomputed bottom-up by two small kernels, CrossRT.h:85-86, 134), 2 when it was BUILT on the device (out[2] = the
+ * build's milliseconds) and 0 when it was built on the host. hpt_set_option("refit", 0) forces the build. */
 int  hpt_get_commit_time(hpt_ctx* ctx, float out[4]);
 int  hpt_get_schedule(hpt_ctx* ctx, int* lastSchedule, uint32_t* lastIterations);
 /* What the last hpt_path_trace_* call walked (no counterpart in the reference: lets a test assert WHICH kernels produced a frame):

@@ -1375,6 +1375,54 @@ def test_wide_compressed_tree_returns_what_the_bvh2_returns():
     assert not np.array_equal(wide.RayQuery_NearestHit(pos, dr).view(np.uint8), hw.view(np.uint8))
 
 
+def test_device_built_tree_returns_what_the_host_built_tree_returns():
+    """CommitScene on the device (hpt_lbvh.hip: Morton sort, Karras hierarchy, bottom-up fit, collapse to 4-wide nodes - CrossRT.h:85-86, 109, 134):
+    chosen by CommitScene(BUILD_LOW / BUILD_MEDIUM) or hpt_set_option("device_build", 1). Hits are decided by the exact triangle test and the
+    (instId, primId) tie rule, never by the tree, so ray queries through the device-built trees (BVH2 and 4-wide) equal the oracle's brute force
+    and the host-built SAH tree's answers bit for bit, frames and generators under both schedules equal the host-built ones, and an UpdateInstance
+    is answered by another device build that equals a context built from scratch."""
+    from hydracore3_amd.api import HipIntegrator
+    from hydracore3_amd import scene as S, synth
+    from oracle.orc import OracleIntegrator
+    sc = synth.interior_scene(160, 96, subdiv=1, tex_size=16)                   # 17 K triangles in 206 instances
+    host, dev = HipIntegrator(sc), HipIntegrator(sc)
+    dev.set_option("device_build", 1); dev.CommitScene()
+    assert dev.commit_time()["device_built"] and not host.commit_time()["device_built"]
+    info = dev.accel_info()
+    assert info["layout"] == "flat" and info["inst_tris"] == host.accel_info()["inst_tris"] and info["sah_node_visits"] >= 20.0
+    pos, dr = random_rays(30000, 29, -5.0, 5.0)
+    hd, hh = dev.RayQuery_NearestHit(pos, dr), host.RayQuery_NearestHit(pos, dr)
+    assert (hh["geomId"] != 0xFFFFFFFF).mean() > 0.5
+    assert np.array_equal(hd.view(np.uint8), hh.view(np.uint8))
+    hc = OracleIntegrator(sc).ray_nearest(pos[:4000], dr[:4000], brute=True)
+    for f in ("primId", "instId", "geomId"):
+        assert np.array_equal(hd[f][:4000], hc[f])
+    assert np.array_equal(hd["t"][:4000].view(np.uint32), hc["t"].view(np.uint32))
+    dr2 = dr.copy(); dr2[:, 3] = np.random.default_rng(5).uniform(0.3, 9.0, dr.shape[0]).astype(np.float32)
+    assert np.array_equal(dev.RayQuery_AnyHit(pos, dr2), host.RayQuery_AnyHit(pos, dr2))
+    narrow = HipIntegrator(sc); narrow.set_option("device_build", 1); narrow.set_option("wide_nodes", 0); narrow.CommitScene()      # the device-built BVH2 itself
+    assert np.array_equal(narrow.RayQuery_NearestHit(pos, dr).view(np.uint8), hh.view(np.uint8))
+    for sched in (1, 2):
+        a, b = HipIntegrator(sc), HipIntegrator(sc)
+        a.set_option("device_build", 1); a.CommitScene()
+        a.set_schedule(sched); b.set_schedule(sched)
+        assert np.array_equal(a.render(3), b.render(3)) and np.array_equal(a.random_gens(), b.random_gens())
+        assert a.last_launch()["wide_nodes"] and a.last_launch()["shade_records"]
+    # CommitScene's BuildOptions choose the builder: BUILD_LOW (1) -> device, BUILD_HIGH (4) -> host
+    opt = HipIntegrator(sc)
+    opt.set_option("refit", 0)                                              # (an unchanged scene would be answered by the 0.6 ms refit of the tree it has)
+    opt.CommitScene(1); assert opt.commit_time()["device_built"]
+    opt.CommitScene(4); assert not opt.commit_time()["device_built"]
+    # an update is answered by another device build
+    m = S.translate(0.4, 0.1, -0.5) @ np.asarray(sc.inst_matrices[6]) @ S.scale(1.3, 0.8, 1.1)
+    for g in (dev, host):
+        g.UpdateInstance(6, m); g.CommitScene()
+    assert dev.commit_time()["device_built"] and host.commit_time()["refitted"]
+    hm = dev.RayQuery_NearestHit(pos, dr)
+    assert np.array_equal(hm.view(np.uint8), host.RayQuery_NearestHit(pos, dr).view(np.uint8)) and not np.array_equal(hm.view(np.uint8), hd.view(np.uint8))
+    assert np.array_equal(dev.render(2), host.render(2))
+
+
 def test_interior_frame_matches_oracle():
     """The kernels BASELINE configs[2] / [4] are timed on - wfShadeKernel<LEAN> + wfTraceKernel<WIDE> on the 4-wide compressed tree with the
     64-byte shading records - against the CPU oracle DIRECTLY (not through the chain wavefront == megakernel == BVH2 == oracle): a

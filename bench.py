@@ -149,7 +149,7 @@ def make_roofline(workload, integ, torch, dev, stream, N, W, H, spp, t_count, ke
     sched_used, wf_rounds = integ.last_schedule()
     probe_spp = min(spp, 8)
     integ.set_schedule(1)                                     # the instrumented build is the megakernel: same rays, same triangle visits ...
-    integ.set_option("stats_wide", 1 if sched_used == 2 else 0)   # ... and the node walk of the tree the timed call used (wavefront: the 4-wide compressed one, where the scene has it)
+    integ.set_option("stats_wide", 1 if integ.last_launch()["wide_nodes"] else 0)   # ... and the node walk of the tree the timed call used (heavy scenes: the 4-wide compressed one)
     integ.set_instrumentation(True)
     integ.InitRandomGens(N)
     integ.set_tid_interleave(0, 1)
@@ -162,7 +162,7 @@ def make_roofline(workload, integ, torch, dev, stream, N, W, H, spp, t_count, ke
     k_ms = float(np.mean(kernel_ms))
     paths = float(t_count) * spp
     hbm_alg = ab["total"] * paths / (k_ms * 1e-3) / 1e9
-    extra = {"kernel": "pathTraceKernel" if sched_used == 1 else f"wavefront: {wf_rounds} x (wfShadeKernel + wfTraceKernel)",
+    extra = {"kernel": {1: "pathTraceKernel", 3: "pathTraceBlockKernel (megakernel, block-local ray repacking)"}.get(sched_used, f"wavefront: {wf_rounds} x (wfShadeKernel + wfTraceKernel)"),
              "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_path": round(ab["total"], 1), "traversal_bytes_per_path": round(ab["traversal"], 1),
              "nodes_per_ray": round(ab["nodes_per_ray"], 2), "tris_per_ray": round(ab["tris_per_ray"], 2), "rays_per_path": round(ab["rays_per_path"], 2)}
     tj = load_profile(f"traffic_{workload}.json")
@@ -171,7 +171,7 @@ def make_roofline(workload, integ, torch, dev, stream, N, W, H, spp, t_count, ke
         traffic = tj["hbm_bytes_per_launch"] * paths / float(tj["paths_per_launch"])     # counter bytes per path x this launch's paths
         traffic_src = f"{tj.get('from')}, collected at commit {tj.get('commit', 'unrecorded (round 1)')}: per-path counter bytes rescaled to this launch, not measured in this run"
     pmc = load_profile(f"pmc_{workload}.json")
-    if sched_used == 1 and pmc and pmc.get("valu_insts_per_path"):
+    if sched_used != 2 and pmc and pmc.get("valu_insts_per_path"):
         # VALU-issue roofline: wave-instructions the kernel issues (profiled count per path, a property of binary + scene) over the
         # LIVE kernel time, against 1024 SIMDs x f_clk / 2 cycles per wave64 instruction
         ginst = pmc["valu_insts_per_path"] * paths / (k_ms * 1e-3) / 1e9
@@ -396,6 +396,10 @@ def run_dr(args, workload, rank, world, dev, dist, backend, steps, warmup, spp_a
     del tgt_int
     integ = HipIntegrator(sc, device=dev.index)
     integ.set_option("dr_skip_nonfinite", 1)                       # an optimisation loop: one NaN sample must not poison Adam's moments
+    if args.blocks_per_cu:
+        integ.set_launch_config(args.blocks_per_cu)
+    if args.schedule:
+        integ.set_schedule(args.schedule, args.refill_below, args.trace_blocks_per_cu, args.groups)
     off, size = integ.PutDiffTex2D(tex_id, tw, tw, 4)
     my_spp = spp
     if samples:
@@ -465,7 +469,8 @@ def run_dr(args, workload, rank, world, dev, dist, backend, steps, warmup, spp_a
     sched_used, wf_rounds = integ.last_schedule()
     launch = integ.last_launch()
     wl = "dr_interior" if big else "dr"
-    roof = {"kernel": "pathTraceKernel<DR>" if sched_used == 1 else f"wavefront DR: {wf_rounds} x (wfShadeKernel<DR> + wfTraceKernel)", "kernel_ms": round(k_ms, 3)}
+    roof = {"kernel": {1: "pathTraceKernel<DR>", 3: "pathTraceBlockKernel<DR> (megakernel, block-local ray repacking)"}.get(sched_used, f"wavefront DR: {wf_rounds} x (wfShadeKernel<DR> + wfTraceKernel)"),
+            "kernel_ms": round(k_ms, 3)}
     if world == 1:
         # the counting probe: the instrumented PathTraceDR megakernel on the same frame at a few passes (it walks the tree the timed call walked)
         probe_spp = min(spp, 8)
@@ -578,7 +583,7 @@ def main():
     ap.add_argument("--no-build", action="store_true", help="never compile (profiler runs: build first, `python __graft_entry__.py`); fail if the library is missing")
     ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the check of the sharded frame against single-GPU renderings of the same shares")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
-    ap.add_argument("--schedule", type=int, default=0, help="0 automatic, 1 persistent megakernel, 2 wavefront (shade + trace kernels)")
+    ap.add_argument("--schedule", type=int, default=0, help="0 automatic, 1 persistent megakernel, 2 wavefront (shade + trace kernels), 3 megakernel with block-local ray repacking")
     ap.add_argument("--refill-below", type=int, default=0, help="wavefront: refill a trace wave when fewer lanes than this hold a ray")
     ap.add_argument("--trace-blocks-per-cu", type=int, default=0)
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],

@@ -70,6 +70,20 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
 template <bool DEEP, bool FLAT, bool SWEEP, bool MOTION, int SCOPE>   // SCOPE 0: the reference's spectral fixtures' needs; 1: + gltf; 2: + glass / blends / normal maps / environment maps / lens; 3: the same at 4 waves per SIMD
 __global__ void __launch_bounds__(256, SCOPE == 2 ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAVES) pathTraceSpectralKernel(const DevScene S, const Job job);
 
+// ---- megakernel with block-local ray repacking (hpt_block.hip) --------------------------------------------------------------------------
+#ifndef HPT_BW_FWD_WAVES
+#define HPT_BW_FWD_WAVES 4
+#endif
+#ifndef HPT_BW_DR_WAVES
+#define HPT_BW_DR_WAVES 4
+#endif
+#ifndef HPT_BW_FULL_WAVES
+#define HPT_BW_FULL_WAVES 3      // every BSDF branch: 74 .. 98 VGPRs spilled at 4 waves per SIMD
+#endif
+#define HPT_BW_WAVES(DR, LEAN) ((DR) ? HPT_BW_DR_WAVES : ((LEAN) ? HPT_BW_FWD_WAVES : HPT_BW_FULL_WAVES))
+template <bool DR, bool LEAN, bool DEEP, bool FLAT, bool WIDE = false>   // WIDE: walk DevScene::nodes4 (heavy single-level scenes)
+__global__ void __launch_bounds__(256, HPT_BW_WAVES(DR, LEAN)) pathTraceBlockKernel(const DevScene S, const Job job, uint refillBelow, uint nodeMin);
+
 // ---- wavefront schedule (hpt_wavefront.hip) --------------------------------------------------------------------------------------------
 static const uint WF_RANGES = 64u;                   // the trace kernel pulls rays from this many ranges of the queue (work stealing)
 static const uint WF_CTR_WORDS = 32u * (1u + WF_RANGES);

@@ -24,6 +24,7 @@
 #include "bvh_build.h"
 #include "hpt_lbvh.h"
 
+static const float BLOCK_SAH_VISITS = 8.0f;                     // automatic schedule: from this many expected inner-node visits per ray the megakernel repacks rays block-locally (hpt_block.hip)
 static const uint MAX_STACK = 64;                           // traversal stack entries per lane: LDS_STACK in LDS + the rest in an HBM overflow buffer
 // Static scenes with at most this many INSTANCED triangles get the single-level world-space BVH (48 B + ~32 B of nodes per triangle:
 // 32 M triangles = 2.6 GB of the 288 GB); beyond it (heavy instancing) the two-level TLAS/BLAS layout is kept.
@@ -153,7 +154,9 @@ struct hpt_ctx
   bool forceFull = false;                // diagnostic (hpt_set_option "force_full_materials")
   bool drSkipNonFinite = false;          // hpt_set_option "dr_skip_nonfinite": off = PixelLossPT as the reference has it
   bool leanMaterials = false;            // every material is gltf or emissive: the kernels without the other BSDF branches are used
-  int  schedule = 0;                     // 0 automatic, 1 megakernel, 2 wavefront (hpt_set_schedule)
+  int  schedule = 0;                     // 0 automatic, 1 megakernel, 2 wavefront, 3 megakernel with block-local ray repacking (hpt_set_schedule)
+  uint bwRefillBelow = 48, bwNodeMin = 4;   // (profiles/bw_sweep.py: test_228 class, refill 32 .. 64 x vote 0 / 4 / 8 / 16)
+  uint bwUnused = 0;   // hpt_block.hip: a wave refills when fewer lanes hold a ray; its node loop's vote
   int  nodeMinOverride = -1;             // env HPT_NODE_MIN (tuning): overrides the per-scene choice of DevScene::nodeMin
   uint wfRefillBelow = 56;               // a trace wave refills from the queue when fewer lanes than this still hold a ray
   int  wfBlocksPerCU = 0;
@@ -1504,6 +1507,15 @@ static void launchPT(const DevScene& S, const Job& job, int blocks, hipStream_t 
   }
 }
 
+template <bool DR, bool LEAN>
+static void launchBlock(const DevScene& S, const Job& job, int blocks, hipStream_t st, bool deep, uint refillBelow, uint nodeMin, bool wide = false)
+{
+  const dim3 g(blocks), b(256);
+  if (wide && LEAN) { if (deep) pathTraceBlockKernel<DR, true, true, true, true><<<g, b, 0, st>>>(S, job, refillBelow, nodeMin); else pathTraceBlockKernel<DR, true, false, true, true><<<g, b, 0, st>>>(S, job, refillBelow, nodeMin); }
+  else if (S.flatMode) { if (deep) pathTraceBlockKernel<DR, LEAN, true, true><<<g, b, 0, st>>>(S, job, refillBelow, nodeMin); else pathTraceBlockKernel<DR, LEAN, false, true><<<g, b, 0, st>>>(S, job, refillBelow, nodeMin); }
+  else            { if (deep) pathTraceBlockKernel<DR, LEAN, true, false><<<g, b, 0, st>>>(S, job, refillBelow, nodeMin); else pathTraceBlockKernel<DR, LEAN, false, false><<<g, b, 0, st>>>(S, job, refillBelow, nodeMin); }
+}
+
 template <int WIDE>
 static void launchSpectral(const DevScene& S, const Job& job, int blocks, hipStream_t st, bool deep)
 {
@@ -1629,7 +1641,24 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   job.stackOverflow = c->dStackOvf.p; job.gridLanes = (uint)blocks * 256u;
   HIPCHK(c, hipEventRecord(c->ev0, st));
   const bool deep = megaStackNeeded(c) > (uint)LDS_STACK;
-  if (motion && film) {
+  // schedule 3: the megakernel with block-local ray repacking (hpt_block.hip) - PathTrace and PathTraceDR on the BVH2 of either layout
+  // automatic: gltf / emissive scenes (and PathTraceDR) whose rays walk a real tree - the test_228 class (SAH estimate 10: 696 -> 735 Mpaths/s at 1024^2,
+  // 527 -> 630 at 512^2, PathTraceDR 428 -> 453) and heavy scenes in calls too small for the wavefront schedule (1 M triangles at 640 x 360: 145 -> 160);
+  // the light fixtures with every BSDF branch stay on the plain megakernel (typed_materials, estimate 4.8: 1186 vs 1133) - profiles/bw_check.py, bw_heavy.py
+  const bool bwLean = dr || (c->leanMaterials && !c->forceFull && c->S.lensCount == 0u);
+  const bool bwAuto = c->schedule == 0 && bwLean && c->sahVisits >= BLOCK_SAH_VISITS;
+  const bool blockLocal = (c->schedule == 3 || bwAuto) && !naive && !inRays && !motion && !film && !stats && c->S.sweep == 0u;
+  if (blockLocal) {
+    const bool lean = dr || (c->leanMaterials && !c->forceFull && c->S.lensCount == 0u);
+    const bool bwide = lean && c->S.megaWide != 0u && c->S.flatMode != 0u && c->nodes4Count != 0u;      // heavy scenes: the 4-wide compressed tree, as the megakernel walks it
+    const bool bdeep = (bwide ? std::max(c->stackNeeded, c->stackNeeded4) : c->stackNeeded) > (uint)LDS_STACK;
+    const uint bNodeMin = bwide ? std::max(c->bwNodeMin, 16u) : c->bwNodeMin;                           // (a 4-wide visit is three times the work: the vote pays earlier)
+    c->lastSchedule = 3; c->lastWide = bwide ? 1u : 0u; c->lastDeep = bdeep ? 1u : 0u;
+    if (dr) launchBlock<true, true>(c->S, job, blocks, st, bdeep, c->bwRefillBelow, bNodeMin, bwide);
+    else if (lean) launchBlock<false, true>(c->S, job, blocks, st, bdeep, c->bwRefillBelow, bNodeMin, bwide);
+    else launchBlock<false, false>(c->S, job, std::min(blocks, c->numCUs * (c->blocksPerCU > 0 ? c->blocksPerCU : HPT_BW_FULL_WAVES)), st, bdeep, c->bwRefillBelow, c->bwNodeMin);
+  }
+  else if (motion && film) {
     if (inRays) launchPTMotion<6>(c->S, job, blocks, st, deep); else if (naive) launchPTMotion<5>(c->S, job, blocks, st, deep); else launchPTMotion<4>(c->S, job, blocks, st, deep);
   }
   else if (motion) {
@@ -1678,7 +1707,7 @@ static const uint   WF_GROUPS_AUTO = 1;            // pixel groups (streams) per
 static bool useWavefront(hpt_ctx* c, bool naive, bool dr, bool stats, uint tidCount)
 {
   if (naive || stats) return false;                // those variants exist as megakernels only
-  if (c->schedule == 1) return false;
+  if (c->schedule == 1 || c->schedule == 3) return false;
   if (c->schedule == 2) return true;
   // ... and only for calls with enough pixels to keep the trace kernel's lanes supplied with replacement rays: measured on the 1M-triangle
   // scene (profiles/share.sh, 2.07 M / 1.04 M / 518 K / 259 K pixels per call): wavefront 226 / 199 / 162 / 108 vs megakernel 171 / 161 / 159 / 146 Mpaths/s
@@ -2183,7 +2212,7 @@ extern "C" int hpt_set_launch_config(hpt_ctx* c, int blocksPerCU) try { if (!c |
 catch (...) { return hptGuard(c, "hpt_set_launch_config"); }
 extern "C" int hpt_set_schedule(hpt_ctx* c, int schedule, int refillBelow, int traceBlocksPerCU, int groups)
 try {
-  if (!c || schedule < 0 || schedule > 2 || refillBelow < 0 || refillBelow > 64 || traceBlocksPerCU < 0 || traceBlocksPerCU > 8 || groups < 0 || groups > 64) return HPT_ERR_ARG;
+  if (!c || schedule < 0 || schedule > 3 || refillBelow < 0 || refillBelow > 64 || traceBlocksPerCU < 0 || traceBlocksPerCU > 8 || groups < 0 || groups > 64) return HPT_ERR_ARG;
   c->wfGroupCount = groups;
   c->schedule = schedule;
   if (refillBelow > 0) c->wfRefillBelow = (uint)refillBelow;
@@ -2204,6 +2233,8 @@ try {
   else if (k == "shade_records") c->shadeTrisEnabled = value != 0;                     // 0: no DevScene::shadeTris (A/B, diagnosis)
   else if (k == "build_threads") c->buildThreads = std::min(value, 64);                // host threads CommitScene builds its trees with (0: the usable cores, at most 16)
   else if (k == "stats_wide") c->statsWide = value != 0;
+  else if (k == "bw_refill_below") { if (value < 1 || value > 64) return c->fail(HPT_ERR_ARG, "bw_refill_below: 1..64"); c->bwRefillBelow = (uint)value; }
+  else if (k == "bw_node_min") { if (value < 0 || value > 64) return c->fail(HPT_ERR_ARG, "bw_node_min: 0..64"); c->bwNodeMin = (uint)value; }
   else if (k == "device_build") { if (value < -1 || value > 1) return c->fail(HPT_ERR_ARG, "device_build: -1 by CommitScene's options, 0 never, 1 always"); c->deviceBuild = value; c->accelCommitted = false; c->flatRefittable = false; }
   else if (k == "wide_nodes") { c->wideEnabled = value != 0; c->S.megaWide = (c->wideEnabled && c->nodes4Count != 0u && c->S.flatMode != 0u && c->sahVisits >= HEAVY_SAH_VISITS) ? 1u : 0u; }   // both users of the tree, at once                             // 0: the wavefront trace kernel walks the BVH2 instead of the 4-wide compressed tree (A/B, diagnosis)
   else if (k == "force_full_materials") c->forceFull = value != 0;                     // diagnostic: never pick the lean (gltf + emissive) kernels

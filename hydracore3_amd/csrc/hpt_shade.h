@@ -515,7 +515,7 @@ HPT_DEV void drClearShadowTerm(float* record, size_t s, size_t idx, uint bounce)
 static const uint DR_STAGE_DWORDS = 16u * 64u;
 HPT_DEV void drReverseSweep(const DevScene& S, const float* record, size_t s, size_t idx, const bool closing, const uint bounceIn, V3 Rn, const V3 diff,
                             float* grad, const bool skipNonFinite, uint* stage, const DrRec& last, const bool lastInRegs,
-                            unsigned long long* statAtomics = nullptr)
+                            unsigned long long* statAtomics = nullptr, const uint ss = 64u)      // ss: dwords between the staging area's rows (64: an area of its own; 256: the wave's columns of a [16][256] array)
 {
   const uint bounce = closing ? bounceIn : 0u;
   const uint lane = lane_id();
@@ -546,11 +546,11 @@ HPT_DEV void drReverseSweep(const DevScene& S, const float* record, size_t s, si
         const float w[4] = { fx1 * fy1, fx * fy1, fx1 * fy, fx * fy };      // bilinearTaps' weights, the same products
         float* sv = (float*)stage;
         for (int k = 0; k < 4; k++) {
-          sv[(3 * k + 0) * 64 + rk] = four ? g.x * w[k] : (g.x + g.y + g.z) * w[k];
-          sv[(3 * k + 1) * 64 + rk] = g.y * w[k];
-          sv[(3 * k + 2) * 64 + rk] = g.z * w[k];
+          sv[(3 * k + 0) * ss + rk] = four ? g.x * w[k] : (g.x + g.y + g.z) * w[k];
+          sv[(3 * k + 1) * ss + rk] = g.y * w[k];
+          sv[(3 * k + 2) * ss + rk] = g.z * w[k];
         }
-        stage[12 * 64 + rk] = e0; stage[13 * 64 + rk] = (uint)dx; stage[14 * 64 + rk] = (uint)dy;
+        stage[12 * ss + rk] = e0; stage[13 * ss + rk] = (uint)dx; stage[14 * ss + rk] = (uint)dy;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -558,9 +558,9 @@ HPT_DEV void drReverseSweep(const DevScene& S, const float* record, size_t s, si
       for (uint p = lane; p < 12u * n; p += 64u) {
         const uint src = (p * 0xAAABu) >> 19;                             // p / 12 (p < 768)
         const uint e = p - 12u * src, tap = (e * 11u) >> 5, ch = e - 3u * tap;   // e / 3, e % 3 (e < 12)
-        const uint ix0 = stage[12 * 64 + src];
-        const uint ix = (ix0 & 0x7FFFFFFFu) + ((tap & 1u) ? stage[13 * 64 + src] : 0u) + ((tap & 2u) ? stage[14 * 64 + src] : 0u);   // (two's complement: negative steps wrap back)
-        const float val = ((const float*)stage)[e * 64 + src];
+        const uint ix0 = stage[12 * ss + src];
+        const uint ix = (ix0 & 0x7FFFFFFFu) + ((tap & 1u) ? stage[13 * ss + src] : 0u) + ((tap & 2u) ? stage[14 * ss + src] : 0u);   // (two's complement: negative steps wrap back)
+        const float val = ((const float*)stage)[e * ss + src];
 #ifndef HPT_DR_NO_ATOMICS    // diagnostic build only: how much of PathTraceDR is the gradient scatter?
         if ((ix0 & 0x80000000u) == 0u) atomicAdd(grad + (size_t)ix + ch, val);
         else if (ch == 0u) atomicAdd(grad + (size_t)ix, val);

@@ -26,7 +26,9 @@ def product_kernel(name):
     if workload == "film":
         return "pathTraceKernel<false, false, 4" in name
     if workload.startswith("dr"):                 # bench.py renders the target image with the forward kernel first: not part of a PathTraceDR call
-        return "pathTraceKernel<false, true" in name or ("wfShadeKernel<true" in name) or (workload == "dr_interior" and ("wfTraceKernel" in name or "wfInitKernel" in name))
+        return "pathTraceKernel<false, true" in name or "pathTraceBlockKernel<true" in name or ("wfShadeKernel<true" in name) or (workload == "dr_interior" and ("wfTraceKernel" in name or "wfInitKernel" in name))
+    if "pathTraceBlockKernel" in name:
+        return "pathTraceBlockKernel<false" in name
     if "pathTraceKernel" in name:
         return "<true" not in name
     return "wfTraceKernel" in name or "wfShadeKernel" in name or "wfInitKernel" in name

@@ -210,7 +210,7 @@ def _c4_setup(width=64, height=64, seed=21):
     return sc, tex_id, data, ref
 
 
-@pytest.mark.parametrize("schedule", [1, 2])
+@pytest.mark.parametrize("schedule", [1, 2, 3])
 def test_c4_dr_test228_matches_oracle(schedule):
     """BASELINE.json configs[3] on its own scene: test_228 (8 202 triangles, two spheres in a box) with matGray bound to the 256 x 256 x 4
     differentiable albedo of drmain.cpp:185, lit by the scene's POINT light with an IES profile - the misWeight = 1 branch of
@@ -223,7 +223,7 @@ def test_c4_dr_test228_matches_oracle(schedule):
     if schedule == 2:
         gpu.set_schedule(2, 56, 0, 1)
     else:
-        gpu.set_schedule(1)
+        gpu.set_schedule(schedule)                                         # 1: megakernel, 3: megakernel with block-local ray repacking (hpt_block.hip)
     assert gpu.PutDiffTex2D(tex_id, 256, 256, 4) == (0, 256 * 256 * 4)
     assert cpu.put_diff_tex2d(tex_id, 256, 256, 4)[1:] == (0, 256 * 256 * 4)
     spp = 4
@@ -234,7 +234,7 @@ def test_c4_dr_test228_matches_oracle(schedule):
     assert gpu.last_schedule()[0] == schedule
     err = np.linalg.norm(grad_g - grad_c) / np.linalg.norm(grad_c)
     d = (out_g[..., :3] - out_c[..., :3]) / spp
-    l2 = float(np.sqrt(np.mean(np.sum(d * d, -1))))
+    l2 = float(np.sqrt(np.sum(d * d, -1)).max())                          # the per-pixel bar: the worst pixel, not a mean over the frame
     same = int(np.sum(np.all(gpu.random_gens() == cpu.random_gens(), axis=1)))
     print(f"schedule {schedule}: loss gpu={loss_g:.6f} cpu={loss_c:.6f}; relative gradient error = {err:.3e}; nnz = {np.count_nonzero(grad_c)}; "
           f"L2 = {l2:.2e}; identical generators {same} / {gpu.N}")

@@ -296,6 +296,41 @@ def test_wavefront_schedule_equals_megakernel(scene_name):
     assert np.array_equal(ia, ib)
 
 
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228", "zoo", "interior", "typed_materials"])
+def test_block_local_schedule_equals_megakernel(scene_name):
+    """hpt_set_schedule(3): the megakernel with block-local ray repacking (hpt_block.hip: the block's lanes pool their next closest-hit and shadow
+    rays in LDS and drain the pool together with ray replacement) runs the same arithmetic per path, so frames and generators equal the
+    megakernel's bit for bit - in both acceleration layouts, for every refill threshold and node-loop vote, over tid windows and accumulated
+    calls; scenes it does not hold (the triangle sweep of the Cornell class) fall back to the megakernel; PathTraceDR likewise (loss, frame,
+    gradient within float-atomic reordering)."""
+    from hydracore3_amd.api import HipIntegrator
+    from hydracore3_amd import synth
+    if scene_name == "zoo":
+        sc = synth.material_zoo(96, 64)
+    elif scene_name == "interior":
+        sc = synth.interior_scene(160, 96, objects=24, subdiv=2, tex_size=64)
+    else:
+        sc = load_hydra_xml(scene_path(scene_name), 96, 96)
+    mega = HipIntegrator(sc); mega.set_schedule(1)
+    ref = mega.render(5)
+    for layout, refill, node_min in ((1, 48, 16), (2, 64, 0), (2, 1, 4), (0, 33, 64)):
+        bw = HipIntegrator(sc, accel_layout=layout); bw.set_schedule(3)
+        bw.set_option("bw_refill_below", refill); bw.set_option("bw_node_min", node_min)
+        img = bw.render(5)
+        assert bw.last_launch()["schedule"] == (1 if (scene_name == "test_035" and layout == 0) else 3)       # (the sweep scene under the automatic layout)
+        assert np.array_equal(img, ref), (layout, refill, node_min)
+        assert np.array_equal(bw.random_gens(), mega.random_gens())
+    a, b = HipIntegrator(sc), HipIntegrator(sc)
+    a.set_schedule(1); b.set_schedule(3)
+    ia, ib = np.zeros_like(ref), np.zeros_like(ref)
+    for integ, im in ((a, ia), (b, ib)):
+        integ.PathTraceBlock(1000, 4, im, 2, tid_begin=500)
+        integ.PathTraceBlock(integ.N, 4, im, 3)
+    assert np.array_equal(ia, ib)
+    one = HipIntegrator(sc); one.set_schedule(3)
+    assert np.array_equal(one.render(3, channels=1), HipIntegrator(sc).render(3, channels=1))
+
+
 def test_sample_sharding_seeds_and_sum(cornell):
     """bench.py --scaling weak: rank r seeds its generators as threads r*N.. of one big InitRandomGens call. The seeding equals
     the oracle's RandomGenInit for those thread ids, a rank's frame equals the oracle run from the same generator states, and the
@@ -1096,23 +1131,27 @@ def test_motion_blur_matches_oracle():
 
 def test_automatic_schedule_follows_the_sah_estimate():
     """The automatic schedule is decided from the committed BVH (hpt_get_accel_info: the surface-area estimate of inner-node visits per ray),
-    not from the triangle count: the reference's 8 202-triangle test_228 (estimate ~10) stays on the megakernel, the 4 850-triangle
-    interior (estimate ~30) goes to the wavefront schedule once the call has 2^19 pixels; either way the frame is the same."""
+    not from the triangle count: the 36-triangle Cornell box is swept by the plain megakernel (1), the reference's 8 202-triangle test_228
+    (estimate ~10: a real tree, gltf materials) gets the megakernel with block-local ray repacking (3), the 4 850-triangle interior
+    (estimate ~30) goes to the wavefront schedule (2) once the call has 2^19 pixels and to (3) below that, a light fixture with every BSDF
+    branch (typed_materials, estimate < 8) stays on (1); whichever runs, the frame is the same."""
     from hydracore3_amd.api import HipIntegrator
     from hydracore3_amd import synth
-    cases = [(load_hydra_xml(scene_path("test_035"), 1024, 512), 1, (4.0, 15.0)), (load_hydra_xml(scene_path("test_228"), 1024, 512), 1, (6.0, 16.0)),
-             (synth.interior_scene(1024, 512, subdiv=0, tex_size=64), 2, (24.0, 45.0))]
+    cases = [(load_hydra_xml(scene_path("test_035"), 1024, 512), 1, (4.0, 15.0)), (load_hydra_xml(scene_path("test_228"), 1024, 512), 3, (8.0, 16.0)),
+             (synth.interior_scene(1024, 512, subdiv=0, tex_size=64), 2, (24.0, 45.0)), (load_hydra_xml(scene_path("typed_materials"), 256, 128), 1, (1.0, 8.0))]
     for sc, want, (lo, hi) in cases:
         g = HipIntegrator(sc)
         info = g.accel_info()
         assert lo < info["sah_node_visits"] < hi, info
         a = g.render(1)
         assert g.last_schedule()[0] == want, (info, g.last_schedule())
-        other = HipIntegrator(sc); other.set_schedule(3 - want)
-        assert np.array_equal(other.render(1), a)
-    small = HipIntegrator(synth.interior_scene(640, 360, subdiv=0, tex_size=64))          # fewer than 2^19 pixels: megakernel even when heavy
+        for sched in (1, 2, 3):
+            if sched != want:
+                other = HipIntegrator(sc); other.set_schedule(sched)
+                assert np.array_equal(other.render(1), a), sched
+    small = HipIntegrator(synth.interior_scene(640, 360, subdiv=0, tex_size=64))          # fewer than 2^19 pixels: too few rays for the chip-wide queue - repacked per block
     small.render(1)
-    assert small.last_schedule()[0] == 1
+    assert small.last_schedule()[0] == 3 and small.last_launch()["wide_nodes"]
 
 
 def test_cam_plugin_driver_loop_matches_the_camera_path(tmp_path):

@@ -70,6 +70,9 @@ __global__ void HPT_PT_BOUNDS(DR, MODE) pathTraceKernel(const DevScene S, const 
 template <bool DEEP, bool FLAT, bool SWEEP, bool MOTION, int SCOPE>   // SCOPE 0: the reference's spectral fixtures' needs; 1: + gltf; 2: + glass / blends / normal maps / environment maps / lens; 3: the same at 4 waves per SIMD
 __global__ void __launch_bounds__(256, SCOPE == 2 ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAVES) pathTraceSpectralKernel(const DevScene S, const Job job);
 
+template <bool DEEP, bool FLAT, bool WIDE, int SCOPE>   // the same integrator under the block-local schedule (work queue, LDS ray pool, ray replacement; hpt_spectral.hip)
+__global__ void __launch_bounds__(256, SCOPE == 2 ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAVES) pathTraceBlockSpectralKernel(const DevScene S, const Job job, uint refillBelow, uint nodeMin);
+
 // ---- megakernel with block-local ray repacking (hpt_block.hip) --------------------------------------------------------------------------
 #ifndef HPT_BW_FWD_WAVES
 #define HPT_BW_FWD_WAVES 4

@@ -1529,6 +1529,15 @@ static void launchSpectral(const DevScene& S, const Job& job, int blocks, hipStr
   else                  { if (deep) pathTraceSpectralKernel<true, false, false, false, WIDE><<<sg, sb, 0, st>>>(S, job); else pathTraceSpectralKernel<false, false, false, false, WIDE><<<sg, sb, 0, st>>>(S, job); }
 }
 
+template <int SCOPE>
+static void launchSpectralBlock(const DevScene& S, const Job& job, int blocks, hipStream_t st, bool deep, bool wide, uint refillBelow, uint nodeMin)
+{
+  const dim3 g(blocks), b(256);
+  if (wide)            { if (deep) pathTraceBlockSpectralKernel<true, true, true, SCOPE><<<g, b, 0, st>>>(S, job, refillBelow, nodeMin); else pathTraceBlockSpectralKernel<false, true, true, SCOPE><<<g, b, 0, st>>>(S, job, refillBelow, nodeMin); }
+  else if (S.flatMode) { if (deep) pathTraceBlockSpectralKernel<true, true, false, SCOPE><<<g, b, 0, st>>>(S, job, refillBelow, nodeMin); else pathTraceBlockSpectralKernel<false, true, false, SCOPE><<<g, b, 0, st>>>(S, job, refillBelow, nodeMin); }
+  else                 { if (deep) pathTraceBlockSpectralKernel<true, false, false, SCOPE><<<g, b, 0, st>>>(S, job, refillBelow, nodeMin); else pathTraceBlockSpectralKernel<false, false, false, SCOPE><<<g, b, 0, st>>>(S, job, refillBelow, nodeMin); }
+}
+
 // the MOTION variants: moving instances (two-level layout only), every BSDF branch
 template <int MODE>
 static void launchPTMotion(const DevScene& S, const Job& job, int blocks, hipStream_t st, bool deep)
@@ -1591,18 +1600,45 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
     if (inRays && job.channels != 1u && job.channels != 4u) return c->fail(HPT_ERR_ARG, "PathTraceFromInputRays in spectral mode: 1 or 4 channels (kernel_CopyColorToOutput)");
     job.naive = naive ? 1u : 0u;
     if (c->hasFilm && !c->filmTablesSpectral) return c->fail(HPT_ERR_ARG, "thin film: m_precomp_thin_films was precomputed for RGB rendering (LoadScene sizes the tables by m_spectral_mode)");
-    const int sblocks = (int)(((size_t)job.tidCount + 255) / 256);
     job.gens = c->dGens.p; job.packedXY = c->dPackedXY.p; job.packedCount = c->packedCount;
-    HIPCHK(c, ensureStackOverflow(c, (size_t)sblocks * 256));
-    job.stackOverflow = c->dStackOvf.p; job.gridLanes = (uint)sblocks * 256u;
-    const bool sdeep = megaStackNeeded(c) > (uint)LDS_STACK;
-    c->lastSchedule = 1;
-    HIPCHK(c, hipEventRecord(c->ev0, st));
     // the scope the scene needs (hpt_spectral.hip: SCOPE): the narrowest instantiations that hold it
     bool heavy = c->S.lensCount != 0u || c->S.envTexId != 0xFFFFFFFFu || c->S.envCamBackId != 0xFFFFFFFFu || c->spectralHeavyMats;
     for (const uint g : c->hLightGeom) heavy = heavy || g == LIGHT_GEOM_ENV;
-    if (heavy && c->fewMaterialTypes) launchSpectral<3>(c->S, job, sblocks, st, sdeep);
-    else if (heavy) launchSpectral<2>(c->S, job, sblocks, st, sdeep); else if (c->spectralGltfMats) launchSpectral<1>(c->S, job, sblocks, st, sdeep); else launchSpectral<0>(c->S, job, sblocks, st, sdeep);
+    const int scope = (heavy && c->fewMaterialTypes) ? 3 : (heavy ? 2 : (c->spectralGltfMats ? 1 : 0));
+    // Schedule: scenes whose rays walk a real tree (SAH estimate >= 8: the reference's spectral fixture, interiors) run the block-local kernel -
+    // persistent blocks on the work queue, rays repacked per block, the 4-wide tree on heavy scenes; the others, input-ray batches, moving
+    // instances and sweep scenes keep the one-thread-per-pixel kernel. hpt_set_schedule(1) / (3) force either.
+    const bool specBlock = !inRays && c->S.motion == 0u && c->S.sweep == 0u && (c->S.traceDepth > 0u || naive) &&
+                           (c->schedule == 3 || (c->schedule == 0 && c->sahVisits >= BLOCK_SAH_VISITS));
+    if (specBlock) {
+      const bool bwide = c->S.megaWide != 0u && c->S.flatMode != 0u && c->nodes4Count != 0u;
+      const bool bdeep = (bwide ? std::max(c->stackNeeded, c->stackNeeded4) : c->stackNeeded) > (uint)LDS_STACK;
+      const int bpc = c->blocksPerCU > 0 ? c->blocksPerCU : (scope == 2 ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAVES);
+      const int blocks = (int)std::min<size_t>((size_t)c->numCUs * bpc, ((size_t)job.tidCount + 255) / 256);
+      HIPCHK(c, c->dQueue.alloc(1));
+      HIPCHK(c, hipMemsetAsync(c->dQueue.p, 0, 4, st));
+      job.queue = c->dQueue.p;
+      HIPCHK(c, ensureStackOverflow(c, (size_t)blocks * 256));
+      job.stackOverflow = c->dStackOvf.p; job.gridLanes = (uint)blocks * 256u;
+      const uint bNodeMin = bwide ? std::max(c->bwNodeMin, 16u) : c->bwNodeMin;
+      c->lastSchedule = 3; c->lastWide = bwide ? 1u : 0u; c->lastDeep = bdeep ? 1u : 0u; c->lastShadeRecords = 0u;
+      HIPCHK(c, hipEventRecord(c->ev0, st));
+      if (scope == 3) launchSpectralBlock<3>(c->S, job, blocks, st, bdeep, bwide, c->bwRefillBelow, bNodeMin);
+      else if (scope == 2) launchSpectralBlock<2>(c->S, job, blocks, st, bdeep, bwide, c->bwRefillBelow, bNodeMin);
+      else if (scope == 1) launchSpectralBlock<1>(c->S, job, blocks, st, bdeep, bwide, c->bwRefillBelow, bNodeMin);
+      else launchSpectralBlock<0>(c->S, job, blocks, st, bdeep, bwide, c->bwRefillBelow, bNodeMin);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipEventRecord(c->ev1, st));
+      return HPT_OK;
+    }
+    const int sblocks = (int)(((size_t)job.tidCount + 255) / 256);
+    HIPCHK(c, ensureStackOverflow(c, (size_t)sblocks * 256));
+    job.stackOverflow = c->dStackOvf.p; job.gridLanes = (uint)sblocks * 256u;
+    const bool sdeep = megaStackNeeded(c) > (uint)LDS_STACK;
+    c->lastSchedule = 1; c->lastWide = (c->S.megaWide != 0u && c->S.flatMode != 0u && c->nodes4Count != 0u && c->S.motion == 0u) ? 1u : 0u; c->lastDeep = sdeep ? 1u : 0u; c->lastShadeRecords = 0u;
+    HIPCHK(c, hipEventRecord(c->ev0, st));
+    if (scope == 3) launchSpectral<3>(c->S, job, sblocks, st, sdeep);
+    else if (scope == 2) launchSpectral<2>(c->S, job, sblocks, st, sdeep); else if (scope == 1) launchSpectral<1>(c->S, job, sblocks, st, sdeep); else launchSpectral<0>(c->S, job, sblocks, st, sdeep);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, st));
     return HPT_OK;

@@ -17,6 +17,7 @@
 // output is the reference's stack of wavelength layers.
 #include <hip/hip_runtime.h>
 #include "hpt_decl.h"
+#include "hpt_block_trace.h"
 #ifndef HPT_SPEC_FILM
 #define HPT_SPEC_FILM 1      // 0: an A/B build without the thin-film branches (what they cost the scenes that have none)
 #endif
@@ -360,6 +361,145 @@ HPT_DEV SpecSample materialSampleSpec(const DevScene& S, const MaterialRec& m, V
   return r;
 }
 
+// One path vertex of the spectral integrator: kernel_GetRayColor's surface fetch + kernel_SampleLightSource + kernel_NextBounce on four wavelengths
+// (integrator_pt.cpp:238-548 with m_spectral_mode != 0), shared by the one-thread-per-pixel kernel below and by the block-local schedule
+// (pathTraceBlockSpectralKernel). As shadeVertex for the RGB kernels: the light sample's BSDF is evaluated before the shadow ray is traced,
+// the caller traces it (wantShadow) and adds `contrib` when it comes back unoccluded. A miss only sets the OUT_OF_SCENE flags.
+template <int SCOPE, bool MOTION>
+HPT_DEV void shadeVertexSpec(const DevScene& S, const HitRec& hit, V3& rpos, V3& rdir, const V4 waves, V4& accum, V4& thr, float& misPdf, float& misIor, uint& flags,
+                             const uint bounce, Rng& gen, const bool naive, bool& wantShadow, V3& shPos, V3& shDir, float& shFar, V4& contrib, const float pathTime)
+{
+  if (hit.inst == 0xFFFFFFFFu) {
+    flags |= (bounce == 0) ? (RAY_FLAG_PRIME_RAY_MISS | RAY_FLAG_IS_DEAD | RAY_FLAG_OUT_OF_SCENE) : (RAY_FLAG_IS_DEAD | RAY_FLAG_OUT_OF_SCENE);
+  } else {
+    // -- surface attributes (integrator_pt.cpp:238-311), as in shadeVertex --
+    const uint instId = hit.inst;
+    const uint geomId = S.insts[instId].geomId;
+    const uint triOffset = S.matVertOffset[2 * geomId + 0], vertOffset = S.matVertOffset[2 * geomId + 1];
+    const V3 hitPos = rpos + hit.t * (1.f - 1e-6f) * rdir;
+    const float uvx = hit.v, uvy = hit.u;
+    const uint A = S.triIndices[(triOffset + hit.prim) * 3 + 0], B = S.triIndices[(triOffset + hit.prim) * 3 + 1], C = S.triIndices[(triOffset + hit.prim) * 3 + 2];
+    const float4 nA = ((const float4*)S.vData8f)[2 * (A + vertOffset)], nB = ((const float4*)S.vData8f)[2 * (B + vertOffset)], nC = ((const float4*)S.vData8f)[2 * (C + vertOffset)];
+    const float tyA = S.vData8f[8 * (A + vertOffset) + 7], tyB = S.vData8f[8 * (B + vertOffset) + 7], tyC = S.vData8f[8 * (C + vertOffset) + 7];
+    const float wA = 1.0f - uvx - uvy;
+    const V3 nrmO = v3(wA * nA.x + uvy * nB.x + uvx * nC.x, wA * nA.y + uvy * nB.y + uvx * nC.y, wA * nA.z + uvy * nB.z + uvx * nC.z);
+    const V2 uv = v2(wA * nA.w + uvy * nB.w + uvx * nC.w, wA * tyA + uvy * tyB + uvx * tyC);
+    const float* nm = S.normMat + 12 * instId;
+    V3 hitNorm = v3(nm[0] * nrmO.x + nm[1] * nrmO.y + nm[2] * nrmO.z, nm[4] * nrmO.x + nm[5] * nrmO.y + nm[6] * nrmO.z, nm[8] * nrmO.x + nm[9] * nrmO.y + nm[10] * nrmO.z);
+    if (MOTION && (S.motion & 2u) == 0u) {                             // integrator_pt.cpp:285-292, as in shadeVertex
+      const float* nm2 = S.normMat2 + 12 * instId;
+      const V3 n2 = v3(nm2[0] * hitNorm.x + nm2[1] * hitNorm.y + nm2[2] * hitNorm.z, nm2[4] * hitNorm.x + nm2[5] * hitNorm.y + nm2[6] * hitNorm.z, nm2[8] * hitNorm.x + nm2[9] * hitNorm.y + nm2[10] * hitNorm.z);
+      hitNorm = hitNorm + pathTime * (n2 - hitNorm);
+    }
+    hitNorm = normalize(hitNorm);
+    const float flipNorm = dot(rdir, hitNorm) > 0.001f ? -1.0f : 1.0f;
+    hitNorm = flipNorm * hitNorm;
+    if (flipNorm < 0.0f) flags |= RAY_FLAG_HAS_INV_NORMAL; else flags &= ~RAY_FLAG_HAS_INV_NORMAL;
+    const uint matId = remapMaterialId(S, S.matIdByPrimId[triOffset + hit.prim], instId) & 0x00FFFFFFu;
+    const MaterialRec& m = S.materials[matId];
+    const uint mtype = m.mtype;
+    const V3 vdir = (-1.0f) * rdir;
+    V4 texColor = v4(1, 1, 1, 1);
+    if (mtype != MAT_TYPE_LIGHT_SOURCE) texColor = texSample(S.textures, m.texid[0], mulRows2x4(m.row0[0], m.row1[0], uv));
+    V3 hitTang = v3(0, 0, 0);                                          // only materials with a normal map (or a blend that may hold one) read it
+    if (SCOPE >= 2 && (mtype == MAT_TYPE_BLEND || (mtype != MAT_TYPE_LIGHT_SOURCE && m.texid[1] != 0xFFFFFFFFu))) hitTang = hitTangent(S, A, B, C, vertOffset, wA, uvx, uvy, nm, flipNorm, (MOTION && (S.motion & 2u) == 0u) ? S.normMat2 + 12 * instId : nullptr, pathTime);
+
+    // -- kernel_SampleLightSource (integrator_pt.cpp:350-424) --
+    V4 shade = v4s(0.0f);
+    if (!naive) {
+      const float rndId = rng_float1(gen);
+      const V4 r4 = rng_float4(gen);
+      const int nLights = (int)S.numLights;
+      const int lightId = min((int)floorf(rndId * float(nLights)), nLights - 1);
+      if (lightId >= 0 && mtype != MAT_TYPE_LIGHT_SOURCE) {
+        const LightRec& L = S.lights[lightId];
+        const LightSam ls = (SCOPE >= 2 && L.geomType == LIGHT_GEOM_ENV) ? envLightSampleRev(S, L, v3(r4.x, r4.y, r4.z), hitPos) : lightSampleRev(L, v3(r4.x, r4.y, r4.z), hitPos);
+        const V3 dlt = hitPos - ls.pos;
+        const float hitDist = sqrtf_(dot(dlt, dlt));
+        const V3 shadowRayDir = normalize(ls.pos - hitPos);
+        const V3 shadowRayPos = hitPos + hitNorm * smax(maxcomp(hitPos), 1.0f) * 5e-6f;
+        const bool inIllumArea = (dot(shadowRayDir, ls.norm) < 0.0f) || ls.isOmni || ls.hasIES;
+        if (inIllumArea) {
+          const SpecEval bv = SCOPE >= 2 ? materialEvalTreeSpec(S, matId, waves, shadowRayDir, vdir, hitNorm, hitTang, uv) : materialEvalSpec<SCOPE>(S, m, waves, shadowRayDir, vdir, hitNorm, hitNorm, texColor, uv);
+          const float cosThetaOut = smax(dot(shadowRayDir, hitNorm), 0.0f);
+          float lgtPdfW = (1.0f / float(nLights)) * lightEvalPDF(L, shadowRayPos, shadowRayDir, ls.pos, ls.norm, ls.pdf);
+          float misWeight = (S.integratorType == INTEGRATOR_MIS_PT) ? misWeightHeuristic(lgtPdfW, bv.pdf) : 1.0f;
+          if (L.geomType == LIGHT_GEOM_DIRECT) { misWeight = 1.0f; lgtPdfW = 1.0f; }
+          else if (L.geomType == LIGHT_GEOM_POINT) misWeight = 1.0f;
+          const bool isDirectLight = (flags & RAY_FLAG_HAS_NON_SPEC) == 0;
+          if ((S.renderLayer == FB_DIRECT && !isDirectLight) || (S.renderLayer == FB_INDIRECT && isDirectLight)) misWeight = 0.0f;
+          const V4 lightColor = lightIntensitySpec<SCOPE>(S, L, waves, shadowRayPos, shadowRayDir);
+          shade = ((lightColor * bv.val) / lgtPdfW) * cosThetaOut * misWeight;
+          wantShadow = true; shPos = shadowRayPos; shDir = shadowRayDir; shFar = hitDist * 0.9995f;
+        }
+      }
+    }
+    // -- kernel_NextBounce (integrator_pt.cpp:426-548) --
+    if (mtype == MAT_TYPE_LIGHT_SOURCE) {
+      const V4 tc = texSample(S.textures, m.texid[0], mulRows2x4(m.row0[0], m.row1[0], uv));
+      const uint lightId = (uint)S.remapInst[2 * instId + 1];
+      V4 lightInt = ld4(m.colors[0]) * tc;
+      float misWeight = 1.0f;
+      if (lightId != 0xFFFFFFFFu) {
+        const LightRec& L = S.lights[lightId];
+        const float lightCos = dot(rdir, ld3(L.norm));
+        const float atten = (lightCos < 0.0f || L.geomType == LIGHT_GEOM_SPHERE) ? 1.0f : 0.0f;
+        lightInt = lightIntensitySpec<SCOPE>(S, L, waves, rpos, rdir) * atten;
+      }
+      if (S.integratorType == INTEGRATOR_MIS_PT) {
+        if (bounce > 0 && lightId != 0xFFFFFFFFu) {
+          const float lgtPdf = (1.0f / float(S.numLights)) * lightEvalPDF(S.lights[lightId], rpos, rdir, hitPos, hitNorm, 1.0f);
+          misWeight = misWeightHeuristic(misPdf, lgtPdf);
+          if (misPdf <= 0.0f) misWeight = 1.0f;
+        }
+      } else if (S.integratorType == INTEGRATOR_SHADOW_PT && (flags & RAY_FLAG_HAS_NON_SPEC) != 0) misWeight = 0.0f;
+      const bool isDirectLight = (flags & RAY_FLAG_HAS_NON_SPEC) == 0, isFirstNonSpec = (flags & RAY_FLAG_FIRST_NON_SPEC) != 0;
+      if (S.renderLayer == FB_INDIRECT && (isDirectLight || isFirstNonSpec)) misWeight = 0.0f;
+      accum = accum + thr * lightInt * misWeight;
+      flags |= (RAY_FLAG_IS_DEAD | RAY_FLAG_HIT_LIGHT);
+      wantShadow = false;
+    } else {
+      // blend descent (BlendSampleAndEval, integrator_pt_mat.cpp:23-54, 123-130): one generator step per layer BEFORE the float4
+      const MaterialRec* lm = &m; uint lt = mtype; V4 ltexColor = texColor; float pdf0 = 1.0f;
+      if (SCOPE >= 2 && mtype == MAT_TYPE_BLEND) {
+        while (lt == MAT_TYPE_BLEND) {
+          const V4 wd = texSample(S.textures, lm->texid[0], mulRows2x4(lm->row0[0], lm->row1[0], uv));
+          const float weight = lm->data[0] * wd.x;
+          const float select = rng_float1(gen);                        // GetRandomNumbersMatB (integrator_pt.cpp:37)
+          if (select < weight) { pdf0 *= weight; lm = &S.materials[lm->datai[1]]; }
+          else                 { pdf0 *= 1.0f - weight; lm = &S.materials[lm->datai[0]]; }
+          lt = lm->mtype;
+        }
+        ltexColor = texSample(S.textures, lm->texid[0], mulRows2x4(lm->row0[0], lm->row1[0], uv));
+      }
+      const MaterialRec& ml = *lm;
+      const bool leafBump = SCOPE >= 2 && ml.texid[1] != 0xFFFFFFFFu;                // the leaf's normal map bends the shading normal (:131-139)
+      const V3 sNorm = leafBump ? bumpNormal(S, ml, hitNorm, hitTang, uv) : hitNorm;
+      const V4 rands = rng_float4(gen);                                // GetRandomNumbersMats
+      SpecSample ms = materialSampleSpec<SCOPE>(S, ml, waves, rands, vdir, sNorm, hitNorm, ltexColor, (flags & 0xFF000000u) | matId, misIor, uv, pdf0);
+      if (lt == MAT_TYPE_DIELECTRIC || lt == MAT_TYPE_THIN_FILM || lt == MAT_TYPE_GLASS) misIor = ms.ior;
+      if (leafBump) {                                                  // the caller multiplies by the cosine to the geometric normal (:298-303)
+        const float c1 = absf(dot(ms.dir, hitNorm)), c2 = absf(dot(ms.dir, sNorm));
+        ms.val = ms.val * (c2 / smax(c1, 1e-10f));
+      }
+      const float invPdf = 1.0f / smax(ms.pdf, 1e-20f);
+      const V4 bxdfVal = ms.val * invPdf;
+      const float cosTheta = absf(dot(ms.dir, hitNorm));
+      misPdf = (ms.flags & RAY_EVENT_S) != 0 ? -1.0f : ms.pdf;
+      if (S.integratorType == INTEGRATOR_STUPID_PT) { thr = thr * (cosTheta * bxdfVal); wantShadow = false; }
+      else { contrib = thr * shade; thr = thr * cosTheta * bxdfVal; }
+      V3 hp = hitPos;
+      if ((ms.flags & RAY_EVENT_T) != 0) hp = hp + hit.t * rdir * 2.0f * 1e-6f;
+      rpos = offsRayPos(hp, hitNorm, ms.dir);
+      rdir = ms.dir;
+      uint nextFlags = ((flags & ~RAY_FLAG_FIRST_NON_SPEC) | ms.flags);
+      if (S.renderLayer == FB_DIRECT && (flags & RAY_FLAG_HAS_NON_SPEC) != 0) nextFlags |= RAY_FLAG_IS_DEAD;
+      else if ((flags & RAY_FLAG_HAS_NON_SPEC) == 0 && (nextFlags & RAY_FLAG_HAS_NON_SPEC) != 0) nextFlags |= RAY_FLAG_FIRST_NON_SPEC;
+      flags = nextFlags;
+    }
+  }
+}
+
 // One thread per pixel of the call, its passes one after the other (the pixel's generator continues from pass to pass as in the RGB kernels).
 // SCOPE: what the scene needs (the host looks at the materials a hit can reach, the lights, the camera): 0 = what the reference's spectral fixtures
 // use (diffuse, conductor, plastic, dielectric, thin films, analytic lights, a sky spectrum); 1 = + gltf surfaces (legacy hydra_material scenes);
@@ -426,135 +566,7 @@ __global__ void __launch_bounds__(256, SCOPE_ == 2 ? HPT_SPEC_WIDE_WAVES : HPT_S
       V3 shPos = v3(0, 0, 0), shDir = v3(0, 0, 1); float shFar = 0.0f;
       V4 contrib = v4s(0.0f);
       if (alive) {
-        if (hit.inst == 0xFFFFFFFFu) {
-          flags |= (bounce == 0) ? (RAY_FLAG_PRIME_RAY_MISS | RAY_FLAG_IS_DEAD | RAY_FLAG_OUT_OF_SCENE) : (RAY_FLAG_IS_DEAD | RAY_FLAG_OUT_OF_SCENE);
-        } else {
-          // -- surface attributes (integrator_pt.cpp:238-311), as in shadeVertex --
-          const uint instId = hit.inst;
-          const uint geomId = S.insts[instId].geomId;
-          const uint triOffset = S.matVertOffset[2 * geomId + 0], vertOffset = S.matVertOffset[2 * geomId + 1];
-          const V3 hitPos = rpos + hit.t * (1.f - 1e-6f) * rdir;
-          const float uvx = hit.v, uvy = hit.u;
-          const uint A = S.triIndices[(triOffset + hit.prim) * 3 + 0], B = S.triIndices[(triOffset + hit.prim) * 3 + 1], C = S.triIndices[(triOffset + hit.prim) * 3 + 2];
-          const float4 nA = ((const float4*)S.vData8f)[2 * (A + vertOffset)], nB = ((const float4*)S.vData8f)[2 * (B + vertOffset)], nC = ((const float4*)S.vData8f)[2 * (C + vertOffset)];
-          const float tyA = S.vData8f[8 * (A + vertOffset) + 7], tyB = S.vData8f[8 * (B + vertOffset) + 7], tyC = S.vData8f[8 * (C + vertOffset) + 7];
-          const float wA = 1.0f - uvx - uvy;
-          const V3 nrmO = v3(wA * nA.x + uvy * nB.x + uvx * nC.x, wA * nA.y + uvy * nB.y + uvx * nC.y, wA * nA.z + uvy * nB.z + uvx * nC.z);
-          const V2 uv = v2(wA * nA.w + uvy * nB.w + uvx * nC.w, wA * tyA + uvy * tyB + uvx * tyC);
-          const float* nm = S.normMat + 12 * instId;
-          V3 hitNorm = v3(nm[0] * nrmO.x + nm[1] * nrmO.y + nm[2] * nrmO.z, nm[4] * nrmO.x + nm[5] * nrmO.y + nm[6] * nrmO.z, nm[8] * nrmO.x + nm[9] * nrmO.y + nm[10] * nrmO.z);
-          if (MOTION && (S.motion & 2u) == 0u) {                             // integrator_pt.cpp:285-292, as in shadeVertex
-            const float* nm2 = S.normMat2 + 12 * instId;
-            const V3 n2 = v3(nm2[0] * hitNorm.x + nm2[1] * hitNorm.y + nm2[2] * hitNorm.z, nm2[4] * hitNorm.x + nm2[5] * hitNorm.y + nm2[6] * hitNorm.z, nm2[8] * hitNorm.x + nm2[9] * hitNorm.y + nm2[10] * hitNorm.z);
-            hitNorm = hitNorm + pathTime * (n2 - hitNorm);
-          }
-          hitNorm = normalize(hitNorm);
-          const float flipNorm = dot(rdir, hitNorm) > 0.001f ? -1.0f : 1.0f;
-          hitNorm = flipNorm * hitNorm;
-          if (flipNorm < 0.0f) flags |= RAY_FLAG_HAS_INV_NORMAL; else flags &= ~RAY_FLAG_HAS_INV_NORMAL;
-          const uint matId = remapMaterialId(S, S.matIdByPrimId[triOffset + hit.prim], instId) & 0x00FFFFFFu;
-          const MaterialRec& m = S.materials[matId];
-          const uint mtype = m.mtype;
-          const V3 vdir = (-1.0f) * rdir;
-          V4 texColor = v4(1, 1, 1, 1);
-          if (mtype != MAT_TYPE_LIGHT_SOURCE) texColor = texSample(S.textures, m.texid[0], mulRows2x4(m.row0[0], m.row1[0], uv));
-          V3 hitTang = v3(0, 0, 0);                                          // only materials with a normal map (or a blend that may hold one) read it
-          if (SCOPE >= 2 && (mtype == MAT_TYPE_BLEND || (mtype != MAT_TYPE_LIGHT_SOURCE && m.texid[1] != 0xFFFFFFFFu))) hitTang = hitTangent(S, A, B, C, vertOffset, wA, uvx, uvy, nm, flipNorm, (MOTION && (S.motion & 2u) == 0u) ? S.normMat2 + 12 * instId : nullptr, pathTime);
-
-          // -- kernel_SampleLightSource (integrator_pt.cpp:350-424) --
-          V4 shade = v4s(0.0f);
-          if (!naive) {
-            const float rndId = rng_float1(gen);
-            const V4 r4 = rng_float4(gen);
-            const int nLights = (int)S.numLights;
-            const int lightId = min((int)floorf(rndId * float(nLights)), nLights - 1);
-            if (lightId >= 0 && mtype != MAT_TYPE_LIGHT_SOURCE) {
-              const LightRec& L = S.lights[lightId];
-              const LightSam ls = (SCOPE >= 2 && L.geomType == LIGHT_GEOM_ENV) ? envLightSampleRev(S, L, v3(r4.x, r4.y, r4.z), hitPos) : lightSampleRev(L, v3(r4.x, r4.y, r4.z), hitPos);
-              const V3 dlt = hitPos - ls.pos;
-              const float hitDist = sqrtf_(dot(dlt, dlt));
-              const V3 shadowRayDir = normalize(ls.pos - hitPos);
-              const V3 shadowRayPos = hitPos + hitNorm * smax(maxcomp(hitPos), 1.0f) * 5e-6f;
-              const bool inIllumArea = (dot(shadowRayDir, ls.norm) < 0.0f) || ls.isOmni || ls.hasIES;
-              if (inIllumArea) {
-                const SpecEval bv = SCOPE >= 2 ? materialEvalTreeSpec(S, matId, waves, shadowRayDir, vdir, hitNorm, hitTang, uv) : materialEvalSpec<SCOPE>(S, m, waves, shadowRayDir, vdir, hitNorm, hitNorm, texColor, uv);
-                const float cosThetaOut = smax(dot(shadowRayDir, hitNorm), 0.0f);
-                float lgtPdfW = (1.0f / float(nLights)) * lightEvalPDF(L, shadowRayPos, shadowRayDir, ls.pos, ls.norm, ls.pdf);
-                float misWeight = (S.integratorType == INTEGRATOR_MIS_PT) ? misWeightHeuristic(lgtPdfW, bv.pdf) : 1.0f;
-                if (L.geomType == LIGHT_GEOM_DIRECT) { misWeight = 1.0f; lgtPdfW = 1.0f; }
-                else if (L.geomType == LIGHT_GEOM_POINT) misWeight = 1.0f;
-                const bool isDirectLight = (flags & RAY_FLAG_HAS_NON_SPEC) == 0;
-                if ((S.renderLayer == FB_DIRECT && !isDirectLight) || (S.renderLayer == FB_INDIRECT && isDirectLight)) misWeight = 0.0f;
-                const V4 lightColor = lightIntensitySpec<SCOPE>(S, L, waves, shadowRayPos, shadowRayDir);
-                shade = ((lightColor * bv.val) / lgtPdfW) * cosThetaOut * misWeight;
-                wantShadow = true; shPos = shadowRayPos; shDir = shadowRayDir; shFar = hitDist * 0.9995f;
-              }
-            }
-          }
-          // -- kernel_NextBounce (integrator_pt.cpp:426-548) --
-          if (mtype == MAT_TYPE_LIGHT_SOURCE) {
-            const V4 tc = texSample(S.textures, m.texid[0], mulRows2x4(m.row0[0], m.row1[0], uv));
-            const uint lightId = (uint)S.remapInst[2 * instId + 1];
-            V4 lightInt = ld4(m.colors[0]) * tc;
-            float misWeight = 1.0f;
-            if (lightId != 0xFFFFFFFFu) {
-              const LightRec& L = S.lights[lightId];
-              const float lightCos = dot(rdir, ld3(L.norm));
-              const float atten = (lightCos < 0.0f || L.geomType == LIGHT_GEOM_SPHERE) ? 1.0f : 0.0f;
-              lightInt = lightIntensitySpec<SCOPE>(S, L, waves, rpos, rdir) * atten;
-            }
-            if (S.integratorType == INTEGRATOR_MIS_PT) {
-              if (bounce > 0 && lightId != 0xFFFFFFFFu) {
-                const float lgtPdf = (1.0f / float(S.numLights)) * lightEvalPDF(S.lights[lightId], rpos, rdir, hitPos, hitNorm, 1.0f);
-                misWeight = misWeightHeuristic(misPdf, lgtPdf);
-                if (misPdf <= 0.0f) misWeight = 1.0f;
-              }
-            } else if (S.integratorType == INTEGRATOR_SHADOW_PT && (flags & RAY_FLAG_HAS_NON_SPEC) != 0) misWeight = 0.0f;
-            const bool isDirectLight = (flags & RAY_FLAG_HAS_NON_SPEC) == 0, isFirstNonSpec = (flags & RAY_FLAG_FIRST_NON_SPEC) != 0;
-            if (S.renderLayer == FB_INDIRECT && (isDirectLight || isFirstNonSpec)) misWeight = 0.0f;
-            accum = accum + thr * lightInt * misWeight;
-            flags |= (RAY_FLAG_IS_DEAD | RAY_FLAG_HIT_LIGHT);
-            wantShadow = false;
-          } else {
-            // blend descent (BlendSampleAndEval, integrator_pt_mat.cpp:23-54, 123-130): one generator step per layer BEFORE the float4
-            const MaterialRec* lm = &m; uint lt = mtype; V4 ltexColor = texColor; float pdf0 = 1.0f;
-            if (SCOPE >= 2 && mtype == MAT_TYPE_BLEND) {
-              while (lt == MAT_TYPE_BLEND) {
-                const V4 wd = texSample(S.textures, lm->texid[0], mulRows2x4(lm->row0[0], lm->row1[0], uv));
-                const float weight = lm->data[0] * wd.x;
-                const float select = rng_float1(gen);                        // GetRandomNumbersMatB (integrator_pt.cpp:37)
-                if (select < weight) { pdf0 *= weight; lm = &S.materials[lm->datai[1]]; }
-                else                 { pdf0 *= 1.0f - weight; lm = &S.materials[lm->datai[0]]; }
-                lt = lm->mtype;
-              }
-              ltexColor = texSample(S.textures, lm->texid[0], mulRows2x4(lm->row0[0], lm->row1[0], uv));
-            }
-            const MaterialRec& ml = *lm;
-            const bool leafBump = SCOPE >= 2 && ml.texid[1] != 0xFFFFFFFFu;                // the leaf's normal map bends the shading normal (:131-139)
-            const V3 sNorm = leafBump ? bumpNormal(S, ml, hitNorm, hitTang, uv) : hitNorm;
-            const V4 rands = rng_float4(gen);                                // GetRandomNumbersMats
-            SpecSample ms = materialSampleSpec<SCOPE>(S, ml, waves, rands, vdir, sNorm, hitNorm, ltexColor, (flags & 0xFF000000u) | matId, misIor, uv, pdf0);
-            if (lt == MAT_TYPE_DIELECTRIC || lt == MAT_TYPE_THIN_FILM || lt == MAT_TYPE_GLASS) misIor = ms.ior;
-            if (leafBump) {                                                  // the caller multiplies by the cosine to the geometric normal (:298-303)
-              const float c1 = absf(dot(ms.dir, hitNorm)), c2 = absf(dot(ms.dir, sNorm));
-              ms.val = ms.val * (c2 / smax(c1, 1e-10f));
-            }
-            const float invPdf = 1.0f / smax(ms.pdf, 1e-20f);
-            const V4 bxdfVal = ms.val * invPdf;
-            const float cosTheta = absf(dot(ms.dir, hitNorm));
-            misPdf = (ms.flags & RAY_EVENT_S) != 0 ? -1.0f : ms.pdf;
-            if (S.integratorType == INTEGRATOR_STUPID_PT) { thr = thr * (cosTheta * bxdfVal); wantShadow = false; }
-            else { contrib = thr * shade; thr = thr * cosTheta * bxdfVal; }
-            V3 hp = hitPos;
-            if ((ms.flags & RAY_EVENT_T) != 0) hp = hp + hit.t * rdir * 2.0f * 1e-6f;
-            rpos = offsRayPos(hp, hitNorm, ms.dir);
-            rdir = ms.dir;
-            uint nextFlags = ((flags & ~RAY_FLAG_FIRST_NON_SPEC) | ms.flags);
-            if (S.renderLayer == FB_DIRECT && (flags & RAY_FLAG_HAS_NON_SPEC) != 0) nextFlags |= RAY_FLAG_IS_DEAD;
-            else if ((flags & RAY_FLAG_HAS_NON_SPEC) == 0 && (nextFlags & RAY_FLAG_HAS_NON_SPEC) != 0) nextFlags |= RAY_FLAG_FIRST_NON_SPEC;
-            flags = nextFlags;
-          }
-        }
+        shadeVertexSpec<SCOPE, MOTION>(S, hit, rpos, rdir, waves, accum, thr, misPdf, misIor, flags, bounce, gen, naive, wantShadow, shPos, shDir, shFar, contrib, pathTime);
       }
       if (wantShadow) {
         HitRec sh;
@@ -592,10 +604,174 @@ __global__ void __launch_bounds__(256, SCOPE_ == 2 ? HPT_SPEC_WIDE_WAVES : HPT_S
   }
 }
 
+// ---- spectral rendering under the block-local schedule (hpt_block.hip's structure on four wavelengths) ------------------------------------------
+// The kernel above is one thread per pixel without a work queue; its lanes keep their ray until the slowest lane of the wave is through. For
+// scenes whose rays walk a real tree - the reference's 16 396-triangle spectral fixture, a 10^6-triangle interior under m_spectral_mode = 1 -
+// this variant is the RGB block-local megakernel with V4 radiance: persistent blocks pulling pixels from the work queue, the lanes' next
+// closest-hit and shadow rays pooled in LDS and drained by the block's four waves with ray replacement (blockTracePhase), the 4-wide compressed
+// tree on heavy scenes. The per-vertex arithmetic is shadeVertexSpec, the same function the kernel above calls, in the same order, so both
+// render bit-identical frames (tests/test_gpu_spectral.py). PathTraceFromInputRays and moving instances stay with the kernel above.
+template <bool DEEP, bool FLAT, bool WIDE, int SCOPE_>
+__global__ void __launch_bounds__(256, SCOPE_ == 2 ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAVES) pathTraceBlockSpectralKernel(const DevScene S, const Job job, uint refillBelow, uint nodeMin)
+{
+  constexpr int SCOPE = SCOPE_ == 3 ? 2 : SCOPE_;
+  __shared__ uint stackMem[LDS_STACK * 256];
+  __shared__ uint pool[8 * BW_POOL];
+  __shared__ float coldPix[3 * 256];
+  __shared__ uint  coldU[3 * 256];
+  __shared__ uint  poolTail, poolHead;
+  const uint glane = blockIdx.x * 256u + threadIdx.x;
+  const uint lane = threadIdx.x & 63u;
+  TravStack stk; stk.lds = &stackMem[threadIdx.x]; stk.ovf = job.stackOverflow + glane; stk.ovfStride = job.gridLanes;
+#define PIX(k)      coldPix[(k) * 256 + threadIdx.x]
+#define PIX_XY      coldU[0 * 256 + threadIdx.x]
+#define PIX_TID     coldU[1 * 256 + threadIdx.x]
+#define PIX_PASSES  coldU[2 * 256 + threadIdx.x]
+  bool havePixel = false, alive = false, drained = false, pend = false, ending = false;
+  uint bounce = 0, flags = 0, myNear = 0, myShad = 0;
+  Rng  gen; gen.sx = gen.sy = 0;
+  V3   rpos = v3(0, 0, 0), rdir = v3(0, 0, 1);
+  V4   waves = v4s(0.0f), accum = v4s(0.0f), thr = v4s(1.0f), contrib = v4s(0.0f);
+  float misPdf = 1.0f, misIor = 1.0f;
+  const bool naive = job.naive != 0u;
+  const uint maxBounce = naive ? S.traceDepth + 1u : S.traceDepth;
+  HitRec hit; hit.inst = 0xFFFFFFFFu; hit.prim = 0; hit.t = 0; hit.u = hit.v = 0;
+  bool occluded = false;
+  if (threadIdx.x == 0u) { poolTail = 0u; poolHead = 0u; }
+  __syncthreads();
+
+  while (true) {
+    bool wantShadow = false;
+    V3 shPos = v3(0, 0, 0), shDir = v3(0, 0, 1); float shFar = 0.0f;
+    if (pend) { if (!occluded) accum = accum + contrib; pend = false; }     // the shadow ray of the last round, added in the plain kernel's order
+    bool finalize = ending;
+    ending = false;
+    if (alive) {
+      if (maxBounce != 0u) {
+        shadeVertexSpec<SCOPE, false>(S, hit, rpos, rdir, waves, accum, thr, misPdf, misIor, flags, bounce, gen, naive, wantShadow, shPos, shDir, shFar, contrib, 0.0f);
+        bounce++;                                                            // (the plain kernel counts every trip, a miss included)
+      }
+      if ((flags & RAY_FLAG_IS_DEAD) != 0 || bounce >= maxBounce) {
+        alive = false;
+        if (wantShadow) ending = true; else finalize = true;
+      }
+    }
+    if (finalize) {
+      if ((flags & RAY_FLAG_OUT_OF_SCENE) != 0) {                            // kernel_HitEnvironment, after the last shadow contribution as in the plain kernel
+        V4 env = ld4(S.envColor);
+        if (SCOPE >= 2) env = environmentRadianceSpec(S, rdir, waves, misPdf, flags, PIX_XY);
+        else if (S.envSpecId != 0xFFFFFFFFu) env = sampleUniformSpectrum(S.specValues, S.specOffsetSz[2u * S.envSpecId], waves) * (S.envSpecMult / 106.856895f);
+        if (S.integratorType == INTEGRATOR_STUPID_PT) accum = thr * env; else accum = accum + thr * env;
+      }
+      // kernel_ContributeToImage (integrator_pt.cpp:598-657), spectral
+      if (job.channels == 1) PIX(0) += accum.x * S.exposureMult;
+      else if (job.channels > 4) {
+        const uint XY = PIX_XY;
+        const uint pixel = ((XY & 0xFFFF0000u) >> 16) * (uint)S.winWidth + (XY & 0x0000FFFFu);
+        const V4 color = accum * S.exposureMult;
+        for (int i = 0; i < 4; i++) {
+          const float t = (comp(waves, i) - LAMBDA_MIN) / (LAMBDA_MAX - LAMBDA_MIN);
+          const int channelId = min(int(float(job.channels) * t), int(job.channels) - 1);
+          job.outColor[(size_t)channelId * (size_t)(S.winWidth * S.winHeight) + pixel] += comp(color, i);   // the pixel is this lane's alone
+        }
+      }
+      else { const V3 rgb = spectralCamResponseToRGB(S, accum, waves, flags); PIX(0) += S.exposureMult * rgb.x; PIX(1) += S.exposureMult * rgb.y; PIX(2) += S.exposureMult * rgb.z; }
+    }
+    const bool idle = !alive && !ending;
+    if (idle && havePixel && PIX_PASSES == 0u) {                             // a finished pixel goes back to HBM
+      const uint XY = PIX_XY;
+      const uint pixel = ((XY & 0xFFFF0000u) >> 16) * (uint)S.winWidth + (XY & 0x0000FFFFu);
+      if (job.channels == 1) job.outColor[pixel] = PIX(0);
+      else if (job.channels <= 4) { float* o = job.outColor + (size_t)pixel * job.channels; o[0] = PIX(0); o[1] = PIX(1); o[2] = PIX(2); }
+      job.gens[PIX_TID] = gen;
+      havePixel = false;
+    }
+    {                                                                        // work queue: ballot the lanes without a pixel, one atomic per wave
+      const bool need = idle && !havePixel && !drained;
+      const unsigned long long mask = __ballot(need);
+      if (mask != 0ull) {
+        uint base = 0;
+        if (need && mbcnt64(mask) == 0u) base = atomicAdd(job.queue, (uint)__popcll(mask));
+        base = __shfl(base, (int)(__ffsll((long long)mask) - 1));
+        if (need) {
+          const uint k = base + mbcnt64(mask);
+          const uint tid = job.tidBegin + (k / job.tidChunk) * job.tidChunk * job.tidStride + (k % job.tidChunk);
+          if (k < job.tidCount && tid < job.tidEnd) {
+            const uint XY = job.packedXY[tid];
+            gen = job.gens[tid];
+            const uint pixel = ((XY & 0xFFFF0000u) >> 16) * (uint)S.winWidth + (XY & 0x0000FFFFu);
+            PIX(0) = 0.0f; PIX(1) = 0.0f; PIX(2) = 0.0f;
+            if (job.channels == 1) PIX(0) = job.outColor[pixel];
+            else if (job.channels <= 4) { const float* o = job.outColor + (size_t)pixel * job.channels; PIX(0) = o[0]; PIX(1) = o[1]; PIX(2) = o[2]; }
+            PIX_XY = XY; PIX_TID = tid; PIX_PASSES = job.passNum;
+            havePixel = true;
+          } else drained = true;
+        }
+      }
+    }
+    if (idle && havePixel) {                                                 // next pass of the pixel: GetRandomNumbersLens, then GetRandomNumbersSpec (integrator_pt.cpp:114-118)
+      PIX_PASSES = PIX_PASSES - 1u;
+      const V4 lens = rng_float4(gen);
+      const uint XY = PIX_XY;
+      cameraRay<(SCOPE >= 2)>(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
+      waves = sampleWavelengths(rng_float1(gen), LAMBDA_MIN, LAMBDA_MAX);
+      accum = v4s(0.0f); thr = v4s(1.0f); misPdf = 1.0f; misIor = 1.0f; flags = 0; bounce = 0;
+      alive = true;
+    }
+    {                                                                        // append this lane's rays to the block's pool
+      const bool qNear = alive && maxBounce != 0u;
+      const unsigned long long mn = __ballot(qNear), ms = __ballot(wantShadow);
+      const uint cn = (uint)__popcll(mn), cs = (uint)__popcll(ms);
+      uint base = 0;
+      if (lane == 0u && cn + cs != 0u) base = atomicAdd(&poolTail, cn + cs);
+      base = __shfl(base, 0);
+      if (qNear) {
+        const uint e = base + mbcnt64(mn);
+        pool[0 * BW_POOL + e] = __float_as_uint(rpos.x); pool[1 * BW_POOL + e] = __float_as_uint(rpos.y); pool[2 * BW_POOL + e] = __float_as_uint(rpos.z);
+        pool[3 * BW_POOL + e] = __float_as_uint(HPT_FLT_MAX);
+        pool[4 * BW_POOL + e] = __float_as_uint(rdir.x); pool[5 * BW_POOL + e] = __float_as_uint(rdir.y); pool[6 * BW_POOL + e] = __float_as_uint(rdir.z);
+        pool[7 * BW_POOL + e] = 0u;
+        myNear = e;
+      }
+      if (wantShadow) {
+        const uint e = base + cn + mbcnt64(ms);
+        pool[0 * BW_POOL + e] = __float_as_uint(shPos.x); pool[1 * BW_POOL + e] = __float_as_uint(shPos.y); pool[2 * BW_POOL + e] = __float_as_uint(shPos.z);
+        pool[3 * BW_POOL + e] = __float_as_uint(shFar);
+        pool[4 * BW_POOL + e] = __float_as_uint(shDir.x); pool[5 * BW_POOL + e] = __float_as_uint(shDir.y); pool[6 * BW_POOL + e] = __float_as_uint(shDir.z);
+        pool[7 * BW_POOL + e] = 1u;
+        myShad = e; pend = true;
+      }
+    }
+    __syncthreads();
+    const uint total = poolTail;
+    if (total == 0u) break;
+    blockTracePhase<DEEP, FLAT, WIDE>(S, stk, pool, &poolHead, total, refillBelow, nodeMin, lane);
+    __syncthreads();
+    if (alive) {
+      hit.t = __uint_as_float(pool[0 * BW_POOL + myNear]); hit.u = __uint_as_float(pool[1 * BW_POOL + myNear]); hit.v = __uint_as_float(pool[2 * BW_POOL + myNear]);
+      hit.prim = pool[3 * BW_POOL + myNear]; hit.inst = pool[4 * BW_POOL + myNear];
+    }
+    if (pend) occluded = pool[0 * BW_POOL + myShad] != 0u;
+    if (threadIdx.x == 0u) { poolTail = 0u; poolHead = 0u; }
+    __syncthreads();
+  }
+#undef PIX
+#undef PIX_XY
+#undef PIX_TID
+#undef PIX_PASSES
+}
+
 // one translation unit per scope (-DHPT_SPEC_INST=1 / 2 / 3 / 4: scope 0 / 1 / 2 / 2 at 4 waves; 0: all), see __graft_entry__.build
 #ifndef HPT_SPEC_INST
 #define HPT_SPEC_INST 0
 #endif
+#define HPT_SPEC_BLOCK(SCOPE) \
+  template __global__ void pathTraceBlockSpectralKernel<false, false, false, SCOPE>(const DevScene, const Job, uint, uint); \
+  template __global__ void pathTraceBlockSpectralKernel<true,  false, false, SCOPE>(const DevScene, const Job, uint, uint); \
+  template __global__ void pathTraceBlockSpectralKernel<false, true,  false, SCOPE>(const DevScene, const Job, uint, uint); \
+  template __global__ void pathTraceBlockSpectralKernel<true,  true,  false, SCOPE>(const DevScene, const Job, uint, uint); \
+  template __global__ void pathTraceBlockSpectralKernel<false, true,  true,  SCOPE>(const DevScene, const Job, uint, uint); \
+  template __global__ void pathTraceBlockSpectralKernel<true,  true,  true,  SCOPE>(const DevScene, const Job, uint, uint);
 #define HPT_SPEC(SCOPE) \
   template __global__ void pathTraceSpectralKernel<false, false, false, false, SCOPE>(const DevScene, const Job); \
   template __global__ void pathTraceSpectralKernel<true,  false, false, false, SCOPE>(const DevScene, const Job); \
@@ -608,15 +784,19 @@ __global__ void __launch_bounds__(256, SCOPE_ == 2 ? HPT_SPEC_WIDE_WAVES : HPT_S
   template __global__ void pathTraceSpectralKernel<true,  true,  false, true,  SCOPE>(const DevScene, const Job);
 #if HPT_SPEC_INST == 0 || HPT_SPEC_INST == 1
 HPT_SPEC(0)
+HPT_SPEC_BLOCK(0)
 #endif
 #if HPT_SPEC_INST == 0 || HPT_SPEC_INST == 2
 HPT_SPEC(1)
+HPT_SPEC_BLOCK(1)
 #endif
 #if HPT_SPEC_INST == 0 || HPT_SPEC_INST == 3
 HPT_SPEC(2)
+HPT_SPEC_BLOCK(2)
 #endif
 #if HPT_SPEC_INST == 0 || HPT_SPEC_INST == 4
 HPT_SPEC(3)
+HPT_SPEC_BLOCK(3)
 #endif
 
 } // namespace hpt

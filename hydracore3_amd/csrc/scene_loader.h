@@ -20,6 +20,7 @@
 #include <fstream>
 #include <array>
 #include <map>
+#include <unordered_map>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -597,14 +598,34 @@ inline bool iesSphericalTexture(const std::string& path, LoadedTexture& tex, std
 
 } // namespace detail
 
-inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, LoadedScene& sc, std::string& err, bool spectral = false)
+// Mesh4fInput (integrator_pt.h:103-119): a mesh handed over as pointers instead of a .vsgf file - what Integrator::LoadScene_SetMeshPointers
+// (:154) receives from the HR2 render driver (hydra_api/hydra_cpu.cpp:36-70) and LoadSceneGeometry reads for <mesh ... ptrs="1"> nodes
+// (integrator_pt_scene.cpp:750-789). Same member names and meaning.
+struct Mesh4fInput
+{
+  const float*    vPosPtr = nullptr; uint32_t vPosByteStride = 16;
+  const float*    vNormPtr4f = nullptr; const float* vTangPtr4f = nullptr; const float* vTexCoord2f = nullptr;
+  const uint32_t* indicesPtr = nullptr; uint32_t indicesNum = 0, vertNum = 0;
+  const uint32_t* matIdPtr = nullptr; uint32_t matIdAll = 0, matIdNum = 1;       // matIdNum != indicesNum / 3: the whole mesh takes matIdAll
+};
+
+inline bool LoadHydraXmlText(const std::string& text, const std::string& folder, int width, int height, LoadedScene& sc, std::string& err, bool spectral = false,
+                             const std::unordered_map<int, Mesh4fInput>* meshPtrs = nullptr);
+
+inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, LoadedScene& sc, std::string& err, bool spectral = false,
+                         const std::unordered_map<int, Mesh4fInput>* meshPtrs = nullptr)
+{
+  std::vector<uint8_t> raw; if (!detail::readFile(xmlPath, raw)) { err = "cannot read " + xmlPath; return false; }
+  const size_t slash = xmlPath.find_last_of("/\\");
+  return LoadHydraXmlText(std::string(raw.begin(), raw.end()), slash == std::string::npos ? std::string(".") : xmlPath.substr(0, slash), width, height, sc, err, spectral, meshPtrs);
+}
+
+// the scene description as TEXT (an HR2 client keeps it in memory: hydra_api's xmlData) + the folder its relative paths start from
+inline bool LoadHydraXmlText(const std::string& text, const std::string& folder, int width, int height, LoadedScene& sc, std::string& err, bool spectral,
+                             const std::unordered_map<int, Mesh4fInput>* meshPtrs)
 {
   using namespace detail;
-  std::vector<uint8_t> raw; if (!readFile(xmlPath, raw)) { err = "cannot read " + xmlPath; return false; }
-  const std::string text(raw.begin(), raw.end());
   XmlNode root; XmlParser parser(text); if (!parser.parse(root, err)) return false;
-  const size_t slash = xmlPath.find_last_of("/\\");
-  const std::string folder = slash == std::string::npos ? std::string(".") : xmlPath.substr(0, slash);
   sc = LoadedScene();
   {                                                         // m_textures[0]: 1x1 white, NEAREST / CLAMP (integrator_pt_scene_tex.cpp:7-16)
     LoadedTexture w; w.width = w.height = 1; w.format = 0; w.flags = 0; w.addressU = w.addressV = 2; w.filter = 0; w.bytes.assign(4, 0xFF);
@@ -1195,6 +1216,28 @@ inline bool LoadHydraXml(const std::string& xmlPath, int width, int height, Load
 
   // geometry: cmesh4::LoadMeshFromVSGF; m_vData8f packs {normal.xyz, u | tangent.xyz, v} (integrator_pt_scene.cpp:727-837)
   if (const XmlNode* lib = root.child("geometry_lib")) for (const XmlNode* mesh : lib->all("mesh")) {
+    if (mesh->get("ptrs") == "1") {                                            // LoadSceneGeometry's pointer branch (integrator_pt_scene.cpp:750-789)
+      const int meshId = std::atoi(mesh->get("id").c_str());
+      const auto it = meshPtrs ? meshPtrs->find(meshId) : std::unordered_map<int, Mesh4fInput>::const_iterator();
+      if (!meshPtrs || it == meshPtrs->end()) { err = "[LoadSceneGeometry]: bad mesh pointer id = " + std::to_string(meshId); return false; }
+      const Mesh4fInput& in = it->second;
+      if (!in.vPosPtr || !in.vNormPtr4f || !in.vTexCoord2f || !in.indicesPtr || in.vPosByteStride % 4 != 0 || in.vPosByteStride < 12) { err = "[LoadSceneGeometry]: incomplete mesh pointers, id = " + std::to_string(meshId); return false; }
+      const uint32_t nv = in.vertNum, nt = in.indicesNum / 3, fs = in.vPosByteStride / 4;
+      sc.matVertOffset.push_back((uint32_t)sc.matIdByPrimId.size()); sc.matVertOffset.push_back((uint32_t)(sc.vPos4f.size() / 4));
+      sc.geomTriCount.push_back(nt); sc.geomVertCount.push_back(nv);
+      for (uint32_t v = 0; v < nv; v++) {
+        const float* pp = in.vPosPtr + (size_t)fs * v;
+        const float p4[4] = { pp[0], pp[1], pp[2], fs >= 4 ? pp[3] : 1.0f };
+        sc.vPos4f.insert(sc.vPos4f.end(), p4, p4 + 4);
+        float d[8] = { in.vNormPtr4f[4 * v], in.vNormPtr4f[4 * v + 1], in.vNormPtr4f[4 * v + 2], in.vTexCoord2f[2 * v], 0, 0, 0, in.vTexCoord2f[2 * v + 1] };
+        if (in.vTangPtr4f) { d[4] = in.vTangPtr4f[4 * v]; d[5] = in.vTangPtr4f[4 * v + 1]; d[6] = in.vTangPtr4f[4 * v + 2]; }   // (else: "render must not compute tangent space")
+        sc.vData8f.insert(sc.vData8f.end(), d, d + 8);
+      }
+      sc.triIndices.insert(sc.triIndices.end(), in.indicesPtr, in.indicesPtr + (size_t)nt * 3);
+      if (in.matIdNum != nt || !in.matIdPtr) sc.matIdByPrimId.insert(sc.matIdByPrimId.end(), nt, in.matIdAll);
+      else sc.matIdByPrimId.insert(sc.matIdByPrimId.end(), in.matIdPtr, in.matIdPtr + nt);
+      continue;
+    }
     std::vector<uint8_t> f; const std::string p = folder + "/" + mesh->get("loc");
     if (!readFile(p, f) || f.size() < 24) { err = "cannot read " + p; return false; }
     uint32_t nv, ni, nm, flags; std::memcpy(&nv, f.data() + 8, 4); std::memcpy(&ni, f.data() + 12, 4); std::memcpy(&nm, f.data() + 16, 4); std::memcpy(&flags, f.data() + 20, 4);

@@ -1312,6 +1312,26 @@ def test_cpp_adapter_renders_whole_scenes_like_the_ctypes_path(xml, tmp_path):
     assert float(frame[..., :3].mean()) > 0.0
 
 
+@pytest.mark.parametrize("scene_name", ["test_035", "test_228"])
+def test_hr2_driver_leg_renders_in_memory_meshes(scene_name, tmp_path):
+    """tests/cpp/hydra_hip_hr2.cpp + csrc/hydra_driver_hip.h: the HR2 render-driver leg (hydra_api/hydra_cpu.cpp:4-127) on the HIP core - the client's
+    meshes handed over as POINTERS (RDScene_Input::pMeshPtrs -> Mesh4fInput -> LoadSceneGeometry's ptrs="1" branch, integrator_pt_scene.cpp:750-789),
+    no geometry file opened by the driver, a second LoadScene without the geometry flag keeping them, then CommitDeviceData and Render() =
+    SetFrameBufferSize / SetViewport / UpdateMembersPlainData / PackXYBlock / PathTraceBlock. The frame equals the file path's frame bit for bit."""
+    import subprocess
+    from conftest import ROOT
+    tool = os.path.join(ROOT, "hydracore3_amd", "hydra_hip_hr2")
+    ref_tool = os.path.join(ROOT, "hydracore3_amd", "hydra_hip_render")
+    out, ref = str(tmp_path / "hr2.bin"), str(tmp_path / "ref.bin")
+    r = subprocess.run([tool, scene_path(scene_name), "96", "64", "6", out], capture_output=True, text=True)
+    print(r.stdout.strip())
+    assert r.returncode == 0 and "meshes by pointers" in r.stdout, r.stdout + r.stderr
+    r2 = subprocess.run([ref_tool, scene_path(scene_name), "96", "64", "6", ref], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    a, b = np.fromfile(out, np.float32), np.fromfile(ref, np.float32)
+    assert a.size == 96 * 64 * 4 and np.array_equal(a, b) and float(a.reshape(64, 96, 4)[..., :3].mean()) > 0.0
+
+
 def test_update_mat_id_offsets_hook(cornell):
     """Update_m_matIdOffsets (integrator_pt.h:470): m_matVertOffset re-uploaded through hpt_update_mat_id_offsets. Pointing mesh 1's triangle
     offset at mesh 0's material ids changes the colours of that instance exactly as a scene built with those offsets does; ranges that leave

@@ -1399,10 +1399,24 @@ HPT_DEV bool traceSweep(const DevScene& S, const V3 wo, const V3 wd, const float
   bool found = false;
   const cfloat4* insts = (const cfloat4*)S.sweepInsts;
   const cfloat4* tris = (const cfloat4*)S.sweepTris;
+  const cfloat4* boxes = (const cfloat4*)S.sweepBoxes;
+  const V3 id = rcp3(wd);
   const uint ni = S.numInsts;
   for (uint i = 0; i < ni; i++) {
     const float4 r0 = ldc4(insts + 4u * i + 0u), r1 = ldc4(insts + 4u * i + 1u), r2 = ldc4(insts + 4u * i + 2u);
     const u32x4n r3 = ((const cuint4*)insts)[4u * i + 3u];                 // {first triangle record, geomId, 0, number of record PAIRS}
+    {
+      // Wave-uniform skip: when NO ray of the wave can reach the instance's (padded) world box within its interval - [tnear, closest hit so far],
+      // or [tnear, tfar] for a shadow ray that has no occluder yet - none of its triangles can change a result, and the whole wave steps over
+      // them (the eye rays of a tile looking past the boxes of the Cornell scene, rays whose hit is already nearer than the box). Boxes only
+      // cull, the slab test is nodeSlabs' (widened: conservative against the exact triangle test), so hits stay bit-identical.
+      const float4 blo = ldc4(boxes + 2u * i), bhi = ldc4(boxes + 2u * i + 1u);
+      const float lim = ANY ? (found ? -1.0f : tfar) : hit.t;
+      const float ax0 = (blo.x - wo.x) * id.x, ax1 = (bhi.x - wo.x) * id.x, ay0 = (blo.y - wo.y) * id.y, ay1 = (bhi.y - wo.y) * id.y, az0 = (blo.z - wo.z) * id.z, az1 = (bhi.z - wo.z) * id.z;
+      const float tn = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), tnear));
+      const float tf = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), lim));
+      if (__ballot(tn * 0.999999f <= tf * 1.000001f) == 0ull) continue;
+    }
     // toObjectSpace (same expressions, same order)
     const V3 o = v3(r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w, r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w, r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w);
     const V3 d = v3(r0.x * wd.x + r0.y * wd.y + r0.z * wd.z, r1.x * wd.x + r1.y * wd.y + r1.z * wd.z, r2.x * wd.x + r2.y * wd.y + r2.z * wd.z);

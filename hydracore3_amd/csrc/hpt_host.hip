@@ -93,7 +93,7 @@ struct hpt_ctx
   uint stackNeeded = 0;
 
   // device buffers
-  DevBuf<BvhNode> dNodes; DevBuf<BvhTri> dTris; DevBuf<BvhInst> dInsts, dSweepInsts; DevBuf<BvhTri> dSweepTris;
+  DevBuf<BvhNode> dNodes; DevBuf<BvhTri> dTris; DevBuf<BvhInst> dInsts, dSweepInsts; DevBuf<BvhTri> dSweepTris; DevBuf<float> dSweepBoxes;
   DevBuf<uint> dTriIndices, dMatIdByPrim, dMatVertOffset, dPackedXY;
   DevBuf<float> dVData, dNormMat;
   DevBuf<int> dRemapInst, dRemapLists;
@@ -237,7 +237,7 @@ try {
   (void)hipDeviceSynchronize();
   (void)hpt_comm_destroy(c);
   lbvhDestroy(c->lbvh); c->lbvh = nullptr;
-  c->dNodes.release(); c->dTris.release(); c->dInsts.release(); c->dSweepInsts.release(); c->dSweepTris.release(); c->dLevelNodes.release(); c->dShadeTris.release(); c->dNodes4.release(); c->dNodes4Src.release(); c->dTriBox.release(); c->dNodeBounds.release(); c->dInstO2W.release(); c->dTriIndices.release(); c->dMatIdByPrim.release();
+  c->dNodes.release(); c->dTris.release(); c->dInsts.release(); c->dSweepInsts.release(); c->dSweepTris.release(); c->dSweepBoxes.release(); c->dLevelNodes.release(); c->dShadeTris.release(); c->dNodes4.release(); c->dNodes4Src.release(); c->dTriBox.release(); c->dNodeBounds.release(); c->dInstO2W.release(); c->dTriIndices.release(); c->dMatIdByPrim.release();
   c->dMatVertOffset.release(); c->dPackedXY.release(); c->dVData.release(); c->dNormMat.release(); c->dRemapInst.release();
   c->dRemapLists.release(); c->dMaterials.release(); c->dLights.release(); c->dTextures.release(); c->dArrays1f.release(); c->dSpecValues.release(); c->dSpecOffsetSz.release(); c->dCieXYZ.release(); c->dFilmsEtaK.release(); c->dPrecompFilms.release(); c->dFilmsSpecId.release(); c->dSpecTexIdsWavelengths.release(); c->dSpecTexOffsetSz.release(); c->dGens.release();
   c->dQueue.release(); c->dStackOvf.release(); c->dCounters.release(); c->dFrame.release(); c->dRecord.release(); c->dRef.release(); c->dData.release();
@@ -887,8 +887,23 @@ try {
     std::vector<BvhInst> sw(dinst);
     for (size_t i = 0; i < ni; i++) { const uint g = c->insts[i].geomId; sw[i].root = geomTriBase[g]; sw[i].pad0 = 0; sw[i].pad1 = (uint)(c->geoms[g].tris.size() + 1) / 2u; }
     HIPCHK(c, c->dSweepInsts.upload(sw.data(), sw.size()));
+    // the instances' padded world boxes (over their triangles' world-space vertices): traceSweep's wave-uniform skip
+    std::vector<float> sb(8 * std::max<size_t>(ni, 1), 0.0f);
+    for (size_t i = 0; i < ni; i++) {
+      const Geom& g = c->geoms[c->insts[i].geomId];
+      const float* m = c->insts[i].m;
+      Aabb b; b.reset();
+      for (size_t v = 0; v + 2 < g.pos.size(); v += 3) {
+        const float* p = &g.pos[v];
+        const float q[3] = { m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12], m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13], m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14] };
+        b.grow(q);
+      }
+      if (g.pos.empty()) { for (int a = 0; a < 3; a++) { b.lo[a] = 1.0f; b.hi[a] = -1.0f; } } else b.pad();
+      for (int a = 0; a < 3; a++) { sb[8 * i + a] = b.lo[a]; sb[8 * i + 4 + a] = b.hi[a]; }
+    }
+    HIPCHK(c, c->dSweepBoxes.upload(sb.data(), sb.size()));
   }
-  c->S.sweep = sweep ? 1u : 0u; c->S.sweepInsts = sweep ? c->dSweepInsts.p : nullptr; c->S.sweepTris = sweep ? c->dSweepTris.p : nullptr;
+  c->S.sweep = sweep ? 1u : 0u; c->S.sweepInsts = sweep ? c->dSweepInsts.p : nullptr; c->S.sweepTris = sweep ? c->dSweepTris.p : nullptr; c->S.sweepBoxes = sweep ? (const float4*)c->dSweepBoxes.p : nullptr;
   if (nodes.empty()) nodes.push_back(BvhNode());           // keep the pointers valid
   if (tris.empty()) tris.push_back(BvhTri());
   HIPCHK(c, c->dNodes.upload(nodes.data(), nodes.size()));

@@ -194,6 +194,8 @@ struct DevScene
   // spectra given by textures (m_spec_tex_ids_wavelengths, m_spec_tex_offset_sz: uint2 each), read by the spectral kernel's colour lookup
   const uint*        specTexIdsWavelengths;
   const uint*        specTexOffsetSz;
+  // sweep scenes: the instances' padded world boxes, {lo.xyz, -} {hi.xyz, -} per instance: a wave skips an instance none of its rays can reach (traceSweep)
+  const float4*      sweepBoxes;
 };
 
 struct Counters { unsigned long long v[32]; };  // rays, nodes, tris, surfaceHits, shadowRays, paths, instEnter, texFetch,

@@ -389,6 +389,7 @@ def run_dr(args, workload, rank, world, dev, dist, backend, steps, warmup, spp_a
     samples = weak or args.shard == "samples"
     # reference image: the same scene with the target (checker) albedo, a few passes on the GPU (identical on every rank)
     tgt_int = HipIntegrator(tgt, device=dev.index)
+    tgt_int.set_schedule(1)                                        # (the plain megakernel: under a profiler its kernel name keeps the reference render apart from the timed PathTraceDR kernels)
     ref = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     tgt_int.path_trace_block_dev(ref.data_ptr(), 64, 0, N, 4, False, stream)
     torch.cuda.synchronize()

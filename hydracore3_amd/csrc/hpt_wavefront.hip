@@ -174,9 +174,11 @@ __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const W
     }
     P.status[s] = (passes << 8) | (alive ? WF_ALIVE : 0u) | (wantShadow ? WF_PEND : 0u) | (ending ? WF_ENDING : 0u);
   }
+#ifndef HPT_DBG_DR_NOSWEEP   // diagnostic builds only (profiles/dr_ab.sh)
   if (DR && __any(closing))
     drReverseSweep(S, job.record, job.itemCount, s < job.itemCount ? s : 0u, closing, sweepBounce, sweepTail, sweepDiff, job.grad, job.drSkipNonFinite != 0u,
                    drStage + (threadIdx.x >> 6) * DR_STAGE_DWORDS, lastRec, lastInRegs);
+#endif
   // ray compaction: ballot + prefix sum, one atomic per wave and queue
   const bool qNear = active && alive, qShad = active && wantShadow;
   uint kn, ks;

@@ -22,7 +22,7 @@ def product_kernel(name):
     """Kernels of one PathTraceBlock call: the persistent megakernel, or the wavefront schedule's shade / trace / init kernels.
     The instrumented build (first template argument true / third for the trace kernel) is bench.py's counting probe, never timed."""
     if workload == "spectral":
-        return "pathTraceSpectralKernel" in name
+        return "SpectralKernel" in name                 # pathTraceSpectralKernel, or pathTraceBlockSpectralKernel under the block-local schedule
     if workload == "film":
         return "pathTraceKernel<false, false, 4" in name
     if workload.startswith("dr"):                 # bench.py renders the target image with the forward kernel first: not part of a PathTraceDR call

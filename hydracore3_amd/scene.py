@@ -918,9 +918,10 @@ def spectrum_mean(values):
 
 def cie_xyz_fit():
     """The CIE 1931 2-degree observer at 360..830 nm, float32 [471, 4] = {x, y, z, 0}. The reference carries the tabulated functions in its
-    source (spectrum.cpp) and hands them to the integrator as m_cie_xyz; no other copy exists in this image, so the fixture loaders use the
-    analytic multi-lobe fit of Wyman, Sloan and Shirley (JCGT 2013; within about 1 % of the tables). A HydraCore3 host passes its own table
-    through hpt_scene_desc::cieXYZ - the kernels only ever read what they are given, and the parity tests feed both sides the same table."""
+    source (spectrum.cpp:103-396) and hands them to the integrator as m_cie_xyz. Reference SOURCE is not copied into this repository, so the
+    fixture loaders use the analytic multi-lobe fit of Wyman, Sloan and Shirley (JCGT 2013; within about 1 % of the tables): spectral frames
+    and RGB thin-film tables made by these loaders differ from the reference renderer's by that much, which the HIP-vs-oracle tests cannot
+    see (both sides get the same fit). A HydraCore3 host passes its own table through hpt_scene_desc::cieXYZ - the kernels only read what they are given."""
     lam = np.arange(int(LAMBDA_MAX - LAMBDA_MIN + 1), dtype=np.float64) + LAMBDA_MIN
 
     def g(mu, s1, s2):

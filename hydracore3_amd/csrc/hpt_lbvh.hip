@@ -109,10 +109,13 @@ __global__ void __launch_bounds__(256) lbvhMortonKernel(const float* __restrict_
   const uint k = blockIdx.x * 256u + threadIdx.x;
   if (k >= n) return;
   unsigned long long key = 0ull;
+  // one scale for the three axes (the scene's longest extent): the Morton cells are cubes whatever the scene's proportions, so a split never
+  // halves an axis that is already the shortest of its cell (a 10 x 4 x 10 room normalised per axis splits y as often as x and z)
+  float ext = 0.0f;
+  for (int a = 0; a < 3; a++) ext = fmaxf(ext, keyFloat(C->sceneHi[a]) - keyFloat(C->sceneLo[a]));
   for (int a = 0; a < 3; a++) {
-    const float lo = keyFloat(C->sceneLo[a]), hi = keyFloat(C->sceneHi[a]);
+    const float lo = keyFloat(C->sceneLo[a]);
     const float c = 0.5f * (triBox[(size_t)a * n + k] + triBox[(size_t)(3 + a) * n + k]);
-    const float ext = hi - lo;
     float u = ext > 0.0f ? (c - lo) / ext : 0.0f;
     u = fminf(fmaxf(u, 0.0f), 1.0f);
     const unsigned long long q = (unsigned long long)fminf(u * 2097152.0f, 2097151.0f);

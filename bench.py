@@ -329,7 +329,8 @@ def run_forward(args, workload, rank, world, dev, dist, backend, steps, warmup, 
     elif shard == "samples":
         sharding = f"fixed work, sample sharding: {world} ranks x all pixels x {spp}/{world} spp (RNG sub-streams) + RCCL reduce(SUM)"
     else:
-        sharding = f"fixed work, pixel sharding: {world} ranks x interleaved 1024-tid chunks of one frame at {spp} spp + RCCL reduce(SUM)"
+        sharding = (f"fixed work, pixel sharding: {world} ranks x interleaved 1024-tid chunks of one frame at {spp} spp + RCCL reduce(SUM); bit-identical to the 1-GPU frame. "
+                    f"A pixel's passes are sequential (one RNG stream per pixel), so a rank has W*H/{world} independent chains: see DESIGN.md 5; the sample split is under 'also'")
     name = (f"scenes/test_035 Cornell box {W}x{H} @ {spp} spp, forward PathTraceBlock" if workload == "cornell"
             else f"synthetic 1M-triangle interior {W}x{H} @ {spp} spp, forward PathTraceBlock")
     return {"metric": "Mpaths/s (fwd PathTraceBlock, MIS path tracing)", "value": round(value, 2), "unit": "Mpaths/s", "n_gpus": world, "steps": steps,

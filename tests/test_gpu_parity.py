@@ -329,6 +329,15 @@ def test_block_local_schedule_equals_megakernel(scene_name):
     assert np.array_equal(ia, ib)
     one = HipIntegrator(sc); one.set_schedule(3)
     assert np.array_equal(one.render(3, channels=1), HipIntegrator(sc).render(3, channels=1))
+    # a multi-GPU pixel share: three "ranks" rendering every third 1024-tid chunk under this schedule reassemble the frame
+    from hydracore3_amd.sharding import tid_interleave
+    sh, acc = HipIntegrator(sc), np.zeros_like(ref)
+    sh.set_schedule(3)
+    for r in range(3):
+        begin, count, chunk, stride = tid_interleave(r, 3, sh.N)
+        sh.set_tid_interleave(chunk, stride)
+        sh.PathTraceBlock(count, 4, acc, 5, tid_begin=begin)
+    assert np.array_equal(acc, ref)
 
 
 def test_sample_sharding_seeds_and_sum(cornell):

@@ -155,6 +155,7 @@ struct hpt_ctx
   bool drSkipNonFinite = false;          // hpt_set_option "dr_skip_nonfinite": off = PixelLossPT as the reference has it
   bool leanMaterials = false;            // every material is gltf or emissive: the kernels without the other BSDF branches are used
   int  schedule = 0;                     // 0 automatic, 1 megakernel, 2 wavefront, 3 megakernel with block-local ray repacking (hpt_set_schedule)
+  int  bwWide = -1;                        // hpt_set_option("bw_wide"): -1 the 4-wide tree on heavy scenes only, 0 never, 1 whenever the scene has one
   uint bwRefillBelow = 48, bwNodeMin = 4;   // (profiles/bw_sweep.py: test_228 class, refill 32 .. 64 x vote 0 / 4 / 8 / 16)
   uint bwUnused = 0;   // hpt_block.hip: a wave refills when fewer lanes hold a ray; its node loop's vote
   int  nodeMinOverride = -1;             // env HPT_NODE_MIN (tuning): overrides the per-scene choice of DevScene::nodeMin
@@ -1701,7 +1702,7 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   const bool blockLocal = (c->schedule == 3 || bwAuto) && !naive && !inRays && !motion && !film && !stats && c->S.sweep == 0u;
   if (blockLocal) {
     const bool lean = dr || (c->leanMaterials && !c->forceFull && c->S.lensCount == 0u);
-    const bool bwide = lean && c->S.megaWide != 0u && c->S.flatMode != 0u && c->nodes4Count != 0u;      // heavy scenes: the 4-wide compressed tree, as the megakernel walks it
+    const bool bwide = lean && (c->bwWide == 1 || (c->bwWide < 0 && c->S.megaWide != 0u)) && c->S.flatMode != 0u && c->nodes4Count != 0u && c->wideEnabled;      // heavy scenes: the 4-wide compressed tree, as the megakernel walks it
     const bool bdeep = (bwide ? std::max(c->stackNeeded, c->stackNeeded4) : c->stackNeeded) > (uint)LDS_STACK;
     const uint bNodeMin = bwide ? std::max(c->bwNodeMin, 16u) : c->bwNodeMin;                           // (a 4-wide visit is three times the work: the vote pays earlier)
     c->lastSchedule = 3; c->lastWide = bwide ? 1u : 0u; c->lastDeep = bdeep ? 1u : 0u;
@@ -2285,6 +2286,7 @@ try {
   else if (k == "build_threads") c->buildThreads = std::min(value, 64);                // host threads CommitScene builds its trees with (0: the usable cores, at most 16)
   else if (k == "stats_wide") c->statsWide = value != 0;
   else if (k == "bw_refill_below") { if (value < 1 || value > 64) return c->fail(HPT_ERR_ARG, "bw_refill_below: 1..64"); c->bwRefillBelow = (uint)value; }
+  else if (k == "bw_wide") { if (value < -1 || value > 1) return c->fail(HPT_ERR_ARG, "bw_wide: -1 automatic, 0, 1"); c->bwWide = value; }
   else if (k == "bw_node_min") { if (value < 0 || value > 64) return c->fail(HPT_ERR_ARG, "bw_node_min: 0..64"); c->bwNodeMin = (uint)value; }
   else if (k == "device_build") { if (value < -1 || value > 1) return c->fail(HPT_ERR_ARG, "device_build: -1 by CommitScene's options, 0 never, 1 always"); c->deviceBuild = value; c->accelCommitted = false; c->flatRefittable = false; }
   else if (k == "wide_nodes") { c->wideEnabled = value != 0; c->S.megaWide = (c->wideEnabled && c->nodes4Count != 0u && c->S.flatMode != 0u && c->sahVisits >= HEAVY_SAH_VISITS) ? 1u : 0u; }   // both users of the tree, at once                             // 0: the wavefront trace kernel walks the BVH2 instead of the 4-wide compressed tree (A/B, diagnosis)

@@ -14,7 +14,7 @@ HPT_DEV void blockTracePhase(const DevScene& S, const TravStack& stk, uint* pool
 {
   bool has = false, isAny = false, found = false;
   uint slot = 0, cur = REF_NONE, curInst = 0xFFFFFFFFu; int sp = 0;
-  V3 wo = v3(0, 0, 0), wd = v3(0, 0, 1), o = wo, d = wd, id = v3(0, 0, 0);
+  V3 wo = v3(0, 0, 0), wd = v3(0, 0, 1), o = wo, d = wd, id = v3(0, 0, 0), oid = v3(0, 0, 0);
   float hitT = 0.0f, hitU = 0.0f, hitV = 0.0f; uint hitPrim = 0xFFFFFFFFu, hitInst = 0xFFFFFFFFu, hitSlot = 0xFFFFFFFFu;
   bool dry = false;                                                      // wave-uniform: the pool had nothing left at the last refill
 #define HPT_PUSH(v) do { if (DEEP) stkPush(stk, sp, (v)); else stk.lds[sp * 256] = (v); sp++; } while (0)
@@ -34,7 +34,7 @@ HPT_DEV void blockTracePhase(const DevScene& S, const TravStack& stk, uint* pool
           hitT = __uint_as_float(pool[3 * BW_POOL + e]);
           wd = v3(__uint_as_float(pool[4 * BW_POOL + e]), __uint_as_float(pool[5 * BW_POOL + e]), __uint_as_float(pool[6 * BW_POOL + e]));
           isAny = pool[7 * BW_POOL + e] != 0u;
-          slot = e; o = wo; d = wd; id = rcp3(wd);
+          slot = e; o = wo; d = wd; slabRay(wo, wd, id, oid);
           cur = WIDE ? S.root4 : S.rootRef; curInst = 0xFFFFFFFFu; sp = 0; found = false;
           hitPrim = 0xFFFFFFFFu; hitInst = 0xFFFFFFFFu; hitSlot = 0xFFFFFFFFu; hitU = 0.0f; hitV = 0.0f;
           has = cur != REF_NONE;
@@ -51,16 +51,15 @@ HPT_DEV void blockTracePhase(const DevScene& S, const TravStack& stk, uint* pool
       while (true) {
         while ((cur & REF_LEAF) == 0u) {
           if (WIDE) {                                                  // the 4-wide compressed tree of heavy single-level scenes (hpt_device.h: wideNodeStep)
-            wideNodeStep<DEEP>(S, stk, wo, id, hitT, cur, sp);
+            wideNodeStep<DEEP>(S, stk, oid, id, hitT, cur, sp);
             if (nodeMin != 0u && (uint)__popcll(__ballot((cur & REF_LEAF) == 0u)) < nodeMin) break;
             continue;
           }
           const float4* np = (const float4*)(S.nodes + cur);
           const float4 q0 = np[0], q1 = np[1], q2 = np[2];
           const uint4  q3 = ((const uint4*)np)[3];
-          const V3 bo = FLAT ? wo : o;
           bool h0, h1; float t0n, t1n;
-          nodeSlabs(q0, q1, q2, bo, id, 0.0f, hitT, h0, h1, t0n, t1n);
+          nodeSlabs(q0, q1, q2, oid, id, 0.0f, hitT, h0, h1, t0n, t1n);
           if (h0 && h1) { const bool firstIs0 = t0n <= t1n; HPT_PUSH(firstIs0 ? q3.y : q3.x); cur = firstIs0 ? q3.x : q3.y; }
           else if (h0) cur = q3.x;
           else if (h1) cur = q3.y;
@@ -89,12 +88,12 @@ HPT_DEV void blockTracePhase(const DevScene& S, const TravStack& stk, uint* pool
           } else if (cnt == 0u) {
             const uint inst = cur & 0x0FFFFFFFu;
             toObjectSpace(S.insts, inst, wo, wd, o, d);
-            id = rcp3(d);
+            slabRay(o, d, id, oid);
             curInst = inst;
             HPT_PUSH(REF_RESTORE);
             cur = S.insts[inst].root;
           } else {
-            o = wo; d = wd; id = rcp3(d); curInst = 0xFFFFFFFFu;
+            o = wo; d = wd; slabRay(o, d, id, oid); curInst = 0xFFFFFFFFu;
             if (sp > 0) HPT_POP(); else done = true;
           }
         }

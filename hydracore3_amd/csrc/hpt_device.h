@@ -1054,6 +1054,16 @@ HPT_DEV bool firstActiveLane() { const uint l = __builtin_amdgcn_mbcnt_hi(~0u, _
 // then do the lanes of the wave handle their leaves together. Mixing the three node kinds in one loop body makes a wave
 // pay for the inner-node code, the triangle code and the instance code on every step, whichever its lanes need.
 HPT_DEV V3 rcp3(V3 d) { return v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); }   // box test only
+// The ray's side of the box tests, once per ray (and per instance entered): the reciprocal direction kept FINITE - a zero component gives +-1e30,
+// the slab then reads "inside for every t" or "never" as with the infinite one, without the inf - inf of the folded form plane * id - origin * id -
+// and origin * that. Against (plane - origin) * id the distances move by a few ulp of (coordinate * id); the boxes carry a relative 1e-5 of padding
+// (Aabb::pad) and the tests their own widening for exactly that. Boxes only cull: hits are decided by the exact triangle test.
+HPT_DEV void slabRay(const V3 o, const V3 d, V3& id, V3& oid)
+{
+  const V3 r = rcp3(d);
+  id = v3(fminf(fmaxf(r.x, -1.0e30f), 1.0e30f), fminf(fmaxf(r.y, -1.0e30f), 1.0e30f), fminf(fmaxf(r.z, -1.0e30f), 1.0e30f));
+  oid = o * id;
+}
 
 // Traversal stack: the first LDS_STACK entries of a lane live in LDS ([depth][lane]: a push or pop is one conflict-free
 // ds_write/ds_read_b32 per wave); deeper entries - rare, a push only happens when both children are hit - go to a per-lane
@@ -1089,16 +1099,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef HPT_PACKED_SLABS
 #define HPT_PACKED_SLABS 0   // measured: v_pk_add/mul_f32 (12 instead of 24 instructions) is NOT faster here: Cornell 1805 vs 1820, 1M triangles 200 vs 206
 #endif
-HPT_DEV void nodeSlabs(const float4 q0, const float4 q1, const float4 q2, const V3 o, const V3 id, const float tnear, const float best,
+HPT_DEV void nodeSlabs(const float4 q0, const float4 q1, const float4 q2, const V3 oid, const V3 id, const float tnear, const float best,
                        bool& h0, bool& h1, float& t0n, float& t1n)
 {
+  // plane distance = plane * id - origin * id (slabRay: id finite, oid = origin * id): one fma per plane
 #if HPT_PACKED_SLABS
-  const f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z}, ix = {id.x, id.x}, iy = {id.y, id.y}, iz = {id.z, id.z};
-  const f32x2 ax = (f32x2{q0.x, q0.y} - ox) * ix, ay = (f32x2{q0.z, q0.w} - oy) * iy, az = (f32x2{q1.x, q1.y} - oz) * iz;
-  const f32x2 bx = (f32x2{q1.z, q1.w} - ox) * ix, by = (f32x2{q2.x, q2.y} - oy) * iy, bz = (f32x2{q2.z, q2.w} - oz) * iz;
+  const f32x2 ox = {-oid.x, -oid.x}, oy = {-oid.y, -oid.y}, oz = {-oid.z, -oid.z}, ix = {id.x, id.x}, iy = {id.y, id.y}, iz = {id.z, id.z};
+  const f32x2 ax = __builtin_elementwise_fma(f32x2{q0.x, q0.y}, ix, ox), ay = __builtin_elementwise_fma(f32x2{q0.z, q0.w}, iy, oy), az = __builtin_elementwise_fma(f32x2{q1.x, q1.y}, iz, oz);
+  const f32x2 bx = __builtin_elementwise_fma(f32x2{q1.z, q1.w}, ix, ox), by = __builtin_elementwise_fma(f32x2{q2.x, q2.y}, iy, oy), bz = __builtin_elementwise_fma(f32x2{q2.z, q2.w}, iz, oz);
 #else
-  const f32x2 ax = {(q0.x - o.x) * id.x, (q0.y - o.x) * id.x}, ay = {(q0.z - o.y) * id.y, (q0.w - o.y) * id.y}, az = {(q1.x - o.z) * id.z, (q1.y - o.z) * id.z};
-  const f32x2 bx = {(q1.z - o.x) * id.x, (q1.w - o.x) * id.x}, by = {(q2.x - o.y) * id.y, (q2.y - o.y) * id.y}, bz = {(q2.z - o.z) * id.z, (q2.w - o.z) * id.z};
+  const f32x2 ax = {__builtin_fmaf(q0.x, id.x, -oid.x), __builtin_fmaf(q0.y, id.x, -oid.x)}, ay = {__builtin_fmaf(q0.z, id.y, -oid.y), __builtin_fmaf(q0.w, id.y, -oid.y)}, az = {__builtin_fmaf(q1.x, id.z, -oid.z), __builtin_fmaf(q1.y, id.z, -oid.z)};
+  const f32x2 bx = {__builtin_fmaf(q1.z, id.x, -oid.x), __builtin_fmaf(q1.w, id.x, -oid.x)}, by = {__builtin_fmaf(q2.x, id.y, -oid.y), __builtin_fmaf(q2.y, id.y, -oid.y)}, bz = {__builtin_fmaf(q2.z, id.z, -oid.z), __builtin_fmaf(q2.w, id.z, -oid.z)};
 #endif
   t0n = fmaxf(fmaxf(fminf(ax.x, ax.y), fminf(ay.x, ay.y)), fmaxf(fminf(az.x, az.y), tnear));
   const float t0f = fminf(fminf(fmaxf(ax.x, ax.y), fmaxf(ay.x, ay.y)), fminf(fmaxf(az.x, az.y), best));
@@ -1170,7 +1181,7 @@ HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, 
   if (cur == REF_NONE) return false;
 
   V3 o = wo, d = wd;                                         // current-space ray; the world-space one is the caller's
-  V3 id = rcp3(d);
+  V3 id, oid; slabRay(o, d, id, oid);
   uint curInst = 0xFFFFFFFFu;
   int sp = 0;
 
@@ -1182,13 +1193,13 @@ HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, 
     // ---- (a) inner nodes: one 64-byte line holds both child boxes ---------------------------------------------------
     // Two copies of the loop: without the vote (small scenes - even a never-taken scalar test per step cost the Cornell box 4 %)
     // and with it (heavy scenes: leave when only a few lanes of the wave are still walking inner nodes, serve the leaves first).
-#define HPT_NODE_STEP(ORG)                                                                              \
+#define HPT_NODE_STEP()                                                                                 \
       const float4* np = (const float4*)(S.nodes + cur);                                                \
       const float4 q0 = np[0], q1 = np[1], q2 = np[2];                                                  \
       const uint4  q3 = ((const uint4*)np)[3];                                                          \
       if (STATS) { st.nodes++; if (firstActiveLane()) st.waveNodeIters++; }                             \
       bool h0, h1; float t0n, t1n;                                                                      \
-      nodeSlabs(q0, q1, q2, ORG, id, tnear, hit.t, h0, h1, t0n, t1n);                                   \
+      nodeSlabs(q0, q1, q2, oid, id, tnear, hit.t, h0, h1, t0n, t1n);                                   \
       if (h0 && h1) {                                                                                   \
         const bool firstIs0 = t0n <= t1n;                                                               \
         HPT_PUSH(firstIs0 ? q3.y : q3.x);                                                               \
@@ -1198,10 +1209,10 @@ HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, 
       else if (sp > 0) HPT_POP();                                                                       \
       else cur = REF_NONE;
     if (S.nodeMin == 0u) {
-      while ((cur & REF_LEAF) == 0u) { HPT_NODE_STEP(o) }
+      while ((cur & REF_LEAF) == 0u) { HPT_NODE_STEP() }
     } else {
       while ((cur & REF_LEAF) == 0u) {
-        HPT_NODE_STEP(o)
+        HPT_NODE_STEP()
         if ((uint)__popcll(__ballot((cur & REF_LEAF) == 0u)) < S.nodeMin) break;
       }
     }
@@ -1227,13 +1238,13 @@ HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, 
       if (STATS) st.insts++;
       if (MOTION && S.insts[inst].pad0 != 0u) toObjectSpaceMotion(S.instMotion + 24u * inst, time, wo, wd, o, d);
       else toObjectSpace(S.insts, inst, wo, wd, o, d);
-      id = rcp3(d);
+      slabRay(o, d, id, oid);
       curInst = inst;
       HPT_PUSH(REF_RESTORE);
       cur = root;
     } else {
       // marker: back to world space
-      o = wo; d = wd; id = rcp3(d); curInst = 0xFFFFFFFFu;
+      o = wo; d = wd; slabRay(o, d, id, oid); curInst = 0xFFFFFFFFu;
       if (sp > 0) HPT_POP(); else break;
     }
   }
@@ -1247,22 +1258,27 @@ HPT_DEV bool traceRay(const DevScene& S, const V3 wo, const V3 wd, float tnear, 
 // were hit by entry distance with a five-exchange network on (distance bits | child index, reference) pairs, continue with the nearest and
 // push the others farthest first. Traversal ORDER never changes a result: the closest hit is min t with ties broken by (instId, primId).
 HPT_DEV float ubyteToFloat(uint w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }      // v_cvt_f32_ubyte<k>
+// Per node the decode and the slab test are folded: plane distance = q * (scale * id) + (base * id - org * id) - one cvt and one fma per plane -
+// and the ray's octant says which of a child's two planes per axis is the near one, so no min / max pairs are spent on finding out. Against
+// decode-then-test the distances move by a few ulp of (coordinate * id); the boxes carry a relative 1e-5 of padding (Aabb::pad) for exactly that.
 template <bool DEEP>
-HPT_DEV void wideNodeStep(const DevScene& S, const TravStack& stk, const V3 org, const V3 id, const float best, uint& cur, int& sp, const float tnear = 0.0f)
+HPT_DEV void wideNodeStep(const DevScene& S, const TravStack& stk, const V3 oid, const V3 id, const float best, uint& cur, int& sp, const float tnear = 0.0f)
 {
   const uint4* np = (const uint4*)(S.nodes4 + cur);
   const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
-  const float sx = __uint_as_float((w0.w & 0xFFu) << 23), sy = __uint_as_float(((w0.w >> 8) & 0xFFu) << 23), sz = __uint_as_float(((w0.w >> 16) & 0xFFu) << 23);
-  const float bx = __uint_as_float(w0.x), by = __uint_as_float(w0.y), bz = __uint_as_float(w0.z);
+  const float sx = __uint_as_float((w0.w & 0xFFu) << 23) * id.x, sy = __uint_as_float(((w0.w >> 8) & 0xFFu) << 23) * id.y, sz = __uint_as_float(((w0.w >> 16) & 0xFFu) << 23) * id.z;
+  const float bx = __builtin_fmaf(__uint_as_float(w0.x), id.x, -oid.x), by = __builtin_fmaf(__uint_as_float(w0.y), id.y, -oid.y), bz = __builtin_fmaf(__uint_as_float(w0.z), id.z, -oid.z);
+  const bool negX = id.x < 0.0f, negY = id.y < 0.0f, negZ = id.z < 0.0f;
+  const uint nX = negX ? w1.w : w1.x, fX = negX ? w1.x : w1.w, nY = negY ? w2.x : w1.y, fY = negY ? w1.y : w2.x, nZ = negZ ? w2.y : w1.z, fZ = negZ ? w1.z : w2.y;
+  const float bestW = best * 1.0000021f;                                                       // (tn * 0.999999 <= tf * 1.000001 of nodeSlabs, as one factor on the far side)
   uint key[4], ref[4] = { w3.x, w3.y, w3.z, w3.w };
 #pragma unroll
   for (int c = 0; c < 4; c++) {
-    const float lx = __builtin_fmaf(ubyteToFloat(w1.x, c), sx, bx), ly = __builtin_fmaf(ubyteToFloat(w1.y, c), sy, by), lz = __builtin_fmaf(ubyteToFloat(w1.z, c), sz, bz);
-    const float hx = __builtin_fmaf(ubyteToFloat(w1.w, c), sx, bx), hy = __builtin_fmaf(ubyteToFloat(w2.x, c), sy, by), hz = __builtin_fmaf(ubyteToFloat(w2.y, c), sz, bz);
-    const float ax0 = (lx - org.x) * id.x, ax1 = (hx - org.x) * id.x, ay0 = (ly - org.y) * id.y, ay1 = (hy - org.y) * id.y, az0 = (lz - org.z) * id.z, az1 = (hz - org.z) * id.z;
-    const float tn = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), tnear));
-    const float tf = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), best));
-    const bool hit = (tn * 0.999999f <= tf * 1.000001f) & (((w0.w >> (24 + c)) & 1u) != 0u);
+    const float tnx = __builtin_fmaf(ubyteToFloat(nX, c), sx, bx), tny = __builtin_fmaf(ubyteToFloat(nY, c), sy, by), tnz = __builtin_fmaf(ubyteToFloat(nZ, c), sz, bz);
+    const float tfx = __builtin_fmaf(ubyteToFloat(fX, c), sx, bx), tfy = __builtin_fmaf(ubyteToFloat(fY, c), sy, by), tfz = __builtin_fmaf(ubyteToFloat(fZ, c), sz, bz);
+    const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tnear));
+    const float tf = fminf(fminf(fminf(tfx, tfy), tfz) * 1.0000021f, bestW);
+    const bool hit = (tn <= tf) & (((w0.w >> (24 + c)) & 1u) != 0u);
     key[c] = hit ? (((__float_as_uint(tn) & 0x7FFFFFFCu)) | (uint)c) : 0xFFFFFFFFu;        // tn >= 0: its bit pattern orders like the value
   }
 #define HPT_CE(a, b) do { const bool sw = key[b] < key[a]; const uint ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b], ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b]; \
@@ -1290,7 +1306,7 @@ HPT_DEV bool traceRayFlat(const DevScene& S, const V3 wo, const V3 wd, float tne
   bool found = false;
   uint cur = S.rootRef;
   if (cur == REF_NONE) return false;
-  const V3 id = rcp3(wd);
+  V3 id, oid; slabRay(wo, wd, id, oid);                       // the boxes of this layout are in world space
   V3 o = wo, d = wd;                                          // object-space ray of instance `curInst`
   uint curInst = 0xFFFFFFFFu;
   int sp = 0;
@@ -1302,14 +1318,14 @@ HPT_DEV bool traceRayFlat(const DevScene& S, const V3 wo, const V3 wd, float tne
     if (wide) {
       while ((cur & REF_LEAF) == 0u) {
         if (STATS) { st.nodes++; if (firstActiveLane()) st.waveNodeIters++; }
-        wideNodeStep<DEEP>(S, stk, wo, id, hit.t, cur, sp, tnear);
+        wideNodeStep<DEEP>(S, stk, oid, id, hit.t, cur, sp, tnear);
         if (S.nodeMin4 != 0u && (uint)__popcll(__ballot((cur & REF_LEAF) == 0u)) < S.nodeMin4) break;
       }
     } else if (S.nodeMin == 0u) {
-      while ((cur & REF_LEAF) == 0u) { HPT_NODE_STEP(wo) }
+      while ((cur & REF_LEAF) == 0u) { HPT_NODE_STEP() }
     } else {
       while ((cur & REF_LEAF) == 0u) {
-        HPT_NODE_STEP(wo)
+        HPT_NODE_STEP()
         if ((uint)__popcll(__ballot((cur & REF_LEAF) == 0u)) < S.nodeMin) break;
       }
     }

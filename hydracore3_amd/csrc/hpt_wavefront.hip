@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
 #endif
   uint slot = 0, cur = REF_NONE, curInst = 0xFFFFFFFFu;
   int  sp = 0;
-  V3 wo = v3(0, 0, 0), wd = v3(0, 0, 1), o = wo, d = wd, id = v3(0, 0, 0);
+  V3 wo = v3(0, 0, 0), wd = v3(0, 0, 1), o = wo, d = wd, id = v3(0, 0, 0), oid = v3(0, 0, 0);
   float hitT = 0.0f, hitU = 0.0f, hitV = 0.0f; uint hitPrim = 0, hitInst = 0xFFFFFFFFu, hitSlot = 0xFFFFFFFFu;
   unsigned long long nodeLane = 0, nodeWave = 0, triLane = 0, triWave = 0, refills = 0, suspended = 0;
   unsigned long long tPh[4] = {0, 0, 0, 0}, tPrev = 0, trips = 0;            // STATS: wave cycles in refill / node loop / leaves / ray end
@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
           const uint q = e[7 * 64];
           if (MOTION) rayTime = __uint_as_float(e[8 * 64]);
           slot = q & 0x3FFFFFFFu; isAny = (q >> 31) != 0u; resumed = (q & 0x40000000u) != 0u;
-          o = wo; d = wd; id = rcp3(wd);
+          o = wo; d = wd; slabRay(wo, wd, id, oid);
           cur = WIDE ? S.root4 : S.rootRef; curInst = 0xFFFFFFFFu; sp = 0; found = false;
           hitPrim = 0xFFFFFFFFu; hitInst = 0xFFFFFFFFu; hitSlot = 0xFFFFFFFFu; hitU = 0.0f; hitV = 0.0f;
           if (resumed) {                                                    // pick the traversal up where the last pass left it
@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
             else if (curInst != 0xFFFFFFFFu) {
               if (MOTION && S.insts[curInst].pad0 != 0u) toObjectSpaceMotion(S.instMotion + 24u * curInst, rayTime, wo, wd, o, d);
               else toObjectSpace(S.insts, curInst, wo, wd, o, d);
-              id = rcp3(d);
+              slabRay(o, d, id, oid);
             }
           }
           has = true;
@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
         if (STATS) trips++;
         while ((cur & REF_LEAF) == 0u) {
           if (WIDE) {
-            wideNodeStep<DEEP>(S, stk, wo, id, hitT, cur, sp);
+            wideNodeStep<DEEP>(S, stk, oid, id, hitT, cur, sp);
             if (S.nodeMin4 != 0u && (uint)__popcll(__ballot((cur & REF_LEAF) == 0u)) < S.nodeMin4) break;
             continue;
           }
@@ -350,9 +350,8 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
           const float4 q0 = np[0], q1 = np[1], q2 = np[2];
           const uint4  q3 = ((const uint4*)np)[3];
           if (STATS) { nodeLane++; if (firstActiveLane()) nodeWave++; }
-          const V3 bo = FLAT ? wo : o;                                         // flat layout: boxes are in world space
           bool h0, h1; float t0n, t1n;
-          nodeSlabs(q0, q1, q2, bo, id, 0.0f, hitT, h0, h1, t0n, t1n);
+          nodeSlabs(q0, q1, q2, oid, id, 0.0f, hitT, h0, h1, t0n, t1n);     // (flat layout: boxes in world space, id / oid stay the world ray's)
           if (h0 && h1) {
             const bool firstIs0 = t0n <= t1n;
             HPT_PUSH(firstIs0 ? q3.y : q3.x);
@@ -392,12 +391,12 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
             const uint inst = cur & 0x0FFFFFFFu;
             if (MOTION && S.insts[inst].pad0 != 0u) toObjectSpaceMotion(S.instMotion + 24u * inst, rayTime, wo, wd, o, d);
             else toObjectSpace(S.insts, inst, wo, wd, o, d);
-            id = rcp3(d);
+            slabRay(o, d, id, oid);
             curInst = inst;
             HPT_PUSH(REF_RESTORE);
             cur = S.insts[inst].root;
           } else {
-            o = wo; d = wd; id = rcp3(d); curInst = 0xFFFFFFFFu;
+            o = wo; d = wd; slabRay(o, d, id, oid); curInst = 0xFFFFFFFFu;
             if (sp > 0) HPT_POP(); else done = true;
           }
         }

@@ -192,7 +192,8 @@ def make_roofline(workload, integ, torch, dev, stream, N, W, H, spp, t_count, ke
               "note": "achieved / frac = ALGORITHMIC bytes (SURVEY 8d) over the live launch time: the top of the BVH is served by L2 / Infinity Cache, "
                       "so the counter fraction (FETCH_SIZE under the rule calibrated in profiles/r3_hbm_counter_probe.json - exact for divergent 64-B record fetches, "
                       "doubled for the shade kernel's coalesced streams - + WRITE_SIZE; Infinity-Cache hits are counted) is the memory-side figure. Random 64-B record "
-                      "fetches themselves top out at 1.1 TB/s from HBM, 3.6 TB/s from the Infinity Cache and 7.6 TB/s from L2 (same probe): the 8 TB/s peak is a streaming figure"}, **extra)
+                      "fetches reach 4.3 TB/s from HBM, 8.7 TB/s from the Infinity Cache and 13.6 TB/s from L2 (profiles/r3_quad_fetch_probe.log): the trace kernel runs at about 0.6 of "
+                      "that for its hit mix - bound by dependent-fetch latency and instruction issue, not by bytes"}, **extra)
     if pmc:
         r["lane_utilisation"] = pmc.get("lane_utilisation"); r["pmc_source"] = f"profiles/pmc_{workload}.json, commit {pmc.get('commit')}"
     return r

@@ -751,6 +751,18 @@ def test_wide_node_quantiser_is_conservative(tmp_path):
     assert r.returncode == 0 and "all conservative" in r.stdout, r.stdout + r.stderr
 
 
+def test_folded_box_tests_are_conservative(tmp_path):
+    """The trace kernels' box tests compute a plane's distance as plane * id - origin * id with a finite reciprocal direction, and in the 4-wide node
+    with the decode folded in (csrc/hpt_device.h: slabRay, nodeSlabs, wideNodeStep). Boxes only cull, so what must hold is one-sided: 1.25 million
+    rays that EXACTLY meet an unpadded box (long double) - aimed at its inside, faces, edges and corners, from near and very far, with tiny and zero
+    direction components, the reciprocal an ulp off, `best` at the exact entry distance - are all answered "hit" by the float tests on the padded
+    (and quantised) box (tests/cpp/slab_fold_test.cpp, plain g++; without Aabb::pad a quarter of them would be missed)."""
+    exe = str(tmp_path / "slab_fold_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(ROOT, "tests", "cpp", "slab_fold_test.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "all conservative" in r.stdout, r.stdout + r.stderr
+
+
 def test_exr_decoders_agree_and_read_what_was_written(tmp_path):
     """OpenEXR textures (LoadImage4fFromEXR / LoadImage1fFromEXR through tinyexr in the reference, imageutils.cpp:317-392): the Python and the C++
     decoder read tests/golden/exr/*.exr (written by make_exr_scene.py: ZIPS + HALF RGB, NONE + FLOAT single channel with an infinity, ZIP + HALF

@@ -515,10 +515,37 @@ HPT_DEV void drClearShadowTerm(float* record, size_t s, size_t idx, uint bounce)
 static const uint DR_STAGE_DWORDS = 16u * 64u;
 HPT_DEV void drReverseSweep(const DevScene& S, const float* record, size_t s, size_t idx, const bool closing, const uint bounceIn, V3 Rn, const V3 diff,
                             float* grad, const bool skipNonFinite, uint* stage, const DrRec& last, const bool lastInRegs,
-                            unsigned long long* statAtomics = nullptr, const uint ss = 64u)      // ss: dwords between the staging area's rows (64: an area of its own; 256: the wave's columns of a [16][256] array)
+                            unsigned long long* statAtomics = nullptr, const uint ss = 64u, const bool defer = true)      // ss: dwords between the staging area's rows (64: an area of its own; 256: the wave's columns of a [16][256] array)
 {
   const uint bounce = closing ? bounceIn : 0u;
   const uint lane = lane_id();
+  // The scatter can be DEFERRED (the megakernels): every level appends its (taps, values) columns to the staging area and the atomics of all levels go out together at the
+  // end (or when the 64 columns are full). Atomics, stores and loads share one in-order counter (vmcnt), so a record load issued behind a level's
+  // atomics would wait for them to complete at the memory side (~1 ... 3 k cycles each time); this way the levels' loads only wait for each other:
+  // PathTraceDR on the test_228 class 467 -> 477 (block-local), 415 -> 431 (megakernel). The wavefront shade kernel scatters level by level (defer = false):
+  // with its many short sweeps in flight the bunched atomics stall the issue instead (256 -> 249, 1 M triangles 229 -> 224 when deferred).
+  uint cnt = 0;                                                             // columns staged so far (wave-uniform)
+  auto flush = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (statAtomics && lane == 0u) *statAtomics += (12u * cnt + 63u) / 64u;       // (instrumented build: atomic wave-instructions of this sweep)
+    for (uint p = lane; p < 12u * cnt; p += 64u) {
+      const uint src = (p * 0xAAABu) >> 19;                               // p / 12 (p < 768)
+      const uint e = p - 12u * src, tap = (e * 11u) >> 5, ch = e - 3u * tap;   // e / 3, e % 3 (e < 12)
+      const uint ix0 = stage[12 * ss + src];
+      const uint ix = (ix0 & 0x7FFFFFFFu) + ((tap & 1u) ? stage[13 * ss + src] : 0u) + ((tap & 2u) ? stage[14 * ss + src] : 0u);   // (two's complement: negative steps wrap back)
+      const float val = ((const float*)stage)[e * ss + src];
+#ifndef HPT_DR_NO_ATOMICS    // diagnostic build only: how much of PathTraceDR is the gradient scatter?
+      if ((ix0 & 0x80000000u) == 0u) atomicAdd(grad + (size_t)ix + ch, val);
+      else if (ch == 0u) atomicAdd(grad + (size_t)ix, val);
+#else
+      if (ix == 0x7FFFFFFFu) grad[0] = val;
+#endif
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    cnt = 0;
+  };
   for (int b = (int)S.traceDepth - 1; b >= 0; b--) {                      // wave-uniform trip count; a lane joins at its own last bounce
     const bool mine = (uint)b < bounce;
     if (__ballot(mine) == 0ull) continue;
@@ -536,7 +563,9 @@ HPT_DEV void drReverseSweep(const DevScene& S, const float* record, size_t s, si
     const bool has = mine && e0 != 0xFFFFFFFFu;
     const unsigned long long hm = __ballot(has);
     if (hm != 0ull) {
-      const uint n = (uint)__popcll(hm), rk = mbcnt64(hm);
+      const uint n = (uint)__popcll(hm);
+      if (cnt + n > 64u) flush();
+      const uint col = cnt + mbcnt64(hm);
       if (has) {
         const V3 dC = TdS + TdA * Rn;
         V3 g = v3(2.0f * diff.x * dC.x, 2.0f * diff.y * dC.y, 2.0f * diff.z * dC.z);
@@ -546,33 +575,18 @@ HPT_DEV void drReverseSweep(const DevScene& S, const float* record, size_t s, si
         const float w[4] = { fx1 * fy1, fx * fy1, fx1 * fy, fx * fy };      // bilinearTaps' weights, the same products
         float* sv = (float*)stage;
         for (int k = 0; k < 4; k++) {
-          sv[(3 * k + 0) * ss + rk] = four ? g.x * w[k] : (g.x + g.y + g.z) * w[k];
-          sv[(3 * k + 1) * ss + rk] = g.y * w[k];
-          sv[(3 * k + 2) * ss + rk] = g.z * w[k];
+          sv[(3 * k + 0) * ss + col] = four ? g.x * w[k] : (g.x + g.y + g.z) * w[k];
+          sv[(3 * k + 1) * ss + col] = g.y * w[k];
+          sv[(3 * k + 2) * ss + col] = g.z * w[k];
         }
-        stage[12 * ss + rk] = e0; stage[13 * ss + rk] = (uint)dx; stage[14 * ss + rk] = (uint)dy;
+        stage[12 * ss + col] = e0; stage[13 * ss + col] = (uint)dx; stage[14 * ss + col] = (uint)dy;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (statAtomics && lane == 0u) *statAtomics += (12u * n + 63u) / 64u;         // (instrumented build: atomic wave-instructions of this sweep)
-      for (uint p = lane; p < 12u * n; p += 64u) {
-        const uint src = (p * 0xAAABu) >> 19;                             // p / 12 (p < 768)
-        const uint e = p - 12u * src, tap = (e * 11u) >> 5, ch = e - 3u * tap;   // e / 3, e % 3 (e < 12)
-        const uint ix0 = stage[12 * ss + src];
-        const uint ix = (ix0 & 0x7FFFFFFFu) + ((tap & 1u) ? stage[13 * ss + src] : 0u) + ((tap & 2u) ? stage[14 * ss + src] : 0u);   // (two's complement: negative steps wrap back)
-        const float val = ((const float*)stage)[e * ss + src];
-#ifndef HPT_DR_NO_ATOMICS    // diagnostic build only: how much of PathTraceDR is the gradient scatter?
-        if ((ix0 & 0x80000000u) == 0u) atomicAdd(grad + (size_t)ix + ch, val);
-        else if (ch == 0u) atomicAdd(grad + (size_t)ix, val);
-#else
-        if (ix == 0x7FFFFFFFu) grad[0] = val;
-#endif
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      cnt += n;
+      if (!defer) flush();
     }
     if (mine) Rn = Sb + A * Rn;
   }
+  if (cnt != 0u) flush();
 }
 
 } // namespace hpt

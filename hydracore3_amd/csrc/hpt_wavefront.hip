@@ -177,7 +177,7 @@ __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const W
 #ifndef HPT_DBG_DR_NOSWEEP   // diagnostic builds only (profiles/dr_ab.sh)
   if (DR && __any(closing))
     drReverseSweep(S, job.record, job.itemCount, s < job.itemCount ? s : 0u, closing, sweepBounce, sweepTail, sweepDiff, job.grad, job.drSkipNonFinite != 0u,
-                   drStage + (threadIdx.x >> 6) * DR_STAGE_DWORDS, lastRec, lastInRegs);
+                   drStage + (threadIdx.x >> 6) * DR_STAGE_DWORDS, lastRec, lastInRegs, nullptr, 64u, false);
 #endif
   // ray compaction: ballot + prefix sum, one atomic per wave and queue
   const bool qNear = active && alive, qShad = active && wantShadow;

@@ -1784,9 +1784,9 @@ static void launchWfTrace(hpt_ctx* c, const WfPool& P, uint iter, int blocks, hi
     }
     return;
   }
-  if (!STATS && wfWide(c)) {                                    // the 4-wide compressed tree (static single-level scenes)
-    if (c->stackNeeded4 > (uint)LDS_STACK) wfTraceKernel<true, true, false, false, true><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
-    else                                   wfTraceKernel<false, true, false, false, true><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
+  if (wfWide(c)) {                                              // the 4-wide compressed tree (static single-level scenes)
+    if (c->stackNeeded4 > (uint)LDS_STACK) wfTraceKernel<true, true, STATS, false, true><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
+    else                                   wfTraceKernel<false, true, STATS, false, true><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
     return;
   }
   if (c->S.flatMode) {

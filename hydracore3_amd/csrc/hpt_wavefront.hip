@@ -342,6 +342,7 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
         if (STATS) trips++;
         while ((cur & REF_LEAF) == 0u) {
           if (WIDE) {
+            if (STATS) { nodeLane++; if (firstActiveLane()) nodeWave++; }
             wideNodeStep<DEEP>(S, stk, oid, id, hitT, cur, sp);
             if (S.nodeMin4 != 0u && (uint)__popcll(__ballot((cur & REF_LEAF) == 0u)) < S.nodeMin4) break;
             continue;
@@ -476,6 +477,8 @@ HPT_WFT(false, false, true)  HPT_WFT(true, false, true)  HPT_WFT(false, true, tr
 HPT_WFTM(false, false) HPT_WFTM(true, false) HPT_WFTM(false, true) HPT_WFTM(true, true)
 template __global__ void wfTraceKernel<false, true, false, false, true>(const DevScene, const WfPool, uint, uint, uint, uint*, uint, Counters*);   // 4-wide compressed tree
 template __global__ void wfTraceKernel<true,  true, false, false, true>(const DevScene, const WfPool, uint, uint, uint, uint*, uint, Counters*);
+template __global__ void wfTraceKernel<false, true, true, false, true>(const DevScene, const WfPool, uint, uint, uint, uint*, uint, Counters*);   // instrumented (hpt_set_option "wf_stats")
+template __global__ void wfTraceKernel<true,  true, true, false, true>(const DevScene, const WfPool, uint, uint, uint, uint*, uint, Counters*);
 #endif
 
 } // namespace hpt

@@ -1088,10 +1088,12 @@ HPT_DEV uint stkPop(const TravStack& k, int sp)
   return v;
 }
 
-// Slab test of both children of a node against a ray (origin o, reciprocal direction id, interval [tnear, best]).
-// The node stores (lo, hi) pairs per axis, so each axis of each child CAN be one packed subtract and one packed multiply
-// (HPT_PACKED_SLABS: v_pk_add_f32 / v_pk_mul_f32, 12 instructions instead of 24, same rounding) - measured slower, off by default. Boxes were padded by the builder; the interval is widened a little more so that rounding (and the 1-ulp reciprocal)
-// can only make the test more conservative than the exact triangle test.
+// Slab test of both children of a node against a ray (slabRay: finite reciprocal direction id, oid = origin * id; interval [tnear, best]).
+// One fma per plane. (Round 2 tried the fma form with the raw reciprocal and dropped it after 8 parity failures: with id = +-inf every plane of that
+// axis reads inf - inf; the finite reciprocal is what makes it work.) The node stores (lo, hi) pairs per axis, so each axis of each child CAN be one
+// packed fma (HPT_PACKED_SLABS: 6 instructions instead of 12) - packed math measured slower in round 2, off by default. Boxes were padded by the
+// builder; the interval is widened a little more so that rounding (and the 1-ulp reciprocal) can only make the test more conservative than the exact triangle test
+// (tests/cpp/slab_fold_test.cpp).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef HPT_FLAT_WIDE
 #define HPT_FLAT_WIDE 0      // 1: the megakernel's single-level traversal walks the 4-wide compressed tree on EVERY scene that has one (default: heavy scenes only, DevScene::megaWide)

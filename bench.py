@@ -552,7 +552,7 @@ def run_fixture(dev, scene_name, spectral, steps=3, size=1024, spp=64, profile=N
         traffic = tj["hbm_bytes_per_launch"] * paths / float(tj["paths_per_launch"]) if tj else None
         roof = {"bound": "valu", "achieved": round(ginst, 2), "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwaveinst/s", "frac": round(ginst / VALU_PEAK_GINST, 4),
                 "traffic": traffic, "lane_utilisation": pmc.get("lane_utilisation"), "useful_lane_frac": round(ginst / VALU_PEAK_GINST * pmc.get("lane_utilisation", 0.0), 4),
-                "kernel": (("pathTraceBlockSpectralKernel (block-local schedule)" if integ.last_launch()["schedule"] == 3 else "pathTraceSpectralKernel") if spectral
+                "kernel": (({3: "pathTraceBlockSpectralKernel (block-local schedule)", 2: "wavefront: wfShadeSpecKernel + wfTraceKernel"}.get(integ.last_launch()["schedule"], "pathTraceSpectralKernel")) if spectral
                            else "pathTraceKernel<MODE 4: thin films>"), "kernel_ms": round(mean_ms, 3),
                 "hbm_counter_frac": round(traffic / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
                 "pmc_source": f"profiles/pmc_{profile}.json, collected at commit {pmc.get('commit')}: SQ_INSTS_VALU per path and lane utilisation; the kernel time is measured in this run"}

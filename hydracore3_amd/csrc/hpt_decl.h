@@ -109,6 +109,8 @@ struct WfPool
   float*  lossSlot;  // DR: per-slot sum of the pixel's sample losses (reduced in double at the end: one float accumulator for 10^7..10^8
                      // samples loses the small increments - measured 1.5 % low on the 1M-triangle scene)
   float*  time;      // motion blur: the path's time in [0, 1] (drawn at regeneration, read by the trace pass and by the shading of every vertex)
+  float4* waves;     // spectral rendering (wfShadeSpecKernel): the path's four wavelengths; thr / acc / contrib then hold four samples each and
+  uint2*  fb;        // ... the flags and the bounce counter live here
   uint*   inflight;  // bit 0 / 1: the slot's closest-hit / shadow ray was suspended by a trace pass and has not finished yet
   uint*   rayQ[2];   // compacted ray queue of round (iteration & 1): slot id | (shadow ray ? 1 << 31 : 0) | (resumed ray ? 1 << 30 : 0)
   uint*   susp[2];   // traversal state of the rays a trace pass suspended, written for the NEXT round: [WF_SUSP_WORDS + stack][maxSusp],
@@ -147,7 +149,32 @@ struct WfJob
 #endif
 #define HPT_WFS_BOUNDS(DR, LEAN) __launch_bounds__(256, (DR) ? HPT_WF_SHADE_DR_WAVES : ((LEAN) ? HPT_WF_SHADE_WAVES : HPT_WF_SHADE_FULL_WAVES))
 
+// Ray compaction of the shade kernels. Every wave ballots its two kinds of rays and prefix-sums the lanes (mbcnt); the four waves of the block add
+// their counts in LDS and ONE atomicAdd per block reserves the block's run of the queue. (One atomic per wave was measured at
+// 0.97 ms per shade pass over 2M slots: ~100 K atomics on one address serialise in a single L2 channel.)
+HPT_DEV void blockAppend(uint* counter, bool qNear, bool qShad, uint& posNear, uint& posShad)
+{
+  __shared__ uint waveCnt[4];
+  __shared__ uint blockBase;
+  const unsigned long long mn = __ballot(qNear), ms = __ballot(qShad);
+  const uint cn = (uint)__popcll(mn), cs = (uint)__popcll(ms);
+  const uint wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63u) == 0u) waveCnt[wave] = cn + cs;
+  __syncthreads();
+  if (threadIdx.x == 0u) {
+    const uint tot = waveCnt[0] + waveCnt[1] + waveCnt[2] + waveCnt[3];
+    blockBase = tot ? atomicAdd(counter, tot) : 0u;
+  }
+  __syncthreads();
+  uint base = blockBase;
+  for (uint w = 0; w < wave; w++) base += waveCnt[w];
+  posNear = base + mbcnt64(mn);
+  posShad = base + cn + mbcnt64(ms);
+}
+
 __global__ void wfInitKernel(WfPool P, uint n, uint passNum);
+template <int SCOPE>                                                    // spectral rendering under the wavefront schedule (hpt_spectral.hip)
+__global__ void __launch_bounds__(256, SCOPE == 2 ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAVES) wfShadeSpecKernel(const DevScene S, const WfPool P, const WfJob job);
 template <bool DR, bool LEAN, bool MOTION = false, bool FILM = false>   // FILM: shadeVertex<FILM> (thin films, hpt_film.h)
 __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const WfPool P, const WfJob job);
 template <bool DEEP, bool FLAT, bool STATS, bool MOTION = false, bool WIDE = false>   // WIDE: walk DevScene::nodes4 (4-wide compressed nodes) instead of the BVH2

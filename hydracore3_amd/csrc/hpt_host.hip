@@ -40,6 +40,7 @@ using namespace hpt;
 // triangles 30 ... 60 - all fastest on the wavefront schedule with the vote (4 850 triangles: 340 vs 254). The triangle count does not
 // separate the two families (test_228 has more triangles than the smallest interior).
 static const float  HEAVY_SAH_VISITS = 20.0f;
+static const uint   WF_AUTO_PIXELS = 1u << 19;            // fewer pixels per call cannot keep the wavefront trace kernel's lanes supplied (see useWavefront)
 static const size_t FLAT_AUTO_TRIS = size_t(1) << 12;      // instanced triangles from which the single-level layout is chosen whatever the instance count
 // Tiny scenes (the Cornell-box class): no tree walk at all, the wave sweeps the instances' triangles with scalar loads (hpt_device.h: traceSweep).
 // Cost is linear in the triangle count (one exact triangle test per lane and triangle, ~72 VALU instructions at 100 % lane utilisation) against
@@ -139,7 +140,7 @@ struct hpt_ctx
   // stream, so that the tail of one group's trace pass overlaps the other groups' work
   struct WfGroup
   {
-    DevBuf<float4> f4[8]; DevBuf<uint> u[9]; DevBuf<float> rec, lossSlot, time;
+    DevBuf<float4> f4[8], waves; DevBuf<uint2> fb; DevBuf<uint> u[9]; DevBuf<float> rec, lossSlot, time;
     hipStream_t stream = nullptr; hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; hipEvent_t done = nullptr;
     uint* progress = nullptr;            // pinned: rays queued after every WF_CHECK-th shade pass (0 = group finished)
     uint checkpoints = 0, itemBase = 0, itemCount = 0; unsigned long long it = 0; bool finished = false;
@@ -1506,7 +1507,7 @@ static int gridBlocks(hpt_ctx* c, bool dr, bool fullMaterials = false)
 
 static bool useWavefront(hpt_ctx* c, bool naive, bool dr, bool stats, uint tidCount);
 static bool wfWide(const hpt_ctx* c);
-static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr);
+static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr, int specScope = -1);
 
 // DEEP: the scene's BVH can need more than LDS_STACK stack entries, so pushes / pops check for the HBM overflow part
 // FLAT: single-level world-space BVH (static scenes within FLAT_TRI_BUDGET) vs two-level TLAS/BLAS
@@ -1626,6 +1627,13 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
     // instances and sweep scenes keep the one-thread-per-pixel kernel. hpt_set_schedule(1) / (3) force either.
     const bool specBlock = !inRays && c->S.motion == 0u && c->S.sweep == 0u && (c->S.traceDepth > 0u || naive) &&
                            (c->schedule == 3 || (c->schedule == 0 && c->sahVisits >= BLOCK_SAH_VISITS));
+    // ... and heavy scenes in calls with enough pixels the wavefront schedule (wfShadeSpecKernel + the shared trace kernel), as their RGB rendering does
+    const bool specWave = !inRays && !naive && c->S.motion == 0u && c->S.sweep == 0u && c->S.traceDepth > 0u && !c->instrument &&
+                          (c->schedule == 2 || (c->schedule == 0 && c->sahVisits >= HEAVY_SAH_VISITS && job.tidCount >= WF_AUTO_PIXELS));
+    if (specWave) {
+      c->lastSchedule = 2; c->lastWide = wfWide(c) ? 1u : 0u; c->lastDeep = (c->lastWide ? c->stackNeeded4 : c->stackNeeded) > (uint)LDS_STACK ? 1u : 0u; c->lastShadeRecords = 0u;
+      return launch_wavefront(c, job, st, false, scope == 0 ? 1 : scope);
+    }
     if (specBlock) {
       const bool bwide = c->S.megaWide != 0u && c->S.flatMode != 0u && c->nodes4Count != 0u;
       const bool bdeep = (bwide ? std::max(c->stackNeeded, c->stackNeeded4) : c->stackNeeded) > (uint)LDS_STACK;
@@ -1750,7 +1758,6 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
 // ---- wavefront schedule ---------------------------------------------------------------------------------------------------------------
 // Heavy scenes (HEAVY_SAH_VISITS) are rendered by the shade / trace kernel pair; on light ones the path state's trip through HBM costs more
 // than the ray replacement gains (measured crossover: see DESIGN.md, "two schedules").
-static const uint   WF_AUTO_PIXELS = 1u << 19;
 static const uint   WF_POOL_MAX = 1u << 22;        // pool slots (pixels in flight) per batch: 4M x 148 B = 620 MB
 static const uint   WF_CHECK = 8;                  // progress word copied back every WF_CHECK shade passes
 static const uint   WF_RING = 8;                   // ... and at most WF_RING such checkpoints in flight
@@ -1770,36 +1777,51 @@ static bool wfWide(const hpt_ctx* c) { return c->wideEnabled && c->S.flatMode !=
 static uint wfStackNeeded(const hpt_ctx* c) { return std::max(std::max(c->stackNeeded, wfWide(c) ? c->stackNeeded4 : 0u), 1u); }   // entries a suspended ray may have to save
 
 template <bool STATS>
-static void launchWfTrace(hpt_ctx* c, const WfPool& P, uint iter, int blocks, hipStream_t st, bool deep, uint* ovf)
+static void launchWfTrace(hpt_ctx* c, const DevScene& S, const WfPool& P, uint iter, int blocks, hipStream_t st, bool deep, uint* ovf)
 {
   const uint lanes = (uint)blocks * 256u; Counters* cn = c->dCounters.p;
   const uint grace = c->wfGrace;
   if (c->S.motion != 0u && !STATS) {                           // moving instances: the rays carry their path's time
     if (c->S.flatMode) {
-      if (deep) wfTraceKernel<true, true, false, true><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
-      else      wfTraceKernel<false, true, false, true><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
+      if (deep) wfTraceKernel<true, true, false, true><<<dim3(blocks), dim3(256), 0, st>>>(S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
+      else      wfTraceKernel<false, true, false, true><<<dim3(blocks), dim3(256), 0, st>>>(S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
     } else {
-      if (deep) wfTraceKernel<true, false, false, true><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
-      else      wfTraceKernel<false, false, false, true><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
+      if (deep) wfTraceKernel<true, false, false, true><<<dim3(blocks), dim3(256), 0, st>>>(S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
+      else      wfTraceKernel<false, false, false, true><<<dim3(blocks), dim3(256), 0, st>>>(S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
     }
     return;
   }
   if (wfWide(c)) {                                              // the 4-wide compressed tree (static single-level scenes)
-    if (c->stackNeeded4 > (uint)LDS_STACK) wfTraceKernel<true, true, STATS, false, true><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
-    else                                   wfTraceKernel<false, true, STATS, false, true><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
+    if (c->stackNeeded4 > (uint)LDS_STACK) wfTraceKernel<true, true, STATS, false, true><<<dim3(blocks), dim3(256), 0, st>>>(S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
+    else                                   wfTraceKernel<false, true, STATS, false, true><<<dim3(blocks), dim3(256), 0, st>>>(S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
     return;
   }
   if (c->S.flatMode) {
-    if (deep) wfTraceKernel<true, true, STATS><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
-    else      wfTraceKernel<false, true, STATS><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
+    if (deep) wfTraceKernel<true, true, STATS><<<dim3(blocks), dim3(256), 0, st>>>(S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
+    else      wfTraceKernel<false, true, STATS><<<dim3(blocks), dim3(256), 0, st>>>(S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
   } else {
-    if (deep) wfTraceKernel<true, false, STATS><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
-    else      wfTraceKernel<false, false, STATS><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
+    if (deep) wfTraceKernel<true, false, STATS><<<dim3(blocks), dim3(256), 0, st>>>(S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
+    else      wfTraceKernel<false, false, STATS><<<dim3(blocks), dim3(256), 0, st>>>(S, P, iter, c->wfRefillBelow, grace, ovf, lanes, cn);
   }
 }
 
-static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr)
+static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr, int specScope)   // specScope >= 0: spectral rendering (wfShadeSpecKernel<scope>)
 {
+  const bool spec = specScope >= 0;
+  DevScene Sw = c->S;
+  if (spec) Sw.shadeTris = nullptr;                  // the spectral shade kernel fetches its surface through the primitive id: the trace pass must report that
+  auto launchShade = [&](const dim3 sg, hipStream_t gs, const WfPool& P, const WfJob& wj) {
+    if (spec) {
+      if (specScope == 3) wfShadeSpecKernel<3><<<sg, dim3(256), 0, gs>>>(Sw, P, wj);
+      else if (specScope == 2) wfShadeSpecKernel<2><<<sg, dim3(256), 0, gs>>>(Sw, P, wj);
+      else wfShadeSpecKernel<1><<<sg, dim3(256), 0, gs>>>(Sw, P, wj);
+    }
+    else if (dr)               wfShadeKernel<true, true><<<sg, dim3(256), 0, gs>>>(c->S, P, wj);
+    else if (c->hasFilm)       { if (c->S.motion) wfShadeKernel<false, false, true, true><<<sg, dim3(256), 0, gs>>>(c->S, P, wj); else wfShadeKernel<false, false, false, true><<<sg, dim3(256), 0, gs>>>(c->S, P, wj); }
+    else if (c->S.motion)      wfShadeKernel<false, false, true><<<sg, dim3(256), 0, gs>>>(c->S, P, wj);
+    else if (c->leanMaterials && !c->forceFull && c->S.lensCount == 0u) wfShadeKernel<false, true><<<sg, dim3(256), 0, gs>>>(c->S, P, wj);
+    else                       wfShadeKernel<false, false><<<sg, dim3(256), 0, gs>>>(c->S, P, wj);
+  };
   // ---- groups: contiguous runs of work items, whole 256-item blocks each ----
   uint nGroups = c->wfGroupCount > 0 ? (uint)c->wfGroupCount : WF_GROUPS_AUTO;
   nGroups = std::max(nGroups, (job.tidCount + WF_POOL_MAX - 1) / WF_POOL_MAX);
@@ -1857,7 +1879,9 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr)
     HIPCHK(c, g.u[7].alloc(suspWords)); HIPCHK(c, g.u[8].alloc(suspWords));
     if (dr) { HIPCHK(c, g.rec.alloc((size_t)g.itemCount * REC_FIELDS * (c->S.traceDepth + 1))); HIPCHK(c, g.lossSlot.alloc(g.itemCount)); }
     if (c->S.motion) HIPCHK(c, g.time.alloc(g.itemCount));
+    if (spec) { HIPCHK(c, g.waves.alloc(g.itemCount)); HIPCHK(c, g.fb.alloc(g.itemCount)); }
     WfPool& P = pools[gi];
+    P.waves = spec ? g.waves.p : nullptr; P.fb = spec ? g.fb.p : nullptr;
     P.rayO = g.f4[0].p; P.rayD = g.f4[1].p; P.thr = g.f4[2].p; P.acc = g.f4[3].p;
     P.shO = g.f4[4].p; P.shD = g.f4[5].p; P.contrib = g.f4[6].p; P.hit = g.f4[7].p;
     P.hitInst = g.u[0].p; P.occl = g.u[1].p; P.lossSlot = dr ? g.lossSlot.p : nullptr; P.time = c->S.motion ? g.time.p : nullptr; P.status = g.u[2].p; P.rayQ[0] = g.u[3].p; P.rayQ[1] = g.u[5].p; P.ctr = g.u[4].p; P.inflight = g.u[6].p;
@@ -1874,11 +1898,7 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr)
       const WfPool& P = pools[gi];
       wj.itemBase = g.itemBase; wj.itemCount = g.itemCount; wj.iter = (uint)g.it; wj.record = g.rec.p;
       const dim3 sg((g.itemCount + 255u) / 256u);
-      if (dr)                    wfShadeKernel<true, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
-      else if (c->hasFilm)       { if (c->S.motion) wfShadeKernel<false, false, true, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj); else wfShadeKernel<false, false, false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj); }
-      else if (c->S.motion)      wfShadeKernel<false, false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
-      else if (c->leanMaterials && !c->forceFull && c->S.lensCount == 0u) wfShadeKernel<false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
-      else                       wfShadeKernel<false, false><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
+      launchShade(sg, g.stream, P, wj);
       if ((g.it % WF_CHECK) == WF_CHECK - 1) {
         const uint slot = g.checkpoints % WF_RING;
         if (g.checkpoints >= WF_RING) {                                     // oldest checkpoint of the ring: wait for it, then look at it
@@ -1897,18 +1917,14 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr)
       }
       if (!g.finished) {
         uint* ovf = c->dStackOvf.p + gi * ovfPerGroup;
-        if (stats) launchWfTrace<true>(c, P, wj.iter, traceBlocks, g.stream, deep, ovf); else launchWfTrace<false>(c, P, wj.iter, traceBlocks, g.stream, deep, ovf);
+        if (stats) launchWfTrace<true>(c, Sw, P, wj.iter, traceBlocks, g.stream, deep, ovf); else launchWfTrace<false>(c, Sw, P, wj.iter, traceBlocks, g.stream, deep, ovf);
         g.it++;
         if (gi == 0) c->lastWfIters++;
         if (g.it >= iterCap) {
           // The safety net tripped. One more shade pass tells whether anything is left: it queues a ray for every path still alive and the
           // rays the last trace pass suspended are already counted in the same word. Work left = an incomplete frame: say so.
           wj.iter = (uint)g.it;
-          if (dr)                    wfShadeKernel<true, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
-          else if (c->hasFilm)       { if (c->S.motion) wfShadeKernel<false, false, true, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj); else wfShadeKernel<false, false, false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj); }
-          else if (c->S.motion)      wfShadeKernel<false, false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
-          else if (c->leanMaterials && !c->forceFull && c->S.lensCount == 0u) wfShadeKernel<false, true><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
-          else                       wfShadeKernel<false, false><<<sg, dim3(256), 0, g.stream>>>(c->S, P, wj);
+          launchShade(sg, g.stream, P, wj);
           uint left = 0;
           HIPCHK(c, hipMemcpyAsync(&left, P.ctr + WF_CTR_WORDS * (wj.iter & 1u), sizeof(uint), hipMemcpyDeviceToHost, g.stream));
           HIPCHK(c, hipStreamSynchronize(g.stream));

@@ -761,6 +761,114 @@ __global__ void __launch_bounds__(256, SCOPE_ == 2 ? HPT_SPEC_WIDE_WAVES : HPT_S
 #undef PIX_PASSES
 }
 
+// ---- wavefront schedule ---------------------------------------------------------------------------------------------------------------------------
+// Heavy scenes in calls with enough pixels (hpt_host.hip: useWavefront's rule): the shade half of a bounce as wfShadeKernel has it for RGB - one lane per
+// pool slot, the previous shadow ray folded in first, shadeVertexSpec for the closest hit, path ends and regeneration in place, the slot's rays appended to
+// the queue the shared trace kernel (hpt_wavefront.hip: wfTraceKernel, the 4-wide tree with ray replacement) drains. Four samples per radiance-valued word:
+// WfPool::thr / acc / contrib are used in full, the wavelengths and (flags, bounce) have arrays of their own. Same arithmetic in the same order as the
+// plain kernel: bit-identical frames (tests/test_gpu_spectral.py). PathTraceBlock only (no naive / input-ray / moving-instance variant: those keep their kernels).
+template <int SCOPE_>
+__global__ void __launch_bounds__(256, SCOPE_ == 2 ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAVES) wfShadeSpecKernel(const DevScene S, const WfPool P, const WfJob job)
+{
+  constexpr int SCOPE = SCOPE_ == 3 ? 2 : SCOPE_;
+  const uint s = blockIdx.x * 256u + threadIdx.x;
+  uint* ctr = P.ctr + WF_CTR_WORDS * (job.iter & 1u);
+  if (s <= WF_RANGES) P.ctr[WF_CTR_WORDS * ((job.iter + 1u) & 1u) + 32u * s] = 0u;   // counters of the NEXT round (its trace pass is long done)
+
+  bool valid = s < job.itemCount;
+  uint tid = 0;
+  if (valid) {
+    const uint k = job.itemBase + s;
+    tid = job.tidBegin + (k / job.tidChunk) * job.tidChunk * job.tidStride + (k % job.tidChunk);
+    valid = tid < job.tidEnd;
+  }
+  if (valid && P.inflight[s] != 0u) valid = false;       // a suspended ray of this pixel is still being traced: the pixel sits this round out
+  uint st = valid ? P.status[s] : 0u;
+  uint passes = st >> 8;
+  bool alive = (st & WF_ALIVE) != 0u, pend = (st & WF_PEND) != 0u, ending = (st & WF_ENDING) != 0u;
+  const bool active = valid && (alive || pend || ending || passes != 0u);
+  bool wantShadow = false;
+
+  if (active) {
+    Rng gen = job.gens[tid];
+    const uint XY = job.packedXY[tid];
+    V4 accum = v4s(0.0f), thr = v4s(1.0f), waves = v4s(0.0f), contrib = v4s(0.0f);
+    V3 rpos = v3(0, 0, 0), rdir = v3(0, 0, 1);
+    float misPdf = 1.0f, misIor = 1.0f; uint flags = 0, bounce = 0;
+    if (alive || ending) {
+      const float4 a = P.acc[s], w = P.waves[s]; const uint2 f = P.fb[s];
+      accum = v4(a.x, a.y, a.z, a.w); waves = v4(w.x, w.y, w.z, w.w); flags = f.x; bounce = f.y;
+    }
+    // the shadow ray traced since the last visit: add the candidate contribution in the plain kernel's order
+    if (pend) {
+      if (P.occl[s] == 0u) { const float4 c = P.contrib[s]; accum = accum + v4(c.x, c.y, c.z, c.w); }
+      pend = false;
+    }
+    bool finalize = ending;                                                // path ended last time, only its shadow ray was outstanding
+    ending = false;
+    V3 shPos = v3(0, 0, 0), shDir = v3(0, 0, 1); float shFar = 0.0f;
+    if (alive) {
+      const float4 ro = P.rayO[s], rd = P.rayD[s], t4 = P.thr[s], h4 = P.hit[s];
+      rpos = v3(ro.x, ro.y, ro.z); misPdf = ro.w; rdir = v3(rd.x, rd.y, rd.z); misIor = rd.w;
+      thr = v4(t4.x, t4.y, t4.z, t4.w);
+      HitRec hit; hit.t = h4.x; hit.u = h4.y; hit.v = h4.z; hit.prim = __float_as_uint(h4.w); hit.inst = P.hitInst[s];   // (the host hands the trace pass a scene without shading records: primitive ids come back)
+      shadeVertexSpec<SCOPE, false>(S, hit, rpos, rdir, waves, accum, thr, misPdf, misIor, flags, bounce, gen, false, wantShadow, shPos, shDir, shFar, contrib, 0.0f);
+      bounce++;                                                              // (the plain kernel counts every trip, a miss included)
+      if ((flags & RAY_FLAG_IS_DEAD) != 0 || bounce >= S.traceDepth) {
+        alive = false;
+        if (wantShadow) ending = true; else finalize = true;
+      }
+    }
+    if (finalize) {
+      if ((flags & RAY_FLAG_OUT_OF_SCENE) != 0) {                            // kernel_HitEnvironment (a ray that left the scene sampled no light: never a slot whose shadow ray was outstanding)
+        V4 env = ld4(S.envColor);
+        if (SCOPE >= 2) env = environmentRadianceSpec(S, rdir, waves, misPdf, flags, XY);
+        else if (S.envSpecId != 0xFFFFFFFFu) env = sampleUniformSpectrum(S.specValues, S.specOffsetSz[2u * S.envSpecId], waves) * (S.envSpecMult / 106.856895f);
+        if (S.integratorType == INTEGRATOR_STUPID_PT) accum = thr * env; else accum = accum + thr * env;
+      }
+      // kernel_ContributeToImage (integrator_pt.cpp:598-657), spectral: the pixel is this slot's alone
+      const uint pixel = ((XY & 0xFFFF0000u) >> 16) * (uint)S.winWidth + (XY & 0x0000FFFFu);
+      if (job.channels == 1) job.outColor[pixel] += accum.x * S.exposureMult;
+      else if (job.channels > 4) {
+        const V4 color = accum * S.exposureMult;
+        for (int i = 0; i < 4; i++) {
+          const float t = (comp(waves, i) - LAMBDA_MIN) / (LAMBDA_MAX - LAMBDA_MIN);
+          const int channelId = min(int(float(job.channels) * t), int(job.channels) - 1);
+          job.outColor[(size_t)channelId * (size_t)(S.winWidth * S.winHeight) + pixel] += comp(color, i);
+        }
+      }
+      else { const V3 rgb = spectralCamResponseToRGB(S, accum, waves, flags); float* o = job.outColor + (size_t)pixel * job.channels; o[0] += S.exposureMult * rgb.x; o[1] += S.exposureMult * rgb.y; o[2] += S.exposureMult * rgb.z; }
+    }
+    if (!alive && !ending && passes != 0u) {                                 // next pass of the pixel: GetRandomNumbersLens, then GetRandomNumbersSpec (integrator_pt.cpp:114-118)
+      passes--;
+      const V4 lens = rng_float4(gen);
+      cameraRay<(SCOPE >= 2)>(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
+      waves = sampleWavelengths(rng_float1(gen), LAMBDA_MIN, LAMBDA_MAX);
+      accum = v4s(0.0f); thr = v4s(1.0f); misPdf = 1.0f; misIor = 1.0f; flags = 0; bounce = 0;
+      alive = true;
+    }
+    job.gens[tid] = gen;
+    if (alive) {
+      P.rayO[s] = make_float4(rpos.x, rpos.y, rpos.z, misPdf);
+      P.rayD[s] = make_float4(rdir.x, rdir.y, rdir.z, misIor);
+      P.thr[s] = make_float4(thr.x, thr.y, thr.z, thr.w);
+    }
+    if (alive || ending) { P.acc[s] = make_float4(accum.x, accum.y, accum.z, accum.w); P.waves[s] = make_float4(waves.x, waves.y, waves.z, waves.w); P.fb[s] = make_uint2(flags, bounce); }
+    if (wantShadow) {
+      P.shO[s] = make_float4(shPos.x, shPos.y, shPos.z, shFar);
+      P.shD[s] = make_float4(shDir.x, shDir.y, shDir.z, 0.0f);
+      P.contrib[s] = make_float4(contrib.x, contrib.y, contrib.z, contrib.w);
+    }
+    P.status[s] = (passes << 8) | (alive ? WF_ALIVE : 0u) | (wantShadow ? WF_PEND : 0u) | (ending ? WF_ENDING : 0u);
+  }
+  const bool qNear = active && alive, qShad = active && wantShadow;
+  uint kn, ks;
+  blockAppend(&ctr[0], qNear, qShad, kn, ks);
+  uint* rayQ = P.rayQ[job.iter & 1u];
+  if (qNear) rayQ[kn] = s;
+  if (qShad) rayQ[ks] = s | 0x80000000u;
+}
+
 // one translation unit per scope (-DHPT_SPEC_INST=1 / 2 / 3 / 4: scope 0 / 1 / 2 / 2 at 4 waves; 0: all), see __graft_entry__.build
 #ifndef HPT_SPEC_INST
 #define HPT_SPEC_INST 0
@@ -789,14 +897,17 @@ HPT_SPEC_BLOCK(0)
 #if HPT_SPEC_INST == 0 || HPT_SPEC_INST == 2
 HPT_SPEC(1)
 HPT_SPEC_BLOCK(1)
+template __global__ void wfShadeSpecKernel<1>(const DevScene, const WfPool, const WfJob);
 #endif
 #if HPT_SPEC_INST == 0 || HPT_SPEC_INST == 3
 HPT_SPEC(2)
 HPT_SPEC_BLOCK(2)
+template __global__ void wfShadeSpecKernel<2>(const DevScene, const WfPool, const WfJob);
 #endif
 #if HPT_SPEC_INST == 0 || HPT_SPEC_INST == 4
 HPT_SPEC(3)
 HPT_SPEC_BLOCK(3)
+template __global__ void wfShadeSpecKernel<3>(const DevScene, const WfPool, const WfJob);
 #endif
 
 } // namespace hpt

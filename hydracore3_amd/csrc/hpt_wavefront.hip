@@ -34,29 +34,6 @@ __global__ void wfInitKernel(WfPool P, uint n, uint passNum)
 }
 #endif
 
-// Ray compaction. Every wave ballots its two kinds of rays and prefix-sums the lanes (mbcnt); the four waves of the block add
-// their counts in LDS and ONE atomicAdd per block reserves the block's run of the queue. (One atomic per wave was measured at
-// 0.97 ms per shade pass over 2M slots: ~100 K atomics on one address serialise in a single L2 channel.)
-HPT_DEV void blockAppend(uint* counter, bool qNear, bool qShad, uint& posNear, uint& posShad)
-{
-  __shared__ uint waveCnt[4];
-  __shared__ uint blockBase;
-  const unsigned long long mn = __ballot(qNear), ms = __ballot(qShad);
-  const uint cn = (uint)__popcll(mn), cs = (uint)__popcll(ms);
-  const uint wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63u) == 0u) waveCnt[wave] = cn + cs;
-  __syncthreads();
-  if (threadIdx.x == 0u) {
-    const uint tot = waveCnt[0] + waveCnt[1] + waveCnt[2] + waveCnt[3];
-    blockBase = tot ? atomicAdd(counter, tot) : 0u;
-  }
-  __syncthreads();
-  uint base = blockBase;
-  for (uint w = 0; w < wave; w++) base += waveCnt[w];
-  posNear = base + mbcnt64(mn);
-  posShad = base + cn + mbcnt64(ms);
-}
-
 template <bool DR, bool LEAN, bool MOTION, bool FILM>
 __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const WfPool P, const WfJob job)
 {

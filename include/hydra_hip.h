@@ -284,13 +284,16 @@ int  hpt_set_launch_config(hpt_ctx* ctx, int blocksPerCU);
 int  hpt_set_accel_layout(hpt_ctx* ctx, int layout);
 /* How hpt_path_trace_block(_dev) schedules the work: 1 = one persistent megakernel (a lane keeps its path from camera to end),
  * 2 = wavefront (a shade kernel and a persistent trace kernel with ballot/prefix-sum ray compaction and ray replacement, path state
- * in HBM), 0 = automatic: wavefront when the committed BVH is expected to cost a ray >= 20 inner-node visits (hpt_get_accel_info's
- * surface-area estimate) and the call has >= 2^19 pixels, else the megakernel. Both give bit-identical frames. refillBelow (1..64,
+ * in HBM), 3 = the megakernel with block-local ray repacking (the rays of a workgroup's 256 lanes pooled in LDS and drained by its four
+ * waves with replacement; gltf / emissive scenes, PathTraceDR and spectral rendering), 0 = automatic: wavefront when the committed BVH is
+ * expected to cost a ray >= 20 inner-node visits (hpt_get_accel_info's surface-area estimate) and the call has >= 2^19 pixels, the
+ * block-local form for lean scenes from an estimate of 8, else the plain megakernel. All give bit-identical frames. refillBelow (1..64,
  * 0 = keep): a trace wave refills from the ray queue when fewer lanes than this still hold a ray; traceBlocksPerCU 0 = automatic.
  * groups (0 = automatic): the pixels of a call are cut into this many groups with their own path pool, ray queue and HIP stream, so
  * that the tail of one group's trace pass (a few long rays) overlaps the other groups' shade and trace passes.
  * The naive integrator and input-ray batches always use the megakernel (scenes with moving instances run under either); PathTraceDR follows the same
- * automatic choice as PathTraceBlock (its wavefront form keeps the adjoint records per pool slot). The wavefront call returns once the frame is nearly done
+ * automatic choice as PathTraceBlock (its wavefront form keeps the adjoint records per pool slot), and so does spectral rendering (m_spectral_mode = 1:
+ * its own shade kernel with four samples per radiance word in front of the same trace kernel). The wavefront call returns once the frame is nearly done
  * (it polls a device progress word); results are complete after the stream is synchronised, as for the megakernel. */
 int  hpt_set_schedule(hpt_ctx* ctx, int schedule, int refillBelow, int traceBlocksPerCU, int groups);
 /* Tuning knobs without a place in the reference's interface (results never depend on them):

@@ -445,8 +445,9 @@ def test_offsets_update_onto_a_glass_material_widens_the_spectral_kernel():
 @pytest.mark.parametrize("name", ["test_spectral", "spectral_plastic", "spectral_glass", "spectral_sky", "spectral_textures", "typed_materials", "env_map", "thin_film"])
 def test_spectral_block_local_schedule_equals_the_plain_kernel(name):
     """m_spectral_mode = 1 under the block-local schedule (pathTraceBlockSpectralKernel: persistent blocks on the work queue, the lanes' rays
-    pooled in LDS and drained with ray replacement) calls the same shadeVertexSpec in the same order as the one-thread-per-pixel kernel:
-    frames and generators are bit-identical in every scope, both layouts, for MIS and naive path tracing and the three framebuffer forms."""
+    pooled in LDS and drained with ray replacement) and under the wavefront schedule (wfShadeSpecKernel + wfTraceKernel) calls the same
+    shadeVertexSpec in the same order as the one-thread-per-pixel kernel: frames and generators are bit-identical in every scope, both
+    layouts, for MIS and (block-local) naive path tracing and the three framebuffer forms."""
     from hydracore3_amd.api import HipIntegrator
     sc = load_hydra_xml(scene_path(name), 96, 64, spectral=True)
     plain = HipIntegrator(sc); plain.set_schedule(1)
@@ -458,15 +459,22 @@ def test_spectral_block_local_schedule_equals_the_plain_kernel(name):
         assert blk.last_launch()["schedule"] == 3
         assert np.array_equal(img, ref), layout
         assert np.array_equal(blk.random_gens(), plain.random_gens())
+        # ... and under the wavefront schedule (wfShadeSpecKernel + the shared trace kernel; a small trace grid so that rays are suspended and resumed too)
+        for trace_blocks in (0, 1):
+            wf = HipIntegrator(sc, accel_layout=layout); wf.set_schedule(2, 56, trace_blocks, 1)
+            img = wf.render(6)
+            assert wf.last_launch()["schedule"] == 2
+            assert np.array_equal(img, ref), (layout, trace_blocks)
+            assert np.array_equal(wf.random_gens(), plain.random_gens())
     a, b = HipIntegrator(sc), HipIntegrator(sc)
     a.set_schedule(1); b.set_schedule(3)
     assert np.array_equal(a.render(3, naive=True), b.render(3, naive=True)) and np.array_equal(a.random_gens(), b.random_gens())
     for channels in (1, 12):
-        fa = np.zeros(96 * 64 * channels, np.float32); fb = fa.copy()
-        a2, b2 = HipIntegrator(sc), HipIntegrator(sc)
-        a2.set_schedule(1); b2.set_schedule(3)
-        a2.PathTraceBlock(a2.N, channels, fa, 3); b2.PathTraceBlock(b2.N, channels, fb, 3)
-        assert np.array_equal(fa, fb) and fa.sum() > 0, channels
+        fa = np.zeros(96 * 64 * channels, np.float32); fb = fa.copy(); fc = fa.copy()
+        a2, b2, c2 = HipIntegrator(sc), HipIntegrator(sc), HipIntegrator(sc)
+        a2.set_schedule(1); b2.set_schedule(3); c2.set_schedule(2)
+        a2.PathTraceBlock(a2.N, channels, fa, 3); b2.PathTraceBlock(b2.N, channels, fb, 3); c2.PathTraceBlock(c2.N, channels, fc, 3)
+        assert np.array_equal(fa, fb) and np.array_equal(fa, fc) and fa.sum() > 0, channels
 
 
 def test_interior_under_spectral_mode_matches_oracle():
@@ -488,3 +496,6 @@ def test_interior_under_spectral_mode_matches_oracle():
     assert_pixel_parity(a, b, spp, gpu, cpu, max_divergent=2, max_over=8, what="interior 160x96 @ 8 spp under spectral mode, block-local kernel + 4-wide tree: ")
     plain = HipIntegrator(sc); plain.set_schedule(1)
     assert np.array_equal(plain.render(spp), a) and np.array_equal(plain.random_gens(), gpu.random_gens())
+    wf = HipIntegrator(sc); wf.set_schedule(2)                  # what a full-size call of this scene takes: wfShadeSpecKernel + the 4-wide trace kernel
+    assert np.array_equal(wf.render(spp), a) and np.array_equal(wf.random_gens(), gpu.random_gens())
+    assert wf.last_launch()["schedule"] == 2 and wf.last_launch()["wide_nodes"]

@@ -532,9 +532,16 @@ def run_fixture(dev, scene_name, spectral, steps=3, size=1024, spp=64, profile=N
     import numpy as np
     from hydracore3_amd.api import HipIntegrator
     from hydracore3_amd.scene import load_hydra_xml
-    sc = load_hydra_xml(os.path.join(ROOT, "tests", "golden", "scenes", scene_name, "statex_00001.xml"), size, size, spectral=spectral)
+    W = H = size
+    if scene_name == "interior":                                   # the 1 M-triangle interior of configs[2] under m_spectral_mode = 1 (gltf colours carried as four samples, a uniform spectrum in the table)
+        W, H = 1920, 1080
+        sc = build_scene("interior", W, H)
+        sc.spectral_mode = 1
+        sc.spec_offset_sz, sc.spec_values = [(0, 471)], np.ones(471, np.float32)
+    else:
+        sc = load_hydra_xml(os.path.join(ROOT, "tests", "golden", "scenes", scene_name, "statex_00001.xml"), size, size, spectral=spectral)
     integ = HipIntegrator(sc, device=dev.index)
-    frame = integ.dev_array(np.zeros((size, size, 4), np.float32))
+    frame = integ.dev_array(np.zeros((H, W, 4), np.float32))
     for _ in range(warmup):
         integ.path_trace_block_dev(frame.ptr, warmup_spp)
     ms = []
@@ -542,10 +549,23 @@ def run_fixture(dev, scene_name, spectral, steps=3, size=1024, spp=64, profile=N
         integ.path_trace_block_dev(frame.ptr, spp)
         ms.append(integ.last_kernel_ms())
     mean_ms = sum(ms) / len(ms)
-    paths = float(size) * size * spp
+    paths = float(W) * H * spp
     roof = None
     pmc = load_profile(f"pmc_{profile}.json") if profile else None
-    if pmc and pmc.get("valu_insts_per_path"):
+    if scene_name == "interior":
+        # a heavy scene: the same tree and statistically the same rays as the RGB interior, whose instrumented walk prices a path; the counters are this workload's own
+        ab = (load_profile("r3i_summary.json") or {}).get("bench", {}).get("roofline", {}).get("algorithmic_bytes_per_path")
+        tj = load_profile(f"traffic_{profile}.json") if profile else None
+        traffic = tj["hbm_bytes_per_launch"] * paths / float(tj["paths_per_launch"]) if tj else None
+        if ab:
+            gbs = ab * paths / (mean_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "hbm_counter_frac": round(traffic / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                    "algorithmic_bytes_per_path": ab, "kernel": "wavefront: wfShadeSpecKernel + wfTraceKernel" if integ.last_launch()["schedule"] == 2 else f"schedule {integ.last_launch()['schedule']}",
+                    "kernel_ms": round(mean_ms, 3),
+                    "note": "algorithmic bytes per path from the RGB interior's instrumented walk (profiles/r3i_summary.json: same scene and tree, statistically the same rays); "
+                            "traffic from this workload's own counter passes (profiles/traffic_spectral_interior.json), rescaled to this launch"}
+    elif pmc and pmc.get("valu_insts_per_path"):
         # these scenes (16 K triangles, tables of a few hundred KB) live in L2: VALU issue binds, priced as for the Cornell megakernel
         ginst = pmc["valu_insts_per_path"] * paths / (mean_ms * 1e-3) / 1e9
         tj = load_profile(f"traffic_{profile}.json")
@@ -556,12 +576,12 @@ def run_fixture(dev, scene_name, spectral, steps=3, size=1024, spp=64, profile=N
                            else "pathTraceKernel<MODE 4: thin films>"), "kernel_ms": round(mean_ms, 3),
                 "hbm_counter_frac": round(traffic / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
                 "pmc_source": f"profiles/pmc_{profile}.json, collected at commit {pmc.get('commit')}: SQ_INSTS_VALU per path and lane utilisation; the kernel time is measured in this run"}
-    return {"workload": f"tests/golden/scenes/{scene_name} {size}x{size} @ {spp} spp, forward PathTraceBlock, " + ("m_spectral_mode = 1" if spectral else "RGB"),
+    return {"workload": (f"synthetic 1M-triangle interior {W}x{H}" if scene_name == "interior" else f"tests/golden/scenes/{scene_name} {size}x{size}") + f" @ {spp} spp, forward PathTraceBlock, " + ("m_spectral_mode = 1" if spectral else "RGB"),
             "metric": "Mpaths/s (fwd PathTraceBlock, MIS path tracing)", "value": round(paths / mean_ms / 1e3, 2), "unit": "Mpaths/s", "steps": steps,
             "ms_per_step": round(mean_ms, 3), "paths_per_step": int(paths), "sharding": "single GPU", "sharded_frame_verified": None, "roofline": roof}
 
 
-FIXTURES = {"spectral": ("test_spectral", True), "film": ("thin_film", False)}
+FIXTURES = {"spectral": ("test_spectral", True), "film": ("thin_film", False), "spectral_interior": ("interior", True)}
 
 
 def compact(r):
@@ -578,7 +598,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cornell", choices=["cornell", "interior", "dr", "dr_interior", "spectral", "film"])
+    ap.add_argument("--workload", default="cornell", choices=["cornell", "interior", "dr", "dr_interior", "spectral", "film", "spectral_interior"])
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=1024)
@@ -692,6 +712,7 @@ def main():
             # the reference's spectral fixture under m_spectral_mode = 1, and the thin-film fixture (RGB): short, kernel-timed
             also.append(run_fixture(dev, "test_spectral", True, profile="spectral"))
             also.append(run_fixture(dev, "thin_film", False, profile="film"))
+            also.append(run_fixture(dev, "interior", True, steps=2, profile="spectral_interior", warmup_spp=8))   # a heavy scene under spectral mode: the wavefront schedule's spectral shade kernel
         if out is not None and also:
             out["also"] = [a for a in also if a is not None]
 

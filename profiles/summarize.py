@@ -25,6 +25,8 @@ CALLS = 3     # profiles/collect.sh runs bench.py --steps 2 --warmup 1: three Pa
 def product_kernel(name):
     """Kernels of one PathTraceBlock call: the persistent megakernel, or the wavefront schedule's shade / trace / init kernels.
     The instrumented build (first template argument true / third for the trace kernel) is bench.py's counting probe, never timed."""
+    if workload == "spectral_interior":           # the wavefront schedule under spectral mode: its own shade kernel in front of the shared trace kernel
+        return "wfTraceKernel" in name or "wfShadeSpecKernel" in name or "wfInitKernel" in name
     if workload == "spectral":
         return "SpectralKernel" in name                 # pathTraceSpectralKernel, or pathTraceBlockSpectralKernel under the block-local schedule
     if workload == "film":
@@ -72,7 +74,7 @@ def fetch_calibrated_kb(sub):
     tot = 0.0
     for r in csv.DictReader(open(f)):
         if product_kernel(r["Kernel_Name"]) and r["Counter_Name"] == "FETCH_SIZE":
-            stream = ("wfShadeKernel" in r["Kernel_Name"]) or ("wfInitKernel" in r["Kernel_Name"])
+            stream = ("wfShadeKernel" in r["Kernel_Name"]) or ("wfShadeSpecKernel" in r["Kernel_Name"]) or ("wfInitKernel" in r["Kernel_Name"])
             tot += float(r["Counter_Value"]) * (2.0 if stream else 1.0)
     return tot / CALLS
 

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mpaths/s of Integrator::PathTraceBlock on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cornell|interior|dr|dr_interior] [--spp S]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cornell|interior|dr|dr_interior|spectral|film|spectral_interior] [--spp S]
 
 A *step* is one PathTraceBlock call over the whole frame (W*H pixels x spp passes, MIS path tracing) with the framebuffer,
 RNG states and scene resident in HBM. N = 1 runs BASELINE.json configs[1] (scenes/test_035 Cornell box, 1024 x 1024, 1024 spp)
 and appends ("also") the other configurations AT THEIR STATED SIZES: configs[2] (1M-triangle interior, 1920 x 1080 @ 1024 spp, wavefront
 schedule, one step), configs[3] (PathTraceDR + Adam on the test_228 class, 512^2 @ 256 spp), configs[4] (1M triangles, 4096^2 x 4 albedo,
-1920 x 1080 @ 512 spp, fwd + bwd + Adam, one step), the reference's spectral fixture and a thin-film fixture - each with its own roofline.
+1920 x 1080 @ 512 spp, fwd + bwd + Adam, one step), the reference's spectral fixture, a thin-film fixture and the 1M-triangle interior under
+spectral mode - each with its own roofline.
 
 N > 1: one rank per GPU (the scene is replicated, no data-path collective but ONE RCCL reduce(SUM) of the framebuffer per step).
 Started plainly (`python bench.py --gpus N`, WORLD_SIZE unset) the script spawns its N ranks itself through

@@ -12,9 +12,11 @@
 //
 // Scope of this kernel: PathTraceBlock with everything the RGB kernels hold - every material type (gltf and the legacy glass carry their colours
 // as four samples as they are; thin films: hpt_film.h), blends, normal maps, every light type with an intensity spectrum, sampled environment
-// maps and back plates, a sky spectrum, moving instances, the lens stack - in a one-thread-per-pixel kernel with in-place path regeneration (no
-// work queue). With more than four channels the
-// output is the reference's stack of wavelength layers.
+// maps and back plates, a sky spectrum, moving instances, the lens stack. Three forms share the per-vertex function shadeVertexSpec and render
+// bit-identical frames: pathTraceSpectralKernel (one thread per pixel, in-place path regeneration, no work queue: light scenes, input-ray batches,
+// moving instances), pathTraceBlockSpectralKernel (block-local ray repacking: scenes whose rays walk a real tree) and wfShadeSpecKernel (the shade
+// half of the wavefront schedule: heavy scenes in calls of 2^19 pixels or more). With more than four channels the output is the reference's stack
+// of wavelength layers.
 #include <hip/hip_runtime.h>
 #include "hpt_decl.h"
 #include "hpt_block_trace.h"

@@ -173,6 +173,12 @@ HPT_DEV void blockAppend(uint* counter, bool qNear, bool qShad, uint& posNear, u
 }
 
 __global__ void wfInitKernel(WfPool P, uint n, uint passNum);
+#ifndef HPT_STREAM_WAVES
+#define HPT_STREAM_WAVES 5
+#endif
+template <bool DEEP>                                                    // block-owned streaming form of the wavefront schedule (hpt_stream.hip; schedule 4)
+__global__ void __launch_bounds__(256, HPT_STREAM_WAVES) streamKernel(const DevScene S, const WfPool P, const WfJob job, uint slotsPerBlock, uint refillBelow, uint* blockQueues,
+                                                                      uint* stackOverflow, uint gridLanes);
 template <int SCOPE>                                                    // spectral rendering under the wavefront schedule (hpt_spectral.hip)
 __global__ void __launch_bounds__(256, SCOPE == 2 ? HPT_SPEC_WIDE_WAVES : HPT_SPEC_WAVES) wfShadeSpecKernel(const DevScene S, const WfPool P, const WfJob job);
 template <bool DR, bool LEAN, bool MOTION = false, bool FILM = false>   // FILM: shadeVertex<FILM> (thin films, hpt_film.h)

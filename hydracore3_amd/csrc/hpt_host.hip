@@ -1508,6 +1508,7 @@ static int gridBlocks(hpt_ctx* c, bool dr, bool fullMaterials = false)
 static bool useWavefront(hpt_ctx* c, bool naive, bool dr, bool stats, uint tidCount);
 static bool wfWide(const hpt_ctx* c);
 static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr, int specScope = -1);
+static int launch_stream(hpt_ctx* c, const Job& job, hipStream_t st);
 
 // DEEP: the scene's BVH can need more than LDS_STACK stack entries, so pushes / pops check for the HBM overflow part
 // FLAT: single-level world-space BVH (static scenes within FLAT_TRI_BUDGET) vs two-level TLAS/BLAS
@@ -1685,6 +1686,11 @@ static int launch_path_trace(hpt_ctx* c, Job& job, bool naive, bool dr, hipStrea
   const bool stats = c->instrument;                            // (the DR probe exists as a megakernel only: hpt_kernels.hip, group 15)
   c->lastSchedule = 1;
   c->lastShadeRecords = c->S.shadeTris != nullptr ? 1u : 0u;
+  // schedule 4 (experimental, never chosen automatically): the block-owned streaming form of the wavefront schedule - heavy static scenes with gltf / emissive materials
+  if (c->schedule == 4 && !inRays && !naive && !dr && !stats && !motion && !film && c->leanMaterials && !c->forceFull && c->S.lensCount == 0u && wfWide(c) && c->S.traceDepth > 0u) {
+    c->lastSchedule = 4; c->lastWide = 1u; c->lastDeep = c->stackNeeded4 > (uint)LDS_STACK ? 1u : 0u;
+    return launch_stream(c, job, st);
+  }
   if (!inRays && useWavefront(c, naive, dr, stats && c->schedule != 2, job.tidCount)) {
     c->lastSchedule = 2; c->lastWide = (wfWide(c) && !c->instrument) ? 1u : 0u; c->lastDeep = (c->lastWide ? c->stackNeeded4 : c->stackNeeded) > (uint)LDS_STACK ? 1u : 0u;
     return launch_wavefront(c, job, st, dr);
@@ -1767,7 +1773,7 @@ static bool useWavefront(hpt_ctx* c, bool naive, bool dr, bool stats, uint tidCo
 {
   if (naive || stats) return false;                // those variants exist as megakernels only
   if (c->schedule == 1 || c->schedule == 3) return false;
-  if (c->schedule == 2) return true;
+  if (c->schedule == 2) return true;                 // (4, where its kernel does not apply: the automatic choice)
   // ... and only for calls with enough pixels to keep the trace kernel's lanes supplied with replacement rays: measured on the 1M-triangle
   // scene (profiles/share.sh, 2.07 M / 1.04 M / 518 K / 259 K pixels per call): wavefront 226 / 199 / 162 / 108 vs megakernel 171 / 161 / 159 / 146 Mpaths/s
   return c->sahVisits >= HEAVY_SAH_VISITS && tidCount >= WF_AUTO_PIXELS;
@@ -1946,6 +1952,45 @@ static int launch_wavefront(hpt_ctx* c, const Job& job, hipStream_t st, bool dr,
   if (capLeft != 0ull)
     return c->fail(HPT_ERR_STATE, "wavefront schedule: stopped after " + std::to_string(iterCap) + " rounds with " + std::to_string(capLeft) +
                    " rays still queued - the frame is incomplete (render it with hpt_set_schedule(ctx, 1, ...) or hpt_set_option(\"wf_grace\", 0))");
+  return HPT_OK;
+}
+
+// ---- schedule 4: block-owned streaming (hpt_stream.hip) -----------------------------------------------------------------------------------
+static int launch_stream(hpt_ctx* c, const Job& job, hipStream_t st)
+{
+  while (c->wfGroups.size() < 1) {
+    hpt_ctx::WfGroup* g = new hpt_ctx::WfGroup();
+    c->wfGroups.push_back(g);
+    HIPCHK(c, hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    HIPCHK(c, hipHostMalloc((void**)&g->progress, WF_RING * sizeof(uint)));
+    for (auto& e : g->ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&g->done, hipEventDisableTiming));
+  }
+  hpt_ctx::WfGroup& g = *c->wfGroups[0];
+  const int bpc = c->wfBlocksPerCU > 0 ? c->wfBlocksPerCU : HPT_STREAM_WAVES;
+  const uint blocks = (uint)std::max(1, std::min(c->numCUs * bpc, (int)((job.tidCount + 255u) / 256u)));
+  uint spb = (job.tidCount + blocks - 1u) / blocks;
+  spb = (spb + 255u) & ~255u;                                   // slots per block: whole 256-slot steps of the shade loop
+  const uint n = job.tidCount;
+  for (int i = 0; i < 8; i++) HIPCHK(c, g.f4[i].alloc(n));
+  for (int i = 0; i < 3; i++) HIPCHK(c, g.u[i].alloc(n));
+  HIPCHK(c, g.u[6].alloc(n));
+  HIPCHK(c, g.u[3].alloc((size_t)blocks * 2u * spb));            // the blocks' ray queues
+  HIPCHK(c, ensureStackOverflow(c, (size_t)blocks * 256));
+  WfPool P; std::memset(&P, 0, sizeof(P));
+  P.rayO = g.f4[0].p; P.rayD = g.f4[1].p; P.thr = g.f4[2].p; P.acc = g.f4[3].p;
+  P.shO = g.f4[4].p; P.shD = g.f4[5].p; P.contrib = g.f4[6].p; P.hit = g.f4[7].p;
+  P.hitInst = g.u[0].p; P.occl = g.u[1].p; P.status = g.u[2].p; P.inflight = g.u[6].p;
+  WfJob wj; std::memset(&wj, 0, sizeof(wj));
+  wj.itemBase = 0; wj.itemCount = n; wj.tidBegin = job.tidBegin; wj.tidChunk = job.tidChunk; wj.tidStride = job.tidStride; wj.tidEnd = job.tidEnd;
+  wj.passNum = job.passNum; wj.channels = job.channels; wj.outColor = job.outColor; wj.gens = job.gens; wj.packedXY = job.packedXY;
+  HIPCHK(c, hipEventRecord(c->ev0, st));
+  wfInitKernel<<<dim3((n + 255u) / 256u), dim3(256), 0, st>>>(P, n, job.passNum);
+  if (c->stackNeeded4 > (uint)LDS_STACK) streamKernel<true><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, wj, spb, c->wfRefillBelow, g.u[3].p, c->dStackOvf.p, blocks * 256u);
+  else                                   streamKernel<false><<<dim3(blocks), dim3(256), 0, st>>>(c->S, P, wj, spb, c->wfRefillBelow, g.u[3].p, c->dStackOvf.p, blocks * 256u);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev1, st));
+  c->lastWfIters = 0;
   return HPT_OK;
 }
 
@@ -2280,7 +2325,7 @@ extern "C" int hpt_set_launch_config(hpt_ctx* c, int blocksPerCU) try { if (!c |
 catch (...) { return hptGuard(c, "hpt_set_launch_config"); }
 extern "C" int hpt_set_schedule(hpt_ctx* c, int schedule, int refillBelow, int traceBlocksPerCU, int groups)
 try {
-  if (!c || schedule < 0 || schedule > 3 || refillBelow < 0 || refillBelow > 64 || traceBlocksPerCU < 0 || traceBlocksPerCU > 8 || groups < 0 || groups > 64) return HPT_ERR_ARG;
+  if (!c || schedule < 0 || schedule > 4 || refillBelow < 0 || refillBelow > 64 || traceBlocksPerCU < 0 || traceBlocksPerCU > 8 || groups < 0 || groups > 64) return HPT_ERR_ARG;
   c->wfGroupCount = groups;
   c->schedule = schedule;
   if (refillBelow > 0) c->wfRefillBelow = (uint)refillBelow;

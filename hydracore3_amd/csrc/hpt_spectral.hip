@@ -784,36 +784,36 @@ __global__ void __launch_bounds__(256, SCOPE_ == 2 ? HPT_SPEC_WIDE_WAVES : HPT_S
     tid = job.tidBegin + (k / job.tidChunk) * job.tidChunk * job.tidStride + (k % job.tidChunk);
     valid = tid < job.tidEnd;
   }
-  if (valid && P.inflight[s] != 0u) valid = false;       // a suspended ray of this pixel is still being traced: the pixel sits this round out
-  uint st = valid ? P.status[s] : 0u;
+  if (valid && ldP(&P.inflight[s]) != 0u) valid = false;       // a suspended ray of this pixel is still being traced: the pixel sits this round out
+  uint st = valid ? ldP(&P.status[s]) : 0u;
   uint passes = st >> 8;
   bool alive = (st & WF_ALIVE) != 0u, pend = (st & WF_PEND) != 0u, ending = (st & WF_ENDING) != 0u;
   const bool active = valid && (alive || pend || ending || passes != 0u);
   bool wantShadow = false;
 
   if (active) {
-    Rng gen = job.gens[tid];
+    Rng gen = ldP(&job.gens[tid]);
     const uint XY = job.packedXY[tid];
     V4 accum = v4s(0.0f), thr = v4s(1.0f), waves = v4s(0.0f), contrib = v4s(0.0f);
     V3 rpos = v3(0, 0, 0), rdir = v3(0, 0, 1);
     float misPdf = 1.0f, misIor = 1.0f; uint flags = 0, bounce = 0;
     if (alive || ending) {
-      const float4 a = P.acc[s], w = P.waves[s]; const uint2 f = P.fb[s];
+      const float4 a = ldP(&P.acc[s]), w = ldP(&P.waves[s]); const uint2 f = ldP(&P.fb[s]);
       accum = v4(a.x, a.y, a.z, a.w); waves = v4(w.x, w.y, w.z, w.w); flags = f.x; bounce = f.y;
     }
     // the shadow ray traced since the last visit: add the candidate contribution in the plain kernel's order
     if (pend) {
-      if (P.occl[s] == 0u) { const float4 c = P.contrib[s]; accum = accum + v4(c.x, c.y, c.z, c.w); }
+      if (ldP(&P.occl[s]) == 0u) { const float4 c = ldP(&P.contrib[s]); accum = accum + v4(c.x, c.y, c.z, c.w); }
       pend = false;
     }
     bool finalize = ending;                                                // path ended last time, only its shadow ray was outstanding
     ending = false;
     V3 shPos = v3(0, 0, 0), shDir = v3(0, 0, 1); float shFar = 0.0f;
     if (alive) {
-      const float4 ro = P.rayO[s], rd = P.rayD[s], t4 = P.thr[s], h4 = P.hit[s];
+      const float4 ro = ldP(&P.rayO[s]), rd = ldP(&P.rayD[s]), t4 = ldP(&P.thr[s]), h4 = ldP(&P.hit[s]);
       rpos = v3(ro.x, ro.y, ro.z); misPdf = ro.w; rdir = v3(rd.x, rd.y, rd.z); misIor = rd.w;
       thr = v4(t4.x, t4.y, t4.z, t4.w);
-      HitRec hit; hit.t = h4.x; hit.u = h4.y; hit.v = h4.z; hit.prim = __float_as_uint(h4.w); hit.inst = P.hitInst[s];   // (the host hands the trace pass a scene without shading records: primitive ids come back)
+      HitRec hit; hit.t = h4.x; hit.u = h4.y; hit.v = h4.z; hit.prim = __float_as_uint(h4.w); hit.inst = ldP(&P.hitInst[s]);   // (the host hands the trace pass a scene without shading records: primitive ids come back)
       shadeVertexSpec<SCOPE, false>(S, hit, rpos, rdir, waves, accum, thr, misPdf, misIor, flags, bounce, gen, false, wantShadow, shPos, shDir, shFar, contrib, 0.0f);
       bounce++;                                                              // (the plain kernel counts every trip, a miss included)
       if ((flags & RAY_FLAG_IS_DEAD) != 0 || bounce >= S.traceDepth) {
@@ -849,26 +849,26 @@ __global__ void __launch_bounds__(256, SCOPE_ == 2 ? HPT_SPEC_WIDE_WAVES : HPT_S
       accum = v4s(0.0f); thr = v4s(1.0f); misPdf = 1.0f; misIor = 1.0f; flags = 0; bounce = 0;
       alive = true;
     }
-    job.gens[tid] = gen;
+    stP(&job.gens[tid], gen);
     if (alive) {
-      P.rayO[s] = make_float4(rpos.x, rpos.y, rpos.z, misPdf);
-      P.rayD[s] = make_float4(rdir.x, rdir.y, rdir.z, misIor);
-      P.thr[s] = make_float4(thr.x, thr.y, thr.z, thr.w);
+      stP(&P.rayO[s], make_float4(rpos.x, rpos.y, rpos.z, misPdf));
+      stP(&P.rayD[s], make_float4(rdir.x, rdir.y, rdir.z, misIor));
+      stP(&P.thr[s], make_float4(thr.x, thr.y, thr.z, thr.w));
     }
-    if (alive || ending) { P.acc[s] = make_float4(accum.x, accum.y, accum.z, accum.w); P.waves[s] = make_float4(waves.x, waves.y, waves.z, waves.w); P.fb[s] = make_uint2(flags, bounce); }
+    if (alive || ending) { stP(&P.acc[s], make_float4(accum.x, accum.y, accum.z, accum.w)); stP(&P.waves[s], make_float4(waves.x, waves.y, waves.z, waves.w)); stP(&P.fb[s], make_uint2(flags, bounce)); }
     if (wantShadow) {
-      P.shO[s] = make_float4(shPos.x, shPos.y, shPos.z, shFar);
-      P.shD[s] = make_float4(shDir.x, shDir.y, shDir.z, 0.0f);
-      P.contrib[s] = make_float4(contrib.x, contrib.y, contrib.z, contrib.w);
+      stP(&P.shO[s], make_float4(shPos.x, shPos.y, shPos.z, shFar));
+      stP(&P.shD[s], make_float4(shDir.x, shDir.y, shDir.z, 0.0f));
+      stP(&P.contrib[s], make_float4(contrib.x, contrib.y, contrib.z, contrib.w));
     }
-    P.status[s] = (passes << 8) | (alive ? WF_ALIVE : 0u) | (wantShadow ? WF_PEND : 0u) | (ending ? WF_ENDING : 0u);
+    stP(&P.status[s], (passes << 8) | (alive ? WF_ALIVE : 0u) | (wantShadow ? WF_PEND : 0u) | (ending ? WF_ENDING : 0u));
   }
   const bool qNear = active && alive, qShad = active && wantShadow;
   uint kn, ks;
   blockAppend(&ctr[0], qNear, qShad, kn, ks);
   uint* rayQ = P.rayQ[job.iter & 1u];
-  if (qNear) rayQ[kn] = s;
-  if (qShad) rayQ[ks] = s | 0x80000000u;
+  if (qNear) stP(&rayQ[kn], s);
+  if (qShad) stP(&rayQ[ks], s | 0x80000000u);
 }
 
 // one translation unit per scope (-DHPT_SPEC_INST=1 / 2 / 3 / 4: scope 0 / 1 / 2 / 2 at 4 waves; 0: all), see __graft_entry__.build

@@ -49,8 +49,8 @@ __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const W
     tid = job.tidBegin + (k / job.tidChunk) * job.tidChunk * job.tidStride + (k % job.tidChunk);
     valid = tid < job.tidEnd;
   }
-  if (valid && P.inflight[s] != 0u) valid = false;       // a suspended ray of this pixel is still being traced: the pixel sits this round out
-  uint st = valid ? P.status[s] : 0u;
+  if (valid && ldP(&P.inflight[s]) != 0u) valid = false;       // a suspended ray of this pixel is still being traced: the pixel sits this round out
+  uint st = valid ? ldP(&P.status[s]) : 0u;
   uint passes = st >> 8;
   bool alive = (st & WF_ALIVE) != 0u, pend = (st & WF_PEND) != 0u, ending = (st & WF_ENDING) != 0u;
   const bool active = valid && (alive || pend || ending || passes != 0u);
@@ -60,17 +60,17 @@ __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const W
   DrRec lastRec = drEmptyRecord(); bool lastInRegs = false;
 
   if (active) {
-    Rng gen = job.gens[tid];
+    Rng gen = ldP(&job.gens[tid]);
     const uint XY = job.packedXY[tid];
     V3 accum = v3(0, 0, 0), thr = v3(1, 1, 1), rpos = v3(0, 0, 0), rdir = v3(0, 0, 1);
     float misPdf = 1.0f, misIor = 1.0f; uint flags = 0, bounce = 0;
     float pathTime = 0.0f;
-    if (MOTION && alive) pathTime = P.time[s];
-    if (alive || ending) { const float4 a = P.acc[s]; accum = v3(a.x, a.y, a.z); bounce = __float_as_uint(a.w); }
-    if (DR && ending) { const float4 t4 = P.thr[s]; thr = v3(t4.x, t4.y, t4.z); }     // the environment term of the finished path needs its throughput
+    if (MOTION && alive) pathTime = ldP(&P.time[s]);
+    if (alive || ending) { const float4 a = ldP(&P.acc[s]); accum = v3(a.x, a.y, a.z); bounce = __float_as_uint(a.w); }
+    if (DR && ending) { const float4 t4 = ldP(&P.thr[s]); thr = v3(t4.x, t4.y, t4.z); }     // the environment term of the finished path needs its throughput
     // (6') the shadow ray traced since the last visit: add the candidate contribution in the megakernel's order
     if (pend) {
-      if (P.occl[s] == 0u) { const float4 c = P.contrib[s]; accum = accum + v3(c.x, c.y, c.z); }
+      if (ldP(&P.occl[s]) == 0u) { const float4 c = ldP(&P.contrib[s]); accum = accum + v3(c.x, c.y, c.z); }
       else if (DR && bounce > 0u) drClearShadowTerm(job.record, job.itemCount, s, bounce - 1u);   // the light sample of the last vertex was occluded
       pend = false;
     }
@@ -80,10 +80,10 @@ __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const W
     V3 tailR = v3(0, 0, 0);                                                 // DR: emission picked up at the terminating vertex, per unit throughput
 
     if (alive) {
-      const float4 ro = P.rayO[s], rd = P.rayD[s], t4 = P.thr[s], h4 = P.hit[s];
+      const float4 ro = ldP(&P.rayO[s]), rd = ldP(&P.rayD[s]), t4 = ldP(&P.thr[s]), h4 = ldP(&P.hit[s]);
       rpos = v3(ro.x, ro.y, ro.z); misPdf = ro.w; rdir = v3(rd.x, rd.y, rd.z); misIor = rd.w;
       thr = v3(t4.x, t4.y, t4.z); flags = __float_as_uint(t4.w);
-      HitRec hit; hit.t = h4.x; hit.u = h4.y; hit.v = h4.z; hit.prim = __float_as_uint(h4.w); hit.inst = P.hitInst[s];
+      HitRec hit; hit.t = h4.x; hit.u = h4.y; hit.v = h4.z; hit.prim = __float_as_uint(h4.w); hit.inst = ldP(&P.hitInst[s]);
       if (S.shadeTris != nullptr) hit.slot = __float_as_uint(h4.w);      // (with the shading records in use the trace pass reports the hit's record, not its primitive id)
       V3 rA = v3(0, 0, 0), rS = v3(0, 0, 0), rdA = v3(0, 0, 0), rdS = v3(0, 0, 0); Taps taps; uint recTex = 0xFFFFFFFFu;   // adjoint record of this vertex (DR)
       for (int k = 0; k < 4; k++) { taps.off[k] = 0; taps.w[k] = 0.0f; }
@@ -134,22 +134,22 @@ __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const W
       accum = v3(0, 0, 0); thr = v3(1, 1, 1); flags = 0; bounce = 0; misPdf = 1.0f; misIor = 1.0f;
       const V4 lens = rng_float4(gen);
       cameraRay<!(DR || LEAN)>(S, XY & 0x0000FFFFu, (XY & 0xFFFF0000u) >> 16, lens, rpos, rdir);
-      if (MOTION) { pathTime = rng_float1(gen); P.time[s] = pathTime; }    // GetRandomNumbersTime (integrator_pt.cpp:114-115): one step per path, after the lens
+      if (MOTION) { pathTime = rng_float1(gen); stP(&P.time[s], pathTime); }    // GetRandomNumbersTime (integrator_pt.cpp:114-115): one step per path, after the lens
       alive = true;
     }
-    job.gens[tid] = gen;
+    stP(&job.gens[tid], gen);
     if (alive) {
-      P.rayO[s] = make_float4(rpos.x, rpos.y, rpos.z, misPdf);
-      P.rayD[s] = make_float4(rdir.x, rdir.y, rdir.z, misIor);
+      stP(&P.rayO[s], make_float4(rpos.x, rpos.y, rpos.z, misPdf));
+      stP(&P.rayD[s], make_float4(rdir.x, rdir.y, rdir.z, misIor));
     }
-    if (alive || (DR && ending)) P.thr[s] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(flags));
-    if (alive || ending) P.acc[s] = make_float4(accum.x, accum.y, accum.z, __uint_as_float(bounce));
+    if (alive || (DR && ending)) stP(&P.thr[s], make_float4(thr.x, thr.y, thr.z, __uint_as_float(flags)));
+    if (alive || ending) stP(&P.acc[s], make_float4(accum.x, accum.y, accum.z, __uint_as_float(bounce)));
     if (wantShadow) {
-      P.shO[s] = make_float4(shPos.x, shPos.y, shPos.z, shFar);
-      P.shD[s] = make_float4(shDir.x, shDir.y, shDir.z, 0.0f);
-      P.contrib[s] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
+      stP(&P.shO[s], make_float4(shPos.x, shPos.y, shPos.z, shFar));
+      stP(&P.shD[s], make_float4(shDir.x, shDir.y, shDir.z, 0.0f));
+      stP(&P.contrib[s], make_float4(contrib.x, contrib.y, contrib.z, 0.0f));
     }
-    P.status[s] = (passes << 8) | (alive ? WF_ALIVE : 0u) | (wantShadow ? WF_PEND : 0u) | (ending ? WF_ENDING : 0u);
+    stP(&P.status[s], (passes << 8) | (alive ? WF_ALIVE : 0u) | (wantShadow ? WF_PEND : 0u) | (ending ? WF_ENDING : 0u));
   }
 #ifndef HPT_DBG_DR_NOSWEEP   // diagnostic builds only (profiles/dr_ab.sh)
   if (DR && __any(closing))
@@ -161,8 +161,8 @@ __global__ void HPT_WFS_BOUNDS(DR, LEAN) wfShadeKernel(const DevScene S, const W
   uint kn, ks;
   blockAppend(&ctr[0], qNear, qShad, kn, ks);
   uint* rayQ = P.rayQ[job.iter & 1u];
-  if (qNear) rayQ[kn] = s;
-  if (qShad) rayQ[ks] = s | 0x80000000u;
+  if (qNear) stP(&rayQ[kn], s);
+  if (qShad) stP(&rayQ[ks], s | 0x80000000u);
 }
 
 #if !defined(HPT_WF_INST) || HPT_WF_INST != 2
@@ -261,16 +261,16 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
               granted = base < rSize ? min(want, rSize - base) : 0u;
               if (lane < granted) {
                 const uint k = rBegin + base + lane;
-                const uint q = rayQ[k];
+                const uint q = ldP(&rayQ[k]);
                 const uint sl = q & 0x3FFFFFFFu;
                 float4 a, b;
-                if ((q >> 31) == 0u) { a = P.rayO[sl]; b = P.rayD[sl]; a.w = HPT_FLT_MAX; }
-                else                 { a = P.shO[sl]; b = P.shD[sl]; }
+                if ((q >> 31) == 0u) { a = ldP(&P.rayO[sl]); b = ldP(&P.rayD[sl]); a.w = HPT_FLT_MAX; }
+                else                 { a = ldP(&P.shO[sl]); b = ldP(&P.shD[sl]); }
                 if ((q & 0x40000000u) != 0u) a.w = __uint_as_float(k);        // resumed ray: its saved state is record k
                 uint* e = stash + (stashCount + lane);
                 e[0 * 64] = __float_as_uint(a.x); e[1 * 64] = __float_as_uint(a.y); e[2 * 64] = __float_as_uint(a.z); e[3 * 64] = __float_as_uint(a.w);
                 e[4 * 64] = __float_as_uint(b.x); e[5 * 64] = __float_as_uint(b.y); e[6 * 64] = __float_as_uint(b.z); e[7 * 64] = q;
-                if (MOTION) e[8 * 64] = __float_as_uint(P.time[sl]);       // both rays of a path carry the path's time
+                if (MOTION) e[8 * 64] = __float_as_uint(ldP(&P.time[sl]));       // both rays of a path carry the path's time
               }
               stashCount += granted;
             }
@@ -380,8 +380,8 @@ __global__ void __launch_bounds__(256, HPT_WF_WAVES) wfTraceKernel(const DevScen
         }
         WSTAMP(2);
         if (done) {
-          if (isAny) P.occl[slot] = found ? 1u : 0u;
-          else { P.hit[slot] = make_float4(hitT, hitU, hitV, __uint_as_float((FLAT && S.shadeTris != nullptr) ? hitSlot : hitPrim)); P.hitInst[slot] = found ? hitInst : 0xFFFFFFFFu; }
+          if (isAny) stP(&P.occl[slot], found ? 1u : 0u);
+          else { stP(&P.hit[slot], make_float4(hitT, hitU, hitV, __uint_as_float((FLAT && S.shadeTris != nullptr) ? hitSlot : hitPrim))); stP(&P.hitInst[slot], found ? hitInst : 0xFFFFFFFFu); }
           if (resumed) atomicAnd(&P.inflight[slot], isAny ? ~2u : ~1u);
           has = false;
           break;

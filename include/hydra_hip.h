@@ -285,7 +285,9 @@ int  hpt_set_accel_layout(hpt_ctx* ctx, int layout);
 /* How hpt_path_trace_block(_dev) schedules the work: 1 = one persistent megakernel (a lane keeps its path from camera to end),
  * 2 = wavefront (a shade kernel and a persistent trace kernel with ballot/prefix-sum ray compaction and ray replacement, path state
  * in HBM), 3 = the megakernel with block-local ray repacking (the rays of a workgroup's 256 lanes pooled in LDS and drained by its four
- * waves with replacement; gltf / emissive scenes, PathTraceDR and spectral rendering), 0 = automatic: wavefront when the committed BVH is
+ * waves with replacement; gltf / emissive scenes, PathTraceDR and spectral rendering), 4 = the wavefront schedule in one launch (every workgroup
+ * owns a tile-interleaved set of pool slots for the whole call and alternates between shading them and draining its own ray queue; heavy static gltf /
+ * emissive scenes on the 4-wide tree - elsewhere the automatic choice is taken; never chosen automatically), 0 = automatic: wavefront when the committed BVH is
  * expected to cost a ray >= 20 inner-node visits (hpt_get_accel_info's surface-area estimate) and the call has >= 2^19 pixels, the
  * block-local form for lean scenes from an estimate of 8, else the plain megakernel. All give bit-identical frames. refillBelow (1..64,
  * 0 = keep): a trace wave refills from the ray queue when fewer lanes than this still hold a ray; traceBlocksPerCU 0 = automatic.

@@ -263,6 +263,38 @@ def test_both_accel_layouts_give_identical_hits_and_images(scene_name):
     assert np.array_equal(t2.render(spp, naive=True), s2.render(spp, naive=True))
 
 
+def test_streaming_schedule_equals_megakernel():
+    """hpt_set_schedule(4): the block-owned streaming form of the wavefront schedule (hpt_stream.hip - every workgroup keeps its own slots for the
+    whole call and alternates between shading them and draining its own ray queue, one launch per call) runs the same arithmetic per path as the
+    megakernel: frames and RNG streams agree bit for bit, with few and many blocks per CU, a tid window, accumulation over calls and one channel.
+    Where its kernel does not apply (no 4-wide tree: the Cornell box) the call takes the automatic choice."""
+    from hydracore3_amd.api import HipIntegrator
+    from hydracore3_amd import synth
+    sc = synth.interior_scene(384, 320, objects=24, subdiv=2, tex_size=64)
+    mega = HipIntegrator(sc, accel_layout=2); mega.set_schedule(1)
+    ref = mega.render(5)
+    for blocks_per_cu, refill in ((0, 0), (1, 48), (3, 64)):
+        st = HipIntegrator(sc, accel_layout=2); st.set_schedule(4, refill, blocks_per_cu)
+        img = st.render(5)
+        assert st.last_launch()["schedule"] == 4 and st.last_launch()["wide_nodes"]
+        assert np.array_equal(img, ref), blocks_per_cu
+        assert np.array_equal(st.random_gens(), mega.random_gens())
+    a, b = HipIntegrator(sc, accel_layout=2), HipIntegrator(sc, accel_layout=2)
+    a.set_schedule(1); b.set_schedule(4)
+    ia, ib = np.zeros_like(ref), np.zeros_like(ref)
+    for integ, im in ((a, ia), (b, ib)):
+        integ.PathTraceBlock(20000, 4, im, 2, tid_begin=5000)
+        integ.PathTraceBlock(integ.N, 4, im, 3)
+    assert np.array_equal(ia, ib) and np.array_equal(a.random_gens(), b.random_gens())
+    fa = np.zeros(384 * 320, np.float32); fb = fa.copy()
+    a.PathTraceBlock(a.N, 1, fa, 2); b.PathTraceBlock(b.N, 1, fb, 2)
+    assert np.array_equal(fa, fb) and fa.sum() > 0
+    box = load_hydra_xml(scene_path("test_035"), 96, 96)
+    c, d = HipIntegrator(box), HipIntegrator(box)
+    c.set_schedule(0); d.set_schedule(4)
+    assert np.array_equal(c.render(4), d.render(4)) and d.last_launch()["schedule"] != 4
+
+
 @pytest.mark.parametrize("scene_name", ["test_035", "test_228", "zoo", "interior"])
 def test_wavefront_schedule_equals_megakernel(scene_name):
     """hpt_set_schedule: the shade/trace kernel pair (ray compaction + replacement, path state in HBM) and the persistent

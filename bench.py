@@ -608,7 +608,7 @@ def main():
     ap.add_argument("--no-build", action="store_true", help="never compile (profiler runs: build first, `python __graft_entry__.py`); fail if the library is missing")
     ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the check of the sharded frame against single-GPU renderings of the same shares")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
-    ap.add_argument("--schedule", type=int, default=0, help="0 automatic, 1 persistent megakernel, 2 wavefront (shade + trace kernels), 3 megakernel with block-local ray repacking")
+    ap.add_argument("--schedule", type=int, default=0, help="0 automatic, 1 persistent megakernel, 2 wavefront (shade + trace kernels), 3 megakernel with block-local ray repacking, 4 wavefront in one launch (block-owned slots)")
     ap.add_argument("--refill-below", type=int, default=0, help="wavefront: refill a trace wave when fewer lanes than this hold a ray")
     ap.add_argument("--trace-blocks-per-cu", type=int, default=0)
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],

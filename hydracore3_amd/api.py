@@ -345,7 +345,8 @@ class HipIntegrator:
         self._chk(self.L.hpt_set_tid_interleave(self.h, chunk, stride))
 
     def set_schedule(self, schedule: int, refill_below: int = 0, trace_blocks_per_cu: int = 0, groups: int = 0):
-        """0 automatic, 1 persistent megakernel, 2 wavefront (shade kernel + trace kernel with ray replacement)."""
+        """0 automatic, 1 persistent megakernel, 2 wavefront (shade kernel + trace kernel with ray replacement), 3 megakernel with block-local ray
+        repacking, 4 the wavefront schedule in one launch (block-owned slots; heavy gltf / emissive scenes, elsewhere the automatic choice). hpt_set_schedule."""
         self._chk(self.L.hpt_set_schedule(self.h, schedule, refill_below, trace_blocks_per_cu, groups))
 
     def Image2D4fRegularizer(self, data, grad):
